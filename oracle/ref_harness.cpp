@@ -1,0 +1,317 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE.
+//
+// A thin C-ABI driver around the UNMODIFIED reference classes (compiled in place from
+// /root/reference by oracle/Makefile, target `ref`).  Nothing here re-implements reference
+// behaviour: every function builds the reference's own containers from flat arrays, calls the
+// reference's own entry point, and copies the result back out.  It is used to
+//   * pin our restatement (oracle/port_*.cpp) bit-for-bit,
+//   * generate the golden vectors under tests/golden/ (tests/golden/make_golden.py),
+//   * serve as bench.py's cpu_baseline of kind "reference".
+// The product never links this file.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <queue>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// The image-generation helpers of PCCEncoder are private members; the harness needs to call them
+// one by one (SURVEY.md §8c "library-level oracle").
+#define private public
+#define protected public
+#include "PCCCommon.h"
+#include "PCCPointSet.h"
+#include "PCCKdTree.h"
+#include "PCCPatch.h"
+#include "PCCNormalsGenerator.h"
+#include "PCCPatchSegmenter.h"
+#include "PCCEncoderParameters.h"
+#include "PCCEncoder.h"
+#include "PCCMetrics.h"
+#include "PCCMetricsParameters.h"
+#include "PCCContext.h"
+#include "PCCFrameContext.h"
+#include "PCCGroupOfFrames.h"
+#include "PCCImage.h"
+#include "PCCVideo.h"
+#undef private
+#undef protected
+
+#include "oracle.h"
+
+using namespace pcc;
+
+namespace {
+
+struct Quiet {  // the reference prints progress to std::cout; silence it while we drive it
+  std::streambuf* old;
+  std::ostringstream sink;
+  Quiet() : old( std::cout.rdbuf( sink.rdbuf() ) ) {}
+  ~Quiet() { std::cout.rdbuf( old ); }
+};
+
+void makeCloud( PCCPointSet3& pc, const int16_t* xyz, const uint8_t* rgb, size_t n ) {
+  pc.resize( n );
+  if ( rgb ) pc.addColors();
+  for ( size_t i = 0; i < n; ++i ) {
+    pc[i] = PCCPoint3D( xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] );
+    if ( rgb ) pc.setColor( i, PCCColor3B( rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] ) );
+  }
+}
+
+PCCNormalsGenerator3Parameters normalsParams( int k, int orientation ) {
+  // same aggregate as PCCPatchSegmenter3::compute builds (PCCPatchSegmenter.cpp:93-105)
+  const double mx = ( std::numeric_limits<double>::max )();
+  PCCNormalsGenerator3Parameters p = {PCCVector3D( 0.0 ), mx, mx, mx, mx, size_t( k ), size_t( k ), size_t( k ), 0,
+                                      static_cast<PCCNormalsGeneratorOrientation>( orientation ), false, false, false};
+  return p;
+}
+
+void toSegParams( const orc_seg_params& s, PCCPatchSegmenter3Parameters& p ) {
+  p.gridBasedSegmentation_               = false;
+  p.voxelDimensionGridBasedSegmentation_ = 2;
+  p.nnNormalEstimation_                  = s.nnNormalEstimation;
+  p.normalOrientation_                   = s.normalOrientation;
+  p.gridBasedRefineSegmentation_         = s.gridBasedRefineSegmentation != 0;
+  p.maxNNCountRefineSegmentation_        = s.maxNNCountRefineSegmentation;
+  p.iterationCountRefineSegmentation_    = s.iterationCountRefineSegmentation;
+  p.voxelDimensionRefineSegmentation_    = s.voxelDimensionRefineSegmentation;
+  p.searchRadiusRefineSegmentation_      = s.searchRadiusRefineSegmentation;
+  p.occupancyResolution_                 = s.occupancyResolution;
+  p.enablePatchSplitting_                = s.enablePatchSplitting != 0;
+  p.maxPatchSize_                        = s.maxPatchSize;
+  p.quantizerSizeX_                      = s.quantizerSizeX;
+  p.quantizerSizeY_                      = s.quantizerSizeY;
+  p.minPointCountPerCCPatchSegmentation_ = s.minPointCountPerCC;
+  p.maxNNCountPatchSegmentation_         = s.maxNNCountPatchSegmentation;
+  p.surfaceThickness_                    = s.surfaceThickness;
+  p.EOMFixBitCount_                      = 2;
+  p.EOMSingleLayerMode_                  = false;
+  p.mapCountMinus1_                      = s.mapCountMinus1;
+  p.minLevel_                            = s.minLevel;
+  p.maxAllowedDepth_                     = s.maxAllowedDepth;
+  p.maxAllowedDist2RawPointsDetection_   = s.maxAllowedDist2RawPointsDetection;
+  p.maxAllowedDist2RawPointsSelection_   = s.maxAllowedDist2RawPointsSelection;
+  p.lambdaRefineSegmentation_            = s.lambdaRefineSegmentation;
+  p.useEnhancedOccupancyMapCode_         = false;
+  p.absoluteD1_                          = true;
+  p.createSubPointCloud_                 = false;
+  p.surfaceSeparation_                   = false;
+  p.weightNormal_                        = PCCVector3D( s.weightNormal[0], s.weightNormal[1], s.weightNormal[2] );
+  p.additionalProjectionPlaneMode_       = 0;
+  p.partialAdditionalProjectionPlane_    = 0.0;
+  p.geometryBitDepth2D_                  = s.geometryBitDepth2D;
+  p.geometryBitDepth3D_                  = s.geometryBitDepth3D;
+  p.patchExpansion_                      = false;
+  p.highGradientSeparation_              = false;
+  p.minGradient_                         = 15.0;
+  p.minNumHighGradientPoints_            = 256;
+  p.enablePointCloudPartitioning_        = false;
+  p.numTilesHor_                         = 2;
+  p.tileHeightToWidthRatio_              = 1.0;
+  p.numCutsAlong1stLongestAxis_          = 1;
+  p.numCutsAlong2ndLongestAxis_          = 1;
+  p.numCutsAlong3rdLongestAxis_          = 1;
+}
+
+// last segmentation result (patch list) kept for the accessor calls
+std::vector<PCCPatch> g_patches;
+
+void fillPatch( const PCCPatch& p, orc_patch& o, int64_t depthOff, int64_t occOff ) {
+  o.index            = int32_t( p.getIndex() );
+  o.viewId           = int32_t( p.getViewId() );
+  o.normalAxis       = int32_t( p.getNormalAxis() );
+  o.tangentAxis      = int32_t( p.getTangentAxis() );
+  o.bitangentAxis    = int32_t( p.getBitangentAxis() );
+  o.projectionMode   = int32_t( p.getProjectionMode() );
+  o.u1               = int32_t( p.getU1() );
+  o.v1               = int32_t( p.getV1() );
+  o.d1               = int32_t( p.getD1() );
+  o.sizeU            = int32_t( p.getSizeU() );
+  o.sizeV            = int32_t( p.getSizeV() );
+  o.sizeD            = int32_t( p.getSizeD() );
+  o.sizeDPixel       = int32_t( p.getSizeDPixel() );
+  o.sizeU0           = int32_t( p.getSizeU0() );
+  o.sizeV0           = int32_t( p.getSizeV0() );
+  o.size2DXInPixel   = int32_t( p.getPatchSize2DXInPixel() );
+  o.size2DYInPixel   = int32_t( p.getPatchSize2DYInPixel() );
+  o.d0Count          = int32_t( p.getD0Count() );
+  o.eomAndD1Count    = int32_t( p.getEOMandD1Count() );
+  o.u0               = int32_t( p.getU0() );
+  o.v0               = int32_t( p.getV0() );
+  o.patchOrientation = int32_t( p.getPatchOrientation() );
+  o.depthOffset      = depthOff;
+  o.occOffset        = occOff;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_version() { return TMC2_VERSION_MAJOR; }
+
+// S1 + nanoflann kNN (PCCKdTree.cpp:56-66).  idx: nq*k u32, dist: nq*k f64 (may be NULL).
+int ref_knn( const int16_t* xyz, size_t n, const int16_t* q, size_t nq, int k, uint32_t* idx, double* dist ) {
+  PCCPointSet3 pc;
+  makeCloud( pc, xyz, nullptr, n );
+  PCCKdTree   tree( pc );
+  PCCNNResult res;
+  for ( size_t i = 0; i < nq; ++i ) {
+    tree.search( PCCPoint3D( q[3 * i], q[3 * i + 1], q[3 * i + 2] ), size_t( k ), res );
+    for ( int j = 0; j < k; ++j ) {
+      idx[i * k + j] = uint32_t( res.indices( j ) );
+      if ( dist ) dist[i * k + j] = res.dist( j );
+    }
+  }
+  return 0;
+}
+
+// canonical radius search (PCCKdTree.cpp:68-79): returns count per query, results capped at cap.
+int ref_radius( const int16_t* xyz, size_t n, const int16_t* q, size_t nq, double radius2, int cap, int32_t* count,
+                uint32_t* idx ) {
+  PCCPointSet3 pc;
+  makeCloud( pc, xyz, nullptr, n );
+  PCCKdTree tree( pc );
+  for ( size_t i = 0; i < nq; ++i ) {
+    PCCNNResult res;
+    tree.searchRadius( PCCPoint3D( q[3 * i], q[3 * i + 1], q[3 * i + 2] ), size_t( cap ), radius2, res );
+    count[i] = int32_t( res.count() );
+    for ( size_t j = 0; j < res.count(); ++j ) idx[i * cap + j] = uint32_t( res.indices( j ) );
+  }
+  return 0;
+}
+
+// S2 (+S3 when orientation==1): PCCNormalsGenerator3 (PCCNormalsGenerator.cpp:61-70).
+// stage 0 = computeNormals only (un-oriented), stage 1 = full compute().
+int ref_normals( const int16_t* xyz, size_t n, int k, int orientation, int stage, double* normals ) {
+  Quiet        quiet;
+  PCCPointSet3 pc;
+  makeCloud( pc, xyz, nullptr, n );
+  PCCKdTree                            tree( pc );
+  PCCNormalsGenerator3                 gen;
+  const PCCNormalsGenerator3Parameters p = normalsParams( k, orientation );
+  if ( stage == 0 ) {
+    gen.nbThread_ = 1;
+    gen.init( n, p );
+    gen.computeNormals( pc, tree, p );
+  } else {
+    gen.compute( pc, tree, p, 1 );
+  }
+  for ( size_t i = 0; i < n; ++i ) {
+    const auto nm      = gen.getNormal( i );
+    normals[3 * i]     = nm[0];
+    normals[3 * i + 1] = nm[1];
+    normals[3 * i + 2] = nm[2];
+  }
+  return 0;
+}
+
+// S0: PCCEncoder::calculateWeightNormal (PCCEncoder.cpp:3569-3626), enhancedPP=1.
+int ref_weight_normal( const int16_t* xyz, size_t n, int geometryBitDepth3D, double minWeightEPP, double* w ) {
+  Quiet        quiet;
+  PCCPointSet3 pc;
+  makeCloud( pc, xyz, nullptr, n );
+  PCCEncoder enc;
+  enc.params_.enhancedPP_   = true;
+  enc.params_.minWeightEPP_ = minWeightEPP;
+  PCCVector3D v             = enc.calculateWeightNormal( size_t( geometryBitDepth3D ), pc );
+  w[0]                      = v[0];
+  w[1]                      = v[1];
+  w[2]                      = v[2];
+  return 0;
+}
+
+// S4: initialSegmentation (PCCPatchSegmenter.cpp:226-265), 6 planes.
+int ref_initial_segmentation( const double* normals, size_t n, const double* weight, uint32_t* partition ) {
+  Quiet                quiet;
+  PCCPointSet3         pc;
+  pc.resize( n );
+  PCCNormalsGenerator3 gen;
+  gen.getNormals().resize( n );
+  for ( size_t i = 0; i < n; ++i )
+    gen.getNormals()[i] = PCCVector3D( normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] );
+  PCCPatchSegmenter3  seg;
+  std::vector<size_t> part;
+  seg.initialSegmentation( pc, gen, seg.orientations6, seg.orientationCount6, part,
+                           PCCVector3D( weight[0], weight[1], weight[2] ) );
+  for ( size_t i = 0; i < n; ++i ) partition[i] = uint32_t( part[i] );
+  return 0;
+}
+
+// S5: refineSegmentationGridBased (PCCPatchSegmenter.cpp:1386-1561), 6 planes, partition in/out.
+int ref_refine_grid( const int16_t* xyz, const double* normals, size_t n, uint32_t* partition, int maxNNCount,
+                     double lambda, int iterationCount, int voxDim, int searchRadius ) {
+  Quiet        quiet;
+  PCCPointSet3 pc;
+  makeCloud( pc, xyz, nullptr, n );
+  PCCNormalsGenerator3 gen;
+  gen.getNormals().resize( n );
+  for ( size_t i = 0; i < n; ++i )
+    gen.getNormals()[i] = PCCVector3D( normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] );
+  std::vector<size_t> part( n );
+  for ( size_t i = 0; i < n; ++i ) part[i] = partition[i];
+  PCCPatchSegmenter3 seg;
+  seg.refineSegmentationGridBased( pc, gen, seg.orientations6, seg.orientationCount6, size_t( maxNNCount ), lambda,
+                                   size_t( iterationCount ), size_t( voxDim ), size_t( searchRadius ), part );
+  for ( size_t i = 0; i < n; ++i ) partition[i] = uint32_t( part[i] );
+  return 0;
+}
+
+// S1-S9: the whole PCCPatchSegmenter3::compute (PCCPatchSegmenter.cpp:53-150).
+// Returns the number of patches; fetch them with ref_get_patches().
+int ref_segment( const int16_t* xyz, const uint8_t* rgb, size_t n, const orc_seg_params* sp ) {
+  Quiet        quiet;
+  PCCPointSet3 pc;
+  makeCloud( pc, xyz, rgb, n );
+  PCCPatchSegmenter3Parameters p;
+  toSegParams( *sp, p );
+  PCCPatchSegmenter3 seg;
+  seg.setNbThread( 1 );
+  g_patches.clear();
+  g_patches.reserve( 256 );
+  std::vector<PCCPointSet3> sub;
+  float                     dist = 0;
+  seg.compute( pc, 0, p, g_patches, sub, dist );
+  return int( g_patches.size() );
+}
+
+// sizes of the pools needed by ref_get_patches
+int ref_patch_pool_sizes( int64_t* depthCount, int64_t* occCount ) {
+  int64_t d = 0, o = 0;
+  for ( auto& p : g_patches ) {
+    d += int64_t( p.getSizeU() * p.getSizeV() );
+    o += int64_t( p.getSizeU0() * p.getSizeV0() );
+  }
+  *depthCount = d;
+  *occCount   = o;
+  return 0;
+}
+
+int ref_get_patches( orc_patch* out, int16_t* depth0, int16_t* depth1, uint8_t* occ ) {
+  int64_t d = 0, o = 0;
+  for ( size_t i = 0; i < g_patches.size(); ++i ) {
+    auto& p = g_patches[i];
+    fillPatch( p, out[i], d, o );
+    const size_t nd = p.getSizeU() * p.getSizeV();
+    for ( size_t j = 0; j < nd; ++j ) {
+      depth0[d + j] = p.getDepth( 0 )[j];
+      depth1[d + j] = p.getDepth( 1 ).size() == nd ? p.getDepth( 1 )[j] : p.getDepth( 0 )[j];
+    }
+    const size_t no = p.getSizeU0() * p.getSizeV0();
+    for ( size_t j = 0; j < no; ++j ) occ[o + j] = p.getOccupancy()[j] ? 1 : 0;
+    d += int64_t( nd );
+    o += int64_t( no );
+  }
+  return 0;
+}
+
+}  // extern "C"
