@@ -1,0 +1,150 @@
+/* tmc2hip.h -- C-ABI of the MI355X-native TMC2 patch-generation / image-generation hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI around this path: the
+ * seams are C++ member functions of PCCPatchSegmenter3 / PCCNormalsGenerator3 / PCCKdTree / PCCEncoder
+ * / PCCMetrics.  Each entry point below names the reference member it replaces (file:line relative
+ * to the reference tree); INTEGRATION.md shows the adaptor a maintainer adds at each call site.
+ *
+ * Conventions
+ *   - plain C, POD only; every function returns 0 on success or a negative TMC2_E_* code and never
+ *     throws or exits (the reference exit()s on fatal conditions, e.g. PCCPatch.cpp:242);
+ *     tmc2_last_error() returns a human-readable message for the calling thread's last failure.
+ *   - a tmc2_ctx is bound to ONE HIP device and owns one stream; it is not thread-safe, create one
+ *     per host thread (the reference calls the segmenter from a tbb::parallel_for over frames,
+ *     PCCEncoder.cpp:4729-4750 -- one ctx per in-flight frame).
+ *   - a tmc2_frame holds the device-resident state of one point-cloud frame; stage functions chain
+ *     on it without bouncing through the host.  Host arrays are AoS exactly like the reference
+ *     containers: xyz = int16[n][3] (PCCPoint3D, PCCMath.h:450), rgb = uint8[n][3] (PCCColor3B :453),
+ *     normals = double[n][3].
+ *   - there is NO CPU fallback: without a HIP device tmc2_ctx_create fails with TMC2_E_NO_DEVICE.
+ */
+#ifndef TMC2HIP_H
+#define TMC2HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMC2_OK 0
+#define TMC2_E_NO_DEVICE -1
+#define TMC2_E_HIP -2
+#define TMC2_E_INVALID -3
+#define TMC2_E_UNSUPPORTED -4
+#define TMC2_E_STATE -5
+
+typedef struct tmc2_ctx   tmc2_ctx;
+typedef struct tmc2_frame tmc2_frame;
+
+/* Flat mirror of the live fields of PCCPatchSegmenter3Parameters (PCCPatchSegmenter.h:48-100) as
+ * filled by PCCEncoder::generateSegments (PCCEncoder.cpp:4672-4723).  Options the CTC lossy
+ * conditions keep off are not representable; tmc2_segmenter_params_check() documents them.        */
+typedef struct tmc2_segmenter_params {
+  int32_t nnNormalEstimation;               /* 16  */
+  int32_t normalOrientation;                /* 1 = PCC_NORMALS_GENERATOR_ORIENTATION_SPANNING_TREE */
+  int32_t gridBasedRefineSegmentation;      /* 1   */
+  int32_t maxNNCountRefineSegmentation;     /* 1024 */
+  int32_t iterationCountRefineSegmentation; /* 10 / 50 longdress / 20 basketball */
+  int32_t voxelDimensionRefineSegmentation; /* 4   */
+  int32_t searchRadiusRefineSegmentation;   /* 192 */
+  int32_t occupancyResolution;              /* 16  */
+  int32_t enablePatchSplitting;             /* 1   */
+  int32_t maxPatchSize;                     /* 1024 */
+  int32_t quantizerSizeX;                   /* 1 << log2QuantizerSizeX = 16 */
+  int32_t quantizerSizeY;                   /* 16  */
+  int32_t minPointCountPerCCPatchSegmentation; /* 16 */
+  int32_t maxNNCountPatchSegmentation;      /* 16  */
+  int32_t surfaceThickness;                 /* 4   */
+  int32_t mapCountMinus1;                   /* 1   */
+  int32_t minLevel;                         /* 64  */
+  int32_t maxAllowedDepth;                  /* (1 << geometryNominal2dBitdepth) - 1 = 255 */
+  int32_t geometryBitDepth2D;               /* 8   */
+  int32_t geometryBitDepth3D;               /* geometry3dCoordinatesBitdepth + 1 = 11 / 12 */
+  double  maxAllowedDist2RawPointsDetection; /* 9 */
+  double  maxAllowedDist2RawPointsSelection; /* 1 */
+  double  lambdaRefineSegmentation;          /* 3 */
+  double  weightNormal[3];                   /* PCCEncoder::calculateWeightNormal, see tmc2_weight_normal */
+} tmc2_segmenter_params;
+
+/* One patch record = the PCCPatch fields the hot path produces (PCCPatch.h:352-409).
+ * depthOffset / occOffset index the frame's pools (see tmc2_frame_get_patches).                     */
+typedef struct tmc2_patch {
+  int32_t index, viewId;
+  int32_t normalAxis, tangentAxis, bitangentAxis, projectionMode;
+  int32_t u1, v1, d1;
+  int32_t sizeU, sizeV, sizeD, sizeDPixel;
+  int32_t sizeU0, sizeV0;
+  int32_t size2DXInPixel, size2DYInPixel;
+  int32_t d0Count, eomAndD1Count;
+  int32_t u0, v0, patchOrientation; /* set by packing */
+  int64_t depthOffset;
+  int64_t occOffset;
+} tmc2_patch;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int         tmc2_ctx_create( int device, tmc2_ctx** out );
+void        tmc2_ctx_destroy( tmc2_ctx* ctx );
+const char* tmc2_last_error( void );
+int         tmc2_ctx_synchronize( tmc2_ctx* ctx );
+/* per-stage GPU time of the last frame operation, milliseconds (hipEvent); name list via index */
+int         tmc2_ctx_stage_count( tmc2_ctx* ctx );
+const char* tmc2_ctx_stage_name( tmc2_ctx* ctx, int i );
+double      tmc2_ctx_stage_ms( tmc2_ctx* ctx, int i );
+void        tmc2_ctx_stage_reset( tmc2_ctx* ctx );
+
+/* ---- frame: upload + PCCKdTree ------------------------------------------------------------- */
+/* replaces: PCCKdTree::PCCKdTree(const PCCPointSet3&) / init  (PccLibCommon/source/PCCKdTree.cpp:44-59).
+ * Copies the points to HBM and builds the nanoflann-identical k-d tree (leaf size 10).              */
+int  tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, uint64_t n, tmc2_frame** out );
+void tmc2_frame_destroy( tmc2_frame* f );
+uint64_t tmc2_frame_point_count( const tmc2_frame* f );
+
+/* replaces: PCCKdTree::search (PCCKdTree.cpp:61-66) for a batch of queries against the frame's tree.
+ * idx = uint32[nq][k] in nanoflann result order; dist2 = uint32[nq][k] squared distances or NULL.   */
+int tmc2_kdtree_search( tmc2_frame* f, const int16_t* queries, uint64_t nq, int k, uint32_t* idx, uint32_t* dist2 );
+
+/* ---- PCCNormalsGenerator3 ------------------------------------------------------------------- */
+/* replaces: PCCNormalsGenerator3::computeNormals (PccLibEncoder/source/PCCNormalsGenerator.cpp:158-185)
+ * and, sharing its k-NN lists, PCCPatchSegmenter3::computeAdjacencyInfo (PCCPatchSegmenter.cpp:267-291). */
+int tmc2_normals_compute_normals( tmc2_frame* f, int k );
+/* replaces: PCCNormalsGenerator3::orientNormals, SPANNING_TREE branch (PCCNormalsGenerator.cpp:198-242).  */
+int tmc2_normals_orient( tmc2_frame* f );
+/* replaces: PCCNormalsGenerator3::compute (PCCNormalsGenerator.cpp:61-70) = both of the above.          */
+int tmc2_normals_compute( tmc2_frame* f, int k, int orientation );
+int tmc2_frame_get_normals( tmc2_frame* f, double* normals /* [n][3] */ );
+int tmc2_frame_set_normals( tmc2_frame* f, const double* normals );
+int tmc2_frame_get_adjacency( tmc2_frame* f, uint32_t* adj /* [n][k] */ );
+
+/* ---- PCCEncoder::calculateWeightNormal (PCCEncoder.cpp:3569-3626) ---------------------------- */
+int tmc2_weight_normal( tmc2_frame* f, int geometryBitDepth3D, double minWeightEPP, double weight[3] );
+
+/* ---- PCCPatchSegmenter3 stages --------------------------------------------------------------- */
+/* replaces: PCCPatchSegmenter3::initialSegmentation (PCCPatchSegmenter.cpp:226-265), 6 planes.        */
+int tmc2_segmenter_initial_segmentation( tmc2_frame* f, const double weight[3] );
+/* replaces: PCCPatchSegmenter3::refineSegmentationGridBased (PCCPatchSegmenter.cpp:1386-1561).       */
+int tmc2_segmenter_refine_grid_based( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount,
+                                      int voxDim, int searchRadius );
+int tmc2_frame_get_partition( tmc2_frame* f, uint32_t* partition /* [n] */ );
+int tmc2_frame_set_partition( tmc2_frame* f, const uint32_t* partition );
+/* replaces: PCCPatchSegmenter3::segmentPatches (PCCPatchSegmenter.cpp:542-1320).                      */
+int tmc2_segmenter_segment_patches( tmc2_frame* f, const tmc2_segmenter_params* p );
+/* replaces: PCCPatchSegmenter3::compute (PCCPatchSegmenter.cpp:53-150) = S1..S9 end to end.           */
+int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p );
+int tmc2_segmenter_params_check( const tmc2_segmenter_params* p );
+
+/* patch list of the frame (after segment_patches / compute) */
+int tmc2_frame_patch_count( tmc2_frame* f );
+int tmc2_frame_patch_pool_sizes( tmc2_frame* f, int64_t* depthCount, int64_t* occCount );
+int tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t* depth0, int16_t* depth1, uint8_t* occupancy );
+
+/* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
+/* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
+int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );
+/* the exact spanning-tree orientation behind tmc2_normals_orient (normals in/out, knn = [n][k]) */
+int tmc2_host_orient_normals( const int16_t* xyz, uint64_t n, const uint32_t* knn, int k, double* normals );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMC2HIP_H */

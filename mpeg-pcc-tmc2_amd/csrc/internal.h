@@ -1,0 +1,130 @@
+// internal.h -- shared internals of libtmc2hip.so (MI355X / gfx950 only; no CPU fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tmc2hip.h"
+
+namespace tmc2 {
+
+void setError( const char* fmt, ... );
+
+#define TMC2_HIP( expr )                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = ( expr );                                                                   \
+    if ( e_ != hipSuccess ) {                                                                   \
+      tmc2::setError( "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString( e_ ) ); \
+      return TMC2_E_HIP;                                                                        \
+    }                                                                                           \
+  } while ( 0 )
+
+#define TMC2_TRY( expr )          \
+  do {                            \
+    int r_ = ( expr );            \
+    if ( r_ != TMC2_OK ) return r_; \
+  } while ( 0 )
+
+// Owning device buffer (hipMalloc'd, freed on destruction / re-allocation).
+template <typename T>
+struct DevBuf {
+  T*     p = nullptr;
+  size_t count = 0;
+  DevBuf() = default;
+  DevBuf( const DevBuf& ) = delete;
+  DevBuf& operator=( const DevBuf& ) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if ( p ) (void)hipFree( p );
+    p     = nullptr;
+    count = 0;
+  }
+  int alloc( size_t n ) {
+    if ( n <= count && p ) return TMC2_OK;
+    release();
+    if ( n == 0 ) n = 1;
+    TMC2_HIP( hipMalloc( reinterpret_cast<void**>( &p ), n * sizeof( T ) ) );
+    count = n;
+    return TMC2_OK;
+  }
+  size_t bytes() const { return count * sizeof( T ); }
+};
+
+// ---- k-d tree, flattened for the device (one 16-byte record per node, pre-order: left child = id+1)
+struct alignas( 16 ) KdNode {
+  int32_t a;       // leaf: first point (tree order)   inner: left child id (== own id + 1)
+  int32_t b;       // leaf: one-past-last point        inner: right child id
+  int16_t divlow;  // inner: upper bound of the left child's box on dim
+  int16_t divhigh; // inner: lower bound of the right child's box on dim
+  int32_t dim;     // -1 for a leaf
+};
+
+struct KdTreeHost {
+  std::vector<uint32_t> perm;   // tree order -> original index
+  std::vector<KdNode>   nodes;
+  int32_t               lo[3], hi[3];
+  int                   depth = 0;
+  void                  build( const int16_t* xyz, size_t n );
+};
+
+// AoS point with padding: one 8-byte load per point
+struct alignas( 8 ) Pt {
+  int16_t x, y, z, w;
+};
+
+struct StageTimer {
+  std::string name;
+  hipEvent_t  e0 = nullptr, e1 = nullptr;
+  double      ms = 0.0;
+  int         calls = 0;
+};
+
+}  // namespace tmc2
+
+struct tmc2_ctx {
+  int                           device = 0;
+  hipStream_t                   stream = nullptr;
+  std::vector<tmc2::StageTimer> stages;
+  int                           cuCount = 256;
+  int  stageBegin( const char* name );
+  void stageEnd( int id );
+  void stageAddHostMs( const char* name, double ms );
+};
+
+struct tmc2_frame {
+  tmc2_ctx* ctx = nullptr;
+  uint64_t  n   = 0;
+  int       k   = 0;  // k of the resident adjacency
+  // host side
+  std::vector<int16_t> h_xyz;
+  std::vector<uint8_t> h_rgb;
+  tmc2::KdTreeHost     tree;
+  // device side
+  tmc2::DevBuf<tmc2::Pt>     d_pts;       // original order
+  tmc2::DevBuf<tmc2::Pt>     d_ptsTree;   // tree order
+  tmc2::DevBuf<uint32_t>     d_perm;      // tree order -> original index
+  tmc2::DevBuf<tmc2::KdNode> d_nodes;
+  tmc2::DevBuf<uint8_t>      d_rgb;       // [n][4] (rgb + pad)
+  tmc2::DevBuf<uint32_t>     d_knn;       // [n][k]
+  tmc2::DevBuf<double>       d_normals;   // [n][3]
+  tmc2::DevBuf<uint8_t>      d_partition; // [n]
+  bool haveKnn = false, haveNormals = false, havePartition = false;
+  // patches (host mirror of the device result)
+  std::vector<tmc2_patch> patches;
+  std::vector<int16_t>    depth0, depth1;
+  std::vector<uint8_t>    occupancy;
+};
+
+namespace tmc2 {
+// kernels / stage launchers (each returns TMC2_OK or an error code; all work is queued on ctx->stream)
+int launchKnnSelf( tmc2_frame* f, int k );
+int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist );
+int launchNormals( tmc2_frame* f );
+int orientNormalsHost( tmc2_frame* f );
+int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
+int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
+}  // namespace tmc2

@@ -1,0 +1,12 @@
+"""tmc2_amd -- Python (ctypes) host-side mirror of the MI355X-native TMC2 hot path.
+
+The product is the C-ABI library `libtmc2hip.so` (include/tmc2hip.h).  This package only binds it for
+tests, bench.py and __graft_entry__.py; it contains no algorithmic code and NO CPU fallback: every
+compute call goes to the HIP library, which fails with TMC2_E_NO_DEVICE when no GPU is visible.
+"""
+from .lib import (Tmc2Error, Context, Frame, SegmenterParams, Patch, load_library, library_path,
+                  host_kdtree_build, host_orient_normals, ctc_params)
+from .synth import synth_cloud, synth_gof
+
+__all__ = ["Tmc2Error", "Context", "Frame", "SegmenterParams", "Patch", "load_library", "library_path",
+           "host_kdtree_build", "host_orient_normals", "ctc_params", "synth_cloud", "synth_gof"]

@@ -1,0 +1,247 @@
+"""ctypes binding of libtmc2hip.so (include/tmc2hip.h).  Class/method names mirror the reference's
+seams: Frame.normals_compute <-> PCCNormalsGenerator3::compute, Frame.segmenter_* <-> PCCPatchSegmenter3::*,
+Frame.kdtree_search <-> PCCKdTree::search."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def library_path():
+    return os.path.normpath(os.path.join(_HERE, "..", "libtmc2hip.so"))
+
+
+class Tmc2Error(RuntimeError):
+    pass
+
+
+class SegmenterParams(C.Structure):
+    """Mirror of tmc2_segmenter_params (PCCPatchSegmenter3Parameters, PCCPatchSegmenter.h:48-100)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "nnNormalEstimation", "normalOrientation", "gridBasedRefineSegmentation", "maxNNCountRefineSegmentation",
+        "iterationCountRefineSegmentation", "voxelDimensionRefineSegmentation", "searchRadiusRefineSegmentation",
+        "occupancyResolution", "enablePatchSplitting", "maxPatchSize", "quantizerSizeX", "quantizerSizeY",
+        "minPointCountPerCCPatchSegmentation", "maxNNCountPatchSegmentation", "surfaceThickness", "mapCountMinus1",
+        "minLevel", "maxAllowedDepth", "geometryBitDepth2D", "geometryBitDepth3D")] + [
+        ("maxAllowedDist2RawPointsDetection", C.c_double), ("maxAllowedDist2RawPointsSelection", C.c_double),
+        ("lambdaRefineSegmentation", C.c_double), ("weightNormal", C.c_double * 3)]
+
+
+class Patch(C.Structure):
+    """Mirror of tmc2_patch (PCCPatch fields produced by the hot path)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "index", "viewId", "normalAxis", "tangentAxis", "bitangentAxis", "projectionMode", "u1", "v1", "d1", "sizeU",
+        "sizeV", "sizeD", "sizeDPixel", "sizeU0", "sizeV0", "size2DXInPixel", "size2DYInPixel", "d0Count",
+        "eomAndD1Count", "u0", "v0", "patchOrientation")] + [("depthOffset", C.c_int64), ("occOffset", C.c_int64)]
+
+
+PATCH_DTYPE = np.dtype([(n, t) for n, t in [(f[0], np.int32) for f in Patch._fields_[:22]] +
+                        [("depthOffset", np.int64), ("occOffset", np.int64)]])
+
+
+def ctc_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0)):
+    """CTC lossy settings (cfg/common/ctc-common.cfg + sequence cfg)."""
+    p = SegmenterParams()
+    p.nnNormalEstimation = 16
+    p.normalOrientation = 1
+    p.gridBasedRefineSegmentation = 1
+    p.maxNNCountRefineSegmentation = 1024
+    p.iterationCountRefineSegmentation = iterations
+    p.voxelDimensionRefineSegmentation = 4
+    p.searchRadiusRefineSegmentation = 192
+    p.occupancyResolution = 16
+    p.enablePatchSplitting = 1
+    p.maxPatchSize = 1024
+    p.quantizerSizeX = 16
+    p.quantizerSizeY = 16
+    p.minPointCountPerCCPatchSegmentation = 16
+    p.maxNNCountPatchSegmentation = 16
+    p.surfaceThickness = 4
+    p.mapCountMinus1 = 1
+    p.minLevel = 64
+    p.maxAllowedDepth = 255
+    p.geometryBitDepth2D = 8
+    p.geometryBitDepth3D = bits3d
+    p.maxAllowedDist2RawPointsDetection = 9.0
+    p.maxAllowedDist2RawPointsSelection = 1.0
+    p.lambdaRefineSegmentation = 3.0
+    p.weightNormal[0], p.weightNormal[1], p.weightNormal[2] = weight
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_library():
+    """Load libtmc2hip.so; raises if it has not been built (no silent fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise Tmc2Error("libtmc2hip.so not built: run `python __graft_entry__.py build` (hipcc, gfx950)")
+    L = C.CDLL(path)
+    L.tmc2_last_error.restype = C.c_char_p
+    L.tmc2_ctx_stage_name.restype = C.c_char_p
+    L.tmc2_ctx_stage_ms.restype = C.c_double
+    L.tmc2_frame_point_count.restype = C.c_uint64
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise Tmc2Error("tmc2hip error %d: %s" % (rc, load_library().tmc2_last_error().decode()))
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _check(self.L.tmc2_ctx_create(int(device), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.tmc2_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self.L.tmc2_ctx_synchronize(self.h))
+
+    def stage_ms(self):
+        return {self.L.tmc2_ctx_stage_name(self.h, i).decode(): self.L.tmc2_ctx_stage_ms(self.h, i)
+                for i in range(self.L.tmc2_ctx_stage_count(self.h))}
+
+    def stage_reset(self):
+        self.L.tmc2_ctx_stage_reset(self.h)
+
+    def frame(self, xyz, rgb=None):
+        return Frame(self, xyz, rgb)
+
+
+class Frame:
+    """Device-resident state of one point-cloud frame (tmc2_frame)."""
+
+    def __init__(self, ctx, xyz, rgb=None):
+        self.ctx, self.L = ctx, ctx.L
+        xyz = np.ascontiguousarray(xyz, dtype=np.int16)
+        assert xyz.ndim == 2 and xyz.shape[1] == 3
+        self.n = len(xyz)
+        self._xyz = xyz
+        self._rgb = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+        self.h = C.c_void_p()
+        _check(self.L.tmc2_frame_create(ctx.h, _ptr(xyz), None if rgb is None else _ptr(self._rgb),
+                                        C.c_uint64(self.n), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.tmc2_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # PCCKdTree::search
+    def kdtree_search(self, queries, k, with_dist=False):
+        q = np.ascontiguousarray(queries, dtype=np.int16)
+        idx = np.empty((len(q), k), np.uint32)
+        d = np.empty((len(q), k), np.uint32) if with_dist else None
+        _check(self.L.tmc2_kdtree_search(self.h, _ptr(q), C.c_uint64(len(q)), int(k), _ptr(idx),
+                                         None if d is None else _ptr(d)))
+        return (idx, d) if with_dist else idx
+
+    # PCCNormalsGenerator3
+    def normals_compute_normals(self, k=16):
+        _check(self.L.tmc2_normals_compute_normals(self.h, int(k)))
+
+    def normals_orient(self):
+        _check(self.L.tmc2_normals_orient(self.h))
+
+    def normals_compute(self, k=16, orientation=1):
+        _check(self.L.tmc2_normals_compute(self.h, int(k), int(orientation)))
+
+    def get_normals(self):
+        out = np.empty((self.n, 3), np.float64)
+        _check(self.L.tmc2_frame_get_normals(self.h, _ptr(out)))
+        return out
+
+    def set_normals(self, normals):
+        a = np.ascontiguousarray(normals, dtype=np.float64)
+        _check(self.L.tmc2_frame_set_normals(self.h, _ptr(a)))
+
+    def get_adjacency(self, k=16):
+        out = np.empty((self.n, k), np.uint32)
+        _check(self.L.tmc2_frame_get_adjacency(self.h, _ptr(out)))
+        return out
+
+    # PCCEncoder::calculateWeightNormal
+    def weight_normal(self, bits3d=11, min_weight_epp=0.6):
+        w = (C.c_double * 3)()
+        _check(self.L.tmc2_weight_normal(self.h, int(bits3d), C.c_double(min_weight_epp), w))
+        return np.array([w[0], w[1], w[2]])
+
+    # PCCPatchSegmenter3
+    def segmenter_initial_segmentation(self, weight):
+        w = (C.c_double * 3)(*[float(x) for x in weight])
+        _check(self.L.tmc2_segmenter_initial_segmentation(self.h, w))
+
+    def segmenter_refine_grid_based(self, max_nn=1024, lam=3.0, iterations=10, vox_dim=4, radius=192):
+        _check(self.L.tmc2_segmenter_refine_grid_based(self.h, int(max_nn), C.c_double(lam), int(iterations),
+                                                       int(vox_dim), int(radius)))
+
+    def get_partition(self):
+        out = np.empty(self.n, np.uint32)
+        _check(self.L.tmc2_frame_get_partition(self.h, _ptr(out)))
+        return out
+
+    def set_partition(self, partition):
+        a = np.ascontiguousarray(partition, dtype=np.uint32)
+        _check(self.L.tmc2_frame_set_partition(self.h, _ptr(a)))
+
+    def segmenter_segment_patches(self, params):
+        _check(self.L.tmc2_segmenter_segment_patches(self.h, C.byref(params)))
+
+    def segmenter_compute(self, params):
+        _check(self.L.tmc2_segmenter_compute(self.h, C.byref(params)))
+
+    def get_patches(self):
+        cnt = self.L.tmc2_frame_patch_count(self.h)
+        dc, oc = C.c_int64(), C.c_int64()
+        _check(self.L.tmc2_frame_patch_pool_sizes(self.h, C.byref(dc), C.byref(oc)))
+        patches = np.zeros(cnt, PATCH_DTYPE)
+        d0 = np.zeros(dc.value, np.int16)
+        d1 = np.zeros(dc.value, np.int16)
+        occ = np.zeros(oc.value, np.uint8)
+        _check(self.L.tmc2_frame_get_patches(self.h, _ptr(patches), _ptr(d0), _ptr(d1), _ptr(occ)))
+        return patches, d0, d1, occ
+
+
+# ---- host-only pieces (no device needed) -----------------------------------------------------------
+def host_kdtree_build(xyz):
+    L = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.int16)
+    perm = np.empty(len(xyz), np.uint32)
+    nodes, depth = C.c_uint64(), C.c_int32()
+    _check(L.tmc2_host_kdtree_build(_ptr(xyz), C.c_uint64(len(xyz)), _ptr(perm), C.byref(nodes), C.byref(depth)))
+    return perm, nodes.value, depth.value
+
+
+def host_orient_normals(xyz, knn, normals):
+    L = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.int16)
+    knn = np.ascontiguousarray(knn, dtype=np.uint32)
+    out = np.array(normals, dtype=np.float64, order="C", copy=True)
+    _check(L.tmc2_host_orient_normals(_ptr(xyz), C.c_uint64(len(xyz)), _ptr(knn), int(knn.shape[1]), _ptr(out)))
+    return out

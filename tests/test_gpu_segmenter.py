@@ -1,0 +1,99 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI, against the oracle and the golden vectors."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import tmc2_amd as T
+from tmc2_amd.synth import synth_cloud
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def digest(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_gpu_matches_golden(gpu_ctx, name):
+    g = np.load(os.path.join(GOLD, "segmenter_%s.npz" % name))
+    xyz, rgb = synth_cloud(name)
+    fr = gpu_ctx.frame(xyz, rgb)
+
+    def check(key, value):
+        if key in g.files:
+            assert np.array_equal(g[key], value), key
+        else:
+            assert str(g[key + "_md5"]) == digest(value), key
+
+    fr.normals_compute_normals(16)
+    check("knn16", fr.get_adjacency(16))
+    check("normals_raw", fr.get_normals())
+    fr.normals_orient()
+    check("normals_oriented", fr.get_normals())
+    q = (xyz[::5] + np.array([3, -2, 5], np.int16)).astype(np.int16)
+    check("knn8_offcloud", fr.kdtree_search(q, 8))
+    check("knn1_offcloud", fr.kdtree_search(q, 1))
+    w = fr.weight_normal(11, 0.6)
+    assert np.array_equal(bits(w), bits(g["weight_normal"]))
+    fr.segmenter_initial_segmentation(w)
+    assert np.array_equal(fr.get_partition(), g["partition_initial"])
+
+
+@pytest.mark.parametrize("name,frame", [("small", 2), ("medium", 0)])
+def test_gpu_matches_oracle(gpu_ctx, oracle, name, frame):
+    xyz, rgb = synth_cloud(name, frame)
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.normals_compute(16, 1)
+    o_adj = oracle.knn_self(xyz, 16)
+    assert np.array_equal(fr.get_adjacency(16), o_adj)
+    o_n = oracle.orient_normals(xyz, o_adj, oracle.compute_normals(xyz, o_adj))
+    assert np.array_equal(bits(fr.get_normals()), bits(o_n))
+    w = fr.weight_normal(11, 0.6)
+    assert np.array_equal(bits(w), bits(oracle.weight_normal(xyz, 11, 0.6)))
+    fr.segmenter_initial_segmentation(w)
+    assert np.array_equal(fr.get_partition(), oracle.initial_segmentation(o_n, w))
+    # distances come back exact
+    idx, d = fr.kdtree_search(xyz[:1000], 16, with_dist=True)
+    oi, od = oracle.knn(xyz, xyz[:1000], 16, with_dist=True)
+    assert np.array_equal(idx, oi) and np.array_equal(d.astype(np.float64), od)
+
+
+def test_gpu_knn_edge_cases(gpu_ctx, oracle):
+    xyz, _ = synth_cloud("tiny")
+    small = xyz[:16].copy()                      # k == n, single-leaf..two-leaf tree
+    fr = gpu_ctx.frame(small)
+    assert np.array_equal(fr.kdtree_search(small, 16), oracle.knn(small, small, 16))
+    fr = gpu_ctx.frame(xyz)
+    far = np.array([[0, 0, 0], [1023, 1023, 1023], [500, -20, 2000]], np.int16)  # outside the root box
+    assert np.array_equal(fr.kdtree_search(far, 16), oracle.knn(xyz, far, 16))
+    with pytest.raises(T.Tmc2Error):
+        gpu_ctx.frame(xyz[:5]).kdtree_search(xyz[:5], 16)                         # k > n is an error, not UB
+
+
+def test_gpu_full_size_properties(gpu_ctx):
+    """BASELINE-size frame (~0.8 M points): size-independent properties instead of the (slow) oracle."""
+    xyz, rgb = synth_cloud("longdress_vox10")
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.normals_compute(16, 1)
+    adj = fr.get_adjacency(16)
+    n = len(xyz)
+    assert np.array_equal(adj[:, 0], np.arange(n, dtype=np.uint32))               # self first (distance 0, unique points)
+    p = xyz.astype(np.int64)
+    d = ((p[adj] - p[:, None, :]) ** 2).sum(-1)
+    assert np.all(np.diff(d, axis=1) >= 0)                                        # sorted by distance
+    assert np.all(np.sort(adj, 1)[:, 1:] != np.sort(adj, 1)[:, :-1])              # no duplicates
+    # exactness of the k-th distance: no point outside the list is strictly closer (checked on a sample)
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, n, 64):
+        di = ((p - p[i]) ** 2).sum(1)
+        assert np.sort(di)[15] == d[i, 15]
+    nrm = fr.get_normals()
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-9)
+    assert (np.einsum("ij,ij->i", nrm, -p.astype(np.float64)) < 0).sum() <= (n + 1) // 2  # majority rule of S3

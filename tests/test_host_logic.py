@@ -1,0 +1,72 @@
+"""CPU tier: the product's host-side logic (k-d tree builder, spanning-tree orientation) and the C-ABI
+surface.  No compute kernels run here -- there is no GPU in this tier."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tmc2_amd as T
+from tmc2_amd.synth import synth_cloud
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tmc2hip.h")).read()
+    names = sorted(set(re.findall(r"\b(tmc2_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 25
+    lib = T.load_library()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "declared in tmc2hip.h but not exported: %s" % missing
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(T.Tmc2Error, match="no HIP device"):
+        T.Context(0)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_host_kdtree_matches_oracle(oracle, name):
+    xyz, _ = synth_cloud(name)
+    perm, nodes, depth = T.host_kdtree_build(xyz)
+    operm, onodes = oracle.kdtree_perm(xyz)
+    assert np.array_equal(perm, operm) and nodes == onodes and 1 < depth <= 64
+
+
+def test_host_kdtree_degenerate_inputs(oracle):
+    rng = np.random.default_rng(5)
+    # coplanar, collinear, heavy ties on the cut plane, fewer points than one leaf
+    cases = [np.stack([rng.integers(0, 40, 500), np.full(500, 7), rng.integers(0, 40, 500)], 1),
+             np.stack([np.arange(300), np.zeros(300), np.zeros(300)], 1),
+             np.stack([rng.integers(0, 3, 800), rng.integers(0, 200, 800), rng.integers(0, 3, 800)], 1),
+             rng.integers(0, 1024, (7, 3))]
+    for c in cases:
+        c = np.unique(c.astype(np.int16), axis=0)
+        perm, nodes, _ = T.host_kdtree_build(c)
+        operm, onodes = oracle.kdtree_perm(c)
+        assert np.array_equal(perm, operm) and nodes == onodes
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_host_orientation_matches_oracle(oracle, name):
+    xyz, _ = synth_cloud(name)
+    knn = oracle.knn_self(xyz, 16)
+    raw = oracle.compute_normals(xyz, knn)
+    assert np.array_equal(bits(T.host_orient_normals(xyz, knn, raw)), bits(oracle.orient_normals(xyz, knn, raw)))
+
+
+def test_host_orientation_disconnected_components(oracle):
+    xyz, _ = synth_cloud("tiny")
+    two = np.concatenate([xyz, xyz + np.array([300, 0, 0], np.int16)])
+    knn = oracle.knn_self(two, 16)
+    raw = oracle.compute_normals(two, knn)
+    assert np.array_equal(bits(T.host_orient_normals(two, knn, raw)), bits(oracle.orient_normals(two, knn, raw)))
