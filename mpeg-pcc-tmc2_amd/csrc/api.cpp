@@ -1,4 +1,5 @@
 // api.cpp -- extern "C" surface of libtmc2hip.so (see include/tmc2hip.h for the reference seams).
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <memory>
@@ -147,6 +148,7 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
   f->ctx = ctx;
   f->n   = n;
   f->h_xyz.assign( xyz, xyz + 3 * n );
+  for ( uint64_t i = 0; i < 3 * n; ++i ) f->geoMax = std::max( f->geoMax, xyz[i] );
   if ( rgb ) f->h_rgb.assign( rgb, rgb + 3 * n );
   const auto t0 = std::chrono::steady_clock::now();
   f->tree.build( xyz, n );
@@ -276,6 +278,13 @@ int tmc2_segmenter_initial_segmentation( tmc2_frame* f, const double weight[3] )
   if ( !f || !weight ) return TMC2_E_INVALID;
   TMC2_HIP( hipSetDevice( f->ctx->device ) );
   return launchInitialSegmentation( f, weight );
+}
+
+int tmc2_segmenter_refine_grid_based( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim,
+                                      int searchRadius ) {
+  if ( !f ) return TMC2_E_INVALID;
+  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  return refineGridBased( f, maxNNCount, lambda, iterationCount, voxDim, searchRadius );
 }
 
 int tmc2_frame_get_partition( tmc2_frame* f, uint32_t* partition ) {

@@ -87,6 +87,8 @@ struct StageTimer {
 
 struct tmc2_ctx {
   int                           device = 0;
+  tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
+  tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
   hipStream_t                   stream = nullptr;
   std::vector<tmc2::StageTimer> stages;
   int                           cuCount = 256;
@@ -113,6 +115,7 @@ struct tmc2_frame {
   tmc2::DevBuf<double>       d_normals;   // [n][3]
   tmc2::DevBuf<uint8_t>      d_partition; // [n]
   bool haveKnn = false, haveNormals = false, havePartition = false;
+  int16_t geoMax = 0;  // largest coordinate (grid geometry of S5)
   // patches (host mirror of the device result)
   std::vector<tmc2_patch> patches;
   std::vector<int16_t>    depth0, depth1;
@@ -127,4 +130,7 @@ int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
+int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
+// exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
+int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );
 }  // namespace tmc2

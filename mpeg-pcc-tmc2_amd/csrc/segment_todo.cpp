@@ -2,10 +2,6 @@
 #include "internal.h"
 using namespace tmc2;
 extern "C" {
-int tmc2_segmenter_refine_grid_based( tmc2_frame*, int, double, int, int, int ) {
-  setError( "refineSegmentationGridBased: not implemented yet" );
-  return TMC2_E_UNSUPPORTED;
-}
 int tmc2_segmenter_segment_patches( tmc2_frame*, const tmc2_segmenter_params* ) {
   setError( "segmentPatches: not implemented yet" );
   return TMC2_E_UNSUPPORTED;

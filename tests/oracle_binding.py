@@ -97,6 +97,16 @@ class Oracle:
         return out
 
 
+    # S5
+    def refine_grid(self, xyz, normals, partition, max_nn=1024, lam=3.0, iterations=10, vox_dim=4, radius=192):
+        xyz = _i16(xyz)
+        nm = np.ascontiguousarray(normals, dtype=np.float64)
+        part = np.array(partition, dtype=np.uint32, order="C", copy=True)
+        self.L.orc_refine_grid(_p(xyz), _p(nm), C.c_size_t(len(xyz)), _p(part), int(max_nn), C.c_double(lam),
+                               int(iterations), int(vox_dim), int(radius))
+        return part
+
+
 class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
@@ -138,3 +148,11 @@ class Reference:
         out = np.empty(len(nm), np.uint32)
         self.L.ref_initial_segmentation(_p(nm), C.c_size_t(len(nm)), _p(w), _p(out))
         return out
+
+    def refine_grid(self, xyz, normals, partition, max_nn=1024, lam=3.0, iterations=10, vox_dim=4, radius=192):
+        xyz = _i16(xyz)
+        nm = np.ascontiguousarray(normals, dtype=np.float64)
+        part = np.array(partition, dtype=np.uint32, order="C", copy=True)
+        self.L.ref_refine_grid(_p(xyz), _p(nm), C.c_size_t(len(xyz)), _p(part), int(max_nn), C.c_double(lam),
+                               int(iterations), int(vox_dim), int(radius))
+        return part

@@ -97,3 +97,30 @@ def test_gpu_full_size_properties(gpu_ctx):
     nrm = fr.get_normals()
     assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-9)
     assert (np.einsum("ij,ij->i", nrm, -p.astype(np.float64)) < 0).sum() <= (n + 1) // 2  # majority rule of S3
+
+
+@pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 50), ("medium", 20)])
+def test_gpu_refine_matches_oracle(gpu_ctx, oracle, name, iters):
+    xyz, rgb = synth_cloud(name)
+    nrm = oracle.normals(xyz)
+    w = oracle.weight_normal(xyz)
+    p0 = oracle.initial_segmentation(nrm, w)
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, iters, 4, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=iters))
+
+
+def test_gpu_refine_key_aliasing(gpu_ctx, oracle):
+    """Coordinates at the top of the range make the reference's voxel key alias; identity is the key."""
+    xyz, _ = synth_cloud("small")
+    xyz = (xyz + (1023 - xyz.max(0))).astype(np.int16)
+    nrm = oracle.normals(xyz)
+    w = oracle.weight_normal(xyz)
+    p0 = oracle.initial_segmentation(nrm, w)
+    fr = gpu_ctx.frame(xyz)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, 10, 4, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10))
