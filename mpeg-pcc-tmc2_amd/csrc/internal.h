@@ -89,6 +89,7 @@ struct tmc2_ctx {
   int                           device = 0;
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
+  tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
   hipStream_t                   stream = nullptr;
   std::vector<tmc2::StageTimer> stages;
   int                           cuCount = 256;
@@ -116,10 +117,14 @@ struct tmc2_frame {
   tmc2::DevBuf<uint8_t>      d_partition; // [n]
   bool haveKnn = false, haveNormals = false, havePartition = false;
   int16_t geoMax = 0;  // largest coordinate (grid geometry of S5)
-  // patches (host mirror of the device result)
+  // patches: records on the host, depth / occupancy pools resident on the device
   std::vector<tmc2_patch> patches;
-  std::vector<int16_t>    depth0, depth1;
-  std::vector<uint8_t>    occupancy;
+  tmc2::DevBuf<int16_t>   d_depth0, d_depth1;  // patch-local depth maps, all patches back to back
+  tmc2::DevBuf<uint8_t>   d_occupancy;         // per-block occupancy, all patches back to back
+  int64_t                 depthCount = 0, occCount = 0;
+  int                     rounds     = 0;
+  bool                    havePatches = false;
+  int                     growPools();         // make the pools hold depthCount / occCount entries (keeps content)
 };
 
 namespace tmc2 {
@@ -130,6 +135,7 @@ int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
+int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );

@@ -1,0 +1,101 @@
+// segmenter_api.cpp -- PCCPatchSegmenter3::compute chain, parameter validation and patch accessors.
+#include <algorithm>
+
+#include "internal.h"
+using namespace tmc2;
+
+template <typename T>
+static int growKeep( DevBuf<T>& b, size_t need, hipStream_t s ) {
+  if ( need <= b.count && b.p ) return TMC2_OK;
+  size_t cap = std::max<size_t>( need + need / 2, 1 << 16 );
+  T*     np  = nullptr;
+  TMC2_HIP( hipMalloc( reinterpret_cast<void**>( &np ), cap * sizeof( T ) ) );
+  if ( b.p && b.count ) {
+    TMC2_HIP( hipMemcpyAsync( np, b.p, b.count * sizeof( T ), hipMemcpyDeviceToDevice, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    (void)hipFree( b.p );
+  }
+  b.p     = np;
+  b.count = cap;
+  return TMC2_OK;
+}
+
+int tmc2_frame::growPools() {
+  TMC2_TRY( growKeep( d_depth0, size_t( depthCount ), ctx->stream ) );
+  TMC2_TRY( growKeep( d_depth1, size_t( depthCount ), ctx->stream ) );
+  TMC2_TRY( growKeep( d_occupancy, size_t( occCount ), ctx->stream ) );
+  return TMC2_OK;
+}
+
+extern "C" {
+
+int tmc2_segmenter_params_check( const tmc2_segmenter_params* p ) {
+  if ( !p ) return TMC2_E_INVALID;
+  if ( p->nnNormalEstimation != 16 || p->maxNNCountPatchSegmentation != 16 ) {
+    setError( "params: nnNormalEstimation / maxNNCountPatchSegmentation must be 16 (one shared k-NN self-join)" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  if ( p->normalOrientation != 1 && p->normalOrientation != 0 ) {
+    setError( "params: normalOrientation %d unsupported (0 none, 1 spanning tree)", p->normalOrientation );
+    return TMC2_E_UNSUPPORTED;
+  }
+  if ( !p->gridBasedRefineSegmentation ) {
+    setError( "params: only gridBasedRefineSegmentation=1 is implemented" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  if ( p->occupancyResolution != 16 ) {
+    setError( "params: occupancyResolution must be 16" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  if ( p->mapCountMinus1 != 1 ) {
+    setError( "params: mapCountMinus1 must be 1 (two maps, absoluteD1)" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  return TMC2_OK;
+}
+
+int tmc2_segmenter_segment_patches( tmc2_frame* f, const tmc2_segmenter_params* p ) {
+  if ( !f || !p ) return TMC2_E_INVALID;
+  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  TMC2_TRY( tmc2_segmenter_params_check( p ) );
+  return segmentPatches( f, p );
+}
+
+int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
+  if ( !f || !p ) return TMC2_E_INVALID;
+  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  TMC2_TRY( tmc2_segmenter_params_check( p ) );
+  TMC2_TRY( tmc2_normals_compute( f, p->nnNormalEstimation, p->normalOrientation ) );
+  TMC2_TRY( tmc2_segmenter_initial_segmentation( f, p->weightNormal ) );
+  TMC2_TRY( tmc2_segmenter_refine_grid_based( f, p->maxNNCountRefineSegmentation, p->lambdaRefineSegmentation,
+                                              p->iterationCountRefineSegmentation, p->voxelDimensionRefineSegmentation,
+                                              p->searchRadiusRefineSegmentation ) );
+  return segmentPatches( f, p );
+}
+
+int tmc2_frame_patch_count( tmc2_frame* f ) { return f ? int( f->patches.size() ) : 0; }
+
+int tmc2_frame_patch_pool_sizes( tmc2_frame* f, int64_t* d, int64_t* o ) {
+  if ( !f || !d || !o ) return TMC2_E_INVALID;
+  *d = f->depthCount;
+  *o = f->occCount;
+  return TMC2_OK;
+}
+
+int tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t* depth0, int16_t* depth1, uint8_t* occ ) {
+  if ( !f || !f->havePatches ) {
+    setError( "get_patches: no patches" );
+    return TMC2_E_STATE;
+  }
+  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  hipStream_t s = f->ctx->stream;
+  if ( patches && !f->patches.empty() ) memcpy( patches, f->patches.data(), f->patches.size() * sizeof( tmc2_patch ) );
+  if ( depth0 && f->depthCount )
+    TMC2_HIP( hipMemcpyAsync( depth0, f->d_depth0.p, size_t( f->depthCount ) * 2, hipMemcpyDeviceToHost, s ) );
+  if ( depth1 && f->depthCount )
+    TMC2_HIP( hipMemcpyAsync( depth1, f->d_depth1.p, size_t( f->depthCount ) * 2, hipMemcpyDeviceToHost, s ) );
+  if ( occ && f->occCount ) TMC2_HIP( hipMemcpyAsync( occ, f->d_occupancy.p, size_t( f->occCount ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  return TMC2_OK;
+}
+}

@@ -9,6 +9,32 @@ import subprocess
 
 import numpy as np
 
+
+class SegParams(C.Structure):
+    """orc_seg_params (oracle/oracle.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "nnNormalEstimation", "normalOrientation", "gridBasedRefineSegmentation", "maxNNCountRefineSegmentation",
+        "iterationCountRefineSegmentation", "voxelDimensionRefineSegmentation", "searchRadiusRefineSegmentation",
+        "occupancyResolution", "enablePatchSplitting", "maxPatchSize", "quantizerSizeX", "quantizerSizeY",
+        "minPointCountPerCC", "maxNNCountPatchSegmentation", "surfaceThickness", "mapCountMinus1", "minLevel",
+        "maxAllowedDepth", "geometryBitDepth2D", "geometryBitDepth3D")] + [
+        ("maxAllowedDist2RawPointsDetection", C.c_double), ("maxAllowedDist2RawPointsSelection", C.c_double),
+        ("lambdaRefineSegmentation", C.c_double), ("weightNormal", C.c_double * 3)]
+
+
+PATCH_DTYPE = np.dtype([(n, np.int32) for n in (
+    "index", "viewId", "normalAxis", "tangentAxis", "bitangentAxis", "projectionMode", "u1", "v1", "d1", "sizeU",
+    "sizeV", "sizeD", "sizeDPixel", "sizeU0", "sizeV0", "size2DXInPixel", "size2DYInPixel", "d0Count",
+    "eomAndD1Count", "u0", "v0", "patchOrientation")] + [("depthOffset", np.int64), ("occOffset", np.int64)])
+
+
+def seg_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0)):
+    p = SegParams(16, 1, 1, 1024, iterations, 4, 192, 16, 1, 1024, 16, 16, 16, 16, 4, 1, 64, 255, 8, bits3d, 9.0, 1.0,
+                  3.0)
+    p.weightNormal[0], p.weightNormal[1], p.weightNormal[2] = [float(x) for x in weight]
+    return p
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libtmc2ref.so")
@@ -107,9 +133,54 @@ class Oracle:
         return part
 
 
+    # S7-S9 and the whole segmenter
+    def _collect(self, r):
+        np_, dc, oc, rc, rounds = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        self.L.orc_seg_result_sizes(r, C.byref(np_), C.byref(dc), C.byref(oc), C.byref(rc), C.byref(rounds))
+        patches = np.zeros(np_.value, PATCH_DTYPE)
+        d0 = np.zeros(dc.value, np.int16)
+        d1 = np.zeros(dc.value, np.int16)
+        occ = np.zeros(oc.value, np.uint8)
+        res = np.zeros((rc.value, 3), np.int16)
+        rr = np.zeros(rounds.value, np.int32)
+        self.L.orc_seg_result_copy(r, _p(patches), _p(d0), _p(d1), _p(occ), _p(res), _p(rr))
+        self.L.orc_seg_result_free(r)
+        return dict(patches=patches, depth0=d0, depth1=d1, occupancy=occ, resampled=res, round_raw=rr)
+
+    def segment_patches(self, xyz, rgb, knn, partition, params):
+        xyz = _i16(xyz)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        knn = np.ascontiguousarray(knn, dtype=np.uint32)
+        part = np.ascontiguousarray(partition, dtype=np.uint32)
+        self.L.orc_segment_patches.restype = C.c_void_p
+        r = C.c_void_p(self.L.orc_segment_patches(_p(xyz), _p(rgb), C.c_size_t(len(xyz)), _p(knn), int(knn.shape[1]),
+                                                  _p(part), C.byref(params)))
+        return self._collect(r)
+
+    def segment(self, xyz, rgb, params):
+        xyz = _i16(xyz)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        self.L.orc_segment.restype = C.c_void_p
+        r = C.c_void_p(self.L.orc_segment(_p(xyz), _p(rgb), C.c_size_t(len(xyz)), C.byref(params)))
+        return self._collect(r)
+
+
 class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
+
+    def segment(self, xyz, rgb, params):
+        xyz = _i16(xyz)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        cnt = self.L.ref_segment(_p(xyz), _p(rgb), C.c_size_t(len(xyz)), C.byref(params))
+        dc, oc = C.c_int64(), C.c_int64()
+        self.L.ref_patch_pool_sizes(C.byref(dc), C.byref(oc))
+        patches = np.zeros(cnt, PATCH_DTYPE)
+        d0 = np.zeros(dc.value, np.int16)
+        d1 = np.zeros(dc.value, np.int16)
+        occ = np.zeros(oc.value, np.uint8)
+        self.L.ref_get_patches(_p(patches), _p(d0), _p(d1), _p(occ))
+        return dict(patches=patches, depth0=d0, depth1=d1, occupancy=occ)
 
     def knn(self, xyz, queries, k, with_dist=False):
         xyz, q = _i16(xyz), _i16(queries)

@@ -124,3 +124,71 @@ def test_gpu_refine_key_aliasing(gpu_ctx, oracle):
     fr.set_partition(p0)
     fr.segmenter_refine_grid_based(1024, 3.0, 10, 4, 192)
     assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10))
+
+
+def _to_oracle_params(p):
+    import oracle_binding as ob
+    return ob.seg_params(p.iterationCountRefineSegmentation, p.geometryBitDepth3D, list(p.weightNormal))
+
+
+def _assert_patches_equal(got, exp):
+    gp, g0, g1, go = got
+    assert len(gp) == len(exp["patches"])
+    for name in exp["patches"].dtype.names:
+        assert np.array_equal(gp[name], exp["patches"][name]), name
+    assert np.array_equal(g0, exp["depth0"]) and np.array_equal(g1, exp["depth1"])
+    assert np.array_equal(go, exp["occupancy"])
+
+
+@pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 10), ("medium", 20)])
+def test_gpu_segment_patches_matches_oracle(gpu_ctx, oracle, name, iters):
+    """S7-S9 alone: oracle-made adjacency / partition in, patch records + depth maps + occupancy out."""
+    xyz, rgb = synth_cloud(name)
+    knn = oracle.knn_self(xyz, 16)
+    nrm = oracle.orient_normals(xyz, knn, oracle.compute_normals(xyz, knn))
+    w = oracle.weight_normal(xyz)
+    part = oracle.refine_grid(xyz, nrm, oracle.initial_segmentation(nrm, w), iterations=iters)
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.normals_compute_normals(16)     # resident adjacency (checked elsewhere against the oracle)
+    fr.set_partition(part)
+    p = T.ctc_params(iters, 11, w)
+    fr.segmenter_segment_patches(p)
+    _assert_patches_equal(fr.get_patches(), oracle.segment_patches(xyz, rgb, knn, part, _to_oracle_params(p)))
+
+
+@pytest.mark.parametrize("name,frame,iters", [("small", 1, 50), ("medium", 2, 10)])
+def test_gpu_segmenter_compute_matches_oracle(gpu_ctx, oracle, name, frame, iters):
+    """PCCPatchSegmenter3::compute end to end (S1..S9) through the C-ABI."""
+    xyz, rgb = synth_cloud(name, frame)
+    fr = gpu_ctx.frame(xyz, rgb)
+    w = fr.weight_normal(11, 0.6)
+    p = T.ctc_params(iters, 11, w)
+    fr.segmenter_compute(p)
+    _assert_patches_equal(fr.get_patches(), oracle.segment(xyz, rgb, _to_oracle_params(p)))
+
+
+def test_gpu_segmenter_full_size_properties(gpu_ctx):
+    """longdress-size frame: structural invariants of the patch set (no oracle at this size)."""
+    xyz, rgb = synth_cloud("longdress_vox10")
+    fr = gpu_ctx.frame(xyz, rgb)
+    w = fr.weight_normal(11, 0.6)
+    p = T.ctc_params(50, 11, w)
+    fr.segmenter_compute(p)
+    patches, d0, d1, occ = fr.get_patches()
+    assert 20 < len(patches) < 2000
+    assert np.array_equal(patches["index"], np.arange(len(patches)))
+    total = 0
+    for q in patches:
+        a = d0[q["depthOffset"]:q["depthOffset"] + q["sizeU"] * q["sizeV"]].reshape(q["sizeV"], q["sizeU"])
+        b = d1[q["depthOffset"]:q["depthOffset"] + q["sizeU"] * q["sizeV"]].reshape(q["sizeV"], q["sizeU"])
+        valid = a < 32767
+        assert valid.sum() == q["d0Count"] and valid.any()
+        assert np.all((b[valid] - a[valid] >= 0) & (b[valid] - a[valid] <= 4))          # surfaceThickness
+        assert a[valid].min() >= 0 and b[valid].max() <= 255 and q["sizeD"] in (0, 63, 127, 191)
+        assert q["d1"] % 64 == 0 and q["sizeU0"] == (q["sizeU"] - 1) // 16 + 1
+        o = occ[q["occOffset"]:q["occOffset"] + q["sizeU0"] * q["sizeV0"]].reshape(q["sizeV0"], q["sizeU0"])
+        blk = np.add.reduceat(np.add.reduceat(valid.astype(np.int32), np.arange(0, q["sizeV"], 16), 0),
+                              np.arange(0, q["sizeU"], 16), 1) > 0
+        assert np.array_equal(o.astype(bool), blk)
+        total += int(valid.sum())
+    assert total > 0.6 * len(xyz)          # D0 pixels alone cover most of the cloud (the rest are D1 / in-between points)
