@@ -23,6 +23,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <unistd.h>
 
 // The image-generation helpers of PCCEncoder are private members; the harness needs to call them
 // one by one (SURVEY.md §8c "library-level oracle").
@@ -43,6 +44,7 @@
 #include "PCCGroupOfFrames.h"
 #include "PCCImage.h"
 #include "PCCVideo.h"
+#include "PCCBitstream.h"
 #undef private
 #undef protected
 
@@ -55,7 +57,9 @@ namespace {
 struct Quiet {  // the reference prints progress to std::cout; silence it while we drive it
   std::streambuf* old;
   std::ostringstream sink;
-  Quiet() : old( std::cout.rdbuf( sink.rdbuf() ) ) {}
+  Quiet() : old( std::cout.rdbuf() ) {
+    if ( !getenv( "TMC2_REF_VERBOSE" ) ) std::cout.rdbuf( sink.rdbuf() );
+  }
   ~Quiet() { std::cout.rdbuf( old ); }
 };
 
@@ -312,6 +316,231 @@ int ref_get_patches( orc_patch* out, int16_t* depth0, int16_t* depth1, uint8_t* 
     o += int64_t( no );
   }
   return 0;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// GOF-level driver: the image-generation half of PCCEncoder::encode (PCCEncoder.cpp:71-730) with the
+// video codec taken as the identity (compress() calls skipped: "decoded" video == generated video).
+// The call ORDER below is the reference's; every call is a reference member function.
+// ================================================================================================
+namespace {
+struct Gof {
+  PCCEncoderParameters params;
+  PCCEncoder           encoder;
+  PCCContext           context;
+  PCCGroupOfFrames     sources, reconstructs;
+  PCCLogger            logger;
+  std::vector<std::vector<uint32_t>> partitions;
+};
+std::unique_ptr<Gof> g_gof;
+
+void setCtcParams( PCCEncoderParameters& p, int iterations, int bits3dMinus1, int occPrecision, int minW, int minH ) {
+  // cfg/common/ctc-common.cfg
+  p.nnNormalEstimation_                     = 16;
+  p.maxNNCountRefineSegmentation_           = 1024;
+  p.iterationCountRefineSegmentation_       = iterations;  // sequence cfg overrides the common 10
+  p.voxelDimensionRefineSegmentation_       = 4;
+  p.searchRadiusRefineSegmentation_         = 192;
+  p.occupancyResolution_                    = 16;
+  p.minPointCountPerCCPatchSegmentation_    = 16;
+  p.maxNNCountPatchSegmentation_            = 16;
+  p.surfaceThickness_                       = 4;
+  p.maxAllowedDist2RawPointsDetection_      = 9;
+  p.maxAllowedDist2RawPointsSelection_      = 1;
+  p.lambdaRefineSegmentation_               = 3;
+  p.minimumImageWidth_                      = minW;
+  p.minimumImageHeight_                     = minH;
+  p.bestColorSearchRange_                   = 0;
+  p.numNeighborsColorTransferFwd_           = 8;
+  p.numNeighborsColorTransferBwd_           = 1;
+  p.useDistWeightedAverageFwd_              = true;
+  p.useDistWeightedAverageBwd_              = true;
+  p.skipAvgIfIdenticalSourcePointPresentFwd_ = true;
+  p.skipAvgIfIdenticalSourcePointPresentBwd_ = true;
+  p.distOffsetFwd_                          = 4;
+  p.distOffsetBwd_                          = 4;
+  p.maxGeometryDist2Fwd_                    = 1000;
+  p.maxGeometryDist2Bwd_                    = 1000;
+  p.maxColorDist2Fwd_                       = 1000;
+  p.maxColorDist2Bwd_                       = 1000;
+  p.maxCandidateCount_                      = 4;
+  p.flagGeometrySmoothing_                  = true;
+  p.gridSmoothing_                          = true;
+  p.gridSize_                               = 8;
+  p.thresholdSmoothing_                     = 64;
+  p.thresholdColorPreSmoothing_             = 10.0;
+  p.thresholdColorPreSmoothingLocalEntropy_ = 4.5;
+  p.radius2ColorPreSmoothing_               = 64;
+  p.neighborCountColorPreSmoothing_         = 64;
+  p.flagColorPreSmoothing_                  = true;
+  p.enablePointCloudPartitioning_           = false;
+  p.enhancedOccupancyMapCode_               = false;
+  p.profileReconstructionIdc_               = 1;
+  // cfg/condition/ctc-all-intra.cfg
+  p.constrainedPack_       = false;
+  p.globalPatchAllocation_ = 0;
+  // cfg/sequence/*.cfg
+  p.geometry3dCoordinatesBitdepth_    = bits3dMinus1;
+  p.geometryNominal2dBitdepth_        = 8;
+  p.minNormSumOfInvDist4MPSelection_  = 0.33;
+  p.partialAdditionalProjectionPlane_ = 0.17;
+  p.maxPatchSize_                     = 1024;
+  p.numTilesHor_                      = 2;
+  p.tileHeightToWidthRatio_           = 1;
+  // cfg/rate/ctc-rN.cfg
+  p.occupancyPrecision_ = occPrecision;
+  // what PccAppEncoder always supplies
+  p.compressedStreamPath_ = "/tmp/tmc2_ref_harness.bin";
+  p.uncompressedDataPath_ = "unused_%04d.ply";
+  p.nbThread_             = 1;
+  p.videoEncoderOccupancyCodecId_ = p.videoEncoderGeometryCodecId_ = p.videoEncoderAttributeCodecId_ = HMAPP;
+  p.videoEncoderOccupancyPath_ = p.videoEncoderGeometryPath_ = p.videoEncoderAttributePath_ = "/bin/true";
+  {
+    std::ostringstream  sink;
+    std::streambuf*     old = std::cerr.rdbuf();
+    if ( !getenv( "TMC2_REF_VERBOSE" ) ) std::cerr.rdbuf( sink.rdbuf() );
+    p.check();  // the reference's own parameter normalisation (forces absoluteD1/T1 for single-stream, ...)
+    std::cerr.rdbuf( old );
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int ref_gof_begin( int frameCount, int iterations, int bits3dMinus1, int occPrecision, int minW, int minH ) {
+  Quiet quiet;
+  g_gof.reset( new Gof() );
+  setCtcParams( g_gof->params, iterations, bits3dMinus1, occPrecision, minW, minH );
+  g_gof->sources.setFrameCount( size_t( frameCount ) );
+  return 0;
+}
+
+int ref_gof_set_frame( int i, const int16_t* xyz, const uint8_t* rgb, size_t n ) {
+  makeCloud( g_gof->sources[size_t( i )], xyz, rgb, n );
+  return 0;
+}
+
+// S0-S16 in the order of PCCEncoder::encode :85-172
+int ref_gof_phase_a() {
+  Quiet quiet;
+  Gof&  G = *g_gof;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );  // the reference also uses printf
+  PCCEncoder& E = G.encoder;
+  E.setLogger( G.logger );
+  E.setParameters( G.params );
+  PCCContext& context = G.context;
+  auto&       sources = G.sources;
+  // what PccAppEncoder::compressVideo does before encode() (PccAppEncoder.cpp:1042-1044)
+  static PCCBitstreamStat bitstreamStat;
+  context.setBitstreamStat( bitstreamStat );
+  context.addV3CParameterSet( 0 );
+  context.setActiveVpsId( 0 );
+  G.reconstructs.setFrameCount( sources.getFrameCount() );
+  context.resizeAtlas( 1 );
+  context.setAtlasIndex( 0 );
+  context.resize( sources.getFrameCount() );
+  auto& frames = context.getFrames();
+  for ( size_t i = 0; i < frames.size(); i++ ) {
+    auto& fc = frames[i].getTitleFrameContext();
+    fc.setFrameIndex( i );
+    fc.setRawPatchEnabledFlag( E.params_.rawPointsPatch_ || E.params_.lossyRawPointsPatch_ );
+    fc.setUseRawPointsSeparateVideo( E.params_.useRawPointsSeparateVideo_ );
+    fc.setGeometry3dCoordinatesBitdepth( E.params_.geometry3dCoordinatesBitdepth_ + 1 );
+    fc.setGeometry2dBitdepth( E.params_.geometryNominal2dBitdepth_ );
+    fc.setMaxDepth( ( 1 << E.params_.geometryNominal2dBitdepth_ ) - 1 );
+    fc.setLog2PatchQuantizerSizeX( E.params_.log2QuantizerSizeX_ );
+    fc.setLog2PatchQuantizerSizeY( E.params_.log2QuantizerSizeY_ );
+  }
+  E.generateSegments( sources, context );
+  E.params_.initializeContext( context );
+  E.placeSegments( sources, context );
+  size_t atlasIndex = context.getAtlasIndex();
+  auto&  sps        = context.getVps();
+  sps.setFrameWidth( atlasIndex, static_cast<uint16_t>( frames[0].getAtlasFrameWidth() ) );
+  sps.setFrameHeight( atlasIndex, static_cast<uint16_t>( frames[0].getAtlasFrameHeight() ) );
+  for ( auto& asps : context.getAtlasSequenceParameterSetList() ) {
+    asps.setFrameHeight( sps.getFrameHeight( atlasIndex ) );
+    asps.setFrameWidth( sps.getFrameWidth( atlasIndex ) );
+  }
+  E.generateOccupancyMap( context, true );
+  E.generateOccupancyMapVideo( sources, context );
+  // identity codec: videoOccupancyMap stays as generated
+  E.generateBlockToPatchFromOccupancyMapVideo( context, E.params_.occupancyResolution_, E.params_.occupancyPrecision_ );
+  E.generateGeometryVideo( sources, context );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
+}
+
+int ref_gof_frame_size( int* width, int* height ) {
+  auto& f = g_gof->context.getFrames()[0].getTitleFrameContext();
+  *width  = int( f.getWidth() );
+  *height = int( f.getHeight() );
+  return 0;
+}
+
+int ref_gof_patch_count( int frame ) {
+  return int( g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches().size() );
+}
+
+// patches of a frame in the (packing-sorted) list order, with u0/v0/orientation; pools optional
+int ref_gof_get_patches( int frame, orc_patch* out ) {
+  auto&   patches = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();
+  int64_t d = 0, o = 0;
+  for ( size_t i = 0; i < patches.size(); ++i ) {
+    fillPatch( patches[i], out[i], d, o );
+    d += int64_t( patches[i].getSizeU() * patches[i].getSizeV() );
+    o += int64_t( patches[i].getSizeU0() * patches[i].getSizeV0() );
+  }
+  return 0;
+}
+
+// occupancy map (u8 W*H), occupancy video luma (u8 (W/p)*(H/p)), blockToPatch (u32 (W/16)*(H/16)),
+// geometry D0 / D1 luma (u16 W*H each).  Any pointer may be NULL.
+int ref_gof_get_images( int frame, uint8_t* occupancy, uint8_t* occVideo, uint32_t* blockToPatch, uint16_t* geo0,
+                        uint16_t* geo1 ) {
+  Gof&  G  = *g_gof;
+  auto& fc = G.context.getFrames()[size_t( frame )].getTitleFrameContext();
+  if ( occupancy ) {
+    auto& om = fc.getOccupancyMap();
+    for ( size_t i = 0; i < om.size(); ++i ) occupancy[i] = uint8_t( om[i] );
+  }
+  if ( occVideo ) {
+    auto& img = G.context.getVideoOccupancyMap().getFrame( size_t( frame ) );
+    auto& ch  = img.getChannel( 0 );
+    for ( size_t i = 0; i < img.getWidth() * img.getHeight(); ++i ) occVideo[i] = ch[i];
+  }
+  if ( blockToPatch ) {
+    auto& b = fc.getBlockToPatch();
+    for ( size_t i = 0; i < b.size(); ++i ) blockToPatch[i] = uint32_t( b[i] );
+  }
+  auto& vg = G.context.getVideoGeometryMultiple()[0];
+  if ( geo0 ) {
+    auto& ch = vg.getFrame( 2 * size_t( frame ) ).getChannel( 0 );
+    std::copy( ch.begin(), ch.end(), geo0 );
+  }
+  if ( geo1 ) {
+    auto& ch = vg.getFrame( 2 * size_t( frame ) + 1 ).getChannel( 0 );
+    std::copy( ch.begin(), ch.end(), geo1 );
+  }
+  return 0;
+}
+
+// chroma planes of the geometry frames must stay zero (generateIntraImage :3932, dilate3DPadding on 3 channels)
+int ref_gof_geometry_chroma_nonzero( int frame ) {
+  auto&  vg = g_gof->context.getVideoGeometryMultiple()[0];
+  size_t nz = 0;
+  for ( size_t m = 0; m < 2; ++m )
+    for ( size_t c = 1; c < 3; ++c )
+      for ( auto v : vg.getFrame( 2 * size_t( frame ) + m ).getChannel( c ) ) nz += v != 0;
+  return int( nz );
 }
 
 }  // extern "C"

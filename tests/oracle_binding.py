@@ -165,9 +165,85 @@ class Oracle:
         return self._collect(r)
 
 
+    # S10-S16
+    def pack_flexible(self, patches, occupancy, preset_width=1280, occ_res=16, tiles_hor=2, ratio=1.0):
+        p = np.array(patches, dtype=PATCH_DTYPE, copy=True)
+        occ = np.ascontiguousarray(occupancy, dtype=np.uint8)
+        order = np.zeros(len(p), np.int32)
+        h = C.c_int32()
+        self.L.orc_pack_flexible(_p(p), len(p), _p(occ), int(preset_width), int(occ_res), int(tiles_hor),
+                                 C.c_double(ratio), _p(order), C.byref(h))
+        return p, order, h.value
+
+    def gof_canvas_size(self, heights, tile_width=1280, min_w=1280, min_h=1280):
+        hs = np.ascontiguousarray(heights, dtype=np.int32)
+        W, H = C.c_int32(), C.c_int32()
+        self.L.orc_gof_canvas_size(_p(hs), len(hs), int(tile_width), int(min_w), int(min_h), C.byref(W), C.byref(H))
+        return W.value, H.value
+
+    def geometry_images(self, patches, order, depth0, depth1, W, H, occ_res=16, occ_precision=4):
+        p = np.ascontiguousarray(patches, dtype=PATCH_DTYPE)
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        out = dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // occ_precision, W // occ_precision), np.uint8),
+                   block_to_patch=np.zeros((H // occ_res, W // occ_res), np.uint32),
+                   geo0=np.zeros((H, W), np.uint16), geo1=np.zeros((H, W), np.uint16))
+        rc = self.L.orc_generate_geometry_images(_p(p), _p(order), len(p), _p(np.ascontiguousarray(depth0, np.int16)),
+                                                 _p(np.ascontiguousarray(depth1, np.int16)), int(W), int(H), int(occ_res),
+                                                 int(occ_precision), _p(out["occupancy"]), _p(out["occ_video"]),
+                                                 _p(out["block_to_patch"]), _p(out["geo0"]), _p(out["geo1"]))
+        assert rc == 0
+        return out
+
+    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280):
+        """S0..S16 for a GOF given as [(xyz, rgb), ...]; mirrors Reference.phase_a."""
+        w = self.weight_normal(frames[0][0], bits3d, 0.6)
+        sp = seg_params(iterations, bits3d, w)
+        per = []
+        for xyz, rgb in frames:
+            seg = self.segment(xyz, rgb, sp)
+            placed, order, h = self.pack_flexible(seg["patches"], seg["occupancy"], min_w)
+            per.append((seg, placed, order, h))
+        W, H = self.gof_canvas_size([x[3] for x in per], min_w, min_w, min_h)
+        out = []
+        for seg, placed, order, h in per:
+            img = self.geometry_images(placed, order, seg["depth0"], seg["depth1"], W, H, 16, occ_precision)
+            img.update(patches=placed[order], width=W, height=H)
+            out.append(img)
+        return out
+
+
 class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
+
+    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280):
+        """S0..S16 through the reference's own PCCEncoder members (identity video codec)."""
+        L = self.L
+        L.ref_gof_begin(len(frames), int(iterations), int(bits3d - 1), int(occ_precision), int(min_w), int(min_h))
+        keep = []
+        for i, (xyz, rgb) in enumerate(frames):
+            xyz = _i16(xyz)
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            keep.append((xyz, rgb))
+            L.ref_gof_set_frame(i, _p(xyz), _p(rgb), C.c_size_t(len(xyz)))
+        L.ref_gof_phase_a()
+        w, h = C.c_int(), C.c_int()
+        L.ref_gof_frame_size(C.byref(w), C.byref(h))
+        W, H = w.value, h.value
+        out = []
+        for i in range(len(frames)):
+            n = L.ref_gof_patch_count(i)
+            pt = np.zeros(n, PATCH_DTYPE)
+            L.ref_gof_get_patches(i, _p(pt))
+            img = dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // occ_precision, W // occ_precision), np.uint8),
+                       block_to_patch=np.zeros((H // 16, W // 16), np.uint32), geo0=np.zeros((H, W), np.uint16),
+                       geo1=np.zeros((H, W), np.uint16))
+            L.ref_gof_get_images(i, _p(img["occupancy"]), _p(img["occ_video"]), _p(img["block_to_patch"]),
+                                 _p(img["geo0"]), _p(img["geo1"]))
+            assert L.ref_gof_geometry_chroma_nonzero(i) == 0
+            img.update(patches=pt, width=W, height=H)
+            out.append(img)
+        return out
 
     def segment(self, xyz, rgb, params):
         xyz = _i16(xyz)
