@@ -138,6 +138,27 @@ int tmc2_frame_patch_count( tmc2_frame* f );
 int tmc2_frame_patch_pool_sizes( tmc2_frame* f, int64_t* depthCount, int64_t* occCount );
 int tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t* depth0, int16_t* depth1, uint8_t* occupancy );
 
+/* ---- PCCEncoder image generation, phase A (all-intra packing) ---------------------------------- */
+/* replaces: PCCEncoder::packFlexible (PccLibEncoder/source/PCCEncoder.cpp:2306-2449) for one frame, as called by
+ * PCCEncoder::placeSegments (:4762-4835) with constrainedPack=0, packingStrategy=1, two orientations.
+ * Sorts the patch list (PCCPatch::gt), assigns u0/v0/patchOrientation, returns the frame's canvas height.  */
+int tmc2_encoder_pack_flexible( tmc2_frame* f, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
+                                int32_t* height );
+/* packing order of the frame: order[listPosition] = patch index (the reference reorders the list itself) */
+int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order );
+/* replaces: resizeTileGeometryVideo + resizeGeometryVideo (PCCEncoder.cpp:5593-5632, 5546-5591): common GOF canvas */
+int tmc2_encoder_canvas_size( const int32_t* frameHeights, int frames, int tileWidth, int minimumImageWidth,
+                              int minimumImageHeight, int32_t* width, int32_t* height );
+/* replaces, for one frame: generateOccupancyMap (:3767-3784), generateOccupancyMapVideo (:806-861),
+ * PCCCodec::generateBlockToPatchFromOccupancyMapVideo (PccLibCommon/source/PCCCodec.cpp:1736-1775),
+ * generateGeometryVideo -> generateIntraImage (:3929-3992) + dilate3DPadding (:5951-6130, geometryPadding=0)
+ * + dilateGroupGeometryVideo (:3717-3739).                                                              */
+int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height, int occupancyPrecision );
+/* canvases of the frame; any pointer may be NULL.  occupancy u8[W*H], occVideo u8[(W/p)*(H/p)],
+ * blockToPatch u32[(W/16)*(H/16)] (list position + 1), geometry D0 / D1 luma u16[W*H] (chroma planes are zero) */
+int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t* occVideo, uint32_t* blockToPatch,
+                                    uint16_t* geometryD0, uint16_t* geometryD1 );
+
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );

@@ -125,6 +125,15 @@ struct tmc2_frame {
   int                     rounds     = 0;
   bool                    havePatches = false;
   int                     growPools();         // make the pools hold depthCount / occCount entries (keeps content)
+  // packing + canvases (phase A images)
+  std::vector<int32_t>    packOrder;            // packing order: list position -> patch index
+  int                     packedHeight = 0;
+  bool                    havePacking = false, haveGeometryImages = false;
+  int                     canvasW = 0, canvasH = 0, occPrecision = 0;
+  tmc2::DevBuf<uint8_t>   d_occMap;             // W*H precise occupancy
+  tmc2::DevBuf<uint8_t>   d_occVideo;           // (W/p)*(H/p)
+  tmc2::DevBuf<uint32_t>  d_blockToPatch;       // (W/16)*(H/16), list position + 1
+  tmc2::DevBuf<uint16_t>  d_geo;                // 2 maps * W*H (D0 then D1), luma only (chroma planes are all-zero)
 };
 
 namespace tmc2 {
@@ -136,6 +145,8 @@ int orientNormalsHost( tmc2_frame* f );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
 int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp );
+int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHor, double tileHeightToWidthRatio );
+int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );

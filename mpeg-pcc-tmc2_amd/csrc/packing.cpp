@@ -1,0 +1,147 @@
+// packing.cpp -- patch placement on the block canvas (S10), host side.
+//
+// Replaces PCCEncoder::packFlexible (reference: source/lib/PccLibEncoder/source/PCCEncoder.cpp:2306-2449) as used
+// by placeSegments for the all-intra CTC condition (constrainedPack=0, packingStrategy=1, safeguard 0, two
+// orientations), PCCPatch::gt / checkFitPatchCanvas / patchBlock2CanvasBlock (PccLibCommon/source/PCCPatch.cpp:253-371)
+// and the canvas-size rule of resizeTileGeometryVideo / resizeGeometryVideo (PCCEncoder.cpp:5593-5632, 5546-5591).
+//
+// Inherently sequential first-fit over a few hundred patches on an 80-block-wide canvas -- microseconds of
+// work on a few KB of data -- so it runs on the host between the segmentation kernels and the raster kernels.
+// The reference copies the whole canvas by value for every probe (PCCPatch.h:219); here each canvas row is a
+// bit mask, and a candidate position is rejected with one AND per row of the patch's box.
+#include <algorithm>
+#include <cmath>
+
+#include "internal.h"
+
+namespace tmc2 {
+
+namespace {
+enum { ORIENT_DEFAULT = 0, ORIENT_SWAP = 1 };
+
+// canvas rows as arrays of 64-bit words; bit x of row y = block (x,y) occupied
+struct BlockCanvas {
+  size_t                width, height, words;
+  std::vector<uint64_t> rows;
+  BlockCanvas( size_t w, size_t h ) : width( w ), height( h ), words( ( w + 63 ) / 64 ), rows( words * h, 0 ) {}
+  void grow( size_t h ) {
+    rows.resize( words * h, 0 );
+    height = h;
+  }
+  bool boxFree( size_t x, size_t y, size_t w, size_t h ) const {
+    if ( x + w > width || y + h > height ) return false;
+    for ( size_t r = y; r < y + h; ++r ) {
+      const uint64_t* row = &rows[r * words];
+      for ( size_t c = x; c < x + w; ) {
+        const size_t   word = c >> 6, bit = c & 63;
+        const size_t   span = std::min<size_t>( 64 - bit, x + w - c );
+        const uint64_t mask = ( span == 64 ? ~0ull : ( ( 1ull << span ) - 1ull ) ) << bit;
+        if ( row[word] & mask ) return false;
+        c += span;
+      }
+    }
+    return true;
+  }
+  void set( size_t x, size_t y ) { rows[y * words + ( x >> 6 )] |= 1ull << ( x & 63 ); }
+};
+}  // namespace
+
+int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHor, double ratio ) {
+  if ( !f->havePatches ) {
+    setError( "packFlexible: no patches" );
+    return TMC2_E_STATE;
+  }
+  const int P = int( f->patches.size() );
+  f->packOrder.resize( P );
+  for ( int i = 0; i < P; ++i ) f->packOrder[i] = i;
+  f->packedHeight = 0;
+  f->havePacking  = true;
+  if ( P == 0 ) return TMC2_OK;
+  // per-block occupancy of the patches comes back from the device (a few KB)
+  std::vector<uint8_t> occ( size_t( f->occCount ) );
+  TMC2_HIP( hipMemcpyAsync( occ.data(), f->d_occupancy.p, occ.size(), hipMemcpyDeviceToHost, f->ctx->stream ) );
+  TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
+  auto& pt = f->patches;
+  // largest block dimension first, then the other dimension, then creation order (a total order)
+  std::sort( f->packOrder.begin(), f->packOrder.end(), [&]( int a, int b ) {
+    const int aMax = std::max( pt[a].sizeU0, pt[a].sizeV0 ), aMin = std::min( pt[a].sizeU0, pt[a].sizeV0 );
+    const int bMax = std::max( pt[b].sizeU0, pt[b].sizeV0 ), bMin = std::min( pt[b].sizeU0, pt[b].sizeV0 );
+    if ( aMax != bMax ) return aMax > bMax;
+    if ( aMin != bMin ) return aMin > bMin;
+    return pt[a].index < pt[b].index;
+  } );
+  size_t sizeU = size_t( presetWidth / occRes );
+  for ( auto& p : pt ) sizeU = std::max( sizeU, size_t( p.sizeU0 + 1 ) );
+  size_t    sizeV = size_t( std::max( pt[f->packOrder[0]].sizeU0, pt[f->packOrder[0]].sizeV0 ) );
+  const int tileH = int( ( int( sizeU ) / numTilesHor ) * ratio );
+  sizeV           = std::max( sizeV, size_t( std::max( tileH, 0 ) ) );
+  size_t      heightBlocks = sizeV;
+  BlockCanvas canvas( sizeU, sizeV );
+  for ( int k = 0; k < P; ++k ) {
+    tmc2_patch& p      = pt[f->packOrder[k]];
+    const bool  wide   = p.sizeU0 > p.sizeV0;
+    const int   first  = wide ? ORIENT_SWAP : ORIENT_DEFAULT;  // wide patches are tried upright first
+    const int   second = wide ? ORIENT_DEFAULT : ORIENT_SWAP;
+    bool        placed = false;
+    while ( !placed ) {
+      for ( size_t v = 0; v < canvas.height && !placed; ++v )
+        for ( size_t u = 0; u < canvas.width && !placed; ++u )
+          for ( int o = 0; o < 2 && !placed; ++o ) {
+            const int    orient = o == 0 ? first : second;
+            const size_t w = orient == ORIENT_DEFAULT ? p.sizeU0 : p.sizeV0, h = orient == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0;
+            if ( canvas.boxFree( u, v, w, h ) ) {
+              p.u0               = int32_t( u );
+              p.v0               = int32_t( v );
+              p.patchOrientation = orient;
+              placed             = true;
+            }
+          }
+      if ( !placed ) canvas.grow( canvas.height * 2 );
+    }
+    const uint8_t* o = occ.data() + p.occOffset;
+    for ( int vb = 0; vb < p.sizeV0; ++vb )
+      for ( int ub = 0; ub < p.sizeU0; ++ub )
+        if ( o[vb * p.sizeU0 + ub] ) {
+          if ( p.patchOrientation == ORIENT_DEFAULT )
+            canvas.set( size_t( p.u0 + ub ), size_t( p.v0 + vb ) );
+          else
+            canvas.set( size_t( p.u0 + vb ), size_t( p.v0 + ub ) );
+        }
+    heightBlocks = std::max( heightBlocks, size_t( p.v0 + ( p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0 ) ) );
+  }
+  f->packedHeight = int( heightBlocks ) * occRes;
+  return TMC2_OK;
+}
+
+}  // namespace tmc2
+
+extern "C" {
+
+int tmc2_encoder_pack_flexible( tmc2_frame* f, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
+                                int32_t* height ) {
+  if ( !f || presetWidth <= 0 || numTilesHor <= 0 ) return TMC2_E_INVALID;
+  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  TMC2_TRY( tmc2::packFlexibleHost( f, presetWidth, 16, numTilesHor, tileHeightToWidthRatio ) );
+  if ( height ) *height = f->packedHeight;
+  return TMC2_OK;
+}
+
+int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order ) {
+  if ( !f || !order || !f->havePacking ) {
+    tmc2::setError( "get_patch_order: frame not packed" );
+    return TMC2_E_STATE;
+  }
+  std::copy( f->packOrder.begin(), f->packOrder.end(), order );
+  return TMC2_OK;
+}
+
+int tmc2_encoder_canvas_size( const int32_t* frameHeights, int frames, int tileWidth, int minimumImageWidth,
+                              int minimumImageHeight, int32_t* width, int32_t* height ) {
+  if ( !frameHeights || frames <= 0 || !width || !height ) return TMC2_E_INVALID;
+  int w = std::max( tileWidth, minimumImageWidth ), h = minimumImageHeight;
+  for ( int i = 0; i < frames; ++i ) h = std::max( h, frameHeights[i] );
+  *width  = int32_t( std::ceil( double( w ) / 64.0 ) * 64 );
+  *height = int32_t( std::ceil( double( h ) / 64.0 ) * 64 );
+  return TMC2_OK;
+}
+}

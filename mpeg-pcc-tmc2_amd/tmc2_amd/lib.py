@@ -228,6 +228,40 @@ class Frame:
         return patches, d0, d1, occ
 
 
+    # PCCEncoder image generation, phase A
+    def encoder_pack_flexible(self, preset_width=1280, tiles_hor=2, ratio=1.0):
+        h = C.c_int32()
+        _check(self.L.tmc2_encoder_pack_flexible(self.h, int(preset_width), int(tiles_hor), C.c_double(ratio), C.byref(h)))
+        return h.value
+
+    def get_patch_order(self):
+        order = np.zeros(self.L.tmc2_frame_patch_count(self.h), np.int32)
+        _check(self.L.tmc2_frame_get_patch_order(self.h, _ptr(order)))
+        return order
+
+    def encoder_generate_geometry_images(self, width, height, occ_precision=4):
+        _check(self.L.tmc2_encoder_generate_geometry_images(self.h, int(width), int(height), int(occ_precision)))
+        self._canvas = (int(width), int(height), int(occ_precision))
+
+    def get_geometry_images(self):
+        W, H, p = self._canvas
+        out = dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // p, W // p), np.uint8),
+                   block_to_patch=np.zeros((H // 16, W // 16), np.uint32), geo0=np.zeros((H, W), np.uint16),
+                   geo1=np.zeros((H, W), np.uint16))
+        _check(self.L.tmc2_frame_get_geometry_images(self.h, _ptr(out["occupancy"]), _ptr(out["occ_video"]),
+                                                     _ptr(out["block_to_patch"]), _ptr(out["geo0"]), _ptr(out["geo1"])))
+        return out
+
+
+def encoder_canvas_size(heights, tile_width=1280, min_w=1280, min_h=1280):
+    """resizeTileGeometryVideo + resizeGeometryVideo: common canvas of a GOF."""
+    L = load_library()
+    hs = np.ascontiguousarray(heights, dtype=np.int32)
+    W, H = C.c_int32(), C.c_int32()
+    _check(L.tmc2_encoder_canvas_size(_ptr(hs), len(hs), int(tile_width), int(min_w), int(min_h), C.byref(W), C.byref(H)))
+    return W.value, H.value
+
+
 # ---- host-only pieces (no device needed) -----------------------------------------------------------
 def host_kdtree_build(xyz):
     L = load_library()
