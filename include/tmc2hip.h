@@ -91,14 +91,20 @@ int         tmc2_ctx_synchronize( tmc2_ctx* ctx );
 int         tmc2_ctx_stage_count( tmc2_ctx* ctx );
 const char* tmc2_ctx_stage_name( tmc2_ctx* ctx, int i );
 double      tmc2_ctx_stage_ms( tmc2_ctx* ctx, int i );
+long        tmc2_ctx_stage_calls( tmc2_ctx* ctx, int i );
 void        tmc2_ctx_stage_reset( tmc2_ctx* ctx );
+void        tmc2_ctx_set_timing( tmc2_ctx* ctx, int enabled ); /* hipEvent timing of stages on/off (default on) */
 
 /* ---- frame: upload + PCCKdTree ------------------------------------------------------------- */
 /* replaces: PCCKdTree::PCCKdTree(const PCCPointSet3&) / init  (PccLibCommon/source/PCCKdTree.cpp:44-59).
- * Copies the points to HBM and builds the nanoflann-identical k-d tree (leaf size 10).              */
+ * Copies the points to HBM; the nanoflann-identical k-d tree (leaf size 10) is built on first use.   */
 int  tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, uint64_t n, tmc2_frame** out );
 void tmc2_frame_destroy( tmc2_frame* f );
+/* the tree is built (host) and uploaded on first use; this forces it (PCCKdTree::init, PCCKdTree.cpp:56-59) */
+int  tmc2_kdtree_build( tmc2_frame* f );
 uint64_t tmc2_frame_point_count( const tmc2_frame* f );
+/* drop every derived result (tree, adjacency, normals, partition, patches, canvases); the points stay in HBM */
+int  tmc2_frame_reset( tmc2_frame* f );
 
 /* replaces: PCCKdTree::search (PCCKdTree.cpp:61-66) for a batch of queries against the frame's tree.
  * idx = uint32[nq][k] in nanoflann result order; dist2 = uint32[nq][k] squared distances or NULL.   */
@@ -158,6 +164,9 @@ int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height,
  * blockToPatch u32[(W/16)*(H/16)] (list position + 1), geometry D0 / D1 luma u16[W*H] (chroma planes are zero) */
 int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t* occVideo, uint32_t* blockToPatch,
                                     uint16_t* geometryD0, uint16_t* geometryD1 );
+/* device addresses of the frame's canvases (valid until the next generate call / frame destroy), for
+ * zero-copy hand-off to a collective (RCCL gather of finished frames) or to a device-side consumer       */
+int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry );
 
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */

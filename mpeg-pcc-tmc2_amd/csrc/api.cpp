@@ -19,6 +19,47 @@ void setError( const char* fmt, ... ) {
   g_lastError = buf;
 }
 
+static thread_local tmc2_ctx* g_tlsCtx = nullptr;
+DevicePool* currentPool() { return g_tlsCtx ? &g_tlsCtx->pool : nullptr; }
+ApiScope::ApiScope( tmc2_ctx* ctx ) : prev( g_tlsCtx ) {
+  g_tlsCtx = ctx;
+  if ( ctx ) (void)hipSetDevice( ctx->device );
+}
+ApiScope::~ApiScope() { g_tlsCtx = prev; }
+
+int DevicePool::acquire( size_t bytes, void** out, size_t* got ) {
+  const size_t cls = sizeClass( bytes );
+  {
+    std::lock_guard<std::mutex> g( lock );
+    auto                        it = freeBlocks.find( cls );
+    if ( it != freeBlocks.end() && !it->second.empty() ) {
+      *out = it->second.back();
+      it->second.pop_back();
+      *got = cls;
+      return TMC2_OK;
+    }
+  }
+  void* p = nullptr;
+  TMC2_HIP( hipMalloc( &p, cls ) );
+  {
+    std::lock_guard<std::mutex> g( lock );
+    bytesHeld += cls;
+  }
+  *out = p;
+  *got = cls;
+  return TMC2_OK;
+}
+void DevicePool::recycle( void* p, size_t cls ) {
+  std::lock_guard<std::mutex> g( lock );
+  freeBlocks[cls].push_back( p );
+}
+void DevicePool::drain() {
+  std::lock_guard<std::mutex> g( lock );
+  for ( auto& kv : freeBlocks )
+    for ( void* p : kv.second ) (void)hipFree( p );
+  freeBlocks.clear();
+}
+
 void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals );
 
 }  // namespace tmc2
@@ -32,39 +73,50 @@ int tmc2_ctx::stageBegin( const char* name ) {
   if ( id < 0 ) {
     StageTimer t;
     t.name = name;
-    (void)hipEventCreate( &t.e0 );
-    (void)hipEventCreate( &t.e1 );
     stages.push_back( t );
     id = int( stages.size() ) - 1;
-  } else if ( stages[id].calls > 0 && stages[id].e0 ) {
-    // fold the previous interval of this stage into the running total before reusing the events
-    float ms = 0.f;
-    if ( hipEventSynchronize( stages[id].e1 ) == hipSuccess &&
-         hipEventElapsedTime( &ms, stages[id].e0, stages[id].e1 ) == hipSuccess )
-      stages[id].ms += ms;
-    stages[id].calls = 0;
   }
-  if ( !stages[id].e0 ) {
-    (void)hipEventCreate( &stages[id].e0 );
-    (void)hipEventCreate( &stages[id].e1 );
+  stages[id].calls++;
+  if ( !timing ) return id;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if ( freeEvents.size() >= 2 ) {
+    e0 = freeEvents.back();
+    freeEvents.pop_back();
+    e1 = freeEvents.back();
+    freeEvents.pop_back();
+  } else {
+    (void)hipEventCreate( &e0 );
+    (void)hipEventCreate( &e1 );
   }
-  (void)hipEventRecord( stages[id].e0, stream );
+  (void)hipEventRecord( e0, stream );
+  stages[id].pending.emplace_back( e0, e1 );
   return id;
 }
 void tmc2_ctx::stageEnd( int id ) {
-  if ( id < 0 ) return;
-  (void)hipEventRecord( stages[id].e1, stream );
-  stages[id].calls = 1;
+  if ( id < 0 || !timing || stages[id].pending.empty() ) return;
+  (void)hipEventRecord( stages[id].pending.back().second, stream );
+}
+void tmc2_ctx::foldStage( StageTimer& t ) {
+  for ( auto& pr : t.pending ) {
+    float ms = 0.f;
+    if ( hipEventSynchronize( pr.second ) == hipSuccess && hipEventElapsedTime( &ms, pr.first, pr.second ) == hipSuccess )
+      t.ms += ms;
+    freeEvents.push_back( pr.first );
+    freeEvents.push_back( pr.second );
+  }
+  t.pending.clear();
 }
 void tmc2_ctx::stageAddHostMs( const char* name, double ms ) {
   for ( auto& s : stages )
     if ( s.name == name ) {
       s.ms += ms;
+      s.calls++;
       return;
     }
   StageTimer t;
-  t.name = name;
-  t.ms   = ms;
+  t.name  = name;
+  t.ms    = ms;
+  t.calls = 1;
   stages.push_back( t );
 }
 
@@ -101,10 +153,16 @@ int tmc2_ctx_create( int device, tmc2_ctx** out ) {
 void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   if ( !ctx ) return;
   (void)hipSetDevice( ctx->device );
-  for ( auto& s : ctx->stages ) {
-    if ( s.e0 ) (void)hipEventDestroy( s.e0 );
-    if ( s.e1 ) (void)hipEventDestroy( s.e1 );
+  for ( auto& s : ctx->stages ) ctx->foldStage( s );
+  for ( auto e : ctx->freeEvents ) (void)hipEventDestroy( e );
+  {
+    ApiScope scope( ctx );
+    ctx->gridTable.release();
+    ctx->scratchU32.release();
+    ctx->voxelBitmap.release();
   }
+  if ( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
+  ctx->pool.drain();
   if ( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
   delete ctx;
 }
@@ -122,19 +180,22 @@ const char* tmc2_ctx_stage_name( tmc2_ctx* ctx, int i ) {
 double tmc2_ctx_stage_ms( tmc2_ctx* ctx, int i ) {
   if ( !ctx || i < 0 || i >= int( ctx->stages.size() ) ) return 0.0;
   auto& s = ctx->stages[i];
-  if ( s.calls > 0 && s.e0 ) {
-    float ms = 0.f;
-    if ( hipEventSynchronize( s.e1 ) == hipSuccess && hipEventElapsedTime( &ms, s.e0, s.e1 ) == hipSuccess ) s.ms += ms;
-    s.calls = 0;
-  }
+  ctx->foldStage( s );
   return s.ms;
 }
 void tmc2_ctx_stage_reset( tmc2_ctx* ctx ) {
   if ( !ctx ) return;
   for ( auto& s : ctx->stages ) {
+    ctx->foldStage( s );
     s.ms    = 0.0;
     s.calls = 0;
   }
+}
+long tmc2_ctx_stage_calls( tmc2_ctx* ctx, int i ) {
+  return ( ctx && i >= 0 && i < int( ctx->stages.size() ) ) ? ctx->stages[i].calls : 0;
+}
+void tmc2_ctx_set_timing( tmc2_ctx* ctx, int enabled ) {
+  if ( ctx ) ctx->timing = enabled != 0;
 }
 
 int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, uint64_t n, tmc2_frame** out ) {
@@ -143,31 +204,20 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
     return TMC2_E_INVALID;
   }
   *out = nullptr;
-  TMC2_HIP( hipSetDevice( ctx->device ) );
+  ApiScope                    scope( ctx );
   std::unique_ptr<tmc2_frame> f( new tmc2_frame() );
   f->ctx = ctx;
   f->n   = n;
   f->h_xyz.assign( xyz, xyz + 3 * n );
   for ( uint64_t i = 0; i < 3 * n; ++i ) f->geoMax = std::max( f->geoMax, xyz[i] );
   if ( rgb ) f->h_rgb.assign( rgb, rgb + 3 * n );
-  const auto t0 = std::chrono::steady_clock::now();
-  f->tree.build( xyz, n );
-  const auto t1 = std::chrono::steady_clock::now();
-  ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
-  // stage AoS-with-padding copies of the points in original and in tree order
-  std::vector<Pt> pts( n ), ptsTree( n );
+  // original-order points (one 8-byte record per point) go to HBM now; the k-d tree is built on first use
+  std::vector<Pt> pts( n );
   for ( uint64_t i = 0; i < n; ++i ) pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
-  for ( uint64_t i = 0; i < n; ++i ) ptsTree[i] = pts[f->tree.perm[i]];
   TMC2_TRY( f->d_pts.alloc( n ) );
-  TMC2_TRY( f->d_ptsTree.alloc( n ) );
-  TMC2_TRY( f->d_perm.alloc( n ) );
-  TMC2_TRY( f->d_nodes.alloc( f->tree.nodes.size() ) );
   hipStream_t s = ctx->stream;
   TMC2_HIP( hipMemcpyAsync( f->d_pts.p, pts.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( f->d_ptsTree.p, ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( f->d_perm.p, f->tree.perm.data(), n * sizeof( uint32_t ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( f->d_nodes.p, f->tree.nodes.data(), f->tree.nodes.size() * sizeof( KdNode ),
-                            hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
   if ( rgb ) {
     std::vector<uint8_t> c4( n * 4 );
     for ( uint64_t i = 0; i < n; ++i ) {
@@ -185,20 +235,67 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
   return TMC2_OK;
 }
 
+}  // extern "C"
+
+int tmc2_frame::ensureTree() {
+  if ( haveTree ) return TMC2_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  tree.build( h_xyz.data(), n );
+  const auto t1 = std::chrono::steady_clock::now();
+  ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+  std::vector<Pt> ptsTree( n );
+  for ( uint64_t i = 0; i < n; ++i ) {
+    const uint32_t j = tree.perm[i];
+    ptsTree[i]       = Pt{h_xyz[3 * size_t( j )], h_xyz[3 * size_t( j ) + 1], h_xyz[3 * size_t( j ) + 2], 0};
+  }
+  TMC2_TRY( d_ptsTree.alloc( n ) );
+  TMC2_TRY( d_perm.alloc( n ) );
+  TMC2_TRY( d_nodes.alloc( tree.nodes.size() ) );
+  hipStream_t s = ctx->stream;
+  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_perm.p, tree.perm.data(), n * sizeof( uint32_t ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_nodes.p, tree.nodes.data(), tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  haveTree = true;
+  return TMC2_OK;
+}
+
+extern "C" {
+
+/* replaces PCCKdTree::init explicitly (otherwise built on first use) */
+int tmc2_kdtree_build( tmc2_frame* f ) {
+  if ( !f ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( f->ctx );
+  return f->ensureTree();
+}
+
 void tmc2_frame_destroy( tmc2_frame* f ) {
   if ( !f ) return;
-  (void)hipSetDevice( f->ctx->device );
+  ApiScope scope( f->ctx );
+  (void)hipStreamSynchronize( f->ctx->stream );
   delete f;
 }
 
 uint64_t tmc2_frame_point_count( const tmc2_frame* f ) { return f ? f->n : 0; }
+
+int tmc2_frame_reset( tmc2_frame* f ) {
+  if ( !f ) return TMC2_E_INVALID;
+  f->haveTree = f->haveKnn = f->haveNormals = f->havePartition = false;
+  f->havePatches = f->havePacking = f->haveGeometryImages = false;
+  f->patches.clear();
+  f->packOrder.clear();
+  f->depthCount = f->occCount = 0;
+  f->rounds = f->packedHeight = 0;
+  return TMC2_OK;
+}
 
 int tmc2_kdtree_search( tmc2_frame* f, const int16_t* queries, uint64_t nq, int k, uint32_t* idx, uint32_t* dist2 ) {
   if ( !f || !queries || !idx || nq == 0 ) {
     setError( "kdtree_search: invalid argument" );
     return TMC2_E_INVALID;
   }
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
+  TMC2_TRY( f->ensureTree() );
   std::vector<Pt> q( nq );
   for ( uint64_t i = 0; i < nq; ++i ) q[i] = Pt{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2], 0};
   DevBuf<Pt>       d_q;
@@ -217,14 +314,15 @@ int tmc2_kdtree_search( tmc2_frame* f, const int16_t* queries, uint64_t nq, int 
 
 int tmc2_normals_compute_normals( tmc2_frame* f, int k ) {
   if ( !f ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
+  TMC2_TRY( f->ensureTree() );
   if ( !f->haveKnn || f->k != k ) TMC2_TRY( launchKnnSelf( f, k ) );
   return launchNormals( f );
 }
 
 int tmc2_normals_orient( tmc2_frame* f ) {
   if ( !f ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   return orientNormalsHost( f );
 }
 
@@ -241,7 +339,7 @@ int tmc2_frame_get_normals( tmc2_frame* f, double* normals ) {
     setError( "get_normals: no normals" );
     return TMC2_E_STATE;
   }
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   TMC2_HIP( hipMemcpyAsync( normals, f->d_normals.p, f->n * 3 * sizeof( double ), hipMemcpyDeviceToHost, f->ctx->stream ) );
   TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
   return TMC2_OK;
@@ -249,7 +347,7 @@ int tmc2_frame_get_normals( tmc2_frame* f, double* normals ) {
 
 int tmc2_frame_set_normals( tmc2_frame* f, const double* normals ) {
   if ( !f || !normals ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( f->d_normals.alloc( f->n * 3 ) );
   TMC2_HIP( hipMemcpyAsync( f->d_normals.p, normals, f->n * 3 * sizeof( double ), hipMemcpyHostToDevice, f->ctx->stream ) );
   TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
@@ -262,7 +360,7 @@ int tmc2_frame_get_adjacency( tmc2_frame* f, uint32_t* adj ) {
     setError( "get_adjacency: no adjacency" );
     return TMC2_E_STATE;
   }
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   TMC2_HIP( hipMemcpyAsync( adj, f->d_knn.p, f->n * size_t( f->k ) * 4, hipMemcpyDeviceToHost, f->ctx->stream ) );
   TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
   return TMC2_OK;
@@ -270,20 +368,20 @@ int tmc2_frame_get_adjacency( tmc2_frame* f, uint32_t* adj ) {
 
 int tmc2_weight_normal( tmc2_frame* f, int geometryBitDepth3D, double minWeightEPP, double weight[3] ) {
   if ( !f || !weight ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   return weightNormal( f, geometryBitDepth3D, minWeightEPP, weight );
 }
 
 int tmc2_segmenter_initial_segmentation( tmc2_frame* f, const double weight[3] ) {
   if ( !f || !weight ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   return launchInitialSegmentation( f, weight );
 }
 
 int tmc2_segmenter_refine_grid_based( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim,
                                       int searchRadius ) {
   if ( !f ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   return refineGridBased( f, maxNNCount, lambda, iterationCount, voxDim, searchRadius );
 }
 
@@ -292,7 +390,7 @@ int tmc2_frame_get_partition( tmc2_frame* f, uint32_t* partition ) {
     setError( "get_partition: no partition" );
     return TMC2_E_STATE;
   }
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   std::vector<uint8_t> tmp( f->n );
   TMC2_HIP( hipMemcpyAsync( tmp.data(), f->d_partition.p, f->n, hipMemcpyDeviceToHost, f->ctx->stream ) );
   TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
@@ -302,7 +400,7 @@ int tmc2_frame_get_partition( tmc2_frame* f, uint32_t* partition ) {
 
 int tmc2_frame_set_partition( tmc2_frame* f, const uint32_t* partition ) {
   if ( !f || !partition ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   std::vector<uint8_t> tmp( f->n );
   for ( uint64_t i = 0; i < f->n; ++i ) tmp[i] = uint8_t( partition[i] );
   TMC2_TRY( f->d_partition.alloc( f->n ) );

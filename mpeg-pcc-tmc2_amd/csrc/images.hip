@@ -295,8 +295,20 @@ extern "C" {
 
 int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height, int occupancyPrecision ) {
   if ( !f ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   return tmc2::generateGeometryImages( f, width, height, 16, occupancyPrecision );
+}
+
+int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry ) {
+  if ( !f || !f->haveGeometryImages ) {
+    tmc2::setError( "device_images: not generated" );
+    return TMC2_E_STATE;
+  }
+  if ( occupancy ) *occupancy = f->d_occMap.p;
+  if ( occVideo ) *occVideo = f->d_occVideo.p;
+  if ( blockToPatch ) *blockToPatch = f->d_blockToPatch.p;
+  if ( geometry ) *geometry = f->d_geo.p;
+  return TMC2_OK;
 }
 
 int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t* occVideo, uint32_t* blockToPatch,
@@ -305,7 +317,7 @@ int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t* 
     tmc2::setError( "get_geometry_images: not generated" );
     return TMC2_E_STATE;
   }
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   hipStream_t  s    = f->ctx->stream;
   const size_t area = size_t( f->canvasW ) * f->canvasH;
   const size_t av   = area / ( size_t( f->occPrecision ) * f->occPrecision );

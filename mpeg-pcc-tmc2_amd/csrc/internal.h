@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,26 +31,63 @@ void setError( const char* fmt, ... );
     if ( r_ != TMC2_OK ) return r_; \
   } while ( 0 )
 
-// Owning device buffer (hipMalloc'd, freed on destruction / re-allocation).
+// Caching device allocator, one per context.  hipMalloc / hipFree are slow and hipFree synchronises the
+// whole device, which would serialise the per-frame host threads; blocks are therefore recycled by size
+// class (powers of two) and only returned to the driver when the context is destroyed.
+struct DevicePool {
+  std::mutex                                 lock;
+  std::map<size_t, std::vector<void*>>       freeBlocks;  // size class -> blocks
+  size_t                                     bytesHeld = 0;
+  static size_t sizeClass( size_t bytes ) {
+    size_t c = 256;
+    while ( c < bytes ) c <<= 1;
+    return c;
+  }
+  int  acquire( size_t bytes, void** out, size_t* got );
+  void recycle( void* p, size_t cls );
+  void drain();
+};
+DevicePool* currentPool();  // pool of the context the calling thread entered (see ApiScope), or nullptr
+
+// Owning device buffer; memory comes from the current context's pool.
 template <typename T>
 struct DevBuf {
-  T*     p = nullptr;
-  size_t count = 0;
+  T*          p = nullptr;
+  size_t      count = 0;
+  size_t      cls   = 0;
+  DevicePool* pool  = nullptr;
   DevBuf() = default;
   DevBuf( const DevBuf& ) = delete;
   DevBuf& operator=( const DevBuf& ) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if ( p ) (void)hipFree( p );
+    if ( p ) {
+      if ( pool )
+        pool->recycle( p, cls );
+      else
+        (void)hipFree( p );
+    }
     p     = nullptr;
     count = 0;
+    pool  = nullptr;
   }
   int alloc( size_t n ) {
     if ( n <= count && p ) return TMC2_OK;
     release();
     if ( n == 0 ) n = 1;
-    TMC2_HIP( hipMalloc( reinterpret_cast<void**>( &p ), n * sizeof( T ) ) );
-    count = n;
+    DevicePool* pl = currentPool();
+    if ( pl ) {
+      void*  q   = nullptr;
+      size_t got = 0;
+      TMC2_TRY( pl->acquire( n * sizeof( T ), &q, &got ) );
+      p     = reinterpret_cast<T*>( q );
+      cls   = got;
+      pool  = pl;
+      count = got / sizeof( T );
+    } else {
+      TMC2_HIP( hipMalloc( reinterpret_cast<void**>( &p ), n * sizeof( T ) ) );
+      count = n;
+    }
     return TMC2_OK;
   }
   size_t bytes() const { return count * sizeof( T ); }
@@ -76,23 +115,29 @@ struct alignas( 8 ) Pt {
   int16_t x, y, z, w;
 };
 
+// GPU time per named stage / kernel: hipEvent pairs recorded on the context's stream, folded lazily when the
+// totals are queried (never blocks the host while work is being queued).
 struct StageTimer {
-  std::string name;
-  hipEvent_t  e0 = nullptr, e1 = nullptr;
-  double      ms = 0.0;
-  int         calls = 0;
+  std::string                                    name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double                                         ms    = 0.0;  // folded GPU (or host) milliseconds
+  long                                           calls = 0;
 };
 
 }  // namespace tmc2
 
 struct tmc2_ctx {
   int                           device = 0;
+  tmc2::DevicePool              pool;
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
   hipStream_t                   stream = nullptr;
   std::vector<tmc2::StageTimer> stages;
+  std::vector<hipEvent_t>       freeEvents;
+  bool                          timing = true;
   int                           cuCount = 256;
+  void foldStage( tmc2::StageTimer& t );
   int  stageBegin( const char* name );
   void stageEnd( int id );
   void stageAddHostMs( const char* name, double ms );
@@ -106,6 +151,8 @@ struct tmc2_frame {
   std::vector<int16_t> h_xyz;
   std::vector<uint8_t> h_rgb;
   tmc2::KdTreeHost     tree;
+  bool                 haveTree = false;
+  int                  ensureTree();  // builds + uploads the k-d tree on first use (S1 belongs to the timed path)
   // device side
   tmc2::DevBuf<tmc2::Pt>     d_pts;       // original order
   tmc2::DevBuf<tmc2::Pt>     d_ptsTree;   // tree order
@@ -137,6 +184,12 @@ struct tmc2_frame {
 };
 
 namespace tmc2 {
+// RAII guard of every extern "C" entry: selects the device and makes the context's pool current
+struct ApiScope {
+  tmc2_ctx* prev;
+  explicit ApiScope( tmc2_ctx* ctx );
+  ~ApiScope();
+};
 // kernels / stage launchers (each returns TMC2_OK or an error code; all work is queued on ctx->stream)
 int launchKnnSelf( tmc2_frame* f, int k );
 int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist );

@@ -120,7 +120,7 @@ extern "C" {
 int tmc2_encoder_pack_flexible( tmc2_frame* f, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
                                 int32_t* height ) {
   if ( !f || presetWidth <= 0 || numTilesHor <= 0 ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( tmc2::packFlexibleHost( f, presetWidth, 16, numTilesHor, tileHeightToWidthRatio ) );
   if ( height ) *height = f->packedHeight;
   return TMC2_OK;

@@ -50,31 +50,60 @@ __global__ __launch_bounds__( 256 ) void ccInitKernel( const uint8_t* __restrict
   ccCount[i] = 0;
 }
 
+// One sweep = every labelled raw point (a) shortcuts its label through its seed's own label ("pointer
+// jumping": label[v] = s and label[s] = t < s mean t reaches s reaches v, all inside one plane of the raw
+// subgraph) and (b) pushes its label along its directed k-NN edges.  A workgroup repeats the sweep over its
+// own 256 points while anything inside it still changes (points are stored in a spatially coherent order, so
+// most edges stay inside a few neighbouring workgroups); labels are read with agent-scope atomics so that
+// values pushed by other workgroups through L2 are seen without relying on L1.
 template <int K>
 __global__ __launch_bounds__( 256 ) void ccPropagateKernel( const uint32_t* __restrict__ knn,
                                                              const uint8_t* __restrict__ partition,
                                                              const uint8_t* __restrict__ raw, uint32_t n,
                                                              uint32_t* __restrict__ label, uint32_t* __restrict__ changed ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u >= n || !raw[u] ) return;
-  const uint32_t lu = __hip_atomic_load( &label[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-  if ( lu == kNoLabel ) return;
-  const uint8_t  pu  = partition[u];
-  const uint4*   row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
-  bool           any = false;
+  __shared__ int blockChanged;
+  const uint32_t u      = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool     mine   = u < n && raw[u];
+  const uint8_t  pu     = mine ? partition[u] : 0;
+  uint32_t       nb[K];
+  uint32_t       okMask = 0;  // neighbours that are raw and on the same plane
+  if ( mine ) {
+    const uint4* row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
 #pragma unroll
-  for ( int j = 0; j < K / 4; ++j ) {
-    const uint4    r    = row[j];
-    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+    for ( int j = 0; j < K / 4; ++j ) {
+      const uint4 r = row[j];
+      nb[4 * j] = r.x, nb[4 * j + 1] = r.y, nb[4 * j + 2] = r.z, nb[4 * j + 3] = r.w;
+    }
 #pragma unroll
-    for ( int t = 0; t < 4; ++t ) {
-      if ( raw[v[t]] && partition[v[t]] == pu ) {
-        const uint32_t old = atomicMin( &label[v[t]], lu );
-        any |= old > lu;
+    for ( int j = 0; j < K; ++j )
+      if ( nb[j] != u && raw[nb[j]] && partition[nb[j]] == pu ) okMask |= 1u << j;
+  }
+  bool everChanged = false;
+  for ( int rep = 0; rep < 16; ++rep ) {
+    if ( threadIdx.x == 0 ) blockChanged = 0;
+    __syncthreads();
+    bool any = false;
+    if ( mine ) {
+      uint32_t lu = __hip_atomic_load( &label[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( lu != kNoLabel ) {
+        const uint32_t l2 = __hip_atomic_load( &label[lu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        if ( l2 < lu ) {
+          atomicMin( &label[u], l2 );
+          lu  = l2;
+          any = true;
+        }
+#pragma unroll
+        for ( int j = 0; j < K; ++j )
+          if ( okMask & ( 1u << j ) ) any |= atomicMin( &label[nb[j]], lu ) > lu;
       }
     }
+    if ( any ) blockChanged = 1;
+    everChanged |= any;
+    __syncthreads();
+    if ( !blockChanged ) break;
+    __syncthreads();
   }
-  if ( any ) *changed = 1;
+  if ( everChanged ) *changed = 1;
 }
 
 __global__ __launch_bounds__( 256 ) void ccCountKernel( const uint32_t* __restrict__ label, uint32_t n,
@@ -455,10 +484,12 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     for ( int guard = 0; guard < 1 << 20; ++guard ) {
       // a few sweeps per host round-trip; the flag is cleared before the LAST sweep of the batch only,
       // so "unchanged" means the final sweep of the batch changed nothing (= fixpoint)
-      for ( int b = 0; b < 8; ++b ) {
-        if ( b == 7 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
+      for ( int b = 0; b < 4; ++b ) {
+        if ( b == 3 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
+        const int kt = ctx->stageBegin( "k:ccPropagate" );
         hipLaunchKernelGGL( ccPropagateKernel<16>, grdN, blk, 0, s, f->d_knn.p, f->d_partition.p, d_raw.p, n, d_label.p,
                             d_small.p );
+        ctx->stageEnd( kt );
       }
       uint32_t changed = 0;
       TMC2_HIP( hipMemcpyAsync( &changed, d_small.p, 4, hipMemcpyDeviceToHost, s ) );

@@ -20,6 +20,7 @@
 //   * per-point re-scoring is one coalesced pass over the points (voxel id, 24 B normal, 1 B label).
 // Scores are fp64: (n . o_k) + w_v * S_k with the products/sums in the reference's order, no FMA.
 #include <algorithm>
+#include <cstdlib>
 
 #include "internal.h"
 
@@ -498,24 +499,66 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
 
   const int sidSweep = ctx->stageBegin( "refine_sweeps" );
   uint32_t* d_changed = d_small.p + 2;
-  for ( int iter = 0; iter < iterationCount; ++iter ) {
-    hipLaunchKernelGGL( smoothKernel, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                        d_rowLen.p, d_adj.p, V, d_S.p, d_arg );
-    for ( int guard = 0; guard < 1 << 20; ++guard ) {
-      TMC2_HIP( hipMemsetAsync( d_changed, 0, 4, s ) );
-      hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                          d_active, d_marked, d_changed );
-      uint32_t changed = 0;
-      TMC2_HIP( hipMemcpyAsync( &changed, d_changed, 4, hipMemcpyDeviceToHost, s ) );
-      TMC2_HIP( hipStreamSynchronize( s ) );
-      if ( !changed ) break;
+  // The INDIRECT-edge closure needs a fixpoint per sweep.  Asking the host after every closure step would cost
+  // ~100 stream round-trips per frame, so the sweeps are queued with a FIXED number of closure steps plus one
+  // more step that only records (sticky flag) whether it still changed anything.  The flag is read once, after
+  // the last sweep; in the rare case it is set, the sweeps are replayed from the saved partition with the
+  // exact host-checked loop.
+  DevBuf<uint8_t> d_partBackup;
+  TMC2_TRY( d_partBackup.alloc( n ) );
+  TMC2_HIP( hipMemcpyAsync( d_partBackup.p, f->d_partition.p, n, hipMemcpyDeviceToDevice, s ) );
+  auto runSweeps = [&]( int closureSteps ) -> int {  // closureSteps < 0: exact, host-checked
+    for ( int iter = 0; iter < iterationCount; ++iter ) {
+      int kt = ctx->stageBegin( "k:refineSmooth" );
+      hipLaunchKernelGGL( smoothKernel, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg );
+      ctx->stageEnd( kt );
+      if ( closureSteps < 0 ) {
+        for ( int guard = 0; guard < 1 << 20; ++guard ) {
+          TMC2_HIP( hipMemsetAsync( d_changed, 0, 4, s ) );
+          hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                              d_active, d_marked, d_changed );
+          uint32_t changed = 0;
+          TMC2_HIP( hipMemcpyAsync( &changed, d_changed, 4, hipMemcpyDeviceToHost, s ) );
+          TMC2_HIP( hipStreamSynchronize( s ) );
+          if ( !changed ) break;
+        }
+      } else {
+        for ( int c = 0; c < closureSteps; ++c )
+          hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                              d_active, d_marked, d_changed + 1 /* scratch word */ );
+        hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                            d_active, d_marked, d_changed /* sticky */ );
+      }
+      hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
+                          reinterpret_cast<uint4*>( d_hist.p ) );
+      kt = ctx->stageBegin( "k:refineRescorePoints" );
+      hipLaunchKernelGGL( rescorePointsKernel, grdN, blk, 0, s, d_vid.p, f->d_normals.p, d_proc, d_S.p, d_weight.p, n,
+                          f->d_partition.p, d_hist.p );
+      ctx->stageEnd( kt );
+      hipLaunchKernelGGL( updateVoxelKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_proc, V,
+                          d_edge, d_ppi, d_active, d_marked );
     }
-    hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
-                        reinterpret_cast<uint4*>( d_hist.p ) );
-    hipLaunchKernelGGL( rescorePointsKernel, grdN, blk, 0, s, d_vid.p, f->d_normals.p, d_proc, d_S.p, d_weight.p, n,
-                        f->d_partition.p, d_hist.p );
-    hipLaunchKernelGGL( updateVoxelKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_proc, V,
-                        d_edge, d_ppi, d_active, d_marked );
+    return TMC2_OK;
+  };
+  TMC2_HIP( hipMemsetAsync( d_changed, 0, 8, s ) );
+  int closureSteps = 3;
+  if ( const char* e = getenv( "TMC2_REFINE_CLOSURE_STEPS" ) ) closureSteps = std::max( 0, atoi( e ) );  // test hook
+  TMC2_TRY( runSweeps( closureSteps ) );
+  uint32_t unconverged = 0;
+  TMC2_HIP( hipMemcpyAsync( &unconverged, d_changed, 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  if ( unconverged ) {
+    // replay exactly: restore the partition and the voxel state derived from it
+    TMC2_HIP( hipMemcpyAsync( f->d_partition.p, d_partBackup.p, n, hipMemcpyDeviceToDevice, s ) );
+    TMC2_HIP( hipMemsetAsync( d_hist.p, 0, size_t( V ) * 16, s ) );
+    TMC2_HIP( hipMemsetAsync( d_state.p, 0, size_t( V ) * 6, s ) );
+    hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
+                        d_hist.p );
+    hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
+                        d_edge, d_ppi, d_active );
+    ctx->stageAddHostMs( "refine_closure_replays", 0.0 );
+    TMC2_TRY( runSweeps( -1 ) );
   }
   ctx->stageEnd( sidSweep );
   TMC2_HIP( hipGetLastError() );

@@ -56,14 +56,14 @@ int tmc2_segmenter_params_check( const tmc2_segmenter_params* p ) {
 
 int tmc2_segmenter_segment_patches( tmc2_frame* f, const tmc2_segmenter_params* p ) {
   if ( !f || !p ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( tmc2_segmenter_params_check( p ) );
   return segmentPatches( f, p );
 }
 
 int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
   if ( !f || !p ) return TMC2_E_INVALID;
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( tmc2_segmenter_params_check( p ) );
   TMC2_TRY( tmc2_normals_compute( f, p->nnNormalEstimation, p->normalOrientation ) );
   TMC2_TRY( tmc2_segmenter_initial_segmentation( f, p->weightNormal ) );
@@ -87,7 +87,7 @@ int tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t* depth0,
     setError( "get_patches: no patches" );
     return TMC2_E_STATE;
   }
-  TMC2_HIP( hipSetDevice( f->ctx->device ) );
+  tmc2::ApiScope scope( f->ctx );
   hipStream_t s = f->ctx->stream;
   if ( patches && !f->patches.empty() ) memcpy( patches, f->patches.data(), f->patches.size() * sizeof( tmc2_patch ) );
   if ( depth0 && f->depthCount )

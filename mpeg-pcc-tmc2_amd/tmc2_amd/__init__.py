@@ -7,6 +7,7 @@ compute call goes to the HIP library, which fails with TMC2_E_NO_DEVICE when no 
 from .lib import (Tmc2Error, Context, Frame, SegmenterParams, Patch, load_library, library_path,
                   host_kdtree_build, host_orient_normals, ctc_params, encoder_canvas_size)
 from .synth import synth_cloud, synth_gof
+from .gof import GofEncoder, Sharder
 
 __all__ = ["Tmc2Error", "Context", "Frame", "SegmenterParams", "Patch", "load_library", "library_path",
-           "host_kdtree_build", "host_orient_normals", "ctc_params", "encoder_canvas_size", "synth_cloud", "synth_gof"]
+           "host_kdtree_build", "host_orient_normals", "ctc_params", "encoder_canvas_size", "synth_cloud", "synth_gof", "GofEncoder", "Sharder"]

@@ -121,8 +121,16 @@ class Context:
         return {self.L.tmc2_ctx_stage_name(self.h, i).decode(): self.L.tmc2_ctx_stage_ms(self.h, i)
                 for i in range(self.L.tmc2_ctx_stage_count(self.h))}
 
+    def stage_calls(self):
+        self.L.tmc2_ctx_stage_calls.restype = C.c_long
+        return {self.L.tmc2_ctx_stage_name(self.h, i).decode(): self.L.tmc2_ctx_stage_calls(self.h, i)
+                for i in range(self.L.tmc2_ctx_stage_count(self.h))}
+
     def stage_reset(self):
         self.L.tmc2_ctx_stage_reset(self.h)
+
+    def set_timing(self, enabled):
+        self.L.tmc2_ctx_set_timing(self.h, 1 if enabled else 0)
 
     def frame(self, xyz, rgb=None):
         return Frame(self, xyz, rgb)
@@ -152,6 +160,20 @@ class Frame:
             self.close()
         except Exception:
             pass
+
+    def reset(self):
+        _check(self.L.tmc2_frame_reset(self.h))
+
+    def kdtree_build(self):
+        _check(self.L.tmc2_kdtree_build(self.h))
+
+    def device_images(self):
+        """Device addresses + shapes of the canvases (for RCCL hand-off): dict name -> (ptr, shape, typestr)."""
+        W, H, p = self._canvas
+        ptrs = [C.c_void_p() for _ in range(4)]
+        _check(self.L.tmc2_frame_device_images(self.h, *[C.byref(x) for x in ptrs]))
+        return dict(occupancy=(ptrs[0].value, (H, W), "|u1"), occ_video=(ptrs[1].value, (H // p, W // p), "|u1"),
+                    block_to_patch=(ptrs[2].value, (H // 16, W // 16), "<u4"), geometry=(ptrs[3].value, (2, H, W), "<u2"))
 
     # PCCKdTree::search
     def kdtree_search(self, queries, k, with_dist=False):

@@ -192,3 +192,19 @@ def test_gpu_segmenter_full_size_properties(gpu_ctx):
         assert np.array_equal(o.astype(bool), blk)
         total += int(valid.sum())
     assert total > 0.6 * len(xyz)          # D0 pixels alone cover most of the cloud (the rest are D1 / in-between points)
+
+
+def test_gpu_refine_closure_replay_path(gpu_ctx, oracle, monkeypatch):
+    """With zero queued closure steps the convergence check trips and the exact host-checked replay runs."""
+    monkeypatch.setenv("TMC2_REFINE_CLOSURE_STEPS", "0")
+    xyz, rgb = synth_cloud("small")
+    nrm = oracle.normals(xyz)
+    w = oracle.weight_normal(xyz)
+    p0 = oracle.initial_segmentation(nrm, w)
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    gpu_ctx.stage_reset()
+    fr.segmenter_refine_grid_based(1024, 3.0, 10, 4, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10))
+    assert gpu_ctx.stage_calls().get("refine_closure_replays", 0) >= 1
