@@ -47,6 +47,9 @@
 #include "PCCBitstream.h"
 #undef private
 #undef protected
+// The reference's PCCEncoder.cpp itself, compiled in this translation unit (see oracle/Makefile): gives the
+// harness the member templates dilateSmoothedPushPull<T> / pushPullMip<T> / pushPullFill<T> defined there.
+#include "PCCEncoder.cpp"
 
 #include "oracle.h"
 
@@ -529,6 +532,105 @@ int ref_gof_get_images( int frame, uint8_t* occupancy, uint8_t* occVideo, uint32
   if ( geo1 ) {
     auto& ch = vg.getFrame( 2 * size_t( frame ) + 1 ).getChannel( 0 );
     std::copy( ch.begin(), ch.end(), geo1 );
+  }
+  return 0;
+}
+
+// S17-S22 in the order of PCCEncoder::encode :313-424 (identity codec: the "decoded" geometry / occupancy videos
+// are the generated ones).  The per-frame padding dispatch and the attribute group dilation are INLINE code of
+// encode() (:342-424), not callable members; the two loops below transcribe that control flow and call the
+// reference members (dilateSmoothedPushPull) for the actual work.
+int ref_gof_phase_b() {
+  Quiet quiet;
+  Gof&  G = *g_gof;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );
+  PCCEncoder& E       = G.encoder;
+  PCCContext& context = G.context;
+  auto&       frames  = context.getFrames();
+  GeneratePointCloudParameters gpcParams;
+  E.setGeneratePointCloudParameters( gpcParams, context );
+  context.allocOneLayerData();
+  G.partitions.assign( context.size(), std::vector<uint32_t>() );
+  for ( size_t frameIdx = 0; frameIdx < context.size(); frameIdx++ ) {
+    auto& frame = context[frameIdx];
+    for ( size_t tileIdx = 0; tileIdx < frame.getNumTilesInAtlasFrame(); tileIdx++ ) {
+      PCCPointSet3 tileReconstrct;
+      E.generatePointCloud( tileReconstrct, context, frameIdx, tileIdx, gpcParams, G.partitions[frameIdx], false );
+      G.reconstructs[frameIdx].appendPointSet( tileReconstrct );
+    }
+  }
+  E.generateAttributeVideo( G.sources, G.reconstructs, context, E.params_ );
+  const size_t mapCount = E.params_.mapCountMinus1_ + 1;
+  for ( size_t f = 0; f < frames.size(); f++ ) {                       // encode() :349-423, attributeBGFill_ == 1
+    for ( size_t mapIdx = 0; mapIdx < mapCount; mapIdx++ ) {
+      auto& videoAttribute = context.getVideoAttributesMultiple()[0];
+      E.dilateSmoothedPushPull( frames[f].getTitleFrameContext(), videoAttribute.getFrame( f * mapCount + mapIdx ) );
+    }
+    if ( mapCount > 1 && E.params_.groupDilation_ ) {                  // encode() :380-402
+      auto& frame        = frames[f].getTitleFrameContext();
+      auto& occupancyMap = frame.getOccupancyMap();
+      auto& frame1       = context.getVideoAttributesMultiple()[0].getFrame( f * mapCount );
+      auto& frame2       = context.getVideoAttributesMultiple()[0].getFrame( f * mapCount + 1 );
+      for ( size_t y = 0; y < frame.getHeight(); y++ )
+        for ( size_t x = 0; x < frame.getWidth(); x++ )
+          if ( occupancyMap[y * frame.getWidth() + x] == 0 )
+            for ( size_t c = 0; c < 3; c++ ) {
+              uint8_t  d0  = frame1.getValue( c, x, y );
+              uint8_t  d1  = frame2.getValue( c, x, y );
+              uint32_t avg = ( static_cast<uint32_t>( d0 ) + static_cast<uint32_t>( d1 ) + 1 ) >> 1;
+              frame1.setValue( c, x, y, static_cast<uint8_t>( avg ) );
+              frame2.setValue( c, x, y, static_cast<uint8_t>( avg ) );
+            }
+    }
+  }
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
+}
+
+int64_t ref_gof_recon_count( int frame ) { return int64_t( g_gof->reconstructs[size_t( frame )].getPointCount() ); }
+
+// reconstructed cloud of a frame: xyz int16[M][3], rgb u8[M][3] (after colour transfer), pointToPixel u32[M][3]
+int ref_gof_get_recon( int frame, int16_t* xyz, uint8_t* rgb, uint32_t* pointToPixel ) {
+  auto& rec = g_gof->reconstructs[size_t( frame )];
+  auto& p2p = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPointToPixel();
+  for ( size_t i = 0; i < rec.getPointCount(); ++i ) {
+    if ( xyz ) {
+      xyz[3 * i]     = rec[i][0];
+      xyz[3 * i + 1] = rec[i][1];
+      xyz[3 * i + 2] = rec[i][2];
+    }
+    if ( rgb ) {
+      const auto c   = rec.getColor( i );
+      rgb[3 * i]     = c[0];
+      rgb[3 * i + 1] = c[1];
+      rgb[3 * i + 2] = c[2];
+    }
+    if ( pointToPixel ) {
+      pointToPixel[3 * i]     = uint32_t( p2p[i][0] );
+      pointToPixel[3 * i + 1] = uint32_t( p2p[i][1] );
+      pointToPixel[3 * i + 2] = uint32_t( p2p[i][2] );
+    }
+  }
+  return 0;
+}
+
+// attribute images of a frame: u8 [2 maps][3 channels][H][W] (values are <= 255 in the reference's uint16 planes)
+int ref_gof_get_attribute_images( int frame, uint8_t* out ) {
+  auto&  va = g_gof->context.getVideoAttributesMultiple()[0];
+  size_t o  = 0;
+  for ( size_t m = 0; m < 2; ++m ) {
+    auto& img = va.getFrame( 2 * size_t( frame ) + m );
+    for ( size_t c = 0; c < 3; ++c )
+      for ( auto v : img.getChannel( c ) ) {
+        if ( v > 255 ) return -1;
+        out[o++] = uint8_t( v );
+      }
   }
   return 0;
 }

@@ -212,9 +212,67 @@ class Oracle:
         return out
 
 
+    # S17-S22
+    def generate_point_cloud(self, img):
+        W, H = img["width"], img["height"]
+        p = np.ascontiguousarray(img["patches"], dtype=PATCH_DTYPE)   # already in packing order
+        order = np.arange(len(p), dtype=np.int32)
+        xyz = np.zeros((2 * W * H, 3), np.int16)
+        p2p = np.zeros((2 * W * H, 3), np.uint32)
+        prec = W // img["occ_video"].shape[1]
+        self.L.orc_generate_point_cloud.restype = C.c_int64
+        M = self.L.orc_generate_point_cloud(_p(p), _p(order), len(p), _p(img["occ_video"]), _p(img["block_to_patch"]),
+                                            _p(img["geo0"]), _p(img["geo1"]), int(W), int(H), 16, int(prec), _p(xyz), _p(p2p))
+        return xyz[:M].copy(), p2p[:M].copy()
+
+    def transfer_colors(self, src_xyz, src_rgb, tgt_xyz):
+        src_xyz, tgt_xyz = _i16(src_xyz), _i16(tgt_xyz)
+        src_rgb = np.ascontiguousarray(src_rgb, dtype=np.uint8)
+        out = np.zeros((len(tgt_xyz), 3), np.uint8)
+        rc = self.L.orc_transfer_colors(_p(src_xyz), _p(src_rgb), C.c_size_t(len(src_xyz)), _p(tgt_xyz),
+                                        C.c_size_t(len(tgt_xyz)), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def attribute_images(self, rgb, p2p, occ_video, W, H, occ_precision=4):
+        out = np.zeros((2, 3, H, W), np.uint8)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        p2p = np.ascontiguousarray(p2p, dtype=np.uint32)
+        self.L.orc_attribute_images(_p(rgb), _p(p2p), C.c_int64(len(rgb)), _p(np.ascontiguousarray(occ_video)), int(W),
+                                    int(H), int(occ_precision), _p(out))
+        return out
+
+    def phase_b(self, frames, phase_a_out, occ_precision=4):
+        """S17..S22 on top of phase_a() output (identity video codec)."""
+        out = []
+        for (xyz, rgb), img in zip(frames, phase_a_out):
+            rec, p2p = self.generate_point_cloud(img)
+            col = self.transfer_colors(xyz, rgb, rec)
+            att = self.attribute_images(col, p2p, img["occ_video"], img["width"], img["height"], occ_precision)
+            out.append(dict(recon_xyz=rec, recon_rgb=col, point_to_pixel=p2p, attribute=att))
+        return out
+
+
 class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
+
+    def phase_b(self, frames, phase_a_out, occ_precision=4):
+        """Must follow phase_a() on the same GOF (state lives in the harness)."""
+        L = self.L
+        L.ref_gof_phase_b()
+        L.ref_gof_recon_count.restype = C.c_int64
+        out = []
+        for i, img in enumerate(phase_a_out):
+            M = L.ref_gof_recon_count(i)
+            rec = np.zeros((M, 3), np.int16)
+            col = np.zeros((M, 3), np.uint8)
+            p2p = np.zeros((M, 3), np.uint32)
+            L.ref_gof_get_recon(i, _p(rec), _p(col), _p(p2p))
+            att = np.zeros((2, 3, img["height"], img["width"]), np.uint8)
+            assert L.ref_gof_get_attribute_images(i, _p(att)) == 0
+            out.append(dict(recon_xyz=rec, recon_rgb=col, point_to_pixel=p2p, attribute=att))
+        return out
 
     def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280):
         """S0..S16 through the reference's own PCCEncoder members (identity video codec)."""
