@@ -164,6 +164,22 @@ int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height,
  * blockToPatch u32[(W/16)*(H/16)] (list position + 1), geometry D0 / D1 luma u16[W*H] (chroma planes are zero) */
 int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t* occVideo, uint32_t* blockToPatch,
                                     uint16_t* geometryD0, uint16_t* geometryD1 );
+/* ---- PCCEncoder image generation, phase B (after the geometry video has been coded and decoded) -------- */
+/* replaces, for one frame: PCCCodec::generatePointCloud (PccLibCommon/source/PCCCodec.cpp:519-980, lossy CTC branch),
+ * PCCPointSet3::transferColors source -> reconstruction (PccLibCommon/source/PCCPointSet.cpp:807-1124, CTC settings),
+ * presmoothPointCloudColor (PCCEncoder.cpp:6593-6655, a no-op in the reference build), generateAttributeVideo
+ * (:6736-6794), dilateSmoothedPushPull (:6542-6591) and the attribute group dilation (encode() :380-402).
+ * Works on the frame's resident occupancy / geometry canvases (decoded == generated when the codec is lossless;
+ * upload decoded planes with tmc2_frame_set_decoded_geometry first when it is not).                         */
+int     tmc2_encoder_generate_attribute_images( tmc2_frame* f );
+int64_t tmc2_frame_recon_count( tmc2_frame* f );
+/* reconstruction: xyz int16[M][3], rgb uint8[M][3], pointToPixel uint32[M][3] = (x, y, layer); any may be NULL */
+int     tmc2_frame_get_reconstruction( tmc2_frame* f, int16_t* xyz, uint8_t* rgb, uint32_t* pointToPixel );
+/* attribute images: uint8[2 maps][3 channels][H][W] (the reference holds the same values in uint16 planes) */
+int     tmc2_frame_get_attribute_images( tmc2_frame* f, uint8_t* attribute );
+/* replace the resident occupancy video / geometry planes by decoded ones (uint8[(W/p)*(H/p)], uint16[2][H][W]) */
+int     tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo, const uint16_t* geometry );
+
 /* device addresses of the frame's canvases (valid until the next generate call / frame destroy), for
  * zero-copy hand-off to a collective (RCCL gather of finished frames) or to a device-side consumer       */
 int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry );

@@ -1,0 +1,538 @@
+// attributes.hip -- phase B on gfx950: point-cloud reconstruction (S17), colour transfer (S18), attribute scatter
+// (S20), push-pull background fill (S21) and attribute group dilation (S22).
+//
+// Replaces (reference: source/lib/...)
+//   PCCCodec::generatePointCloud, lossy CTC branch      PccLibCommon/source/PCCCodec.cpp:519-980 (+ generatePoints :329-517,
+//                                                       PCCPatch::generatePoint PccLibCommon/include/PCCPatch.h:177-207)
+//   PCCPointSet3::transferColors (CTC settings)         PccLibCommon/source/PCCPointSet.cpp:807-1124
+//   PCCEncoder::presmoothPointCloudColor                PccLibEncoder/source/PCCEncoder.cpp:6593-6655 -- a no-op in the reference
+//                                                       build (boundary type 2 is never produced), therefore skipped
+//   PCCEncoder::generateAttributeVideo (per tile)       PCCEncoder.cpp:6736-6794
+//   PCCEncoder::dilateSmoothedPushPull / pushPullMip / pushPullFill / mean4w   PCCEncoder.cpp:6357-6591
+//   attribute group dilation, inline in PCCEncoder::encode                      PCCEncoder.cpp:380-402
+//
+// S17 is a stream compaction whose ORDER is part of the contract (patch list order, block raster, pixel raster, D0
+// before D1): one workgroup per 16x16 patch block counts its points (ballot + popcount), a prefix sum over the tile
+// list gives each tile its output offset, and a second pass emits with an in-tile prefix (wave scan).
+// S18 reuses the exact nanoflann-order k-NN kernel: 8-NN of every reconstructed point in the SOURCE tree (the frame's
+// own tree) and 1-NN of every source point in a tree built over the reconstruction; the backward votes are bucketed
+// per target (count, scan, fill), ordered by (distance, source index) -- the order the reference's insertion sort
+// leaves for its <=16-element lists -- and reduced in fp64 in that order.
+// S21: every pyramid level is an image-parallel kernel over all six planes (2 maps x RGB) at once.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "internal.h"
+
+namespace tmc2 {
+namespace {
+
+__device__ __forceinline__ void toCanvasB( const PlaceDev& p, int u, int v, int& x, int& y ) {
+  if ( p.orient == 0 ) {
+    x = u + p.u0 * 16;
+    y = v + p.v0 * 16;
+  } else {
+    x = v + p.u0 * 16;
+    y = u + p.v0 * 16;
+  }
+}
+
+__device__ __forceinline__ int normalCoord( const PlaceDev& p, int depth ) {
+  return p.mode == 0 ? depth + p.d1 : max( 0, p.d1 - depth );
+}
+
+// EMIT = false: tileCount[tile] = number of points of the tile.  EMIT = true: write them at tileOffset[tile].
+template <bool EMIT>
+__global__ __launch_bounds__( 256 ) void reconTileKernel( const PlaceDev* __restrict__ place,
+                                                           const uint32_t* __restrict__ tilePatch,
+                                                           const uint8_t* __restrict__ occVideo,
+                                                           const uint32_t* __restrict__ blockToPatch,
+                                                           const uint16_t* __restrict__ geo, int W, int H, int prec,
+                                                           uint32_t* __restrict__ tileCount,
+                                                           const uint32_t* __restrict__ tileOffset, Pt* __restrict__ recon,
+                                                           uint32_t* __restrict__ pointToPixel ) {
+  __shared__ uint32_t waveTotal[4];
+  const uint32_t      tile  = blockIdx.x;
+  const uint32_t      k     = tilePatch[tile];
+  const PlaceDev      p     = place[k];
+  const int           local = int( tile ) - p.tileBase;
+  const int           ub = local % p.sizeU0, vb = local / p.sizeU0;
+  const int           bx = p.orient == 0 ? ub + p.u0 : vb + p.u0, by = p.orient == 0 ? vb + p.v0 : ub + p.v0;
+  const bool          owned = blockToPatch[size_t( by ) * ( W / 16 ) + bx] == k + 1;
+  const int           u = ub * 16 + int( threadIdx.x & 15 ), v = vb * 16 + int( threadIdx.x >> 4 );
+  int                 x, y;
+  toCanvasB( p, u, v, x, y );
+  uint32_t cnt = 0;
+  int      c0 = 0, c1 = 0;
+  if ( owned && x < W && y < H && occVideo[size_t( y / prec ) * ( W / prec ) + x / prec] ) {
+    c0  = normalCoord( p, geo[size_t( y ) * W + x] );
+    c1  = normalCoord( p, geo[size_t( W ) * H + size_t( y ) * W + x] );
+    cnt = c1 != c0 ? 2u : 1u;
+  }
+  // inclusive scan of cnt over the 256 lanes (pixel raster order == lane order)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t  inc  = cnt;
+#pragma unroll
+  for ( int off = 1; off < 64; off <<= 1 ) {
+    const uint32_t t = __shfl_up( inc, off, 64 );
+    if ( lane >= off ) inc += t;
+  }
+  if ( lane == 63 ) waveTotal[wave] = inc;
+  __syncthreads();
+  if ( !EMIT ) {
+    if ( threadIdx.x == 0 ) tileCount[tile] = waveTotal[0] + waveTotal[1] + waveTotal[2] + waveTotal[3];
+    return;
+  }
+  if ( cnt == 0 ) return;
+  uint32_t off = tileOffset[tile] + inc - cnt;
+  for ( int w = 0; w < wave; ++w ) off += waveTotal[w];
+  int c[3];
+  c[p.axT] = u + p.u1;
+  c[p.axB] = v + p.v1;
+  c[p.axN] = c0;
+  recon[off]        = Pt{int16_t( c[0] ), int16_t( c[1] ), int16_t( c[2] ), 0};
+  pointToPixel[off] = uint32_t( x ) | ( uint32_t( y ) << 12 ) | ( cnt == 2 ? 1u << 25 : 0u );
+  if ( cnt == 2 ) {
+    c[p.axN]              = c1;
+    recon[off + 1]        = Pt{int16_t( c[0] ), int16_t( c[1] ), int16_t( c[2] ), 0};
+    pointToPixel[off + 1] = uint32_t( x ) | ( uint32_t( y ) << 12 ) | ( 1u << 24 );
+  }
+}
+
+// ---- S18 ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t toU8( double v ) { return uint8_t( fmax( 0.0, fmin( round( v ), 255.0 ) ) ); }
+
+__global__ __launch_bounds__( 256 ) void forwardColorKernel( const uint32_t* __restrict__ idx8, const uint32_t* __restrict__ dist8,
+                                                              const uint8_t* __restrict__ srcRgb4, uint32_t m,
+                                                              uint8_t* __restrict__ fwdRgb4 ) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( t >= m ) return;
+  const uint4* ir = reinterpret_cast<const uint4*>( idx8 + size_t( t ) * 8 );
+  const uint4* dr = reinterpret_cast<const uint4*>( dist8 + size_t( t ) * 8 );
+  const uint4  i0 = ir[0], i1 = ir[1], d0 = dr[0], d1 = dr[1];
+  const uint32_t id[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+  const uint32_t ds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+  uchar4         out;
+  if ( ds[0] == 0 ) {  // "dist < 0.0001": an identical source point exists, take its colour
+    out = reinterpret_cast<const uchar4*>( srcRgb4 )[id[0]];
+  } else {
+    double r = 0.0, g = 0.0, b = 0.0, sw = 0.0;
+#pragma unroll
+    for ( int i = 0; i < 8; ++i ) {
+      const double w = __ddiv_rn( 1.0, double( ds[i] ) + 4.0 );
+      const uchar4 c = reinterpret_cast<const uchar4*>( srcRgb4 )[id[i]];
+      r += double( c.x ) * w;
+      g += double( c.y ) * w;
+      b += double( c.z ) * w;
+      sw += w;
+    }
+    out = make_uchar4( toU8( __ddiv_rn( r, sw ) ), toU8( __ddiv_rn( g, sw ) ), toU8( __ddiv_rn( b, sw ) ), 0 );
+  }
+  reinterpret_cast<uchar4*>( fwdRgb4 )[t] = out;
+}
+
+__global__ __launch_bounds__( 256 ) void backwardCountKernel( const uint32_t* __restrict__ idx1, uint32_t n,
+                                                               uint32_t* __restrict__ count ) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( s < n ) atomicAdd( &count[idx1[s]], 1u );
+}
+
+__global__ __launch_bounds__( 256 ) void backwardFillKernel( const uint32_t* __restrict__ idx1, const uint32_t* __restrict__ dist1,
+                                                              const uint32_t* __restrict__ offset, uint32_t n,
+                                                              uint32_t* __restrict__ cursor, uint2* __restrict__ entries ) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( s >= n ) return;
+  const uint32_t t          = idx1[s];
+  const uint32_t slot       = atomicAdd( &cursor[t], 1u );
+  entries[offset[t] + slot] = make_uint2( dist1[s], s );
+}
+
+__global__ __launch_bounds__( 256 ) void combineColorKernel( const uint32_t* __restrict__ count, const uint32_t* __restrict__ offset,
+                                                              const uint2* __restrict__ entries,
+                                                              const uint8_t* __restrict__ srcRgb4,
+                                                              const uint8_t* __restrict__ fwdRgb4, uint32_t m,
+                                                              uint8_t* __restrict__ outRgb4, uint32_t* __restrict__ error ) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( t >= m ) return;
+  const uint32_t n = count[t];
+  if ( n == 0 ) {
+    reinterpret_cast<uchar4*>( outRgb4 )[t] = reinterpret_cast<const uchar4*>( fwdRgb4 )[t];
+    return;
+  }
+  if ( n > 16 ) {  // the reference's std::sort is only stable (insertion sort) up to 16 candidates
+    *error = 1;
+    return;
+  }
+  // consume the candidates in (distance, source index) order: repeated selection of the next key, n <= 16
+  const uint2* e = entries + offset[t];
+  double       r = 0.0, g = 0.0, b = 0.0, sw = 0.0;
+  uint64_t     last  = 0;
+  bool         exact = false;  // first candidate is an identical point, or the only one: its colour, unweighted
+  for ( uint32_t k = 0; k < n; ++k ) {
+    uint64_t best = ~0ull;
+    for ( uint32_t j = 0; j < n; ++j ) {
+      const uint2    c   = e[j];
+      const uint64_t key = ( uint64_t( c.x ) << 32 ) | c.y;
+      if ( ( k == 0 || key > last ) && key < best ) best = key;
+    }
+    last                 = best;
+    const uint32_t dist2 = uint32_t( best >> 32 ), src = uint32_t( best );
+    const uchar4   c     = reinterpret_cast<const uchar4*>( srcRgb4 )[src];
+    if ( k == 0 && ( dist2 == 0 || n == 1 ) ) {
+      r     = double( c.x );
+      g     = double( c.y );
+      b     = double( c.z );
+      exact = true;
+      break;
+    }
+    const double w = __ddiv_rn( 1.0, __dsqrt_rn( double( dist2 ) ) + 4.0 );
+    r += double( c.x ) * w;
+    g += double( c.y ) * w;
+    b += double( c.z ) * w;
+    sw += w;
+  }
+  if ( !exact ) {
+    r = __ddiv_rn( r, sw );
+    g = __ddiv_rn( g, sw );
+    b = __ddiv_rn( b, sw );
+  }
+  const uchar4 f = reinterpret_cast<const uchar4*>( fwdRgb4 )[t];
+  // fixWeight: w = 0  ->  round( 0 * centroid1 + 1 * centroid2 )
+  reinterpret_cast<uchar4*>( outRgb4 )[t] = make_uchar4( toU8( 0.0 * double( f.x ) + 1.0 * r ), toU8( 0.0 * double( f.y ) + 1.0 * g ),
+                                                         toU8( 0.0 * double( f.z ) + 1.0 * b ), 0 );
+}
+
+// ---- S20 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__( 256 ) void attributeScatterKernel( const uint8_t* __restrict__ rgb4,
+                                                                  const uint32_t* __restrict__ pointToPixel, uint32_t m,
+                                                                  int W, int H, uint8_t* __restrict__ attr ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= m ) return;
+  const uint32_t pp = pointToPixel[i];
+  const size_t   px = size_t( ( pp >> 12 ) & 0xFFF ) * W + ( pp & 0xFFF ), plane = size_t( W ) * H;
+  const uchar4   c  = reinterpret_cast<const uchar4*>( rgb4 )[i];
+  const bool     layer1 = ( pp >> 24 ) & 1, hasD1 = ( pp >> 25 ) & 1;
+  if ( !layer1 ) {
+    attr[px] = c.x, attr[plane + px] = c.y, attr[2 * plane + px] = c.z;
+    if ( !hasD1 ) attr[3 * plane + px] = c.x, attr[4 * plane + px] = c.y, attr[5 * plane + px] = c.z;
+  } else {
+    attr[3 * plane + px] = c.x, attr[4 * plane + px] = c.y, attr[5 * plane + px] = c.z;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void upsampleOccupancyKernel( const uint8_t* __restrict__ occVideo, int W, int H, int prec,
+                                                                   uint8_t* __restrict__ occ ) {
+  const size_t c = size_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+  if ( c >= size_t( W ) * H ) return;
+  occ[c] = occVideo[size_t( ( c / W ) / prec ) * ( W / prec ) + ( c % W ) / prec];
+}
+
+// ---- S21 ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mean4w( int p1, int w1, int p2, int w2, int p3, int w3, int p4, int w4 ) {
+  return ( p1 * w1 + p2 * w2 + p3 * w3 + p4 * w4 ) / ( w1 + w2 + w3 + w4 );
+}
+
+// six planes (2 maps x 3 channels) of size W*H each, plane stride = W*H
+__global__ __launch_bounds__( 256 ) void pushPullMipKernel( const uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W,
+                                                             int H, uint8_t* __restrict__ mip, uint8_t* __restrict__ mipOcc, int w,
+                                                             int h ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= w * h ) return;
+  const int  x = i % w, y = i / w, X = 2 * x, Y = 2 * y;
+  const bool i2 = X + 1 < W, i3 = Y + 1 < H;
+  const int  w1 = occ[size_t( Y ) * W + X] ? 255 : 0;
+  const int  w2 = ( i2 && occ[size_t( Y ) * W + X + 1] ) ? 255 : 0;
+  const int  w3 = ( i3 && occ[size_t( Y + 1 ) * W + X] ) ? 255 : 0;
+  const int  w4 = ( i2 && i3 && occ[size_t( Y + 1 ) * W + X + 1] ) ? 255 : 0;
+  const bool any = ( w1 + w2 + w3 + w4 ) > 0;
+  mipOcc[i]      = any ? 1 : 0;
+#pragma unroll
+  for ( int p = 0; p < 6; ++p ) {
+    const uint8_t* s = img + size_t( p ) * W * H;
+    uint8_t        v = 0;
+    if ( any ) {
+      const int v1 = s[size_t( Y ) * W + X], v2 = i2 ? s[size_t( Y ) * W + X + 1] : 0;
+      const int v3 = i3 ? s[size_t( Y + 1 ) * W + X] : 0, v4 = ( i2 && i3 ) ? s[size_t( Y + 1 ) * W + X + 1] : 0;
+      v            = uint8_t( mean4w( v1, w1, v2, w2, v3, w3, v4, w4 ) );
+    }
+    mip[size_t( p ) * w * h + i] = v;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void pushPullFillKernel( uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W, int H,
+                                                              const uint8_t* __restrict__ mip, int w, int h ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= W * H || occ[i] ) return;
+  const int  X = i % W, Y = i / W, x = X >> 1, y = Y >> 1;
+  const int  dx = ( X & 1 ) ? 1 : -1, dy = ( Y & 1 ) ? 1 : -1;
+  const bool hx = dx < 0 ? x > 0 : x < w - 1, hy = dy < 0 ? y > 0 : y < h - 1;
+#pragma unroll
+  for ( int p = 0; p < 6; ++p ) {
+    const uint8_t* m  = mip + size_t( p ) * w * h;
+    const int      v  = m[size_t( y ) * w + x];
+    const int      vx = hx ? m[size_t( y ) * w + x + dx] : 0;
+    const int      vy = hy ? m[size_t( y + dy ) * w + x] : 0;
+    const int      vd = ( hx && hy ) ? m[size_t( y + dy ) * w + x + dx] : 0;
+    img[size_t( p ) * W * H + i] = uint8_t( mean4w( v, 144, vx, hx ? 48 : 0, vy, hy ? 48 : 0, vd, ( hx && hy ) ? 16 : 0 ) );
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void pushPullBlurKernel( const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                              const uint8_t* __restrict__ occ, int W, int H ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= W * H || occ[i] ) return;
+  const int x = i % W, y = i / W;
+  const int x1 = x > 0 ? x - 1 : x, y1 = y > 0 ? y - 1 : y, x2 = x < W - 1 ? x + 1 : x, y2 = y < H - 1 ? y + 1 : y;
+#pragma unroll
+  for ( int p = 0; p < 6; ++p ) {
+    const uint8_t* s   = src + size_t( p ) * W * H;
+    const int      sum = s[size_t( y1 ) * W + x1] + s[size_t( y1 ) * W + x2] + s[size_t( y2 ) * W + x1] + s[size_t( y2 ) * W + x2] +
+                    s[size_t( y ) * W + x1] + s[size_t( y ) * W + x2] + s[size_t( y1 ) * W + x] + s[size_t( y2 ) * W + x];
+    dst[size_t( p ) * W * H + i] = uint8_t( ( sum + 4 ) >> 3 );
+  }
+}
+
+// ---- S22 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__( 256 ) void attributeGroupDilateKernel( const uint8_t* __restrict__ occ, int W, int H,
+                                                                      uint8_t* __restrict__ attr ) {
+  const size_t c = size_t( blockIdx.x ) * blockDim.x + threadIdx.x, plane = size_t( W ) * H;
+  if ( c >= plane || occ[c] ) return;
+#pragma unroll
+  for ( int k = 0; k < 3; ++k ) {
+    const uint32_t a = attr[k * plane + c], b = attr[( 3 + k ) * plane + c];
+    const uint8_t  v = uint8_t( ( a + b + 1 ) >> 1 );
+    attr[k * plane + c] = attr[( 3 + k ) * plane + c] = v;
+  }
+}
+
+}  // namespace
+
+int generateAttributeImages( tmc2_frame* f ) {
+  if ( !f->haveGeometryImages ) {
+    setError( "generateAttributeImages: geometry images missing" );
+    return TMC2_E_STATE;
+  }
+  if ( f->d_rgb.count == 0 ) {
+    setError( "generateAttributeImages: the frame has no colours" );
+    return TMC2_E_STATE;
+  }
+  TMC2_TRY( f->ensureTree() );
+  tmc2_ctx*    ctx = f->ctx;
+  hipStream_t  s   = ctx->stream;
+  const int    W = f->canvasW, H = f->canvasH, prec = f->occPrecision;
+  const size_t area = size_t( W ) * H;
+  const dim3   blk( 256 );
+  const uint32_t tiles = f->tileCount, n = uint32_t( f->n );
+  // ---- S17 ----------------------------------------------------------------------------------------------
+  int sid = ctx->stageBegin( "reconstruct" );
+  DevBuf<uint32_t> d_tileCount, d_tileOffset, d_small;
+  TMC2_TRY( d_tileCount.alloc( std::max( tiles, 1u ) ) );
+  TMC2_TRY( d_tileOffset.alloc( std::max( tiles, 1u ) ) );
+  TMC2_TRY( d_small.alloc( 8 ) );
+  uint32_t M = 0;
+  if ( tiles ) {
+    hipLaunchKernelGGL( reconTileKernel<false>, dim3( tiles ), blk, 0, s, f->d_place.p, f->d_tilePatch.p, f->d_occVideo.p,
+                        f->d_blockToPatch.p, f->d_geo.p, W, H, prec, d_tileCount.p, (const uint32_t*)nullptr, (Pt*)nullptr,
+                        (uint32_t*)nullptr );
+    TMC2_TRY( exclusiveScanU32( ctx, d_tileCount.p, d_tileOffset.p, tiles, d_small.p ) );
+    TMC2_HIP( hipMemcpyAsync( &M, d_small.p, 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+  }
+  if ( M == 0 ) {
+    ctx->stageEnd( sid );
+    setError( "generateAttributeImages: empty reconstruction" );
+    return TMC2_E_STATE;
+  }
+  TMC2_TRY( f->d_recon.alloc( M ) );
+  TMC2_TRY( f->d_pointToPixel.alloc( M ) );
+  hipLaunchKernelGGL( reconTileKernel<true>, dim3( tiles ), blk, 0, s, f->d_place.p, f->d_tilePatch.p, f->d_occVideo.p,
+                      f->d_blockToPatch.p, f->d_geo.p, W, H, prec, d_tileCount.p, d_tileOffset.p, f->d_recon.p,
+                      f->d_pointToPixel.p );
+  ctx->stageEnd( sid );
+  f->reconCount = M;
+  // ---- tree over the reconstruction (host build, like S1) ------------------------------------------------
+  {
+    std::vector<Pt> h_recon( M );
+    TMC2_HIP( hipMemcpyAsync( h_recon.data(), f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    const auto           t0 = std::chrono::steady_clock::now();
+    std::vector<int16_t> xyz( 3 * size_t( M ) );
+    for ( uint32_t i = 0; i < M; ++i ) xyz[3 * size_t( i )] = h_recon[i].x, xyz[3 * size_t( i ) + 1] = h_recon[i].y, xyz[3 * size_t( i ) + 2] = h_recon[i].z;
+    f->reconTree.build( xyz.data(), M );
+    std::vector<Pt> ptsTree( M );
+    for ( uint32_t i = 0; i < M; ++i ) ptsTree[i] = h_recon[f->reconTree.perm[i]];
+    const auto t1 = std::chrono::steady_clock::now();
+    ctx->stageAddHostMs( "kdtree_build_recon_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+    TMC2_TRY( f->d_reconTreePts.alloc( M ) );
+    TMC2_TRY( f->d_reconPerm.alloc( M ) );
+    TMC2_TRY( f->d_reconNodes.alloc( f->reconTree.nodes.size() ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_reconTreePts.p, ptsTree.data(), size_t( M ) * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_reconPerm.p, f->reconTree.perm.data(), size_t( M ) * 4, hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_reconNodes.p, f->reconTree.nodes.data(), f->reconTree.nodes.size() * sizeof( KdNode ),
+                              hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+  }
+  TreeDev rt;
+  rt.ptsTree = f->d_reconTreePts.p;
+  rt.perm    = f->d_reconPerm.p;
+  rt.nodes   = f->d_reconNodes.p;
+  for ( int d = 0; d < 3; ++d ) rt.lo[d] = f->reconTree.lo[d], rt.hi[d] = f->reconTree.hi[d];
+  rt.depth = f->reconTree.depth;
+  rt.n     = M;
+  // ---- S18 ----------------------------------------------------------------------------------------------
+  DevBuf<uint32_t> d_idx8, d_dist8, d_idx1, d_dist1, d_count, d_offset, d_cursor;
+  DevBuf<uint2>    d_entries;
+  DevBuf<uint8_t>  d_fwd;
+  TMC2_TRY( d_idx8.alloc( size_t( M ) * 8 ) );
+  TMC2_TRY( d_dist8.alloc( size_t( M ) * 8 ) );
+  TMC2_TRY( d_idx1.alloc( n ) );
+  TMC2_TRY( d_dist1.alloc( n ) );
+  TMC2_TRY( d_count.alloc( M ) );
+  TMC2_TRY( d_offset.alloc( M ) );
+  TMC2_TRY( d_cursor.alloc( M ) );
+  TMC2_TRY( d_entries.alloc( n ) );
+  TMC2_TRY( d_fwd.alloc( size_t( M ) * 4 ) );
+  TMC2_TRY( f->d_reconRgb.alloc( size_t( M ) * 4 ) );
+  TMC2_TRY( launchKnnTree( ctx, frameTree( f ), f->d_recon.p, M, 8, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
+  TMC2_TRY( launchKnnTree( ctx, rt, f->d_pts.p, n, 1, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
+  sid = ctx->stageBegin( "transfer_colors" );
+  TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( M ) * 4, s ) );
+  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( M ) * 4, s ) );
+  TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 4, s ) );
+  const dim3 grdM( ( M + 255 ) / 256 ), grdN( ( n + 255 ) / 256 );
+  hipLaunchKernelGGL( forwardColorKernel, grdM, blk, 0, s, d_idx8.p, d_dist8.p, f->d_rgb.p, M, d_fwd.p );
+  hipLaunchKernelGGL( backwardCountKernel, grdN, blk, 0, s, d_idx1.p, n, d_count.p );
+  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, M, nullptr ) );
+  hipLaunchKernelGGL( backwardFillKernel, grdN, blk, 0, s, d_idx1.p, d_dist1.p, d_offset.p, n, d_cursor.p, d_entries.p );
+  hipLaunchKernelGGL( combineColorKernel, grdM, blk, 0, s, d_count.p, d_offset.p, d_entries.p, f->d_rgb.p, d_fwd.p, M,
+                      f->d_reconRgb.p, d_small.p + 1 );
+  ctx->stageEnd( sid );
+  // ---- S20 ----------------------------------------------------------------------------------------------
+  sid = ctx->stageBegin( "attribute_images" );
+  DevBuf<uint8_t> d_occ;
+  TMC2_TRY( d_occ.alloc( area ) );
+  TMC2_TRY( f->d_attr.alloc( 6 * area ) );
+  TMC2_HIP( hipMemsetAsync( f->d_attr.p, 0, 6 * area, s ) );
+  hipLaunchKernelGGL( upsampleOccupancyKernel, dim3( uint32_t( ( area + 255 ) / 256 ) ), blk, 0, s, f->d_occVideo.p, W, H, prec,
+                      d_occ.p );
+  hipLaunchKernelGGL( attributeScatterKernel, grdM, blk, 0, s, f->d_reconRgb.p, f->d_pointToPixel.p, M, W, H, f->d_attr.p );
+  // ---- S21: pyramid ------------------------------------------------------------------------------------------
+  struct Level {
+    int      w, h;
+    uint8_t *img, *tmp, *occ;
+  };
+  std::vector<Level> lv;
+  lv.push_back( Level{W, H, f->d_attr.p, nullptr, d_occ.p} );
+  size_t pyramidBytes = 6 * area;  // ping-pong partner of level 0
+  {
+    int w = W, h = H;
+    for ( ;; ) {
+      w = ( w + 1 ) >> 1;
+      h = ( h + 1 ) >> 1;
+      lv.push_back( Level{w, h, nullptr, nullptr, nullptr} );
+      pyramidBytes += size_t( w ) * h * ( 6 + 6 + 1 );
+      if ( w <= 4 || h <= 4 ) break;
+    }
+  }
+  DevBuf<uint8_t> d_pyr;
+  TMC2_TRY( d_pyr.alloc( pyramidBytes + 64 * lv.size() ) );
+  {
+    uint8_t* p = d_pyr.p;
+    lv[0].tmp  = p;
+    p += 6 * area;
+    for ( size_t l = 1; l < lv.size(); ++l ) {
+      const size_t a = size_t( lv[l].w ) * lv[l].h;
+      lv[l].img = p, p += 6 * a;
+      lv[l].tmp = p, p += 6 * a;
+      lv[l].occ = p, p += ( a + 15 ) & ~size_t( 15 );
+    }
+  }
+  for ( size_t l = 1; l < lv.size(); ++l ) {
+    const int cnt = lv[l].w * lv[l].h;
+    hipLaunchKernelGGL( pushPullMipKernel, dim3( ( cnt + 255 ) / 256 ), blk, 0, s, lv[l - 1].img, lv[l - 1].occ, lv[l - 1].w,
+                        lv[l - 1].h, lv[l].img, lv[l].occ, lv[l].w, lv[l].h );
+  }
+  int iters = 4;
+  for ( size_t l = lv.size() - 1; l >= 1; --l ) {
+    Level&    fine = lv[l - 1];
+    const int cnt  = fine.w * fine.h;
+    const dim3 grd( ( cnt + 255 ) / 256 );
+    hipLaunchKernelGGL( pushPullFillKernel, grd, blk, 0, s, fine.img, fine.occ, fine.w, fine.h, lv[l].img, lv[l].w, lv[l].h );
+    TMC2_HIP( hipMemcpyAsync( fine.tmp, fine.img, size_t( 6 ) * cnt, hipMemcpyDeviceToDevice, s ) );
+    uint8_t *src = fine.img, *dst = fine.tmp;
+    for ( int it = 0; it < iters; ++it ) {
+      hipLaunchKernelGGL( pushPullBlurKernel, grd, blk, 0, s, src, dst, fine.occ, fine.w, fine.h );
+      std::swap( src, dst );
+    }
+    if ( src != fine.img ) {  // odd iteration count: latest result sits in the partner buffer
+      if ( l - 1 == 0 )
+        TMC2_HIP( hipMemcpyAsync( fine.img, src, size_t( 6 ) * cnt, hipMemcpyDeviceToDevice, s ) );
+      else
+        std::swap( fine.img, fine.tmp );
+    }
+    iters = std::min( iters + 1, 16 );
+  }
+  // ---- S22 ----------------------------------------------------------------------------------------------
+  hipLaunchKernelGGL( attributeGroupDilateKernel, dim3( uint32_t( ( area + 255 ) / 256 ) ), blk, 0, s, d_occ.p, W, H, f->d_attr.p );
+  ctx->stageEnd( sid );
+  uint32_t err = 0;
+  TMC2_HIP( hipMemcpyAsync( &err, d_small.p + 1, 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  TMC2_HIP( hipGetLastError() );
+  if ( err ) {
+    setError( "transferColors: a reconstructed point collected more than 16 backward candidates (the reference's "
+              "std::sort order for such lists is not reproduced)" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  f->haveAttributeImages = true;
+  return TMC2_OK;
+}
+
+}  // namespace tmc2
+
+extern "C" {
+
+int tmc2_encoder_generate_attribute_images( tmc2_frame* f ) {
+  if ( !f ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( f->ctx );
+  return tmc2::generateAttributeImages( f );
+}
+
+int64_t tmc2_frame_recon_count( tmc2_frame* f ) { return ( f && f->haveAttributeImages ) ? int64_t( f->reconCount ) : 0; }
+
+int tmc2_frame_get_reconstruction( tmc2_frame* f, int16_t* xyz, uint8_t* rgb, uint32_t* pointToPixel ) {
+  if ( !f || !f->haveAttributeImages ) {
+    tmc2::setError( "get_reconstruction: not generated" );
+    return TMC2_E_STATE;
+  }
+  tmc2::ApiScope scope( f->ctx );
+  hipStream_t    s = f->ctx->stream;
+  const size_t   M = f->reconCount;
+  std::vector<tmc2::Pt>  pts( M );
+  std::vector<uint8_t>   c4( 4 * M );
+  std::vector<uint32_t>  pp( M );
+  TMC2_HIP( hipMemcpyAsync( pts.data(), f->d_recon.p, M * sizeof( tmc2::Pt ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( c4.data(), f->d_reconRgb.p, 4 * M, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( pp.data(), f->d_pointToPixel.p, 4 * M, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  for ( size_t i = 0; i < M; ++i ) {
+    if ( xyz ) xyz[3 * i] = pts[i].x, xyz[3 * i + 1] = pts[i].y, xyz[3 * i + 2] = pts[i].z;
+    if ( rgb ) rgb[3 * i] = c4[4 * i], rgb[3 * i + 1] = c4[4 * i + 1], rgb[3 * i + 2] = c4[4 * i + 2];
+    if ( pointToPixel )
+      pointToPixel[3 * i] = pp[i] & 0xFFF, pointToPixel[3 * i + 1] = ( pp[i] >> 12 ) & 0xFFF, pointToPixel[3 * i + 2] = ( pp[i] >> 24 ) & 1;
+  }
+  return TMC2_OK;
+}
+
+int tmc2_frame_get_attribute_images( tmc2_frame* f, uint8_t* attribute ) {
+  if ( !f || !attribute || !f->haveAttributeImages ) {
+    tmc2::setError( "get_attribute_images: not generated" );
+    return TMC2_E_STATE;
+  }
+  tmc2::ApiScope scope( f->ctx );
+  TMC2_HIP( hipMemcpyAsync( attribute, f->d_attr.p, size_t( 6 ) * f->canvasW * f->canvasH, hipMemcpyDeviceToHost, f->ctx->stream ) );
+  TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
+  return TMC2_OK;
+}
+}

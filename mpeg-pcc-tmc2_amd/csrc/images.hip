@@ -27,13 +27,6 @@
 namespace tmc2 {
 namespace {
 
-struct PlaceDev {
-  int32_t u0, v0, orient;
-  int32_t sizeU, sizeV, sizeU0, sizeV0;
-  int32_t tileBase;
-  int64_t depthOff;
-};
-
 __device__ __forceinline__ void toCanvas( const PlaceDev& p, int u, int v, int& x, int& y ) {
   if ( p.orient == 0 ) {
     x = u + p.u0 * 16;
@@ -235,14 +228,18 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
     d.sizeU = t.sizeU, d.sizeV = t.sizeV, d.sizeU0 = t.sizeU0, d.sizeV0 = t.sizeV0;
     d.tileBase = int32_t( tilePatch.size() );
     d.depthOff = t.depthOffset;
+    d.u1 = t.u1, d.v1 = t.v1, d.d1 = t.d1;
+    d.axN = t.normalAxis, d.axT = t.tangentAxis, d.axB = t.bitangentAxis, d.mode = t.projectionMode;
+    d.pad = 0;
     if ( t.patchOrientation != 0 && t.patchOrientation != 1 ) {
       setError( "generateGeometryImages: patch orientation %d unsupported", t.patchOrientation );
       return TMC2_E_UNSUPPORTED;
     }
     tilePatch.insert( tilePatch.end(), size_t( t.sizeU0 ) * t.sizeV0, uint32_t( k ) );
   }
-  DevBuf<PlaceDev> d_place;
-  DevBuf<uint32_t> d_tilePatch, d_err;
+  DevBuf<PlaceDev>& d_place     = f->d_place;
+  DevBuf<uint32_t>& d_tilePatch = f->d_tilePatch;
+  DevBuf<uint32_t>  d_err;
   DevBuf<uint8_t>  d_empty;
   TMC2_TRY( d_place.alloc( std::max( P, 1 ) ) );
   TMC2_TRY( d_tilePatch.alloc( std::max<size_t>( tilePatch.size(), 1 ) ) );
@@ -282,6 +279,7 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
     setError( "generateGeometryImages: a patch falls outside the %dx%d canvas (the reference exits with code 180)", W, H );
     return TMC2_E_INVALID;
   }
+  f->tileCount          = uint32_t( tilePatch.size() );
   f->canvasW            = W;
   f->canvasH            = H;
   f->occPrecision       = occPrecision;
@@ -297,6 +295,22 @@ int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height,
   if ( !f ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   return tmc2::generateGeometryImages( f, width, height, 16, occupancyPrecision );
+}
+
+int tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo, const uint16_t* geometry ) {
+  if ( !f || !f->haveGeometryImages ) {
+    tmc2::setError( "set_decoded_geometry: canvases not generated" );
+    return TMC2_E_STATE;
+  }
+  tmc2::ApiScope scope( f->ctx );
+  hipStream_t    s    = f->ctx->stream;
+  const size_t   area = size_t( f->canvasW ) * f->canvasH;
+  if ( occVideo )
+    TMC2_HIP( hipMemcpyAsync( f->d_occVideo.p, occVideo, area / ( size_t( f->occPrecision ) * f->occPrecision ),
+                              hipMemcpyHostToDevice, s ) );
+  if ( geometry ) TMC2_HIP( hipMemcpyAsync( f->d_geo.p, geometry, 2 * area * sizeof( uint16_t ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  return TMC2_OK;
 }
 
 int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry ) {

@@ -115,6 +115,27 @@ struct alignas( 8 ) Pt {
   int16_t x, y, z, w;
 };
 
+// placement + projection of one patch on the device, in packing order (shared by the image kernels)
+struct PlaceDev {
+  int32_t u0, v0, orient;
+  int32_t sizeU, sizeV, sizeU0, sizeV0;
+  int32_t tileBase;
+  int32_t u1, v1, d1;
+  int32_t axN, axT, axB, mode;
+  int32_t pad;
+  int64_t depthOff;
+};
+
+// a k-d tree resident on the device (tree-order points, permutation, nodes) -- what the k-NN kernels traverse
+struct TreeDev {
+  const Pt*       ptsTree = nullptr;
+  const uint32_t* perm    = nullptr;
+  const KdNode*   nodes   = nullptr;
+  int32_t         lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  int             depth = 0;
+  uint64_t        n     = 0;
+};
+
 // GPU time per named stage / kernel: hipEvent pairs recorded on the context's stream, folded lazily when the
 // totals are queried (never blocks the host while work is being queued).
 struct StageTimer {
@@ -181,6 +202,20 @@ struct tmc2_frame {
   tmc2::DevBuf<uint8_t>   d_occVideo;           // (W/p)*(H/p)
   tmc2::DevBuf<uint32_t>  d_blockToPatch;       // (W/16)*(H/16), list position + 1
   tmc2::DevBuf<uint16_t>  d_geo;                // 2 maps * W*H (D0 then D1), luma only (chroma planes are all-zero)
+  tmc2::DevBuf<tmc2::PlaceDev> d_place;         // patches in packing order
+  tmc2::DevBuf<uint32_t>  d_tilePatch;          // 16x16 patch blocks -> list position
+  uint32_t                tileCount = 0;
+  // phase B: reconstruction + attribute images
+  uint64_t                reconCount = 0;
+  bool                    haveAttributeImages = false;
+  tmc2::DevBuf<tmc2::Pt>  d_recon;              // reconstructed points (generatePointCloud order)
+  tmc2::DevBuf<uint32_t>  d_pointToPixel;       // x | y << 12 | layer << 24 | hasD1 << 25
+  tmc2::DevBuf<uint8_t>   d_reconRgb;           // [M][4]
+  tmc2::DevBuf<uint8_t>   d_attr;               // [2 maps][3 channels][H][W]
+  tmc2::KdTreeHost        reconTree;
+  tmc2::DevBuf<tmc2::Pt>  d_reconTreePts;
+  tmc2::DevBuf<uint32_t>  d_reconPerm;
+  tmc2::DevBuf<tmc2::KdNode> d_reconNodes;
 };
 
 namespace tmc2 {
@@ -193,6 +228,10 @@ struct ApiScope {
 // kernels / stage launchers (each returns TMC2_OK or an error code; all work is queued on ctx->stream)
 int launchKnnSelf( tmc2_frame* f, int k );
 int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist );
+int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx,
+                   uint32_t* d_dist, const char* stage );
+TreeDev frameTree( const tmc2_frame* f );
+int generateAttributeImages( tmc2_frame* f );
 int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );

@@ -128,22 +128,25 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
 }
 
 template <bool SELF>
-int dispatch( tmc2_frame* f, const Pt* q, uint64_t nq, int k, uint32_t* idx, uint32_t* dist ) {
-  if ( f->tree.depth > kMaxStack ) {
-    setError( "k-d tree depth %d exceeds the traversal stack (%d)", f->tree.depth, kMaxStack );
+int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, uint32_t* idx, uint32_t* dist ) {
+  if ( t.depth > kMaxStack ) {
+    setError( "k-d tree depth %d exceeds the traversal stack (%d)", t.depth, kMaxStack );
     return TMC2_E_UNSUPPORTED;
+  }
+  if ( uint64_t( k ) > t.n ) {
+    setError( "k=%d larger than the cloud (%llu points)", k, (unsigned long long)t.n );
+    return TMC2_E_INVALID;
   }
   RootBox rb;
   for ( int d = 0; d < 3; ++d ) {
-    rb.lo[d] = f->tree.lo[d];
-    rb.hi[d] = f->tree.hi[d];
+    rb.lo[d] = t.lo[d];
+    rb.hi[d] = t.hi[d];
   }
-  const dim3  block( 256 );
-  const dim3  grid( uint32_t( ( nq + 255 ) / 256 ) );
-  hipStream_t s = f->ctx->stream;
-#define TMC2_LAUNCH_K( KK )                                                                                          \
-  hipLaunchKernelGGL( ( knnKernel<KK, SELF> ), grid, block, 0, s, f->d_ptsTree.p, f->d_perm.p, f->d_nodes.p, rb, q, \
-                      uint32_t( nq ), idx, dist )
+  const dim3 block( 256 );
+  const dim3 grid( uint32_t( ( nq + 255 ) / 256 ) );
+#define TMC2_LAUNCH_K( KK )                                                                                   \
+  hipLaunchKernelGGL( ( knnKernel<KK, SELF> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q, uint32_t( nq ), \
+                      idx, dist )
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
     case 4: TMC2_LAUNCH_K( 4 ); break;
@@ -158,14 +161,24 @@ int dispatch( tmc2_frame* f, const Pt* q, uint64_t nq, int k, uint32_t* idx, uin
 
 }  // namespace
 
-int launchKnnSelf( tmc2_frame* f, int k ) {
-  if ( uint64_t( k ) > f->n ) {
-    setError( "k=%d larger than the cloud (%llu points)", k, (unsigned long long)f->n );
-    return TMC2_E_INVALID;
+TreeDev frameTree( const tmc2_frame* f ) {
+  TreeDev t;
+  t.ptsTree = f->d_ptsTree.p;
+  t.perm    = f->d_perm.p;
+  t.nodes   = f->d_nodes.p;
+  for ( int d = 0; d < 3; ++d ) {
+    t.lo[d] = f->tree.lo[d];
+    t.hi[d] = f->tree.hi[d];
   }
+  t.depth = f->tree.depth;
+  t.n     = f->n;
+  return t;
+}
+
+int launchKnnSelf( tmc2_frame* f, int k ) {
   TMC2_TRY( f->d_knn.alloc( f->n * size_t( k ) ) );
   const int sid = f->ctx->stageBegin( "knn_self" );
-  const int r   = dispatch<true>( f, nullptr, f->n, k, f->d_knn.p, nullptr );
+  const int r   = dispatch<true>( f->ctx->stream, frameTree( f ), nullptr, f->n, k, f->d_knn.p, nullptr );
   f->ctx->stageEnd( sid );
   if ( r == TMC2_OK ) {
     f->k       = k;
@@ -175,13 +188,14 @@ int launchKnnSelf( tmc2_frame* f, int k ) {
 }
 
 int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist ) {
-  if ( uint64_t( k ) > f->n ) {
-    setError( "k=%d larger than the cloud (%llu points)", k, (unsigned long long)f->n );
-    return TMC2_E_INVALID;
-  }
-  const int sid = f->ctx->stageBegin( "knn_query" );
-  const int r   = dispatch<false>( f, d_queries, nq, k, d_idx, d_dist );
-  f->ctx->stageEnd( sid );
+  return launchKnnTree( f->ctx, frameTree( f ), d_queries, nq, k, d_idx, d_dist, "knn_query" );
+}
+
+int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx,
+                   uint32_t* d_dist, const char* stage ) {
+  const int sid = ctx->stageBegin( stage );
+  const int r   = dispatch<false>( ctx->stream, tree, d_queries, nq, k, d_idx, d_dist );
+  ctx->stageEnd( sid );
   return r;
 }
 

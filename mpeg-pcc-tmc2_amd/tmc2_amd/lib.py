@@ -275,6 +275,29 @@ class Frame:
         return out
 
 
+    # PCCEncoder image generation, phase B
+    def encoder_generate_attribute_images(self):
+        _check(self.L.tmc2_encoder_generate_attribute_images(self.h))
+
+    def get_reconstruction(self):
+        self.L.tmc2_frame_recon_count.restype = C.c_int64
+        M = self.L.tmc2_frame_recon_count(self.h)
+        xyz, rgb, p2p = np.zeros((M, 3), np.int16), np.zeros((M, 3), np.uint8), np.zeros((M, 3), np.uint32)
+        _check(self.L.tmc2_frame_get_reconstruction(self.h, _ptr(xyz), _ptr(rgb), _ptr(p2p)))
+        return xyz, rgb, p2p
+
+    def get_attribute_images(self):
+        W, H, _ = self._canvas
+        out = np.zeros((2, 3, H, W), np.uint8)
+        _check(self.L.tmc2_frame_get_attribute_images(self.h, _ptr(out)))
+        return out
+
+    def set_decoded_geometry(self, occ_video=None, geometry=None):
+        ov = None if occ_video is None else np.ascontiguousarray(occ_video, dtype=np.uint8)
+        g = None if geometry is None else np.ascontiguousarray(geometry, dtype=np.uint16)
+        _check(self.L.tmc2_frame_set_decoded_geometry(self.h, None if ov is None else _ptr(ov), None if g is None else _ptr(g)))
+
+
 def encoder_canvas_size(heights, tile_width=1280, min_w=1280, min_h=1280):
     """resizeTileGeometryVideo + resizeGeometryVideo: common canvas of a GOF."""
     L = load_library()
