@@ -635,6 +635,54 @@ int ref_gof_get_attribute_images( int frame, uint8_t* out ) {
   return 0;
 }
 
+// S23: PCCMetrics::compute (PCCMetrics.cpp:324-375) on one frame.  normals may be NULL (then no D2).
+// out[3][8] = for q1 (A->B), q2 (B->A), final: c2cMse, c2cPsnr, c2pMse, c2pPsnr, colorMse[3] (Y,U,V) + colorPsnr[0].
+// counts[2] = point counts of source / reconstruction after duplicate removal.
+int ref_metrics( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const int16_t* recXyz, const uint8_t* recRgb,
+                 size_t m, const double* srcNormals, double resolution, double* out, int64_t* counts ) {
+  Quiet quiet;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );
+  PCCGroupOfFrames sources, recs, normals;
+  sources.setFrameCount( 1 );
+  recs.setFrameCount( 1 );
+  makeCloud( sources[0], srcXyz, srcRgb, n );
+  makeCloud( recs[0], recXyz, recRgb, m );
+  if ( srcNormals ) {
+    normals.setFrameCount( 1 );
+    makeCloud( normals[0], srcXyz, srcRgb, n );
+    normals[0].addNormals();
+    for ( size_t i = 0; i < n; ++i )
+      normals[0].setNormal( i, PCCNormal3D( srcNormals[3 * i], srcNormals[3 * i + 1], srcNormals[3 * i + 2] ) );
+  }
+  PCCMetricsParameters mp;
+  mp.resolution_ = size_t( resolution );
+  mp.computeC2p_ = srcNormals != nullptr;
+  PCCMetrics metrics;
+  metrics.setParameters( mp );
+  metrics.compute( sources, recs, normals );
+  QualityMetrics* q[3] = {&metrics.quality1_[0], &metrics.quality2_[0], &metrics.qualityF_[0]};
+  for ( int i = 0; i < 3; ++i ) {
+    out[8 * i + 0] = q[i]->c2cMse_;
+    out[8 * i + 1] = q[i]->c2cPsnr_;
+    out[8 * i + 2] = q[i]->c2pMse_;
+    out[8 * i + 3] = q[i]->c2pPsnr_;
+    out[8 * i + 4] = q[i]->colorMse_[0];
+    out[8 * i + 5] = q[i]->colorMse_[1];
+    out[8 * i + 6] = q[i]->colorMse_[2];
+    out[8 * i + 7] = q[i]->colorPsnr_[0];
+  }
+  counts[0] = int64_t( metrics.sourceDuplicates_[0] );
+  counts[1] = int64_t( metrics.reconstructDuplicates_[0] );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
+}
+
 // chroma planes of the geometry frames must stay zero (generateIntraImage :3932, dilate3DPadding on 3 channels)
 int ref_gof_geometry_chroma_nonzero( int frame ) {
   auto&  vg = g_gof->context.getVideoGeometryMultiple()[0];

@@ -212,6 +212,23 @@ class Oracle:
         return out
 
 
+    _metrics_fn = "orc_metrics"
+
+    def metrics(self, src_xyz, src_rgb, rec_xyz, rec_rgb, normals=None, resolution=1023.0):
+        """S23: returns (q[3][8], counts[2]); rows = A->B, B->A, symmetric; columns = c2cMse, c2cPsnr, c2pMse, c2pPsnr,
+        colorMse Y/U/V, colorPsnr Y."""
+        src_xyz, rec_xyz = _i16(src_xyz), _i16(rec_xyz)
+        src_rgb = np.ascontiguousarray(src_rgb, dtype=np.uint8)
+        rec_rgb = np.ascontiguousarray(rec_rgb, dtype=np.uint8)
+        nm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        out = np.zeros((3, 8), np.float64)
+        counts = np.zeros(2, np.int64)
+        rc = getattr(self.L, self._metrics_fn)(_p(src_xyz), _p(src_rgb), C.c_size_t(len(src_xyz)), _p(rec_xyz), _p(rec_rgb),
+                                               C.c_size_t(len(rec_xyz)), None if nm is None else _p(nm),
+                                               C.c_double(resolution), _p(out), _p(counts))
+        assert rc == 0, rc
+        return out, counts
+
     # S17-S22
     def generate_point_cloud(self, img):
         W, H = img["width"], img["height"]
@@ -256,6 +273,23 @@ class Oracle:
 class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
+
+    _metrics_fn = "ref_metrics"
+
+    def metrics(self, src_xyz, src_rgb, rec_xyz, rec_rgb, normals=None, resolution=1023.0):
+        """S23: returns (q[3][8], counts[2]); rows = A->B, B->A, symmetric; columns = c2cMse, c2cPsnr, c2pMse, c2pPsnr,
+        colorMse Y/U/V, colorPsnr Y."""
+        src_xyz, rec_xyz = _i16(src_xyz), _i16(rec_xyz)
+        src_rgb = np.ascontiguousarray(src_rgb, dtype=np.uint8)
+        rec_rgb = np.ascontiguousarray(rec_rgb, dtype=np.uint8)
+        nm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        out = np.zeros((3, 8), np.float64)
+        counts = np.zeros(2, np.int64)
+        rc = getattr(self.L, self._metrics_fn)(_p(src_xyz), _p(src_rgb), C.c_size_t(len(src_xyz)), _p(rec_xyz), _p(rec_rgb),
+                                               C.c_size_t(len(rec_xyz)), None if nm is None else _p(nm),
+                                               C.c_double(resolution), _p(out), _p(counts))
+        assert rc == 0, rc
+        return out, counts
 
     def phase_b(self, frames, phase_a_out, occ_precision=4):
         """Must follow phase_a() on the same GOF (state lives in the harness)."""
