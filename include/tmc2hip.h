@@ -184,6 +184,17 @@ int     tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo,
  * zero-copy hand-off to a collective (RCCL gather of finished frames) or to a device-side consumer       */
 int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry );
 
+/* ---- PCCMetrics ------------------------------------------------------------------------------------ */
+/* replaces: PCCMetrics::compute for one frame (PccLibMetrics/source/PCCMetrics.cpp:324-375) with the defaults of
+ * PCCMetricsParameters (dropDuplicates 2, neighborsProc 1, no Hausdorff): duplicate removal, normal copy / scaling,
+ * QualityMetrics::compute both ways (:73-229) and their symmetric combination (:289-322).
+ * srcNormals (double[n][3], the normals of the SOURCE cloud, e.g. from tmc2_frame_get_normals) may be NULL: no D2.
+ * out[3][8]: rows A->B, B->A, symmetric; columns c2cMse, c2cPsnr, c2pMse, c2pPsnr, colorMse Y,U,V, colorPsnr Y.
+ * counts[2]: points after duplicate removal (source, reconstruction).                                     */
+int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n, const int16_t* recXyz,
+                          const uint8_t* recRgb, uint64_t m, const double* srcNormals, double resolution, double* out,
+                          int64_t* counts );
+
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );

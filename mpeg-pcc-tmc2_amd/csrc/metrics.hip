@@ -1,0 +1,390 @@
+// metrics.hip -- D1 / D2 / colour distortion (S23) on gfx950.
+//
+// Replaces PCCMetrics::compute for one frame (reference: source/lib/PccLibMetrics/source/PCCMetrics.cpp:324-375),
+// QualityMetrics::compute (:73-229) and operator+ (:289-322), with PCCPointSet3::removeDuplicate
+// (PccLibCommon/source/PCCPointSet.cpp:169-220), copyNormals (:2282-2320) and scaleNormals (:2322-2380).
+//
+// Every neighbour query of the metric asks for "all points at the minimum distance" (k grows 5,10,..30 until the
+// k-th result is farther than the first).  That set is canonical as long as it has fewer than k members, and its
+// RESULT order (needed only where the reference sums fp64 normals in result order) is the k-d tree visiting order,
+// independent of k -- so one exact k=16 search per query serves all of them; a group that fills all 16 slots is
+// reported as unsupported instead of being approximated.
+// Device: the four query batches (exact nanoflann-order k-NN kernel), the per-recon-point ordered normal
+// accumulation, the per-point distortion terms.  Host: lexicographic de-duplication (a sort), the three tree builds,
+// and the final ORDERED fp64 sums over the points (the reference accumulates sequentially; D1 is a sum of
+// integers and order-free, D2 and colour are not).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <numeric>
+
+#include "internal.h"
+
+namespace tmc2 {
+namespace {
+
+constexpr int K = 16;
+
+struct HostCloud {
+  std::vector<int16_t> xyz;
+  std::vector<uint8_t> rgb;
+  std::vector<double>  nrm;
+  size_t               size() const { return xyz.size() / 3; }
+};
+
+HostCloud dedupLexicographic( const int16_t* xyz, const uint8_t* rgb, size_t n ) {
+  // key = x,y,z packed (coordinates < 2^15, non-negative); ties keep input order
+  std::vector<uint64_t> key( n );
+  for ( size_t i = 0; i < n; ++i )
+    key[i] = ( uint64_t( uint16_t( xyz[3 * i] ) ) << 48 ) | ( uint64_t( uint16_t( xyz[3 * i + 1] ) ) << 32 ) |
+             ( uint64_t( uint16_t( xyz[3 * i + 2] ) ) << 16 );
+  std::vector<uint32_t> order( n );
+  std::iota( order.begin(), order.end(), 0u );
+  std::stable_sort( order.begin(), order.end(), [&]( uint32_t a, uint32_t b ) { return key[a] < key[b]; } );
+  HostCloud c;
+  c.xyz.reserve( 3 * n );
+  c.rgb.reserve( 3 * n );
+  for ( size_t i = 0; i < n; ) {
+    size_t j = i + 1;
+    while ( j < n && key[order[j]] == key[order[i]] ) ++j;
+    for ( int d = 0; d < 3; ++d ) c.xyz.push_back( xyz[3 * size_t( order[i] ) + d] );
+    size_t s[3] = {0, 0, 0};
+    for ( size_t k = i; k < j; ++k )
+      for ( int d = 0; d < 3; ++d ) s[d] += rgb[3 * size_t( order[k] ) + d];
+    for ( int d = 0; d < 3; ++d ) c.rgb.push_back( uint8_t( s[d] / ( j - i ) ) );
+    i = j;
+  }
+  return c;
+}
+
+// a cloud + its tree on the device
+struct DevCloud {
+  size_t           n = 0;
+  KdTreeHost       tree;
+  DevBuf<Pt>       pts, ptsTree;
+  DevBuf<uint32_t> perm;
+  DevBuf<KdNode>   nodes;
+  DevBuf<uint8_t>  rgb4;
+  DevBuf<double>   nrm;
+  TreeDev          dev() const {
+    TreeDev t;
+    t.ptsTree = ptsTree.p, t.perm = perm.p, t.nodes = nodes.p;
+    for ( int d = 0; d < 3; ++d ) t.lo[d] = tree.lo[d], t.hi[d] = tree.hi[d];
+    t.depth = tree.depth, t.n = n;
+    return t;
+  }
+};
+
+int uploadCloud( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, const double* nrm, size_t n, bool withTree,
+                 DevCloud& dc ) {
+  hipStream_t s = ctx->stream;
+  dc.n          = n;
+  std::vector<Pt> pts( n );
+  for ( size_t i = 0; i < n; ++i ) pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
+  TMC2_TRY( dc.pts.alloc( n ) );
+  TMC2_HIP( hipMemcpyAsync( dc.pts.p, pts.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+  std::vector<Pt>      ptsTree;
+  std::vector<uint8_t> c4;
+  if ( withTree ) {
+    dc.tree.build( xyz, n );
+    ptsTree.resize( n );
+    for ( size_t i = 0; i < n; ++i ) ptsTree[i] = pts[dc.tree.perm[i]];
+    TMC2_TRY( dc.ptsTree.alloc( n ) );
+    TMC2_TRY( dc.perm.alloc( n ) );
+    TMC2_TRY( dc.nodes.alloc( dc.tree.nodes.size() ) );
+    TMC2_HIP( hipMemcpyAsync( dc.ptsTree.p, ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( dc.perm.p, dc.tree.perm.data(), n * 4, hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( dc.nodes.p, dc.tree.nodes.data(), dc.tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
+  }
+  if ( rgb ) {
+    c4.resize( 4 * n );
+    for ( size_t i = 0; i < n; ++i ) c4[4 * i] = rgb[3 * i], c4[4 * i + 1] = rgb[3 * i + 1], c4[4 * i + 2] = rgb[3 * i + 2], c4[4 * i + 3] = 0;
+    TMC2_TRY( dc.rgb4.alloc( 4 * n ) );
+    TMC2_HIP( hipMemcpyAsync( dc.rgb4.p, c4.data(), 4 * n, hipMemcpyHostToDevice, s ) );
+  }
+  if ( nrm ) {
+    TMC2_TRY( dc.nrm.alloc( 3 * n ) );
+    TMC2_HIP( hipMemcpyAsync( dc.nrm.p, nrm, 3 * n * sizeof( double ), hipMemcpyHostToDevice, s ) );
+  }
+  TMC2_HIP( hipStreamSynchronize( s ) );  // staging vectors go out of scope
+  return TMC2_OK;
+}
+
+// size of the minimum-distance group of one 16-NN row (leading entries equal to the first distance)
+__device__ __forceinline__ int groupSize( const uint32_t* dist ) {
+  int g = 1;
+  while ( g < K && dist[g] == dist[0] ) ++g;
+  return g;
+}
+
+// scaleNormals, pass 1: every source point votes for its nearest reconstructed points
+__global__ __launch_bounds__( 256 ) void votesCountKernel( const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+                                                            uint32_t n, uint32_t* __restrict__ count, uint32_t* __restrict__ error ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n ) return;
+  const int g = groupSize( dist + size_t( i ) * K );
+  if ( g == K ) *error = 1;
+  for ( int j = 0; j < g; ++j ) atomicAdd( &count[idx[size_t( i ) * K + j]], 1u );
+}
+__global__ __launch_bounds__( 256 ) void votesFillKernel( const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+                                                           uint32_t n, const uint32_t* __restrict__ offset,
+                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ voters ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n ) return;
+  const int g = groupSize( dist + size_t( i ) * K );
+  for ( int j = 0; j < g; ++j ) {
+    const uint32_t r             = idx[size_t( i ) * K + j];
+    voters[offset[r] + atomicAdd( &cursor[r], 1u )] = i;
+  }
+}
+// pass 2: per reconstructed point, add the voters' normals in increasing source index, divide by the count
+__global__ __launch_bounds__( 256 ) void votesReduceKernel( const uint32_t* __restrict__ count, const uint32_t* __restrict__ offset,
+                                                             const uint32_t* __restrict__ voters,
+                                                             const double* __restrict__ srcNormals, uint32_t m,
+                                                             double* __restrict__ recNormals ) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( r >= m ) return;
+  const uint32_t  c = count[r];
+  const uint32_t* v = voters + offset[r];
+  double          x = 0.0, y = 0.0, z = 0.0;
+  uint32_t        last = 0;
+  for ( uint32_t k = 0; k < c; ++k ) {
+    uint32_t best = 0xFFFFFFFFu;
+    for ( uint32_t j = 0; j < c; ++j )
+      if ( ( k == 0 || v[j] > last ) && v[j] < best ) best = v[j];
+    last = best;
+    x += srcNormals[3 * size_t( best )];
+    y += srcNormals[3 * size_t( best ) + 1];
+    z += srcNormals[3 * size_t( best ) + 2];
+  }
+  if ( c ) {
+    x = __ddiv_rn( x, double( c ) );
+    y = __ddiv_rn( y, double( c ) );
+    z = __ddiv_rn( z, double( c ) );
+  }
+  recNormals[3 * size_t( r )] = x, recNormals[3 * size_t( r ) + 1] = y, recNormals[3 * size_t( r ) + 2] = z;
+}
+// reconstructed points nobody voted for: mean normal of their own nearest source points, in RESULT order
+__global__ __launch_bounds__( 256 ) void orphanNormalsKernel( const uint32_t* __restrict__ orphan, uint32_t nOrphan,
+                                                               const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+                                                               const double* __restrict__ srcNormals,
+                                                               double* __restrict__ recNormals, uint32_t* __restrict__ error ) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( o >= nOrphan ) return;
+  const int g = groupSize( dist + size_t( o ) * K );
+  if ( g == K ) *error = 1;
+  double x = 0.0, y = 0.0, z = 0.0;
+  for ( int j = 0; j < g; ++j ) {
+    const size_t s = idx[size_t( o ) * K + j];
+    x += srcNormals[3 * s], y += srcNormals[3 * s + 1], z += srcNormals[3 * s + 2];
+  }
+  const size_t r = orphan[o];
+  recNormals[3 * r] = __ddiv_rn( x, double( g ) ), recNormals[3 * r + 1] = __ddiv_rn( y, double( g ) ),
+                 recNormals[3 * r + 2] = __ddiv_rn( z, double( g ) );
+}
+
+__device__ __forceinline__ void yuv709( const uchar4 c, float& y, float& u, float& v ) {
+  y = float( __ddiv_rn( 0.2126 * double( c.x ) + 0.7152 * double( c.y ) + 0.0722 * double( c.z ), 255.0 ) );
+  u = float( __ddiv_rn( -0.1146 * double( c.x ) - 0.3854 * double( c.y ) + 0.5000 * double( c.z ), 255.0 ) + 0.5000 );
+  v = float( __ddiv_rn( 0.5000 * double( c.x ) - 0.4542 * double( c.y ) - 0.0458 * double( c.z ), 255.0 ) + 0.5000 );
+}
+
+// per point of A: D1 term (min squared distance), D2 term, three colour terms against its nearest group in B
+__global__ __launch_bounds__( 256 ) void distortionTermsKernel( const Pt* __restrict__ ptsA, const uint8_t* __restrict__ rgbA,
+                                                                 const Pt* __restrict__ ptsB, const uint8_t* __restrict__ rgbB,
+                                                                 const double* __restrict__ nrmB,
+                                                                 const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+                                                                 uint32_t nA, double* __restrict__ terms /* [nA][5] */,
+                                                                 uint32_t* __restrict__ error ) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( a >= nA ) return;
+  const uint32_t* d = dist + size_t( a ) * K;
+  const int       g = groupSize( d );
+  if ( g == K ) *error = 1;
+  uint32_t same[K];
+  for ( int j = 0; j < g; ++j ) same[j] = idx[size_t( a ) * K + j];
+  for ( int j = 1; j < g; ++j ) {  // ascending index
+    const uint32_t v = same[j];
+    int            k = j - 1;
+    while ( k >= 0 && same[k] > v ) {
+      same[k + 1] = same[k];
+      --k;
+    }
+    same[k + 1] = v;
+  }
+  const Pt pa  = ptsA[a];
+  double   c2p = 0.0;
+  unsigned r = 0, gg = 0, b = 0;
+  for ( int j = 0; j < g; ++j ) {
+    const uint32_t ib = same[j];
+    if ( nrmB ) {
+      const Pt     pb = ptsB[ib];
+      const double e0 = double( int( pa.x ) - int( pb.x ) ), e1 = double( int( pa.y ) - int( pb.y ) ), e2 = double( int( pa.z ) - int( pb.z ) );
+      const double dp = e0 * nrmB[3 * size_t( ib )] + e1 * nrmB[3 * size_t( ib ) + 1] + e2 * nrmB[3 * size_t( ib ) + 2];
+      c2p += dp * dp;
+    }
+    const uchar4 cb = reinterpret_cast<const uchar4*>( rgbB )[ib];
+    r += cb.x, gg += cb.y, b += cb.z;
+  }
+  if ( nrmB ) c2p = __ddiv_rn( c2p, double( g ) );
+  const uchar4 avg = make_uchar4( (unsigned char)round( __ddiv_rn( double( r ), double( g ) ) ),
+                                  (unsigned char)round( __ddiv_rn( double( gg ), double( g ) ) ),
+                                  (unsigned char)round( __ddiv_rn( double( b ), double( g ) ) ), 0 );
+  float ya, ua, va, yb, ub, vb;
+  yuv709( reinterpret_cast<const uchar4*>( rgbA )[a], ya, ua, va );
+  yuv709( avg, yb, ub, vb );
+  const float dy = ya - yb, du = ua - ub, dv = va - vb;
+  double*     t  = terms + size_t( a ) * 5;
+  t[0]           = double( d[0] );
+  t[1]           = c2p;
+  t[2]           = double( float( dy * dy ) );
+  t[3]           = double( float( du * du ) );
+  t[4]           = double( float( dv * dv ) );
+}
+
+double psnr( double dist, double p, double factor ) { return 10 * std::log10( ( factor * p * p ) / dist ); }
+
+int quality( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, double resolution, double* out,
+             uint32_t* d_error ) {
+  hipStream_t      s = ctx->stream;
+  const uint32_t   nA = uint32_t( A.n );
+  DevBuf<uint32_t> d_idx, d_dist;
+  DevBuf<double>   d_terms;
+  TMC2_TRY( d_idx.alloc( size_t( nA ) * K ) );
+  TMC2_TRY( d_dist.alloc( size_t( nA ) * K ) );
+  TMC2_TRY( d_terms.alloc( size_t( nA ) * 5 ) );
+  TMC2_TRY( launchKnnTree( ctx, B.dev(), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
+  const int sid = ctx->stageBegin( "metrics_terms" );
+  hipLaunchKernelGGL( distortionTermsKernel, dim3( ( nA + 255 ) / 256 ), dim3( 256 ), 0, s, A.pts.p, A.rgb4.p, B.pts.p, B.rgb4.p,
+                      withNormals ? B.nrm.p : (const double*)nullptr, d_idx.p, d_dist.p, nA, d_terms.p, d_error );
+  ctx->stageEnd( sid );
+  std::vector<double> terms( size_t( nA ) * 5 );
+  TMC2_HIP( hipMemcpyAsync( terms.data(), d_terms.p, terms.size() * sizeof( double ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  double sse[5] = {0, 0, 0, 0, 0};
+  for ( size_t a = 0; a < nA; ++a )  // the reference's accumulation order
+    for ( int k = 0; k < 5; ++k ) sse[k] += terms[5 * a + k];
+  const double num = double( nA );
+  out[0]           = sse[0] / num;
+  out[1]           = psnr( out[0], resolution, 3 );
+  out[2]           = withNormals ? sse[1] / num : 0.0;
+  out[3]           = withNormals ? psnr( out[2], resolution, 3 ) : 0.0;
+  for ( int i = 0; i < 3; ++i ) out[4 + i] = sse[2 + i] / num;
+  out[7] = psnr( out[4], 1.0, 1.0 );
+  return TMC2_OK;
+}
+
+}  // namespace
+}  // namespace tmc2
+
+extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n,
+                                     const int16_t* recXyz, const uint8_t* recRgb, uint64_t m, const double* srcNormals,
+                                     double resolution, double* out, int64_t* counts ) {
+  using namespace tmc2;
+  if ( !ctx || !srcXyz || !srcRgb || !recXyz || !recRgb || !out || n == 0 || m == 0 ) {
+    setError( "metrics_compute: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  ApiScope    scope( ctx );
+  hipStream_t s  = ctx->stream;
+  const auto  t0 = std::chrono::steady_clock::now();
+  HostCloud   S = dedupLexicographic( srcXyz, srcRgb, n ), R = dedupLexicographic( recXyz, recRgb, m );
+  if ( counts ) counts[0] = int64_t( S.size() ), counts[1] = int64_t( R.size() );
+  const bool withNormals = srcNormals != nullptr;
+  if ( S.size() < size_t( K ) || R.size() < size_t( K ) ) {
+    setError( "metrics_compute: clouds smaller than %d points unsupported", K );
+    return TMC2_E_UNSUPPORTED;
+  }
+  if ( withNormals ) {
+    if ( S.size() != n ) {
+      setError( "metrics_compute: the source has duplicate positions; normals cannot be attached (the reference exits)" );
+      return TMC2_E_INVALID;
+    }
+    // copyNormals: the de-duplicated source is the lexicographic sort of the input
+    std::vector<uint64_t> key( n );
+    for ( size_t i = 0; i < n; ++i )
+      key[i] = ( uint64_t( uint16_t( srcXyz[3 * i] ) ) << 48 ) | ( uint64_t( uint16_t( srcXyz[3 * i + 1] ) ) << 32 ) |
+               ( uint64_t( uint16_t( srcXyz[3 * i + 2] ) ) << 16 );
+    std::vector<uint32_t> order( n );
+    std::iota( order.begin(), order.end(), 0u );
+    std::sort( order.begin(), order.end(), [&]( uint32_t a, uint32_t b ) { return key[a] < key[b]; } );
+    S.nrm.resize( 3 * n );
+    for ( size_t i = 0; i < n; ++i )
+      for ( int d = 0; d < 3; ++d ) S.nrm[3 * i + d] = srcNormals[3 * size_t( order[i] ) + d];
+  }
+  DevCloud dS, dR, dN;  // de-duplicated source, de-duplicated reconstruction, normal cloud (original source order)
+  TMC2_TRY( uploadCloud( ctx, S.xyz.data(), S.rgb.data(), withNormals ? S.nrm.data() : nullptr, S.size(), true, dS ) );
+  TMC2_TRY( uploadCloud( ctx, R.xyz.data(), R.rgb.data(), nullptr, R.size(), true, dR ) );
+  ctx->stageAddHostMs( "metrics_host_prepare", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
+  DevBuf<uint32_t> d_error;
+  TMC2_TRY( d_error.alloc( 1 ) );
+  TMC2_HIP( hipMemsetAsync( d_error.p, 0, 4, s ) );
+  const dim3 blk( 256 );
+  if ( withNormals ) {
+    // scaleNormals
+    const uint32_t mR = uint32_t( R.size() ), nS = uint32_t( n );
+    TMC2_TRY( uploadCloud( ctx, srcXyz, nullptr, srcNormals, n, false, dN ) );
+    DevBuf<uint32_t> d_idx, d_dist, d_count, d_offset, d_cursor, d_voters, d_total;
+    TMC2_TRY( d_idx.alloc( size_t( nS ) * K ) );
+    TMC2_TRY( d_dist.alloc( size_t( nS ) * K ) );
+    TMC2_TRY( d_count.alloc( mR ) );
+    TMC2_TRY( d_offset.alloc( mR ) );
+    TMC2_TRY( d_cursor.alloc( mR ) );
+    TMC2_TRY( d_total.alloc( 1 ) );
+    TMC2_TRY( dR.nrm.alloc( 3 * size_t( mR ) ) );
+    TMC2_TRY( launchKnnTree( ctx, dR.dev(), dN.pts.p, nS, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
+    TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( mR ) * 4, s ) );
+    TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( mR ) * 4, s ) );
+    hipLaunchKernelGGL( votesCountKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, nS, d_count.p, d_error.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, mR, d_total.p ) );
+    uint32_t total = 0;
+    TMC2_HIP( hipMemcpyAsync( &total, d_total.p, 4, hipMemcpyDeviceToHost, s ) );
+    std::vector<uint32_t> h_count( mR );
+    TMC2_HIP( hipMemcpyAsync( h_count.data(), d_count.p, size_t( mR ) * 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    TMC2_TRY( d_voters.alloc( std::max( total, 1u ) ) );
+    hipLaunchKernelGGL( votesFillKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, nS, d_offset.p, d_cursor.p,
+                        d_voters.p );
+    hipLaunchKernelGGL( votesReduceKernel, dim3( ( mR + 255 ) / 256 ), blk, 0, s, d_count.p, d_offset.p, d_voters.p, dN.nrm.p, mR,
+                        dR.nrm.p );
+    std::vector<uint32_t> orphans;
+    for ( uint32_t r = 0; r < mR; ++r )
+      if ( h_count[r] == 0 ) orphans.push_back( r );
+    if ( !orphans.empty() ) {
+      // these query the tree of the NORMAL cloud (original source order)
+      DevCloud dNT;
+      TMC2_TRY( uploadCloud( ctx, srcXyz, nullptr, nullptr, n, true, dNT ) );
+      const uint32_t   nO = uint32_t( orphans.size() );
+      std::vector<Pt>  q( nO );
+      for ( uint32_t o = 0; o < nO; ++o ) q[o] = Pt{R.xyz[3 * size_t( orphans[o] )], R.xyz[3 * size_t( orphans[o] ) + 1], R.xyz[3 * size_t( orphans[o] ) + 2], 0};
+      DevBuf<Pt>       d_q;
+      DevBuf<uint32_t> d_orph, d_oi, d_od;
+      TMC2_TRY( d_q.alloc( nO ) );
+      TMC2_TRY( d_orph.alloc( nO ) );
+      TMC2_TRY( d_oi.alloc( size_t( nO ) * K ) );
+      TMC2_TRY( d_od.alloc( size_t( nO ) * K ) );
+      TMC2_HIP( hipMemcpyAsync( d_q.p, q.data(), size_t( nO ) * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+      TMC2_HIP( hipMemcpyAsync( d_orph.p, orphans.data(), size_t( nO ) * 4, hipMemcpyHostToDevice, s ) );
+      TMC2_TRY( launchKnnTree( ctx, dNT.dev(), d_q.p, nO, K, d_oi.p, d_od.p, "metrics_knn16" ) );
+      hipLaunchKernelGGL( orphanNormalsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, d_orph.p, nO, d_oi.p, d_od.p, dN.nrm.p,
+                          dR.nrm.p, d_error.p );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+    }
+  }
+  TMC2_TRY( quality( ctx, dS, dR, withNormals, resolution, out, d_error.p ) );
+  TMC2_TRY( quality( ctx, dR, dS, withNormals, resolution, out + 8, d_error.p ) );
+  for ( int i = 0; i < 8; ++i ) {
+    const bool isPsnr = ( i == 1 || i == 3 || i == 7 );
+    out[16 + i]       = isPsnr ? std::min( out[i], out[8 + i] ) : std::max( out[i], out[8 + i] );
+  }
+  uint32_t err = 0;
+  TMC2_HIP( hipMemcpyAsync( &err, d_error.p, 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  TMC2_HIP( hipGetLastError() );
+  if ( err ) {
+    setError( "metrics_compute: a query has 16 or more equidistant nearest neighbours (the reference extends its search "
+              "to 30; not reproduced)" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  return TMC2_OK;
+}

@@ -135,6 +135,19 @@ class Context:
     def frame(self, xyz, rgb=None):
         return Frame(self, xyz, rgb)
 
+    # PCCMetrics::compute (one frame)
+    def metrics_compute(self, src_xyz, src_rgb, rec_xyz, rec_rgb, normals=None, resolution=1023.0):
+        a = np.ascontiguousarray(src_xyz, np.int16)
+        b = np.ascontiguousarray(src_rgb, np.uint8)
+        c = np.ascontiguousarray(rec_xyz, np.int16)
+        d = np.ascontiguousarray(rec_rgb, np.uint8)
+        nm = None if normals is None else np.ascontiguousarray(normals, np.float64)
+        out = np.zeros((3, 8), np.float64)
+        counts = np.zeros(2, np.int64)
+        _check(self.L.tmc2_metrics_compute(self.h, _ptr(a), _ptr(b), C.c_uint64(len(a)), _ptr(c), _ptr(d), C.c_uint64(len(c)),
+                                           None if nm is None else _ptr(nm), C.c_double(resolution), _ptr(out), _ptr(counts)))
+        return out, counts
+
 
 class Frame:
     """Device-resident state of one point-cloud frame (tmc2_frame)."""
