@@ -183,6 +183,7 @@ int     tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo,
 /* device addresses of the frame's canvases (valid until the next generate call / frame destroy), for
  * zero-copy hand-off to a collective (RCCL gather of finished frames) or to a device-side consumer       */
 int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry );
+int tmc2_frame_device_attribute( tmc2_frame* f, void** attribute );
 
 /* ---- PCCMetrics ------------------------------------------------------------------------------------ */
 /* replaces: PCCMetrics::compute for one frame (PccLibMetrics/source/PCCMetrics.cpp:324-375) with the defaults of

@@ -525,6 +525,12 @@ int tmc2_frame_get_reconstruction( tmc2_frame* f, int16_t* xyz, uint8_t* rgb, ui
   return TMC2_OK;
 }
 
+int tmc2_frame_device_attribute( tmc2_frame* f, void** attribute ) {
+  if ( !f || !attribute || !f->haveAttributeImages ) return TMC2_E_STATE;
+  *attribute = f->d_attr.p;
+  return TMC2_OK;
+}
+
 int tmc2_frame_get_attribute_images( tmc2_frame* f, uint8_t* attribute ) {
   if ( !f || !attribute || !f->haveAttributeImages ) {
     tmc2::setError( "get_attribute_images: not generated" );

@@ -48,9 +48,10 @@ class Sharder:
         if self.world == 1:
             return [tensor]
         import torch
-        out = [torch.empty_like(tensor) for _ in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(tensor, out, dst=0)
-        return out
+        raw = tensor.contiguous().view(torch.uint8)          # transport as bytes: collectives lack 16-bit integer types
+        out = [torch.empty_like(raw) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(raw, out, dst=0)
+        return [o.view(tensor.dtype).view(tensor.shape) for o in out] if out is not None else None
 
     def barrier(self):
         if self.world > 1:
@@ -63,7 +64,7 @@ class _DevArray:
 
 
 class GofEncoder:
-    """Phase A (S0-S16) of a GOF on one GPU with `workers` concurrent frames."""
+    """Phase A (S0-S16) and phase B (S17-S22) of a GOF on one GPU with `workers` concurrent frames."""
 
     def __init__(self, device=0, workers=4, iterations=50, bits3d=11, occ_precision=4, min_w=1280, min_h=1280,
                  timing=True):
@@ -106,6 +107,10 @@ class GofEncoder:
         W, H = lib.encoder_canvas_size([gof_h], self.min_w, self.min_w, self.min_h)
         self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
         return W, H
+
+    def phase_b(self, frames):
+        """S17-S22 on the resident (decoded == generated) occupancy / geometry canvases."""
+        self._per_worker(frames, lambda fr: fr.encoder_generate_attribute_images())
 
     def stage_ms(self):
         tot = {}

@@ -185,8 +185,12 @@ class Frame:
         W, H, p = self._canvas
         ptrs = [C.c_void_p() for _ in range(4)]
         _check(self.L.tmc2_frame_device_images(self.h, *[C.byref(x) for x in ptrs]))
-        return dict(occupancy=(ptrs[0].value, (H, W), "|u1"), occ_video=(ptrs[1].value, (H // p, W // p), "|u1"),
-                    block_to_patch=(ptrs[2].value, (H // 16, W // 16), "<u4"), geometry=(ptrs[3].value, (2, H, W), "<u2"))
+        out = dict(occupancy=(ptrs[0].value, (H, W), "|u1"), occ_video=(ptrs[1].value, (H // p, W // p), "|u1"),
+                   block_to_patch=(ptrs[2].value, (H // 16, W // 16), "<u4"), geometry=(ptrs[3].value, (2, H, W), "<u2"))
+        a = C.c_void_p()
+        if self.L.tmc2_frame_device_attribute(self.h, C.byref(a)) == 0:
+            out["attribute"] = (a.value, (2, 3, H, W), "|u1")
+        return out
 
     # PCCKdTree::search
     def kdtree_search(self, queries, k, with_dist=False):

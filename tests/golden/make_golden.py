@@ -47,5 +47,31 @@ def main():
         print(name, len(xyz), {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
 
 
+def gof():
+    """Whole path S0-S23 on a 2-frame GOF through the reference's own PCCEncoder / PCCMetrics members."""
+    ref = ob.Reference()
+    frames = [synth_cloud("tiny", f) for f in range(2)]
+    a = ref.phase_a(frames, 10, 11, 4)
+    b = ref.phase_b(frames, a, 4)
+    out = {"input_md5": np.array("".join(digest(x) + digest(c) for x, c in frames)),
+           "canvas": np.array([a[0]["width"], a[0]["height"]])}
+    for i, (pa, pb) in enumerate(zip(a, b)):
+        p = pa["patches"]
+        out["f%d_patches" % i] = np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        out["f%d_block_to_patch" % i] = pa["block_to_patch"].astype(np.uint16)
+        out["f%d_occ_video" % i] = np.packbits(pa["occ_video"])
+        for k in ("occupancy", "geo0", "geo1"):
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pa[k]))
+        for k in ("recon_xyz", "recon_rgb", "point_to_pixel", "attribute"):
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pb[k]))
+        nrm = ref.normals(frames[i][0], 16, oriented=True)
+        q, counts = ref.metrics(frames[i][0], frames[i][1], pb["recon_xyz"], pb["recon_rgb"], nrm)
+        out["f%d_metrics" % i] = q
+        out["f%d_metric_counts" % i] = counts
+    np.savez_compressed(os.path.join(HERE, "gof_tiny2.npz"), **out)
+    print("gof_tiny2", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
+    gof()

@@ -117,3 +117,27 @@ def test_gpu_phase_b_decoded_geometry_roundtrip(gpu_ctx, oracle):
     exp = oracle.phase_b([(xyz, rgb)], [ea], 4)[0]
     for k in ("recon_xyz", "point_to_pixel", "recon_rgb", "attribute"):
         assert np.array_equal(got[k], exp[k]), k
+
+
+def test_gpu_gof_matches_golden_fixture(gpu_ctx):
+    """Whole path S0-S23 against the fixture generated from the unmodified reference (no oracle involved)."""
+    from test_oracle_golden import _gof_fixture, check_gof_against_fixture
+    g, frames = _gof_fixture()
+    frs = [gpu_ctx.frame(xyz, rgb) for xyz, rgb in frames]
+    w = frs[0].weight_normal(11, 0.6)
+    p = T.ctc_params(10, 11, w)
+    heights = []
+    for fr in frs:
+        fr.segmenter_compute(p)
+        heights.append(fr.encoder_pack_flexible(1280, 2, 1.0))
+    W, H = T.encoder_canvas_size(heights, 1280, 1280, 1280)
+    a = []
+    for fr in frs:
+        fr.encoder_generate_geometry_images(W, H, 4)
+        img = fr.get_geometry_images()
+        img.update(patches=fr.get_patches()[0][fr.get_patch_order()], width=W, height=H)
+        a.append(img)
+    b = gpu_phase_b(frs)
+    normals = {id(fr._xyz): fr for fr in frs}
+    check_gof_against_fixture(g, frames, a, b, gpu_ctx.metrics_compute,
+                              lambda xyz: next(fr for fr in frs if fr._xyz is xyz or np.array_equal(fr._xyz, xyz)).get_normals())

@@ -68,3 +68,50 @@ def test_oracle_matches_reference_live(oracle, reference):
     # disconnected components exercise the orientation's re-seeding path
     two = np.concatenate([xyz[:3000], xyz[:3000] + np.array([300, 0, 0], np.int16)])
     assert np.array_equal(bits(oracle.normals(two, 16)), bits(reference.normals(two, 16)))
+
+
+def _gof_fixture():
+    g = np.load(os.path.join(GOLD, "gof_tiny2.npz"))
+    frames = [synth_cloud("tiny", f) for f in range(2)]
+    assert str(g["input_md5"]) == "".join(digest(x) + digest(c) for x, c in frames)
+    return g, frames
+
+
+def check_gof_against_fixture(g, frames, a, b, metrics_fn, normals_fn):
+    """Shared by the CPU (oracle) and GPU tiers: phase A/B outputs and the metric against the reference's fixture."""
+    assert [a[0]["width"], a[0]["height"]] == g["canvas"].tolist()
+    for i, (pa, pb) in enumerate(zip(a, b)):
+        p = pa["patches"]
+        mat = np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        assert np.array_equal(mat, g["f%d_patches" % i])
+        assert np.array_equal(pa["block_to_patch"].astype(np.uint16), g["f%d_block_to_patch" % i])
+        assert np.array_equal(np.packbits(pa["occ_video"]), g["f%d_occ_video" % i])
+        for k in ("occupancy", "geo0", "geo1"):
+            assert digest(pa[k]) == str(g["f%d_%s_md5" % (i, k)]), k
+        for k in ("recon_xyz", "recon_rgb", "point_to_pixel", "attribute"):
+            assert digest(pb[k]) == str(g["f%d_%s_md5" % (i, k)]), k
+        q, counts = metrics_fn(frames[i][0], frames[i][1], pb["recon_xyz"], pb["recon_rgb"], normals_fn(frames[i][0]))
+        assert np.array_equal(counts, g["f%d_metric_counts" % i])
+        assert np.array_equal(bits(q), bits(g["f%d_metrics" % i]))      # D1/D2/colour MSE + PSNR doubles, bit-equal
+
+
+def test_oracle_gof_matches_golden(oracle):
+    g, frames = _gof_fixture()
+    a = oracle.phase_a(frames, 10, 11, 4)
+    b = oracle.phase_b(frames, a, 4)
+    check_gof_against_fixture(g, frames, a, b, oracle.metrics, lambda xyz: oracle.normals(xyz, 16, True))
+
+
+def test_oracle_gof_matches_reference_live(oracle, reference):
+    """A different GOF than the fixture (3 frames, occupancy precision 2), where the compiled reference is present."""
+    frames = [synth_cloud("small", f + 5) for f in range(3)]
+    ra = reference.phase_a(frames, 10, 11, 2)
+    rb = reference.phase_b(frames, ra, 2)
+    oa = oracle.phase_a(frames, 10, 11, 2)
+    obb = oracle.phase_b(frames, oa, 2)
+    for x, y in zip(ra, oa):
+        for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(rb, obb):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k

@@ -1,0 +1,70 @@
+"""CPU tier: the multi-GPU sharding logic (frame -> rank, axis-weight broadcast, canvas-height all-reduce, gather of the
+finished canvases to rank 0) under torch.distributed with the gloo backend, world_size 2.  The per-frame compute is
+faked (this tier has no GPU); what is covered is exactly the code bench.py runs between the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tmc2_amd.gof import Sharder
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, frame_count, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = Sharder(rank, world, dist, "cpu")
+    mine = sh.frames_of(frame_count)
+    w = sh.broadcast_weight([0.75, 0.6, 1.0] if rank == 0 else [0.0, 0.0, 0.0])
+    gof_h = sh.max_height([1280 + 16 * f for f in mine])               # frame f "packs" to height 1280 + 16 f
+    canv = torch.stack([torch.full((2, 4, 4), f, dtype=torch.int16) for f in mine])   # fake canvases, value = frame id
+    got = sh.gather(canv)
+    sh.barrier()
+    if rank == 0:
+        order = [f for r in range(world) for f in sh.frames_of(frame_count, r)]
+        q.put((mine, w.tolist(), gof_h, [int(t[i, 0, 0, 0]) for t in got for i in range(t.shape[0])], order))
+    else:
+        q.put((mine, w.tolist(), gof_h, None, None))
+    dist.destroy_process_group()
+
+
+def test_sharder_world2_gloo():
+    world, frames = 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    covered = sorted(f for r in res for f in r[0])
+    assert covered == list(range(frames))                               # every frame on exactly one rank
+    for mine, w, h, gathered, order in res:
+        assert w == [0.75, 0.6, 1.0]                                    # rank 0's weights everywhere
+        assert h == 1280 + 16 * (frames - 1)                            # max over ALL frames, not just the local ones
+        if gathered is not None:
+            assert gathered == order and sorted(gathered) == list(range(frames))
+
+
+def test_sharder_single_process_is_identity():
+    sh = Sharder()
+    assert sh.frames_of(5) == [0, 1, 2, 3, 4]
+    assert sh.max_height([3, 9, 4]) == 9
+    assert np.array_equal(sh.broadcast_weight([1, 2, 3]), np.array([1.0, 2.0, 3.0]))
+    t = torch.zeros(3)
+    assert sh.gather(t)[0] is t
