@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--workers", type=int, default=0, help="concurrent frames per GPU (0 = auto)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
+    ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
+                    "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
     return ap.parse_args()
 
 
@@ -45,9 +47,9 @@ def _gen(arg):
     return synth_cloud(arg[0], arg[1])
 
 
-def make_frames(workload, indices):
+def make_frames(workload, indices, gen_procs=0):
     import multiprocessing as mp
-    procs = max(1, min(len(indices), (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 16))
+    procs = gen_procs or max(1, min(len(indices), (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 16))
     if procs == 1 or len(indices) < 2:
         return [_gen((workload, i)) for i in indices]
     with mp.get_context("fork").Pool(procs) as pool:
@@ -96,7 +98,7 @@ def main():
     import numpy as np
     import tmc2_amd as T
     my_indices = list(range(rank, a.frames, world))
-    clouds = make_frames(a.workload, my_indices)         # before any GPU context exists (fork-safe)
+    clouds = make_frames(a.workload, my_indices, a.gen_procs)         # before any GPU context exists (fork-safe)
     import torch
     dist = None
     if world > 1:

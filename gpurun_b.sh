@@ -1,3 +1,2 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python bench.py --steps 2 --warmup 1 --cpu-baseline 0 2>&1 | tail -1
-python bench.py --steps 2 --warmup 1 --cpu-baseline 0 --workers 1 --frames 4 2>&1 | tail -1
+timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 600 python bench.py --steps 2 --warmup 1 2>&1 | tail -1 | tee gpurun_out/bench_r01_b.json

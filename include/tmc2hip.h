@@ -172,6 +172,10 @@ int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t* 
  * Works on the frame's resident occupancy / geometry canvases (decoded == generated when the codec is lossless;
  * upload decoded planes with tmc2_frame_set_decoded_geometry first when it is not).                         */
 int     tmc2_encoder_generate_attribute_images( tmc2_frame* f );
+/* replaces: PCCPointSet3::transferColors (PccLibCommon/source/PCCPointSet.cpp:807-1124) alone, on two host clouds, with the
+ * arguments PCCEncoder::generateAttributeVideo passes under the CTC (PCCEncoder.cpp:6679-6697); tgtRgb = uint8[m][3]      */
+int     tmc2_transfer_colors( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n, const int16_t* tgtXyz,
+                              uint64_t m, uint8_t* tgtRgb );
 int64_t tmc2_frame_recon_count( tmc2_frame* f );
 /* reconstruction: xyz int16[M][3], rgb uint8[M][3], pointToPixel uint32[M][3] = (x, y, layer); any may be NULL */
 int     tmc2_frame_get_reconstruction( tmc2_frame* f, int16_t* xyz, uint8_t* rgb, uint32_t* pointToPixel );

@@ -148,51 +148,146 @@ __global__ __launch_bounds__( 256 ) void backwardFillKernel( const uint32_t* __r
   entries[offset[t] + slot] = make_uint2( dist1[s], s );
 }
 
+// The reference orders a target's backward candidates with std::sort( ..., dist < dist ): libstdc++'s introsort
+// (median-of-3 quicksort down to 16-element runs, then one insertion sort).  It is not stable, so for equal
+// distances the outcome depends on the algorithm's exact moves -- reproduced here move for move on the list that
+// is first brought into source-index order (the order in which the reference appended the candidates).
+struct CandSort {
+  uint2* a;
+  __device__ bool less( int i, int j ) const { return a[i].x < a[j].x; }
+  __device__ void swap( int i, int j ) const {
+    const uint2 t = a[i];
+    a[i]          = a[j];
+    a[j]          = t;
+  }
+  __device__ void unguardedLinearInsert( int last ) const {
+    const uint2 val  = a[last];
+    int         next = last - 1;
+    while ( val.x < a[next].x ) {
+      a[last] = a[next];
+      last    = next;
+      --next;
+    }
+    a[last] = val;
+  }
+  __device__ void insertionSort( int first, int last ) const {
+    for ( int i = first + 1; i < last; ++i ) {
+      if ( a[i].x < a[first].x ) {
+        const uint2 val = a[i];
+        for ( int k = i; k > first; --k ) a[k] = a[k - 1];
+        a[first] = val;
+      } else {
+        unguardedLinearInsert( i );
+      }
+    }
+  }
+  __device__ void moveMedianToFirst( int result, int x, int y, int z ) const {
+    if ( less( x, y ) ) {
+      if ( less( y, z ) )
+        swap( result, y );
+      else if ( less( x, z ) )
+        swap( result, z );
+      else
+        swap( result, x );
+    } else if ( less( x, z ) )
+      swap( result, x );
+    else if ( less( y, z ) )
+      swap( result, z );
+    else
+      swap( result, y );
+  }
+  __device__ int unguardedPartition( int first, int last, int pivot ) const {
+    for ( ;; ) {
+      while ( less( first, pivot ) ) ++first;
+      --last;
+      while ( less( pivot, last ) ) --last;
+      if ( !( first < last ) ) return first;
+      swap( first, last );
+      ++first;
+    }
+  }
+  // returns false if the depth limit was reached (libstdc++ would switch to heapsort; not reproduced)
+  __device__ bool sort( int n ) const {
+    if ( n < 2 ) return true;
+    int lg = 0;
+    while ( ( n >> ( lg + 1 ) ) > 0 ) ++lg;
+    // __introsort_loop: recursion on the right part, iteration on the left -> explicit stack of right parts
+    int  stackFirst[64], stackLast[64], stackDepth[64], sp = 0;
+    int  first = 0, last = n, depth = 2 * lg;
+    bool ok = true;
+    for ( ;; ) {
+      while ( last - first > 16 ) {
+        if ( depth == 0 ) {
+          ok = false;
+          break;
+        }
+        --depth;
+        const int mid = first + ( last - first ) / 2;
+        moveMedianToFirst( first, first + 1, mid, last - 1 );
+        const int cut = unguardedPartition( first + 1, last, first );
+        // the reference recurses into [cut,last) FIRST and then continues with [first,cut); the two ranges are
+        // disjoint, so the order in which they are processed does not change the result
+        if ( sp < 64 ) {
+          stackFirst[sp] = cut, stackLast[sp] = last, stackDepth[sp] = depth;
+          ++sp;
+        } else {
+          ok = false;
+        }
+        last = cut;
+      }
+      if ( sp == 0 ) break;
+      --sp;
+      first = stackFirst[sp], last = stackLast[sp], depth = stackDepth[sp];
+    }
+    // __final_insertion_sort
+    if ( n > 16 ) {
+      insertionSort( 0, 16 );
+      for ( int i = 16; i < n; ++i ) unguardedLinearInsert( i );
+    } else {
+      insertionSort( 0, n );
+    }
+    return ok;
+  }
+};
+
 __global__ __launch_bounds__( 256 ) void combineColorKernel( const uint32_t* __restrict__ count, const uint32_t* __restrict__ offset,
-                                                              const uint2* __restrict__ entries,
-                                                              const uint8_t* __restrict__ srcRgb4,
+                                                              uint2* __restrict__ entries, const uint8_t* __restrict__ srcRgb4,
                                                               const uint8_t* __restrict__ fwdRgb4, uint32_t m,
                                                               uint8_t* __restrict__ outRgb4, uint32_t* __restrict__ error ) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if ( t >= m ) return;
-  const uint32_t n = count[t];
+  const int n = int( count[t] );
   if ( n == 0 ) {
     reinterpret_cast<uchar4*>( outRgb4 )[t] = reinterpret_cast<const uchar4*>( fwdRgb4 )[t];
     return;
   }
-  if ( n > 16 ) {  // the reference's std::sort is only stable (insertion sort) up to 16 candidates
-    *error = 1;
-    return;
-  }
-  // consume the candidates in (distance, source index) order: repeated selection of the next key, n <= 16
-  const uint2* e = entries + offset[t];
-  double       r = 0.0, g = 0.0, b = 0.0, sw = 0.0;
-  uint64_t     last  = 0;
-  bool         exact = false;  // first candidate is an identical point, or the only one: its colour, unweighted
-  for ( uint32_t k = 0; k < n; ++k ) {
-    uint64_t best = ~0ull;
-    for ( uint32_t j = 0; j < n; ++j ) {
-      const uint2    c   = e[j];
-      const uint64_t key = ( uint64_t( c.x ) << 32 ) | c.y;
-      if ( ( k == 0 || key > last ) && key < best ) best = key;
+  uint2* e = entries + offset[t];
+  // (a) source-index order (keys unique): plain insertion sort
+  for ( int i = 1; i < n; ++i ) {
+    const uint2 v = e[i];
+    int         k = i - 1;
+    while ( k >= 0 && e[k].y > v.y ) {
+      e[k + 1] = e[k];
+      --k;
     }
-    last                 = best;
-    const uint32_t dist2 = uint32_t( best >> 32 ), src = uint32_t( best );
-    const uchar4   c     = reinterpret_cast<const uchar4*>( srcRgb4 )[src];
-    if ( k == 0 && ( dist2 == 0 || n == 1 ) ) {
-      r     = double( c.x );
-      g     = double( c.y );
-      b     = double( c.z );
-      exact = true;
-      break;
-    }
-    const double w = __ddiv_rn( 1.0, __dsqrt_rn( double( dist2 ) ) + 4.0 );
-    r += double( c.x ) * w;
-    g += double( c.y ) * w;
-    b += double( c.z ) * w;
-    sw += w;
+    e[k + 1] = v;
   }
-  if ( !exact ) {
+  // (b) std::sort by distance
+  const CandSort cs{e};
+  if ( !cs.sort( n ) ) *error = 1;
+  double r = 0.0, g = 0.0, b = 0.0, sw = 0.0;
+  if ( e[0].x == 0 || n == 1 ) {  // an identical source point, or a single candidate: its colour, unweighted
+    const uchar4 c = reinterpret_cast<const uchar4*>( srcRgb4 )[e[0].y];
+    r = double( c.x ), g = double( c.y ), b = double( c.z );
+  } else {
+    for ( int k = 0; k < n; ++k ) {
+      const uchar4 c = reinterpret_cast<const uchar4*>( srcRgb4 )[e[k].y];
+      const double w = __ddiv_rn( 1.0, __dsqrt_rn( double( e[k].x ) ) + 4.0 );
+      r += double( c.x ) * w;
+      g += double( c.y ) * w;
+      b += double( c.z ) * w;
+      sw += w;
+    }
     r = __ddiv_rn( r, sw );
     g = __ddiv_rn( g, sw );
     b = __ddiv_rn( b, sw );
@@ -308,6 +403,41 @@ __global__ __launch_bounds__( 256 ) void attributeGroupDilateKernel( const uint8
 
 }  // namespace
 
+// S18 on device-resident clouds: source (tree + original-order points + colours) -> target (tree + points)
+int transferColorsDevice( tmc2_ctx* ctx, const TreeDev& srcTree, const Pt* d_srcPts, const uint8_t* d_srcRgb4, uint32_t n,
+                          const TreeDev& tgtTree, const Pt* d_tgtPts, uint32_t M, uint8_t* d_outRgb4, uint32_t* d_error ) {
+  hipStream_t      s = ctx->stream;
+  const dim3       blk( 256 );
+  DevBuf<uint32_t> d_idx8, d_dist8, d_idx1, d_dist1, d_count, d_offset, d_cursor;
+  DevBuf<uint2>    d_entries;
+  DevBuf<uint8_t>  d_fwd;
+  TMC2_TRY( d_idx8.alloc( size_t( M ) * 8 ) );
+  TMC2_TRY( d_dist8.alloc( size_t( M ) * 8 ) );
+  TMC2_TRY( d_idx1.alloc( n ) );
+  TMC2_TRY( d_dist1.alloc( n ) );
+  TMC2_TRY( d_count.alloc( M ) );
+  TMC2_TRY( d_offset.alloc( M ) );
+  TMC2_TRY( d_cursor.alloc( M ) );
+  TMC2_TRY( d_entries.alloc( n ) );
+  TMC2_TRY( d_fwd.alloc( size_t( M ) * 4 ) );
+  TMC2_TRY( launchKnnTree( ctx, srcTree, d_tgtPts, M, 8, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
+  TMC2_TRY( launchKnnTree( ctx, tgtTree, d_srcPts, n, 1, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
+  const int sid = ctx->stageBegin( "transfer_colors" );
+  TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( M ) * 4, s ) );
+  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( M ) * 4, s ) );
+  TMC2_HIP( hipMemsetAsync( d_error, 0, 4, s ) );
+  const dim3 grdM( ( M + 255 ) / 256 ), grdN( ( n + 255 ) / 256 );
+  hipLaunchKernelGGL( forwardColorKernel, grdM, blk, 0, s, d_idx8.p, d_dist8.p, d_srcRgb4, M, d_fwd.p );
+  hipLaunchKernelGGL( backwardCountKernel, grdN, blk, 0, s, d_idx1.p, n, d_count.p );
+  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, M, nullptr ) );
+  hipLaunchKernelGGL( backwardFillKernel, grdN, blk, 0, s, d_idx1.p, d_dist1.p, d_offset.p, n, d_cursor.p, d_entries.p );
+  hipLaunchKernelGGL( combineColorKernel, grdM, blk, 0, s, d_count.p, d_offset.p, d_entries.p, d_srcRgb4, d_fwd.p, M,
+                      d_outRgb4, d_error );
+  ctx->stageEnd( sid );
+  TMC2_HIP( hipGetLastError() );
+  return TMC2_OK;
+}
+
 int generateAttributeImages( tmc2_frame* f ) {
   if ( !f->haveGeometryImages ) {
     setError( "generateAttributeImages: geometry images missing" );
@@ -381,33 +511,10 @@ int generateAttributeImages( tmc2_frame* f ) {
   rt.depth = f->reconTree.depth;
   rt.n     = M;
   // ---- S18 ----------------------------------------------------------------------------------------------
-  DevBuf<uint32_t> d_idx8, d_dist8, d_idx1, d_dist1, d_count, d_offset, d_cursor;
-  DevBuf<uint2>    d_entries;
-  DevBuf<uint8_t>  d_fwd;
-  TMC2_TRY( d_idx8.alloc( size_t( M ) * 8 ) );
-  TMC2_TRY( d_dist8.alloc( size_t( M ) * 8 ) );
-  TMC2_TRY( d_idx1.alloc( n ) );
-  TMC2_TRY( d_dist1.alloc( n ) );
-  TMC2_TRY( d_count.alloc( M ) );
-  TMC2_TRY( d_offset.alloc( M ) );
-  TMC2_TRY( d_cursor.alloc( M ) );
-  TMC2_TRY( d_entries.alloc( n ) );
-  TMC2_TRY( d_fwd.alloc( size_t( M ) * 4 ) );
   TMC2_TRY( f->d_reconRgb.alloc( size_t( M ) * 4 ) );
-  TMC2_TRY( launchKnnTree( ctx, frameTree( f ), f->d_recon.p, M, 8, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
-  TMC2_TRY( launchKnnTree( ctx, rt, f->d_pts.p, n, 1, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
-  sid = ctx->stageBegin( "transfer_colors" );
-  TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( M ) * 4, s ) );
-  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( M ) * 4, s ) );
-  TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 4, s ) );
-  const dim3 grdM( ( M + 255 ) / 256 ), grdN( ( n + 255 ) / 256 );
-  hipLaunchKernelGGL( forwardColorKernel, grdM, blk, 0, s, d_idx8.p, d_dist8.p, f->d_rgb.p, M, d_fwd.p );
-  hipLaunchKernelGGL( backwardCountKernel, grdN, blk, 0, s, d_idx1.p, n, d_count.p );
-  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, M, nullptr ) );
-  hipLaunchKernelGGL( backwardFillKernel, grdN, blk, 0, s, d_idx1.p, d_dist1.p, d_offset.p, n, d_cursor.p, d_entries.p );
-  hipLaunchKernelGGL( combineColorKernel, grdM, blk, 0, s, d_count.p, d_offset.p, d_entries.p, f->d_rgb.p, d_fwd.p, M,
-                      f->d_reconRgb.p, d_small.p + 1 );
-  ctx->stageEnd( sid );
+  const dim3 grdM( ( M + 255 ) / 256 );
+  TMC2_TRY( transferColorsDevice( ctx, frameTree( f ), f->d_pts.p, f->d_rgb.p, n, rt, f->d_recon.p, M, f->d_reconRgb.p,
+                                  d_small.p + 1 ) );
   // ---- S20 ----------------------------------------------------------------------------------------------
   sid = ctx->stageBegin( "attribute_images" );
   DevBuf<uint8_t> d_occ;
@@ -481,8 +588,8 @@ int generateAttributeImages( tmc2_frame* f ) {
   TMC2_HIP( hipStreamSynchronize( s ) );
   TMC2_HIP( hipGetLastError() );
   if ( err ) {
-    setError( "transferColors: a reconstructed point collected more than 16 backward candidates (the reference's "
-              "std::sort order for such lists is not reproduced)" );
+    setError( "transferColors: a backward candidate list hit std::sort's depth limit (heapsort fallback of libstdc++ "
+              "introsort is not reproduced)" );
     return TMC2_E_UNSUPPORTED;
   }
   f->haveAttributeImages = true;
@@ -492,6 +599,66 @@ int generateAttributeImages( tmc2_frame* f ) {
 }  // namespace tmc2
 
 extern "C" {
+
+// replaces PCCPointSet3::transferColors on two host clouds (CTC settings); rgb out = uint8[m][3]
+int tmc2_transfer_colors( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n, const int16_t* tgtXyz,
+                          uint64_t m, uint8_t* tgtRgb ) {
+  using namespace tmc2;
+  if ( !ctx || !srcXyz || !srcRgb || !tgtXyz || !tgtRgb || n < 8 || m < 1 ) {
+    setError( "transfer_colors: invalid argument (the source needs at least 8 points)" );
+    return TMC2_E_INVALID;
+  }
+  ApiScope    scope( ctx );
+  hipStream_t s = ctx->stream;
+  struct Side {
+    KdTreeHost       tree;
+    DevBuf<Pt>       pts, ptsTree;
+    DevBuf<uint32_t> perm;
+    DevBuf<KdNode>   nodes;
+    TreeDev          dev;
+  } S, T;
+  auto upload = [&]( Side& sd, const int16_t* xyz, uint64_t cnt ) -> int {
+    std::vector<Pt> pts( cnt ), ptsTree( cnt );
+    for ( uint64_t i = 0; i < cnt; ++i ) pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
+    sd.tree.build( xyz, cnt );
+    for ( uint64_t i = 0; i < cnt; ++i ) ptsTree[i] = pts[sd.tree.perm[i]];
+    TMC2_TRY( sd.pts.alloc( cnt ) );
+    TMC2_TRY( sd.ptsTree.alloc( cnt ) );
+    TMC2_TRY( sd.perm.alloc( cnt ) );
+    TMC2_TRY( sd.nodes.alloc( sd.tree.nodes.size() ) );
+    TMC2_HIP( hipMemcpyAsync( sd.pts.p, pts.data(), cnt * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( sd.ptsTree.p, ptsTree.data(), cnt * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( sd.perm.p, sd.tree.perm.data(), cnt * 4, hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( sd.nodes.p, sd.tree.nodes.data(), sd.tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    sd.dev.ptsTree = sd.ptsTree.p, sd.dev.perm = sd.perm.p, sd.dev.nodes = sd.nodes.p;
+    for ( int d = 0; d < 3; ++d ) sd.dev.lo[d] = sd.tree.lo[d], sd.dev.hi[d] = sd.tree.hi[d];
+    sd.dev.depth = sd.tree.depth, sd.dev.n = cnt;
+    return TMC2_OK;
+  };
+  TMC2_TRY( upload( S, srcXyz, n ) );
+  TMC2_TRY( upload( T, tgtXyz, m ) );
+  std::vector<uint8_t> c4( 4 * n );
+  for ( uint64_t i = 0; i < n; ++i ) c4[4 * i] = srcRgb[3 * i], c4[4 * i + 1] = srcRgb[3 * i + 1], c4[4 * i + 2] = srcRgb[3 * i + 2], c4[4 * i + 3] = 0;
+  DevBuf<uint8_t>  d_rgb, d_out;
+  DevBuf<uint32_t> d_err;
+  TMC2_TRY( d_rgb.alloc( 4 * n ) );
+  TMC2_TRY( d_out.alloc( 4 * m ) );
+  TMC2_TRY( d_err.alloc( 1 ) );
+  TMC2_HIP( hipMemcpyAsync( d_rgb.p, c4.data(), 4 * n, hipMemcpyHostToDevice, s ) );
+  TMC2_TRY( transferColorsDevice( ctx, S.dev, S.pts.p, d_rgb.p, uint32_t( n ), T.dev, T.pts.p, uint32_t( m ), d_out.p, d_err.p ) );
+  std::vector<uint8_t> o4( 4 * m );
+  uint32_t             err = 0;
+  TMC2_HIP( hipMemcpyAsync( o4.data(), d_out.p, 4 * m, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( &err, d_err.p, 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  if ( err ) {
+    setError( "transferColors: a backward candidate list hit std::sort's depth limit (not reproduced)" );
+    return TMC2_E_UNSUPPORTED;
+  }
+  for ( uint64_t i = 0; i < m; ++i ) tgtRgb[3 * i] = o4[4 * i], tgtRgb[3 * i + 1] = o4[4 * i + 1], tgtRgb[3 * i + 2] = o4[4 * i + 2];
+  return TMC2_OK;
+}
 
 int tmc2_encoder_generate_attribute_images( tmc2_frame* f ) {
   if ( !f ) return TMC2_E_INVALID;

@@ -135,6 +135,15 @@ class Context:
     def frame(self, xyz, rgb=None):
         return Frame(self, xyz, rgb)
 
+    # PCCPointSet3::transferColors
+    def transfer_colors(self, src_xyz, src_rgb, tgt_xyz):
+        a = np.ascontiguousarray(src_xyz, np.int16)
+        b = np.ascontiguousarray(src_rgb, np.uint8)
+        c = np.ascontiguousarray(tgt_xyz, np.int16)
+        out = np.zeros((len(c), 3), np.uint8)
+        _check(self.L.tmc2_transfer_colors(self.h, _ptr(a), _ptr(b), C.c_uint64(len(a)), _ptr(c), C.c_uint64(len(c)), _ptr(out)))
+        return out
+
     # PCCMetrics::compute (one frame)
     def metrics_compute(self, src_xyz, src_rgb, rec_xyz, rec_rgb, normals=None, resolution=1023.0):
         a = np.ascontiguousarray(src_xyz, np.int16)

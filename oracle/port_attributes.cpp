@@ -166,8 +166,7 @@ int64_t orc_generate_point_cloud( const orc_patch* patches, const int32_t* order
   return M;
 }
 
-// S18 (+S19 no-op).  Returns -2 if a target collects more than 16 backward candidates (the reference's unstable
-// std::sort would decide their order; not reproduced).
+// S18 (+S19 no-op).
 int orc_transfer_colors( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const int16_t* tgtXyz, size_t m,
                          uint8_t* tgtRgb ) {
   orc_kdtree*           srcTree = orc_kdtree_build( srcXyz, n );
@@ -208,8 +207,9 @@ int orc_transfer_colors( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n,
       for ( int k = 0; k < 3; ++k ) tgtRgb[3 * t + k] = fwd[3 * t + k];
       continue;
     }
-    if ( L.size() > 16 ) return -2;
-    std::stable_sort( L.begin(), L.end(), []( const Cand& a, const Cand& b ) { return a.d < b.d; } );  // <=16: insertion sort
+    // the reference's std::sort by distance only: NOT stable beyond 16 elements, so equal distances come out in
+    // libstdc++ introsort order; the oracle is built with the same libstdc++ and simply calls it
+    std::sort( L.begin(), L.end(), []( const Cand& a, const Cand& b ) { return a.d < b.d; } );
     double c2[3] = {0.0, 0.0, 0.0};
     if ( L[0].d < 0.0001 || L.size() == 1 ) {
       for ( int k = 0; k < 3; ++k ) c2[k] = srcRgb[3 * size_t( L[0].s ) + k];

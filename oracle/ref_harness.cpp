@@ -635,6 +635,29 @@ int ref_gof_get_attribute_images( int frame, uint8_t* out ) {
   return 0;
 }
 
+// S18 alone: PCCPointSet3::transferColors (PCCPointSet.cpp:807-1124) with the arguments PCCEncoder::generateAttributeVideo
+// passes under the CTC (PCCEncoder.cpp:6679-6697)
+int ref_transfer_colors( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const int16_t* tgtXyz, size_t m, uint8_t* tgtRgb ) {
+  Quiet quiet;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );
+  PCCPointSet3 src, tgt;
+  makeCloud( src, srcXyz, srcRgb, n );
+  makeCloud( tgt, tgtXyz, nullptr, m );
+  src.transferColors( tgt, 0, false, 8, 1, true, true, true, true, 4, 4, 1000, 1000, 1000, 1000, false, 10.0 );
+  for ( size_t i = 0; i < m; ++i ) {
+    const auto c = tgt.getColor( i );
+    tgtRgb[3 * i] = c[0], tgtRgb[3 * i + 1] = c[1], tgtRgb[3 * i + 2] = c[2];
+  }
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
+}
+
 // S23: PCCMetrics::compute (PCCMetrics.cpp:324-375) on one frame.  normals may be NULL (then no D2).
 // out[3][8] = for q1 (A->B), q2 (B->A), final: c2cMse, c2cPsnr, c2pMse, c2pPsnr, colorMse[3] (Y,U,V) + colorPsnr[0].
 // counts[2] = point counts of source / reconstruction after duplicate removal.

@@ -274,6 +274,13 @@ class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
 
+    def transfer_colors(self, src_xyz, src_rgb, tgt_xyz):
+        src_xyz, tgt_xyz = _i16(src_xyz), _i16(tgt_xyz)
+        src_rgb = np.ascontiguousarray(src_rgb, dtype=np.uint8)
+        out = np.zeros((len(tgt_xyz), 3), np.uint8)
+        self.L.ref_transfer_colors(_p(src_xyz), _p(src_rgb), C.c_size_t(len(src_xyz)), _p(tgt_xyz), C.c_size_t(len(tgt_xyz)), _p(out))
+        return out
+
     _metrics_fn = "ref_metrics"
 
     def metrics(self, src_xyz, src_rgb, rec_xyz, rec_rgb, normals=None, resolution=1023.0):

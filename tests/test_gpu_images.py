@@ -141,3 +141,11 @@ def test_gpu_gof_matches_golden_fixture(gpu_ctx):
     normals = {id(fr._xyz): fr for fr in frs}
     check_gof_against_fixture(g, frames, a, b, gpu_ctx.metrics_compute,
                               lambda xyz: next(fr for fr in frs if fr._xyz is xyz or np.array_equal(fr._xyz, xyz)).get_normals())
+
+
+def test_gpu_transfer_colors_long_candidate_lists(gpu_ctx, oracle):
+    """std::sort's non-stable ordering of > 16 equal-distance candidates is reproduced on the device."""
+    from test_oracle_golden import _sparse_target_case
+    for seed in (0, 1):
+        xyz, rgb, tgt = _sparse_target_case(seed)
+        assert np.array_equal(gpu_ctx.transfer_colors(xyz, rgb, tgt), oracle.transfer_colors(xyz, rgb, tgt))

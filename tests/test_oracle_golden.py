@@ -115,3 +115,18 @@ def test_oracle_gof_matches_reference_live(oracle, reference):
     for x, y in zip(rb, obb):
         for k in x:
             assert np.array_equal(x[k], y[k]), k
+
+
+def _sparse_target_case(seed=0):
+    """A dense source and a ~40x sparser target: every target collects dozens of backward candidates, many at equal
+    distance -- the regime where the reference's std::sort (introsort, not stable beyond 16) decides the fp64 order."""
+    xyz, rgb = synth_cloud("small", seed)
+    rng = np.random.default_rng(seed)
+    tgt = xyz[rng.choice(len(xyz), len(xyz) // 40, replace=False)]
+    tgt = np.unique((tgt + rng.integers(-1, 2, tgt.shape)).astype(np.int16), axis=0)
+    return xyz, rgb, tgt
+
+
+def test_oracle_transfer_colors_long_candidate_lists(oracle, reference):
+    xyz, rgb, tgt = _sparse_target_case()
+    assert np.array_equal(oracle.transfer_colors(xyz, rgb, tgt), reference.transfer_colors(xyz, rgb, tgt))
