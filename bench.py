@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=32, help="frames per GOF (BASELINE: 32)")
     ap.add_argument("--workload", default="longdress_vox10")
     ap.add_argument("--workers", type=int, default=0, help="concurrent frames per GPU (0 = auto)")
+    ap.add_argument("--host-steps", type=int, default=16, help="max concurrent host-resident steps (tree build, orientation)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
@@ -106,10 +107,22 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     sharder = T.Sharder(rank, world, dist, "cuda:%d" % local)
-    workers = a.workers or max(1, min(len(clouds), 16, (os.cpu_count() or 8) // world))
+    workers = a.workers or max(1, min(len(clouds), 32, (os.cpu_count() or 8) // world))
+    T.load_library().tmc2_set_host_parallelism(max(1, a.host_steps // world))
     enc = T.GofEncoder(local, workers, a.iterations, 11, 4, 1280, 1280, timing=True)
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
+
+    host_cache = {}
+
+    def host_out(W, H):
+        """Host-side destination of the finished canvases (what the video encoder reads), allocated once."""
+        if (W, H) not in host_cache:
+            host_cache[(W, H)] = [(dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // 4, W // 4), np.uint8),
+                                        block_to_patch=np.zeros((H // 16, W // 16), np.uint32),
+                                        geo0=np.zeros((H, W), np.uint16), geo1=np.zeros((H, W), np.uint16)),
+                                   np.zeros((2, 3, H, W), np.uint8)) for _ in frames]
+        return host_cache[(W, H)]
 
     def step():
         for fr in frames:
@@ -119,9 +132,9 @@ def main():
         # resident canvases.  Finished canvases -> rank 0 -> host memory, where the video encoder reads them.
         enc.phase_b(frames)
         if world == 1:
-            for fr in frames:
-                fr.get_geometry_images()
-                fr.get_attribute_images()
+            for fr, (gbuf, abuf) in zip(frames, host_out(W, H)):
+                fr.get_geometry_images(gbuf)
+                fr.get_attribute_images(abuf)
         else:
             for fr in frames:
                 g = sharder.gather(enc.device_tensor(fr, "geometry"))

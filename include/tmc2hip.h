@@ -87,6 +87,10 @@ int         tmc2_ctx_create( int device, tmc2_ctx** out );
 void        tmc2_ctx_destroy( tmc2_ctx* ctx );
 const char* tmc2_last_error( void );
 int         tmc2_ctx_synchronize( tmc2_ctx* ctx );
+/* process-wide limit on concurrently running host-resident steps (k-d tree builds, normal orientation); 0 = none.
+ * Frames of a GOF run on separate host threads; this keeps the cache-hungry host steps at the core-complex count
+ * while the GPU phases of the other frames proceed.                                                          */
+void        tmc2_set_host_parallelism( int maxConcurrentHostSteps );
 /* per-stage GPU time of the last frame operation, milliseconds (hipEvent); name list via index */
 int         tmc2_ctx_stage_count( tmc2_ctx* ctx );
 const char* tmc2_ctx_stage_name( tmc2_ctx* ctx, int i );

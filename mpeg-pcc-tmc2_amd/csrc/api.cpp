@@ -1,6 +1,7 @@
 // api.cpp -- extern "C" surface of libtmc2hip.so (see include/tmc2hip.h for the reference seams).
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <memory>
 
@@ -17,6 +18,25 @@ void setError( const char* fmt, ... ) {
   vsnprintf( buf, sizeof( buf ), fmt, ap );
   va_end( ap );
   g_lastError = buf;
+}
+
+static std::mutex              g_gateMutex;
+static std::condition_variable g_gateCv;
+static int                     g_gateLimit = 0, g_gateBusy = 0;
+void setHostParallelism( int n ) {
+  std::lock_guard<std::mutex> g( g_gateMutex );
+  g_gateLimit = n < 0 ? 0 : n;
+  g_gateCv.notify_all();
+}
+HostGate::HostGate() {
+  std::unique_lock<std::mutex> lk( g_gateMutex );
+  g_gateCv.wait( lk, [] { return g_gateLimit == 0 || g_gateBusy < g_gateLimit; } );
+  ++g_gateBusy;
+}
+HostGate::~HostGate() {
+  std::lock_guard<std::mutex> g( g_gateMutex );
+  --g_gateBusy;
+  g_gateCv.notify_one();
 }
 
 static thread_local tmc2_ctx* g_tlsCtx = nullptr;
@@ -60,7 +80,7 @@ void DevicePool::drain() {
   freeBlocks.clear();
 }
 
-void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals );
+void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch );
 
 }  // namespace tmc2
 
@@ -167,6 +187,8 @@ void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   delete ctx;
 }
 
+void tmc2_set_host_parallelism( int maxConcurrentHostSteps ) { tmc2::setHostParallelism( maxConcurrentHostSteps ); }
+
 int tmc2_ctx_synchronize( tmc2_ctx* ctx ) {
   if ( !ctx ) return TMC2_E_INVALID;
   TMC2_HIP( hipStreamSynchronize( ctx->stream ) );
@@ -239,11 +261,16 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
 
 int tmc2_frame::ensureTree() {
   if ( haveTree ) return TMC2_OK;
+  tmc2::HostGate gate;
   const auto t0 = std::chrono::steady_clock::now();
   tree.build( h_xyz.data(), n );
   const auto t1 = std::chrono::steady_clock::now();
   ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
-  std::vector<Pt> ptsTree( n );
+  Pt* ptsTree = ctx->hostD.get<Pt>( n );
+  if ( !ptsTree ) {
+    setError( "kdtree: hipHostMalloc failed" );
+    return TMC2_E_HIP;
+  }
   for ( uint64_t i = 0; i < n; ++i ) {
     const uint32_t j = tree.perm[i];
     ptsTree[i]       = Pt{h_xyz[3 * size_t( j )], h_xyz[3 * size_t( j ) + 1], h_xyz[3 * size_t( j ) + 2], 0};
@@ -252,7 +279,7 @@ int tmc2_frame::ensureTree() {
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( tree.nodes.size() ) );
   hipStream_t s = ctx->stream;
-  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, ptsTree, n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipMemcpyAsync( d_perm.p, tree.perm.data(), n * sizeof( uint32_t ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipMemcpyAsync( d_nodes.p, tree.nodes.data(), tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
@@ -423,7 +450,7 @@ int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint
 
 int tmc2_host_orient_normals( const int16_t* xyz, uint64_t n, const uint32_t* knn, int k, double* normals ) {
   if ( !xyz || !knn || !normals || k < 1 ) return TMC2_E_INVALID;
-  orientNormalsSpanningTree( xyz, n, knn, k, normals );
+  orientNormalsSpanningTree( xyz, n, knn, k, normals, nullptr );
   return TMC2_OK;
 }
 

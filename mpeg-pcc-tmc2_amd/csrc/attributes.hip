@@ -486,6 +486,7 @@ int generateAttributeImages( tmc2_frame* f ) {
     std::vector<Pt> h_recon( M );
     TMC2_HIP( hipMemcpyAsync( h_recon.data(), f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    HostGate             gate;
     const auto           t0 = std::chrono::steady_clock::now();
     std::vector<int16_t> xyz( 3 * size_t( M ) );
     for ( uint32_t i = 0; i < M; ++i ) xyz[3 * size_t( i )] = h_recon[i].x, xyz[3 * size_t( i ) + 1] = h_recon[i].y, xyz[3 * size_t( i ) + 2] = h_recon[i].z;

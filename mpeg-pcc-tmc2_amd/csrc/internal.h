@@ -147,9 +147,41 @@ struct StageTimer {
 
 }  // namespace tmc2
 
+namespace tmc2 {
+// Page-locked host staging buffer that only ever grows; lives in the context so that the per-frame host steps
+// (k-d tree build, normal orientation) neither re-fault ~100 MB of fresh pages nor copy through pageable memory.
+struct PinnedBuf {
+  void*  p     = nullptr;
+  size_t bytes = 0;
+  PinnedBuf() = default;
+  PinnedBuf( const PinnedBuf& ) = delete;
+  PinnedBuf& operator=( const PinnedBuf& ) = delete;
+  ~PinnedBuf() {
+    if ( p ) (void)hipHostFree( p );
+  }
+  template <typename T>
+  T* get( size_t count ) {
+    const size_t need = count * sizeof( T );
+    if ( need > bytes ) {
+      if ( p ) (void)hipHostFree( p );
+      p     = nullptr;
+      bytes = 0;
+      const size_t cap = need + need / 4;
+      if ( hipHostMalloc( &p, cap, hipHostMallocDefault ) != hipSuccess ) {
+        p = nullptr;
+        return nullptr;
+      }
+      bytes = cap;
+    }
+    return reinterpret_cast<T*>( p );
+  }
+};
+}  // namespace tmc2
+
 struct tmc2_ctx {
   int                           device = 0;
   tmc2::DevicePool              pool;
+  tmc2::PinnedBuf               hostA, hostB, hostC, hostD, hostE;  // staging for the host-side steps
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
@@ -219,6 +251,14 @@ struct tmc2_frame {
 };
 
 namespace tmc2 {
+// Process-wide gate around the host-resident, cache-hungry steps (k-d tree build, normal orientation): each walks a
+// ~100 MB working set, so running more of them at once than there are last-level-cache domains makes all of them
+// slower.  Frames beyond the limit wait here while their siblings' GPU phases proceed.  0 = unlimited.
+struct HostGate {
+  HostGate();
+  ~HostGate();
+};
+void setHostParallelism( int n );
 // RAII guard of every extern "C" entry: selects the device and makes the context's pool current
 struct ApiScope {
   tmc2_ctx* prev;

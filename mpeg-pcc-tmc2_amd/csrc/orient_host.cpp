@@ -17,6 +17,7 @@
 // maximum is the same edge the reference's queue would accept next; stale entries never exist.
 #include <chrono>
 #include <cmath>
+#include <cstring>
 
 #include "internal.h"
 
@@ -24,68 +25,85 @@ namespace tmc2 {
 
 namespace {
 
+// per-vertex state, one 16-byte record (one cache line touch per neighbour test)
+struct VState {
+  double   w;    // weight of the best pending in-edge
+  uint32_t s;    // its start vertex
+  int32_t  pos;  // slot in the heap; kAbsent = no pending in-edge yet; kVisited = already oriented
+};
+constexpr int32_t kAbsent = -1, kVisited = -2;
+
+// heap entries carry their own key, so sifting compares contiguous records instead of chasing vertex ids
+struct HeapEntry {
+  double   w;
+  uint32_t s, v;
+};
+
 struct VertexHeap {
-  std::vector<uint32_t> heap;  // vertex ids
-  std::vector<int32_t>  pos;   // vertex -> slot, -1 if absent
-  std::vector<double>   w;     // key part 1
-  std::vector<uint32_t> s;     // key part 2 (start vertex of the best in-edge)
+  std::vector<HeapEntry> heap;
+  VState*                st;
 
-  explicit VertexHeap( size_t n ) : pos( n, -1 ), w( n, 0.0 ), s( n, 0 ) { heap.reserve( n / 4 + 16 ); }
-
+  VertexHeap( size_t n, VState* state ) : st( state ) {
+    for ( size_t i = 0; i < n; ++i ) st[i] = VState{0.0, 0u, kAbsent};
+    heap.reserve( n / 4 + 16 );
+  }
   // strict "a has a smaller key than b" in the reference's edge order (weight, start, end)
-  bool less( uint32_t a, uint32_t b ) const {
-    if ( w[a] == w[b] ) return s[a] == s[b] ? a < b : s[a] < s[b];
-    return w[a] < w[b];
+  static bool less( const HeapEntry& a, const HeapEntry& b ) {
+    if ( a.w == b.w ) return a.s == b.s ? a.v < b.v : a.s < b.s;
+    return a.w < b.w;
   }
   void siftUp( size_t i ) {
-    const uint32_t v = heap[i];
+    const HeapEntry e = heap[i];
     while ( i > 0 ) {
       const size_t p = ( i - 1 ) >> 1;
-      if ( !less( heap[p], v ) ) break;
-      heap[i]      = heap[p];
-      pos[heap[i]] = int32_t( i );
-      i            = p;
+      if ( !less( heap[p], e ) ) break;
+      heap[i]            = heap[p];
+      st[heap[i].v].pos  = int32_t( i );
+      i                  = p;
     }
-    heap[i] = v;
-    pos[v]  = int32_t( i );
+    heap[i]     = e;
+    st[e.v].pos = int32_t( i );
   }
   void siftDown( size_t i ) {
-    const size_t   n = heap.size();
-    const uint32_t v = heap[i];
+    const size_t    n = heap.size();
+    const HeapEntry e = heap[i];
     for ( ;; ) {
       size_t c = 2 * i + 1;
       if ( c >= n ) break;
       if ( c + 1 < n && less( heap[c], heap[c + 1] ) ) ++c;
-      if ( !less( v, heap[c] ) ) break;
-      heap[i]      = heap[c];
-      pos[heap[i]] = int32_t( i );
-      i            = c;
+      if ( !less( e, heap[c] ) ) break;
+      heap[i]           = heap[c];
+      st[heap[i].v].pos = int32_t( i );
+      i                 = c;
     }
-    heap[i] = v;
-    pos[v]  = int32_t( i );
+    heap[i]     = e;
+    st[e.v].pos = int32_t( i );
   }
   // offer in-edge (weight, start) to unvisited vertex v
   void offer( uint32_t v, double weight, uint32_t start ) {
-    if ( pos[v] < 0 ) {
-      w[v] = weight;
-      s[v] = start;
-      heap.push_back( v );
+    VState& sv = st[v];
+    if ( sv.pos == kAbsent ) {
+      sv.w = weight;
+      sv.s = start;
+      heap.push_back( HeapEntry{weight, start, v} );
       siftUp( heap.size() - 1 );
-    } else if ( weight > w[v] || ( weight == w[v] && start > s[v] ) ) {
-      w[v] = weight;
-      s[v] = start;
-      siftUp( size_t( pos[v] ) );
+    } else if ( weight > sv.w || ( weight == sv.w && start > sv.s ) ) {
+      sv.w                 = weight;
+      sv.s                 = start;
+      heap[sv.pos].w       = weight;
+      heap[sv.pos].s       = start;
+      siftUp( size_t( sv.pos ) );
     }
   }
-  uint32_t popMax() {
-    const uint32_t top = heap[0];
-    pos[top]           = -1;
-    const uint32_t last = heap.back();
+  HeapEntry popMax() {
+    const HeapEntry top  = heap[0];
+    const HeapEntry last = heap.back();
     heap.pop_back();
     if ( !heap.empty() ) {
       heap[0] = last;
       siftDown( 0 );
     }
+    st[top.v].pos = kVisited;
     return top;
   }
 };
@@ -94,13 +112,18 @@ inline double dot( const double* a, const double* b ) { return a[0] * b[0] + a[1
 
 }  // namespace
 
-// normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]
-void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals ) {
+// normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]; scratch: n * 16 bytes or nullptr
+void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch ) {
   if ( n == 0 ) return;
-  VertexHeap           heap( n );
-  std::vector<uint8_t> visited( n, 0 );
-  double               acc[3];
-  size_t               accCount = 0;
+  std::vector<VState> own;
+  if ( !scratch ) {
+    own.resize( n );
+    scratch = own.data();
+  }
+  VState*    st = reinterpret_cast<VState*>( scratch );
+  VertexHeap heap( n, st );
+  double     acc[3];
+  size_t     accCount = 0;
   auto expand = [&]( uint32_t cur ) {
     acc[0] = acc[1] = acc[2] = 0.0;
     accCount                 = 0;
@@ -108,7 +131,7 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
     const uint32_t* row = knn + size_t( cur ) * k;
     for ( int j = 0; j < k; ++j ) {
       const uint32_t v = row[j];
-      if ( !visited[v] ) {
+      if ( st[v].pos != kVisited ) {
         heap.offer( v, std::fabs( dot( nc, normals + 3 * size_t( v ) ) ), cur );
       } else if ( v != cur ) {
         acc[0] += normals[3 * size_t( v )];
@@ -124,8 +147,9 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
     normals[3 * i + 2] = -normals[3 * i + 2];
   };
   for ( size_t seed = 0; seed < n; ++seed ) {
-    if ( visited[seed] ) continue;
-    visited[seed] = 1;
+    if ( st[seed].pos == kVisited ) continue;
+    // a seed is never in the heap: the heap is empty whenever a new seed is picked
+    st[seed].pos = kVisited;
     expand( uint32_t( seed ) );
     if ( accCount == 0 ) {
       if ( seed != 0 ) {
@@ -140,11 +164,9 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
     }
     if ( dot( normals + 3 * seed, acc ) < 0.0 ) flip( seed );
     while ( !heap.heap.empty() ) {
-      const uint32_t v     = heap.popMax();
-      const uint32_t start = heap.s[v];
-      visited[v]           = 1;
-      if ( dot( normals + 3 * size_t( start ), normals + 3 * size_t( v ) ) < 0.0 ) flip( v );
-      expand( v );
+      const HeapEntry e = heap.popMax();
+      if ( dot( normals + 3 * size_t( e.s ), normals + 3 * size_t( e.v ) ) < 0.0 ) flip( e.v );
+      expand( e.v );
     }
   }
   size_t negCount = 0;
@@ -161,18 +183,28 @@ int orientNormalsHost( tmc2_frame* f ) {
     setError( "orientNormals: adjacency / normals not computed" );
     return TMC2_E_STATE;
   }
-  const size_t          n = f->n;
-  std::vector<uint32_t> knn( n * size_t( f->k ) );
-  std::vector<double>   nrm( n * 3 );
-  hipStream_t           s = f->ctx->stream;
-  TMC2_HIP( hipMemcpyAsync( knn.data(), f->d_knn.p, knn.size() * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipMemcpyAsync( nrm.data(), f->d_normals.p, nrm.size() * sizeof( double ), hipMemcpyDeviceToHost, s ) );
+  const size_t n   = f->n;
+  tmc2_ctx*    ctx = f->ctx;
+  uint32_t*    knn = ctx->hostA.get<uint32_t>( n * size_t( f->k ) );
+  double*      nrm = ctx->hostB.get<double>( n * 3 );
+  uint8_t*     scr = ctx->hostC.get<uint8_t>( n * 16 );
+  if ( !knn || !nrm || !scr ) {
+    setError( "orientNormals: hipHostMalloc failed" );
+    return TMC2_E_HIP;
+  }
+  hipStream_t s = ctx->stream;
+  TMC2_HIP( hipMemcpyAsync( knn, f->d_knn.p, n * size_t( f->k ) * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( nrm, f->d_normals.p, n * 3 * sizeof( double ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
-  const auto t0 = std::chrono::steady_clock::now();
-  orientNormalsSpanningTree( f->h_xyz.data(), n, knn.data(), f->k, nrm.data() );
-  const auto t1 = std::chrono::steady_clock::now();
-  f->ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
-  TMC2_HIP( hipMemcpyAsync( f->d_normals.p, nrm.data(), nrm.size() * sizeof( double ), hipMemcpyHostToDevice, s ) );
+  std::chrono::steady_clock::time_point t0, t1;
+  {
+    HostGate gate;
+    t0 = std::chrono::steady_clock::now();
+    orientNormalsSpanningTree( f->h_xyz.data(), n, knn, f->k, nrm, scr );
+    t1 = std::chrono::steady_clock::now();
+  }
+  ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+  TMC2_HIP( hipMemcpyAsync( f->d_normals.p, nrm, n * 3 * sizeof( double ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   return TMC2_OK;
 }

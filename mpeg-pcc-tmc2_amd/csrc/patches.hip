@@ -40,14 +40,33 @@ struct PatchDev {
 
 __device__ __forceinline__ int coordOf( const Pt p, int axis ) { return axis == 0 ? p.x : ( axis == 1 ? p.y : p.z ); }
 
+// Wave-aggregated reductions keyed by a small integer (patch / component id).  Neighbouring points almost always
+// share the key, so instead of 64 atomics on one address per wavefront the lanes holding the same key are reduced
+// with cross-lane shuffles and ONE lane issues the atomics.  Loops once per distinct key present in the wave.
+// All 64 lanes must call these (key < 0 = nothing to contribute).
+__device__ __forceinline__ int waveMinMasked( int v, bool mine ) {
+  v = mine ? v : 0x7FFFFFFF;
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) v = min( v, __shfl_xor( v, off, 64 ) );
+  return v;
+}
+__device__ __forceinline__ int waveMaxMasked( int v, bool mine ) {
+  v = mine ? v : int( 0x80000000 );
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) v = max( v, __shfl_xor( v, off, 64 ) );
+  return v;
+}
+
 // ---- S7 ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__( 256 ) void ccInitKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ dist,
                                                         uint32_t thrDetection, uint32_t n, uint32_t* __restrict__ label,
-                                                        uint32_t* __restrict__ ccCount ) {
+                                                        uint32_t* __restrict__ ccCount, uint32_t* __restrict__ dirty ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  label[i]   = ( raw[i] && dist[i] > thrDetection ) ? i : kNoLabel;
-  ccCount[i] = 0;
+  const bool seed = raw[i] && dist[i] > thrDetection;
+  label[i]        = seed ? i : kNoLabel;
+  dirty[i]        = seed ? 1u : 0u;  // a point re-pushes only after its label was lowered
+  ccCount[i]      = 0;
 }
 
 // One sweep = every labelled raw point (a) shortcuts its label through its seed's own label ("pointer
@@ -60,41 +79,48 @@ template <int K>
 __global__ __launch_bounds__( 256 ) void ccPropagateKernel( const uint32_t* __restrict__ knn,
                                                              const uint8_t* __restrict__ partition,
                                                              const uint8_t* __restrict__ raw, uint32_t n,
-                                                             uint32_t* __restrict__ label, uint32_t* __restrict__ changed ) {
+                                                             uint32_t* __restrict__ label, uint32_t* __restrict__ dirty,
+                                                             uint32_t* __restrict__ changed ) {
   __shared__ int blockChanged;
   const uint32_t u      = blockIdx.x * blockDim.x + threadIdx.x;
   const bool     mine   = u < n && raw[u];
-  const uint8_t  pu     = mine ? partition[u] : 0;
+  bool           loaded = false;
+  uint8_t        pu     = 0;
   uint32_t       nb[K];
-  uint32_t       okMask = 0;  // neighbours that are raw and on the same plane
-  if ( mine ) {
-    const uint4* row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
-#pragma unroll
-    for ( int j = 0; j < K / 4; ++j ) {
-      const uint4 r = row[j];
-      nb[4 * j] = r.x, nb[4 * j + 1] = r.y, nb[4 * j + 2] = r.z, nb[4 * j + 3] = r.w;
-    }
-#pragma unroll
-    for ( int j = 0; j < K; ++j )
-      if ( nb[j] != u && raw[nb[j]] && partition[nb[j]] == pu ) okMask |= 1u << j;
-  }
-  bool everChanged = false;
-  for ( int rep = 0; rep < 16; ++rep ) {
+  bool           everChanged = false;
+  for ( int rep = 0; rep < 32; ++rep ) {
     if ( threadIdx.x == 0 ) blockChanged = 0;
     __syncthreads();
     bool any = false;
-    if ( mine ) {
+    // frontier: only points whose label was lowered since their last push have anything new to say.  The flag is
+    // taken with an atomic exchange so that the label load below is ordered after it (a later lowering re-arms it).
+    if ( mine && atomicExch( &dirty[u], 0u ) ) {
+      if ( !loaded ) {
+        loaded           = true;
+        pu               = partition[u];
+        const uint4* row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
+#pragma unroll
+        for ( int j = 0; j < K / 4; ++j ) {
+          const uint4 r = row[j];
+          nb[4 * j] = r.x, nb[4 * j + 1] = r.y, nb[4 * j + 2] = r.z, nb[4 * j + 3] = r.w;
+        }
+      }
       uint32_t lu = __hip_atomic_load( &label[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
       if ( lu != kNoLabel ) {
+        // pointer jumping: label[u] = s and label[s] = t < s  =>  t reaches s reaches u
         const uint32_t l2 = __hip_atomic_load( &label[lu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         if ( l2 < lu ) {
           atomicMin( &label[u], l2 );
-          lu  = l2;
-          any = true;
+          lu = l2;
         }
 #pragma unroll
-        for ( int j = 0; j < K; ++j )
-          if ( okMask & ( 1u << j ) ) any |= atomicMin( &label[nb[j]], lu ) > lu;
+        for ( int j = 0; j < K; ++j ) {
+          const uint32_t v = nb[j];
+          if ( v != u && raw[v] && partition[v] == pu && atomicMin( &label[v], lu ) > lu ) {
+            dirty[v] = 1u;
+            any      = true;
+          }
+        }
       }
     }
     if ( any ) blockChanged = 1;
@@ -106,12 +132,78 @@ __global__ __launch_bounds__( 256 ) void ccPropagateKernel( const uint32_t* __re
   if ( everChanged ) *changed = 1;
 }
 
+// Persistent form of the sweep above: a fixed, fully resident grid in which every lane owns a strided set of points
+// and keeps re-visiting them while labels are still moving anywhere on the chip (global activity counter, as in the
+// refinement's closure kernel).  One launch walks the whole propagation front -- hundreds of dependent hops at the
+// cost of an L2 round trip each instead of a kernel launch each.  Retirement is heuristic; the caller always follows
+// with ordinary sweeps, which either confirm the fixpoint (no label changed) or finish the job.
+template <int K>
+__global__ __launch_bounds__( 256 ) void ccPersistentKernel( const uint32_t* __restrict__ knn,
+                                                              const uint8_t* __restrict__ partition,
+                                                              const uint8_t* __restrict__ raw, uint32_t n,
+                                                              uint32_t* __restrict__ label, uint32_t* __restrict__ dirty,
+                                                              uint32_t* __restrict__ activity ) {
+  __shared__ int worked;
+  __shared__ int retire;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t       seen   = 0;
+  int            quiet  = 0;
+  for ( int rep = 0; rep < 1000000; ++rep ) {
+    if ( threadIdx.x == 0 ) worked = 0;
+    __syncthreads();
+    bool any = false;
+    for ( uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride ) {
+      if ( !__hip_atomic_load( &dirty[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) continue;
+      if ( !atomicExch( &dirty[u], 0u ) ) continue;
+      uint32_t lu = __hip_atomic_load( &label[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( lu == kNoLabel ) continue;
+      const uint32_t l2 = __hip_atomic_load( &label[lu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( l2 < lu ) {
+        atomicMin( &label[u], l2 );
+        lu = l2;
+      }
+      const uint8_t pu  = partition[u];
+      const uint4*  row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
+#pragma unroll
+      for ( int j = 0; j < K / 4; ++j ) {
+        const uint4    r    = row[j];
+        const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for ( int t = 0; t < 4; ++t )
+          if ( v[t] != u && raw[v[t]] && partition[v[t]] == pu && atomicMin( &label[v[t]], lu ) > lu ) {
+            __hip_atomic_store( &dirty[v[t]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+            any = true;
+          }
+      }
+    }
+    if ( any ) worked = 1;
+    __syncthreads();
+    if ( threadIdx.x == 0 ) {
+      if ( worked ) __hip_atomic_fetch_add( activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      const uint32_t now = __hip_atomic_load( activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      quiet              = ( worked || now != seen ) ? 0 : quiet + 1;
+      seen               = now;
+      retire             = quiet >= 32;
+      if ( !worked ) __builtin_amdgcn_s_sleep( 16 );
+    }
+    __syncthreads();
+    if ( retire ) break;
+  }
+}
+
 __global__ __launch_bounds__( 256 ) void ccCountKernel( const uint32_t* __restrict__ label, uint32_t n,
                                                          uint32_t* __restrict__ ccCount ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n ) return;
-  const uint32_t l = label[i];
-  if ( l != kNoLabel ) atomicAdd( &ccCount[l], 1u );
+  const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63;
+  const uint32_t l    = i < n ? label[i] : kNoLabel;
+  unsigned long long todo = __ballot( l != kNoLabel );
+  while ( todo ) {
+    const int                leader = __ffsll( (long long)todo ) - 1;
+    const uint32_t           key    = __shfl( l, leader, 64 );
+    const unsigned long long same   = __ballot( l == key );
+    if ( lane == leader ) atomicAdd( &ccCount[key], uint32_t( __popcll( same ) ) );
+    todo &= ~same;
+  }
 }
 
 __global__ __launch_bounds__( 256 ) void ccSeedFlagKernel( const uint32_t* __restrict__ label,
@@ -144,40 +236,68 @@ __global__ __launch_bounds__( 256 ) void ccAssignKernel( const uint32_t* __restr
 __global__ __launch_bounds__( 256 ) void patchMinUvKernel( const Pt* __restrict__ pts, const int32_t* __restrict__ pointPatch,
                                                             const int32_t* __restrict__ patchView, uint32_t n,
                                                             int32_t* __restrict__ minUv ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n ) return;
-  const int32_t p = pointPatch[i];
-  if ( p < 0 ) return;
-  const int view = patchView[p] % 3;
-  const int axT = view == 0 ? 2 : ( view == 1 ? 2 : 0 ), axB = view == 0 ? 1 : ( view == 1 ? 0 : 1 );
-  const Pt  q = pts[i];
-  atomicMin( &minUv[2 * p], coordOf( q, axT ) );
-  atomicMin( &minUv[2 * p + 1], coordOf( q, axB ) );
+  const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63;
+  const int32_t  p    = i < n ? pointPatch[i] : -1;
+  int            u = 0, v = 0;
+  if ( p >= 0 ) {
+    const int view = patchView[p] % 3;
+    const int axT = view == 0 ? 2 : ( view == 1 ? 2 : 0 ), axB = view == 0 ? 1 : ( view == 1 ? 0 : 1 );
+    const Pt  q = pts[i];
+    u = coordOf( q, axT ), v = coordOf( q, axB );
+  }
+  unsigned long long todo = __ballot( p >= 0 );
+  while ( todo ) {
+    const int                leader = __ffsll( (long long)todo ) - 1;
+    const int32_t            key    = __shfl( p, leader, 64 );
+    const bool               mine   = p == key;
+    const unsigned long long same   = __ballot( mine );
+    const int                mu = waveMinMasked( u, mine ), mv = waveMinMasked( v, mine );
+    if ( lane == leader ) {
+      atomicMin( &minUv[2 * key], mu );
+      atomicMin( &minUv[2 * key + 1], mv );
+    }
+    todo &= ~same;
+  }
 }
 
 __global__ __launch_bounds__( 256 ) void patchTrimBboxKernel( const Pt* __restrict__ pts, const int32_t* __restrict__ patchView,
                                                                const int32_t* __restrict__ minUv, int splitting,
                                                                int maxPatchSize, uint32_t n,
                                                                int32_t* __restrict__ pointPatch, int32_t* __restrict__ bbox ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n ) return;
-  const int32_t p = pointPatch[i];
-  if ( p < 0 ) return;
-  const Pt q = pts[i];
-  if ( splitting ) {
-    const int view = patchView[p] % 3;
-    const int axT = view == 0 ? 2 : ( view == 1 ? 2 : 0 ), axB = view == 0 ? 1 : ( view == 1 ? 0 : 1 );
-    if ( !( coordOf( q, axT ) - minUv[2 * p] < maxPatchSize && coordOf( q, axB ) - minUv[2 * p + 1] < maxPatchSize ) ) {
-      pointPatch[i] = -1;  // trimmed: stays raw for a later round
-      return;
+  const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63;
+  int32_t        p    = i < n ? pointPatch[i] : -1;
+  Pt             q    = Pt{0, 0, 0, 0};
+  if ( p >= 0 ) {
+    q = pts[i];
+    if ( splitting ) {
+      const int view = patchView[p] % 3;
+      const int axT = view == 0 ? 2 : ( view == 1 ? 2 : 0 ), axB = view == 0 ? 1 : ( view == 1 ? 0 : 1 );
+      if ( !( coordOf( q, axT ) - minUv[2 * p] < maxPatchSize && coordOf( q, axB ) - minUv[2 * p + 1] < maxPatchSize ) ) {
+        pointPatch[i] = -1;  // trimmed: stays raw for a later round
+        p             = -1;
+      }
     }
   }
-  atomicMin( &bbox[6 * p + 0], int( q.x ) );
-  atomicMin( &bbox[6 * p + 1], int( q.y ) );
-  atomicMin( &bbox[6 * p + 2], int( q.z ) );
-  atomicMax( &bbox[6 * p + 3], int( q.x ) );
-  atomicMax( &bbox[6 * p + 4], int( q.y ) );
-  atomicMax( &bbox[6 * p + 5], int( q.z ) );
+  unsigned long long todo = __ballot( p >= 0 );
+  while ( todo ) {
+    const int                leader = __ffsll( (long long)todo ) - 1;
+    const int32_t            key    = __shfl( p, leader, 64 );
+    const bool               mine   = p == key;
+    const unsigned long long same   = __ballot( mine );
+    const int x0 = waveMinMasked( q.x, mine ), y0 = waveMinMasked( q.y, mine ), z0 = waveMinMasked( q.z, mine );
+    const int x1 = waveMaxMasked( q.x, mine ), y1 = waveMaxMasked( q.y, mine ), z1 = waveMaxMasked( q.z, mine );
+    if ( lane == leader ) {
+      atomicMin( &bbox[6 * key + 0], x0 );
+      atomicMin( &bbox[6 * key + 1], y0 );
+      atomicMin( &bbox[6 * key + 2], z0 );
+      atomicMax( &bbox[6 * key + 3], x1 );
+      atomicMax( &bbox[6 * key + 4], y1 );
+      atomicMax( &bbox[6 * key + 5], z1 );
+    }
+    todo &= ~same;
+  }
 }
 
 // D0 candidates: 64-bit (depth << 32 | point) min (mode 0) / max (mode 1) per pixel
@@ -450,13 +570,14 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_TRY( ctx->voxelBitmap.alloc( bitmapWords ) );
   TMC2_HIP( hipMemsetAsync( ctx->voxelBitmap.p, 0, bitmapWords * 4, s ) );
 
-  DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src;
+  DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_dirty;
   DevBuf<uint8_t>  d_raw;
   DevBuf<int32_t>  d_pointPatch, d_patchView, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
   DevBuf<int>      d_offsets;
   DevBuf<PatchDev> d_patches;
   DevBuf<unsigned long long> d_map64;
   TMC2_TRY( d_label.alloc( n ) );
+  TMC2_TRY( d_dirty.alloc( n ) );
   TMC2_TRY( d_ccCount.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
   TMC2_TRY( d_rank.alloc( n ) );
@@ -480,15 +601,24 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );
-    hipLaunchKernelGGL( ccInitKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_label.p, d_ccCount.p );
+    hipLaunchKernelGGL( ccInitKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_label.p, d_ccCount.p, d_dirty.p );
+    {
+      // the bulk of the propagation in ONE persistent launch (grid sized to be fully co-resident)
+      const uint32_t persistentBlocks = uint32_t( std::min<size_t>( ( n + 255 ) / 256, size_t( ctx->cuCount ) * 4 ) );
+      TMC2_HIP( hipMemsetAsync( d_small.p + 3, 0, 4, s ) );
+      const int kt = ctx->stageBegin( "k:ccPersistent" );
+      hipLaunchKernelGGL( ccPersistentKernel<16>, dim3( persistentBlocks ), blk, 0, s, f->d_knn.p, f->d_partition.p, d_raw.p, n,
+                          d_label.p, d_dirty.p, d_small.p + 3 );
+      ctx->stageEnd( kt );
+    }
     for ( int guard = 0; guard < 1 << 20; ++guard ) {
       // a few sweeps per host round-trip; the flag is cleared before the LAST sweep of the batch only,
       // so "unchanged" means the final sweep of the batch changed nothing (= fixpoint)
-      for ( int b = 0; b < 4; ++b ) {
-        if ( b == 3 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
+      for ( int b = 0; b < 2; ++b ) {
+        if ( b == 1 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
         const int kt = ctx->stageBegin( "k:ccPropagate" );
         hipLaunchKernelGGL( ccPropagateKernel<16>, grdN, blk, 0, s, f->d_knn.p, f->d_partition.p, d_raw.p, n, d_label.p,
-                            d_small.p );
+                            d_dirty.p, d_small.p );
         ctx->stageEnd( kt );
       }
       uint32_t changed = 0;

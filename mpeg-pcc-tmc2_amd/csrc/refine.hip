@@ -127,7 +127,7 @@ __device__ __forceinline__ void classify( const uint32_t ( &b )[6], int& nonZero
 __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __restrict__ hist,
                                                                 const uint32_t* __restrict__ count, uint32_t V,
                                                                 uint8_t* __restrict__ edge, uint8_t* __restrict__ ppi,
-                                                                uint8_t* __restrict__ active ) {
+                                                                uint32_t* __restrict__ active ) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if ( v >= V ) return;
   uint32_t b[6];
@@ -281,35 +281,67 @@ __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__
   }
 }
 
-// one closure step: every active voxel u marks the uniform DEV neighbours that disagree with arg[u];
-// a marked neighbour with a larger index becomes active in THIS sweep.
+// INDIRECT-edge closure.  Every active voxel u marks the uniform DEV neighbours that disagree with arg[u]; a marked
+// neighbour with a LARGER index becomes active in this sweep and must mark in turn (the reference's in-order loop).
+// That is reachability in a DAG whose chains can be tens of voxels deep, so the kernel is persistent: every workgroup
+// (all are co-resident: V/256 <= 2048) keeps polling its 256 voxels for activations arriving through L2 and bumps a
+// global activity counter whenever it did work; a workgroup retires once that counter has been quiet for a window
+// much longer than a cross-CU hand-off.  Retirement is a heuristic, not a proof -- VERIFY = true re-checks the
+// fixpoint and raises a sticky flag, on which the host replays the sweeps with the host-checked loop.
+template <bool VERIFY>
 __global__ __launch_bounds__( 256 ) void closureKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
                                                          const uint8_t* __restrict__ arg,
                                                          const uint32_t* __restrict__ adjOff,
                                                          const uint32_t* __restrict__ devLen,
                                                          const uint32_t* __restrict__ adj, uint32_t V,
-                                                         uint8_t* __restrict__ active, uint8_t* __restrict__ marked,
-                                                         uint32_t* __restrict__ changed ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u >= V || !active[u] ) return;
-  const uint32_t* row = adj + adjOff[u];
-  const uint32_t  len = devLen[u];
-  const uint8_t   a   = arg[u];
-  for ( uint32_t i = 0; i < len; ++i ) {
-    const uint32_t v = row[i];
-    if ( edge[v] == NO_EDGE && ppi[v] != a ) {
-      marked[v] = 1;
-      if ( v > u && !active[v] ) {
-        active[v] = 1;
-        *changed  = 1;
+                                                         uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
+                                                         uint32_t* __restrict__ unconverged, uint32_t* __restrict__ activity ) {
+  __shared__ int  worked;
+  __shared__ int  retire;
+  const uint32_t  u     = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool      valid = u < V;
+  const uint32_t* row   = valid ? adj + adjOff[u] : nullptr;
+  const uint32_t  len   = valid ? devLen[u] : 0;
+  const uint8_t   a     = valid ? arg[u] : 0;
+  bool            done  = false;  // this voxel has issued its marks
+  uint32_t        seen  = 0;      // thread 0: last observed value of the activity counter
+  int             quiet = 0;      // thread 0: consecutive polls without local work or global activity
+  for ( int rep = 0; rep < 100000; ++rep ) {
+    if ( threadIdx.x == 0 ) worked = 0;
+    __syncthreads();
+    if ( valid && !done && __hip_atomic_load( &active[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) {
+      done = true;
+      for ( uint32_t i = 0; i < len; ++i ) {
+        const uint32_t v = row[i];
+        if ( edge[v] == NO_EDGE && ppi[v] != a ) {
+          if ( VERIFY ) {
+            if ( v > u && !__hip_atomic_load( &active[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) *unconverged = 1;
+          } else {
+            marked[v] = 1;
+            if ( v > u ) __hip_atomic_store( &active[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+          }
+        }
       }
+      worked = 1;
     }
+    __syncthreads();
+    if ( VERIFY ) break;
+    if ( threadIdx.x == 0 ) {
+      if ( worked ) __hip_atomic_fetch_add( activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      const uint32_t now = __hip_atomic_load( activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      quiet              = ( worked || now != seen ) ? 0 : quiet + 1;
+      seen               = now;
+      retire             = quiet >= 48;
+      if ( !worked ) __builtin_amdgcn_s_sleep( 16 );
+    }
+    __syncthreads();
+    if ( retire ) break;
   }
 }
 
 // proc[v] = voxel is re-scored this sweep; its histogram is zeroed for re-accumulation
 __global__ __launch_bounds__( 256 ) void decideKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                        const uint8_t* __restrict__ active, const uint4* __restrict__ S,
+                                                        const uint32_t* __restrict__ active, const uint4* __restrict__ S,
                                                         uint32_t V, uint8_t* __restrict__ proc, uint4* __restrict__ hist ) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if ( v >= V ) return;
@@ -364,7 +396,7 @@ __global__ __launch_bounds__( 256 ) void rescorePointsKernel( const uint32_t* __
 // end of sweep: refresh edge class / ppi of re-scored voxels, apply INDIRECT marks, arm the next sweep
 __global__ __launch_bounds__( 256 ) void updateVoxelKernel( const uint4* __restrict__ hist, const uint8_t* __restrict__ proc,
                                                              uint32_t V, uint8_t* __restrict__ edge,
-                                                             uint8_t* __restrict__ ppi, uint8_t* __restrict__ active,
+                                                             uint8_t* __restrict__ ppi, uint32_t* __restrict__ active,
                                                              uint8_t* __restrict__ marked ) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if ( v >= V ) return;
@@ -452,7 +484,8 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   DevBuf<uint32_t> d_count, d_rowLen, d_devLen, d_adjOff, d_hist;
   DevBuf<Pt>       d_centre;
   DevBuf<double>   d_weight;
-  DevBuf<uint8_t>  d_state;  // edge | ppi | arg | active | marked | proc, V bytes each
+  DevBuf<uint8_t>  d_state;  // edge | ppi | arg | marked | proc, V bytes each
+  DevBuf<uint32_t> d_activeBuf;
   DevBuf<int>      d_offsets;
   DevBuf<uint4>    d_S;
   TMC2_TRY( d_count.alloc( V ) );
@@ -463,11 +496,12 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   TMC2_TRY( d_centre.alloc( V ) );
   TMC2_TRY( d_weight.alloc( V ) );
   TMC2_TRY( d_state.alloc( size_t( V ) * 6 ) );
+  TMC2_TRY( d_activeBuf.alloc( V ) );
   TMC2_TRY( d_offsets.alloc( offsets.size() ) );
   TMC2_TRY( d_S.alloc( V ) );
   uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + V, *d_arg = d_state.p + 2 * size_t( V ),
-          *d_active = d_state.p + 3 * size_t( V ), *d_marked = d_state.p + 4 * size_t( V ),
-          *d_proc = d_state.p + 5 * size_t( V );
+          *d_marked = d_state.p + 4 * size_t( V ), *d_proc = d_state.p + 5 * size_t( V );
+  uint32_t* d_active = d_activeBuf.p;
   TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( V ) * 4, s ) );
   TMC2_HIP( hipMemsetAsync( d_hist.p, 0, size_t( V ) * 16, s ) );
   TMC2_HIP( hipMemsetAsync( d_state.p, 0, size_t( V ) * 6, s ) );
@@ -515,9 +549,11 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
       ctx->stageEnd( kt );
       if ( closureSteps < 0 ) {
         for ( int guard = 0; guard < 1 << 20; ++guard ) {
+          hipLaunchKernelGGL( closureKernel<false>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                              d_active, d_marked, d_changed + 1, d_small.p + 4 );
           TMC2_HIP( hipMemsetAsync( d_changed, 0, 4, s ) );
-          hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                              d_active, d_marked, d_changed );
+          hipLaunchKernelGGL( closureKernel<true>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                              d_active, d_marked, d_changed, d_small.p + 4 );
           uint32_t changed = 0;
           TMC2_HIP( hipMemcpyAsync( &changed, d_changed, 4, hipMemcpyDeviceToHost, s ) );
           TMC2_HIP( hipStreamSynchronize( s ) );
@@ -525,10 +561,10 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
         }
       } else {
         for ( int c = 0; c < closureSteps; ++c )
-          hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                              d_active, d_marked, d_changed + 1 /* scratch word */ );
-        hipLaunchKernelGGL( closureKernel, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                            d_active, d_marked, d_changed /* sticky */ );
+          hipLaunchKernelGGL( closureKernel<false>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                              d_active, d_marked, d_changed + 1, d_small.p + 4 );
+        hipLaunchKernelGGL( closureKernel<true>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
+                            d_active, d_marked, d_changed /* sticky */, d_small.p + 4 );
       }
       hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
                           reinterpret_cast<uint4*>( d_hist.p ) );
@@ -541,8 +577,8 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     }
     return TMC2_OK;
   };
-  TMC2_HIP( hipMemsetAsync( d_changed, 0, 8, s ) );
-  int closureSteps = 3;
+  TMC2_HIP( hipMemsetAsync( d_changed, 0, 12, s ) );  // sticky flag, scratch word, activity counter
+  int closureSteps = 1;
   if ( const char* e = getenv( "TMC2_REFINE_CLOSURE_STEPS" ) ) closureSteps = std::max( 0, atoi( e ) );  // test hook
   TMC2_TRY( runSweeps( closureSteps ) );
   uint32_t unconverged = 0;

@@ -291,11 +291,12 @@ class Frame:
         _check(self.L.tmc2_encoder_generate_geometry_images(self.h, int(width), int(height), int(occ_precision)))
         self._canvas = (int(width), int(height), int(occ_precision))
 
-    def get_geometry_images(self):
+    def get_geometry_images(self, out=None):
         W, H, p = self._canvas
-        out = dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // p, W // p), np.uint8),
-                   block_to_patch=np.zeros((H // 16, W // 16), np.uint32), geo0=np.zeros((H, W), np.uint16),
-                   geo1=np.zeros((H, W), np.uint16))
+        if out is None:
+            out = dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // p, W // p), np.uint8),
+                       block_to_patch=np.zeros((H // 16, W // 16), np.uint32), geo0=np.zeros((H, W), np.uint16),
+                       geo1=np.zeros((H, W), np.uint16))
         _check(self.L.tmc2_frame_get_geometry_images(self.h, _ptr(out["occupancy"]), _ptr(out["occ_video"]),
                                                      _ptr(out["block_to_patch"]), _ptr(out["geo0"]), _ptr(out["geo1"])))
         return out
@@ -312,9 +313,10 @@ class Frame:
         _check(self.L.tmc2_frame_get_reconstruction(self.h, _ptr(xyz), _ptr(rgb), _ptr(p2p)))
         return xyz, rgb, p2p
 
-    def get_attribute_images(self):
+    def get_attribute_images(self, out=None):
         W, H, _ = self._canvas
-        out = np.zeros((2, 3, H, W), np.uint8)
+        if out is None:
+            out = np.zeros((2, 3, H, W), np.uint8)
         _check(self.L.tmc2_frame_get_attribute_images(self.h, _ptr(out)))
         return out
 
