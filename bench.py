@@ -64,8 +64,9 @@ def algorithmic_bytes(kernel, n_points):
         "knn8_recon_in_source": 8 + 64,     # per reconstructed point (M ~ 1.05 N): point in, 8 ids + 8 distances out
         "knn1_source_in_recon": 8 + 8,
         "normals": 64 + 24,                 # neighbour ids in, fp64 normal out (neighbour positions are cache hits)
-        "k:ccPropagate": 64 + 1 + 1 + 4,    # adjacency row, plane, raw flag, label
-        "k:refineRescorePoints": 4 + 1 + 24 + 1,  # voxel id, proc flag, normal, label
+        "k:ccMutualMask": 64 + 2,           # own adjacency row in, 16-bit mask out (neighbour rows are cache hits)
+        "k:ccUnionFind": 64 + 2 + 1 + 1 + 4 + 4,  # row, mask, plane, raw flag, parent, group label
+        "k:ccRelax": 64 + 2 + 1 + 1 + 4,    # per sweep
         "initial_segmentation": 24 + 1,
     }
     return per_point.get(kernel, 0) * n_points

@@ -106,6 +106,9 @@ int  tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, u
 void tmc2_frame_destroy( tmc2_frame* f );
 /* the tree is built (host) and uploaded on first use; this forces it (PCCKdTree::init, PCCKdTree.cpp:56-59) */
 int  tmc2_kdtree_build( tmc2_frame* f );
+/* inspection: the permutation nanoflann's build leaves in vind (tree order -> point index), uint32[n], and the
+ * number of tree levels; the search order under distance ties is a function of exactly this permutation */
+int  tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth );
 uint64_t tmc2_frame_point_count( const tmc2_frame* f );
 /* drop every derived result (tree, adjacency, normals, partition, patches, canvases); the points stay in HBM */
 int  tmc2_frame_reset( tmc2_frame* f );

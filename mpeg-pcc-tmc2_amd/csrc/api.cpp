@@ -259,8 +259,26 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
 
 }  // extern "C"
 
+namespace tmc2 {
+// test hook: TMC2_KDTREE_HOST=1 builds the trees with the host builder (kdtree_build.cpp) instead of the device one
+bool kdtreeOnHost() {
+  static const bool v = [] {
+    const char* e = getenv( "TMC2_KDTREE_HOST" );
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+}  // namespace tmc2
+
 int tmc2_frame::ensureTree() {
   if ( haveTree ) return TMC2_OK;
+  if ( !tmc2::kdtreeOnHost() ) {
+    const int sid = ctx->stageBegin( "kdtree_build" );
+    TMC2_TRY( tmc2::buildKdTreeDevice( ctx, d_pts.p, n, d_ptsTree, d_perm, d_nodes, tree.lo, tree.hi, tree.depth ) );
+    ctx->stageEnd( sid );
+    haveTree = true;
+    return TMC2_OK;
+  }
   tmc2::HostGate gate;
   const auto t0 = std::chrono::steady_clock::now();
   tree.build( h_xyz.data(), n );
@@ -294,6 +312,16 @@ int tmc2_kdtree_build( tmc2_frame* f ) {
   if ( !f ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   return f->ensureTree();
+}
+
+int tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth ) {
+  if ( !f || !perm ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( f->ctx );
+  TMC2_TRY( f->ensureTree() );
+  TMC2_HIP( hipMemcpyAsync( perm, f->d_perm.p, f->n * sizeof( uint32_t ), hipMemcpyDeviceToHost, f->ctx->stream ) );
+  TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
+  if ( depth ) *depth = f->tree.depth;
+  return TMC2_OK;
 }
 
 void tmc2_frame_destroy( tmc2_frame* f ) {

@@ -481,8 +481,13 @@ int generateAttributeImages( tmc2_frame* f ) {
                       f->d_pointToPixel.p );
   ctx->stageEnd( sid );
   f->reconCount = M;
-  // ---- tree over the reconstruction (host build, like S1) ------------------------------------------------
-  {
+  // ---- tree over the reconstruction (like S1) --------------------------------------------------------------
+  if ( !kdtreeOnHost() ) {
+    const int kt = ctx->stageBegin( "kdtree_build_recon" );
+    TMC2_TRY( buildKdTreeDevice( ctx, f->d_recon.p, M, f->d_reconTreePts, f->d_reconPerm, f->d_reconNodes, f->reconTree.lo,
+                                 f->reconTree.hi, f->reconTree.depth ) );
+    ctx->stageEnd( kt );
+  } else {
     std::vector<Pt> h_recon( M );
     TMC2_HIP( hipMemcpyAsync( h_recon.data(), f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
@@ -619,19 +624,12 @@ int tmc2_transfer_colors( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
     TreeDev          dev;
   } S, T;
   auto upload = [&]( Side& sd, const int16_t* xyz, uint64_t cnt ) -> int {
-    std::vector<Pt> pts( cnt ), ptsTree( cnt );
+    std::vector<Pt> pts( cnt );
     for ( uint64_t i = 0; i < cnt; ++i ) pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
-    sd.tree.build( xyz, cnt );
-    for ( uint64_t i = 0; i < cnt; ++i ) ptsTree[i] = pts[sd.tree.perm[i]];
     TMC2_TRY( sd.pts.alloc( cnt ) );
-    TMC2_TRY( sd.ptsTree.alloc( cnt ) );
-    TMC2_TRY( sd.perm.alloc( cnt ) );
-    TMC2_TRY( sd.nodes.alloc( sd.tree.nodes.size() ) );
     TMC2_HIP( hipMemcpyAsync( sd.pts.p, pts.data(), cnt * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( sd.ptsTree.p, ptsTree.data(), cnt * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( sd.perm.p, sd.tree.perm.data(), cnt * 4, hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( sd.nodes.p, sd.tree.nodes.data(), sd.tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    TMC2_TRY( buildKdTreeDevice( ctx, sd.pts.p, cnt, sd.ptsTree, sd.perm, sd.nodes, sd.tree.lo, sd.tree.hi, sd.tree.depth ) );
     sd.dev.ptsTree = sd.ptsTree.p, sd.dev.perm = sd.perm.p, sd.dev.nodes = sd.nodes.p;
     for ( int d = 0; d < 3; ++d ) sd.dev.lo[d] = sd.tree.lo[d], sd.dev.hi[d] = sd.tree.hi[d];
     sd.dev.depth = sd.tree.depth, sd.dev.n = cnt;

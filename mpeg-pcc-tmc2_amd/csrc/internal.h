@@ -281,5 +281,8 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
 int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
+bool kdtreeOnHost();
+int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,
+                       DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
 int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );
 }  // namespace tmc2

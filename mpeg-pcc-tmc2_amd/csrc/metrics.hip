@@ -83,19 +83,8 @@ int uploadCloud( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, const do
   for ( size_t i = 0; i < n; ++i ) pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
   TMC2_TRY( dc.pts.alloc( n ) );
   TMC2_HIP( hipMemcpyAsync( dc.pts.p, pts.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-  std::vector<Pt>      ptsTree;
   std::vector<uint8_t> c4;
-  if ( withTree ) {
-    dc.tree.build( xyz, n );
-    ptsTree.resize( n );
-    for ( size_t i = 0; i < n; ++i ) ptsTree[i] = pts[dc.tree.perm[i]];
-    TMC2_TRY( dc.ptsTree.alloc( n ) );
-    TMC2_TRY( dc.perm.alloc( n ) );
-    TMC2_TRY( dc.nodes.alloc( dc.tree.nodes.size() ) );
-    TMC2_HIP( hipMemcpyAsync( dc.ptsTree.p, ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( dc.perm.p, dc.tree.perm.data(), n * 4, hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( dc.nodes.p, dc.tree.nodes.data(), dc.tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
-  }
+  if ( withTree ) TMC2_TRY( buildKdTreeDevice( ctx, dc.pts.p, n, dc.ptsTree, dc.perm, dc.nodes, dc.tree.lo, dc.tree.hi, dc.tree.depth ) );
   if ( rgb ) {
     c4.resize( 4 * n );
     for ( size_t i = 0; i < n; ++i ) c4[4 * i] = rgb[3 * i], c4[4 * i + 1] = rgb[3 * i + 1], c4[4 * i + 2] = rgb[3 * i + 2], c4[4 * i + 3] = 0;

@@ -58,137 +58,161 @@ __device__ __forceinline__ int waveMaxMasked( int v, bool mine ) {
 }
 
 // ---- S7 ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__( 256 ) void ccInitKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ dist,
-                                                        uint32_t thrDetection, uint32_t n, uint32_t* __restrict__ label,
-                                                        uint32_t* __restrict__ ccCount, uint32_t* __restrict__ dirty ) {
+// Connected components of the reference = "smallest eligible seed that reaches v" over the DIRECTED k-NN graph
+// restricted to raw points of one plane.  Pushing labels along edges needs as many dependent steps as
+// the graph is deep (hundreds of hops on a body-sized patch).  Instead:
+//   1. mutual edges (u in knn[v] and v in knn[u]) are bidirectional, so everything they connect is reached by
+//      exactly the same seeds: a lock-free union-find over the mutual edges (hooking with atomicCAS under the root of
+//      smaller HASHED priority -- hooking by index would grow chains as long as the scan order of the cloud -- and
+//      path halving) collapses each such group in O(log) dependent steps;
+//   2. lab[root] = smallest ELIGIBLE member (atomicMin);
+//   3. the remaining one-way edges connect groups; lab[] is relaxed along them until nothing changes -- on the
+//      condensed graph that is a handful of sweeps, each touching only the one-way edges.
+// The result is the unique fixpoint, so it does not depend on scheduling.
+
+// bit j of mutual[u] = knn[u][j] lists u in its own row.  Depends only on the adjacency: once per call.
+template <int K>
+__global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __restrict__ knn, uint32_t n,
+                                                              uint16_t* __restrict__ mutual ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u >= n ) return;
+  uint32_t     nb[K];
+  const uint4* row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
+#pragma unroll
+  for ( int j = 0; j < K / 4; ++j ) {
+    const uint4 r = row[j];
+    nb[4 * j] = r.x, nb[4 * j + 1] = r.y, nb[4 * j + 2] = r.z, nb[4 * j + 3] = r.w;
+  }
+  uint32_t m = 0;
+#pragma unroll
+  for ( int j = 0; j < K; ++j ) {
+    const uint32_t v = nb[j];
+    if ( v == u ) continue;
+    const uint4* rv  = reinterpret_cast<const uint4*>( knn + size_t( v ) * K );
+    bool         hit = false;
+#pragma unroll
+    for ( int t = 0; t < K / 4; ++t ) {
+      const uint4 r = rv[t];
+      hit |= ( r.x == u ) | ( r.y == u ) | ( r.z == u ) | ( r.w == u );
+    }
+    m |= hit ? ( 1u << j ) : 0u;
+  }
+  mutual[u] = uint16_t( m );
+}
+
+__global__ __launch_bounds__( 256 ) void ccInitKernel( uint32_t n, uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
+                                                        uint32_t* __restrict__ ccCount ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  const bool seed = raw[i] && dist[i] > thrDetection;
-  label[i]        = seed ? i : kNoLabel;
-  dirty[i]        = seed ? 1u : 0u;  // a point re-pushes only after its label was lowered
-  ccCount[i]      = 0;
+  parent[i]  = i;
+  lab[i]     = kNoLabel;
+  ccCount[i] = 0;
 }
 
-// One sweep = every labelled raw point (a) shortcuts its label through its seed's own label ("pointer
-// jumping": label[v] = s and label[s] = t < s mean t reaches s reaches v, all inside one plane of the raw
-// subgraph) and (b) pushes its label along its directed k-NN edges.  A workgroup repeats the sweep over its
-// own 256 points while anything inside it still changes (points are stored in a spatially coherent order, so
-// most edges stay inside a few neighbouring workgroups); labels are read with agent-scope atomics so that
-// values pushed by other workgroups through L2 are seen without relying on L1.
-template <int K>
-__global__ __launch_bounds__( 256 ) void ccPropagateKernel( const uint32_t* __restrict__ knn,
-                                                             const uint8_t* __restrict__ partition,
-                                                             const uint8_t* __restrict__ raw, uint32_t n,
-                                                             uint32_t* __restrict__ label, uint32_t* __restrict__ dirty,
-                                                             uint32_t* __restrict__ changed ) {
-  __shared__ int blockChanged;
-  const uint32_t u      = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool     mine   = u < n && raw[u];
-  bool           loaded = false;
-  uint8_t        pu     = 0;
-  uint32_t       nb[K];
-  bool           everChanged = false;
-  for ( int rep = 0; rep < 32; ++rep ) {
-    if ( threadIdx.x == 0 ) blockChanged = 0;
-    __syncthreads();
-    bool any = false;
-    // frontier: only points whose label was lowered since their last push have anything new to say.  The flag is
-    // taken with an atomic exchange so that the label load below is ordered after it (a later lowering re-arms it).
-    if ( mine && atomicExch( &dirty[u], 0u ) ) {
-      if ( !loaded ) {
-        loaded           = true;
-        pu               = partition[u];
-        const uint4* row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
-#pragma unroll
-        for ( int j = 0; j < K / 4; ++j ) {
-          const uint4 r = row[j];
-          nb[4 * j] = r.x, nb[4 * j + 1] = r.y, nb[4 * j + 2] = r.z, nb[4 * j + 3] = r.w;
-        }
-      }
-      uint32_t lu = __hip_atomic_load( &label[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      if ( lu != kNoLabel ) {
-        // pointer jumping: label[u] = s and label[s] = t < s  =>  t reaches s reaches u
-        const uint32_t l2 = __hip_atomic_load( &label[lu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-        if ( l2 < lu ) {
-          atomicMin( &label[u], l2 );
-          lu = l2;
-        }
-#pragma unroll
-        for ( int j = 0; j < K; ++j ) {
-          const uint32_t v = nb[j];
-          if ( v != u && raw[v] && partition[v] == pu && atomicMin( &label[v], lu ) > lu ) {
-            dirty[v] = 1u;
-            any      = true;
-          }
-        }
-      }
-    }
-    if ( any ) blockChanged = 1;
-    everChanged |= any;
-    __syncthreads();
-    if ( !blockChanged ) break;
-    __syncthreads();
+// a parent always has a smaller priority than its child, so the forest stays acyclic and a stale read during find
+// is still an ancestor-or-self of the truth
+__device__ __forceinline__ uint32_t ufPriority( uint32_t x ) { return x * 2654435761u; }  // odd multiplier: a bijection
+__device__ __forceinline__ uint32_t ufFind( uint32_t* parent, uint32_t x ) {
+  uint32_t p = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  while ( p != x ) {
+    const uint32_t g = __hip_atomic_load( &parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( g != p ) __hip_atomic_store( &parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );  // path halving
+    x = p;
+    p = g;
   }
-  if ( everChanged ) *changed = 1;
+  return x;
 }
 
-// Persistent form of the sweep above: a fixed, fully resident grid in which every lane owns a strided set of points
-// and keeps re-visiting them while labels are still moving anywhere on the chip (global activity counter, as in the
-// refinement's closure kernel).  One launch walks the whole propagation front -- hundreds of dependent hops at the
-// cost of an L2 round trip each instead of a kernel launch each.  Retirement is heuristic; the caller always follows
-// with ordinary sweeps, which either confirm the fixpoint (no label changed) or finish the job.
 template <int K>
-__global__ __launch_bounds__( 256 ) void ccPersistentKernel( const uint32_t* __restrict__ knn,
-                                                              const uint8_t* __restrict__ partition,
-                                                              const uint8_t* __restrict__ raw, uint32_t n,
-                                                              uint32_t* __restrict__ label, uint32_t* __restrict__ dirty,
-                                                              uint32_t* __restrict__ activity ) {
-  __shared__ int worked;
-  __shared__ int retire;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  uint32_t       seen   = 0;
-  int            quiet  = 0;
-  for ( int rep = 0; rep < 1000000; ++rep ) {
-    if ( threadIdx.x == 0 ) worked = 0;
-    __syncthreads();
-    bool any = false;
-    for ( uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride ) {
-      if ( !__hip_atomic_load( &dirty[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) continue;
-      if ( !atomicExch( &dirty[u], 0u ) ) continue;
-      uint32_t lu = __hip_atomic_load( &label[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      if ( lu == kNoLabel ) continue;
-      const uint32_t l2 = __hip_atomic_load( &label[lu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      if ( l2 < lu ) {
-        atomicMin( &label[u], l2 );
-        lu = l2;
+__global__ __launch_bounds__( 256 ) void ccUnionKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
+                                                         const uint8_t* __restrict__ partition,
+                                                         const uint8_t* __restrict__ raw, uint32_t n,
+                                                         uint32_t* __restrict__ parent ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u >= n || !raw[u] ) return;
+  uint32_t m = mutual[u];
+  if ( !m ) return;
+  const uint8_t   pu  = partition[u];
+  const uint32_t* row = knn + size_t( u ) * K;
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    const uint32_t v = row[j];
+    if ( v > u || !raw[v] || partition[v] != pu ) continue;  // every mutual edge is seen from both ends: larger one acts
+    uint32_t a = u, b = v;
+    while ( true ) {
+      a = ufFind( parent, a );
+      b = ufFind( parent, b );
+      if ( a == b ) break;
+      if ( ufPriority( a ) < ufPriority( b ) ) {
+        const uint32_t t = a;
+        a                = b;
+        b                = t;
       }
-      const uint8_t pu  = partition[u];
-      const uint4*  row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
-#pragma unroll
-      for ( int j = 0; j < K / 4; ++j ) {
-        const uint4    r    = row[j];
-        const uint32_t v[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for ( int t = 0; t < 4; ++t )
-          if ( v[t] != u && raw[v[t]] && partition[v[t]] == pu && atomicMin( &label[v[t]], lu ) > lu ) {
-            __hip_atomic_store( &dirty[v[t]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-            any = true;
-          }
-      }
+      if ( atomicCAS( &parent[a], a, b ) == a ) break;  // hook the root of larger priority under the other
     }
-    if ( any ) worked = 1;
-    __syncthreads();
-    if ( threadIdx.x == 0 ) {
-      if ( worked ) __hip_atomic_fetch_add( activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      const uint32_t now = __hip_atomic_load( activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      quiet              = ( worked || now != seen ) ? 0 : quiet + 1;
-      seen               = now;
-      retire             = quiet >= 32;
-      if ( !worked ) __builtin_amdgcn_s_sleep( 16 );
-    }
-    __syncthreads();
-    if ( retire ) break;
   }
+}
+
+__global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ dist,
+                                                               uint32_t thrDetection, uint32_t n,
+                                                               uint32_t* __restrict__ parent, uint32_t* __restrict__ lab ) {
+  const uint32_t u    = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63;
+  uint32_t       r    = kNoLabel;
+  bool           seed = false;
+  if ( u < n && raw[u] ) {
+    r = ufFind( parent, u );
+    __hip_atomic_store( &parent[u], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    seed = dist[u] > thrDetection;
+  }
+  // a body-sized group has hundreds of thousands of members: one atomic per wave and group, and only if it can lower
+  unsigned long long todo = __ballot( seed );
+  while ( todo ) {
+    const int                leader = __ffsll( (long long)todo ) - 1;
+    const uint32_t           key    = __shfl( r, leader, 64 );
+    const unsigned long long same   = __ballot( seed && r == key );
+    // lanes are in index order, so the leader (lowest lane of its group) holds the group's smallest index in the wave
+    if ( lane == leader && __hip_atomic_load( &lab[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) > u )
+      atomicMin( &lab[key], u );
+    todo &= ~same;
+  }
+}
+
+// one relaxation sweep over the one-way edges between groups (parent[] is flat here)
+template <int K>
+__global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
+                                                         const uint8_t* __restrict__ partition,
+                                                         const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
+                                                         uint32_t n, uint32_t* __restrict__ lab, uint32_t* __restrict__ changed ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u >= n || !raw[u] ) return;
+  uint32_t m = ~uint32_t( mutual[u] ) & ( ( 1u << K ) - 1u );
+  if ( !m ) return;
+  const uint32_t ru = parent[u];
+  const uint32_t lu = __hip_atomic_load( &lab[ru], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  if ( lu == kNoLabel ) return;
+  const uint8_t   pu  = partition[u];
+  const uint32_t* row = knn + size_t( u ) * K;
+  bool            any = false;
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    const uint32_t v = row[j];
+    if ( v == u || !raw[v] || partition[v] != pu ) continue;
+    const uint32_t rv = parent[v];
+    if ( rv != ru && __hip_atomic_load( &lab[rv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) > lu &&
+         atomicMin( &lab[rv], lu ) > lu )
+      any = true;
+  }
+  if ( any ) *changed = 1;
+}
+
+__global__ __launch_bounds__( 256 ) void ccLabelKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
+                                                         const uint32_t* __restrict__ lab, uint32_t n,
+                                                         uint32_t* __restrict__ label ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u < n ) label[u] = raw[u] ? lab[parent[u]] : kNoLabel;
 }
 
 __global__ __launch_bounds__( 256 ) void ccCountKernel( const uint32_t* __restrict__ label, uint32_t n,
@@ -570,14 +594,17 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_TRY( ctx->voxelBitmap.alloc( bitmapWords ) );
   TMC2_HIP( hipMemsetAsync( ctx->voxelBitmap.p, 0, bitmapWords * 4, s ) );
 
-  DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_dirty;
+  DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_lab;
+  DevBuf<uint16_t> d_mutual;
   DevBuf<uint8_t>  d_raw;
   DevBuf<int32_t>  d_pointPatch, d_patchView, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
   DevBuf<int>      d_offsets;
   DevBuf<PatchDev> d_patches;
   DevBuf<unsigned long long> d_map64;
   TMC2_TRY( d_label.alloc( n ) );
-  TMC2_TRY( d_dirty.alloc( n ) );
+  TMC2_TRY( d_parent.alloc( n ) );
+  TMC2_TRY( d_lab.alloc( n ) );
+  TMC2_TRY( d_mutual.alloc( n ) );
   TMC2_TRY( d_ccCount.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
   TMC2_TRY( d_rank.alloc( n ) );
@@ -596,36 +623,38 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
   uint32_t   rawCount = n;
   int        rounds   = 0;
-  const int  sidCC = -1;
-  (void)sidCC;
+  {
+    const int kt = ctx->stageBegin( "k:ccMutualMask" );
+    hipLaunchKernelGGL( ccMutualMaskKernel<16>, grdN, blk, 0, s, f->d_knn.p, n, d_mutual.p );
+    ctx->stageEnd( kt );
+  }
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );
-    hipLaunchKernelGGL( ccInitKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_label.p, d_ccCount.p, d_dirty.p );
+    hipLaunchKernelGGL( ccInitKernel, grdN, blk, 0, s, n, d_parent.p, d_lab.p, d_ccCount.p );
     {
-      // the bulk of the propagation in ONE persistent launch (grid sized to be fully co-resident)
-      const uint32_t persistentBlocks = uint32_t( std::min<size_t>( ( n + 255 ) / 256, size_t( ctx->cuCount ) * 4 ) );
-      TMC2_HIP( hipMemsetAsync( d_small.p + 3, 0, 4, s ) );
-      const int kt = ctx->stageBegin( "k:ccPersistent" );
-      hipLaunchKernelGGL( ccPersistentKernel<16>, dim3( persistentBlocks ), blk, 0, s, f->d_knn.p, f->d_partition.p, d_raw.p, n,
-                          d_label.p, d_dirty.p, d_small.p + 3 );
+      const int kt = ctx->stageBegin( "k:ccUnionFind" );
+      hipLaunchKernelGGL( ccUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
+                          d_parent.p );
+      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p );
       ctx->stageEnd( kt );
     }
     for ( int guard = 0; guard < 1 << 20; ++guard ) {
       // a few sweeps per host round-trip; the flag is cleared before the LAST sweep of the batch only,
       // so "unchanged" means the final sweep of the batch changed nothing (= fixpoint)
-      for ( int b = 0; b < 2; ++b ) {
-        if ( b == 1 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
-        const int kt = ctx->stageBegin( "k:ccPropagate" );
-        hipLaunchKernelGGL( ccPropagateKernel<16>, grdN, blk, 0, s, f->d_knn.p, f->d_partition.p, d_raw.p, n, d_label.p,
-                            d_dirty.p, d_small.p );
-        ctx->stageEnd( kt );
+      const int kt = ctx->stageBegin( "k:ccRelax" );
+      for ( int b = 0; b < 3; ++b ) {
+        if ( b == 2 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
+        hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
+                            d_parent.p, n, d_lab.p, d_small.p );
       }
+      ctx->stageEnd( kt );
       uint32_t changed = 0;
       TMC2_HIP( hipMemcpyAsync( &changed, d_small.p, 4, hipMemcpyDeviceToHost, s ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
       if ( !changed ) break;
     }
+    hipLaunchKernelGGL( ccLabelKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p );
     hipLaunchKernelGGL( ccCountKernel, grdN, blk, 0, s, d_label.p, n, d_ccCount.p );
     hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
                         uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );

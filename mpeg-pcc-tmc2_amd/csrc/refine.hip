@@ -16,7 +16,8 @@
 //     wave prefix sum of member counts for the 1024-point truncation (:1484-1501).
 //   * each sweep is Jacobi in the histograms (they are refreshed only at the end of a sweep); the only
 //     sequential coupling is the INDIRECT_EDGE marking, visible to later voxels of the same sweep
-//     (:1513, :1528-1532).  It is a monotone closure in voxel-index order, solved by a short fixpoint loop.
+//     (:1513, :1528-1532).  It is reachability in a static DAG (voxel-index order): one data-parallel round from the
+//     voxels active at sweep start, then a single workgroup drains the dependent tail from a queue (exact, no polling).
 //   * per-point re-scoring is one coalesced pass over the points (voxel id, 24 B normal, 1 B label).
 // Scores are fp64: (n . o_k) + w_v * S_k with the products/sums in the reference's order, no FMA.
 #include <algorithm>
@@ -248,10 +249,16 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
 
 // ---- sweep kernels ----------------------------------------------------------------------------------
 // S[v] = sum of the neighbourhood's histograms (u16 lanes), arg[v] = first maximum.  One wave per voxel.
+// UPDATE = true also closes the PREVIOUS sweep for voxel v (refresh edge class / ppi of re-scored voxels, apply the
+// INDIRECT marks, arm `active`): that only reads hist[v] and nothing here writes histograms, so it rides along.
+template <bool UPDATE>
 __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__ hist, const uint32_t* __restrict__ adjOff,
                                                         const uint32_t* __restrict__ rowLen,
                                                         const uint32_t* __restrict__ adj, uint32_t V,
-                                                        uint4* __restrict__ S, uint8_t* __restrict__ arg ) {
+                                                        uint4* __restrict__ S, uint8_t* __restrict__ arg,
+                                                        const uint8_t* __restrict__ proc, uint8_t* __restrict__ edge,
+                                                        uint8_t* __restrict__ ppi, uint32_t* __restrict__ active,
+                                                        uint8_t* __restrict__ marked ) {
   const int      lane = threadIdx.x & 63;
   const uint32_t v    = blockIdx.x * 4 + ( threadIdx.x >> 6 );
   if ( v >= V ) return;
@@ -278,65 +285,174 @@ __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__
     int nz, a;
     classify( b, nz, a );
     arg[v] = uint8_t( a );
+    if ( UPDATE ) {
+      uint8_t e = edge[v];
+      if ( proc[v] ) {
+        unpackHist( hist[v], b );
+        classify( b, nz, a );
+        if ( e != S_DIRECT_EDGE ) e = ( nz == 1 ) ? NO_EDGE : M_DIRECT_EDGE;
+        ppi[v] = uint8_t( a );
+      } else if ( marked[v] && e == NO_EDGE ) {
+        e = INDIRECT_EDGE;
+      }
+      edge[v]   = e;
+      active[v] = e != NO_EDGE;
+      marked[v] = 0;
+    }
   }
 }
 
-// INDIRECT-edge closure.  Every active voxel u marks the uniform DEV neighbours that disagree with arg[u]; a marked
+// INDIRECT-edge closure.  Every active voxel u marks the uniform DEV neighbours v that disagree with arg[u]; a marked
 // neighbour with a LARGER index becomes active in this sweep and must mark in turn (the reference's in-order loop).
-// That is reachability in a DAG whose chains can be tens of voxels deep, so the kernel is persistent: every workgroup
-// (all are co-resident: V/256 <= 2048) keeps polling its 256 voxels for activations arriving through L2 and bumps a
-// global activity counter whenever it did work; a workgroup retires once that counter has been quiet for a window
-// much longer than a cross-CU hand-off.  Retirement is a heuristic, not a proof -- VERIFY = true re-checks the
-// fixpoint and raises a sticky flag, on which the host replays the sweeps with the host-checked loop.
-template <bool VERIFY>
-__global__ __launch_bounds__( 256 ) void closureKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                         const uint8_t* __restrict__ arg,
-                                                         const uint32_t* __restrict__ adjOff,
-                                                         const uint32_t* __restrict__ devLen,
-                                                         const uint32_t* __restrict__ adj, uint32_t V,
-                                                         uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
-                                                         uint32_t* __restrict__ unconverged, uint32_t* __restrict__ activity ) {
-  __shared__ int  worked;
-  __shared__ int  retire;
-  const uint32_t  u     = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool      valid = u < V;
-  const uint32_t* row   = valid ? adj + adjOff[u] : nullptr;
-  const uint32_t  len   = valid ? devLen[u] : 0;
-  const uint8_t   a     = valid ? arg[u] : 0;
-  bool            done  = false;  // this voxel has issued its marks
-  uint32_t        seen  = 0;      // thread 0: last observed value of the activity counter
-  int             quiet = 0;      // thread 0: consecutive polls without local work or global activity
-  for ( int rep = 0; rep < 100000; ++rep ) {
-    if ( threadIdx.x == 0 ) worked = 0;
-    __syncthreads();
-    if ( valid && !done && __hip_atomic_load( &active[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) {
-      done = true;
-      for ( uint32_t i = 0; i < len; ++i ) {
-        const uint32_t v = row[i];
-        if ( edge[v] == NO_EDGE && ppi[v] != a ) {
-          if ( VERIFY ) {
-            if ( v > u && !__hip_atomic_load( &active[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) *unconverged = 1;
-          } else {
-            marked[v] = 1;
-            if ( v > u ) __hip_atomic_store( &active[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+// edge / ppi / arg are frozen during the closure, so the "u marks v" relation is a static DAG:
+//   round 0 (closureRoundZeroKernel, all voxels, 32 lanes per voxel): out[u] = compact list of the voxels u would
+//            mark; the voxels active at sweep start issue their marks and flag what they newly activate in a bitmap;
+//   tail    (closureTailKernel, ONE workgroup): walks the dependent hops level by level with the active / frontier
+//            bitmaps in LDS, so a hop costs one global load (the 16-byte head of out[u]) instead of a chain of them.
+//            The tail has next to no parallelism, so one workgroup loses nothing, needs no cross-workgroup polling,
+//            terminates exactly when the frontier is empty, and leaves the rest of the chip to the other frames.
+constexpr uint32_t kDevPad = 0xFFFFFFFFu;
+
+// dev[u][0..31]: the DEV candidates of u (Chebyshev <= 1: a prefix of its neighbourhood row), padded.  Static.
+__global__ __launch_bounds__( 256 ) void devTableKernel( const uint32_t* __restrict__ adjOff, const uint32_t* __restrict__ devLen,
+                                                          const uint32_t* __restrict__ adj, uint32_t V,
+                                                          uint32_t* __restrict__ dev ) {
+  const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
+  const uint32_t lane = threadIdx.x & 31;
+  if ( u >= V ) return;
+  dev[size_t( u ) * 32 + lane] = lane < devLen[u] ? adj[adjOff[u] + lane] : kDevPad;
+}
+
+__global__ __launch_bounds__( 256 ) void closureRoundZeroKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
+                                                                  const uint8_t* __restrict__ arg,
+                                                                  const uint32_t* __restrict__ dev, uint32_t V,
+                                                                  uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
+                                                                  uint32_t* __restrict__ out, uint32_t* __restrict__ activeBits,
+                                                                  uint32_t* __restrict__ frontierBits ) {
+  const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
+  const uint32_t lane = threadIdx.x & 31;
+  const int      half = ( threadIdx.x >> 5 ) & 1;
+  if ( u >= V ) return;
+  const uint32_t v    = dev[size_t( u ) * 32 + lane];
+  const uint8_t  a    = arg[u];
+  const bool     pred = v != kDevPad && edge[v] == NO_EDGE && ppi[v] != a;
+  const uint32_t m    = uint32_t( __ballot( pred ) >> ( 32 * half ) );
+  if ( pred ) out[size_t( u ) * 32 + 1 + __popc( m & ( ( 1u << lane ) - 1u ) )] = v;
+  if ( lane == 0 ) out[size_t( u ) * 32] = uint32_t( __popc( m ) );
+  // a voxel activated by a lower one during this very kernel may or may not be seen here; either way it is in the
+  // frontier bitmap, and being handled twice is harmless -- marking is idempotent
+  if ( !__hip_atomic_load( &active[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) return;
+  if ( lane == 0 ) atomicOr( &activeBits[u >> 5], 1u << ( u & 31 ) );
+  if ( pred ) {
+    marked[v] = 1;
+    if ( v > u && atomicExch( &active[v], 1u ) == 0u ) {
+      atomicOr( &activeBits[v >> 5], 1u << ( v & 31 ) );
+      atomicOr( &frontierBits[v >> 5], 1u << ( v & 31 ) );
+    }
+  }
+}
+
+__global__ __launch_bounds__( 1024 ) void closureTailKernel( const uint32_t* __restrict__ out, uint32_t W,
+                                                              uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
+                                                              uint32_t* __restrict__ activeBits,
+                                                              uint32_t* __restrict__ frontierBits ) {
+  extern __shared__ uint32_t lds[];
+  uint32_t *      act = lds, *fr = lds + W, *nx = lds + 2 * size_t( W );
+  __shared__ int  any;
+  for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
+    act[w] = activeBits[w];
+    fr[w]  = frontierBits[w];
+    nx[w]  = 0;
+    if ( fr[w] ) frontierBits[w] = 0;  // both bitmaps are handed back empty for the next sweep
+    if ( act[w] ) activeBits[w] = 0;
+  }
+  if ( threadIdx.x == 0 ) any = 0;
+  __syncthreads();
+  while ( true ) {
+    bool mine = false;
+    for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
+      uint32_t bits = fr[w];
+      while ( bits ) {
+        const uint32_t u = w * 32 + uint32_t( __ffs( int( bits ) ) - 1 );
+        bits &= bits - 1;
+        const uint32_t* row  = out + size_t( u ) * 32;
+        const uint4     head = *reinterpret_cast<const uint4*>( row );  // count + the first three targets
+        const uint32_t  cnt  = head.x;
+        for ( uint32_t k = 0; k < cnt; ++k ) {
+          const uint32_t v = k == 0 ? head.y : ( k == 1 ? head.z : ( k == 2 ? head.w : row[1 + k] ) );
+          marked[v]        = 1;
+          if ( v > u ) {
+            const uint32_t bit = 1u << ( v & 31 );
+            if ( !( atomicOr( &act[v >> 5], bit ) & bit ) ) {
+              active[v] = 1u;
+              atomicOr( &nx[v >> 5], bit );
+              mine = true;
+            }
           }
         }
       }
-      worked = 1;
     }
+    if ( mine ) any = 1;
     __syncthreads();
-    if ( VERIFY ) break;
-    if ( threadIdx.x == 0 ) {
-      if ( worked ) __hip_atomic_fetch_add( activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      const uint32_t now = __hip_atomic_load( activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      quiet              = ( worked || now != seen ) ? 0 : quiet + 1;
-      seen               = now;
-      retire             = quiet >= 48;
-      if ( !worked ) __builtin_amdgcn_s_sleep( 16 );
+    const bool more = any != 0;
+    __syncthreads();
+    if ( !more ) break;
+    for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
+      fr[w] = nx[w];
+      nx[w] = 0;
     }
+    if ( threadIdx.x == 0 ) any = 0;
     __syncthreads();
-    if ( retire ) break;
   }
+}
+
+// fallback of the tail for grids whose bitmaps do not fit the LDS: same walk, bitmaps in global memory
+__global__ __launch_bounds__( 1024 ) void closureTailGlobalKernel( const uint32_t* __restrict__ out, uint32_t W,
+                                                                    uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
+                                                                    uint32_t* __restrict__ activeBits,
+                                                                    uint32_t* __restrict__ frontierBits,
+                                                                    uint32_t* __restrict__ nextBits ) {
+  __shared__ int any;
+  uint32_t*      fr = frontierBits;
+  uint32_t*      nx = nextBits;
+  if ( threadIdx.x == 0 ) any = 0;
+  __syncthreads();
+  while ( true ) {
+    bool mine = false;
+    for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
+      uint32_t bits = __hip_atomic_load( &fr[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( bits ) __hip_atomic_store( &fr[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      while ( bits ) {
+        const uint32_t u = w * 32 + uint32_t( __ffs( int( bits ) ) - 1 );
+        bits &= bits - 1;
+        const uint32_t* row = out + size_t( u ) * 32;
+        const uint32_t  cnt = row[0];
+        for ( uint32_t k = 0; k < cnt; ++k ) {
+          const uint32_t v = row[1 + k];
+          marked[v]        = 1;
+          if ( v > u ) {
+            const uint32_t bit = 1u << ( v & 31 );
+            if ( !( atomicOr( &activeBits[v >> 5], bit ) & bit ) ) {
+              active[v] = 1u;
+              atomicOr( &nx[v >> 5], bit );
+              mine = true;
+            }
+          }
+        }
+      }
+    }
+    if ( mine ) any = 1;
+    __syncthreads();
+    const bool more = any != 0;
+    __syncthreads();
+    if ( !more ) break;
+    uint32_t* t = fr;
+    fr          = nx;
+    nx          = t;
+    if ( threadIdx.x == 0 ) any = 0;
+    __syncthreads();
+  }
+  for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) activeBits[w] = 0;
 }
 
 // proc[v] = voxel is re-scored this sweep; its histogram is zeroed for re-accumulation
@@ -391,29 +507,6 @@ __global__ __launch_bounds__( 256 ) void rescorePointsKernel( const uint32_t* __
   }
   partition[j] = uint8_t( best );
   atomicAdd( &hist[4 * size_t( v ) + ( best >> 1 )], 1u << ( 16 * ( best & 1 ) ) );
-}
-
-// end of sweep: refresh edge class / ppi of re-scored voxels, apply INDIRECT marks, arm the next sweep
-__global__ __launch_bounds__( 256 ) void updateVoxelKernel( const uint4* __restrict__ hist, const uint8_t* __restrict__ proc,
-                                                             uint32_t V, uint8_t* __restrict__ edge,
-                                                             uint8_t* __restrict__ ppi, uint32_t* __restrict__ active,
-                                                             uint8_t* __restrict__ marked ) {
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( v >= V ) return;
-  uint8_t e = edge[v];
-  if ( proc[v] ) {
-    uint32_t b[6];
-    unpackHist( hist[v], b );
-    int nz, a;
-    classify( b, nz, a );
-    if ( e != S_DIRECT_EDGE ) e = ( nz == 1 ) ? NO_EDGE : M_DIRECT_EDGE;
-    ppi[v] = uint8_t( a );
-  } else if ( marked[v] && e == NO_EDGE ) {
-    e = INDIRECT_EDGE;
-  }
-  edge[v]   = e;
-  active[v] = e != NO_EDGE;
-  marked[v] = 0;
 }
 
 }  // namespace
@@ -532,69 +625,40 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   TMC2_HIP( hipGetLastError() );
 
   const int sidSweep = ctx->stageBegin( "refine_sweeps" );
-  uint32_t* d_changed = d_small.p + 2;
-  // The INDIRECT-edge closure needs a fixpoint per sweep.  Asking the host after every closure step would cost
-  // ~100 stream round-trips per frame, so the sweeps are queued with a FIXED number of closure steps plus one
-  // more step that only records (sticky flag) whether it still changed anything.  The flag is read once, after
-  // the last sweep; in the rare case it is set, the sweeps are replayed from the saved partition with the
-  // exact host-checked loop.
-  DevBuf<uint8_t> d_partBackup;
-  TMC2_TRY( d_partBackup.alloc( n ) );
-  TMC2_HIP( hipMemcpyAsync( d_partBackup.p, f->d_partition.p, n, hipMemcpyDeviceToDevice, s ) );
-  auto runSweeps = [&]( int closureSteps ) -> int {  // closureSteps < 0: exact, host-checked
-    for ( int iter = 0; iter < iterationCount; ++iter ) {
-      int kt = ctx->stageBegin( "k:refineSmooth" );
-      hipLaunchKernelGGL( smoothKernel, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg );
-      ctx->stageEnd( kt );
-      if ( closureSteps < 0 ) {
-        for ( int guard = 0; guard < 1 << 20; ++guard ) {
-          hipLaunchKernelGGL( closureKernel<false>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                              d_active, d_marked, d_changed + 1, d_small.p + 4 );
-          TMC2_HIP( hipMemsetAsync( d_changed, 0, 4, s ) );
-          hipLaunchKernelGGL( closureKernel<true>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                              d_active, d_marked, d_changed, d_small.p + 4 );
-          uint32_t changed = 0;
-          TMC2_HIP( hipMemcpyAsync( &changed, d_changed, 4, hipMemcpyDeviceToHost, s ) );
-          TMC2_HIP( hipStreamSynchronize( s ) );
-          if ( !changed ) break;
-        }
-      } else {
-        for ( int c = 0; c < closureSteps; ++c )
-          hipLaunchKernelGGL( closureKernel<false>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                              d_active, d_marked, d_changed + 1, d_small.p + 4 );
-        hipLaunchKernelGGL( closureKernel<true>, grdV, blk, 0, s, d_edge, d_ppi, d_arg, d_adjOff.p, d_devLen.p, d_adj.p, V,
-                            d_active, d_marked, d_changed /* sticky */, d_small.p + 4 );
-      }
-      hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
-                          reinterpret_cast<uint4*>( d_hist.p ) );
-      kt = ctx->stageBegin( "k:refineRescorePoints" );
-      hipLaunchKernelGGL( rescorePointsKernel, grdN, blk, 0, s, d_vid.p, f->d_normals.p, d_proc, d_S.p, d_weight.p, n,
-                          f->d_partition.p, d_hist.p );
-      ctx->stageEnd( kt );
-      hipLaunchKernelGGL( updateVoxelKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_proc, V,
-                          d_edge, d_ppi, d_active, d_marked );
-    }
-    return TMC2_OK;
-  };
-  TMC2_HIP( hipMemsetAsync( d_changed, 0, 12, s ) );  // sticky flag, scratch word, activity counter
-  int closureSteps = 1;
-  if ( const char* e = getenv( "TMC2_REFINE_CLOSURE_STEPS" ) ) closureSteps = std::max( 0, atoi( e ) );  // test hook
-  TMC2_TRY( runSweeps( closureSteps ) );
-  uint32_t unconverged = 0;
-  TMC2_HIP( hipMemcpyAsync( &unconverged, d_changed, 4, hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
-  if ( unconverged ) {
-    // replay exactly: restore the partition and the voxel state derived from it
-    TMC2_HIP( hipMemcpyAsync( f->d_partition.p, d_partBackup.p, n, hipMemcpyDeviceToDevice, s ) );
-    TMC2_HIP( hipMemsetAsync( d_hist.p, 0, size_t( V ) * 16, s ) );
-    TMC2_HIP( hipMemsetAsync( d_state.p, 0, size_t( V ) * 6, s ) );
-    hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
-                        d_hist.p );
-    hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
-                        d_edge, d_ppi, d_active );
-    ctx->stageAddHostMs( "refine_closure_replays", 0.0 );
-    TMC2_TRY( runSweeps( -1 ) );
+  DevBuf<uint32_t> d_dev, d_out, d_bits;
+  const uint32_t   W = ( V + 31 ) / 32;
+  TMC2_TRY( d_dev.alloc( size_t( V ) * 32 ) );
+  TMC2_TRY( d_out.alloc( size_t( V ) * 32 ) );
+  TMC2_TRY( d_bits.alloc( 3 * size_t( W ) ) );
+  uint32_t *d_activeBits = d_bits.p, *d_frontierBits = d_bits.p + W, *d_nextBits = d_bits.p + 2 * size_t( W );
+  TMC2_HIP( hipMemsetAsync( d_bits.p, 0, 3 * size_t( W ) * 4, s ) );
+  const dim3 grdV32( ( V + 7 ) / 8 );
+  hipLaunchKernelGGL( devTableKernel, grdV32, blk, 0, s, d_adjOff.p, d_devLen.p, d_adj.p, V, d_dev.p );
+  const size_t tailLds   = 3 * size_t( W ) * 4;
+  const bool   tailInLds = tailLds <= 128 * 1024;
+  if ( tailInLds && tailLds > 48 * 1024 )
+    TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureTailKernel ),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, int( tailLds ) ) );
+  for ( int iter = 0; iter < iterationCount; ++iter ) {
+    if ( iter == 0 )
+      hipLaunchKernelGGL( smoothKernel<false>, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked );
+    else
+      hipLaunchKernelGGL( smoothKernel<true>, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked );
+    hipLaunchKernelGGL( closureRoundZeroKernel, grdV32, blk, 0, s, d_edge, d_ppi, d_arg, d_dev.p, V, d_active, d_marked,
+                        d_out.p, d_activeBits, d_frontierBits );
+    if ( tailInLds )
+      hipLaunchKernelGGL( closureTailKernel, dim3( 1 ), dim3( 1024 ), tailLds, s, d_out.p, W, d_active, d_marked,
+                          d_activeBits, d_frontierBits );
+    else
+      hipLaunchKernelGGL( closureTailGlobalKernel, dim3( 1 ), dim3( 1024 ), 0, s, d_out.p, W, d_active, d_marked,
+                          d_activeBits, d_frontierBits, d_nextBits );
+    hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
+                        reinterpret_cast<uint4*>( d_hist.p ) );
+    hipLaunchKernelGGL( rescorePointsKernel, grdN, blk, 0, s, d_vid.p, f->d_normals.p, d_proc, d_S.p, d_weight.p, n,
+                        f->d_partition.p, d_hist.p );
+    // the voxel-state update of this sweep rides in the next sweep's smoothKernel; after the last sweep nobody reads it
   }
   ctx->stageEnd( sidSweep );
   TMC2_HIP( hipGetLastError() );

@@ -189,6 +189,13 @@ class Frame:
     def kdtree_build(self):
         _check(self.L.tmc2_kdtree_build(self.h))
 
+    def kdtree_order(self):
+        """(perm, depth): the permutation the tree build leaves behind (tree order -> point index) and the levels."""
+        perm = np.empty(self.n, np.uint32)
+        depth = C.c_int32()
+        _check(self.L.tmc2_frame_get_kdtree_order(self.h, _ptr(perm), C.byref(depth)))
+        return perm, depth.value
+
     def device_images(self):
         """Device addresses + shapes of the canvases (for RCCL hand-off): dict name -> (ptr, shape, typestr)."""
         W, H, p = self._canvas

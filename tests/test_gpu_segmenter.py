@@ -77,6 +77,33 @@ def test_gpu_knn_edge_cases(gpu_ctx, oracle):
         gpu_ctx.frame(xyz[:5]).kdtree_search(xyz[:5], 16)                         # k > n is an error, not UB
 
 
+@pytest.mark.parametrize("case", ["tiny", "small", "medium", "longdress_vox10", "line", "plane", "duplicates", "eleven"])
+def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, case):
+    """The level-parallel device build must leave exactly the permutation of nanoflann's recursive build (the oracle's
+    restatement for the small clouds, the library's host builder -- itself pinned to the oracle on CPU -- for all)."""
+    rng = np.random.default_rng(5)
+    if case == "line":                               # every split degenerates to one dimension, long equal runs
+        xyz = np.zeros((5000, 3), np.int16); xyz[:, 1] = rng.integers(0, 40, 5000)
+    elif case == "plane":
+        xyz = rng.integers(0, 64, (20000, 3)).astype(np.int16); xyz[:, 2] = 7
+    elif case == "duplicates":                       # count/2 fallback: everything equal to the cut
+        xyz = np.repeat(rng.integers(0, 1024, (40, 3)).astype(np.int16), 300, axis=0)
+    elif case == "eleven":                           # smallest cloud that splits
+        xyz = rng.integers(0, 1024, (11, 3)).astype(np.int16)
+    else:
+        xyz, _ = synth_cloud(case)
+    fr = gpu_ctx.frame(xyz)
+    perm, depth = fr.kdtree_order()
+    hperm, _, hdepth = T.host_kdtree_build(xyz)
+    assert np.array_equal(perm, hperm) and depth == hdepth
+    if len(xyz) <= 300000:
+        assert np.array_equal(perm, oracle.kdtree_perm(xyz)[0])
+    q = xyz[rng.integers(0, len(xyz), 2000)]
+    k = min(16, len(xyz))
+    if len(xyz) <= 300000:
+        assert np.array_equal(fr.kdtree_search(q, k), oracle.knn(xyz, q, k))
+
+
 def test_gpu_full_size_properties(gpu_ctx):
     """BASELINE-size frame (~0.8 M points): size-independent properties instead of the (slow) oracle."""
     xyz, rgb = synth_cloud("longdress_vox10")
@@ -194,17 +221,16 @@ def test_gpu_segmenter_full_size_properties(gpu_ctx):
     assert total > 0.6 * len(xyz)          # D0 pixels alone cover most of the cloud (the rest are D1 / in-between points)
 
 
-def test_gpu_refine_closure_replay_path(gpu_ctx, oracle, monkeypatch):
-    """With zero queued closure steps the convergence check trips and the exact host-checked replay runs."""
-    monkeypatch.setenv("TMC2_REFINE_CLOSURE_STEPS", "0")
+def test_gpu_refine_many_sweeps(gpu_ctx, oracle):
+    """50 sweeps (the longdress setting): the INDIRECT-edge closure chains get their full depth and the per-sweep
+    voxel-state update rides in the following sweep -- the partition must still match the in-order reference loop."""
     xyz, rgb = synth_cloud("small")
     nrm = oracle.normals(xyz)
     w = oracle.weight_normal(xyz)
     p0 = oracle.initial_segmentation(nrm, w)
-    fr = gpu_ctx.frame(xyz, rgb)
-    fr.set_normals(nrm)
-    fr.set_partition(p0)
-    gpu_ctx.stage_reset()
-    fr.segmenter_refine_grid_based(1024, 3.0, 10, 4, 192)
-    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10))
-    assert gpu_ctx.stage_calls().get("refine_closure_replays", 0) >= 1
+    for iters in (1, 2, 50):
+        fr = gpu_ctx.frame(xyz, rgb)
+        fr.set_normals(nrm)
+        fr.set_partition(p0)
+        fr.segmenter_refine_grid_based(1024, 3.0, iters, 4, 192)
+        assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=iters)), iters
