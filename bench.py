@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--workload", default="longdress_vox10")
     ap.add_argument("--workers", type=int, default=0, help="concurrent frames per GPU (0 = auto)")
     ap.add_argument("--host-steps", type=int, default=16, help="max concurrent host-resident steps (tree build, orientation)")
+    ap.add_argument("--kdtree", default="auto", choices=["auto", "device", "host"],
+                    help="where the k-d trees are built (auto: host when >= 8 frames are in flight per GPU, else device)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
@@ -110,7 +112,10 @@ def main():
     sharder = T.Sharder(rank, world, dist, "cuda:%d" % local)
     workers = a.workers or max(1, min(len(clouds), 32, (os.cpu_count() or 8) // world))
     T.load_library().tmc2_set_host_parallelism(max(1, a.host_steps // world))
-    enc = T.GofEncoder(local, workers, a.iterations, 11, 4, 1280, 1280, timing=True)
+    # many frames in flight and idle host cores: the (exact) host k-d tree builder leaves the GPU to the other stages
+    kd_host = a.kdtree == "host" or (a.kdtree == "auto" and workers >= 8)
+    T.load_library().tmc2_set_kdtree_placement(1 if kd_host else 0)
+    enc = T.GofEncoder(local, workers, a.iterations, 11, 4, 1280, 1280, timing=True, first_domain=rank * workers)
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
 
@@ -133,9 +138,8 @@ def main():
         # resident canvases.  Finished canvases -> rank 0 -> host memory, where the video encoder reads them.
         enc.phase_b(frames)
         if world == 1:
-            for fr, (gbuf, abuf) in zip(frames, host_out(W, H)):
-                fr.get_geometry_images(gbuf)
-                fr.get_attribute_images(abuf)
+            bufs = host_out(W, H)
+            enc.per_frame(frames, lambda fr, i: (fr.get_geometry_images(bufs[i][0]), fr.get_attribute_images(bufs[i][1])))
         else:
             for fr in frames:
                 g = sharder.gather(enc.device_tensor(fr, "geometry"))

@@ -1,5 +1,6 @@
 // api.cpp -- extern "C" surface of libtmc2hip.so (see include/tmc2hip.h for the reference seams).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -260,14 +261,18 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
 }  // extern "C"
 
 namespace tmc2 {
-// test hook: TMC2_KDTREE_HOST=1 builds the trees with the host builder (kdtree_build.cpp) instead of the device one
+// where the k-d trees are built (tmc2_set_kdtree_placement; TMC2_KDTREE_HOST=1 presets "host")
+static std::atomic<int> g_kdtreeOnHost{-1};
 bool kdtreeOnHost() {
-  static const bool v = [] {
+  int v = g_kdtreeOnHost.load( std::memory_order_relaxed );
+  if ( v < 0 ) {
     const char* e = getenv( "TMC2_KDTREE_HOST" );
-    return e && e[0] == '1';
-  }();
-  return v;
+    v             = ( e && e[0] == '1' ) ? 1 : 0;
+    g_kdtreeOnHost.store( v, std::memory_order_relaxed );
+  }
+  return v != 0;
 }
+void setKdtreeOnHost( bool host ) { g_kdtreeOnHost.store( host ? 1 : 0, std::memory_order_relaxed ); }
 }  // namespace tmc2
 
 int tmc2_frame::ensureTree() {
@@ -323,6 +328,8 @@ int tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth )
   if ( depth ) *depth = f->tree.depth;
   return TMC2_OK;
 }
+
+void tmc2_set_kdtree_placement( int onHost ) { tmc2::setKdtreeOnHost( onHost != 0 ); }
 
 void tmc2_frame_destroy( tmc2_frame* f ) {
   if ( !f ) return;

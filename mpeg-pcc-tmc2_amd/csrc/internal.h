@@ -182,6 +182,7 @@ struct tmc2_ctx {
   int                           device = 0;
   tmc2::DevicePool              pool;
   tmc2::PinnedBuf               hostA, hostB, hostC, hostD, hostE;  // staging for the host-side steps
+  std::vector<int32_t>          orientScratch;                      // per-vertex state of the orientation walk
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
@@ -274,6 +275,10 @@ TreeDev frameTree( const tmc2_frame* f );
 int generateAttributeImages( tmc2_frame* f );
 int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
+int launchEdgeDots( tmc2_frame* f, double* d_edgeDot );
+int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount );
+void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
+                              const double* edgeDot, int8_t* sign, void* scratch );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
 int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp );

@@ -19,8 +19,13 @@
 //   * children: node ids and next-level slots from atomic counters (ids are arbitrary: the traversal follows explicit
 //     child ids; only the ROOT must be node 0), loose boxes handed down, and each child reports its tight range to
 //     the parent's divlow / divhigh when it is measured at the next level.
-// Cost: ~12 short launches per level over <= n points, depth ~ 2 log2(n/10) levels; no host work except one 8-byte
-// read-back per level once termination becomes possible.
+// A level is nine short launches (two of them single-block scans of the tile totals) over <= n points, a tree ~25
+// levels.  Per-node quantities that cost a handful of loads (split rule, sweep limits) are re-derived per point rather
+// than materialised by extra per-node launches.  Termination needs the host only from the level on at which the tree
+// CAN end (10 * 2^level >= n), and then once per three levels (launches past the last level find nothing to do).
+// (A single persistent launch with grid-wide barriers was measured too: on this multi-XCD part every barrier is an L2
+// write-back + invalidate per workgroup, ~45 us per pass, and the builds of concurrent frames serialise.  Separate
+// launches leave the gaps of one frame to the passes of the others.)
 #include <algorithm>
 
 #include "internal.h"
@@ -28,197 +33,83 @@
 namespace tmc2 {
 namespace {
 
-constexpr uint32_t kNone     = 0xFFFFFFFFu;
-constexpr int      kScanTile = 2048;  // 256 threads x 8
-constexpr int      kLeafMax  = 10;
+constexpr uint32_t kNone      = 0xFFFFFFFFu;
+constexpr int      kBlock     = 256;
+constexpr int      kWaves     = kBlock / 64;
+constexpr int      kScanTile  = kBlock * 8;
+constexpr int      kLeafMax   = 10;
+constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kernels
 
 struct BuildSeg {
   uint32_t begin, end;    // range in tree order
   uint32_t node, parent;  // own node id; parent's node id (kNone for the root)
   int32_t  mn[3], mx[3];  // tight range of the points (atomics)
-  int16_t  lo[3], hi[3];  // loose box handed down by the parent
+  int16_t  lo[3], hi[3];  // loose box handed down by the parent (root: unused, its box is its range)
   uint8_t  side, pdim;    // which child of the parent we are, and the parent's cut dimension
   uint8_t  split, cutDim;
   int32_t  cut;
-  uint32_t lim1, m1, r1b, r1m;  // first sweep : #L, #swaps, prefix at begin, prefix at begin + lim1
-  uint32_t nE, m2, r2b, r2m;    // second sweep: #(== cut), #swaps, prefix at begin + lim1, prefix at begin + lim1 + nE
-  uint32_t mid;                 // begin + idx: first point of the right child
-  uint32_t slot;                // next-level slot of the left child (right = slot + 1)
+  uint32_t mid;           // begin + idx: first point of the right child
+  uint32_t slot;          // next-level slot of the left child (right = slot + 1)
+};
+
+struct BuildArgs {
+  const Pt* pts;
+  uint32_t  n, tiles;
+  Pt*       P;
+  uint32_t *perm, *seg;
+  BuildSeg *segA, *segB;
+  KdNode*   nodes;
+  uint32_t *loc1, *loc2, *tile1, *tile2, *list;  // tile1 / tile2: [tiles + 1] tile totals, scanned in place (+ total)
+  uint32_t* counts;     // [kMaxLevels + 1] segments per level
+  uint32_t* nodeCount;
+  int32_t*  rootBox;    // [6]
+  uint32_t* levels;     // out: number of levels
 };
 
 __device__ __forceinline__ int coordOf( const Pt p, int d ) { return d == 0 ? p.x : ( d == 1 ? p.y : p.z ); }
 
-__device__ __forceinline__ uint32_t prefixAt( const uint32_t* __restrict__ loc, const uint32_t* __restrict__ sums,
-                                              const uint32_t* __restrict__ total, uint32_t i, uint32_t n ) {
-  return i < n ? loc[i] + sums[i / kScanTile] : *total;
-}
-
-__global__ __launch_bounds__( 256 ) void initKernel( const Pt* __restrict__ pts, uint32_t n, Pt* __restrict__ P,
-                                                      uint32_t* __restrict__ perm, uint32_t* __restrict__ seg,
-                                                      BuildSeg* __restrict__ root, uint32_t* __restrict__ counts,
-                                                      uint32_t* __restrict__ nodeCount ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i < n ) {
-    P[i]    = pts[i];
-    perm[i] = i;
-    seg[i]  = 0;
-  }
-  if ( i == 0 ) {
-    BuildSeg r{};
-    r.begin  = 0;
-    r.end    = n;
-    r.node   = 0;
-    r.parent = kNone;
-    for ( int d = 0; d < 3; ++d ) r.mn[d] = 0x7FFFFFFF, r.mx[d] = int32_t( 0x80000000 );
-    *root      = r;
-    counts[0]  = 1;  // segments of level 0
-    *nodeCount = 1;  // node 0 = the root
-  }
-}
-
-// level entry: move every point to its segment of THIS level (children of the previous level's segments), then
-// accumulate the tight ranges.  Points of one segment are contiguous, so a segmented shuffle reduction leaves the
-// range of each run in its first lane and only that lane touches memory.
-template <bool FIRST>
-__global__ __launch_bounds__( 256 ) void rangeKernel( const Pt* __restrict__ P, uint32_t n, uint32_t* __restrict__ seg,
-                                                       const BuildSeg* __restrict__ prev, BuildSeg* __restrict__ cur ) {
-  const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63;
-  uint32_t       s    = kNone;
-  if ( i < n ) {
-    if ( FIRST ) {
-      s = 0;
-    } else {
-      const uint32_t so = seg[i];
-      if ( so != kNone ) {
-        if ( prev[so].split ) s = prev[so].slot + ( i >= prev[so].mid ? 1u : 0u );
-        seg[i] = s;
-      }
-    }
-  }
-  int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mnz = 0x7FFFFFFF, mxx = int( 0x80000000 ), mxy = mxx, mxz = mxx;
-  if ( s != kNone ) {
-    const Pt p = P[i];
-    mnx = mxx = p.x;
-    mny = mxy = p.y;
-    mnz = mxz = p.z;
-  }
+// leaf or split rule of one segment (kdtree_build.cpp, state 0).  Returns false for a leaf.
+__device__ __forceinline__ bool splitRule( const BuildSeg* q, int& cutDim, int32_t& cut ) {
+  if ( q->end - q->begin <= uint32_t( kLeafMax ) ) return false;
+  const bool root = q->parent == kNone;
+  int32_t    lo[3], hi[3], mn[3], mx[3];
 #pragma unroll
-  for ( int off = 1; off < 64; off <<= 1 ) {
-    const uint32_t os = __shfl_down( s, off, 64 );
-    const int      a = __shfl_down( mnx, off, 64 ), b = __shfl_down( mny, off, 64 ), c = __shfl_down( mnz, off, 64 );
-    const int      d = __shfl_down( mxx, off, 64 ), e = __shfl_down( mxy, off, 64 ), g = __shfl_down( mxz, off, 64 );
-    if ( lane + off < 64 && os == s ) {
-      mnx = min( mnx, a ), mny = min( mny, b ), mnz = min( mnz, c );
-      mxx = max( mxx, d ), mxy = max( mxy, e ), mxz = max( mxz, g );
-    }
+  for ( int d = 0; d < 3; ++d ) {
+    mn[d] = q->mn[d], mx[d] = q->mx[d];
+    lo[d] = root ? mn[d] : int32_t( q->lo[d] );
+    hi[d] = root ? mx[d] : int32_t( q->hi[d] );
   }
-  const uint32_t ps = __shfl_up( s, 1, 64 );
-  if ( s != kNone && ( lane == 0 || ps != s ) ) {
-    BuildSeg* q = cur + s;
-    atomicMin( &q->mn[0], mnx ), atomicMin( &q->mn[1], mny ), atomicMin( &q->mn[2], mnz );
-    atomicMax( &q->mx[0], mxx ), atomicMax( &q->mx[1], mxy ), atomicMax( &q->mx[2], mxz );
-  }
-}
-
-// per segment: report the tight range to the parent, then leaf or split rule (kdtree_build.cpp, state 0)
-__global__ __launch_bounds__( 256 ) void decideKernel( BuildSeg* __restrict__ cur, const uint32_t* __restrict__ count,
-                                                        KdNode* __restrict__ nodes, int32_t* __restrict__ rootBox ) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( s >= *count ) return;
-  BuildSeg q = cur[s];
-  if ( q.parent == kNone ) {
-    for ( int d = 0; d < 3; ++d ) {
-      q.lo[d] = int16_t( q.mn[d] ), q.hi[d] = int16_t( q.mx[d] );
-      rootBox[d] = q.mn[d], rootBox[3 + d] = q.mx[d];
-    }
-  } else if ( q.side == 0 ) {
-    nodes[q.parent].divlow = int16_t( q.mx[q.pdim] );
-  } else {
-    nodes[q.parent].divhigh = int16_t( q.mn[q.pdim] );
-  }
-  const uint32_t cnt = q.end - q.begin;
-  if ( cnt <= uint32_t( kLeafMax ) ) {
-    KdNode nd;
-    nd.a = int32_t( q.begin ), nd.b = int32_t( q.end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
-    nodes[q.node] = nd;
-    q.split       = 0;
-  } else {
-    int32_t maxSpan = 0;
-    for ( int d = 0; d < 3; ++d ) maxSpan = max( maxSpan, int32_t( q.hi[d] ) - int32_t( q.lo[d] ) );
-    int     cutDim     = 0;
-    int32_t bestSpread = -1;
-    for ( int d = 0; d < 3; ++d ) {
-      const int32_t span = int32_t( q.hi[d] ) - int32_t( q.lo[d] );
-      if ( double( span ) > ( 1.0 - 0.00001 ) * double( maxSpan ) ) {
-        const int32_t spread = q.mx[d] - q.mn[d];
-        if ( spread > bestSpread ) {
-          bestSpread = spread;
-          cutDim     = d;
-        }
+  const int32_t maxSpan = max( hi[0] - lo[0], max( hi[1] - lo[1], hi[2] - lo[2] ) );
+  cutDim                = 0;
+  int32_t bestSpread    = -1;
+#pragma unroll
+  for ( int d = 0; d < 3; ++d ) {
+    if ( double( hi[d] - lo[d] ) > ( 1.0 - 0.00001 ) * double( maxSpan ) ) {
+      const int32_t spread = mx[d] - mn[d];
+      if ( spread > bestSpread ) {
+        bestSpread = spread;
+        cutDim     = d;
       }
     }
-    const int32_t mid = ( int32_t( q.lo[cutDim] ) + int32_t( q.hi[cutDim] ) ) / 2;
-    q.cut             = min( max( mid, q.mn[cutDim] ), q.mx[cutDim] );
-    q.cutDim          = uint8_t( cutDim );
-    q.split           = 1;
   }
-  cur[s] = q;
+  const int32_t l = cutDim == 0 ? lo[0] : ( cutDim == 1 ? lo[1] : lo[2] ), h = cutDim == 0 ? hi[0] : ( cutDim == 1 ? hi[1] : hi[2] );
+  const int32_t a = cutDim == 0 ? mn[0] : ( cutDim == 1 ? mn[1] : mn[2] ), b = cutDim == 0 ? mx[0] : ( cutDim == 1 ? mx[1] : mx[2] );
+  cut             = min( max( ( l + h ) / 2, a ), b );
+  return true;
 }
 
-// tile-local exclusive prefix of the sweep's class flag (PASS 1: value >= cut; PASS 2: value > cut on [begin+lim1, end))
-template <int PASS>
-__global__ __launch_bounds__( 256 ) void flagScanTilesKernel( const Pt* __restrict__ P, const uint32_t* __restrict__ seg,
-                                                               const BuildSeg* __restrict__ cur, uint32_t n,
-                                                               uint32_t* __restrict__ loc, uint32_t* __restrict__ sums ) {
-  __shared__ uint32_t waveSum[4];
+// exclusive prefix of the class flag at position i: tile-local part + scanned tile totals
+__device__ __forceinline__ uint32_t prefixAt( const uint32_t* __restrict__ loc, const uint32_t* sums, uint32_t tiles,
+                                              uint32_t i, uint32_t n ) {
+  return i < n ? loc[i] + sums[i / kScanTile] : sums[tiles];
+}
+
+// one block: exclusive scan of the tile totals in place, grand total to sums[tiles]
+__global__ __launch_bounds__( kBlock ) void scanTileTotalsKernel( uint32_t* __restrict__ sums, uint32_t tiles ) {
+  __shared__ uint32_t waveSum[kWaves];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t      base = blockIdx.x * kScanTile + threadIdx.x * 8;
-  uint32_t            v[8], run = 0;
-#pragma unroll
-  for ( int k = 0; k < 8; ++k ) {
-    const uint32_t i = base + k;
-    uint32_t       f = 0;
-    if ( i < n ) {
-      const uint32_t s = seg[i];
-      if ( s != kNone ) {
-        const BuildSeg* q = cur + s;
-        if ( q->split ) {
-          const int val = coordOf( P[i], q->cutDim );
-          f             = PASS == 1 ? ( val >= q->cut ) : ( i >= q->begin + q->lim1 && val > q->cut );
-        }
-      }
-    }
-    v[k] = f;
-    run += f;
-  }
-  uint32_t inc = run;
-#pragma unroll
-  for ( int off = 1; off < 64; off <<= 1 ) {
-    const uint32_t t = __shfl_up( inc, off, 64 );
-    if ( lane >= off ) inc += t;
-  }
-  if ( lane == 63 ) waveSum[wave] = inc;
-  __syncthreads();
-  uint32_t offset = inc - run;
-  for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
-#pragma unroll
-  for ( int k = 0; k < 8; ++k ) {
-    if ( base + k < n ) loc[base + k] = offset;
-    offset += v[k];
-  }
-  if ( threadIdx.x == 255 ) sums[blockIdx.x] = offset;
-}
-
-// one block: exclusive scan of the tile totals in place, grand total to *total
-__global__ __launch_bounds__( 256 ) void scanSumsKernel( uint32_t* __restrict__ sums, uint32_t tiles,
-                                                          uint32_t* __restrict__ total ) {
-  __shared__ uint32_t waveSum[4];
-  __shared__ uint32_t carry;
-  const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ( threadIdx.x == 0 ) carry = 0;
-  __syncthreads();
-  for ( uint32_t base = 0; base < tiles; base += 256 ) {
+  uint32_t            carry = 0;
+  for ( uint32_t base = 0; base < tiles; base += kBlock ) {
     const uint32_t i   = base + threadIdx.x;
     const uint32_t v   = i < tiles ? sums[i] : 0u;
     uint32_t       inc = v;
@@ -232,113 +123,394 @@ __global__ __launch_bounds__( 256 ) void scanSumsKernel( uint32_t* __restrict__ 
     uint32_t offset = carry + inc - v;
     for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
     if ( i < tiles ) sums[i] = offset;
-    __syncthreads();
-    if ( threadIdx.x == 255 ) carry = offset + v;
+    for ( int w = 0; w < kWaves; ++w ) carry += waveSum[w];
     __syncthreads();
   }
-  if ( threadIdx.x == 0 ) *total = carry;
+  if ( threadIdx.x == 0 ) sums[tiles] = carry;
 }
 
-// per segment, after the first prefix sum: lim1 and the number of swaps of the first sweep
-__global__ __launch_bounds__( 256 ) void sweepOneKernel( BuildSeg* __restrict__ cur, const uint32_t* __restrict__ count,
-                                                          const uint32_t* __restrict__ loc, const uint32_t* __restrict__ sums,
-                                                          const uint32_t* __restrict__ total, uint32_t n ) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( s >= *count ) return;
-  BuildSeg* q = cur + s;
-  if ( !q->split ) return;
-  const uint32_t rb = prefixAt( loc, sums, total, q->begin, n ), re = prefixAt( loc, sums, total, q->end, n );
-  const uint32_t nL = ( q->end - q->begin ) - ( re - rb );
-  const uint32_t rm = prefixAt( loc, sums, total, q->begin + nL, n );
-  q->lim1 = nL, q->r1b = rb, q->r1m = rm, q->m1 = rm - rb;
+// first sweep of a segment, from the first prefix sum: #L (= lim1), prefix at begin and at begin + lim1
+struct Sweep {
+  uint32_t b, edge, m, rb, rm;  // swept range start, end of its left class, #swaps, prefix at b and at edge
+};
+__device__ __forceinline__ Sweep sweepOne( const BuildSeg* q, const uint32_t* __restrict__ loc1, const uint32_t* sums1,
+                                           uint32_t tiles, uint32_t n ) {
+  Sweep s;
+  s.b  = q->begin;
+  s.rb = prefixAt( loc1, sums1, tiles, q->begin, n );
+  const uint32_t re = prefixAt( loc1, sums1, tiles, q->end, n );
+  s.edge            = s.b + ( ( q->end - q->begin ) - ( re - s.rb ) );
+  s.rm              = prefixAt( loc1, sums1, tiles, s.edge, n );
+  s.m               = s.rm - s.rb;
+  return s;
+}
+// second sweep ("<= cut" on [begin + lim1, end)), from the second prefix sum
+__device__ __forceinline__ Sweep sweepTwo( const BuildSeg* q, uint32_t lim1Pos, const uint32_t* __restrict__ loc2,
+                                           const uint32_t* sums2, uint32_t tiles, uint32_t n ) {
+  Sweep s;
+  s.b  = lim1Pos;
+  s.rb = prefixAt( loc2, sums2, tiles, lim1Pos, n );
+  const uint32_t re = prefixAt( loc2, sums2, tiles, q->end, n );
+  s.edge            = s.b + ( ( q->end - lim1Pos ) - ( re - s.rb ) );
+  s.rm              = prefixAt( loc2, sums2, tiles, s.edge, n );
+  s.m               = s.rm - s.rb;
+  return s;
 }
 
-// misplaced right-hand elements publish their position under their rank counted from the right
-template <int PASS>
-__global__ __launch_bounds__( 256 ) void publishKernel( const Pt* __restrict__ P, const uint32_t* __restrict__ seg,
-                                                         const BuildSeg* __restrict__ cur, uint32_t n,
-                                                         const uint32_t* __restrict__ loc, const uint32_t* __restrict__ sums,
-                                                         uint32_t* __restrict__ list ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n ) return;
-  const uint32_t s = seg[i];
-  if ( s == kNone ) return;
-  const BuildSeg* q = cur + s;
-  if ( !q->split ) return;
-  const uint32_t b    = PASS == 1 ? q->begin : q->begin + q->lim1;            // start of the swept range
-  const uint32_t edge = b + ( PASS == 1 ? q->lim1 : q->nE );                   // where the left class ends
-  const uint32_t m    = PASS == 1 ? q->m1 : q->m2;
-  if ( i < edge || m == 0 ) return;
-  const int  val  = coordOf( P[i], q->cutDim );
-  const bool left = PASS == 1 ? ( val < q->cut ) : ( val <= q->cut );
-  if ( !left ) return;
-  const uint32_t rightBefore = ( loc[i] + sums[i / kScanTile] ) - ( PASS == 1 ? q->r1m : q->r2m );  // flagged in [edge, i)
-  const uint32_t leftBefore  = ( i - edge ) - rightBefore;
-  list[b + ( m - 1 - leftBefore )] = i;
+__global__ __launch_bounds__( kBlock ) void initKernel( BuildArgs a ) {
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  // ---- init ------------------------------------------------------------------------------------------------
+  for ( uint32_t i = gtid; i < n; i += gsize ) {
+    a.P[i]    = a.pts[i];
+    a.perm[i] = i;
+    a.seg[i]  = 0;
+  }
+  if ( gtid == 0 ) {
+    BuildSeg r{};
+    r.begin  = 0;
+    r.end    = n;
+    r.node   = 0;
+    r.parent = kNone;
+    for ( int d = 0; d < 3; ++d ) r.mn[d] = 0x7FFFFFFF, r.mx[d] = int32_t( 0x80000000 );
+    a.segA[0]    = r;
+    a.counts[0]  = 1;
+    *a.nodeCount = 1;  // node 0 = the root
+  }
 }
 
-// misplaced left-hand elements swap with the published position of equal rank
-template <int PASS>
-__global__ __launch_bounds__( 256 ) void swapKernel( Pt* __restrict__ P, uint32_t* __restrict__ perm,
-                                                      const uint32_t* __restrict__ seg, const BuildSeg* __restrict__ cur,
-                                                      uint32_t n, const uint32_t* __restrict__ loc,
-                                                      const uint32_t* __restrict__ sums, const uint32_t* __restrict__ list ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n ) return;
-  const uint32_t s = seg[i];
-  if ( s == kNone ) return;
-  const BuildSeg* q = cur + s;
-  if ( !q->split ) return;
-  const uint32_t b    = PASS == 1 ? q->begin : q->begin + q->lim1;
-  const uint32_t edge = b + ( PASS == 1 ? q->lim1 : q->nE );
-  if ( i < b || i >= edge ) return;
-  const Pt   pi    = P[i];
-  const int  val   = coordOf( pi, q->cutDim );
-  const bool right = PASS == 1 ? ( val >= q->cut ) : ( val > q->cut );
-  if ( !right ) return;
-  const uint32_t r  = ( loc[i] + sums[i / kScanTile] ) - ( PASS == 1 ? q->r1b : q->r2b );
-  const uint32_t j  = list[b + r];
-  const Pt       pj = P[j];
-  P[i]              = pj;
-  P[j]              = pi;
-  const uint32_t t  = perm[i];
-  perm[i]           = perm[j];
-  perm[j]           = t;
+__global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t level ) {
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  const uint32_t nRound = ( n + uint32_t( kBlock ) - 1u ) & ~( uint32_t( kBlock ) - 1u );
+  // ---- pass 1: move every point to its segment of this level, accumulate the tight ranges ------------------
+  for ( uint32_t base = blockIdx.x * blockDim.x; base < nRound; base += gsize ) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t       s = kNone;
+    if ( i < n ) {
+      if ( level == 0 ) {
+        s = 0;
+      } else {
+        const uint32_t so = a.seg[i];
+        if ( so != kNone ) {
+          const BuildSeg* p = other + so;
+          if ( p->split ) s = p->slot + ( i >= p->mid ? 1u : 0u );
+          a.seg[i] = s;
+        }
+      }
+    }
+    int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mnz = 0x7FFFFFFF, mxx = int( 0x80000000 ), mxy = mxx, mxz = mxx;
+    if ( s != kNone ) {
+      const Pt p = a.P[i];
+      mnx = mxx = p.x;
+      mny = mxy = p.y;
+      mnz = mxz = p.z;
+    }
+    // points of one segment are contiguous: a segmented shuffle reduction leaves each run's range in its first lane
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t os = __shfl_down( s, off, 64 );
+      const int      x0 = __shfl_down( mnx, off, 64 ), y0 = __shfl_down( mny, off, 64 ), z0 = __shfl_down( mnz, off, 64 );
+      const int      x1 = __shfl_down( mxx, off, 64 ), y1 = __shfl_down( mxy, off, 64 ), z1 = __shfl_down( mxz, off, 64 );
+      if ( lane + off < 64 && os == s ) {
+        mnx = min( mnx, x0 ), mny = min( mny, y0 ), mnz = min( mnz, z0 );
+        mxx = max( mxx, x1 ), mxy = max( mxy, y1 ), mxz = max( mxz, z1 );
+      }
+    }
+    const uint32_t ps = __shfl_up( s, 1, 64 );
+    if ( s != kNone && ( lane == 0 || ps != s ) ) {
+      BuildSeg* q = cur + s;
+      atomicMin( &q->mn[0], mnx ), atomicMin( &q->mn[1], mny ), atomicMin( &q->mn[2], mnz );
+      atomicMax( &q->mx[0], mxx ), atomicMax( &q->mx[1], mxy ), atomicMax( &q->mx[2], mxz );
+    }
+  }
 }
 
-// per segment, after the second prefix sum: lim2, the balance rule, the node record and the two children
-__global__ __launch_bounds__( 256 ) void childrenKernel( BuildSeg* __restrict__ cur, const uint32_t* __restrict__ count,
-                                                          const uint32_t* __restrict__ loc, const uint32_t* __restrict__ sums,
-                                                          const uint32_t* __restrict__ total, uint32_t n,
-                                                          BuildSeg* __restrict__ next, uint32_t* __restrict__ nextCount,
-                                                          uint32_t* __restrict__ nodeCount, KdNode* __restrict__ nodes ) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( s >= *count ) return;
-  BuildSeg* q = cur + s;
-  if ( !q->split ) return;
-  const uint32_t b2 = q->begin + q->lim1;
-  const uint32_t rb = prefixAt( loc, sums, total, b2, n ), re = prefixAt( loc, sums, total, q->end, n );
-  const uint32_t nE = ( q->end - b2 ) - ( re - rb );
-  const uint32_t rm = prefixAt( loc, sums, total, b2 + nE, n );
-  q->nE = nE, q->r2b = rb, q->r2m = rm, q->m2 = rm - rb;
-  const uint32_t cnt = q->end - q->begin, half = cnt / 2, lim1 = q->lim1, lim2 = q->lim1 + nE;
-  const uint32_t idx = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
-  q->mid             = q->begin + idx;
-  const uint32_t id  = atomicAdd( nodeCount, 2u );
-  const uint32_t sl  = atomicAdd( nextCount, 2u );
-  q->slot            = sl;
-  KdNode nd;
-  nd.a = int32_t( id ), nd.b = int32_t( id + 1 ), nd.divlow = nd.divhigh = 0, nd.dim = q->cutDim;
-  nodes[q->node] = nd;
-  BuildSeg c{};
-  c.parent = q->node;
-  c.pdim   = q->cutDim;
-  for ( int d = 0; d < 3; ++d ) c.mn[d] = 0x7FFFFFFF, c.mx[d] = int32_t( 0x80000000 ), c.lo[d] = q->lo[d], c.hi[d] = q->hi[d];
-  BuildSeg l = c, r = c;
-  l.begin = q->begin, l.end = q->mid, l.node = id, l.side = 0, l.hi[q->cutDim] = int16_t( q->cut );
-  r.begin = q->mid, r.end = q->end, r.node = id + 1, r.side = 1, r.lo[q->cutDim] = int16_t( q->cut );
-  next[sl]     = l;
-  next[sl + 1] = r;
+__global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint32_t level ) {
+  __shared__ uint32_t waveSum[kWaves];
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 2: per segment: report the range to the parent, leaf record or split rule;
+  //              per point  : first-sweep class flag (the rule is cheap enough to be re-derived per point) -----
+  for ( uint32_t s = gtid; s < count; s += gsize ) {
+    BuildSeg* q = cur + s;
+    if ( q->parent == kNone ) {
+      for ( int d = 0; d < 3; ++d ) a.rootBox[d] = q->mn[d], a.rootBox[3 + d] = q->mx[d];
+    } else {
+      const int pd = q->pdim;
+      if ( q->side == 0 )
+        a.nodes[q->parent].divlow = int16_t( pd == 0 ? q->mx[0] : ( pd == 1 ? q->mx[1] : q->mx[2] ) );
+      else
+        a.nodes[q->parent].divhigh = int16_t( pd == 0 ? q->mn[0] : ( pd == 1 ? q->mn[1] : q->mn[2] ) );
+    }
+    int     cutDim;
+    int32_t cut;
+    if ( splitRule( q, cutDim, cut ) ) {
+      q->split = 1, q->cutDim = uint8_t( cutDim ), q->cut = cut;
+    } else {
+      KdNode nd;
+      nd.a = int32_t( q->begin ), nd.b = int32_t( q->end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
+      a.nodes[q->node] = nd;
+      q->split         = 0;
+    }
+  }
+  for ( uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x ) {
+    const uint32_t base = tile * kScanTile + threadIdx.x * 8;
+    uint32_t       v[8], run = 0;
+#pragma unroll
+    for ( int k = 0; k < 8; ++k ) {
+      const uint32_t i = base + k;
+      uint32_t       f = 0;
+      if ( i < n ) {
+        const uint32_t s = a.seg[i];
+        if ( s != kNone ) {
+          int     cutDim;
+          int32_t cut;
+          if ( splitRule( cur + s, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
+        }
+      }
+      v[k] = f;
+      run += f;
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += t;
+    }
+    if ( lane == 63 ) waveSum[wave] = inc;
+    __syncthreads();
+    uint32_t offset = inc - run;
+    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
+#pragma unroll
+    for ( int k = 0; k < 8; ++k ) {
+      if ( base + k < n ) a.loc1[base + k] = offset;
+      offset += v[k];
+    }
+    if ( threadIdx.x == kBlock - 1 ) a.tile1[tile] = offset;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__( kBlock ) void publishOneKernel( BuildArgs a, uint32_t level ) {
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 3: first sweep, misplaced right-hand elements publish their position by rank from the right ----
+  for ( uint32_t i = gtid; i < n; i += gsize ) {
+    const uint32_t s = a.seg[i];
+    if ( s == kNone ) continue;
+    const BuildSeg* q = cur + s;
+    if ( !q->split ) continue;
+    const Sweep w = sweepOne( q, a.loc1, sums1, tiles, n );
+    if ( i < w.edge || w.m == 0 ) continue;
+    if ( coordOf( a.P[i], q->cutDim ) >= q->cut ) continue;
+    const uint32_t rightBefore = ( a.loc1[i] + sums1[i / kScanTile] ) - w.rm;  // flagged in [edge, i)
+    a.list[w.b + ( w.m - 1 - ( ( i - w.edge ) - rightBefore ) )] = i;
+  }
+}
+
+__global__ __launch_bounds__( kBlock ) void swapOneKernel( BuildArgs a, uint32_t level ) {
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 4: first sweep, misplaced left-hand elements swap with the published position of equal rank -----
+  for ( uint32_t i = gtid; i < n; i += gsize ) {
+    const uint32_t s = a.seg[i];
+    if ( s == kNone ) continue;
+    const BuildSeg* q = cur + s;
+    if ( !q->split ) continue;
+    const Sweep w = sweepOne( q, a.loc1, sums1, tiles, n );
+    if ( i >= w.edge ) continue;
+    const Pt pi = a.P[i];
+    if ( coordOf( pi, q->cutDim ) < q->cut ) continue;
+    const uint32_t r  = ( a.loc1[i] + sums1[i / kScanTile] ) - w.rb;
+    const uint32_t j  = a.list[w.b + r];
+    const Pt       pj = a.P[j];
+    a.P[i]            = pj;
+    a.P[j]            = pi;
+    const uint32_t t  = a.perm[i];
+    a.perm[i]         = a.perm[j];
+    a.perm[j]         = t;
+  }
+}
+
+__global__ __launch_bounds__( kBlock ) void flagTwoKernel( BuildArgs a, uint32_t level ) {
+  __shared__ uint32_t waveSum[kWaves];
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 5: second-sweep class flag ("> cut" on [begin + lim1, end)) ---------------------------------------
+  for ( uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x ) {
+    const uint32_t base = tile * kScanTile + threadIdx.x * 8;
+    uint32_t       v[8], run = 0;
+#pragma unroll
+    for ( int k = 0; k < 8; ++k ) {
+      const uint32_t i = base + k;
+      uint32_t       f = 0;
+      if ( i < n ) {
+        const uint32_t s = a.seg[i];
+        if ( s != kNone ) {
+          const BuildSeg* q = cur + s;
+          if ( q->split && coordOf( a.P[i], q->cutDim ) > q->cut ) f = i >= sweepOne( q, a.loc1, sums1, tiles, n ).edge;
+        }
+      }
+      v[k] = f;
+      run += f;
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += t;
+    }
+    if ( lane == 63 ) waveSum[wave] = inc;
+    __syncthreads();
+    uint32_t offset = inc - run;
+    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
+#pragma unroll
+    for ( int k = 0; k < 8; ++k ) {
+      if ( base + k < n ) a.loc2[base + k] = offset;
+      offset += v[k];
+    }
+    if ( threadIdx.x == kBlock - 1 ) a.tile2[tile] = offset;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__( kBlock ) void childrenPublishKernel( BuildArgs a, uint32_t level ) {
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 6: per segment: lim2, the balance rule, the node record and the two children;
+  //              per point  : second sweep, publish ------------------------------------------------------------
+  for ( uint32_t s = gtid; s < count; s += gsize ) {
+    BuildSeg* q = cur + s;
+    if ( !q->split ) continue;
+    const Sweep    w1   = sweepOne( q, a.loc1, sums1, tiles, n );
+    const Sweep    w2   = sweepTwo( q, w1.edge, a.loc2, sums2, tiles, n );
+    const uint32_t cnt  = q->end - q->begin, half = cnt / 2, lim1 = w1.edge - q->begin, lim2 = w2.edge - q->begin;
+    const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
+    const uint32_t mid  = q->begin + idx;
+    const uint32_t id   = atomicAdd( a.nodeCount, 2u );
+    const uint32_t sl   = atomicAdd( &a.counts[level + 1], 2u );
+    q->mid              = mid;
+    q->slot             = sl;
+    KdNode nd;
+    nd.a = int32_t( id ), nd.b = int32_t( id + 1 ), nd.divlow = nd.divhigh = 0, nd.dim = q->cutDim;
+    a.nodes[q->node] = nd;
+    const bool root  = q->parent == kNone;
+    BuildSeg   c{};
+    c.parent = q->node;
+    c.pdim   = q->cutDim;
+    for ( int d = 0; d < 3; ++d ) {
+      c.mn[d] = 0x7FFFFFFF, c.mx[d] = int32_t( 0x80000000 );
+      c.lo[d] = root ? int16_t( q->mn[d] ) : q->lo[d];
+      c.hi[d] = root ? int16_t( q->mx[d] ) : q->hi[d];
+    }
+    BuildSeg l = c, r = c;
+    l.begin = q->begin, l.end = mid, l.node = id, l.side = 0;
+    r.begin = mid, r.end = q->end, r.node = id + 1, r.side = 1;
+    const int16_t cut = int16_t( q->cut );
+    if ( q->cutDim == 0 ) l.hi[0] = cut, r.lo[0] = cut;
+    if ( q->cutDim == 1 ) l.hi[1] = cut, r.lo[1] = cut;
+    if ( q->cutDim == 2 ) l.hi[2] = cut, r.lo[2] = cut;
+    other[sl]     = l;
+    other[sl + 1] = r;
+  }
+  for ( uint32_t i = gtid; i < n; i += gsize ) {
+    const uint32_t s = a.seg[i];
+    if ( s == kNone ) continue;
+    const BuildSeg* q = cur + s;
+    if ( !q->split ) continue;
+    const uint32_t lim1Pos = sweepOne( q, a.loc1, sums1, tiles, n ).edge;
+    if ( i < lim1Pos ) continue;
+    const Sweep w = sweepTwo( q, lim1Pos, a.loc2, sums2, tiles, n );
+    if ( i < w.edge || w.m == 0 ) continue;
+    if ( coordOf( a.P[i], q->cutDim ) > q->cut ) continue;
+    const uint32_t rightBefore = ( a.loc2[i] + sums2[i / kScanTile] ) - w.rm;
+    a.list[w.b + ( w.m - 1 - ( ( i - w.edge ) - rightBefore ) )] = i;
+  }
+}
+
+__global__ __launch_bounds__( kBlock ) void swapTwoKernel( BuildArgs a, uint32_t level ) {
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
+  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
+  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
+  const uint32_t  count = a.counts[level];
+  const uint32_t* sums1 = a.tile1;
+  const uint32_t* sums2 = a.tile2;
+  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 7: second sweep, swap --------------------------------------------------------------------------------
+  for ( uint32_t i = gtid; i < n; i += gsize ) {
+    const uint32_t s = a.seg[i];
+    if ( s == kNone ) continue;
+    const BuildSeg* q = cur + s;
+    if ( !q->split ) continue;
+    const uint32_t lim1Pos = sweepOne( q, a.loc1, sums1, tiles, n ).edge;
+    if ( i < lim1Pos ) continue;
+    const Sweep w = sweepTwo( q, lim1Pos, a.loc2, sums2, tiles, n );
+    if ( i >= w.edge ) continue;
+    const Pt pi = a.P[i];
+    if ( coordOf( pi, q->cutDim ) <= q->cut ) continue;
+    const uint32_t r  = ( a.loc2[i] + sums2[i / kScanTile] ) - w.rb;
+    const uint32_t j  = a.list[w.b + r];
+    const Pt       pj = a.P[j];
+    a.P[i]            = pj;
+    a.P[j]            = pi;
+    const uint32_t t  = a.perm[i];
+    a.perm[i]         = a.perm[j];
+    a.perm[j]         = t;
+  }
 }
 
 }  // namespace
@@ -358,72 +530,58 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( maxNode ) );
-  DevBuf<uint32_t> d_seg, d_loc, d_sums, d_list, d_small;
+  DevBuf<uint32_t> d_work, d_small;
   DevBuf<BuildSeg> d_segs;
-  TMC2_TRY( d_seg.alloc( n ) );
-  TMC2_TRY( d_loc.alloc( 2 * size_t( n ) ) );
-  TMC2_TRY( d_sums.alloc( 2 * size_t( tiles ) ) );
-  TMC2_TRY( d_list.alloc( n ) );
+  TMC2_TRY( d_work.alloc( 4 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, list, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
-  constexpr int kMaxLevels = 64;                     // = the traversal stack of the k-NN kernels
-  TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );      // [0..64] segments per level, [65] node count, [66],[67] scan totals, [72..77] root box
-  uint32_t* d_counts = d_small.p;
-  uint32_t* d_nodeCount = d_small.p + kMaxLevels + 1;
-  uint32_t* d_total1 = d_small.p + kMaxLevels + 2, *d_total2 = d_small.p + kMaxLevels + 3;
-  uint32_t *d_loc1 = d_loc.p, *d_loc2 = d_loc.p + n, *d_sums1 = d_sums.p, *d_sums2 = d_sums.p + tiles;
-  int32_t*  d_rootBox = reinterpret_cast<int32_t*>( d_small.p + kMaxLevels + 8 );
+  TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
   TMC2_HIP( hipMemsetAsync( d_small.p, 0, ( kMaxLevels + 16 ) * 4, s ) );
-  const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
-  BuildSeg*  segA = d_segs.p;
-  BuildSeg*  segB = d_segs.p + maxSegs;
-  hipLaunchKernelGGL( initKernel, grdN, blk, 0, s, d_pts, n, d_ptsTree.p, d_perm.p, d_seg.p, segA, d_counts, d_nodeCount );
-  uint32_t segBound = 1;  // upper bound of this level's segment count (exact once it has been read back)
-  int      level    = 0;
-  for ( ; level < kMaxLevels; ++level ) {
-    BuildSeg*  cur = ( level & 1 ) ? segB : segA;
-    BuildSeg*  nxt = ( level & 1 ) ? segA : segB;
-    const dim3 grdS( ( segBound + 255 ) / 256 );
-    if ( level == 0 )
-      hipLaunchKernelGGL( rangeKernel<true>, grdN, blk, 0, s, d_ptsTree.p, n, d_seg.p, nxt, cur );
-    else
-      hipLaunchKernelGGL( rangeKernel<false>, grdN, blk, 0, s, d_ptsTree.p, n, d_seg.p, nxt, cur );
-    hipLaunchKernelGGL( decideKernel, grdS, blk, 0, s, cur, d_counts + level, d_nodes.p, d_rootBox );
-    hipLaunchKernelGGL( flagScanTilesKernel<1>, dim3( tiles ), blk, 0, s, d_ptsTree.p, d_seg.p, cur, n, d_loc1, d_sums1 );
-    hipLaunchKernelGGL( scanSumsKernel, dim3( 1 ), blk, 0, s, d_sums1, tiles, d_total1 );
-    hipLaunchKernelGGL( sweepOneKernel, grdS, blk, 0, s, cur, d_counts + level, d_loc1, d_sums1, d_total1, n );
-    hipLaunchKernelGGL( publishKernel<1>, grdN, blk, 0, s, d_ptsTree.p, d_seg.p, cur, n, d_loc1, d_sums1, d_list.p );
-    hipLaunchKernelGGL( swapKernel<1>, grdN, blk, 0, s, d_ptsTree.p, d_perm.p, d_seg.p, cur, n, d_loc1, d_sums1, d_list.p );
-    hipLaunchKernelGGL( flagScanTilesKernel<2>, dim3( tiles ), blk, 0, s, d_ptsTree.p, d_seg.p, cur, n, d_loc2, d_sums2 );
-    hipLaunchKernelGGL( scanSumsKernel, dim3( 1 ), blk, 0, s, d_sums2, tiles, d_total2 );
-    hipLaunchKernelGGL( childrenKernel, grdS, blk, 0, s, cur, d_counts + level, d_loc2, d_sums2, d_total2, n, nxt,
-                        d_counts + level + 1, d_nodeCount, d_nodes.p );
-    hipLaunchKernelGGL( publishKernel<2>, grdN, blk, 0, s, d_ptsTree.p, d_seg.p, cur, n, d_loc2, d_sums2, d_list.p );
-    hipLaunchKernelGGL( swapKernel<2>, grdN, blk, 0, s, d_ptsTree.p, d_perm.p, d_seg.p, cur, n, d_loc2, d_sums2, d_list.p );
-    // a level with more than 10 * 2^level points still has a splittable segment: no need to ask
-    if ( ( uint64_t( kLeafMax ) << std::min( level, 40 ) ) < n ) {
-      segBound = uint32_t( std::min<uint64_t>( uint64_t( segBound ) * 2, maxSegs ) );
-      continue;
+  BuildArgs a;
+  a.pts = d_pts, a.n = n, a.tiles = tiles, a.P = d_ptsTree.p, a.perm = d_perm.p;
+  a.seg = d_work.p, a.loc1 = d_work.p + n, a.loc2 = d_work.p + 2 * size_t( n ), a.list = d_work.p + 3 * size_t( n );
+  a.tile1 = d_work.p + 4 * size_t( n ), a.tile2 = a.tile1 + tiles + 1;
+  a.segA = d_segs.p, a.segB = d_segs.p + maxSegs, a.nodes = d_nodes.p;
+  a.counts    = d_small.p;
+  a.nodeCount = d_small.p + kMaxLevels + 1;
+  a.levels    = d_small.p + kMaxLevels + 2;
+  a.rootBox   = reinterpret_cast<int32_t*>( d_small.p + kMaxLevels + 8 );
+  // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
+  const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
+  hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
+  uint32_t out[kMaxLevels + 16];
+  int      found = -1;
+  for ( uint32_t level = 0; level < uint32_t( kMaxLevels ) && found < 0; ) {
+    // levels that cannot be the last are queued back to back; afterwards three at a time per read-back
+    uint32_t chunkEnd = level + 1;
+    while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kLeafMax ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
+    if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 3, kMaxLevels );
+    for ( ; level < chunkEnd; ++level ) {
+      hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
+      hipLaunchKernelGGL( decideFlagKernel, grdT, blk, 0, s, a, level );
+      hipLaunchKernelGGL( scanTileTotalsKernel, dim3( 1 ), blk, 0, s, a.tile1, tiles );
+      hipLaunchKernelGGL( publishOneKernel, grdE, blk, 0, s, a, level );
+      hipLaunchKernelGGL( swapOneKernel, grdE, blk, 0, s, a, level );
+      hipLaunchKernelGGL( flagTwoKernel, grdT, blk, 0, s, a, level );
+      hipLaunchKernelGGL( scanTileTotalsKernel, dim3( 1 ), blk, 0, s, a.tile2, tiles );
+      hipLaunchKernelGGL( childrenPublishKernel, grdE, blk, 0, s, a, level );
+      hipLaunchKernelGGL( swapTwoKernel, grdE, blk, 0, s, a, level );
     }
-    uint32_t nextSegs = 0;
-    TMC2_HIP( hipMemcpyAsync( &nextSegs, d_counts + level + 1, 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipGetLastError() );
+    TMC2_HIP( hipMemcpyAsync( out, d_small.p, sizeof( out ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
-    if ( nextSegs == 0 ) break;
-    if ( nextSegs > maxSegs ) {
-      setError( "kdtree: internal segment bound exceeded" );
-      return TMC2_E_INVALID;
-    }
-    segBound = nextSegs;
+    for ( uint32_t l = 0; l <= level && l <= uint32_t( kMaxLevels ); ++l )
+      if ( out[l] == 0 ) {
+        found = int( l );
+        break;
+      }
   }
-  if ( level >= kMaxLevels ) {
-    setError( "kdtree: more than %d levels", kMaxLevels );
+  if ( found < 0 ) {
+    setError( "kdtree: more than %d levels", kMaxLevels - 1 );
     return TMC2_E_UNSUPPORTED;
   }
-  depth = level + 1;
-  int32_t box[6];
-  TMC2_HIP( hipMemcpyAsync( box, d_rootBox, sizeof( box ), hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
+  depth = found;
+  const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
-  TMC2_HIP( hipGetLastError() );
   return TMC2_OK;
 }
 

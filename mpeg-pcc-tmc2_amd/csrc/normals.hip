@@ -212,6 +212,70 @@ int launchNormals( tmc2_frame* f ) {
   return TMC2_OK;
 }
 
+// ---- S3, device side --------------------------------------------------------------------------------------------
+// The spanning-tree growth itself is sequential and stays on the host (orient_host.cpp); what it needs per edge is
+// one number, n_u . n_v, and what it produces per point is one sign.  Both ends of that are data parallel:
+//   edgeDotKernel      : edgeDot[u][j] = n_u . n_knn[u][j] (same operand order and rounding as the reference's dot
+//                        product, PCCMath.h operator*), so that the host walk streams rows instead of chasing normals;
+//   applySignsKernel   : negate the normals the walk flipped, count how many of the results look away from the origin
+//                        (orientNormals' final majority test, PCCNormalsGenerator.cpp:226-241);
+//   majorityFlipKernel : negate everything if that count exceeds half -- decided on the device, no round trip.
+__global__ __launch_bounds__( 256 ) void edgeDotKernel( const double* __restrict__ normals, const uint32_t* __restrict__ knn,
+                                                         uint32_t n, int k, double* __restrict__ edgeDot ) {
+  const size_t e = size_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+  if ( e >= size_t( n ) * k ) return;
+  const size_t  u = e / k, v = knn[e];
+  const double* a = normals + 3 * u;
+  const double* b = normals + 3 * v;
+  edgeDot[e]      = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+__global__ __launch_bounds__( 256 ) void applySignsKernel( const Pt* __restrict__ pts, const int8_t* __restrict__ sign,
+                                                            uint32_t n, double* __restrict__ normals,
+                                                            uint32_t* __restrict__ negCount ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool           neg = false;
+  if ( i < n ) {
+    double nx = normals[3 * size_t( i )], ny = normals[3 * size_t( i ) + 1], nz = normals[3 * size_t( i ) + 2];
+    if ( sign[i] < 0 ) {
+      nx = -nx, ny = -ny, nz = -nz;
+      normals[3 * size_t( i )] = nx, normals[3 * size_t( i ) + 1] = ny, normals[3 * size_t( i ) + 2] = nz;
+    }
+    const Pt     p  = pts[i];
+    const double tx = 0.0 - double( p.x ), ty = 0.0 - double( p.y ), tz = 0.0 - double( p.z );
+    neg             = nx * tx + ny * ty + nz * tz < 0.0;
+  }
+  const unsigned long long m = __ballot( neg );
+  if ( ( threadIdx.x & 63 ) == 0 && m ) atomicAdd( negCount, uint32_t( __popcll( m ) ) );
+}
+
+__global__ __launch_bounds__( 256 ) void majorityFlipKernel( const uint32_t* __restrict__ negCount, uint32_t n,
+                                                              double* __restrict__ normals ) {
+  if ( *negCount <= ( n + 1 ) / 2 ) return;
+  const size_t i = size_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+  if ( i < 3 * size_t( n ) ) normals[i] = -normals[i];
+}
+
+int launchEdgeDots( tmc2_frame* f, double* d_edgeDot ) {
+  const size_t edges = f->n * size_t( f->k );
+  hipLaunchKernelGGL( edgeDotKernel, dim3( uint32_t( ( edges + 255 ) / 256 ) ), dim3( 256 ), 0, f->ctx->stream, f->d_normals.p,
+                      f->d_knn.p, uint32_t( f->n ), f->k, d_edgeDot );
+  TMC2_HIP( hipGetLastError() );
+  return TMC2_OK;
+}
+
+int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount ) {
+  hipStream_t    s = f->ctx->stream;
+  const uint32_t n = uint32_t( f->n );
+  TMC2_HIP( hipMemsetAsync( d_negCount, 0, 4, s ) );
+  hipLaunchKernelGGL( applySignsKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, s, f->d_pts.p, d_sign, n, f->d_normals.p,
+                      d_negCount );
+  hipLaunchKernelGGL( majorityFlipKernel, dim3( uint32_t( ( 3 * size_t( n ) + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_negCount, n,
+                      f->d_normals.p );
+  TMC2_HIP( hipGetLastError() );
+  return TMC2_OK;
+}
+
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] ) {
   if ( !f->haveNormals ) {
     setError( "initialSegmentation: normals not computed" );

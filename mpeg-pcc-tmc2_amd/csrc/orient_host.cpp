@@ -25,74 +25,88 @@ namespace tmc2 {
 
 namespace {
 
-// per-vertex state, one 16-byte record (one cache line touch per neighbour test)
-struct VState {
-  double   w;    // weight of the best pending in-edge
-  uint32_t s;    // its start vertex
-  int32_t  pos;  // slot in the heap; kAbsent = no pending in-edge yet; kVisited = already oriented
-};
-constexpr int32_t kAbsent = -1, kVisited = -2;
+// per-vertex state: the slot of the vertex's best pending in-edge in the heap, or one of two markers.  Four bytes per
+// vertex keep the randomly accessed part of the working set at n * 4 bytes (3.3 MB at longdress size): several walks
+// can share one last-level cache, which is what bounds the number of frames the host can orient at once.
+using VState = int32_t;
+constexpr int32_t kAbsent = -1, kVisited = -2;  // no pending in-edge yet / already oriented
 
-// heap entries carry their own key, so sifting compares contiguous records instead of chasing vertex ids
+// heap entries carry their own key, so sifting compares contiguous records instead of chasing vertex ids.
+// Field order matters: read as two 64-bit words, (|d| bits, s:v) is the reference's edge order (weight, start, end)
+// as one 128-bit unsigned number -- |d| >= 0, so its IEEE bit pattern orders like the value -- and the comparison
+// compiles to branch-free code (the outcomes are coin flips; mispredictions used to dominate the sifts).
 struct HeapEntry {
-  double   w;
-  uint32_t s, v;
+  double   d;
+  uint32_t v, s;
 };
+static_assert( sizeof( HeapEntry ) == 16, "HeapEntry layout" );
 
+__attribute__( ( always_inline ) ) inline unsigned __int128 edgeKey( const HeapEntry& e ) {
+  uint64_t w[2];
+  memcpy( w, &e, 16 );
+  return ( static_cast<unsigned __int128>( w[0] & 0x7FFFFFFFFFFFFFFFull ) << 64 ) | w[1];
+}
+
+// 4-ary max-heap: half the levels of a binary heap, and the four children of a slot share one cache line
 struct VertexHeap {
   std::vector<HeapEntry> heap;
   VState*                st;
 
   VertexHeap( size_t n, VState* state ) : st( state ) {
-    for ( size_t i = 0; i < n; ++i ) st[i] = VState{0.0, 0u, kAbsent};
+    for ( size_t i = 0; i < n; ++i ) st[i] = kAbsent;
     heap.reserve( n / 4 + 16 );
   }
   // strict "a has a smaller key than b" in the reference's edge order (weight, start, end)
-  static bool less( const HeapEntry& a, const HeapEntry& b ) {
-    if ( a.w == b.w ) return a.s == b.s ? a.v < b.v : a.s < b.s;
-    return a.w < b.w;
-  }
+  static bool less( const HeapEntry& a, const HeapEntry& b ) { return edgeKey( a ) < edgeKey( b ); }
   void siftUp( size_t i ) {
     const HeapEntry e = heap[i];
     while ( i > 0 ) {
-      const size_t p = ( i - 1 ) >> 1;
+      const size_t p = ( i - 1 ) >> 2;
       if ( !less( heap[p], e ) ) break;
-      heap[i]            = heap[p];
-      st[heap[i].v].pos  = int32_t( i );
-      i                  = p;
+      heap[i]           = heap[p];
+      st[heap[i].v] = int32_t( i );
+      i                 = p;
     }
     heap[i]     = e;
-    st[e.v].pos = int32_t( i );
+    st[e.v] = int32_t( i );
   }
   void siftDown( size_t i ) {
     const size_t    n = heap.size();
     const HeapEntry e = heap[i];
     for ( ;; ) {
-      size_t c = 2 * i + 1;
-      if ( c >= n ) break;
-      if ( c + 1 < n && less( heap[c], heap[c + 1] ) ) ++c;
+      const size_t c0 = 4 * i + 1;
+      if ( c0 >= n ) break;
+      size_t       c  = c0;
+      const size_t ce = c0 + 4 < n ? c0 + 4 : n;
+      unsigned __int128 best = edgeKey( heap[c0] );
+      for ( size_t t = c0 + 1; t < ce; ++t ) {
+        const unsigned __int128 kt = edgeKey( heap[t] );
+        const bool              gt = best < kt;
+        c                          = gt ? t : c;
+        best                       = gt ? kt : best;
+      }
       if ( !less( e, heap[c] ) ) break;
       heap[i]           = heap[c];
-      st[heap[i].v].pos = int32_t( i );
+      st[heap[i].v] = int32_t( i );
       i                 = c;
     }
     heap[i]     = e;
-    st[e.v].pos = int32_t( i );
+    st[e.v] = int32_t( i );
   }
-  // offer in-edge (weight, start) to unvisited vertex v
-  void offer( uint32_t v, double weight, uint32_t start ) {
-    VState& sv = st[v];
-    if ( sv.pos == kAbsent ) {
-      sv.w = weight;
-      sv.s = start;
-      heap.push_back( HeapEntry{weight, start, v} );
+  // offer in-edge (signed dot d as it stands now, start) to unvisited vertex v whose state is `pos`; the key of a
+  // pending vertex lives in its heap entry (the heap is small and cache resident)
+  void offer( uint32_t v, int32_t pos, double d, uint32_t start ) {
+    if ( pos == kAbsent ) {
+      heap.push_back( HeapEntry{d, v, start} );
       siftUp( heap.size() - 1 );
-    } else if ( weight > sv.w || ( weight == sv.w && start > sv.s ) ) {
-      sv.w                 = weight;
-      sv.s                 = start;
-      heap[sv.pos].w       = weight;
-      heap[sv.pos].s       = start;
-      siftUp( size_t( sv.pos ) );
+    } else {
+      HeapEntry&   h = heap[size_t( pos )];
+      const double w = std::fabs( d ), cur = std::fabs( h.d );
+      if ( w > cur || ( w == cur && start > h.s ) ) {
+        h.d = d;
+        h.s = start;
+        siftUp( size_t( pos ) );
+      }
     }
   }
   HeapEntry popMax() {
@@ -103,7 +117,7 @@ struct VertexHeap {
       heap[0] = last;
       siftDown( 0 );
     }
-    st[top.v].pos = kVisited;
+    st[top.v] = kVisited;
     return top;
   }
 };
@@ -112,8 +126,16 @@ inline double dot( const double* a, const double* b ) { return a[0] * b[0] + a[1
 
 }  // namespace
 
-// normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]; scratch: n * 16 bytes or nullptr
-void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch ) {
+// Spanning-tree growth proper.  edgeDot[u][j] = n_u . n_knn[u][j] on the ORIGINAL normals (fp64, evaluated as dot()
+// above -- on the device path it is computed by edgeDotKernel).  Negating a normal negates its dot products exactly,
+// so the walk never touches the normals: the weight of an edge is |edgeDot|, and with sign[u] = +-1 the orientation
+// already given to u, the reference's test "n_u(now) . n_v < 0" is sign[u] * edgeDot < 0.  Normals are read only at
+// the (rare) seeds of new components.  Output: sign[i] = -1 where the reference would have negated normal i by the end
+// of the growth (the global majority flip is left to the caller).  scratch: n * 4 bytes or nullptr.
+// The walk is bound by the latency of its scattered reads (the 16 state records of a row's neighbours, the rows of the
+// next vertex), so those are issued together / ahead of use.
+void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
+                              const double* edgeDot, int8_t* sign, void* scratch ) {
   if ( n == 0 ) return;
   std::vector<VState> own;
   if ( !scratch ) {
@@ -122,60 +144,91 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
   }
   VState*    st = reinterpret_cast<VState*>( scratch );
   VertexHeap heap( n, st );
-  double     acc[3];
-  size_t     accCount = 0;
+  for ( size_t i = 0; i < n; ++i ) sign[i] = 1;
+  constexpr int kMaxK = 64;
+  auto prefetchRows = [&]( uint32_t v ) {
+    const char* r = reinterpret_cast<const char*>( knn + size_t( v ) * k );
+    const char* d = reinterpret_cast<const char*>( edgeDot + size_t( v ) * k );
+    // rows are read exactly once: non-temporal, so that they do not evict the state records from the shared L3
+    for ( int o = 0; o < k * 4; o += 64 ) __builtin_prefetch( r + o, 0, 0 );
+    for ( int o = 0; o < k * 8; o += 64 ) __builtin_prefetch( d + o, 0, 0 );
+  };
   auto expand = [&]( uint32_t cur ) {
-    acc[0] = acc[1] = acc[2] = 0.0;
-    accCount                 = 0;
-    const double*   nc  = normals + 3 * size_t( cur );
+    const double    sc  = double( sign[cur] );
     const uint32_t* row = knn + size_t( cur ) * k;
+    const double*   dr  = edgeDot + size_t( cur ) * k;
+    int32_t         pos[kMaxK];
+    for ( int j = 0; j < k; ++j ) pos[j] = st[row[j]];  // independent loads: the misses overlap
+    for ( int j = 0; j < k; ++j )
+      // an earlier offer of this row may have moved things: re-read the (now cached) state of a pending vertex
+      if ( pos[j] != kVisited ) heap.offer( row[j], st[row[j]], sc * dr[j], cur );
+  };
+  for ( size_t seed = 0; seed < n; ++seed ) {
+    if ( st[seed] == kVisited ) continue;
+    // a seed is never in the heap: the heap is empty whenever a new seed is picked
+    st[seed] = kVisited;
+    // reference direction of the seed: sum of its already oriented neighbours (row order), else the previous point's
+    // normal as it stands, else the view point
+    double          acc[3]   = {0.0, 0.0, 0.0};
+    size_t          accCount = 0;
+    const uint32_t* row      = knn + seed * k;
     for ( int j = 0; j < k; ++j ) {
       const uint32_t v = row[j];
-      if ( st[v].pos != kVisited ) {
-        heap.offer( v, std::fabs( dot( nc, normals + 3 * size_t( v ) ) ), cur );
-      } else if ( v != cur ) {
-        acc[0] += normals[3 * size_t( v )];
-        acc[1] += normals[3 * size_t( v ) + 1];
-        acc[2] += normals[3 * size_t( v ) + 2];
+      if ( st[v] == kVisited && v != seed ) {
+        const double sv = double( sign[v] );
+        acc[0] += sv * normals[3 * size_t( v )];
+        acc[1] += sv * normals[3 * size_t( v ) + 1];
+        acc[2] += sv * normals[3 * size_t( v ) + 2];
         ++accCount;
       }
     }
-  };
-  auto flip = [&]( size_t i ) {
-    normals[3 * i]     = -normals[3 * i];
-    normals[3 * i + 1] = -normals[3 * i + 1];
-    normals[3 * i + 2] = -normals[3 * i + 2];
-  };
-  for ( size_t seed = 0; seed < n; ++seed ) {
-    if ( st[seed].pos == kVisited ) continue;
-    // a seed is never in the heap: the heap is empty whenever a new seed is picked
-    st[seed].pos = kVisited;
-    expand( uint32_t( seed ) );
     if ( accCount == 0 ) {
       if ( seed != 0 ) {
-        acc[0] = normals[3 * ( seed - 1 )];
-        acc[1] = normals[3 * ( seed - 1 ) + 1];
-        acc[2] = normals[3 * ( seed - 1 ) + 2];
+        const double sp = double( sign[seed - 1] );
+        acc[0] = sp * normals[3 * ( seed - 1 )];
+        acc[1] = sp * normals[3 * ( seed - 1 ) + 1];
+        acc[2] = sp * normals[3 * ( seed - 1 ) + 2];
       } else {
         acc[0] = 0.0 - xyz[0];
         acc[1] = 0.0 - xyz[1];
         acc[2] = 0.0 - xyz[2];
       }
     }
-    if ( dot( normals + 3 * seed, acc ) < 0.0 ) flip( seed );
+    if ( dot( normals + 3 * seed, acc ) < 0.0 ) sign[seed] = -1;
+    expand( uint32_t( seed ) );
     while ( !heap.heap.empty() ) {
       const HeapEntry e = heap.popMax();
-      if ( dot( normals + 3 * size_t( e.s ), normals + 3 * size_t( e.v ) ) < 0.0 ) flip( e.v );
+      // the new top is the likeliest next pop: have its rows on the way while this vertex is expanded
+      if ( !heap.heap.empty() ) prefetchRows( heap.heap[0].v );
+      if ( e.d < 0.0 ) sign[e.v] = -1;
       expand( e.v );
     }
   }
+}
+
+// normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]; scratch: n * 4 bytes or nullptr
+void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch ) {
+  if ( n == 0 ) return;
+  std::vector<double> edgeDot( n * size_t( k ) );
+  for ( size_t u = 0; u < n; ++u )
+    for ( int j = 0; j < k; ++j ) edgeDot[u * k + j] = dot( normals + 3 * u, normals + 3 * size_t( knn[u * k + j] ) );
+  std::vector<int8_t> sign( n );
+  const auto          tt0 = std::chrono::steady_clock::now();
+  orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot.data(), sign.data(), scratch );
+  if ( getenv( "TMC2_ORIENT_TIMING" ) )  // test hook: time of the growth alone
+    fprintf( stderr, "orient core %.1f ms\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tt0 ).count() );
   size_t negCount = 0;
   for ( size_t i = 0; i < n; ++i ) {
+    if ( sign[i] < 0 ) {
+      normals[3 * i]     = -normals[3 * i];
+      normals[3 * i + 1] = -normals[3 * i + 1];
+      normals[3 * i + 2] = -normals[3 * i + 2];
+    }
     const double toView[3] = {0.0 - xyz[3 * i], 0.0 - xyz[3 * i + 1], 0.0 - xyz[3 * i + 2]};
     if ( dot( normals + 3 * i, toView ) < 0.0 ) ++negCount;
   }
   if ( negCount > ( n + 1 ) / 2 )
-    for ( size_t i = 0; i < n; ++i ) flip( i );
+    for ( size_t i = 0; i < 3 * n; ++i ) normals[i] = -normals[i];
 }
 
 int orientNormalsHost( tmc2_frame* f ) {
@@ -183,28 +236,41 @@ int orientNormalsHost( tmc2_frame* f ) {
     setError( "orientNormals: adjacency / normals not computed" );
     return TMC2_E_STATE;
   }
-  const size_t n   = f->n;
+  const size_t n = f->n, edges = n * size_t( f->k );
   tmc2_ctx*    ctx = f->ctx;
-  uint32_t*    knn = ctx->hostA.get<uint32_t>( n * size_t( f->k ) );
-  double*      nrm = ctx->hostB.get<double>( n * 3 );
-  uint8_t*     scr = ctx->hostC.get<uint8_t>( n * 16 );
-  if ( !knn || !nrm || !scr ) {
+  hipStream_t  s   = ctx->stream;
+  // device: per-edge dot products; host staging (pinned, reused per context): rows, dots, normals (seeds only), signs
+  DevBuf<double>   d_edgeDot;
+  DevBuf<int8_t>   d_sign;
+  DevBuf<uint32_t> d_negCount;
+  TMC2_TRY( d_edgeDot.alloc( edges ) );
+  TMC2_TRY( d_sign.alloc( n ) );
+  TMC2_TRY( d_negCount.alloc( 1 ) );
+  TMC2_TRY( launchEdgeDots( f, d_edgeDot.p ) );
+  uint32_t* knn  = ctx->hostA.get<uint32_t>( edges );
+  double*   nrm  = ctx->hostB.get<double>( n * 3 );
+  double*   dots = ctx->hostE.get<double>( edges );
+  int8_t*   sign = ctx->hostC.get<int8_t>( n );
+  if ( !knn || !nrm || !dots || !sign ) {
     setError( "orientNormals: hipHostMalloc failed" );
     return TMC2_E_HIP;
   }
-  hipStream_t s = ctx->stream;
-  TMC2_HIP( hipMemcpyAsync( knn, f->d_knn.p, n * size_t( f->k ) * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( knn, f->d_knn.p, edges * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( dots, d_edgeDot.p, edges * sizeof( double ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipMemcpyAsync( nrm, f->d_normals.p, n * 3 * sizeof( double ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   std::chrono::steady_clock::time_point t0, t1;
   {
     HostGate gate;
     t0 = std::chrono::steady_clock::now();
-    orientNormalsSpanningTree( f->h_xyz.data(), n, knn, f->k, nrm, scr );
+    // the randomly accessed state lives in ordinary (not pinned) memory of this thread
+    if ( ctx->orientScratch.size() < n ) ctx->orientScratch.resize( n );
+    orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data() );
     t1 = std::chrono::steady_clock::now();
   }
   ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
-  TMC2_HIP( hipMemcpyAsync( f->d_normals.p, nrm, n * 3 * sizeof( double ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_sign.p, sign, n, hipMemcpyHostToDevice, s ) );
+  TMC2_TRY( launchApplyOrientation( f, d_sign.p, d_negCount.p ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   return TMC2_OK;
 }

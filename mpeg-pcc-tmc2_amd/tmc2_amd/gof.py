@@ -5,8 +5,9 @@ multi-GPU runs, frames sharded over ranks: frame f -> rank f % world.  The only 
 the all-intra path is (a) the axis weights of frame 0 (24 bytes, broadcast) and (b) the common canvas
 size (max over frames, all-reduce); finished canvases are gathered to rank 0 (RCCL over xGMI under the
 "nccl" backend, gloo in the CPU tests).  This module holds no algorithmic code."""
+import os
+import queue
 import threading
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -63,34 +64,125 @@ class _DevArray:
         self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
 
 
+def l3_domains():
+    """CPU ids grouped by shared last-level cache (one entry per CCD on EPYC), SMT siblings dropped; [] if unknown."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        groups, seen_core = {}, set()
+        for cpu in sorted(allowed):
+            base = "/sys/devices/system/cpu/cpu%d/" % cpu
+            with open(base + "topology/thread_siblings_list") as f:
+                first = int(f.read().replace("-", ",").split(",")[0])
+            if first in seen_core and first != cpu:
+                continue                                     # second hardware thread of a core already listed
+            seen_core.add(first)
+            with open(base + "cache/index3/shared_cpu_list") as f:
+                key = f.read().strip()
+            groups.setdefault(key, []).append(cpu)
+        return [g for _, g in sorted(groups.items(), key=lambda kv: kv[1][0])]
+    except (OSError, ValueError, AttributeError):
+        return []
+
+
+class _Worker(threading.Thread):
+    """One host thread per in-flight frame slot.  It owns its tmc2_ctx (created after the thread has been pinned, so
+    the context's page-locked staging and scratch land on the thread's NUMA node) and runs every call on it."""
+
+    def __init__(self, index, device, cpu, timing):
+        super().__init__(daemon=True)
+        self.index, self.device, self.cpu, self.timing = index, device, cpu, timing
+        self.jobs, self.ctx, self.ready = queue.Queue(), None, threading.Event()
+        self.start()
+        self.ready.wait()
+
+    def run(self):
+        if self.cpu is not None:
+            try:
+                os.sched_setaffinity(0, {self.cpu})          # applies to the calling thread
+            except OSError:
+                pass
+        self.ctx = lib.Context(self.device)
+        self.ctx.set_timing(self.timing)
+        self.ready.set()
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            fn, done = job
+            try:
+                done.append(("ok", fn()))
+            except BaseException as e:                        # handed back to the caller
+                done.append(("err", e))
+            done.event.set()
+
+
+class _Done(list):
+    def __init__(self):
+        super().__init__()
+        self.event = threading.Event()
+
+
 class GofEncoder:
-    """Phase A (S0-S16) and phase B (S17-S22) of a GOF on one GPU with `workers` concurrent frames."""
+    """Phase A (S0-S16) and phase B (S17-S22) of a GOF on one GPU with `workers` concurrent frames.
+    Worker w is pinned to a core of L3 domain (first_domain + w) % domains: the host-resident steps (orientation, the
+    host k-d tree builds) are cache- and memory-latency bound, so they are spread over all last-level caches and both
+    sockets instead of wherever the scheduler happens to wake them."""
 
     def __init__(self, device=0, workers=4, iterations=50, bits3d=11, occ_precision=4, min_w=1280, min_h=1280,
-                 timing=True):
+                 timing=True, pin=True, first_domain=0):
         self.device, self.workers = device, workers
         self.iterations, self.bits3d, self.occ_precision = iterations, bits3d, occ_precision
         self.min_w, self.min_h = min_w, min_h
-        self.ctxs = [lib.Context(device) for _ in range(workers)]
-        for c in self.ctxs:
-            c.set_timing(timing)
-        self.pool = ThreadPoolExecutor(max_workers=workers)
+        doms = l3_domains() if pin and workers > 1 and os.environ.get("TMC2_PIN", "1") != "0" else []
+        cpus = [None] * workers
+        if doms:
+            for w in range(workers):
+                d = doms[(first_domain + w) % len(doms)]
+                cpus[w] = d[((first_domain + w) // len(doms)) % len(d)]
+        self.threads = [_Worker(w, device, cpus[w], timing) for w in range(workers)]
+        self.ctxs = [t.ctx for t in self.threads]
+
+    def close(self):
+        for t in self.threads:
+            t.jobs.put(None)
 
     def upload(self, clouds):
         """Untimed: copy the GOF's point arrays to HBM (frame i lives on worker i % workers)."""
-        return [self.ctxs[i % self.workers].frame(xyz, rgb) for i, (xyz, rgb) in enumerate(clouds)]
+        frames = [None] * len(clouds)
+
+        def make(i):
+            frames[i] = self.ctxs[i % self.workers].frame(*clouds[i])
+        self._dispatch([(i % self.workers, (lambda i=i: make(i))) for i in range(len(clouds))])
+        return frames
+
+    def _dispatch(self, jobs):
+        """jobs: [(worker, callable)]; calls on one worker run in order; returns the results in job order."""
+        per = [[] for _ in range(self.workers)]
+        for j, (w, fn) in enumerate(jobs):
+            per[w].append((j, fn))
+        out, waits = [None] * len(jobs), []
+        for w, lst in enumerate(per):
+            if not lst:
+                continue
+
+            def run(lst=lst):
+                for j, fn in lst:
+                    out[j] = fn()
+            d = _Done()
+            self.threads[w].jobs.put((run, d))
+            waits.append(d)
+        for d in waits:
+            d.event.wait()
+            if d[0][0] == "err":
+                raise d[0][1]
+        return out
 
     def _per_worker(self, frames, fn):
-        buckets = [[] for _ in range(self.workers)]
-        for i, fr in enumerate(frames):
-            buckets[i % self.workers].append((i, fr))
-        out = [None] * len(frames)
+        return self._dispatch([(i % self.workers, (lambda fr=fr: fn(fr))) for i, fr in enumerate(frames)])
 
-        def run(bucket):
-            for i, fr in bucket:
-                out[i] = fn(fr)
-        list(self.pool.map(run, [b for b in buckets if b]))
-        return out
+    def per_frame(self, frames, fn):
+        """fn(frame, index) on the frame's own worker thread (e.g. the copies of finished canvases to host memory)."""
+        return self._dispatch([(i % self.workers, (lambda fr=fr, i=i: fn(fr, i))) for i, fr in enumerate(frames)])
 
     def phase_a(self, frames, sharder=None, weight=None):
         sharder = sharder or Sharder()

@@ -85,6 +85,8 @@ def load_library():
         raise Tmc2Error("libtmc2hip.so not built: run `python __graft_entry__.py build` (hipcc, gfx950)")
     L = C.CDLL(path)
     L.tmc2_last_error.restype = C.c_char_p
+    L.tmc2_set_kdtree_placement.restype = None
+    L.tmc2_set_host_parallelism.restype = None
     L.tmc2_ctx_stage_name.restype = C.c_char_p
     L.tmc2_ctx_stage_ms.restype = C.c_double
     L.tmc2_frame_point_count.restype = C.c_uint64

@@ -149,3 +149,29 @@ def test_gpu_transfer_colors_long_candidate_lists(gpu_ctx, oracle):
     for seed in (0, 1):
         xyz, rgb, tgt = _sparse_target_case(seed)
         assert np.array_equal(gpu_ctx.transfer_colors(xyz, rgb, tgt), oracle.transfer_colors(xyz, rgb, tgt))
+
+
+@pytest.mark.parametrize("placement", ["device", "host"])
+def test_gpu_gof_encoder_worker_threads(oracle, placement):
+    """The GOF orchestration used by bench.py: one pinned worker thread + context per in-flight frame, both k-d tree
+    placements.  Five frames over three workers, everything compared with the oracle."""
+    frames = [synth_cloud("tiny", f) for f in range(5)]
+    T.load_library().tmc2_set_kdtree_placement(1 if placement == "host" else 0)
+    try:
+        enc = T.GofEncoder(0, workers=3, iterations=10)
+        frs = enc.upload(frames)
+        W, H = enc.phase_a(frs)
+        enc.phase_b(frs)
+        exp_a = oracle.phase_a(frames, 10, 11, 4)
+        exp_b = oracle.phase_b(frames, exp_a, 4)
+        for fr, ea, eb in zip(frs, exp_a, exp_b):
+            img = fr.get_geometry_images()
+            assert (W, H) == (ea["width"], ea["height"])
+            for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+                assert np.array_equal(img[k], ea[k]), k
+            assert np.array_equal(fr.get_attribute_images(), eb["attribute"])
+        used = enc.stage_calls()
+        assert used.get("kdtree_build_host" if placement == "host" else "kdtree_build", 0) >= 5
+        enc.close()
+    finally:
+        T.load_library().tmc2_set_kdtree_placement(0)
