@@ -289,20 +289,11 @@ int tmc2_frame::ensureTree() {
   tree.build( h_xyz.data(), n );
   const auto t1 = std::chrono::steady_clock::now();
   ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
-  Pt* ptsTree = ctx->hostD.get<Pt>( n );
-  if ( !ptsTree ) {
-    setError( "kdtree: hipHostMalloc failed" );
-    return TMC2_E_HIP;
-  }
-  for ( uint64_t i = 0; i < n; ++i ) {
-    const uint32_t j = tree.perm[i];
-    ptsTree[i]       = Pt{h_xyz[3 * size_t( j )], h_xyz[3 * size_t( j ) + 1], h_xyz[3 * size_t( j ) + 2], 0};
-  }
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( tree.nodes.size() ) );
   hipStream_t s = ctx->stream;
-  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, ptsTree, n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, tree.ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipMemcpyAsync( d_perm.p, tree.perm.data(), n * sizeof( uint32_t ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipMemcpyAsync( d_nodes.p, tree.nodes.data(), tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );

@@ -496,8 +496,7 @@ int generateAttributeImages( tmc2_frame* f ) {
     std::vector<int16_t> xyz( 3 * size_t( M ) );
     for ( uint32_t i = 0; i < M; ++i ) xyz[3 * size_t( i )] = h_recon[i].x, xyz[3 * size_t( i ) + 1] = h_recon[i].y, xyz[3 * size_t( i ) + 2] = h_recon[i].z;
     f->reconTree.build( xyz.data(), M );
-    std::vector<Pt> ptsTree( M );
-    for ( uint32_t i = 0; i < M; ++i ) ptsTree[i] = h_recon[f->reconTree.perm[i]];
+    const std::vector<Pt>& ptsTree = f->reconTree.ptsTree;
     const auto t1 = std::chrono::steady_clock::now();
     ctx->stageAddHostMs( "kdtree_build_recon_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
     TMC2_TRY( f->d_reconTreePts.alloc( M ) );

@@ -102,18 +102,19 @@ struct alignas( 16 ) KdNode {
   int32_t dim;     // -1 for a leaf
 };
 
+// AoS point with padding: one 8-byte load per point
+struct alignas( 8 ) Pt {
+  int16_t x, y, z, w;
+};
 struct KdTreeHost {
-  std::vector<uint32_t> perm;   // tree order -> original index
+  std::vector<uint32_t> perm;     // tree order -> original index
+  std::vector<Pt>       ptsTree;  // the points in tree order
   std::vector<KdNode>   nodes;
   int32_t               lo[3], hi[3];
   int                   depth = 0;
   void                  build( const int16_t* xyz, size_t n );
 };
 
-// AoS point with padding: one 8-byte load per point
-struct alignas( 8 ) Pt {
-  int16_t x, y, z, w;
-};
 
 // placement + projection of one patch on the device, in packing order (shared by the image kernels)
 struct PlaceDev {

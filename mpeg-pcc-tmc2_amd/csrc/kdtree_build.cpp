@@ -11,7 +11,10 @@
 //   * the permutation left behind by the two-pass "Hoare" partition (swap for swap),
 //   * the balance fallback (count/2) and the bottom-up tightening that defines divlow/divhigh.
 // Unlike the reference it is iterative (explicit frame stack), gathers the three per-dimension ranges
-// of a node in ONE pass, and emits a flat pre-order node array ready for upload.
+// of a node in ONE pass, emits a flat pre-order node array ready for upload, and carries the points
+// along with the index permutation (8-byte records swapped together), so that every pass over a node
+// streams through contiguous memory instead of gathering coordinates through the index array -- the
+// build is memory-latency bound otherwise.
 #include <algorithm>
 
 #include "internal.h"
@@ -36,41 +39,60 @@ struct Frame {
   Box3     lb, rb;       // child boxes (tightened by the children)
 };
 
-// two-pass partition; returns lim1/lim2.  Literal swap sequence (see header comment).
-inline void partitionTwoPass( uint32_t* ind, uint32_t count, const int16_t* xyz, int dim, int32_t cut, uint32_t& lim1,
-                              uint32_t& lim2 ) {
-  auto     val   = [&]( uint32_t i ) -> int32_t { return xyz[3 * size_t( ind[i] ) + dim]; };
-  uint32_t left  = 0;
-  uint32_t right = count - 1;
-  while ( true ) {
-    while ( left <= right && val( left ) < cut ) ++left;
-    while ( right != 0 && left <= right && val( right ) >= cut ) --right;
-    if ( left > right || right == 0 ) break;
-    const uint32_t t = ind[left];
-    ind[left]        = ind[right];
-    ind[right]       = t;
-    ++left;
-    --right;
+// two-pass partition; returns lim1/lim2.
+// nanoflann runs two Hoare sweeps (first with "< cut" on the left, then "<= cut" on the left of what remained).  A
+// Hoare sweep ends with every left-class element in [0, nL) and has swapped, in order, the i-th misplaced element from
+// the left with the i-th misplaced element from the right; elements already on their side never move.  Counting the
+// class, listing the misplaced positions of both sides and swapping them pairwise therefore leaves EXACTLY the same
+// permutation -- but as three branch-free streaming loops instead of two sweeps of coin-flip branches (the same
+// closed form the device builder uses, kdtree_device.hip).
+// one sweep over [0, count) whose left class is "value < c" and holds nL elements
+inline void hoareSweep( uint32_t* ind, Pt* pts, uint32_t count, uint32_t nL, int dim, int32_t c, uint32_t* scratch ) {
+  const int16_t* v         = &pts[0].x + dim;  // stride 4 int16
+  uint32_t*      fromLeft  = scratch;           // misplaced (right-class) positions in [0, nL), ascending
+  uint32_t*      fromRight = scratch + nL + 1;  // misplaced (left-class) positions in [nL, count), descending
+  uint32_t       m = 0, m2 = 0;
+  for ( uint32_t i = 0; i < nL; ++i ) {
+    fromLeft[m] = i;
+    m += uint32_t( int32_t( v[4 * size_t( i )] ) >= c );
   }
-  lim1  = left;
-  right = count - 1;
-  while ( true ) {
-    while ( left <= right && val( left ) <= cut ) ++left;
-    while ( right != 0 && left <= right && val( right ) > cut ) --right;
-    if ( left > right || right == 0 ) break;
-    const uint32_t t = ind[left];
-    ind[left]        = ind[right];
-    ind[right]       = t;
-    ++left;
-    --right;
+  for ( uint32_t j = count; j-- > nL; ) {
+    fromRight[m2] = j;
+    m2 += uint32_t( int32_t( v[4 * size_t( j )] ) < c );
   }
-  lim2 = left;
+  for ( uint32_t t = 0; t < m; ++t ) {
+    const uint32_t a = fromLeft[t], b = fromRight[t];
+    const uint32_t x = ind[a];
+    ind[a]           = ind[b];
+    ind[b]           = x;
+    const Pt q       = pts[a];
+    pts[a]           = pts[b];
+    pts[b]           = q;
+  }
+}
+inline void partitionTwoPass( uint32_t* ind, Pt* pts, uint32_t count, int dim, int32_t cut, uint32_t& lim1, uint32_t& lim2,
+                              uint32_t* scratch ) {
+  const int16_t* v  = &pts[0].x + dim;
+  uint32_t       lt = 0, le = 0;  // both class sizes in one pass: every "< cut" element is also "<= cut"
+  for ( uint32_t i = 0; i < count; ++i ) {
+    const int32_t x = v[4 * size_t( i )];
+    lt += uint32_t( x < cut );
+    le += uint32_t( x <= cut );
+  }
+  lim1 = lt;
+  lim2 = le;
+  hoareSweep( ind, pts, count, lt, dim, cut, scratch );
+  hoareSweep( ind + lt, pts + lt, count - lt, le - lt, dim, cut + 1, scratch );
 }
 }  // namespace
 
 void KdTreeHost::build( const int16_t* xyz, size_t n ) {
   perm.resize( n );
-  for ( size_t i = 0; i < n; ++i ) perm[i] = uint32_t( i );
+  ptsTree.resize( n );
+  for ( size_t i = 0; i < n; ++i ) {
+    perm[i]    = uint32_t( i );
+    ptsTree[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
+  }
   nodes.clear();
   nodes.reserve( n / 4 + 16 );
   depth = 0;
@@ -87,7 +109,8 @@ void KdTreeHost::build( const int16_t* xyz, size_t n ) {
     lo[d] = root.lo[d];
     hi[d] = root.hi[d];
   }
-  std::vector<Frame> stack;
+  std::vector<uint32_t> scratch( n + 2 );  // the two position lists of a sweep: nL + 1 and count - nL + 1 entries... at most count + 2
+  std::vector<Frame>    stack;
   stack.reserve( 128 );
   {
     Frame f{};
@@ -115,15 +138,14 @@ void KdTreeHost::build( const int16_t* xyz, size_t n ) {
       depth                = std::max( depth, f.depth );
       const uint32_t count = f.end - f.begin;
       uint32_t*      ind   = perm.data() + f.begin;
+      Pt*            pts   = ptsTree.data() + f.begin;
       // one pass: actual range of the node's points in all three dims
-      int32_t mn[3], mx[3];
-      for ( int d = 0; d < 3; ++d ) mn[d] = mx[d] = xyz[3 * size_t( ind[0] ) + d];
+      int32_t mn[3] = {pts[0].x, pts[0].y, pts[0].z}, mx[3] = {pts[0].x, pts[0].y, pts[0].z};
       for ( uint32_t i = 1; i < count; ++i ) {
-        const int16_t* p = xyz + 3 * size_t( ind[i] );
-        for ( int d = 0; d < 3; ++d ) {
-          mn[d] = std::min<int32_t>( mn[d], p[d] );
-          mx[d] = std::max<int32_t>( mx[d], p[d] );
-        }
+        const Pt p = pts[i];
+        mn[0] = std::min<int32_t>( mn[0], p.x ), mx[0] = std::max<int32_t>( mx[0], p.x );
+        mn[1] = std::min<int32_t>( mn[1], p.y ), mx[1] = std::max<int32_t>( mx[1], p.y );
+        mn[2] = std::min<int32_t>( mn[2], p.z ), mx[2] = std::max<int32_t>( mx[2], p.z );
       }
       if ( count <= 10 ) {
         KdNode& nd = nodes[f.node];
@@ -157,7 +179,7 @@ void KdTreeHost::build( const int16_t* xyz, size_t n ) {
       const int32_t mid = ( f.box.lo[cutDim] + f.box.hi[cutDim] ) / 2;
       const int32_t cut = std::min( std::max( mid, mn[cutDim] ), mx[cutDim] );
       uint32_t      lim1, lim2;
-      partitionTwoPass( ind, count, xyz, cutDim, cut, lim1, lim2 );
+      partitionTwoPass( ind, pts, count, cutDim, cut, lim1, lim2, scratch.data() );
       const uint32_t half = count / 2;
       const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
       f.cutDim            = int16_t( cutDim );
