@@ -18,7 +18,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
-#include <sys/mman.h>
 
 #include "internal.h"
 
@@ -207,48 +206,13 @@ void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn,
   }
 }
 
-namespace {
-// anonymous memory backed by 2 MiB pages where the kernel grants them (THP "madvise" or "always").  The walk touches
-// ~200 bytes at a random place of a ~160 MB table per vertex: with 4 KiB pages nearly every touch is a TLB miss plus a
-// page walk; with 2 MiB pages the whole table is covered by the second-level TLB.
-struct HugeBuf {
-  void*  p     = nullptr;
-  size_t bytes = 0;
-  ~HugeBuf() { release(); }
-  void release() {
-    if ( p ) munmap( p, bytes );
-    p = nullptr, bytes = 0;
-  }
-  void* get( size_t want ) {
-    if ( want <= bytes ) return p;
-    release();
-    const size_t two = size_t( 2 ) << 20;
-    bytes            = ( want + two - 1 ) / two * two;
-    p                = mmap( nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0 );
-    if ( p == MAP_FAILED ) {
-      p = nullptr, bytes = 0;
-      return nullptr;
-    }
-    madvise( p, bytes, MADV_HUGEPAGE );  // best effort
-    return p;
-  }
-};
-}  // namespace
-
 // normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]; scratch: n * 4 bytes or nullptr
 void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch ) {
   if ( n == 0 ) return;
-  HugeBuf hd, hk;
-  const bool huge = getenv( "TMC2_ORIENT_HUGE" ) != nullptr;
-  std::vector<double> plain( huge ? 0 : n * size_t( k ) );
-  double* edgeDot = huge ? static_cast<double*>( hd.get( n * size_t( k ) * 8 ) ) : plain.data();
+  std::vector<double> edgeDotV( n * size_t( k ) );
+  double*             edgeDot = edgeDotV.data();
   for ( size_t u = 0; u < n; ++u )
     for ( int j = 0; j < k; ++j ) edgeDot[u * k + j] = dot( normals + 3 * u, normals + 3 * size_t( knn[u * k + j] ) );
-  if ( huge ) {
-    uint32_t* kk = static_cast<uint32_t*>( hk.get( n * size_t( k ) * 4 ) );
-    memcpy( kk, knn, n * size_t( k ) * 4 );
-    knn = kk;
-  }
   std::vector<int8_t> sign( n );
   const auto          tt0 = std::chrono::steady_clock::now();
   orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch );
