@@ -284,17 +284,27 @@ int tmc2_frame::ensureTree() {
     haveTree = true;
     return TMC2_OK;
   }
-  tmc2::HostGate gate;
-  const auto t0 = std::chrono::steady_clock::now();
-  tree.build( h_xyz.data(), n );
-  const auto t1 = std::chrono::steady_clock::now();
-  ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+  // built in page-locked staging (the orientation's row / sign staging is idle at this point) and uploaded as is
+  Pt*       hp = ctx->hostD.get<Pt>( n );
+  uint32_t* hi = ctx->hostA.get<uint32_t>( n );
+  if ( !hp || !hi ) {
+    setError( "kdtree: hipHostMalloc failed" );
+    return TMC2_E_HIP;
+  }
+  {
+    tmc2::HostGate gate;
+    const auto     t0 = std::chrono::steady_clock::now();
+    for ( uint64_t i = 0; i < n; ++i ) hp[i] = Pt{h_xyz[3 * size_t( i )], h_xyz[3 * size_t( i ) + 1], h_xyz[3 * size_t( i ) + 2], 0};
+    tree.buildInPlace( hp, hi, n );
+    const auto t1 = std::chrono::steady_clock::now();
+    ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+  }
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( tree.nodes.size() ) );
   hipStream_t s = ctx->stream;
-  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, tree.ptsTree.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( d_perm.p, tree.perm.data(), n * sizeof( uint32_t ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_ptsTree.p, hp, n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_perm.p, hi, n * sizeof( uint32_t ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipMemcpyAsync( d_nodes.p, tree.nodes.data(), tree.nodes.size() * sizeof( KdNode ), hipMemcpyHostToDevice, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   haveTree = true;

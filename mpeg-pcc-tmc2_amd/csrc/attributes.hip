@@ -488,22 +488,26 @@ int generateAttributeImages( tmc2_frame* f ) {
                                  f->reconTree.hi, f->reconTree.depth ) );
     ctx->stageEnd( kt );
   } else {
-    std::vector<Pt> h_recon( M );
-    TMC2_HIP( hipMemcpyAsync( h_recon.data(), f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
+    Pt*       hp = ctx->hostD.get<Pt>( M );
+    uint32_t* hi = ctx->hostA.get<uint32_t>( M );
+    if ( !hp || !hi ) {
+      setError( "generateAttributeImages: hipHostMalloc failed" );
+      return TMC2_E_HIP;
+    }
+    TMC2_HIP( hipMemcpyAsync( hp, f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
-    HostGate             gate;
-    const auto           t0 = std::chrono::steady_clock::now();
-    std::vector<int16_t> xyz( 3 * size_t( M ) );
-    for ( uint32_t i = 0; i < M; ++i ) xyz[3 * size_t( i )] = h_recon[i].x, xyz[3 * size_t( i ) + 1] = h_recon[i].y, xyz[3 * size_t( i ) + 2] = h_recon[i].z;
-    f->reconTree.build( xyz.data(), M );
-    const std::vector<Pt>& ptsTree = f->reconTree.ptsTree;
-    const auto t1 = std::chrono::steady_clock::now();
-    ctx->stageAddHostMs( "kdtree_build_recon_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+    {
+      HostGate   gate;
+      const auto t0 = std::chrono::steady_clock::now();
+      f->reconTree.buildInPlace( hp, hi, M );
+      const auto t1 = std::chrono::steady_clock::now();
+      ctx->stageAddHostMs( "kdtree_build_recon_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+    }
     TMC2_TRY( f->d_reconTreePts.alloc( M ) );
     TMC2_TRY( f->d_reconPerm.alloc( M ) );
     TMC2_TRY( f->d_reconNodes.alloc( f->reconTree.nodes.size() ) );
-    TMC2_HIP( hipMemcpyAsync( f->d_reconTreePts.p, ptsTree.data(), size_t( M ) * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( f->d_reconPerm.p, f->reconTree.perm.data(), size_t( M ) * 4, hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_reconTreePts.p, hp, size_t( M ) * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_reconPerm.p, hi, size_t( M ) * 4, hipMemcpyHostToDevice, s ) );
     TMC2_HIP( hipMemcpyAsync( f->d_reconNodes.p, f->reconTree.nodes.data(), f->reconTree.nodes.size() * sizeof( KdNode ),
                               hipMemcpyHostToDevice, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );

@@ -112,7 +112,8 @@ struct KdTreeHost {
   std::vector<KdNode>   nodes;
   int32_t               lo[3], hi[3];
   int                   depth = 0;
-  void                  build( const int16_t* xyz, size_t n );
+  void                  build( const int16_t* xyz, size_t n );              // fills perm / ptsTree
+  void                  buildInPlace( Pt* pts, uint32_t* ind, size_t n );   // caller-owned storage; perm / ptsTree stay empty
 };
 
 

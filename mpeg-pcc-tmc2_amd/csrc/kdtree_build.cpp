@@ -89,22 +89,26 @@ inline void partitionTwoPass( uint32_t* ind, Pt* pts, uint32_t count, int dim, i
 void KdTreeHost::build( const int16_t* xyz, size_t n ) {
   perm.resize( n );
   ptsTree.resize( n );
-  for ( size_t i = 0; i < n; ++i ) {
-    perm[i]    = uint32_t( i );
-    ptsTree[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
-  }
+  for ( size_t i = 0; i < n; ++i ) ptsTree[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
+  buildInPlace( ptsTree.data(), perm.data(), n );
+}
+
+// pts: the points in their original order on entry, in tree order on return; ind receives the permutation.
+// (The device-facing callers pass page-locked staging here, so that the result is uploaded without another copy.)
+void KdTreeHost::buildInPlace( Pt* ptsIO, uint32_t* ind, size_t n ) {
+  for ( size_t i = 0; i < n; ++i ) ind[i] = uint32_t( i );
   nodes.clear();
   nodes.reserve( n / 4 + 16 );
   depth = 0;
   if ( n == 0 ) return;
   Box3 root;
-  for ( int d = 0; d < 3; ++d ) root.lo[d] = root.hi[d] = xyz[d];
-  for ( size_t i = 1; i < n; ++i )
-    for ( int d = 0; d < 3; ++d ) {
-      const int32_t v = xyz[3 * i + d];
-      root.lo[d]      = std::min( root.lo[d], v );
-      root.hi[d]      = std::max( root.hi[d], v );
-    }
+  root.lo[0] = root.hi[0] = ptsIO[0].x, root.lo[1] = root.hi[1] = ptsIO[0].y, root.lo[2] = root.hi[2] = ptsIO[0].z;
+  for ( size_t i = 1; i < n; ++i ) {
+    const Pt p = ptsIO[i];
+    root.lo[0] = std::min<int32_t>( root.lo[0], p.x ), root.hi[0] = std::max<int32_t>( root.hi[0], p.x );
+    root.lo[1] = std::min<int32_t>( root.lo[1], p.y ), root.hi[1] = std::max<int32_t>( root.hi[1], p.y );
+    root.lo[2] = std::min<int32_t>( root.lo[2], p.z ), root.hi[2] = std::max<int32_t>( root.hi[2], p.z );
+  }
   for ( int d = 0; d < 3; ++d ) {
     lo[d] = root.lo[d];
     hi[d] = root.hi[d];
@@ -137,8 +141,8 @@ void KdTreeHost::build( const int16_t* xyz, size_t n ) {
       nodes.push_back( KdNode{} );
       depth                = std::max( depth, f.depth );
       const uint32_t count = f.end - f.begin;
-      uint32_t*      ind   = perm.data() + f.begin;
-      Pt*            pts   = ptsTree.data() + f.begin;
+      uint32_t*      seg   = ind + f.begin;
+      Pt*            pts   = ptsIO + f.begin;
       // one pass: actual range of the node's points in all three dims
       int32_t mn[3] = {pts[0].x, pts[0].y, pts[0].z}, mx[3] = {pts[0].x, pts[0].y, pts[0].z};
       for ( uint32_t i = 1; i < count; ++i ) {
@@ -179,7 +183,7 @@ void KdTreeHost::build( const int16_t* xyz, size_t n ) {
       const int32_t mid = ( f.box.lo[cutDim] + f.box.hi[cutDim] ) / 2;
       const int32_t cut = std::min( std::max( mid, mn[cutDim] ), mx[cutDim] );
       uint32_t      lim1, lim2;
-      partitionTwoPass( ind, pts, count, cutDim, cut, lim1, lim2, scratch.data() );
+      partitionTwoPass( seg, pts, count, cutDim, cut, lim1, lim2, scratch.data() );
       const uint32_t half = count / 2;
       const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
       f.cutDim            = int16_t( cutDim );
