@@ -279,8 +279,8 @@ int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int launchEdgeDots( tmc2_frame* f, double* d_edgeDot );
 int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount );
-void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
-                              const double* edgeDot, int8_t* sign, void* scratch );
+int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
+                             const double* edgeDot, int8_t* sign, void* scratch );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
 int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp );

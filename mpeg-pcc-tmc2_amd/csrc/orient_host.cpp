@@ -109,6 +109,19 @@ struct VertexHeap {
       }
     }
   }
+  // delete the pending entry in slot i (its vertex has been reached another way)
+  void remove( size_t i ) {
+    const HeapEntry last = heap.back();
+    heap.pop_back();
+    if ( i == heap.size() ) return;
+    const bool up = less( heap[i], last );
+    heap[i]       = last;
+    st[last.v]    = int32_t( i );
+    if ( up )
+      siftUp( i );
+    else
+      siftDown( i );
+  }
   HeapEntry popMax() {
     const HeapEntry top  = heap[0];
     const HeapEntry last = heap.back();
@@ -131,21 +144,32 @@ inline double dot( const double* a, const double* b ) { return a[0] * b[0] + a[1
 // so the walk never touches the normals: the weight of an edge is |edgeDot|, and with sign[u] = +-1 the orientation
 // already given to u, the reference's test "n_u(now) . n_v < 0" is sign[u] * edgeDot < 0.  Normals are read only at
 // the (rare) seeds of new components.  Output: sign[i] = -1 where the reference would have negated normal i by the end
-// of the growth (the global majority flip is left to the caller).  scratch: n * 4 bytes or nullptr.
+// of the growth (the global majority flip is left to the caller).
+//
+// Strong edges.  The growth always takes the heaviest pending edge, so once it stands on a vertex it exhausts every
+// edge of weight >= tau it can reach before it takes any lighter one: between two light edges it absorbs exactly the
+// set R reachable from the entry vertex over strong (>= tau) directed edges, and no strong edge leads from anything
+// visited earlier into R (it would have been taken before the light edge).  WHICH strong edges become tree edges
+// depends on their order, but if every strong edge with both ends in R agrees with one sign assignment (the signed
+// graph on R is balanced -- the normal case: neighbouring normals that are nearly parallel up to sign), every
+// admissible tree yields that same assignment.  So R is absorbed by a plain breadth-first sweep: no heap traffic for
+// strong edges, light edges are offered as usual (their order of arrival is immaterial: the heap keeps the best
+// in-edge per vertex under an order-independent rule, and none of them can be taken before R is complete).  Every
+// strong edge inside R is checked against the assignment; a single disagreement means the order would have
+// mattered, and the caller repeats the whole growth the plain way (tau = infinity).
+// scratch: n * 8 bytes or nullptr.
 // The walk is bound by the latency of its scattered reads (the 16 state records of a row's neighbours, the rows of the
 // next vertex), so those are issued together / ahead of use.
-void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
-                              const double* edgeDot, int8_t* sign, void* scratch ) {
-  if ( n == 0 ) return;
-  std::vector<VState> own;
-  if ( !scratch ) {
-    own.resize( n );
-    scratch = own.data();
-  }
-  VState*    st = reinterpret_cast<VState*>( scratch );
+static bool growSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
+                       const double* edgeDot, int8_t* sign, void* scratch, double tau ) {
+  VState*    st    = reinterpret_cast<VState*>( scratch );
+  uint32_t*  phase = reinterpret_cast<uint32_t*>( scratch ) + n;  // which absorption reached the vertex
   VertexHeap heap( n, st );
-  for ( size_t i = 0; i < n; ++i ) sign[i] = 1;
-  constexpr int kMaxK = 64;
+  for ( size_t i = 0; i < n; ++i ) sign[i] = 1, phase[i] = 0;
+  constexpr int         kMaxK = 64;
+  std::vector<uint32_t> queue;
+  queue.reserve( 1 << 16 );
+  uint32_t epoch = 0;
   auto prefetchRows = [&]( uint32_t v ) {
     const char* r = reinterpret_cast<const char*>( knn + size_t( v ) * k );
     const char* d = reinterpret_cast<const char*>( edgeDot + size_t( v ) * k );
@@ -153,15 +177,40 @@ void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn,
     for ( int o = 0; o < k * 4; o += 64 ) __builtin_prefetch( r + o, 0, 0 );
     for ( int o = 0; o < k * 8; o += 64 ) __builtin_prefetch( d + o, 0, 0 );
   };
-  auto expand = [&]( uint32_t cur ) {
-    const double    sc  = double( sign[cur] );
-    const uint32_t* row = knn + size_t( cur ) * k;
-    const double*   dr  = edgeDot + size_t( cur ) * k;
-    int32_t         pos[kMaxK];
-    for ( int j = 0; j < k; ++j ) pos[j] = st[row[j]];  // independent loads: the misses overlap
-    for ( int j = 0; j < k; ++j )
-      // an earlier offer of this row may have moved things: re-read the (now cached) state of a pending vertex
-      if ( pos[j] != kVisited ) heap.offer( row[j], st[row[j]], sc * dr[j], cur );
+  // v0 has just been visited and signed: absorb everything strongly reachable from it.  false = inconsistent
+  auto absorb = [&]( uint32_t v0 ) -> bool {
+    ++epoch;
+    phase[v0] = epoch;
+    queue.clear();
+    queue.push_back( v0 );
+    for ( size_t head = 0; head < queue.size(); ++head ) {
+      const uint32_t cur = queue[head];
+      if ( head + 1 < queue.size() ) prefetchRows( queue[head + 1] );
+      const double    sc  = double( sign[cur] );
+      const uint32_t* row = knn + size_t( cur ) * k;
+      const double*   dr  = edgeDot + size_t( cur ) * k;
+      int32_t         pos[kMaxK];
+      for ( int j = 0; j < k; ++j ) pos[j] = st[row[j]];  // independent loads: the misses overlap
+      for ( int j = 0; j < k; ++j ) {
+        const uint32_t v      = row[j];
+        const double   d      = sc * dr[j];
+        const bool     strong = std::fabs( d ) >= tau;
+        const int32_t  pv     = st[v];  // an earlier edge of this row may have changed it (cached by now)
+        if ( pv == kVisited ) {
+          if ( strong && phase[v] == epoch && ( d < 0.0 ) != ( sign[v] < 0 ) && v != cur ) return false;
+        } else if ( strong ) {
+          if ( pv >= 0 ) heap.remove( size_t( pv ) );
+          st[v]    = kVisited;
+          sign[v]  = d < 0.0 ? -1 : 1;
+          phase[v] = epoch;
+          queue.push_back( v );
+        } else {
+          heap.offer( v, pv, d, cur );
+        }
+      }
+      (void)pos;
+    }
+    return true;
   };
   for ( size_t seed = 0; seed < n; ++seed ) {
     if ( st[seed] == kVisited ) continue;
@@ -195,18 +244,44 @@ void orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn,
       }
     }
     if ( dot( normals + 3 * seed, acc ) < 0.0 ) sign[seed] = -1;
-    expand( uint32_t( seed ) );
+    if ( !absorb( uint32_t( seed ) ) ) return false;
     while ( !heap.heap.empty() ) {
       const HeapEntry e = heap.popMax();
       // the new top is the likeliest next pop: have its rows on the way while this vertex is expanded
       if ( !heap.heap.empty() ) prefetchRows( heap.heap[0].v );
       if ( e.d < 0.0 ) sign[e.v] = -1;
-      expand( e.v );
+      if ( !absorb( e.v ) ) return false;
     }
   }
+  return true;
 }
 
-// normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]; scratch: n * 4 bytes or nullptr
+// returns the number of growths it took (1: the first strong-edge threshold held; each disagreement costs one more)
+int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
+                             const double* edgeDot, int8_t* sign, void* scratch ) {
+  if ( n == 0 ) return 0;
+  std::vector<uint64_t> own;
+  if ( !scratch ) {
+    own.resize( n );
+    scratch = own.data();
+  }
+  // thresholds tried in turn: ~11 degrees first (nearly every edge on a smooth surface is strong, the growth is
+  // mostly a breadth-first sweep), then ~3.6 degrees, then none (the plain growth, always exact by construction)
+  static const double first = [] {
+    const char* e = getenv( "TMC2_ORIENT_TAU" );  // test hook; >= 2 goes straight to the plain growth
+    return e ? atof( e ) : 0.98;
+  }();
+  int growths = 0;
+  for ( double tau : {first, 0.998} ) {
+    if ( tau > 1.5 ) break;
+    ++growths;
+    if ( growSigns( xyz, n, knn, k, normals, edgeDot, sign, scratch, tau ) ) return growths;
+  }
+  growSigns( xyz, n, knn, k, normals, edgeDot, sign, scratch, 4.0 );  // no edge is "strong"
+  return growths + 1;
+}
+
+// normals: [n][3] in/out (host), knn: [n][k] (host), xyz: [n][3]; scratch: n * 8 bytes or nullptr
 void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch ) {
   if ( n == 0 ) return;
   std::vector<double> edgeDotV( n * size_t( k ) );
@@ -215,9 +290,10 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
     for ( int j = 0; j < k; ++j ) edgeDot[u * k + j] = dot( normals + 3 * u, normals + 3 * size_t( knn[u * k + j] ) );
   std::vector<int8_t> sign( n );
   const auto          tt0 = std::chrono::steady_clock::now();
-  orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch );
+  const int growths = orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch );
   if ( getenv( "TMC2_ORIENT_TIMING" ) )  // test hook: time of the growth alone
-    fprintf( stderr, "orient core %.1f ms\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tt0 ).count() );
+    fprintf( stderr, "orient core %.1f ms (%d growth%s)\n",
+             std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tt0 ).count(), growths, growths == 1 ? "" : "s" );
   size_t negCount = 0;
   for ( size_t i = 0; i < n; ++i ) {
     if ( sign[i] < 0 ) {
@@ -265,8 +341,9 @@ int orientNormalsHost( tmc2_frame* f ) {
     HostGate gate;
     t0 = std::chrono::steady_clock::now();
     // the randomly accessed state lives in ordinary (not pinned) memory of this thread
-    if ( ctx->orientScratch.size() < n ) ctx->orientScratch.resize( n );
-    orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data() );
+    if ( ctx->orientScratch.size() < 2 * n ) ctx->orientScratch.resize( 2 * n );
+    if ( orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data() ) > 1 )
+      ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames whose first threshold did not hold
     t1 = std::chrono::steady_clock::now();
   }
   ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );

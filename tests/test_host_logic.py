@@ -70,3 +70,23 @@ def test_host_orientation_disconnected_components(oracle):
     knn = oracle.knn_self(two, 16)
     raw = oracle.compute_normals(two, knn)
     assert np.array_equal(bits(T.host_orient_normals(two, knn, raw)), bits(oracle.orient_normals(two, knn, raw)))
+
+
+@pytest.mark.parametrize("tau", ["0.0", "0.5", "0.9", "0.98", "0.9999", "4"])
+def test_host_orientation_strong_edge_thresholds(oracle, tau, tmp_path):
+    """The strong-edge shortcut of the orientation (breadth-first absorption of >= tau edges, verified for sign
+    consistency, repeated with a tighter threshold / the plain growth on disagreement) must give the reference's
+    result for ANY threshold: 0 makes every edge strong (fails the check at once on real clouds and falls back),
+    4 disables it.  The threshold is read once per process, hence the subprocess."""
+    import subprocess, sys, os
+    xyz, _ = synth_cloud("small")
+    knn = oracle.knn_self(xyz, 16)
+    raw = oracle.compute_normals(xyz, knn)
+    exp = oracle.orient_normals(xyz, knn, raw)
+    np.savez(tmp_path / "in.npz", xyz=xyz, knn=knn, raw=raw)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import tmc2_amd as T; z = np.load(%r);"
+            "np.save(%r, T.host_orient_normals(z['xyz'], z['knn'], z['raw']))"
+            % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpeg-pcc-tmc2_amd"),
+               str(tmp_path / "in.npz"), str(tmp_path / "out.npy")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, TMC2_ORIENT_TAU=tau))
+    assert np.array_equal(bits(np.load(tmp_path / "out.npy")), bits(exp))
