@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--workload", default="longdress_vox10")
     ap.add_argument("--workers", type=int, default=0, help="concurrent frames per GPU (0 = auto)")
     ap.add_argument("--host-steps", type=int, default=16, help="max concurrent host-resident steps (tree build, orientation)")
-    ap.add_argument("--kdtree", default="auto", choices=["auto", "device", "host"],
+    ap.add_argument("--kdtree", default="auto", choices=["auto", "device", "host", "adaptive"],
                     help="where the k-d trees are built (auto: host when >= 8 frames are in flight per GPU, else device)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
@@ -67,7 +67,7 @@ def algorithmic_bytes(kernel, n_points):
         "knn1_source_in_recon": 8 + 8,
         "normals": 64 + 24,                 # neighbour ids in, fp64 normal out (neighbour positions are cache hits)
         "k:ccMutualMask": 64 + 2,           # own adjacency row in, 16-bit mask out (neighbour rows are cache hits)
-        "k:ccUnionFind": 64 + 2 + 1 + 1 + 4 + 4,  # row, mask, plane, raw flag, parent, group label
+        "k:ccUnion": 64 + 2 + 1 + 1 + 4,    # row, mask, plane, raw flag, parent
         "k:ccRelax": 64 + 2 + 1 + 1 + 4,    # per sweep
         "initial_segmentation": 24 + 1,
     }
@@ -113,8 +113,8 @@ def main():
     workers = a.workers or max(1, min(len(clouds), 32, (os.cpu_count() or 8) // world))
     T.load_library().tmc2_set_host_parallelism(max(1, a.host_steps // world))
     # many frames in flight and idle host cores: the (exact) host k-d tree builder leaves the GPU to the other stages
-    kd_host = a.kdtree == "host" or (a.kdtree == "auto" and workers >= 8)
-    T.load_library().tmc2_set_kdtree_placement(1 if kd_host else 0)
+    kd_mode = {"device": 0, "host": 1, "adaptive": 2}.get(a.kdtree, 1 if workers >= 8 else 0)
+    T.load_library().tmc2_set_kdtree_placement(kd_mode)
     enc = T.GofEncoder(local, workers, a.iterations, 11, 4, 1280, 1280, timing=True, first_domain=rank * workers)
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
@@ -179,6 +179,14 @@ def main():
     avg_ms = gpu_kernels[dom] / launches
     pts_per_launch = n_points / max(1, len(frames))
     achieved = algorithmic_bytes(dom, pts_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), if this kernel is in them
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if dom in pmc.get("stages", {}) and a.workload == pmc.get("workload"):
+            traffic = pmc["stages"][dom]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "encoder patch+image-gen frames/sec, longdress_vox10 32-frame GOF",
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -193,7 +201,7 @@ def main():
                              "reported separately (metric_ms_per_frame)",
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(achieved / 8000.0, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                     "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                      "launches": launches},
         "stage_ms_per_frame": {k: round(v / (a.steps * len(frames)), 3) for k, v in sorted(ms.items())},
     }

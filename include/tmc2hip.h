@@ -108,8 +108,10 @@ void tmc2_frame_destroy( tmc2_frame* f );
 int  tmc2_kdtree_build( tmc2_frame* f );
 /* process-wide: where PCCKdTree::init runs.  0 (default): on the device, lowest latency for a frame on its own;
  * 1: on the host (same algorithm, same tree) -- with many frames in flight and idle host cores this leaves the
- * GPU to the stages only it can run.  Both builders are exact; the choice never changes a result.           */
-void tmc2_set_kdtree_placement( int onHost );
+ * GPU to the stages only it can run; 2: adaptive -- on the host while one of the host slots
+ * (tmc2_set_host_parallelism) is free at that moment, else on the device.  Both builders are exact; the choice
+ * never changes a result.                                                                                   */
+void tmc2_set_kdtree_placement( int mode );
 /* inspection: the permutation nanoflann's build leaves in vind (tree order -> point index), uint32[n], and the
  * number of tree levels; the search order under distance ties is a function of exactly this permutation */
 int  tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth );

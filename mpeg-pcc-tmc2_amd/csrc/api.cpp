@@ -29,12 +29,17 @@ void setHostParallelism( int n ) {
   g_gateLimit = n < 0 ? 0 : n;
   g_gateCv.notify_all();
 }
-HostGate::HostGate() {
+HostGate::HostGate( bool wait ) {
   std::unique_lock<std::mutex> lk( g_gateMutex );
+  if ( !wait && g_gateLimit != 0 && g_gateBusy >= g_gateLimit ) return;  // no free slot: not held
   g_gateCv.wait( lk, [] { return g_gateLimit == 0 || g_gateBusy < g_gateLimit; } );
   ++g_gateBusy;
+  held = true;
 }
-HostGate::~HostGate() {
+HostGate::~HostGate() { release(); }
+void HostGate::release() {
+  if ( !held ) return;
+  held = false;
   std::lock_guard<std::mutex> g( g_gateMutex );
   --g_gateBusy;
   g_gateCv.notify_one();
@@ -263,21 +268,24 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
 namespace tmc2 {
 // where the k-d trees are built (tmc2_set_kdtree_placement; TMC2_KDTREE_HOST=1 presets "host")
 static std::atomic<int> g_kdtreeOnHost{-1};
-bool kdtreeOnHost() {
+int kdtreePlacement() {
   int v = g_kdtreeOnHost.load( std::memory_order_relaxed );
   if ( v < 0 ) {
     const char* e = getenv( "TMC2_KDTREE_HOST" );
-    v             = ( e && e[0] == '1' ) ? 1 : 0;
+    v             = ( e && e[0] >= '0' && e[0] <= '2' ) ? e[0] - '0' : 0;
     g_kdtreeOnHost.store( v, std::memory_order_relaxed );
   }
-  return v != 0;
+  return v;
 }
-void setKdtreeOnHost( bool host ) { g_kdtreeOnHost.store( host ? 1 : 0, std::memory_order_relaxed ); }
+void setKdtreePlacement( int mode ) { g_kdtreeOnHost.store( mode < 0 || mode > 2 ? 0 : mode, std::memory_order_relaxed ); }
 }  // namespace tmc2
 
 int tmc2_frame::ensureTree() {
   if ( haveTree ) return TMC2_OK;
-  if ( !tmc2::kdtreeOnHost() ) {
+  const int placement = tmc2::kdtreePlacement();
+  // adaptive: take a host slot if one is free right now, otherwise the device builds it (same tree either way)
+  tmc2::HostGate gate( placement == 1 );
+  if ( placement == 0 || !gate.held ) {
     const int sid = ctx->stageBegin( "kdtree_build" );
     TMC2_TRY( tmc2::buildKdTreeDevice( ctx, d_pts.p, n, d_ptsTree, d_perm, d_nodes, tree.lo, tree.hi, tree.depth ) );
     ctx->stageEnd( sid );
@@ -292,13 +300,13 @@ int tmc2_frame::ensureTree() {
     return TMC2_E_HIP;
   }
   {
-    tmc2::HostGate gate;
-    const auto     t0 = std::chrono::steady_clock::now();
+    const auto t0 = std::chrono::steady_clock::now();
     for ( uint64_t i = 0; i < n; ++i ) hp[i] = Pt{h_xyz[3 * size_t( i )], h_xyz[3 * size_t( i ) + 1], h_xyz[3 * size_t( i ) + 2], 0};
     tree.buildInPlace( hp, hi, n );
     const auto t1 = std::chrono::steady_clock::now();
     ctx->stageAddHostMs( "kdtree_build_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
   }
+  gate.release();
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( tree.nodes.size() ) );
@@ -330,7 +338,7 @@ int tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth )
   return TMC2_OK;
 }
 
-void tmc2_set_kdtree_placement( int onHost ) { tmc2::setKdtreeOnHost( onHost != 0 ); }
+void tmc2_set_kdtree_placement( int mode ) { tmc2::setKdtreePlacement( mode ); }
 
 void tmc2_frame_destroy( tmc2_frame* f ) {
   if ( !f ) return;
@@ -360,7 +368,11 @@ int tmc2_kdtree_search( tmc2_frame* f, const int16_t* queries, uint64_t nq, int 
   tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( f->ensureTree() );
   std::vector<Pt> q( nq );
-  for ( uint64_t i = 0; i < nq; ++i ) q[i] = Pt{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2], 0};
+  bool bounded = true;  // every coordinate in [-4096, 12287]: the packed LDS-stack traversal applies
+  for ( uint64_t i = 0; i < nq; ++i ) {
+    q[i] = Pt{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2], 0};
+    for ( int d = 0; d < 3; ++d ) bounded = bounded && queries[3 * i + d] >= -4096 && queries[3 * i + d] <= 12287;
+  }
   DevBuf<Pt>       d_q;
   DevBuf<uint32_t> d_idx, d_dist;
   TMC2_TRY( d_q.alloc( nq ) );
@@ -368,7 +380,7 @@ int tmc2_kdtree_search( tmc2_frame* f, const int16_t* queries, uint64_t nq, int 
   if ( dist2 ) TMC2_TRY( d_dist.alloc( nq * size_t( k ) ) );
   hipStream_t s = f->ctx->stream;
   TMC2_HIP( hipMemcpyAsync( d_q.p, q.data(), nq * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-  TMC2_TRY( launchKnnQueries( f, d_q.p, nq, k, d_idx.p, dist2 ? d_dist.p : nullptr ) );
+  TMC2_TRY( launchKnnQueries( f, d_q.p, nq, k, d_idx.p, dist2 ? d_dist.p : nullptr, bounded ) );
   TMC2_HIP( hipMemcpyAsync( idx, d_idx.p, nq * size_t( k ) * 4, hipMemcpyDeviceToHost, s ) );
   if ( dist2 ) TMC2_HIP( hipMemcpyAsync( dist2, d_dist.p, nq * size_t( k ) * 4, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );

@@ -482,7 +482,9 @@ int generateAttributeImages( tmc2_frame* f ) {
   ctx->stageEnd( sid );
   f->reconCount = M;
   // ---- tree over the reconstruction (like S1) --------------------------------------------------------------
-  if ( !kdtreeOnHost() ) {
+  const int placement = kdtreePlacement();
+  HostGate  treeGate( placement == 1 );
+  if ( placement == 0 || !treeGate.held ) {
     const int kt = ctx->stageBegin( "kdtree_build_recon" );
     TMC2_TRY( buildKdTreeDevice( ctx, f->d_recon.p, M, f->d_reconTreePts, f->d_reconPerm, f->d_reconNodes, f->reconTree.lo,
                                  f->reconTree.hi, f->reconTree.depth ) );
@@ -497,12 +499,12 @@ int generateAttributeImages( tmc2_frame* f ) {
     TMC2_HIP( hipMemcpyAsync( hp, f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
     {
-      HostGate   gate;
       const auto t0 = std::chrono::steady_clock::now();
       f->reconTree.buildInPlace( hp, hi, M );
       const auto t1 = std::chrono::steady_clock::now();
       ctx->stageAddHostMs( "kdtree_build_recon_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
     }
+    treeGate.release();
     TMC2_TRY( f->d_reconTreePts.alloc( M ) );
     TMC2_TRY( f->d_reconPerm.alloc( M ) );
     TMC2_TRY( f->d_reconNodes.alloc( f->reconTree.nodes.size() ) );
@@ -519,6 +521,7 @@ int generateAttributeImages( tmc2_frame* f ) {
   for ( int d = 0; d < 3; ++d ) rt.lo[d] = f->reconTree.lo[d], rt.hi[d] = f->reconTree.hi[d];
   rt.depth = f->reconTree.depth;
   rt.n     = M;
+  rt.queriesBounded = true;  // queried with the frame's own points; dispatch() checks both boxes
   // ---- S18 ----------------------------------------------------------------------------------------------
   TMC2_TRY( f->d_reconRgb.alloc( size_t( M ) * 4 ) );
   const dim3 grdM( ( M + 255 ) / 256 );

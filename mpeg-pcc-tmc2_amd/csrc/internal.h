@@ -136,6 +136,7 @@ struct TreeDev {
   int32_t         lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   int             depth = 0;
   uint64_t        n     = 0;
+  bool            queriesBounded = false;  // the caller vouches: every query coordinate lies in [-4096, 12287]
 };
 
 // GPU time per named stage / kernel: hipEvent pairs recorded on the context's stream, folded lazily when the
@@ -258,8 +259,10 @@ namespace tmc2 {
 // ~100 MB working set, so running more of them at once than there are last-level-cache domains makes all of them
 // slower.  Frames beyond the limit wait here while their siblings' GPU phases proceed.  0 = unlimited.
 struct HostGate {
-  HostGate();
+  explicit HostGate( bool wait = true );  // wait = false: take a slot only if one is free right now
   ~HostGate();
+  void release();
+  bool held = false;
 };
 void setHostParallelism( int n );
 // RAII guard of every extern "C" entry: selects the device and makes the context's pool current
@@ -270,7 +273,8 @@ struct ApiScope {
 };
 // kernels / stage launchers (each returns TMC2_OK or an error code; all work is queued on ctx->stream)
 int launchKnnSelf( tmc2_frame* f, int k );
-int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist );
+int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist,
+                      bool queriesBounded );
 int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx,
                    uint32_t* d_dist, const char* stage );
 TreeDev frameTree( const tmc2_frame* f );
@@ -288,7 +292,7 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
 int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
-bool kdtreeOnHost();
+int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
 int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,
                        DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
 int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );

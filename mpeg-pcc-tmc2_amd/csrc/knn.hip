@@ -18,16 +18,26 @@
 //   * the recursion of searchLevel is unrolled into near-descend / far-stack form.  A far child is
 //     visited iff mindist <= worst AT THE TIME THE NEAR SUBTREE HAS BEEN FINISHED -- exactly when it
 //     is popped.  Because worst never grows, entries that already fail at push time can be dropped.
+//   * the far-child stack is the memory hog: every query pushes ~one entry per tree level on its first descent.  As a
+//     16-byte scratch record that is ~1 KB of private memory per lane, ~200 MB live across the chip: it streams
+//     through L2 and evicts the (small, shared) tree, and the counters show 56x the algorithmic bytes.  So the
+//     stack lives in LDS, packed to 8 bytes per entry: every per-dimension distance on the path is the SQUARE of an
+//     integer offset to a split / box plane, so the entry keeps node id (22 bits) + three offsets (14 bits each).
+//     Callers that cannot bound their coordinates (|offset| < 16384) or their tree (< 4 M nodes, <= kLdsLevels levels)
+//     get the scratch-stack kernel instead (same traversal, same results).
 //   * all arithmetic is int32: coordinates < 2^12, squared distances < 2^26 (the reference holds the
 //     same integers in float/double -- exact below 2^24 for <= 11-bit data, KDTreeVectorOfVectorsAdaptor.h:126).
+#include <algorithm>
+
 #include "internal.h"
 
 namespace tmc2 {
 
 namespace {
 
-constexpr int      kMaxStack = 64;
-constexpr uint32_t kInf      = 0x7FFFFFFFu;
+constexpr int      kMaxStack  = 64;
+constexpr int      kLdsLevels = 40;  // deepest tree the LDS-stack kernel takes (its LDS use is levels x 2 KiB per block)
+constexpr uint32_t kInf       = 0x7FFFFFFFu;
 
 struct RootBox {
   int lo[3], hi[3];
@@ -49,7 +59,8 @@ __device__ __forceinline__ void knnInsert( uint32_t ( &bd )[K], uint32_t ( &bi )
 
 // SELF = true : queries are the tree-order points themselves, row j is written to out[perm[j]]
 // SELF = false: queries come from `queries` (any order), row j is written to out[j]
-template <int K, bool SELF>
+// LDS = true: far-child stack in LDS, 8-byte packed entries (see the header); false: 16-byte entries in scratch
+template <int K, bool SELF, bool LDS>
 __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTree, const uint32_t* __restrict__ perm,
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
@@ -65,33 +76,41 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
     bd[i] = kInf;
     bi[i] = 0;
   }
-  // distance of the query to the root box, per dimension (nanoflann computeInitialDistances)
-  int d0 = 0, d1 = 0, d2 = 0;
-  if ( qx < root.lo[0] ) d0 = ( qx - root.lo[0] ) * ( qx - root.lo[0] );
-  if ( qx > root.hi[0] ) d0 = ( qx - root.hi[0] ) * ( qx - root.hi[0] );
-  if ( qy < root.lo[1] ) d1 = ( qy - root.lo[1] ) * ( qy - root.lo[1] );
-  if ( qy > root.hi[1] ) d1 = ( qy - root.hi[1] ) * ( qy - root.hi[1] );
-  if ( qz < root.lo[2] ) d2 = ( qz - root.lo[2] ) * ( qz - root.lo[2] );
-  if ( qz > root.hi[2] ) d2 = ( qz - root.hi[2] ) * ( qz - root.hi[2] );
+  // offset of the query to the root box, per dimension (nanoflann computeInitialDistances); the per-dimension
+  // distances are the squares of these offsets all the way down
+  int o0 = 0, o1 = 0, o2 = 0;
+  if ( qx < root.lo[0] ) o0 = root.lo[0] - qx;
+  if ( qx > root.hi[0] ) o0 = qx - root.hi[0];
+  if ( qy < root.lo[1] ) o1 = root.lo[1] - qy;
+  if ( qy > root.hi[1] ) o1 = qy - root.hi[1];
+  if ( qz < root.lo[2] ) o2 = root.lo[2] - qz;
+  if ( qz > root.hi[2] ) o2 = qz - root.hi[2];
 
-  uint4    stack[kMaxStack];
+  extern __shared__ unsigned long long ldsStack[];  // [level][thread], LDS = true only
+  uint4    scratchStack[LDS ? 1 : kMaxStack];
   int      sp   = 0;
   uint32_t node = 0;
   for ( ;; ) {
     KdNode nd = nodes[node];
     while ( nd.dim >= 0 ) {
       const int  v        = nd.dim == 0 ? qx : ( nd.dim == 1 ? qy : qz );
-      const int  dcur     = nd.dim == 0 ? d0 : ( nd.dim == 1 ? d1 : d2 );
+      const int  ocur     = nd.dim == 0 ? o0 : ( nd.dim == 1 ? o1 : o2 );
       const int  diff1    = v - nd.divlow;
       const int  diff2    = v - nd.divhigh;
       const bool leftNear = ( diff1 + diff2 ) < 0;
-      const int  cut      = leftNear ? diff2 * diff2 : diff1 * diff1;
+      const int  ofar     = leftNear ? abs( diff2 ) : abs( diff1 );
       const uint32_t nearC = leftNear ? uint32_t( nd.a ) : uint32_t( nd.b );
       const uint32_t farC  = leftNear ? uint32_t( nd.b ) : uint32_t( nd.a );
-      const uint32_t farMin = uint32_t( d0 + d1 + d2 + cut - dcur );
-      if ( farMin <= bd[K - 1] && sp < kMaxStack ) {
-        stack[sp++] = make_uint4( farC, uint32_t( nd.dim == 0 ? cut : d0 ), uint32_t( nd.dim == 1 ? cut : d1 ),
-                                  uint32_t( nd.dim == 2 ? cut : d2 ) );
+      const uint32_t farMin = uint32_t( o0 * o0 + o1 * o1 + o2 * o2 + ofar * ofar - ocur * ocur );
+      if ( farMin <= bd[K - 1] && sp < ( LDS ? kLdsLevels : kMaxStack ) ) {
+        const uint32_t f0 = uint32_t( nd.dim == 0 ? ofar : o0 ), f1 = uint32_t( nd.dim == 1 ? ofar : o1 ),
+                       f2 = uint32_t( nd.dim == 2 ? ofar : o2 );
+        if ( LDS )
+          ldsStack[sp * 256 + threadIdx.x] = (unsigned long long)farC | ( (unsigned long long)f0 << 22 ) |
+                                             ( (unsigned long long)f1 << 36 ) | ( (unsigned long long)f2 << 50 );
+        else
+          scratchStack[sp] = make_uint4( farC, f0, f1, f2 );
+        ++sp;
       }
       node = nearC;
       nd   = nodes[node];
@@ -104,12 +123,20 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
     }
     bool found = false;
     while ( sp > 0 ) {
-      const uint4 e = stack[--sp];
-      if ( e.y + e.z + e.w <= bd[K - 1] ) {
-        node  = e.x;
-        d0    = int( e.y );
-        d1    = int( e.z );
-        d2    = int( e.w );
+      --sp;
+      uint32_t en, e0, e1, e2;
+      if ( LDS ) {
+        const unsigned long long e = ldsStack[sp * 256 + threadIdx.x];
+        en = uint32_t( e ) & 0x3FFFFFu, e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
+      } else {
+        const uint4 e = scratchStack[sp];
+        en = e.x, e0 = e.y, e1 = e.z, e2 = e.w;
+      }
+      if ( e0 * e0 + e1 * e1 + e2 * e2 <= bd[K - 1] ) {
+        node  = en;
+        o0    = int( e0 );
+        o1    = int( e1 );
+        o2    = int( e2 );
         found = true;
         break;
       }
@@ -144,9 +171,22 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
   }
   const dim3 block( 256 );
   const dim3 grid( uint32_t( ( nq + 255 ) / 256 ) );
-#define TMC2_LAUNCH_K( KK )                                                                                   \
-  hipLaunchKernelGGL( ( knnKernel<KK, SELF> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q, uint32_t( nq ), \
-                      idx, dist )
+  // the packed LDS stack needs: every offset < 2^14 (tree box and queries inside a 16383-wide window -- the caller
+  // vouches for the queries with t.queriesBounded), node ids < 2^22, and at most kLdsLevels pending far children
+  bool lds = t.queriesBounded && t.depth <= kLdsLevels && t.n <= ( uint64_t( 1 ) << 21 );
+  for ( int d = 0; d < 3; ++d ) lds = lds && t.lo[d] >= 0 && t.hi[d] <= 8191;
+  const size_t ldsBytes = lds ? size_t( std::max( t.depth, 1 ) ) * 256 * 8 : 0;
+#define TMC2_LAUNCH_K( KK )                                                                                          \
+  if ( lds ) {                                                                                                       \
+    if ( ldsBytes > 48 * 1024 )                                                                                      \
+      TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( knnKernel<KK, SELF, true> ),                       \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, int( ldsBytes ) ) );               \
+    hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, ldsBytes, s, t.ptsTree, t.perm, t.nodes, rb, q,   \
+                        uint32_t( nq ), idx, dist );                                                                 \
+  } else {                                                                                                           \
+    hipLaunchKernelGGL( ( knnKernel<KK, SELF, false> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,         \
+                        uint32_t( nq ), idx, dist );                                                                 \
+  }
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
     case 4: TMC2_LAUNCH_K( 4 ); break;
@@ -172,6 +212,8 @@ TreeDev frameTree( const tmc2_frame* f ) {
   }
   t.depth = f->tree.depth;
   t.n     = f->n;
+  // queries against a frame's tree are the frame's own points or its reconstruction (non-negative, < 2^13)
+  t.queriesBounded = true;
   return t;
 }
 
@@ -187,8 +229,11 @@ int launchKnnSelf( tmc2_frame* f, int k ) {
   return r;
 }
 
-int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist ) {
-  return launchKnnTree( f->ctx, frameTree( f ), d_queries, nq, k, d_idx, d_dist, "knn_query" );
+int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx, uint32_t* d_dist,
+                      bool queriesBounded ) {
+  TreeDev t        = frameTree( f );
+  t.queriesBounded = queriesBounded;
+  return launchKnnTree( f->ctx, t, d_queries, nq, k, d_idx, d_dist, "knn_query" );
 }
 
 int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx,

@@ -633,11 +633,11 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     int sid = ctx->stageBegin( "patches_cc" );
     hipLaunchKernelGGL( ccInitKernel, grdN, blk, 0, s, n, d_parent.p, d_lab.p, d_ccCount.p );
     {
-      const int kt = ctx->stageBegin( "k:ccUnionFind" );
+      const int kt = ctx->stageBegin( "k:ccUnion" );
       hipLaunchKernelGGL( ccUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
                           d_parent.p );
-      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p );
       ctx->stageEnd( kt );
+      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p );
     }
     for ( int guard = 0; guard < 1 << 20; ++guard ) {
       // a few sweeps per host round-trip; the flag is cleared before the LAST sweep of the batch only,

@@ -151,12 +151,13 @@ def test_gpu_transfer_colors_long_candidate_lists(gpu_ctx, oracle):
         assert np.array_equal(gpu_ctx.transfer_colors(xyz, rgb, tgt), oracle.transfer_colors(xyz, rgb, tgt))
 
 
-@pytest.mark.parametrize("placement", ["device", "host"])
+@pytest.mark.parametrize("placement", ["device", "host", "adaptive"])
 def test_gpu_gof_encoder_worker_threads(oracle, placement):
     """The GOF orchestration used by bench.py: one pinned worker thread + context per in-flight frame, both k-d tree
     placements.  Five frames over three workers, everything compared with the oracle."""
     frames = [synth_cloud("tiny", f) for f in range(5)]
-    T.load_library().tmc2_set_kdtree_placement(1 if placement == "host" else 0)
+    T.load_library().tmc2_set_kdtree_placement({"device": 0, "host": 1, "adaptive": 2}[placement])
+    T.load_library().tmc2_set_host_parallelism(1 if placement == "adaptive" else 16)   # adaptive: one host slot, the rest spills to the device
     try:
         enc = T.GofEncoder(0, workers=3, iterations=10)
         frs = enc.upload(frames)
@@ -171,7 +172,9 @@ def test_gpu_gof_encoder_worker_threads(oracle, placement):
                 assert np.array_equal(img[k], ea[k]), k
             assert np.array_equal(fr.get_attribute_images(), eb["attribute"])
         used = enc.stage_calls()
-        assert used.get("kdtree_build_host" if placement == "host" else "kdtree_build", 0) >= 5
+        host, dev = used.get("kdtree_build_host", 0), used.get("kdtree_build", 0)
+        assert (host, dev) == (5, 0) if placement == "host" else (host, dev) == (0, 5) if placement == "device" else host + dev == 5
         enc.close()
     finally:
         T.load_library().tmc2_set_kdtree_placement(0)
+        T.load_library().tmc2_set_host_parallelism(16)

@@ -73,6 +73,8 @@ def test_gpu_knn_edge_cases(gpu_ctx, oracle):
     fr = gpu_ctx.frame(xyz)
     far = np.array([[0, 0, 0], [1023, 1023, 1023], [500, -20, 2000]], np.int16)  # outside the root box
     assert np.array_equal(fr.kdtree_search(far, 16), oracle.knn(xyz, far, 16))
+    wide = np.array([[-6000, 10, 10], [20000, 5, 5], [512, 512, -32768]], np.int16)  # beyond the packed-offset range:
+    assert np.array_equal(fr.kdtree_search(wide, 16), oracle.knn(xyz, wide, 16))    # takes the scratch-stack kernel
     with pytest.raises(T.Tmc2Error):
         gpu_ctx.frame(xyz[:5]).kdtree_search(xyz[:5], 16)                         # k > n is an error, not UB
 
