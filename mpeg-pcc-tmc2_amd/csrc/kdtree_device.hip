@@ -193,6 +193,8 @@ __global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t l
   const uint32_t* sums2 = a.tile2;
   (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
   const uint32_t nRound = ( n + uint32_t( kBlock ) - 1u ) & ~( uint32_t( kBlock ) - 1u );
+  __shared__ uint32_t blockSeg;
+  __shared__ int      blockRange[6 * kWaves];
   // ---- pass 1: move every point to its segment of this level, accumulate the tight ranges ------------------
   for ( uint32_t base = blockIdx.x * blockDim.x; base < nRound; base += gsize ) {
     const uint32_t i = base + threadIdx.x;
@@ -216,6 +218,38 @@ __global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t l
       mny = mxy = p.y;
       mnz = mxz = p.z;
     }
+    // Near the root a whole block sits inside one segment (segments are contiguous): then the block reduces in
+    // registers / LDS and reports ONCE -- otherwise thousands of waves would queue up on the same six words.
+    if ( threadIdx.x == 0 ) blockSeg = s;
+    __syncthreads();
+    const bool uniform = __syncthreads_and( s == blockSeg ) != 0;
+    if ( uniform ) {
+      if ( blockSeg != kNone ) {
+#pragma unroll
+        for ( int off = 32; off > 0; off >>= 1 ) {
+          mnx = min( mnx, __shfl_xor( mnx, off, 64 ) ), mny = min( mny, __shfl_xor( mny, off, 64 ) ), mnz = min( mnz, __shfl_xor( mnz, off, 64 ) );
+          mxx = max( mxx, __shfl_xor( mxx, off, 64 ) ), mxy = max( mxy, __shfl_xor( mxy, off, 64 ) ), mxz = max( mxz, __shfl_xor( mxz, off, 64 ) );
+        }
+        if ( lane == 0 ) {
+          int* w = blockRange + 6 * wave;
+          w[0] = mnx, w[1] = mny, w[2] = mnz, w[3] = mxx, w[4] = mxy, w[5] = mxz;
+        }
+        __syncthreads();
+        if ( threadIdx.x < 6 ) {
+          int v = blockRange[threadIdx.x];
+          for ( int w = 1; w < kWaves; ++w ) v = threadIdx.x < 3 ? min( v, blockRange[6 * w + threadIdx.x] ) : max( v, blockRange[6 * w + threadIdx.x] );
+          BuildSeg* q = cur + blockSeg;
+          int32_t*  slot = threadIdx.x < 3 ? &q->mn[threadIdx.x] : &q->mx[threadIdx.x - 3];
+          if ( threadIdx.x < 3 ) {
+            if ( v < __hip_atomic_load( slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( slot, v );
+          } else {
+            if ( v > __hip_atomic_load( slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( slot, v );
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     // points of one segment are contiguous: a segmented shuffle reduction leaves each run's range in its first lane
 #pragma unroll
     for ( int off = 1; off < 64; off <<= 1 ) {
@@ -229,9 +263,14 @@ __global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t l
     }
     const uint32_t ps = __shfl_up( s, 1, 64 );
     if ( s != kNone && ( lane == 0 || ps != s ) ) {
+      // near the root thousands of waves report to the same record: look first, most have nothing to add
       BuildSeg* q = cur + s;
-      atomicMin( &q->mn[0], mnx ), atomicMin( &q->mn[1], mny ), atomicMin( &q->mn[2], mnz );
-      atomicMax( &q->mx[0], mxx ), atomicMax( &q->mx[1], mxy ), atomicMax( &q->mx[2], mxz );
+      if ( mnx < __hip_atomic_load( &q->mn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( &q->mn[0], mnx );
+      if ( mny < __hip_atomic_load( &q->mn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( &q->mn[1], mny );
+      if ( mnz < __hip_atomic_load( &q->mn[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( &q->mn[2], mnz );
+      if ( mxx > __hip_atomic_load( &q->mx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &q->mx[0], mxx );
+      if ( mxy > __hip_atomic_load( &q->mx[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &q->mx[1], mxy );
+      if ( mxz > __hip_atomic_load( &q->mx[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &q->mx[2], mxz );
     }
   }
 }

@@ -44,6 +44,14 @@ __device__ __forceinline__ int coordOf( const Pt p, int axis ) { return axis == 
 // share the key, so instead of 64 atomics on one address per wavefront the lanes holding the same key are reduced
 // with cross-lane shuffles and ONE lane issues the atomics.  Loops once per distinct key present in the wave.
 // All 64 lanes must call these (key < 0 = nothing to contribute).
+// A body-sized patch still receives one report per wave (thousands per address): look before the atomic -- the running
+// value is monotone, so a stale read can only cause a redundant atomic, never a missed one.
+__device__ __forceinline__ void lazyAtomicMin( int32_t* a, int v ) {
+  if ( v < __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( a, v );
+}
+__device__ __forceinline__ void lazyAtomicMax( int32_t* a, int v ) {
+  if ( v > __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( a, v );
+}
 __device__ __forceinline__ int waveMinMasked( int v, bool mine ) {
   v = mine ? v : 0x7FFFFFFF;
 #pragma unroll
@@ -278,8 +286,8 @@ __global__ __launch_bounds__( 256 ) void patchMinUvKernel( const Pt* __restrict_
     const unsigned long long same   = __ballot( mine );
     const int                mu = waveMinMasked( u, mine ), mv = waveMinMasked( v, mine );
     if ( lane == leader ) {
-      atomicMin( &minUv[2 * key], mu );
-      atomicMin( &minUv[2 * key + 1], mv );
+      lazyAtomicMin( &minUv[2 * key], mu );
+      lazyAtomicMin( &minUv[2 * key + 1], mv );
     }
     todo &= ~same;
   }
@@ -313,12 +321,12 @@ __global__ __launch_bounds__( 256 ) void patchTrimBboxKernel( const Pt* __restri
     const int x0 = waveMinMasked( q.x, mine ), y0 = waveMinMasked( q.y, mine ), z0 = waveMinMasked( q.z, mine );
     const int x1 = waveMaxMasked( q.x, mine ), y1 = waveMaxMasked( q.y, mine ), z1 = waveMaxMasked( q.z, mine );
     if ( lane == leader ) {
-      atomicMin( &bbox[6 * key + 0], x0 );
-      atomicMin( &bbox[6 * key + 1], y0 );
-      atomicMin( &bbox[6 * key + 2], z0 );
-      atomicMax( &bbox[6 * key + 3], x1 );
-      atomicMax( &bbox[6 * key + 4], y1 );
-      atomicMax( &bbox[6 * key + 5], z1 );
+      lazyAtomicMin( &bbox[6 * key + 0], x0 );
+      lazyAtomicMin( &bbox[6 * key + 1], y0 );
+      lazyAtomicMin( &bbox[6 * key + 2], z0 );
+      lazyAtomicMax( &bbox[6 * key + 3], x1 );
+      lazyAtomicMax( &bbox[6 * key + 4], y1 );
+      lazyAtomicMax( &bbox[6 * key + 5], z1 );
     }
     todo &= ~same;
   }

@@ -10,8 +10,8 @@ import re
 import sys
 from collections import defaultdict
 
-STAGE_OF = {"knnKernel<16, true>": "knn_self", "knnKernel<8, false>": "knn8_recon_in_source",
-            "knnKernel<1, false>": "knn1_source_in_recon", "normalsKernel<16>": "normals",
+STAGE_OF = {"knnKernel<16, true, true>": "knn_self", "knnKernel<8, false, true>": "knn8_recon_in_source",
+            "knnKernel<1, false, true>": "knn1_source_in_recon", "normalsKernel<16>": "normals",
             "ccUnionKernel<16>": "k:ccUnion", "ccRelaxKernel<16>": "k:ccRelax", "ccMutualMaskKernel<16>": "k:ccMutualMask",
             "initialSegmentationKernel": "initial_segmentation"}
 
