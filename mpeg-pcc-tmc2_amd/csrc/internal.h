@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "tmc2hip.h"
@@ -283,8 +284,29 @@ int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int launchEdgeDots( tmc2_frame* f, double* d_edgeDot );
 int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount );
+// contracted orientation graph (orient_host.cpp): clusters of mutual strong edges, their cross edges grouped by source
+struct OrientCrossEdge {
+  uint32_t u, v;  // start / end vertex (original indices)
+  double   d;     // n_u . n_v on the original normals
+};
+struct OrientContraction {
+  const uint32_t*        root;    // [n]   cluster (= root vertex id) of every vertex
+  const uint8_t*         parity;  // [n]   1: the vertex' sign is the opposite of its cluster's
+  const uint32_t*        off;     // [n+1] cross edges of cluster c: edges[off[c] .. off[c+1])
+  const OrientCrossEdge* edges;
+};
+bool orientContractedSigns( size_t n, const OrientContraction& g, double tau,
+                            const std::function<int( uint32_t, const std::function<int( uint32_t )>& )>& seedSign,
+                            int8_t* clusterSign, void* scratch );
+int  orientSeedSign( uint32_t i, const uint32_t* row, int k, const std::function<const double*( uint32_t )>& normalOf,
+                     const int16_t* xyz0, const std::function<int( uint32_t )>& signOf );
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
-                             const double* edgeDot, int8_t* sign, void* scratch );
+                             const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction );
+double orientFirstTau();
+int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_root,
+                               DevBuf<uint8_t>& d_parity, OrientContraction& g, bool& ok );
+int launchClusterSigns( tmc2_frame* f, const uint32_t* d_root, const uint8_t* d_parity, const int8_t* d_clusterSign,
+                        int8_t* d_sign );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
 int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp );

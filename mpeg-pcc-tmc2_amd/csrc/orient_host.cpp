@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 
 #include "internal.h"
 
@@ -51,11 +52,13 @@ __attribute__( ( always_inline ) ) inline unsigned __int128 edgeKey( const HeapE
 struct VertexHeap {
   std::vector<HeapEntry> heap;
   VState*                st;
+  const uint32_t*        owner;  // nullptr: one pending entry per vertex; else per owner[vertex] (cluster walk)
 
-  VertexHeap( size_t n, VState* state ) : st( state ) {
+  VertexHeap( size_t n, VState* state, const uint32_t* ownerOf = nullptr ) : st( state ), owner( ownerOf ) {
     for ( size_t i = 0; i < n; ++i ) st[i] = kAbsent;
     heap.reserve( n / 4 + 16 );
   }
+  size_t slotOf( uint32_t v ) const { return owner ? owner[v] : v; }
   // strict "a has a smaller key than b" in the reference's edge order (weight, start, end)
   static bool less( const HeapEntry& a, const HeapEntry& b ) { return edgeKey( a ) < edgeKey( b ); }
   void siftUp( size_t i ) {
@@ -64,11 +67,11 @@ struct VertexHeap {
       const size_t p = ( i - 1 ) >> 2;
       if ( !less( heap[p], e ) ) break;
       heap[i]           = heap[p];
-      st[heap[i].v] = int32_t( i );
+      st[slotOf( heap[i].v )] = int32_t( i );
       i                 = p;
     }
     heap[i]     = e;
-    st[e.v] = int32_t( i );
+    st[slotOf( e.v )] = int32_t( i );
   }
   void siftDown( size_t i ) {
     const size_t    n = heap.size();
@@ -87,11 +90,11 @@ struct VertexHeap {
       }
       if ( !less( e, heap[c] ) ) break;
       heap[i]           = heap[c];
-      st[heap[i].v] = int32_t( i );
+      st[slotOf( heap[i].v )] = int32_t( i );
       i                 = c;
     }
     heap[i]     = e;
-    st[e.v] = int32_t( i );
+    st[slotOf( e.v )] = int32_t( i );
   }
   // offer in-edge (signed dot d as it stands now, start) to unvisited vertex v whose state is `pos`; the key of a
   // pending vertex lives in its heap entry (the heap is small and cache resident)
@@ -100,11 +103,10 @@ struct VertexHeap {
       heap.push_back( HeapEntry{d, v, start} );
       siftUp( heap.size() - 1 );
     } else {
-      HeapEntry&   h = heap[size_t( pos )];
-      const double w = std::fabs( d ), cur = std::fabs( h.d );
-      if ( w > cur || ( w == cur && start > h.s ) ) {
-        h.d = d;
-        h.s = start;
+      HeapEntry&      h = heap[size_t( pos )];
+      const HeapEntry c{d, v, start};  // same end vertex in the per-vertex walk; any vertex of the cluster otherwise
+      if ( less( h, c ) ) {
+        h = c;
         siftUp( size_t( pos ) );
       }
     }
@@ -116,7 +118,7 @@ struct VertexHeap {
     if ( i == heap.size() ) return;
     const bool up = less( heap[i], last );
     heap[i]       = last;
-    st[last.v]    = int32_t( i );
+    st[slotOf( last.v )] = int32_t( i );
     if ( up )
       siftUp( i );
     else
@@ -130,7 +132,7 @@ struct VertexHeap {
       heap[0] = last;
       siftDown( 0 );
     }
-    st[top.v] = kVisited;
+    st[slotOf( top.v )] = kVisited;
     return top;
   }
 };
@@ -256,22 +258,231 @@ static bool growSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k,
   return true;
 }
 
-// returns the number of growths it took (1: the first strong-edge threshold held; each disagreement costs one more)
+// ---- the same growth on the CONTRACTED graph ----------------------------------------------------------------------
+// Vertices joined by MUTUAL strong edges (u lists v, v lists u, |n_u . n_v| >= tau) reach each other over strong
+// edges, so the growth absorbs such a cluster as a whole the moment it touches it (see above); if the cluster's strong
+// edges agree with one relative sign assignment (parity to a root -- established and verified by the contraction,
+// device: orient_contract.hip, host: contractOnHost below), only the cluster's sign S is left to decide:
+// sign[v] = S[root[v]] * (-1)^parity[v].  What remains of the graph are the CROSS edges (both ends in different
+// clusters), a few per cent of all edges on a smooth surface, grouped by source cluster.  The walk below is
+// growSigns() with clusters for vertices: strong cross edges (one-way ones) are absorbed breadth-first and checked,
+// light ones go through the heap, whose key is still the reference's (weight, start vertex, end vertex) -- one pending
+// entry per unvisited cluster: the best edge into any of its vertices is the one the per-vertex heap would pop first.
+// seedSign( i, signOf ) returns the orientation the reference gives seed vertex i (its rule needs the seed's k-NN row
+// and a few normals: the caller knows where those live).  Returns false if a strong cross edge disagrees.
+bool orientContractedSigns( size_t n, const OrientContraction& g, double tau,
+                            const std::function<int( uint32_t, const std::function<int( uint32_t )>& )>& seedSign,
+                            int8_t* clusterSign, void* scratch ) {
+  VState*    st    = reinterpret_cast<VState*>( scratch );       // by cluster (root vertex id)
+  uint32_t*  phase = reinterpret_cast<uint32_t*>( scratch ) + n;
+  VertexHeap heap( n, st, g.root );
+  for ( size_t i = 0; i < n; ++i ) clusterSign[i] = 1, phase[i] = 0;
+  std::vector<uint32_t> queue;
+  queue.reserve( 1 << 12 );
+  uint32_t epoch = 0;
+  auto absorb = [&]( uint32_t c0 ) -> bool {
+    ++epoch;
+    phase[c0] = epoch;
+    queue.clear();
+    queue.push_back( c0 );
+    for ( size_t head = 0; head < queue.size(); ++head ) {
+      const uint32_t c  = queue[head];
+      const double   sc = double( clusterSign[c] );
+      for ( uint32_t e = g.off[c]; e < g.off[c + 1]; ++e ) {
+        const OrientCrossEdge& x  = g.edges[e];
+        const uint32_t         c2 = g.root[x.v];
+        const double           d  = ( ( g.parity[x.u] ^ g.parity[x.v] ) & 1 ) ? -( sc * x.d ) : sc * x.d;  // = sign[u] n_u.n_v (-1)^parity[v]
+        const bool             strong = std::fabs( x.d ) >= tau;
+        const int32_t          pv     = st[c2];
+        if ( pv == kVisited ) {
+          if ( strong && phase[c2] == epoch && ( d < 0.0 ) != ( clusterSign[c2] < 0 ) ) return false;
+        } else if ( strong ) {
+          if ( pv >= 0 ) heap.remove( size_t( pv ) );
+          st[c2]          = kVisited;
+          clusterSign[c2] = d < 0.0 ? -1 : 1;
+          phase[c2]       = epoch;
+          queue.push_back( c2 );
+        } else {
+          heap.offer( x.v, pv, d, x.u );
+        }
+      }
+    }
+    return true;
+  };
+  const std::function<int( uint32_t )> signOf = [&]( uint32_t v ) -> int {  // 0: not oriented yet
+    const uint32_t c = g.root[v];
+    if ( st[c] != kVisited ) return 0;
+    return ( g.parity[v] & 1 ) ? -int( clusterSign[c] ) : int( clusterSign[c] );
+  };
+  for ( size_t seed = 0; seed < n; ++seed ) {
+    const uint32_t c = g.root[seed];
+    if ( st[c] == kVisited ) continue;
+    const int sv   = seedSign( uint32_t( seed ), signOf );  // evaluated while the seed's cluster is still unvisited
+    st[c]          = kVisited;
+    clusterSign[c] = int8_t( ( g.parity[seed] & 1 ) ? -sv : sv );
+    if ( !absorb( c ) ) return false;
+    while ( !heap.heap.empty() ) {
+      const HeapEntry e  = heap.popMax();
+      const uint32_t  c2 = g.root[e.v];
+      clusterSign[c2]    = e.d < 0.0 ? -1 : 1;
+      if ( !absorb( c2 ) ) return false;
+    }
+  }
+  return true;
+}
+
+// orientation of seed vertex i by the reference's rule (PCCNormalsGenerator.cpp:198-225): the sum of the already
+// oriented neighbours' normals as they stand (row order), else the previous point's normal as it stands, else the
+// direction to the view point
+int orientSeedSign( uint32_t i, const uint32_t* row, int k, const std::function<const double*( uint32_t )>& normalOf,
+                    const int16_t* xyz0, const std::function<int( uint32_t )>& signOf ) {
+  double acc[3]   = {0.0, 0.0, 0.0};
+  size_t accCount = 0;
+  for ( int j = 0; j < k; ++j ) {
+    const uint32_t v  = row[j];
+    const int      sv = v != i ? signOf( v ) : 0;
+    if ( sv != 0 ) {
+      const double* nv = normalOf( v );
+      acc[0] += double( sv ) * nv[0];
+      acc[1] += double( sv ) * nv[1];
+      acc[2] += double( sv ) * nv[2];
+      ++accCount;
+    }
+  }
+  if ( accCount == 0 ) {
+    if ( i != 0 ) {
+      const int     sp = signOf( i - 1 );  // i is the smallest unvisited index: i - 1 has been oriented
+      const double* np = normalOf( i - 1 );
+      acc[0] = double( sp == 0 ? 1 : sp ) * np[0];
+      acc[1] = double( sp == 0 ? 1 : sp ) * np[1];
+      acc[2] = double( sp == 0 ? 1 : sp ) * np[2];
+    } else {
+      acc[0] = 0.0 - xyz0[0];
+      acc[1] = 0.0 - xyz0[1];
+      acc[2] = 0.0 - xyz0[2];
+    }
+  }
+  return dot( normalOf( i ), acc ) < 0.0 ? -1 : 1;
+}
+
+// host-side contraction (the device path does the same in orient_contract.hip): union-find with parity over the
+// mutual strong edges, consistency check, cross edges grouped by source cluster.  false = some cluster's strong edges
+// disagree (the caller then grows the plain way / with a tighter threshold).
+static bool contractOnHost( size_t n, const uint32_t* knn, int k, const double* edgeDot, double tau,
+                            std::vector<uint32_t>& root, std::vector<uint8_t>& parity, std::vector<uint32_t>& off,
+                            std::vector<OrientCrossEdge>& edges ) {
+  std::vector<uint32_t> parent( n );
+  std::vector<uint8_t>  par( n, 0 );  // parity to the parent
+  for ( size_t i = 0; i < n; ++i ) parent[i] = uint32_t( i );
+  auto find = [&]( uint32_t x, uint8_t& px ) -> uint32_t {  // with path compression
+    uint32_t r = x;
+    uint8_t  p = 0;
+    while ( parent[r] != r ) p ^= par[r], r = parent[r];
+    // second pass: point everything at the root with the accumulated parity
+    uint32_t y = x;
+    uint8_t  q = p;
+    while ( parent[y] != y ) {
+      const uint32_t next = parent[y];
+      const uint8_t  step = par[y];
+      parent[y]           = r;
+      par[y]              = q;
+      q ^= step;
+      y = next;
+    }
+    px = p;
+    return r;
+  };
+  for ( size_t u = 0; u < n; ++u )
+    for ( int j = 0; j < k; ++j ) {
+      const uint32_t v = knn[u * k + j];
+      const double   d = edgeDot[u * k + j];
+      if ( v >= u || std::fabs( d ) < tau ) continue;  // every mutual edge is seen from both ends: the larger acts
+      bool mutual = false;
+      for ( int t = 0; t < k; ++t ) mutual |= knn[size_t( v ) * k + t] == u;
+      if ( !mutual ) continue;
+      uint8_t        pu, pv;
+      const uint32_t ru = find( uint32_t( u ), pu ), rv = find( v, pv );
+      const uint8_t  s  = d < 0.0 ? 1 : 0;
+      if ( ru == rv ) {
+        if ( ( pu ^ pv ) != s ) return false;
+      } else {
+        parent[ru] = rv;
+        par[ru]    = uint8_t( pu ^ pv ^ s );
+      }
+    }
+  root.resize( n );
+  parity.resize( n );
+  for ( size_t i = 0; i < n; ++i ) root[i] = find( uint32_t( i ), parity[i] );
+  off.assign( n + 1, 0 );
+  for ( size_t u = 0; u < n; ++u )
+    for ( int j = 0; j < k; ++j )
+      if ( root[knn[u * k + j]] != root[u] ) ++off[root[u] + 1];
+  for ( size_t i = 0; i < n; ++i ) off[i + 1] += off[i];
+  edges.resize( off[n] );
+  std::vector<uint32_t> cursor( off.begin(), off.end() - 1 );
+  for ( size_t u = 0; u < n; ++u )
+    for ( int j = 0; j < k; ++j ) {
+      const uint32_t v = knn[u * k + j];
+      if ( root[v] != root[u] ) edges[cursor[root[u]]++] = OrientCrossEdge{uint32_t( u ), v, edgeDot[u * k + j]};
+    }
+  return true;
+}
+
+// first strong-edge threshold: ~11 degrees (nearly every edge on a smooth surface is strong)
+double orientFirstTau() {
+  static const double first = [] {
+    const char* e = getenv( "TMC2_ORIENT_TAU" );  // test hook; >= 2 goes straight to the plain growth
+    return e ? atof( e ) : 0.98;
+  }();
+  return first;
+}
+
+// returns the number of growths it took (1: the first attempt held; each disagreement costs one more).
+// tryContraction: contract on the host first (the device path has done that -- or failed at it -- on the device)
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
-                             const double* edgeDot, int8_t* sign, void* scratch ) {
+                             const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction ) {
   if ( n == 0 ) return 0;
   std::vector<uint64_t> own;
   if ( !scratch ) {
     own.resize( n );
     scratch = own.data();
   }
-  // thresholds tried in turn: ~11 degrees first (nearly every edge on a smooth surface is strong, the growth is
-  // mostly a breadth-first sweep), then ~3.6 degrees, then none (the plain growth, always exact by construction)
-  static const double first = [] {
-    const char* e = getenv( "TMC2_ORIENT_TAU" );  // test hook; >= 2 goes straight to the plain growth
-    return e ? atof( e ) : 0.98;
-  }();
+  // thresholds tried in turn: the first (contracted, then point by point), then ~3.6 degrees, then none (the plain
+  // growth, always exact by construction)
+  const double first = orientFirstTau();
   int growths = 0;
+  if ( tryContraction && first <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) ) {  // (test hook: point-level walk only)
+    // contracted walk: clusters of mutual strong edges first
+    ++growths;
+    std::vector<uint32_t>        root, off;
+    std::vector<uint8_t>         parity;
+    std::vector<OrientCrossEdge> edges;
+    const auto tc0 = std::chrono::steady_clock::now();
+    const bool okc = contractOnHost( n, knn, k, edgeDot, first, root, parity, off, edges );
+    const auto tc1 = std::chrono::steady_clock::now();
+    if ( getenv( "TMC2_ORIENT_TIMING" ) ) {
+      size_t clusters = 0;
+      for ( size_t i = 0; okc && i < n; ++i ) clusters += root[i] == i;
+      fprintf( stderr, "contraction %.1f ms ok=%d clusters %zu cross edges %zu of %zu\n",
+               std::chrono::duration<double, std::milli>( tc1 - tc0 ).count(), int( okc ), clusters, edges.size(), n * size_t( k ) );
+    }
+    if ( okc ) {
+      const OrientContraction g{root.data(), parity.data(), off.data(), edges.data()};
+      const auto normalOf = [&]( uint32_t v ) { return normals + 3 * size_t( v ); };
+      const auto seedSign = [&]( uint32_t i, const std::function<int( uint32_t )>& signOf ) {
+        return orientSeedSign( i, knn + size_t( i ) * k, k, normalOf, xyz, signOf );
+      };
+      std::vector<int8_t> clusterSign( n );
+      const auto tw0 = std::chrono::steady_clock::now();
+      const bool okw = orientContractedSigns( n, g, first, seedSign, clusterSign.data(), scratch );
+      if ( getenv( "TMC2_ORIENT_TIMING" ) )
+        fprintf( stderr, "contracted walk %.1f ms ok=%d\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tw0 ).count(), int( okw ) );
+      if ( okw ) {
+        for ( size_t i = 0; i < n; ++i ) sign[i] = int8_t( ( parity[i] & 1 ) ? -clusterSign[root[i]] : clusterSign[root[i]] );
+        return growths;
+      }
+    }
+  }
   for ( double tau : {first, 0.998} ) {
     if ( tau > 1.5 ) break;
     ++growths;
@@ -290,7 +501,7 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
     for ( int j = 0; j < k; ++j ) edgeDot[u * k + j] = dot( normals + 3 * u, normals + 3 * size_t( knn[u * k + j] ) );
   std::vector<int8_t> sign( n );
   const auto          tt0 = std::chrono::steady_clock::now();
-  const int growths = orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch );
+  const int growths = orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch, true );
   if ( getenv( "TMC2_ORIENT_TIMING" ) )  // test hook: time of the growth alone
     fprintf( stderr, "orient core %.1f ms (%d growth%s)\n",
              std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tt0 ).count(), growths, growths == 1 ? "" : "s" );
@@ -316,14 +527,68 @@ int orientNormalsHost( tmc2_frame* f ) {
   const size_t n = f->n, edges = n * size_t( f->k );
   tmc2_ctx*    ctx = f->ctx;
   hipStream_t  s   = ctx->stream;
-  // device: per-edge dot products; host staging (pinned, reused per context): rows, dots, normals (seeds only), signs
   DevBuf<double>   d_edgeDot;
-  DevBuf<int8_t>   d_sign;
-  DevBuf<uint32_t> d_negCount;
+  DevBuf<int8_t>   d_sign, d_clusterSign;
+  DevBuf<uint32_t> d_negCount, d_root;
+  DevBuf<uint8_t>  d_parity;
   TMC2_TRY( d_edgeDot.alloc( edges ) );
   TMC2_TRY( d_sign.alloc( n ) );
   TMC2_TRY( d_negCount.alloc( 1 ) );
   TMC2_TRY( launchEdgeDots( f, d_edgeDot.p ) );
+  if ( ctx->orientScratch.size() < 2 * n ) ctx->orientScratch.resize( 2 * n );
+  const double tau = orientFirstTau();
+
+  // ---- fast path: contract on the device, walk the clusters on the host --------------------------------------------
+  bool contracted = false;
+  if ( tau <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) ) {
+    OrientContraction g{};
+    const int         sid = ctx->stageBegin( "orient_contract" );
+    TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );
+    ctx->stageEnd( sid );
+    if ( contracted ) {
+      int8_t* clusterSign = ctx->hostC.get<int8_t>( 2 * n ) + n;  // second half: the first holds the parities (g.parity)
+      // the reference's seed rule reads a k-NN row and a few normals per connected component; which ones is only known
+      // during the walk, and a read-back per seed would queue behind the other frames' bulk copies: both tables come
+      // along in one piece (host memory is touched only where a seed looks)
+      uint32_t* knn = ctx->hostD.get<uint32_t>( edges );
+      double*   nrm = ctx->hostB.get<double>( n * 3 );
+      if ( !knn || !nrm ) {
+        setError( "orientNormals: hipHostMalloc failed" );
+        return TMC2_E_HIP;
+      }
+      TMC2_HIP( hipMemcpyAsync( knn, f->d_knn.p, edges * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipMemcpyAsync( nrm, f->d_normals.p, n * 3 * sizeof( double ), hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+      const int  err      = TMC2_OK;
+      const auto normalOf = [&]( uint32_t v ) -> const double* { return nrm + 3 * size_t( v ); };
+      const auto seedSign = [&]( uint32_t i, const std::function<int( uint32_t )>& signOf ) -> int {
+        return orientSeedSign( i, knn + size_t( i ) * f->k, f->k, normalOf, f->h_xyz.data(), signOf );
+      };
+      bool ok;
+      {
+        HostGate   gate;
+        const auto t0 = std::chrono::steady_clock::now();
+        ok            = orientContractedSigns( n, g, tau, seedSign, clusterSign, ctx->orientScratch.data() );
+        const auto t1 = std::chrono::steady_clock::now();
+        ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
+      }
+      if ( err != TMC2_OK ) {
+        setError( "orientNormals: device read-back failed" );
+        return err;
+      }
+      if ( ok ) {
+        TMC2_TRY( d_clusterSign.alloc( n ) );
+        TMC2_HIP( hipMemcpyAsync( d_clusterSign.p, clusterSign, n, hipMemcpyHostToDevice, s ) );
+        TMC2_TRY( launchClusterSigns( f, d_root.p, d_parity.p, d_clusterSign.p, d_sign.p ) );
+        TMC2_TRY( launchApplyOrientation( f, d_sign.p, d_negCount.p ) );
+        TMC2_HIP( hipStreamSynchronize( s ) );
+        return TMC2_OK;
+      }
+    }
+    ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames that needed the point-level walk
+  }
+
+  // ---- point-level walk: rows, dot products and normals to the host ----------------------------------------------------
   uint32_t* knn  = ctx->hostA.get<uint32_t>( edges );
   double*   nrm  = ctx->hostB.get<double>( n * 3 );
   double*   dots = ctx->hostE.get<double>( edges );
@@ -340,10 +605,7 @@ int orientNormalsHost( tmc2_frame* f ) {
   {
     HostGate gate;
     t0 = std::chrono::steady_clock::now();
-    // the randomly accessed state lives in ordinary (not pinned) memory of this thread
-    if ( ctx->orientScratch.size() < 2 * n ) ctx->orientScratch.resize( 2 * n );
-    if ( orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data() ) > 1 )
-      ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames whose first threshold did not hold
+    orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data(), false );
     t1 = std::chrono::steady_clock::now();
   }
   ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );

@@ -2,6 +2,12 @@
 seams: Frame.normals_compute <-> PCCNormalsGenerator3::compute, Frame.segmenter_* <-> PCCPatchSegmenter3::*,
 Frame.kdtree_search <-> PCCKdTree::search."""
 import ctypes as C
+import os as _os
+
+# One HIP stream per in-flight frame (32 per GPU in a GOF run): the runtime multiplexes streams onto 4 hardware queues by
+# default, and a queue is held by whatever kernel is at its head (e.g. a 140 us single-workgroup closure tail).  Must be
+# set before the HIP runtime initialises; an explicit setting of the user wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import os
 import numpy as np
 

@@ -236,3 +236,20 @@ def test_gpu_refine_many_sweeps(gpu_ctx, oracle):
         fr.set_partition(p0)
         fr.segmenter_refine_grid_based(1024, 3.0, iters, 4, 192)
         assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=iters)), iters
+
+
+@pytest.mark.parametrize("name", ["small", "medium"])
+def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch, name):
+    """S3 both ways: clusters contracted on the device + cluster walk on the host (default), and the point-level walk
+    (what a frame falls back to when a cluster's strong edges disagree) -- same bits as the reference's growth."""
+    xyz, rgb = synth_cloud(name)
+    exp = oracle.normals(xyz)
+    fr = gpu_ctx.frame(xyz, rgb)
+    gpu_ctx.stage_reset()
+    fr.normals_compute(16, 1)
+    assert np.array_equal(fr.get_normals().view(np.uint64), exp.view(np.uint64))
+    assert gpu_ctx.stage_calls().get("orient_contract", 0) == 1 and gpu_ctx.stage_calls().get("orient_normals_regrowth", 0) == 0
+    monkeypatch.setenv("TMC2_ORIENT_NO_CONTRACTION", "1")
+    fr2 = gpu_ctx.frame(xyz, rgb)
+    fr2.normals_compute(16, 1)
+    assert np.array_equal(fr2.get_normals().view(np.uint64), exp.view(np.uint64))
