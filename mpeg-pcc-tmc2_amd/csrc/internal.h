@@ -295,11 +295,13 @@ struct OrientContraction {
   const uint32_t*        off;     // [n+1] cross edges of cluster c: edges[off[c] .. off[c+1])
   const OrientCrossEdge* edges;
 };
-bool orientContractedSigns( size_t n, const OrientContraction& g, double tau,
-                            const std::function<int( uint32_t, const std::function<int( uint32_t )>& )>& seedSign,
-                            int8_t* clusterSign, void* scratch );
-int  orientSeedSign( uint32_t i, const uint32_t* row, int k, const std::function<const double*( uint32_t )>& normalOf,
-                     const int16_t* xyz0, const std::function<int( uint32_t )>& signOf );
+bool orientContractedSigns( size_t n, const OrientContraction& g, double tau, int8_t* clusterSign, uint32_t* component,
+                            std::vector<uint32_t>& seeds, void* scratch );
+void resolveSeedSigns( size_t n, const OrientContraction& g, int kNN, const std::vector<uint32_t>& seeds,
+                       const uint32_t* component, const std::function<const uint32_t*( size_t )>& rowOf,
+                       const std::function<const double*( size_t, int )>& normalOf, const int16_t* xyz0,
+                       int8_t* clusterSign );
+int gatherSeedTables( tmc2_frame* f, const std::vector<uint32_t>& seeds, std::vector<uint32_t>& rows, std::vector<double>& normals );
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
                              const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction );
 double orientFirstTau();

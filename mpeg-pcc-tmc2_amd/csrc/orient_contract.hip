@@ -157,7 +157,43 @@ __global__ __launch_bounds__( 256 ) void clusterSignsKernel( const uint32_t* __r
   if ( u < n ) sign[u] = int8_t( parity[u] ? -clusterSign[root[u]] : clusterSign[root[u]] );
 }
 
+// inputs of the reference's seed rule for the listed seeds: their k-NN rows and the normals of (0) the seed, (1) the
+// point before it in index order, (2 + t) its t-th neighbour
+template <int K>
+__global__ __launch_bounds__( 256 ) void seedTableKernel( const uint32_t* __restrict__ seeds, uint32_t count,
+                                                           const uint32_t* __restrict__ knn, const double* __restrict__ normals,
+                                                           uint32_t* __restrict__ rows, double* __restrict__ out ) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( t >= count * ( K + 2 ) ) return;
+  const uint32_t s = t / ( K + 2 ), j = t % ( K + 2 );
+  const uint32_t i = seeds[s];
+  const uint32_t v = j == 0 ? i : ( j == 1 ? ( i ? i - 1 : 0 ) : knn[size_t( i ) * K + ( j - 2 )] );
+  if ( j >= 2 ) rows[size_t( s ) * K + ( j - 2 )] = v;
+  for ( int c = 0; c < 3; ++c ) out[3 * size_t( t ) + c] = normals[3 * size_t( v ) + c];
+}
+
 }  // namespace
+
+// rows: [count][16], normals: [count][18][3] (host vectors), for the seeds the walk has listed
+int gatherSeedTables( tmc2_frame* f, const std::vector<uint32_t>& seeds, std::vector<uint32_t>& rows, std::vector<double>& normals ) {
+  const uint32_t count = uint32_t( seeds.size() );
+  rows.assign( size_t( count ) * 16, 0 );
+  normals.assign( size_t( count ) * 18 * 3, 0.0 );
+  if ( !count ) return TMC2_OK;
+  hipStream_t      s = f->ctx->stream;
+  DevBuf<uint32_t> d_seeds, d_rows;
+  DevBuf<double>   d_out;
+  TMC2_TRY( d_seeds.alloc( count ) );
+  TMC2_TRY( d_rows.alloc( size_t( count ) * 16 ) );
+  TMC2_TRY( d_out.alloc( size_t( count ) * 18 * 3 ) );
+  TMC2_HIP( hipMemcpyAsync( d_seeds.p, seeds.data(), size_t( count ) * 4, hipMemcpyHostToDevice, s ) );
+  hipLaunchKernelGGL( seedTableKernel<16>, dim3( ( count * 18 + 255 ) / 256 ), dim3( 256 ), 0, s, d_seeds.p, count, f->d_knn.p,
+                      f->d_normals.p, d_rows.p, d_out.p );
+  TMC2_HIP( hipMemcpyAsync( rows.data(), d_rows.p, rows.size() * 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( normals.data(), d_out.p, normals.size() * 8, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  return TMC2_OK;
+}
 
 // Contracts the orientation graph of frame f on the device (k = 16) and brings it to the host (page-locked staging of the
 // context).  ok = false: some cluster's strong edges disagree.  d_root / d_parity stay valid for launchClusterSigns.

@@ -15,6 +15,7 @@
 // are popped after it has been visited and are then ignored), so we keep one key (w, start) per
 // unvisited vertex in an indexed max-heap and raise it when a better in-edge appears.  The heap's
 // maximum is the same edge the reference's queue would accept next; stale entries never exist.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -268,11 +269,15 @@ static bool growSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k,
 // growSigns() with clusters for vertices: strong cross edges (one-way ones) are absorbed breadth-first and checked,
 // light ones go through the heap, whose key is still the reference's (weight, start vertex, end vertex) -- one pending
 // entry per unvisited cluster: the best edge into any of its vertices is the one the per-vertex heap would pop first.
-// seedSign( i, signOf ) returns the orientation the reference gives seed vertex i (its rule needs the seed's k-NN row
-// and a few normals: the caller knows where those live).  Returns false if a strong cross edge disagrees.
-bool orientContractedSigns( size_t n, const OrientContraction& g, double tau,
-                            const std::function<int( uint32_t, const std::function<int( uint32_t )>& )>& seedSign,
-                            int8_t* clusterSign, void* scratch ) {
+// Seeds.  The reference orients the first point of every connected component by a rule that reads the normals of its
+// already oriented neighbours (orientSeedSign below).  Everything else in the component is oriented RELATIVE to its
+// seed, so the walk gives every seed +1 provisionally, numbers the components in the order it opens them
+// (component[c], per cluster) and lists the seeds; resolveSeedSigns() then applies the rule seed by seed -- "already
+// oriented" at the time seed k was picked means exactly "in a component < k" -- and a cluster's final sign is its
+// provisional one times its component's.  The rule's inputs (one k-NN row and <= k + 2 normals per seed) can thus be
+// fetched in one piece after the walk.  Returns false if a strong cross edge disagrees.
+bool orientContractedSigns( size_t n, const OrientContraction& g, double tau, int8_t* clusterSign, uint32_t* component,
+                            std::vector<uint32_t>& seeds, void* scratch ) {
   VState*    st    = reinterpret_cast<VState*>( scratch );       // by cluster (root vertex id)
   uint32_t*  phase = reinterpret_cast<uint32_t*>( scratch ) + n;
   VertexHeap heap( n, st, g.root );
@@ -309,17 +314,13 @@ bool orientContractedSigns( size_t n, const OrientContraction& g, double tau,
     }
     return true;
   };
-  const std::function<int( uint32_t )> signOf = [&]( uint32_t v ) -> int {  // 0: not oriented yet
-    const uint32_t c = g.root[v];
-    if ( st[c] != kVisited ) return 0;
-    return ( g.parity[v] & 1 ) ? -int( clusterSign[c] ) : int( clusterSign[c] );
-  };
+  seeds.clear();
   for ( size_t seed = 0; seed < n; ++seed ) {
     const uint32_t c = g.root[seed];
     if ( st[c] == kVisited ) continue;
-    const int sv   = seedSign( uint32_t( seed ), signOf );  // evaluated while the seed's cluster is still unvisited
+    seeds.push_back( uint32_t( seed ) );
     st[c]          = kVisited;
-    clusterSign[c] = int8_t( ( g.parity[seed] & 1 ) ? -sv : sv );
+    clusterSign[c] = int8_t( ( g.parity[seed] & 1 ) ? -1 : 1 );  // the seed itself: +1 for now
     if ( !absorb( c ) ) return false;
     while ( !heap.heap.empty() ) {
       const HeapEntry e  = heap.popMax();
@@ -327,42 +328,71 @@ bool orientContractedSigns( size_t n, const OrientContraction& g, double tau,
       clusterSign[c2]    = e.d < 0.0 ? -1 : 1;
       if ( !absorb( c2 ) ) return false;
     }
+    // everything visited since the last seed belongs to this component: stamp it (phase[] holds absorption epochs,
+    // the epochs of one component are consecutive)
+  }
+  // component of a cluster = number of seeds opened before (or at) its absorption: epochs are handed out in order, so
+  // a second pass over the seeds' epochs is enough
+  {
+    std::vector<uint32_t> firstEpoch( seeds.size() );
+    for ( size_t k = 0; k < seeds.size(); ++k ) firstEpoch[k] = phase[g.root[seeds[k]]];
+    for ( size_t i = 0; i < n; ++i ) {
+      if ( g.root[i] != i ) continue;
+      const uint32_t ep = phase[i];
+      component[i]      = uint32_t( std::upper_bound( firstEpoch.begin(), firstEpoch.end(), ep ) - firstEpoch.begin() ) - 1u;
+    }
   }
   return true;
 }
 
-// orientation of seed vertex i by the reference's rule (PCCNormalsGenerator.cpp:198-225): the sum of the already
-// oriented neighbours' normals as they stand (row order), else the previous point's normal as it stands, else the
-// direction to the view point
-int orientSeedSign( uint32_t i, const uint32_t* row, int k, const std::function<const double*( uint32_t )>& normalOf,
-                    const int16_t* xyz0, const std::function<int( uint32_t )>& signOf ) {
-  double acc[3]   = {0.0, 0.0, 0.0};
-  size_t accCount = 0;
-  for ( int j = 0; j < k; ++j ) {
-    const uint32_t v  = row[j];
-    const int      sv = v != i ? signOf( v ) : 0;
-    if ( sv != 0 ) {
-      const double* nv = normalOf( v );
-      acc[0] += double( sv ) * nv[0];
-      acc[1] += double( sv ) * nv[1];
-      acc[2] += double( sv ) * nv[2];
-      ++accCount;
+// Seed rule, after the walk: compSign[k] for every component, and the clusters' final signs.
+// rowOf( k ) / normalOf( k, j ): the k-NN row of seed k and the normals of (j = 0) the seed, (j = 1) the point before it
+// in index order, (j = 2 + t) its t-th neighbour.
+void resolveSeedSigns( size_t n, const OrientContraction& g, int kNN, const std::vector<uint32_t>& seeds,
+                       const uint32_t* component, const std::function<const uint32_t*( size_t )>& rowOf,
+                       const std::function<const double*( size_t, int )>& normalOf, const int16_t* xyz0,
+                       int8_t* clusterSign ) {
+  std::vector<int8_t> compSign( seeds.size(), 1 );
+  for ( size_t k = 0; k < seeds.size(); ++k ) {
+    const uint32_t  i   = seeds[k];
+    const uint32_t* row = rowOf( k );
+    // sign of v as it stood when seed k was picked: 0 if v had not been oriented yet
+    const auto signThen = [&]( uint32_t v ) -> int {
+      const uint32_t c = g.root[v];
+      if ( component[c] >= k ) return 0;
+      const int sc = int( clusterSign[c] ) * int( compSign[component[c]] );
+      return ( g.parity[v] & 1 ) ? -sc : sc;
+    };
+    double acc[3]   = {0.0, 0.0, 0.0};
+    size_t accCount = 0;
+    for ( int j = 0; j < kNN; ++j ) {
+      const uint32_t v  = row[j];
+      const int      sv = v != i ? signThen( v ) : 0;
+      if ( sv != 0 ) {
+        const double* nv = normalOf( k, 2 + j );
+        acc[0] += double( sv ) * nv[0];
+        acc[1] += double( sv ) * nv[1];
+        acc[2] += double( sv ) * nv[2];
+        ++accCount;
+      }
     }
-  }
-  if ( accCount == 0 ) {
-    if ( i != 0 ) {
-      const int     sp = signOf( i - 1 );  // i is the smallest unvisited index: i - 1 has been oriented
-      const double* np = normalOf( i - 1 );
-      acc[0] = double( sp == 0 ? 1 : sp ) * np[0];
-      acc[1] = double( sp == 0 ? 1 : sp ) * np[1];
-      acc[2] = double( sp == 0 ? 1 : sp ) * np[2];
-    } else {
-      acc[0] = 0.0 - xyz0[0];
-      acc[1] = 0.0 - xyz0[1];
-      acc[2] = 0.0 - xyz0[2];
+    if ( accCount == 0 ) {
+      if ( i != 0 ) {
+        const int     sp = signThen( i - 1 );  // i is the smallest index not oriented yet: i - 1 has been
+        const double* np = normalOf( k, 1 );
+        acc[0] = double( sp == 0 ? 1 : sp ) * np[0];
+        acc[1] = double( sp == 0 ? 1 : sp ) * np[1];
+        acc[2] = double( sp == 0 ? 1 : sp ) * np[2];
+      } else {
+        acc[0] = 0.0 - xyz0[0];
+        acc[1] = 0.0 - xyz0[1];
+        acc[2] = 0.0 - xyz0[2];
+      }
     }
+    compSign[k] = dot( normalOf( k, 0 ), acc ) < 0.0 ? -1 : 1;
   }
-  return dot( normalOf( i ), acc ) < 0.0 ? -1 : 1;
+  for ( size_t i = 0; i < n; ++i )
+    if ( g.root[i] == i && compSign[component[i]] < 0 ) clusterSign[i] = int8_t( -clusterSign[i] );
 }
 
 // host-side contraction (the device path does the same in orient_contract.hip): union-find with parity over the
@@ -468,15 +498,21 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
     }
     if ( okc ) {
       const OrientContraction g{root.data(), parity.data(), off.data(), edges.data()};
-      const auto normalOf = [&]( uint32_t v ) { return normals + 3 * size_t( v ); };
-      const auto seedSign = [&]( uint32_t i, const std::function<int( uint32_t )>& signOf ) {
-        return orientSeedSign( i, knn + size_t( i ) * k, k, normalOf, xyz, signOf );
-      };
-      std::vector<int8_t> clusterSign( n );
+      std::vector<int8_t>   clusterSign( n );
+      std::vector<uint32_t> component( n ), seeds;
       const auto tw0 = std::chrono::steady_clock::now();
-      const bool okw = orientContractedSigns( n, g, first, seedSign, clusterSign.data(), scratch );
+      const bool okw = orientContractedSigns( n, g, first, clusterSign.data(), component.data(), seeds, scratch );
+      if ( okw ) {
+        const auto rowOf    = [&]( size_t s ) { return knn + size_t( seeds[s] ) * k; };
+        const auto normalOf = [&]( size_t s, int j ) {
+          const uint32_t i = seeds[s];
+          const uint32_t v = j == 0 ? i : ( j == 1 ? ( i ? i - 1 : 0 ) : knn[size_t( i ) * k + ( j - 2 )] );
+          return normals + 3 * size_t( v );
+        };
+        resolveSeedSigns( n, g, k, seeds, component.data(), rowOf, normalOf, xyz, clusterSign.data() );
+      }
       if ( getenv( "TMC2_ORIENT_TIMING" ) )
-        fprintf( stderr, "contracted walk %.1f ms ok=%d\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tw0 ).count(), int( okw ) );
+        fprintf( stderr, "contracted walk %.1f ms ok=%d seeds %zu\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tw0 ).count(), int( okw ), seeds.size() );
       if ( okw ) {
         for ( size_t i = 0; i < n; ++i ) sign[i] = int8_t( ( parity[i] & 1 ) ? -clusterSign[root[i]] : clusterSign[root[i]] );
         return growths;
@@ -546,35 +582,29 @@ int orientNormalsHost( tmc2_frame* f ) {
     TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );
     ctx->stageEnd( sid );
     if ( contracted ) {
-      int8_t* clusterSign = ctx->hostC.get<int8_t>( 2 * n ) + n;  // second half: the first holds the parities (g.parity)
-      // the reference's seed rule reads a k-NN row and a few normals per connected component; which ones is only known
-      // during the walk, and a read-back per seed would queue behind the other frames' bulk copies: both tables come
-      // along in one piece (host memory is touched only where a seed looks)
-      uint32_t* knn = ctx->hostD.get<uint32_t>( edges );
-      double*   nrm = ctx->hostB.get<double>( n * 3 );
-      if ( !knn || !nrm ) {
+      int8_t*               clusterSign = ctx->hostC.get<int8_t>( 2 * n ) + n;  // second half: the first holds the parities (g.parity)
+      std::vector<uint32_t> seeds;
+      uint32_t*             component = reinterpret_cast<uint32_t*>( ctx->hostB.get<uint32_t>( n ) );
+      if ( !component ) {
         setError( "orientNormals: hipHostMalloc failed" );
         return TMC2_E_HIP;
       }
-      TMC2_HIP( hipMemcpyAsync( knn, f->d_knn.p, edges * sizeof( uint32_t ), hipMemcpyDeviceToHost, s ) );
-      TMC2_HIP( hipMemcpyAsync( nrm, f->d_normals.p, n * 3 * sizeof( double ), hipMemcpyDeviceToHost, s ) );
-      TMC2_HIP( hipStreamSynchronize( s ) );
-      const int  err      = TMC2_OK;
-      const auto normalOf = [&]( uint32_t v ) -> const double* { return nrm + 3 * size_t( v ); };
-      const auto seedSign = [&]( uint32_t i, const std::function<int( uint32_t )>& signOf ) -> int {
-        return orientSeedSign( i, knn + size_t( i ) * f->k, f->k, normalOf, f->h_xyz.data(), signOf );
-      };
       bool ok;
       {
         HostGate   gate;
         const auto t0 = std::chrono::steady_clock::now();
-        ok            = orientContractedSigns( n, g, tau, seedSign, clusterSign, ctx->orientScratch.data() );
+        ok            = orientContractedSigns( n, g, tau, clusterSign, component, seeds, ctx->orientScratch.data() );
         const auto t1 = std::chrono::steady_clock::now();
         ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
       }
-      if ( err != TMC2_OK ) {
-        setError( "orientNormals: device read-back failed" );
-        return err;
+      if ( ok ) {
+        // the seed rule's inputs, gathered on the device for exactly the seeds the walk has listed (a few KB)
+        std::vector<uint32_t> rows;
+        std::vector<double>   seedNormals;
+        TMC2_TRY( gatherSeedTables( f, seeds, rows, seedNormals ) );
+        const auto rowOf    = [&]( size_t k ) { return rows.data() + 16 * k; };
+        const auto normalOf = [&]( size_t k, int j ) { return seedNormals.data() + 3 * ( 18 * k + size_t( j ) ); };
+        resolveSeedSigns( n, g, f->k, seeds, component, rowOf, normalOf, f->h_xyz.data(), clusterSign );
       }
       if ( ok ) {
         TMC2_TRY( d_clusterSign.alloc( n ) );
