@@ -258,10 +258,10 @@ __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__
                                                         uint4* __restrict__ S, uint8_t* __restrict__ arg,
                                                         const uint8_t* __restrict__ proc, uint8_t* __restrict__ edge,
                                                         uint8_t* __restrict__ ppi, uint32_t* __restrict__ active,
-                                                        uint8_t* __restrict__ marked ) {
+                                                        uint8_t* __restrict__ marked, uint32_t* __restrict__ flags, int iter ) {
   const int      lane = threadIdx.x & 63;
   const uint32_t v    = blockIdx.x * 4 + ( threadIdx.x >> 6 );
-  if ( v >= V ) return;
+  if ( v >= V || flags[0] ) return;
   const uint32_t* row = adj + adjOff[v];
   const uint32_t  len = rowLen[v];
   uint32_t        s0 = 0, s1 = 0, s2 = 0;  // packed u16 pairs; sums <= 1024 + 255, no carry between halves
@@ -286,15 +286,19 @@ __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__
     classify( b, nz, a );
     arg[v] = uint8_t( a );
     if ( UPDATE ) {
-      uint8_t e = edge[v];
+      const uint8_t e0 = edge[v];
+      uint8_t       e  = e0;
+      bool          changed = false;
       if ( proc[v] ) {
         unpackHist( hist[v], b );
         classify( b, nz, a );
         if ( e != S_DIRECT_EDGE ) e = ( nz == 1 ) ? NO_EDGE : M_DIRECT_EDGE;
-        ppi[v] = uint8_t( a );
+        changed = ppi[v] != uint8_t( a );
+        ppi[v]  = uint8_t( a );
       } else if ( marked[v] && e == NO_EDGE ) {
         e = INDIRECT_EDGE;
       }
+      if ( changed || e != e0 ) flags[2 * iter] = 1u;  // the voxel state the previous sweep leaves differs from what it found
       edge[v]   = e;
       active[v] = e != NO_EDGE;
       marked[v] = 0;
@@ -328,10 +332,18 @@ __global__ __launch_bounds__( 256 ) void closureRoundZeroKernel( const uint8_t* 
                                                                   const uint32_t* __restrict__ dev, uint32_t V,
                                                                   uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
                                                                   uint32_t* __restrict__ out, uint32_t* __restrict__ activeBits,
-                                                                  uint32_t* __restrict__ frontierBits ) {
+                                                                  uint32_t* __restrict__ frontierBits, uint32_t* __restrict__ flags,
+                                                                  int iter ) {
   const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
   const uint32_t lane = threadIdx.x & 31;
   const int      half = ( threadIdx.x >> 5 ) & 1;
+  // Fixpoint: a sweep that changed neither a label nor a voxel state leaves the next one the same input, so every
+  // later sweep is a no-op too (the reference keeps iterating to its fixed count; the result is the same).
+  if ( flags[0] ) return;
+  if ( iter > 0 && flags[2 * iter - 1] == 0 && flags[2 * iter] == 0 ) {
+    flags[0] = 1u;
+    return;
+  }
   if ( u >= V ) return;
   const uint32_t v    = dev[size_t( u ) * 32 + lane];
   const uint8_t  a    = arg[u];
@@ -355,7 +367,8 @@ __global__ __launch_bounds__( 256 ) void closureRoundZeroKernel( const uint8_t* 
 __global__ __launch_bounds__( 1024 ) void closureTailKernel( const uint32_t* __restrict__ out, uint32_t W,
                                                               uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
                                                               uint32_t* __restrict__ activeBits,
-                                                              uint32_t* __restrict__ frontierBits ) {
+                                                              uint32_t* __restrict__ frontierBits, const uint32_t* __restrict__ flags ) {
+  if ( flags[0] ) return;
   extern __shared__ uint32_t lds[];
   uint32_t *      act = lds, *fr = lds + W, *nx = lds + 2 * size_t( W );
   __shared__ int  any;
@@ -411,7 +424,8 @@ __global__ __launch_bounds__( 1024 ) void closureTailGlobalKernel( const uint32_
                                                                     uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
                                                                     uint32_t* __restrict__ activeBits,
                                                                     uint32_t* __restrict__ frontierBits,
-                                                                    uint32_t* __restrict__ nextBits ) {
+                                                                    uint32_t* __restrict__ nextBits, const uint32_t* __restrict__ flags ) {
+  if ( flags[0] ) return;
   __shared__ int any;
   uint32_t*      fr = frontierBits;
   uint32_t*      nx = nextBits;
@@ -458,9 +472,10 @@ __global__ __launch_bounds__( 1024 ) void closureTailGlobalKernel( const uint32_
 // proc[v] = voxel is re-scored this sweep; its histogram is zeroed for re-accumulation
 __global__ __launch_bounds__( 256 ) void decideKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
                                                         const uint32_t* __restrict__ active, const uint4* __restrict__ S,
-                                                        uint32_t V, uint8_t* __restrict__ proc, uint4* __restrict__ hist ) {
+                                                        uint32_t V, uint8_t* __restrict__ proc, uint4* __restrict__ hist,
+                                                        const uint32_t* __restrict__ flags ) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( v >= V ) return;
+  if ( v >= V || flags[0] ) return;
   uint8_t p = 0;
   if ( active[v] ) {
     const uint8_t edgeAt = edge[v] != NO_EDGE ? edge[v] : uint8_t( INDIRECT_EDGE );
@@ -483,9 +498,9 @@ __global__ __launch_bounds__( 256 ) void rescorePointsKernel( const uint32_t* __
                                                                const uint4* __restrict__ S,
                                                                const double* __restrict__ weight, uint32_t n,
                                                                uint8_t* __restrict__ partition,
-                                                               uint32_t* __restrict__ hist ) {
+                                                               uint32_t* __restrict__ hist, uint32_t* __restrict__ flags, int iter ) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( j >= n ) return;
+  if ( j >= n || flags[0] ) return;
   const uint32_t v = vid[j];
   if ( !proc[v] ) return;
   uint32_t b[6];
@@ -505,7 +520,10 @@ __global__ __launch_bounds__( 256 ) void rescorePointsKernel( const uint32_t* __
       best = k;
     }
   }
-  partition[j] = uint8_t( best );
+  if ( partition[j] != uint8_t( best ) ) {
+    partition[j]        = uint8_t( best );
+    atomicAdd( &flags[2 * iter + 1], 1u );  // this sweep moved a point (a count, for the trace hook)
+  }
   atomicAdd( &hist[4 * size_t( v ) + ( best >> 1 )], 1u << ( 16 * ( best & 1 ) ) );
 }
 
@@ -639,30 +657,50 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   if ( tailInLds && tailLds > 48 * 1024 )
     TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureTailKernel ),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, int( tailLds ) ) );
+  DevBuf<uint32_t> d_flags;  // [0] fixpoint reached; [2k + 1] sweep k moved a point; [2k + 2] sweep k changed a voxel state
+  TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
+  TMC2_HIP( hipMemsetAsync( d_flags.p, 0, ( 2 * size_t( iterationCount ) + 2 ) * 4, s ) );
   for ( int iter = 0; iter < iterationCount; ++iter ) {
     if ( iter == 0 )
       hipLaunchKernelGGL( smoothKernel<false>, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked );
+                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
     else
       hipLaunchKernelGGL( smoothKernel<true>, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked );
+                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
     hipLaunchKernelGGL( closureRoundZeroKernel, grdV32, blk, 0, s, d_edge, d_ppi, d_arg, d_dev.p, V, d_active, d_marked,
-                        d_out.p, d_activeBits, d_frontierBits );
+                        d_out.p, d_activeBits, d_frontierBits, d_flags.p, iter );
     if ( tailInLds )
       hipLaunchKernelGGL( closureTailKernel, dim3( 1 ), dim3( 1024 ), tailLds, s, d_out.p, W, d_active, d_marked,
-                          d_activeBits, d_frontierBits );
+                          d_activeBits, d_frontierBits, d_flags.p );
     else
       hipLaunchKernelGGL( closureTailGlobalKernel, dim3( 1 ), dim3( 1024 ), 0, s, d_out.p, W, d_active, d_marked,
-                          d_activeBits, d_frontierBits, d_nextBits );
+                          d_activeBits, d_frontierBits, d_nextBits, d_flags.p );
     hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
-                        reinterpret_cast<uint4*>( d_hist.p ) );
+                        reinterpret_cast<uint4*>( d_hist.p ), d_flags.p );
     hipLaunchKernelGGL( rescorePointsKernel, grdN, blk, 0, s, d_vid.p, f->d_normals.p, d_proc, d_S.p, d_weight.p, n,
-                        f->d_partition.p, d_hist.p );
+                        f->d_partition.p, d_hist.p, d_flags.p, iter );
     // the voxel-state update of this sweep rides in the next sweep's smoothKernel; after the last sweep nobody reads it
   }
+  std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
+  TMC2_HIP( hipMemcpyAsync( h_flags.data(), d_flags.p, h_flags.size() * 4, hipMemcpyDeviceToHost, s ) );
   ctx->stageEnd( sidSweep );
   TMC2_HIP( hipGetLastError() );
   TMC2_HIP( hipStreamSynchronize( s ) );
+  {
+    int executed = iterationCount;
+    if ( h_flags[0] )
+      for ( int m = 1; m < iterationCount; ++m )
+        if ( h_flags[2 * m - 1] == 0 && h_flags[2 * m] == 0 ) {
+          executed = m;
+          break;
+        }
+    ctx->stageAddHostMs( "refine_sweeps_executed", double( executed ) );  // (a count, not milliseconds)
+    if ( getenv( "TMC2_REFINE_TRACE" ) ) {  // test hook: points moved per sweep
+      fprintf( stderr, "refine: points moved per sweep:" );
+      for ( int m = 0; m < iterationCount; ++m ) fprintf( stderr, " %u", h_flags[2 * m + 1] );
+      fprintf( stderr, "\n" );
+    }
+  }
   return TMC2_OK;
 }
 
