@@ -223,7 +223,17 @@ class GofEncoder:
             c.stage_reset()
 
     def device_tensor(self, frame, name):
-        """torch view (zero copy) of a frame's canvas, for collectives."""
+        """torch view (zero copy) of a frame's canvas as BYTES, shape (*canvas shape, itemsize), for collectives
+        (they lack 16/32-bit unsigned types; the receiver reinterprets: see canvas_from_bytes)."""
         import torch
         ptr, shape, typestr = frame.device_images()[name]
-        return torch.as_tensor(_DevArray(ptr, shape, typestr), device="cuda:%d" % self.device)
+        itemsize = int(typestr[2:])
+        return torch.as_tensor(_DevArray(ptr, tuple(shape) + (itemsize,), "|u1"), device="cuda:%d" % self.device)
+
+    @staticmethod
+    def canvas_from_bytes(tensor, name):
+        """numpy canvas from the byte tensor device_tensor() / a gather of it delivers."""
+        dtype = {"occupancy": np.uint8, "occ_video": np.uint8, "block_to_patch": np.uint32, "geometry": np.uint16,
+                 "attribute": np.uint8}[name]
+        a = tensor.cpu().numpy()
+        return np.ascontiguousarray(a).view(dtype).reshape(a.shape[:-1])

@@ -171,6 +171,14 @@ def test_gpu_gof_encoder_worker_threads(oracle, placement):
             for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
                 assert np.array_equal(img[k], ea[k]), k
             assert np.array_equal(fr.get_attribute_images(), eb["attribute"])
+        if placement == "device":      # zero-copy byte views of the canvases (what the multi-GPU gather ships)
+            img = frs[0].get_geometry_images()
+            geo = T.GofEncoder.canvas_from_bytes(enc.device_tensor(frs[0], "geometry"), "geometry")
+            assert np.array_equal(geo[0], img["geo0"]) and np.array_equal(geo[1], img["geo1"])
+            b2p = T.GofEncoder.canvas_from_bytes(enc.device_tensor(frs[0], "block_to_patch"), "block_to_patch")
+            assert np.array_equal(b2p, img["block_to_patch"])
+            att = T.GofEncoder.canvas_from_bytes(enc.device_tensor(frs[0], "attribute"), "attribute")
+            assert np.array_equal(att, frs[0].get_attribute_images())
         used = enc.stage_calls()
         host, dev = used.get("kdtree_build_host", 0), used.get("kdtree_build", 0)
         assert (host, dev) == (5, 0) if placement == "host" else (host, dev) == (0, 5) if placement == "device" else host + dev == 5
@@ -178,3 +186,35 @@ def test_gpu_gof_encoder_worker_threads(oracle, placement):
     finally:
         T.load_library().tmc2_set_kdtree_placement(0)
         T.load_library().tmc2_set_host_parallelism(16)
+
+
+def test_gpu_vox11_full_path_properties(gpu_ctx):
+    """basketball_player_vox11-size frame (3.0 M points, 11-bit geometry, BASELINE configs[1..]): the whole path S0-S22 with
+    the CTC settings of that sequence (20 refine iterations, 12-bit 3-D range) -- size-dependent tables (2^33-bit voxel
+    bitmap, 2^28-word key table, > 2^21 points: scratch-stack k-NN, deep trees) and size-independent invariants."""
+    xyz, rgb = synth_cloud("basketball_player_vox11")
+    fr = gpu_ctx.frame(xyz, rgb)
+    w = fr.weight_normal(12, 0.6)
+    fr.segmenter_compute(T.ctc_params(20, 12, w))
+    perm, depth = fr.kdtree_order()
+    assert np.array_equal(np.sort(perm), np.arange(len(xyz), dtype=np.uint32)) and 20 < depth < 64
+    adj = fr.get_adjacency(16)
+    assert np.array_equal(adj[:, 0], np.arange(len(xyz), dtype=np.uint32))
+    part = fr.get_partition()
+    assert part.max() <= 5 and np.bincount(part, minlength=6).min() > 0.02 * len(xyz)
+    h = fr.encoder_pack_flexible(1280, 2, 1.0)
+    W, H = T.encoder_canvas_size([h], 1280, 1280, 1280)
+    fr.encoder_generate_geometry_images(W, H, 4)
+    img = fr.get_geometry_images()
+    occ = img["occupancy"].astype(bool)
+    assert 0.3 * len(xyz) < occ.sum() <= len(xyz)
+    assert np.all(img["geo1"][occ].astype(np.int32) - img["geo0"][occ] >= 0)
+    fr.encoder_generate_attribute_images()
+    rx, rc, p2p = fr.get_reconstruction()
+    assert 0.9 * len(xyz) < len(rx) < 1.2 * len(xyz)
+    # every reconstructed point sits within one voxel of a source point along its projection axis: spot check by hashing
+    src = set(map(tuple, xyz[::7].tolist()))
+    hit = sum(tuple(p) in src for p in rx[::50].tolist())
+    assert hit > 0          # lossless D0 positions reappear exactly
+    att = fr.get_attribute_images()
+    assert att.shape == (2, 3, H, W) and att[0, :, occ].any()
