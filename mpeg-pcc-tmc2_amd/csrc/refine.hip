@@ -145,17 +145,16 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
 // ---- neighbourhoods ---------------------------------------------------------------------------------
 // One wavefront per voxel.  offsets[] = all integer (dx,dy,dz) with d2 < radius2, packed, any order.
 // Collect hits (d2 << 26 | voxel id) in LDS, bitonic-sort, cut after the cumulative member count reaches
-// maxNN.  FILL=false: write row length + weight + DEV prefix length; FILL=true: write the row at adjOff[v].
+// maxNN; write row length, weight, DEV prefix length and the row itself (fixed stride).
 constexpr int kMaxBall = 2048;
 
-template <bool FILL>
 __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restrict__ centre,
                                                                const uint32_t* __restrict__ count,
                                                                const uint32_t* __restrict__ table, Grid g, uint32_t V,
                                                                const int* __restrict__ offsets, int nOffsets, int maxNN,
                                                                double lambda, uint32_t* __restrict__ rowLen,
                                                                uint32_t* __restrict__ devLen, double* __restrict__ weight,
-                                                               const uint32_t* __restrict__ adjOff,
+                                                               uint32_t stride, uint32_t* __restrict__ adjOff,
                                                                uint32_t* __restrict__ adj ) {
   __shared__ uint32_t keysAll[4][kMaxBall];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,18 +232,18 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
       nn      = running;
     }
   }
-  if ( !FILL ) {
-    if ( lane == 0 ) {
-      rowLen[v] = uint32_t( used );
-      weight[v] = __ddiv_rn( lambda, double( nn ) );
-      int dev   = 0;  // DEV candidates (Chebyshev <= 1) are exactly the entries with d2 <= 3: a prefix of the row
-      while ( dev < used && ( keys[dev] >> 26 ) <= 3u ) ++dev;
-      devLen[v] = uint32_t( dev );
-    }
-  } else {
-    uint32_t* row = adj + adjOff[v];
-    for ( int i = lane; i < used; i += 64 ) row[i] = keys[i] & 0x3FFFFFFu;
+  if ( lane == 0 ) {
+    rowLen[v] = uint32_t( used );
+    adjOff[v] = v * stride;
+    weight[v] = __ddiv_rn( lambda, double( nn ) );
+    int dev   = 0;  // DEV candidates (Chebyshev <= 1) are exactly the entries with d2 <= 3: a prefix of the row
+    while ( dev < used && ( keys[dev] >> 26 ) <= 3u ) ++dev;
+    devLen[v] = uint32_t( dev );
   }
+  // rows at a fixed stride (the ball's size bounds their length): one pass, no offsets to prefix-sum, no second sort;
+  // the sweeps read only rowLen[v] entries of each, so the slack costs address space, not bandwidth
+  uint32_t* row = adj + size_t( v ) * stride;
+  for ( int i = lane; i < used; i += 64 ) row[i] = keys[i] & 0x3FFFFFFu;
 }
 
 // ---- sweep kernels ----------------------------------------------------------------------------------
@@ -625,18 +624,16 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   const dim3 grdV( ( V + 255 ) / 256 ), grdW( ( V + 3 ) / 4 );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
                       d_edge, d_ppi, d_active );
-  // neighbourhoods: count pass, offsets, fill pass
-  hipLaunchKernelGGL( neighbourhoodKernel<false>, grdW, blk, 0, s, d_centre.p, d_count.p, table, g, V, d_offsets.p,
-                      int( offsets.size() ), maxNNCount, lambda, d_rowLen.p, d_devLen.p, d_weight.p,
-                      (const uint32_t*)nullptr, (uint32_t*)nullptr );
-  TMC2_TRY( exclusiveScanU32( ctx, d_rowLen.p, d_adjOff.p, V, d_small.p + 1 ) );
-  uint32_t adjTotal = 0;
-  TMC2_HIP( hipMemcpyAsync( &adjTotal, d_small.p + 1, 4, hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
+  // neighbourhoods
+  const uint32_t stride = ( uint32_t( offsets.size() ) + 31u ) & ~31u;
+  if ( uint64_t( V ) * stride > 0xFFFFFFFFull ) {
+    setError( "refineSegmentationGridBased: %u voxels x %u ball cells exceed the neighbourhood table", V, stride );
+    return TMC2_E_UNSUPPORTED;
+  }
   DevBuf<uint32_t> d_adj;
-  TMC2_TRY( d_adj.alloc( adjTotal ) );
-  hipLaunchKernelGGL( neighbourhoodKernel<true>, grdW, blk, 0, s, d_centre.p, d_count.p, table, g, V, d_offsets.p,
-                      int( offsets.size() ), maxNNCount, lambda, d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p,
+  TMC2_TRY( d_adj.alloc( size_t( V ) * stride ) );
+  hipLaunchKernelGGL( neighbourhoodKernel, grdW, blk, 0, s, d_centre.p, d_count.p, table, g, V, d_offsets.p,
+                      int( offsets.size() ), maxNNCount, lambda, d_rowLen.p, d_devLen.p, d_weight.p, stride, d_adjOff.p,
                       d_adj.p );
   hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
   ctx->stageEnd( sidSetup );
