@@ -468,62 +468,86 @@ __global__ __launch_bounds__( 1024 ) void closureTailGlobalKernel( const uint32_
   for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) activeBits[w] = 0;
 }
 
-// proc[v] = voxel is re-scored this sweep; its histogram is zeroed for re-accumulation
-__global__ __launch_bounds__( 256 ) void decideKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                        const uint32_t* __restrict__ active, const uint4* __restrict__ S,
-                                                        uint32_t V, uint8_t* __restrict__ proc, uint4* __restrict__ hist,
-                                                        const uint32_t* __restrict__ flags ) {
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+// points grouped by voxel (any order inside a voxel: re-scoring is per point, the histograms are integer sums)
+__global__ __launch_bounds__( 256 ) void voxelPointListKernel( const uint32_t* __restrict__ vid, const uint32_t* __restrict__ start,
+                                                                uint32_t n, uint32_t* __restrict__ cursor,
+                                                                uint32_t* __restrict__ list ) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( j >= n ) return;
+  const uint32_t v                            = vid[j];
+  list[start[v] + atomicAdd( &cursor[v], 1u )] = j;
+}
+
+// decide + re-score in one pass over the VOXELS (16 lanes each): the voxels that are re-scored this sweep are few
+// (patch borders), so walking their point lists beats a pass over every point, and a voxel's new histogram is built in
+// registers and written once instead of through atomics.
+//   proc[v] = active and (multi-plane edge, or its smoothed histogram is not unanimous for its own plane)
+__global__ __launch_bounds__( 256 ) void rescoreVoxelsKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
+                                                               const uint32_t* __restrict__ active, const uint4* __restrict__ S,
+                                                               const double* __restrict__ weight,
+                                                               const uint32_t* __restrict__ pointStart,
+                                                               const uint32_t* __restrict__ pointList,
+                                                               const double* __restrict__ normals, uint32_t V,
+                                                               uint8_t* __restrict__ proc, uint4* __restrict__ hist,
+                                                               uint8_t* __restrict__ partition, uint32_t* __restrict__ flags,
+                                                               int iter ) {
+  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  const int      sub  = threadIdx.x & 15;
   if ( v >= V || flags[0] ) return;
-  uint8_t p = 0;
+  uint32_t b[6];
+  uint8_t  p = 0;
   if ( active[v] ) {
     const uint8_t edgeAt = edge[v] != NO_EDGE ? edge[v] : uint8_t( INDIRECT_EDGE );
-    p                    = 1;
+    unpackHist( S[v], b );
+    p = 1;
     if ( edgeAt != M_DIRECT_EDGE ) {
-      uint32_t b[6];
-      unpackHist( S[v], b );
       int nz, a;
       classify( b, nz, a );
       if ( nz == 1 && b[ppi[v]] > 0 ) p = 0;
     }
   }
-  proc[v] = p;
-  if ( p ) hist[v] = make_uint4( 0, 0, 0, 0 );
-}
-
-__global__ __launch_bounds__( 256 ) void rescorePointsKernel( const uint32_t* __restrict__ vid,
-                                                               const double* __restrict__ normals,
-                                                               const uint8_t* __restrict__ proc,
-                                                               const uint4* __restrict__ S,
-                                                               const double* __restrict__ weight, uint32_t n,
-                                                               uint8_t* __restrict__ partition,
-                                                               uint32_t* __restrict__ hist, uint32_t* __restrict__ flags, int iter ) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( j >= n || flags[0] ) return;
-  const uint32_t v = vid[j];
-  if ( !proc[v] ) return;
-  uint32_t b[6];
-  unpackHist( S[v], b );
-  const double w  = weight[v];
-  const double nx = normals[3 * size_t( j )], ny = normals[3 * size_t( j ) + 1], nz = normals[3 * size_t( j ) + 2];
-  const double d[6] = {nx * 1.0 + ny * 0.0 + nz * 0.0,  nx * 0.0 + ny * 1.0 + nz * 0.0,
-                       nx * 0.0 + ny * 0.0 + nz * 1.0,  nx * -1.0 + ny * 0.0 + nz * 0.0,
-                       nx * 0.0 + ny * -1.0 + nz * 0.0, nx * 0.0 + ny * 0.0 + nz * -1.0};
-  int          best = 0;
-  double       bs   = d[0] + w * double( b[0] );
+  if ( sub == 0 ) proc[v] = p;
+  if ( !p ) return;  // (uniform over the 16 lanes of the voxel)
+  const double   w     = weight[v];
+  const uint32_t begin = pointStart[v], end = pointStart[v + 1];
+  uint32_t       h0 = 0, h1 = 0, h2 = 0;  // packed u16 pairs like the histogram words
+  uint32_t       moved = 0;
+  for ( uint32_t q = begin + sub; q < end; q += 16 ) {
+    const uint32_t j  = pointList[q];
+    const double   nx = normals[3 * size_t( j )], ny = normals[3 * size_t( j ) + 1], nz = normals[3 * size_t( j ) + 2];
+    const double d[6] = {nx * 1.0 + ny * 0.0 + nz * 0.0,  nx * 0.0 + ny * 1.0 + nz * 0.0,
+                         nx * 0.0 + ny * 0.0 + nz * 1.0,  nx * -1.0 + ny * 0.0 + nz * 0.0,
+                         nx * 0.0 + ny * -1.0 + nz * 0.0, nx * 0.0 + ny * 0.0 + nz * -1.0};
+    int    best = 0;
+    double bs   = d[0] + w * double( b[0] );
 #pragma unroll
-  for ( int k = 1; k < 6; ++k ) {
-    const double sc = d[k] + w * double( b[k] );
-    if ( sc > bs ) {
-      bs   = sc;
-      best = k;
+    for ( int k = 1; k < 6; ++k ) {
+      const double sc = d[k] + w * double( b[k] );
+      if ( sc > bs ) {
+        bs   = sc;
+        best = k;
+      }
     }
+    if ( partition[j] != uint8_t( best ) ) {
+      partition[j] = uint8_t( best );
+      ++moved;
+    }
+    const uint32_t one = 1u << ( 16 * ( best & 1 ) );
+    h0 += ( best >> 1 ) == 0 ? one : 0u;
+    h1 += ( best >> 1 ) == 1 ? one : 0u;
+    h2 += ( best >> 1 ) == 2 ? one : 0u;
   }
-  if ( partition[j] != uint8_t( best ) ) {
-    partition[j]        = uint8_t( best );
-    atomicAdd( &flags[2 * iter + 1], 1u );  // this sweep moved a point (a count, for the trace hook)
+#pragma unroll
+  for ( int off = 8; off > 0; off >>= 1 ) {  // the 16 lanes of a voxel are an aligned quarter of the wave
+    h0 += __shfl_xor( h0, off, 64 );
+    h1 += __shfl_xor( h1, off, 64 );
+    h2 += __shfl_xor( h2, off, 64 );
+    moved += __shfl_xor( moved, off, 64 );
   }
-  atomicAdd( &hist[4 * size_t( v ) + ( best >> 1 )], 1u << ( 16 * ( best & 1 ) ) );
+  if ( sub == 0 ) {
+    hist[v] = make_uint4( h0, h1, h2, 0 );
+    if ( moved ) atomicAdd( &flags[2 * iter + 1], moved );  // this sweep moved points (the count feeds the trace hook)
+  }
 }
 
 }  // namespace
@@ -598,7 +622,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   DevBuf<uint32_t> d_activeBuf;
   DevBuf<int>      d_offsets;
   DevBuf<uint4>    d_S;
-  TMC2_TRY( d_count.alloc( V ) );
+  TMC2_TRY( d_count.alloc( size_t( V ) + 1 ) );  // (+1: scanned into the point-list offsets)
   TMC2_TRY( d_rowLen.alloc( V ) );
   TMC2_TRY( d_devLen.alloc( V ) );
   TMC2_TRY( d_adjOff.alloc( V + 1 ) );
@@ -612,7 +636,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + V, *d_arg = d_state.p + 2 * size_t( V ),
           *d_marked = d_state.p + 4 * size_t( V ), *d_proc = d_state.p + 5 * size_t( V );
   uint32_t* d_active = d_activeBuf.p;
-  TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( V ) * 4, s ) );
+  TMC2_HIP( hipMemsetAsync( d_count.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
   TMC2_HIP( hipMemsetAsync( d_hist.p, 0, size_t( V ) * 16, s ) );
   TMC2_HIP( hipMemsetAsync( d_state.p, 0, size_t( V ) * 6, s ) );
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
@@ -621,7 +645,15 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
   hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
                       d_hist.p );
-  const dim3 grdV( ( V + 255 ) / 256 ), grdW( ( V + 3 ) / 4 );
+  const dim3 grdV( ( V + 255 ) / 256 ), grdW( ( V + 3 ) / 4 ), grdV16( ( V + 15 ) / 16 );
+  // points grouped by voxel, for the re-scoring pass
+  DevBuf<uint32_t> d_pointStart, d_pointList, d_cursor;
+  TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
+  TMC2_TRY( d_pointList.alloc( n ) );
+  TMC2_TRY( d_cursor.alloc( V ) );
+  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( V ) * 4, s ) );
+  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_pointStart.p, size_t( V ) + 1, nullptr ) );
+  hipLaunchKernelGGL( voxelPointListKernel, grdN, blk, 0, s, d_vid.p, d_pointStart.p, n, d_cursor.p, d_pointList.p );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
                       d_edge, d_ppi, d_active );
   // neighbourhoods
@@ -672,10 +704,9 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     else
       hipLaunchKernelGGL( closureTailGlobalKernel, dim3( 1 ), dim3( 1024 ), 0, s, d_out.p, W, d_active, d_marked,
                           d_activeBits, d_frontierBits, d_nextBits, d_flags.p );
-    hipLaunchKernelGGL( decideKernel, grdV, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, V, d_proc,
-                        reinterpret_cast<uint4*>( d_hist.p ), d_flags.p );
-    hipLaunchKernelGGL( rescorePointsKernel, grdN, blk, 0, s, d_vid.p, f->d_normals.p, d_proc, d_S.p, d_weight.p, n,
-                        f->d_partition.p, d_hist.p, d_flags.p, iter );
+    hipLaunchKernelGGL( rescoreVoxelsKernel, grdV16, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, d_weight.p, d_pointStart.p,
+                        d_pointList.p, f->d_normals.p, V, d_proc, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p,
+                        d_flags.p, iter );
     // the voxel-state update of this sweep rides in the next sweep's smoothKernel; after the last sweep nobody reads it
   }
   std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
