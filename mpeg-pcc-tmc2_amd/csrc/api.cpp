@@ -351,7 +351,7 @@ uint64_t tmc2_frame_point_count( const tmc2_frame* f ) { return f ? f->n : 0; }
 
 int tmc2_frame_reset( tmc2_frame* f ) {
   if ( !f ) return TMC2_E_INVALID;
-  f->haveTree = f->haveKnn = f->haveNormals = f->havePartition = false;
+  f->haveTree = f->haveKnn = f->haveNormals = f->havePartition = f->haveMutual = false;
   f->havePatches = f->havePacking = f->haveGeometryImages = f->haveAttributeImages = false;
   f->patches.clear();
   f->packOrder.clear();

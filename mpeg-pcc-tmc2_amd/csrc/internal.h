@@ -221,6 +221,8 @@ struct tmc2_frame {
   tmc2::DevBuf<double>       d_normals;   // [n][3]
   tmc2::DevBuf<uint8_t>      d_partition; // [n]
   bool haveKnn = false, haveNormals = false, havePartition = false;
+  tmc2::DevBuf<uint16_t>     d_mutual;    // [n] bit j: knn[i][j] lists i in its own row (k = 16); shared by S3 and S7
+  bool haveMutual = false;
   int16_t geoMax = 0;  // largest coordinate (grid geometry of S5)
   // patches: records on the host, depth / occupancy pools resident on the device
   std::vector<tmc2_patch> patches;
@@ -282,6 +284,7 @@ TreeDev frameTree( const tmc2_frame* f );
 int generateAttributeImages( tmc2_frame* f );
 int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
+int ensureMutualMask( tmc2_frame* f );  // k = 16 only
 int launchEdgeDots( tmc2_frame* f, double* d_edgeDot );
 int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount );
 // contracted orientation graph (orient_host.cpp): clusters of mutual strong edges, their cross edges grouped by source

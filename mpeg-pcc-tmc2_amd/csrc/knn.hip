@@ -224,7 +224,8 @@ int launchKnnSelf( tmc2_frame* f, int k ) {
   f->ctx->stageEnd( sid );
   if ( r == TMC2_OK ) {
     f->k       = k;
-    f->haveKnn = true;
+    f->haveKnn    = true;
+    f->haveMutual = false;
   }
   return r;
 }

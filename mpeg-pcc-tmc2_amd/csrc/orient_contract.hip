@@ -21,27 +21,19 @@ namespace {
 
 __device__ __forceinline__ uint32_t ufPriority( uint32_t x ) { return x * 2654435761u; }  // odd multiplier: a bijection
 
-// bit j: knn[u][j] is a mutual strong neighbour of u
+// bit j: knn[u][j] is a mutual strong neighbour of u (mutual bits: ensureMutualMask, shared with S7)
 template <int K>
-__global__ __launch_bounds__( 256 ) void strongMutualMaskKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
+__global__ __launch_bounds__( 256 ) void strongMutualMaskKernel( const uint16_t* __restrict__ mutual, const double* __restrict__ edgeDot,
                                                                   uint32_t n, double tau, uint16_t* __restrict__ mask ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n ) return;
-  uint32_t m = 0;
-#pragma unroll
-  for ( int j = 0; j < K; ++j ) {
-    const uint32_t v = knn[size_t( u ) * K + j];
-    if ( v == u || !( fabs( edgeDot[size_t( u ) * K + j] ) >= tau ) ) continue;
-    const uint4* rv  = reinterpret_cast<const uint4*>( knn + size_t( v ) * K );
-    bool         hit = false;
-#pragma unroll
-    for ( int t = 0; t < K / 4; ++t ) {
-      const uint4 r = rv[t];
-      hit |= ( r.x == u ) | ( r.y == u ) | ( r.z == u ) | ( r.w == u );
-    }
-    m |= hit ? ( 1u << j ) : 0u;
+  uint32_t m = mutual[u], out = 0;
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    if ( fabs( edgeDot[size_t( u ) * K + j] ) >= tau ) out |= 1u << j;
   }
-  mask[u] = uint16_t( m );
+  mask[u] = uint16_t( out );
 }
 
 __global__ __launch_bounds__( 256 ) void initWordsKernel( uint32_t n, uint32_t* __restrict__ word, uint32_t* __restrict__ count ) {
@@ -217,7 +209,8 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 ), grdN1( ( n + 256 ) / 256 );
   TMC2_HIP( hipMemsetAsync( d_small.p, 0, 16, s ) );
   TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( n ) * 4, s ) );
-  hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, n, tau, d_mask.p );
+  TMC2_TRY( ensureMutualMask( f ) );
+  hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );
   hipLaunchKernelGGL( initWordsKernel, grdN1, blk, 0, s, n, d_word.p, d_count.p );
   hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p );
   hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p );

@@ -552,6 +552,20 @@ __global__ __launch_bounds__( 256 ) void rawDistanceKernel( const Pt* __restrict
 
 }  // namespace
 
+// bit j of mutual[i] = knn[i][j] lists i in its own row.  Depends only on the adjacency: once per frame.
+int ensureMutualMask( tmc2_frame* f ) {
+  if ( f->haveMutual ) return TMC2_OK;
+  const uint32_t n = uint32_t( f->n );
+  TMC2_TRY( f->d_mutual.alloc( n ) );
+  const int kt = f->ctx->stageBegin( "k:ccMutualMask" );
+  hipLaunchKernelGGL( ccMutualMaskKernel<16>, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, f->ctx->stream, f->d_knn.p, n,
+                      f->d_mutual.p );
+  f->ctx->stageEnd( kt );
+  TMC2_HIP( hipGetLastError() );
+  f->haveMutual = true;
+  return TMC2_OK;
+}
+
 int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   if ( !f->haveKnn || !f->havePartition ) {
     setError( "segmentPatches: adjacency / partition missing" );
@@ -603,7 +617,6 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_HIP( hipMemsetAsync( ctx->voxelBitmap.p, 0, bitmapWords * 4, s ) );
 
   DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_lab;
-  DevBuf<uint16_t> d_mutual;
   DevBuf<uint8_t>  d_raw;
   DevBuf<int32_t>  d_pointPatch, d_patchView, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
   DevBuf<int>      d_offsets;
@@ -612,7 +625,6 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_TRY( d_label.alloc( n ) );
   TMC2_TRY( d_parent.alloc( n ) );
   TMC2_TRY( d_lab.alloc( n ) );
-  TMC2_TRY( d_mutual.alloc( n ) );
   TMC2_TRY( d_ccCount.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
   TMC2_TRY( d_rank.alloc( n ) );
@@ -631,11 +643,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
   uint32_t   rawCount = n;
   int        rounds   = 0;
-  {
-    const int kt = ctx->stageBegin( "k:ccMutualMask" );
-    hipLaunchKernelGGL( ccMutualMaskKernel<16>, grdN, blk, 0, s, f->d_knn.p, n, d_mutual.p );
-    ctx->stageEnd( kt );
-  }
+  TMC2_TRY( ensureMutualMask( f ) );  // usually there already: the orientation (S3) needs the same bits
+  DevBuf<uint16_t>& d_mutual = f->d_mutual;
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );

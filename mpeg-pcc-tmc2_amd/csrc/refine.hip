@@ -247,7 +247,8 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
 }
 
 // ---- sweep kernels ----------------------------------------------------------------------------------
-// S[v] = sum of the neighbourhood's histograms (u16 lanes), arg[v] = first maximum.  One wave per voxel.
+// S[v] = sum of the neighbourhood's histograms (u16 lanes), arg[v] = first maximum.  16 lanes per voxel (rows hold ~64
+// entries: four independent gathers per lane, a four-step reduction).
 // UPDATE = true also closes the PREVIOUS sweep for voxel v (refresh edge class / ppi of re-scored voxels, apply the
 // INDIRECT marks, arm `active`): that only reads hist[v] and nothing here writes histograms, so it rides along.
 template <bool UPDATE>
@@ -258,23 +259,23 @@ __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__
                                                         const uint8_t* __restrict__ proc, uint8_t* __restrict__ edge,
                                                         uint8_t* __restrict__ ppi, uint32_t* __restrict__ active,
                                                         uint8_t* __restrict__ marked, uint32_t* __restrict__ flags, int iter ) {
-  const int      lane = threadIdx.x & 63;
-  const uint32_t v    = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+  const int      lane = threadIdx.x & 15;
+  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
   if ( v >= V || flags[0] ) return;
   const uint32_t* row = adj + adjOff[v];
   const uint32_t  len = rowLen[v];
   uint32_t        s0 = 0, s1 = 0, s2 = 0;  // packed u16 pairs; sums <= 1024 + 255, no carry between halves
-  for ( uint32_t i = lane; i < len; i += 64 ) {
+  for ( uint32_t i = lane; i < len; i += 16 ) {
     const uint4 h = hist[row[i]];
     s0 += h.x;
     s1 += h.y;
     s2 += h.z;
   }
 #pragma unroll
-  for ( int off = 32; off > 0; off >>= 1 ) {
-    s0 += __shfl_down( s0, off, 64 );
-    s1 += __shfl_down( s1, off, 64 );
-    s2 += __shfl_down( s2, off, 64 );
+  for ( int off = 8; off > 0; off >>= 1 ) {  // the 16 lanes of a voxel are an aligned quarter of the wave
+    s0 += __shfl_xor( s0, off, 64 );
+    s1 += __shfl_xor( s1, off, 64 );
+    s2 += __shfl_xor( s2, off, 64 );
   }
   if ( lane == 0 ) {
     const uint4 out = make_uint4( s0, s1, s2, 0 );
@@ -645,7 +646,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
   hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
                       d_hist.p );
-  const dim3 grdV( ( V + 255 ) / 256 ), grdW( ( V + 3 ) / 4 ), grdV16( ( V + 15 ) / 16 );
+  const dim3 grdV( ( V + 255 ) / 256 ), grdW( ( V + 3 ) / 4 ), grdV16( ( V + 15 ) / 16 );  // one wave / 16 lanes per voxel
   // points grouped by voxel, for the re-scoring pass
   DevBuf<uint32_t> d_pointStart, d_pointList, d_cursor;
   TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
@@ -691,10 +692,10 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   TMC2_HIP( hipMemsetAsync( d_flags.p, 0, ( 2 * size_t( iterationCount ) + 2 ) * 4, s ) );
   for ( int iter = 0; iter < iterationCount; ++iter ) {
     if ( iter == 0 )
-      hipLaunchKernelGGL( smoothKernel<false>, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+      hipLaunchKernelGGL( smoothKernel<false>, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
                           d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
     else
-      hipLaunchKernelGGL( smoothKernel<true>, grdW, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+      hipLaunchKernelGGL( smoothKernel<true>, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
                           d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
     hipLaunchKernelGGL( closureRoundZeroKernel, grdV32, blk, 0, s, d_edge, d_ppi, d_arg, d_dev.p, V, d_active, d_marked,
                         d_out.p, d_activeBits, d_frontierBits, d_flags.p, iter );
