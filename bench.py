@@ -205,6 +205,18 @@ def main():
                      "launches": launches},
         "stage_ms_per_frame": {k: round(v / (a.steps * len(frames)), 3) for k, v in sorted(ms.items())},
     }
+    # The timed region runs 32 frames at once: their k-NN launches share the chip, so the per-launch time above is the
+    # time under that sharing.  For reference, the same kernel with the GPU to itself (one frame, outside the timing):
+    enc.stage_reset()
+    frames[0].reset()
+    enc.phase_a(frames[:1], sharder=T.Sharder())
+    enc.phase_b(frames[:1])
+    solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
+    if solo_ms.get(dom, 0.0) > 0:
+        s_avg = solo_ms[dom] / max(1, solo_calls.get(dom, 1))
+        s_ach = algorithmic_bytes(dom, len(clouds[0][0])) / (s_avg * 1e-3) / 1e9
+        out["roofline"].update(alone_avg_launch_ms=round(s_avg, 4), alone_achieved=round(s_ach, 2),
+                               alone_frac=round(s_ach / 8000.0, 5))
     # S23 is reported separately: one frame, D1 + D2 + colour, both directions
     rx, rc, _ = frames[0].get_reconstruction()
     t0 = time.time()
