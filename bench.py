@@ -172,13 +172,24 @@ def main():
             dist.destroy_process_group()
         return
     ms, calls = enc.stage_ms(), enc.stage_calls()
-    gpu_kernels = {k: v for k, v in ms.items() if not k.endswith("_host") and (k.startswith("k:") or k in
-                   ("knn_self", "normals", "initial_segmentation", "knn8_recon_in_source", "knn1_source_in_recon"))}
+    # The timed region runs 32 frames at once: their launches share the chip and queue behind each other, so a kernel's
+    # event-bracketed time in the region says how long it was in flight, not how much of the GPU it needs.  The kernel the
+    # roofline is reported for is therefore chosen by its time with the GPU to itself (one frame, outside the timing);
+    # both durations are reported.
+    enc.stage_reset()
+    frames[0].reset()
+    enc.phase_a(frames[:1], sharder=T.Sharder())
+    enc.phase_b(frames[:1])
+    solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
+    timed = ("knn_self", "normals", "initial_segmentation", "knn8_recon_in_source", "knn1_source_in_recon")
+    gpu_kernels = {k: v for k, v in solo_ms.items() if (k.startswith("k:") or k in timed) and ms.get(k, 0.0) > 0}
     dom = max(gpu_kernels, key=gpu_kernels.get)
     launches = max(1, calls.get(dom, 1))
-    avg_ms = gpu_kernels[dom] / launches
+    avg_ms = ms[dom] / launches
     pts_per_launch = n_points / max(1, len(frames))
     achieved = algorithmic_bytes(dom, pts_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    s_avg = solo_ms[dom] / max(1, solo_calls.get(dom, 1))
+    s_ach = algorithmic_bytes(dom, len(clouds[0][0])) / (s_avg * 1e-3) / 1e9
     traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), if this kernel is in them
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -202,21 +213,10 @@ def main():
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                     "launches": launches},
+                     "launches": launches, "alone_avg_launch_ms": round(s_avg, 4), "alone_achieved": round(s_ach, 2),
+                     "alone_frac": round(s_ach / 8000.0, 5)},
         "stage_ms_per_frame": {k: round(v / (a.steps * len(frames)), 3) for k, v in sorted(ms.items())},
     }
-    # The timed region runs 32 frames at once: their k-NN launches share the chip, so the per-launch time above is the
-    # time under that sharing.  For reference, the same kernel with the GPU to itself (one frame, outside the timing):
-    enc.stage_reset()
-    frames[0].reset()
-    enc.phase_a(frames[:1], sharder=T.Sharder())
-    enc.phase_b(frames[:1])
-    solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
-    if solo_ms.get(dom, 0.0) > 0:
-        s_avg = solo_ms[dom] / max(1, solo_calls.get(dom, 1))
-        s_ach = algorithmic_bytes(dom, len(clouds[0][0])) / (s_avg * 1e-3) / 1e9
-        out["roofline"].update(alone_avg_launch_ms=round(s_avg, 4), alone_achieved=round(s_ach, 2),
-                               alone_frac=round(s_ach / 8000.0, 5))
     # S23 is reported separately: one frame, D1 + D2 + colour, both directions
     rx, rc, _ = frames[0].get_reconstruction()
     t0 = time.time()

@@ -23,6 +23,10 @@
 //     through L2 and evicts the (small, shared) tree, and the counters show 56x the algorithmic bytes.  So the
 //     stack lives in LDS, packed to 8 bytes per entry: every per-dimension distance on the path is the SQUARE of an
 //     integer offset to a split / box plane, so the entry keeps node id (22 bits) + three offsets (14 bits each).
+//     A full-depth LDS stack (tree depth x 2 KiB per block) would cap occupancy at 3 waves per SIMD, and this kernel
+//     lives on latency hiding; only the TOP kLdsTop slots -- where nearly all pushes and pops happen, next to the
+//     leaves -- are in LDS (16 KiB per block, occupancy back at the register limit), the slots below (filled once on
+//     the first descent, emptied once at the end) are packed 8-byte private memory.
 //     Callers that cannot bound their coordinates (|offset| < 16384) or their tree (< 4 M nodes, <= kLdsLevels levels)
 //     get the scratch-stack kernel instead (same traversal, same results).
 //   * all arithmetic is int32: coordinates < 2^12, squared distances < 2^26 (the reference holds the
@@ -36,7 +40,8 @@ namespace tmc2 {
 namespace {
 
 constexpr int      kMaxStack  = 64;
-constexpr int      kLdsLevels = 40;  // deepest tree the LDS-stack kernel takes (its LDS use is levels x 2 KiB per block)
+constexpr int      kLdsLevels = 40;  // deepest tree the packed-stack kernel takes
+constexpr int      kLdsTop    = 8;   // stack slots kept in LDS (the top of the stack)
 constexpr uint32_t kInf       = 0x7FFFFFFFu;
 
 struct RootBox {
@@ -64,7 +69,8 @@ template <int K, bool SELF, bool LDS>
 __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTree, const uint32_t* __restrict__ perm,
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
-                                                     uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist ) {
+                                                     uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist,
+                                                     int ldsBase ) {  // LDS: stack slots >= ldsBase live in LDS
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if ( j >= nq ) return;
   const Pt  qp = SELF ? ptsTree[j] : queries[j];
@@ -86,8 +92,9 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   if ( qz < root.lo[2] ) o2 = root.lo[2] - qz;
   if ( qz > root.hi[2] ) o2 = qz - root.hi[2];
 
-  extern __shared__ unsigned long long ldsStack[];  // [level][thread], LDS = true only
-  uint4    scratchStack[LDS ? 1 : kMaxStack];
+  __shared__ unsigned long long ldsStack[LDS ? kLdsTop * 256 : 1];  // [slot - ldsBase][thread]
+  unsigned long long            lowStack[LDS ? kLdsLevels : 1];       // slots below ldsBase (private memory)
+  uint4                         scratchStack[LDS ? 1 : kMaxStack];
   int      sp   = 0;
   uint32_t node = 0;
   for ( ;; ) {
@@ -105,11 +112,16 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       if ( farMin <= bd[K - 1] && sp < ( LDS ? kLdsLevels : kMaxStack ) ) {
         const uint32_t f0 = uint32_t( nd.dim == 0 ? ofar : o0 ), f1 = uint32_t( nd.dim == 1 ? ofar : o1 ),
                        f2 = uint32_t( nd.dim == 2 ? ofar : o2 );
-        if ( LDS )
-          ldsStack[sp * 256 + threadIdx.x] = (unsigned long long)farC | ( (unsigned long long)f0 << 22 ) |
-                                             ( (unsigned long long)f1 << 36 ) | ( (unsigned long long)f2 << 50 );
-        else
+        if ( LDS ) {
+          const unsigned long long e = (unsigned long long)farC | ( (unsigned long long)f0 << 22 ) |
+                                       ( (unsigned long long)f1 << 36 ) | ( (unsigned long long)f2 << 50 );
+          if ( sp >= ldsBase )
+            ldsStack[( sp - ldsBase ) * 256 + threadIdx.x] = e;
+          else
+            lowStack[sp] = e;
+        } else {
           scratchStack[sp] = make_uint4( farC, f0, f1, f2 );
+        }
         ++sp;
       }
       node = nearC;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       --sp;
       uint32_t en, e0, e1, e2;
       if ( LDS ) {
-        const unsigned long long e = ldsStack[sp * 256 + threadIdx.x];
+        const unsigned long long e = sp >= ldsBase ? ldsStack[( sp - ldsBase ) * 256 + threadIdx.x] : lowStack[sp];
         en = uint32_t( e ) & 0x3FFFFFu, e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
       } else {
         const uint4 e = scratchStack[sp];
@@ -175,17 +187,14 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
   // vouches for the queries with t.queriesBounded), node ids < 2^22, and at most kLdsLevels pending far children
   bool lds = t.queriesBounded && t.depth <= kLdsLevels && t.n <= ( uint64_t( 1 ) << 21 );
   for ( int d = 0; d < 3; ++d ) lds = lds && t.lo[d] >= 0 && t.hi[d] <= 8191;
-  const size_t ldsBytes = lds ? size_t( std::max( t.depth, 1 ) ) * 256 * 8 : 0;
+  const int ldsBase = std::max( 0, t.depth - kLdsTop );  // at most depth - 1 far children are ever pending
 #define TMC2_LAUNCH_K( KK )                                                                                          \
   if ( lds ) {                                                                                                       \
-    if ( ldsBytes > 48 * 1024 )                                                                                      \
-      TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( knnKernel<KK, SELF, true> ),                       \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, int( ldsBytes ) ) );               \
-    hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, ldsBytes, s, t.ptsTree, t.perm, t.nodes, rb, q,   \
-                        uint32_t( nq ), idx, dist );                                                                 \
+    hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,          \
+                        uint32_t( nq ), idx, dist, ldsBase );                                                        \
   } else {                                                                                                           \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, false> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,         \
-                        uint32_t( nq ), idx, dist );                                                                 \
+                        uint32_t( nq ), idx, dist, 0 );                                                              \
   }
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
