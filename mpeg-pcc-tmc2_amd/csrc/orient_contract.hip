@@ -36,10 +36,31 @@ __global__ __launch_bounds__( 256 ) void strongMutualMaskKernel( const uint16_t*
   mask[u] = uint16_t( out );
 }
 
-__global__ __launch_bounds__( 256 ) void initWordsKernel( uint32_t n, uint32_t* __restrict__ word, uint32_t* __restrict__ count ) {
+// Initial forest without a single atomic: every point hooks itself under the mutual strong neighbour of smallest hashed
+// priority, if that is smaller than its own (priorities strictly decrease along parent links: no cycles; the word
+// states a true relation).  Most of the union work is done before the first compare-and-swap, and the paths the
+// union pass walks end at local priority minima a few steps away.
+template <int K>
+__global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
+                                                           const uint16_t* __restrict__ mask, uint32_t n,
+                                                           uint32_t* __restrict__ word, uint32_t* __restrict__ count ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i < n ) word[i] = i << 1, count[i] = 0;
   if ( i == n ) count[n] = 0;
+  if ( i >= n ) return;
+  count[i]      = 0;
+  uint32_t best = i, bestPrio = ufPriority( i ), parity = 0;
+  uint32_t m    = mask[i];
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    const uint32_t v = knn[size_t( i ) * K + j];
+    if ( ufPriority( v ) < bestPrio ) {
+      best     = v;
+      bestPrio = ufPriority( v );
+      parity   = edgeDot[size_t( i ) * K + j] < 0.0 ? 1u : 0u;
+    }
+  }
+  word[i] = ( best << 1 ) | ( best == i ? 0u : parity );
 }
 
 // root of x and the parity of x relative to it; halves the path on the way
@@ -102,43 +123,43 @@ template <int K>
 __global__ __launch_bounds__( 256 ) void verifyCountKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
                                                              const uint16_t* __restrict__ mask, const uint32_t* __restrict__ root,
                                                              const uint8_t* __restrict__ parity, uint32_t n,
-                                                             uint32_t* __restrict__ count, uint32_t* __restrict__ bad ) {
+                                                             uint32_t* __restrict__ count, uint16_t* __restrict__ crossMask,
+                                                             uint32_t* __restrict__ bad ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n ) return;
   const uint32_t ru = root[u], m = mask[u];
   const uint32_t pu = parity[u];
-  uint32_t       cross = 0;
+  uint32_t       cross = 0;  // bit j: edge j leaves the cluster (kept for the scatter pass: no second round of gathers)
   bool           wrong = false;
 #pragma unroll
   for ( int j = 0; j < K; ++j ) {
     const uint32_t v = knn[size_t( u ) * K + j];
-    if ( root[v] != ru ) ++cross;
+    if ( root[v] != ru ) cross |= 1u << j;
     if ( ( m >> j ) & 1u ) {
       const uint32_t s = edgeDot[size_t( u ) * K + j] < 0.0 ? 1u : 0u;
       wrong |= ( pu ^ parity[v] ) != s;
     }
   }
-  if ( cross ) atomicAdd( &count[ru], cross );
+  crossMask[u] = uint16_t( cross );
+  if ( cross ) atomicAdd( &count[ru], uint32_t( __popc( cross ) ) );
   if ( wrong ) *bad = 1u;
 }
 
 template <int K>
 __global__ __launch_bounds__( 256 ) void scatterCrossKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
                                                               const uint32_t* __restrict__ root, const uint32_t* __restrict__ off,
-                                                              uint32_t n, uint32_t* __restrict__ cursor,
-                                                              OrientCrossEdge* __restrict__ edges ) {
+                                                              const uint16_t* __restrict__ crossMask, uint32_t n,
+                                                              uint32_t* __restrict__ cursor, OrientCrossEdge* __restrict__ edges ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n ) return;
-  const uint32_t ru    = root[u];
-  uint32_t       cross = 0;
-#pragma unroll
-  for ( int j = 0; j < K; ++j ) cross += root[knn[size_t( u ) * K + j]] != ru;
-  if ( !cross ) return;
-  uint32_t at = off[ru] + atomicAdd( &cursor[ru], cross );
-#pragma unroll
-  for ( int j = 0; j < K; ++j ) {
-    const uint32_t v = knn[size_t( u ) * K + j];
-    if ( root[v] != ru ) edges[at++] = OrientCrossEdge{u, v, edgeDot[size_t( u ) * K + j]};
+  uint32_t m = crossMask[u];
+  if ( !m ) return;
+  const uint32_t ru = root[u];
+  uint32_t       at = off[ru] + atomicAdd( &cursor[ru], uint32_t( __popc( m ) ) );
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    edges[at++] = OrientCrossEdge{u, knn[size_t( u ) * K + j], edgeDot[size_t( u ) * K + j]};
   }
 }
 
@@ -211,11 +232,13 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( n ) * 4, s ) );
   TMC2_TRY( ensureMutualMask( f ) );
   hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );
-  hipLaunchKernelGGL( initWordsKernel, grdN1, blk, 0, s, n, d_word.p, d_count.p );
+  hipLaunchKernelGGL( initWordsKernel<16>, grdN1, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, d_count.p );
   hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p );
   hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p );
+  DevBuf<uint16_t> d_crossMask;
+  TMC2_TRY( d_crossMask.alloc( n ) );
   hipLaunchKernelGGL( verifyCountKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_parity.p, n,
-                      d_count.p, d_small.p );
+                      d_count.p, d_crossMask.p, d_small.p );
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
   uint32_t head[2] = {0, 0};
   TMC2_HIP( hipMemcpyAsync( head, d_small.p, 8, hipMemcpyDeviceToHost, s ) );
@@ -224,8 +247,8 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   const uint32_t   E = head[1];
   DevBuf<OrientCrossEdge> d_edges;
   TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
-  hipLaunchKernelGGL( scatterCrossKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_root.p, d_off.p, n, d_cursor.p,
-                      d_edges.p );
+  hipLaunchKernelGGL( scatterCrossKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_root.p, d_off.p, d_crossMask.p, n,
+                      d_cursor.p, d_edges.p );
   uint32_t*        h_root   = ctx->hostA.get<uint32_t>( 2 * size_t( n ) + 2 );  // root | off
   uint8_t*         h_parity = ctx->hostC.get<uint8_t>( 2 * size_t( n ) );       // parity | (cluster signs, see the caller)
   OrientCrossEdge* h_edges  = ctx->hostE.get<OrientCrossEdge>( std::max<uint32_t>( E, 1u ) );

@@ -108,18 +108,39 @@ __global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __r
   mutual[u] = uint16_t( m );
 }
 
-__global__ __launch_bounds__( 256 ) void ccInitKernel( uint32_t n, uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
+__device__ __forceinline__ uint32_t ufPriority( uint32_t x ) { return x * 2654435761u; }  // odd multiplier: a bijection
+
+// Initial forest without atomics: every raw point hooks itself under the eligible mutual neighbour of smallest hashed
+// priority, if smaller than its own (priorities strictly decrease along parent links: acyclic).  Most unions are done
+// before the first compare-and-swap, and the paths the union pass walks end at local priority minima.
+template <int K>
+__global__ __launch_bounds__( 256 ) void ccInitKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
+                                                        const uint8_t* __restrict__ partition, const uint8_t* __restrict__ raw,
+                                                        uint32_t n, uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
                                                         uint32_t* __restrict__ ccCount ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  parent[i]  = i;
-  lab[i]     = kNoLabel;
-  ccCount[i] = 0;
+  lab[i]        = kNoLabel;
+  ccCount[i]    = 0;
+  uint32_t best = i;
+  if ( raw[i] ) {
+    uint32_t      bestPrio = ufPriority( i ), m = mutual[i];
+    const uint8_t pi       = partition[i];
+    while ( m ) {
+      const int j = __ffs( int( m ) ) - 1;
+      m &= m - 1;
+      const uint32_t v = knn[size_t( i ) * K + j];
+      if ( ufPriority( v ) < bestPrio && raw[v] && partition[v] == pi ) {
+        best     = v;
+        bestPrio = ufPriority( v );
+      }
+    }
+  }
+  parent[i] = best;
 }
 
 // a parent always has a smaller priority than its child, so the forest stays acyclic and a stale read during find
 // is still an ancestor-or-self of the truth
-__device__ __forceinline__ uint32_t ufPriority( uint32_t x ) { return x * 2654435761u; }  // odd multiplier: a bijection
 __device__ __forceinline__ uint32_t ufFind( uint32_t* parent, uint32_t x ) {
   uint32_t p = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   while ( p != x ) {
@@ -648,7 +669,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );
-    hipLaunchKernelGGL( ccInitKernel, grdN, blk, 0, s, n, d_parent.p, d_lab.p, d_ccCount.p );
+    hipLaunchKernelGGL( ccInitKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n, d_parent.p,
+                        d_lab.p, d_ccCount.p );
     {
       const int kt = ctx->stageBegin( "k:ccUnion" );
       hipLaunchKernelGGL( ccUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
