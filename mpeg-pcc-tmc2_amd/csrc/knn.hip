@@ -24,9 +24,10 @@
 //     stack lives in LDS, packed to 8 bytes per entry: every per-dimension distance on the path is the SQUARE of an
 //     integer offset to a split / box plane, so the entry keeps node id (22 bits) + three offsets (14 bits each).
 //     A full-depth LDS stack (tree depth x 2 KiB per block) would cap occupancy at 3 waves per SIMD, and this kernel
-//     lives on latency hiding; only the TOP kLdsTop slots -- where nearly all pushes and pops happen, next to the
-//     leaves -- are in LDS (16 KiB per block, occupancy back at the register limit), the slots below (filled once on
-//     the first descent, emptied once at the end) are packed 8-byte private memory.
+//     lives on latency hiding.  But the stack is only deep during the first descent (unbounded list: one pending far
+//     child per level); once the list is full it is purged of everything that already fails the bound and stays a
+//     few entries deep.  So slots 0..kLdsTop-1 are in LDS (16 KiB per block, occupancy back at the register limit) and
+//     the slots above spill to packed private memory, written and read once, while the wave's lanes are in step.
 //     Callers that cannot bound their coordinates (|offset| < 16384) or their tree (< 4 M nodes, <= kLdsLevels levels)
 //     get the scratch-stack kernel instead (same traversal, same results).
 //   * all arithmetic is int32: coordinates < 2^12, squared distances < 2^26 (the reference holds the
@@ -70,7 +71,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
                                                      uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist,
-                                                     int ldsBase ) {  // LDS: stack slots >= ldsBase live in LDS
+                                                     int /*unused*/ ) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if ( j >= nq ) return;
   const Pt  qp = SELF ? ptsTree[j] : queries[j];
@@ -92,10 +93,11 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   if ( qz < root.lo[2] ) o2 = root.lo[2] - qz;
   if ( qz > root.hi[2] ) o2 = qz - root.hi[2];
 
-  __shared__ unsigned long long ldsStack[LDS ? kLdsTop * 256 : 1];  // [slot - ldsBase][thread]
-  unsigned long long            lowStack[LDS ? kLdsLevels : 1];       // slots below ldsBase (private memory)
+  __shared__ unsigned long long ldsStack[LDS ? kLdsTop * 256 : 1];  // [slot][thread], slots < kLdsTop
+  unsigned long long            lowStack[LDS ? kLdsLevels : 1];       // slots >= kLdsTop (private memory)
   uint4                         scratchStack[LDS ? 1 : kMaxStack];
-  int      sp   = 0;
+  bool     swept = false;  // LDS: the stack has been purged once (see below)
+  int      sp    = 0;
   uint32_t node = 0;
   for ( ;; ) {
     KdNode nd = nodes[node];
@@ -115,10 +117,10 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
         if ( LDS ) {
           const unsigned long long e = (unsigned long long)farC | ( (unsigned long long)f0 << 22 ) |
                                        ( (unsigned long long)f1 << 36 ) | ( (unsigned long long)f2 << 50 );
-          if ( sp >= ldsBase )
-            ldsStack[( sp - ldsBase ) * 256 + threadIdx.x] = e;
+          if ( sp < kLdsTop )
+            ldsStack[sp * 256 + threadIdx.x] = e;
           else
-            lowStack[sp] = e;
+            lowStack[sp - kLdsTop] = e;
         } else {
           scratchStack[sp] = make_uint4( farC, f0, f1, f2 );
         }
@@ -133,12 +135,33 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       const uint32_t dist = uint32_t( ex * ex + ey * ey + ez * ez );
       if ( dist < bd[K - 1] ) knnInsert<K>( bd, bi, dist, perm[p] );
     }
+    // The first descent runs with an unbounded list and therefore leaves one pending far child per tree level.  As soon as
+    // the list is full, nearly all of them (the far side of the coarse splits) fail the bound, and the bound only
+    // tightens: purge them NOW, while the lanes of the wave are still in step (their private-memory slots are read
+    // coalesced), instead of one by one at the very end, when every lane unwinds on its own (each read then costs whole
+    // cache lines: 1.7 GB of HBM traffic per launch).  Same test, same order of the survivors: same traversal.
+    if ( LDS && !swept && bd[K - 1] != kInf ) {
+      swept = true;
+      int w = 0;
+      for ( int i = 0; i < sp; ++i ) {
+        const unsigned long long e = i < kLdsTop ? ldsStack[i * 256 + threadIdx.x] : lowStack[i - kLdsTop];
+        const uint32_t e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
+        if ( e0 * e0 + e1 * e1 + e2 * e2 <= bd[K - 1] ) {
+          if ( w < kLdsTop )
+            ldsStack[w * 256 + threadIdx.x] = e;
+          else
+            lowStack[w - kLdsTop] = e;
+          ++w;
+        }
+      }
+      sp = w;
+    }
     bool found = false;
     while ( sp > 0 ) {
       --sp;
       uint32_t en, e0, e1, e2;
       if ( LDS ) {
-        const unsigned long long e = sp >= ldsBase ? ldsStack[( sp - ldsBase ) * 256 + threadIdx.x] : lowStack[sp];
+        const unsigned long long e = sp < kLdsTop ? ldsStack[sp * 256 + threadIdx.x] : lowStack[sp - kLdsTop];
         en = uint32_t( e ) & 0x3FFFFFu, e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
       } else {
         const uint4 e = scratchStack[sp];
