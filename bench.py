@@ -122,12 +122,16 @@ def main():
     host_cache = {}
 
     def host_out(W, H):
-        """Host-side destination of the finished canvases (what the video encoder reads), allocated once."""
+        """Host-side destination of the finished canvases (what the video encoder reads), allocated once: page-locked
+        host memory, so that the copies are plain DMA instead of being staged through the runtime's bounce buffers."""
+        def pinned(shape, dtype):
+            t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8, pin_memory=True)
+            return t.numpy().view(dtype).reshape(shape)
         if (W, H) not in host_cache:
-            host_cache[(W, H)] = [(dict(occupancy=np.zeros((H, W), np.uint8), occ_video=np.zeros((H // 4, W // 4), np.uint8),
-                                        block_to_patch=np.zeros((H // 16, W // 16), np.uint32),
-                                        geo0=np.zeros((H, W), np.uint16), geo1=np.zeros((H, W), np.uint16)),
-                                   np.zeros((2, 3, H, W), np.uint8)) for _ in frames]
+            host_cache[(W, H)] = [(dict(occupancy=pinned((H, W), np.uint8), occ_video=pinned((H // 4, W // 4), np.uint8),
+                                        block_to_patch=pinned((H // 16, W // 16), np.uint32),
+                                        geo0=pinned((H, W), np.uint16), geo1=pinned((H, W), np.uint16)),
+                                   pinned((2, 3, H, W), np.uint8)) for _ in frames]
         return host_cache[(W, H)]
 
     def step():

@@ -683,7 +683,9 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   const dim3 grdV32( ( V + 7 ) / 8 );
   hipLaunchKernelGGL( devTableKernel, grdV32, blk, 0, s, d_adjOff.p, d_devLen.p, d_adj.p, V, d_dev.p );
   const size_t tailLds   = 3 * size_t( W ) * 4;
-  const bool   tailInLds = tailLds <= 128 * 1024;
+  // (test hook TMC2_REFINE_TAIL=global: take the global-memory tail regardless, the path of grids > 349 K voxels)
+  const char*  tailEnv   = getenv( "TMC2_REFINE_TAIL" );
+  const bool   tailInLds = tailLds <= 128 * 1024 && !( tailEnv && tailEnv[0] == 'g' );
   if ( tailInLds && tailLds > 48 * 1024 )
     TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureTailKernel ),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, int( tailLds ) ) );

@@ -253,3 +253,16 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch
     fr2 = gpu_ctx.frame(xyz, rgb)
     fr2.normals_compute(16, 1)
     assert np.array_equal(fr2.get_normals().view(np.uint64), exp.view(np.uint64))
+
+
+def test_gpu_refine_global_memory_tail(gpu_ctx, oracle, monkeypatch):
+    """Grids too large for the LDS bitmaps drain the closure tail through global memory: same partition."""
+    monkeypatch.setenv("TMC2_REFINE_TAIL", "global")
+    xyz, rgb = synth_cloud("small")
+    nrm = oracle.normals(xyz)
+    p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, 20, 4, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=20))
