@@ -163,6 +163,16 @@ int tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t* depth0,
  * Sorts the patch list (PCCPatch::gt), assigns u0/v0/patchOrientation, returns the frame's canvas height.  */
 int tmc2_encoder_pack_flexible( tmc2_frame* f, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
                                 int32_t* height );
+/* replaces: PCCEncoder::spatialConsistencyPackFlexible (PccLibEncoder/source/PCCEncoder.cpp:1183-1412) for one frame, as called
+ * by placeSegments (:4790-4795) for frames after the first when constrainedPack = 1 (the program default and the CTC
+ * low-delay condition; globalPatchAllocation 0), packingStrategy = 1, two orientations: patches are matched to those of
+ * `previous` (same view, bounding-box IoU > 0.2, pcc::computeIOU PCCPatchSegmenter.cpp:1563), matched ones go first,
+ * in the previous frame's order and if possible at the previous position.  `previous` must be packed already.       */
+int tmc2_encoder_pack_spatial_consistency( tmc2_frame* f, tmc2_frame* previous, int presetWidth, int numTilesHor,
+                                           double tileHeightToWidthRatio, int32_t* height );
+/* per list position: the position of the matched patch in the previous frame's list (PCCPatch::getBestMatchIdx), -1 = none
+ * (all -1 after tmc2_encoder_pack_flexible) */
+int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches );
 /* packing order of the frame: order[listPosition] = patch index (the reference reorders the list itself) */
 int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order );
 /* replaces: resizeTileGeometryVideo + resizeGeometryVideo (PCCEncoder.cpp:5593-5632, 5546-5591): common GOF canvas */
@@ -216,6 +226,11 @@ int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );
+/* the placement logic behind tmc2_encoder_pack_spatial_consistency on plain records: patches by index (u0 / v0 /
+ * patchOrientation out), their block-occupancy pool, the previous frame's patches in list order */
+int tmc2_host_pack_spatial_consistency( tmc2_patch* patches, int count, const uint8_t* occupancy, const tmc2_patch* previous,
+                                        int previousCount, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
+                                        int32_t* order, int32_t* matches, int32_t* height );
 /* the exact spanning-tree orientation behind tmc2_normals_orient (normals in/out, knn = [n][k]) */
 int tmc2_host_orient_normals( const int16_t* xyz, uint64_t n, const uint32_t* knn, int k, double* normals );
 

@@ -355,6 +355,7 @@ int tmc2_frame_reset( tmc2_frame* f ) {
   f->havePatches = f->havePacking = f->haveGeometryImages = f->haveAttributeImages = false;
   f->patches.clear();
   f->packOrder.clear();
+  f->packMatch.clear();
   f->depthCount = f->occCount = 0;
   f->rounds = f->packedHeight = 0;
   return TMC2_OK;

@@ -230,6 +230,7 @@ struct tmc2_frame {
   tmc2::DevBuf<uint8_t>   d_occupancy;         // per-block occupancy, all patches back to back
   int64_t                 depthCount = 0, occCount = 0;
   int                     rounds     = 0;
+  std::vector<int32_t>    packMatch;           // S10': per list position the matched position in the previous frame, -1
   bool                    havePatches = false;
   int                     growPools();         // make the pools hold depthCount / occCount entries (keeps content)
   // packing + canvases (phase A images)

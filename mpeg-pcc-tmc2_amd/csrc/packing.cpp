@@ -5,6 +5,9 @@
 // orientations), PCCPatch::gt / checkFitPatchCanvas / patchBlock2CanvasBlock (PccLibCommon/source/PCCPatch.cpp:253-371)
 // and the canvas-size rule of resizeTileGeometryVideo / resizeGeometryVideo (PCCEncoder.cpp:5593-5632, 5546-5591).
 //
+// S10' (low-delay condition, constrainedPack = 1): PCCEncoder::spatialConsistencyPackFlexible (:1183-1412) with
+// pcc::computeIOU (PCCPatchSegmenter.cpp:1563-1570) -- frames after the first are packed against their predecessor.
+//
 // Inherently sequential first-fit over a few hundred patches on an 80-block-wide canvas -- microseconds of
 // work on a few KB of data -- so it runs on the host between the segmentation kernels and the raster kernels.
 // The reference copies the whole canvas by value for every probe (PCCPatch.h:219); here each canvas row is a
@@ -53,6 +56,7 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
   }
   const int P = int( f->patches.size() );
   f->packOrder.resize( P );
+  f->packMatch.assign( P, -1 );
   for ( int i = 0; i < P; ++i ) f->packOrder[i] = i;
   f->packedHeight = 0;
   f->havePacking  = true;
@@ -113,6 +117,145 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
   return TMC2_OK;
 }
 
+
+namespace {
+bool gtOrder( const tmc2_patch& A, const tmc2_patch& B ) {  // PCCPatch::gt
+  const int aMax = std::max( A.sizeU0, A.sizeV0 ), aMin = std::min( A.sizeU0, A.sizeV0 );
+  const int bMax = std::max( B.sizeU0, B.sizeV0 ), bMin = std::min( B.sizeU0, B.sizeV0 );
+  if ( aMax != bMax ) return aMax > bMax;
+  if ( aMin != bMin ) return aMin > bMin;
+  return A.index < B.index;
+}
+}  // namespace
+
+// Core of S10' on plain records (no device involved).  pt: this frame's patches by index (u0 / v0 / orientation out);
+// occ: their block occupancy pool; prev: the previous frame's patches IN LIST ORDER, packed.  order: list order out;
+// match: per list position the matched position in prev, or -1.  Returns the frame height in pixels.
+int packSpatialConsistencyCore( tmc2_patch* pt, int P, const uint8_t* occ, const tmc2_patch* prev, int Pprev, int presetWidth,
+                                int occRes, int numTilesHor, double ratio, int32_t* order, int32_t* match ) {
+  if ( P == 0 ) return 0;
+  std::vector<int> sorted( P );
+  for ( int i = 0; i < P; ++i ) sorted[i] = i;
+  std::sort( sorted.begin(), sorted.end(), [&]( int a, int b ) { return gtOrder( pt[a], pt[b] ); } );
+  size_t sizeU = size_t( presetWidth / occRes );
+  size_t sizeV = size_t( std::max( pt[sorted[0]].sizeU0, pt[sorted[0]].sizeV0 ) );
+  // matching: every patch of the previous frame, in its list order, claims the unmatched patch of the same view whose
+  // bounding box overlaps its own most (intersection over union, float as in the reference, first maximum wins)
+  std::vector<int> matchOf( P, -1 ), list;
+  list.reserve( P );
+  for ( int id = 0; id < Pprev; ++id ) {
+    const tmc2_patch& q      = prev[id];
+    float             maxIou = 0.0F;
+    int               best   = -1;
+    for ( int c = 0; c < P; ++c ) {
+      const tmc2_patch& r = pt[sorted[c]];
+      if ( q.viewId != r.viewId || matchOf[sorted[c]] != -1 ) continue;
+      const int x1 = std::max( q.u1, r.u1 ), y1 = std::max( q.v1, r.v1 );
+      int       w  = std::min( q.u1 + q.sizeU, r.u1 + r.sizeU ) - x1, h = std::min( q.v1 + q.sizeV, r.v1 + r.sizeV ) - y1;
+      if ( w <= 0 || h <= 0 ) w = h = 0;
+      const int   inter = w * h, uni = q.sizeU * q.sizeV + r.sizeU * r.sizeV - inter;
+      const float iou   = static_cast<float>( inter ) / uni;
+      if ( iou > maxIou ) {
+        maxIou = iou;
+        best   = c;
+      }
+    }
+    if ( maxIou > 0.2F ) {
+      matchOf[sorted[best]] = id;
+      list.push_back( sorted[best] );
+    }
+  }
+  for ( int c = 0; c < P; ++c )
+    if ( matchOf[sorted[c]] == -1 ) list.push_back( sorted[c] );
+  for ( int k = 0; k < P; ++k ) {
+    order[k] = list[k];
+    match[k] = matchOf[list[k]];
+    sizeU    = std::max( sizeU, size_t( pt[list[k]].sizeU0 + 1 ) );
+  }
+  const int tileH = int( ( int( sizeU ) / numTilesHor ) * ratio );
+  sizeV           = std::max( sizeV, size_t( std::max( tileH, 0 ) ) );
+  size_t      heightBlocks = sizeV;
+  BlockCanvas canvas( sizeU, sizeV );
+  auto boxOf = [&]( const tmc2_patch& p, size_t& w, size_t& h ) {
+    w = p.patchOrientation == ORIENT_DEFAULT ? p.sizeU0 : p.sizeV0;
+    h = p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0;
+  };
+  for ( int k = 0; k < P; ++k ) {
+    tmc2_patch& p      = pt[list[k]];
+    bool        placed = false;
+    size_t      w, h;
+    while ( !placed ) {
+      if ( match[k] != -1 ) {
+        // same orientation as the match; its position first, then the first free position in raster order
+        const tmc2_patch& q = prev[match[k]];
+        p.patchOrientation  = q.patchOrientation;
+        boxOf( p, w, h );
+        if ( q.u0 >= 0 && q.v0 >= 0 && canvas.boxFree( size_t( q.u0 ), size_t( q.v0 ), w, h ) ) {
+          p.u0   = q.u0;
+          p.v0   = q.v0;
+          placed = true;
+        }
+        for ( size_t v = 0; v < canvas.height && !placed; ++v )
+          for ( size_t u = 0; u < canvas.width && !placed; ++u )
+            if ( canvas.boxFree( u, v, w, h ) ) {
+              p.u0   = int32_t( u );
+              p.v0   = int32_t( v );
+              placed = true;
+            }
+      } else {
+        const bool wide   = p.sizeU0 > p.sizeV0;
+        const int  first  = wide ? ORIENT_SWAP : ORIENT_DEFAULT;
+        const int  second = wide ? ORIENT_DEFAULT : ORIENT_SWAP;
+        for ( size_t v = 0; v < canvas.height && !placed; ++v )
+          for ( size_t u = 0; u < canvas.width && !placed; ++u )
+            for ( int o = 0; o < 2 && !placed; ++o ) {
+              p.patchOrientation = o == 0 ? first : second;
+              boxOf( p, w, h );
+              if ( canvas.boxFree( u, v, w, h ) ) {
+                p.u0   = int32_t( u );
+                p.v0   = int32_t( v );
+                placed = true;
+              }
+            }
+      }
+      if ( !placed ) canvas.grow( canvas.height * 2 );
+    }
+    const uint8_t* o = occ + p.occOffset;
+    for ( int vb = 0; vb < p.sizeV0; ++vb )
+      for ( int ub = 0; ub < p.sizeU0; ++ub )
+        if ( o[vb * p.sizeU0 + ub] ) {
+          if ( p.patchOrientation == ORIENT_DEFAULT )
+            canvas.set( size_t( p.u0 + ub ), size_t( p.v0 + vb ) );
+          else
+            canvas.set( size_t( p.u0 + vb ), size_t( p.v0 + ub ) );
+        }
+    heightBlocks = std::max( heightBlocks, size_t( p.v0 + ( p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0 ) ) );
+  }
+  return int( heightBlocks ) * occRes;
+}
+
+int packSpatialConsistencyHost( tmc2_frame* f, tmc2_frame* prevFrame, int presetWidth, int occRes, int numTilesHor, double ratio ) {
+  if ( !f->havePatches || !prevFrame->havePacking ) {
+    setError( "packSpatialConsistency: this frame has no patches or the previous frame is not packed" );
+    return TMC2_E_STATE;
+  }
+  const int P = int( f->patches.size() );
+  f->packOrder.assign( P, 0 );
+  f->packMatch.assign( P, -1 );
+  f->packedHeight = 0;
+  f->havePacking  = true;
+  if ( P == 0 ) return TMC2_OK;
+  std::vector<uint8_t> occ( size_t( f->occCount ) );
+  TMC2_HIP( hipMemcpyAsync( occ.data(), f->d_occupancy.p, occ.size(), hipMemcpyDeviceToHost, f->ctx->stream ) );
+  TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
+  std::vector<tmc2_patch> prevList( prevFrame->patches.size() );
+  for ( size_t k = 0; k < prevList.size(); ++k ) prevList[k] = prevFrame->patches[prevFrame->packOrder[k]];
+  f->packedHeight = packSpatialConsistencyCore( f->patches.data(), P, occ.data(), prevList.data(), int( prevList.size() ),
+                                                presetWidth, occRes, numTilesHor, ratio, f->packOrder.data(),
+                                                f->packMatch.data() );
+  return TMC2_OK;
+}
+
 }  // namespace tmc2
 
 extern "C" {
@@ -123,6 +266,35 @@ int tmc2_encoder_pack_flexible( tmc2_frame* f, int presetWidth, int numTilesHor,
   tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( tmc2::packFlexibleHost( f, presetWidth, 16, numTilesHor, tileHeightToWidthRatio ) );
   if ( height ) *height = f->packedHeight;
+  return TMC2_OK;
+}
+
+int tmc2_encoder_pack_spatial_consistency( tmc2_frame* f, tmc2_frame* previous, int presetWidth, int numTilesHor,
+                                           double tileHeightToWidthRatio, int32_t* height ) {
+  if ( !f || !previous || presetWidth <= 0 || numTilesHor <= 0 ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( f->ctx );
+  TMC2_TRY( tmc2::packSpatialConsistencyHost( f, previous, presetWidth, 16, numTilesHor, tileHeightToWidthRatio ) );
+  if ( height ) *height = f->packedHeight;
+  return TMC2_OK;
+}
+
+int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches ) {
+  if ( !f || !matches || !f->havePacking ) {
+    tmc2::setError( "get_patch_matches: frame not packed" );
+    return TMC2_E_STATE;
+  }
+  for ( size_t k = 0; k < f->packOrder.size(); ++k ) matches[k] = k < f->packMatch.size() ? f->packMatch[k] : -1;
+  return TMC2_OK;
+}
+
+int tmc2_host_pack_spatial_consistency( tmc2_patch* patches, int count, const uint8_t* occupancy, const tmc2_patch* previous,
+                                        int previousCount, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
+                                        int32_t* order, int32_t* matches, int32_t* height ) {
+  if ( count < 0 || previousCount < 0 || presetWidth <= 0 || numTilesHor <= 0 || !order || !matches || !height ||
+       ( count && ( !patches || !occupancy ) ) || ( previousCount && !previous ) )
+    return TMC2_E_INVALID;
+  *height = tmc2::packSpatialConsistencyCore( patches, count, occupancy, previous, previousCount, presetWidth, 16, numTilesHor,
+                                              tileHeightToWidthRatio, order, matches );
   return TMC2_OK;
 }
 

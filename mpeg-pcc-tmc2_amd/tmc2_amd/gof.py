@@ -184,8 +184,13 @@ class GofEncoder:
         """fn(frame, index) on the frame's own worker thread (e.g. the copies of finished canvases to host memory)."""
         return self._dispatch([(i % self.workers, (lambda fr=fr, i=i: fn(fr, i))) for i, fr in enumerate(frames)])
 
-    def phase_a(self, frames, sharder=None, weight=None):
+    def phase_a(self, frames, sharder=None, weight=None, constrained_pack=False):
+        """constrained_pack: the low-delay condition -- frames after the first are packed against their predecessor (S10',
+        a sequential chain over the GOF, microseconds per frame on the host; single-process only: the chain would cross
+        ranks)."""
         sharder = sharder or Sharder()
+        if constrained_pack and sharder.world > 1:
+            raise ValueError("constrained packing chains the frames of a GOF: run it in one process")
         if weight is None:
             w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
             weight = sharder.broadcast_weight(w)
@@ -194,7 +199,13 @@ class GofEncoder:
         def segment_and_pack(fr):
             fr.segmenter_compute(params)
             return fr.encoder_pack_flexible(self.min_w, 2, 1.0)
-        heights = self._per_worker(frames, segment_and_pack)
+        if constrained_pack:
+            self._per_worker(frames, lambda fr: fr.segmenter_compute(params))
+            heights = [frames[0].encoder_pack_flexible(self.min_w, 2, 1.0)]
+            for prev, fr in zip(frames[:-1], frames[1:]):
+                heights.append(fr.encoder_pack_spatial_consistency(prev, self.min_w, 2, 1.0))
+        else:
+            heights = self._per_worker(frames, segment_and_pack)
         gof_h = sharder.max_height(heights)
         W, H = lib.encoder_canvas_size([gof_h], self.min_w, self.min_w, self.min_h)
         self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))

@@ -297,6 +297,18 @@ class Frame:
         _check(self.L.tmc2_encoder_pack_flexible(self.h, int(preset_width), int(tiles_hor), C.c_double(ratio), C.byref(h)))
         return h.value
 
+    def encoder_pack_spatial_consistency(self, previous, preset_width=1280, tiles_hor=2, ratio=1.0):
+        """S10' (constrainedPack): pack against the previous frame of the GOF (which must be packed already)."""
+        h = C.c_int32()
+        _check(self.L.tmc2_encoder_pack_spatial_consistency(self.h, previous.h, int(preset_width), int(tiles_hor),
+                                                            C.c_double(ratio), C.byref(h)))
+        return h.value
+
+    def get_patch_matches(self):
+        m = np.zeros(self.L.tmc2_frame_patch_count(self.h), np.int32)
+        _check(self.L.tmc2_frame_get_patch_matches(self.h, _ptr(m)))
+        return m
+
     def get_patch_order(self):
         order = np.zeros(self.L.tmc2_frame_patch_count(self.h), np.int32)
         _check(self.L.tmc2_frame_get_patch_order(self.h, _ptr(order)))
@@ -358,6 +370,18 @@ def host_kdtree_build(xyz):
     nodes, depth = C.c_uint64(), C.c_int32()
     _check(L.tmc2_host_kdtree_build(_ptr(xyz), C.c_uint64(len(xyz)), _ptr(perm), C.byref(nodes), C.byref(depth)))
     return perm, nodes.value, depth.value
+
+
+def host_pack_spatial_consistency(patches, occupancy, previous_list, preset_width=1280, tiles_hor=2, ratio=1.0):
+    """(placed patches by index, order, matches per list position, height) -- the S10' placement on plain records."""
+    L = load_library()
+    p = np.array(patches, dtype=PATCH_DTYPE, order="C", copy=True)
+    prev = np.ascontiguousarray(previous_list, dtype=PATCH_DTYPE)
+    occ = np.ascontiguousarray(occupancy, dtype=np.uint8)
+    order, match, h = np.zeros(len(p), np.int32), np.zeros(len(p), np.int32), C.c_int32()
+    _check(L.tmc2_host_pack_spatial_consistency(_ptr(p), len(p), _ptr(occ), _ptr(prev), len(prev), int(preset_width),
+                                                int(tiles_hor), C.c_double(ratio), _ptr(order), _ptr(match), C.byref(h)))
+    return p, order, match, h.value
 
 
 def host_orient_normals(xyz, knn, normals):

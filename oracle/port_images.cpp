@@ -101,6 +101,123 @@ int orc_pack_flexible( orc_patch* patches, int P, const uint8_t* occupancy, int 
   return 0;
 }
 
+// S10' (low-delay condition: constrainedPack = 1, globalPatchAllocation = 0)
+//      PCCEncoder::spatialConsistencyPackFlexible (PCCEncoder.cpp:1183-1412, packingStrategy = 1, safeguard 0, two
+//      orientations, lowDelayEncoding off), pcc::computeIOU (PCCPatchSegmenter.cpp:1563-1570), Rect::operator&
+//      (PCCPatchSegmenter.h:407-417): patches of the previous frame (in ITS list order) look, one after the other, for
+//      the still unmatched patch of this frame (sorted by gt) with the same view and the largest bounding-box IoU
+//      (float, > 0.2); matched patches come first, in the previous frame's order, and are tried at their match's
+//      position and orientation before a raster scan that keeps the orientation; the others follow as in packFlexible.
+// patches: in/out, indexed by patch index; prev: the previous frame's patches in list order (u0, v0, orientation set).
+// order: out, list order; bestMatch: out, per LIST position the matched position in prev or -1.
+int orc_pack_spatial_consistency( orc_patch* patches, int P, const uint8_t* occupancy, const orc_patch* prev, int Pprev,
+                                  int presetWidth, int occRes, int numTilesHor, double tileHeightToWidthRatio,
+                                  int32_t* order, int32_t* bestMatch, int32_t* height ) {
+  if ( P == 0 ) {
+    *height = 0;
+    return 0;
+  }
+  std::vector<int> sorted( P );
+  for ( int i = 0; i < P; ++i ) sorted[i] = i;
+  std::sort( sorted.begin(), sorted.end(), [&]( int a, int b ) {
+    const orc_patch &A = patches[a], &B = patches[b];
+    const int        aMax = std::max( A.sizeU0, A.sizeV0 ), aMin = std::min( A.sizeU0, A.sizeV0 );
+    const int        bMax = std::max( B.sizeU0, B.sizeV0 ), bMin = std::min( B.sizeU0, B.sizeV0 );
+    return aMax != bMax ? aMax > bMax : ( aMin != bMin ? aMin > bMin : A.index < B.index );
+  } );
+  size_t sizeU = size_t( presetWidth / occRes );
+  size_t sizeV = size_t( std::max( patches[sorted[0]].sizeU0, patches[sorted[0]].sizeV0 ) );
+  std::vector<int> match( P, -1 );  // per patch index
+  std::vector<int> list;
+  for ( int id = 0; id < Pprev; ++id ) {
+    const orc_patch& q       = prev[id];
+    float            maxIou  = 0.0F;
+    int              bestIdx = -1;
+    for ( int c = 0; c < P; ++c ) {
+      const orc_patch& r = patches[sorted[c]];
+      if ( q.viewId != r.viewId || match[sorted[c]] != -1 ) continue;
+      const int x1 = std::max( q.u1, r.u1 ), y1 = std::max( q.v1, r.v1 );
+      int       w  = std::min( q.u1 + q.sizeU, r.u1 + r.sizeU ) - x1, h = std::min( q.v1 + q.sizeV, r.v1 + r.sizeV ) - y1;
+      if ( w <= 0 || h <= 0 ) w = h = 0;
+      const int   inter = w * h, uni = q.sizeU * q.sizeV + r.sizeU * r.sizeV - inter;
+      const float iou   = static_cast<float>( inter ) / uni;
+      if ( iou > maxIou ) {
+        maxIou  = iou;
+        bestIdx = c;
+      }
+    }
+    if ( maxIou > 0.2F ) {
+      match[sorted[bestIdx]] = id;
+      list.push_back( sorted[bestIdx] );
+    }
+  }
+  for ( int c = 0; c < P; ++c )
+    if ( match[sorted[c]] == -1 ) list.push_back( sorted[c] );
+  for ( int k = 0; k < P; ++k ) {
+    order[k]     = list[k];
+    bestMatch[k] = match[list[k]];
+    sizeU        = std::max( sizeU, size_t( patches[list[k]].sizeU0 + 1 ) );
+  }
+  const int tileW = int( sizeU ) / numTilesHor;
+  const int tileH = int( tileW * tileHeightToWidthRatio );
+  if ( int( sizeV ) < tileH ) sizeV = size_t( tileH );
+  size_t               hPix = sizeV * occRes;
+  std::vector<uint8_t> canvas( sizeU * sizeV, 0 );
+  auto fits = [&]( const orc_patch& p ) {
+    const size_t w = p.patchOrientation == ORIENT_DEFAULT ? p.sizeU0 : p.sizeV0;
+    const size_t h = p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0;
+    if ( size_t( p.u0 ) + w > sizeU || size_t( p.v0 ) + h > sizeV ) return false;
+    for ( size_t y = p.v0; y < p.v0 + h; ++y )
+      for ( size_t x = p.u0; x < p.u0 + w; ++x )
+        if ( canvas[y * sizeU + x] ) return false;
+    return true;
+  };
+  for ( int k = 0; k < P; ++k ) {
+    orc_patch& p     = patches[list[k]];
+    bool       found = false;
+    while ( !found ) {
+      if ( match[list[k]] != -1 ) {
+        const orc_patch& q = prev[match[list[k]]];
+        p.patchOrientation = q.patchOrientation;
+        p.u0               = q.u0;
+        p.v0               = q.v0;
+        found              = fits( p );
+        for ( size_t v = 0; v <= sizeV && !found; ++v )
+          for ( size_t u = 0; u <= sizeU && !found; ++u ) {
+            p.u0  = int32_t( u );
+            p.v0  = int32_t( v );
+            found = fits( p );
+          }
+      } else {
+        for ( size_t v = 0; v < sizeV && !found; ++v )
+          for ( size_t u = 0; u < sizeU && !found; ++u )
+            for ( int o = 0; o < 2 && !found; ++o ) {
+              p.u0               = int32_t( u );
+              p.v0               = int32_t( v );
+              p.patchOrientation = ( p.sizeU0 > p.sizeV0 ) ? ( o == 0 ? ORIENT_SWAP : ORIENT_DEFAULT )
+                                                           : ( o == 0 ? ORIENT_DEFAULT : ORIENT_SWAP );
+              found              = fits( p );
+            }
+      }
+      if ( !found ) {
+        sizeV *= 2;
+        canvas.resize( sizeU * sizeV, 0 );
+      }
+    }
+    const uint8_t* occ = occupancy + p.occOffset;
+    for ( int vb = 0; vb < p.sizeV0; ++vb )
+      for ( int ub = 0; ub < p.sizeU0; ++ub ) {
+        const size_t x = p.patchOrientation == ORIENT_DEFAULT ? ub + p.u0 : vb + p.u0;
+        const size_t y = p.patchOrientation == ORIENT_DEFAULT ? vb + p.v0 : ub + p.v0;
+        canvas[y * sizeU + x] = canvas[y * sizeU + x] || occ[vb * p.sizeU0 + ub];
+      }
+    const int span = p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0;
+    hPix           = std::max( hPix, size_t( p.v0 + span ) * occRes );
+  }
+  *height = int32_t( hPix );
+  return 0;
+}
+
 // common canvas of a GOF: max over frames and the configured minimum, rounded up to 64
 int orc_gof_canvas_size( const int32_t* frameHeights, int frames, int tileWidth, int minWidth, int minHeight,
                          int32_t* W, int32_t* H ) {

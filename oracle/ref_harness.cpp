@@ -412,6 +412,25 @@ void setCtcParams( PCCEncoderParameters& p, int iterations, int bits3dMinus1, in
 
 extern "C" {
 
+// constrainedPack != 0: cfg/condition/ctc-low-delay.cfg (the program default: frames after the first are packed by
+// spatialConsistencyPackFlexible against their predecessor)
+int ref_gof_begin2( int frameCount, int iterations, int bits3dMinus1, int occPrecision, int minW, int minH,
+                    int constrainedPack ) {
+  Quiet quiet;
+  g_gof.reset( new Gof() );
+  setCtcParams( g_gof->params, iterations, bits3dMinus1, occPrecision, minW, minH );
+  g_gof->params.constrainedPack_ = constrainedPack != 0;
+  g_gof->sources.setFrameCount( size_t( frameCount ) );
+  return 0;
+}
+
+// per list position: position of the matched patch in the previous frame's list, or -1
+int ref_gof_get_patch_matches( int frame, int32_t* out ) {
+  auto& patches = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();
+  for ( size_t i = 0; i < patches.size(); ++i ) out[i] = int32_t( patches[i].getBestMatchIdx() );
+  return 0;
+}
+
 int ref_gof_begin( int frameCount, int iterations, int bits3dMinus1, int occPrecision, int minW, int minH ) {
   Quiet quiet;
   g_gof.reset( new Gof() );

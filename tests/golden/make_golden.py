@@ -72,6 +72,26 @@ def gof():
     print("gof_tiny2", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
+def gof_low_delay():
+    """S0-S16 of a 4-frame GOF under the low-delay packing (constrainedPack = 1: frames after the first are packed by
+    spatialConsistencyPackFlexible against their predecessor), through the reference's own placeSegments."""
+    ref = ob.Reference()
+    frames = [synth_cloud("tiny", f) for f in range(4)]
+    a = ref.phase_a(frames, 10, 11, 4, constrained_pack=True)
+    out = {"input_md5": np.array("".join(digest(x) + digest(c) for x, c in frames)),
+           "canvas": np.array([a[0]["width"], a[0]["height"]])}
+    for i, pa in enumerate(a):
+        p = pa["patches"]
+        out["f%d_patches" % i] = np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        out["f%d_matches" % i] = pa["matches"].astype(np.int32)
+        out["f%d_block_to_patch" % i] = pa["block_to_patch"].astype(np.uint16)
+        for k in ("occupancy", "geo0", "geo1"):
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pa[k]))
+    np.savez_compressed(os.path.join(HERE, "gof_tiny4_low_delay.npz"), **out)
+    print("gof_tiny4_low_delay", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
     gof()
+    gof_low_delay()

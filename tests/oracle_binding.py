@@ -194,20 +194,40 @@ class Oracle:
         assert rc == 0
         return out
 
-    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280):
-        """S0..S16 for a GOF given as [(xyz, rgb), ...]; mirrors Reference.phase_a."""
+    def pack_spatial_consistency(self, patches, occupancy, prev_list, preset_width=1280, occ_res=16, tiles_hor=2, ratio=1.0):
+        """S10' for one frame against the previous frame's patch list (in list order).
+        Returns (placed patches by index, order, matches per list position, height)."""
+        p = np.array(patches, dtype=PATCH_DTYPE, order="C", copy=True)
+        prev = np.ascontiguousarray(prev_list, dtype=PATCH_DTYPE)
+        occ = np.ascontiguousarray(occupancy, dtype=np.uint8)
+        order = np.zeros(len(p), np.int32)
+        match = np.zeros(len(p), np.int32)
+        h = C.c_int32()
+        self.L.orc_pack_spatial_consistency(_p(p), len(p), _p(occ), _p(prev), len(prev), int(preset_width), int(occ_res),
+                                            int(tiles_hor), C.c_double(ratio), _p(order), _p(match), C.byref(h))
+        return p, order, match, h.value
+
+    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False):
+        """S0..S16 for a GOF given as [(xyz, rgb), ...]; mirrors Reference.phase_a.  constrained_pack: the low-delay
+        condition (frames after the first packed against their predecessor, S10')."""
         w = self.weight_normal(frames[0][0], bits3d, 0.6)
         sp = seg_params(iterations, bits3d, w)
         per = []
         for xyz, rgb in frames:
             seg = self.segment(xyz, rgb, sp)
-            placed, order, h = self.pack_flexible(seg["patches"], seg["occupancy"], min_w)
+            if constrained_pack and per:
+                pseg, pplaced, porder, _ = per[-1][:4]
+                placed, order, match, h = self.pack_spatial_consistency(seg["patches"], seg["occupancy"], pplaced[porder], min_w)
+                seg["matches"] = match
+            else:
+                placed, order, h = self.pack_flexible(seg["patches"], seg["occupancy"], min_w)
+                seg["matches"] = np.full(len(order), -1, np.int32)
             per.append((seg, placed, order, h))
         W, H = self.gof_canvas_size([x[3] for x in per], min_w, min_w, min_h)
         out = []
         for seg, placed, order, h in per:
             img = self.geometry_images(placed, order, seg["depth0"], seg["depth1"], W, H, 16, occ_precision)
-            img.update(patches=placed[order], width=W, height=H)
+            img.update(patches=placed[order], width=W, height=H, matches=seg["matches"])
             out.append(img)
         return out
 
@@ -315,10 +335,11 @@ class Reference:
             out.append(dict(recon_xyz=rec, recon_rgb=col, point_to_pixel=p2p, attribute=att))
         return out
 
-    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280):
+    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False):
         """S0..S16 through the reference's own PCCEncoder members (identity video codec)."""
         L = self.L
-        L.ref_gof_begin(len(frames), int(iterations), int(bits3d - 1), int(occ_precision), int(min_w), int(min_h))
+        L.ref_gof_begin2(len(frames), int(iterations), int(bits3d - 1), int(occ_precision), int(min_w), int(min_h),
+                         1 if constrained_pack else 0)
         keep = []
         for i, (xyz, rgb) in enumerate(frames):
             xyz = _i16(xyz)
@@ -340,7 +361,9 @@ class Reference:
             L.ref_gof_get_images(i, _p(img["occupancy"]), _p(img["occ_video"]), _p(img["block_to_patch"]),
                                  _p(img["geo0"]), _p(img["geo1"]))
             assert L.ref_gof_geometry_chroma_nonzero(i) == 0
-            img.update(patches=pt, width=W, height=H)
+            mt = np.zeros(n, np.int32)
+            L.ref_gof_get_patch_matches(i, _p(mt))
+            img.update(patches=pt, width=W, height=H, matches=mt)
             out.append(img)
         return out
 

@@ -218,3 +218,22 @@ def test_gpu_vox11_full_path_properties(gpu_ctx):
     assert hit > 0          # lossless D0 positions reappear exactly
     att = fr.get_attribute_images()
     assert att.shape == (2, 3, H, W) and att[0, :, occ].any()
+
+
+def test_gpu_low_delay_packing_matches_golden_fixture():
+    """S0-S16 under the low-delay packing (S10': frames after the first packed against their predecessor) through the GOF
+    orchestration, against the fixture generated from the unmodified reference."""
+    from test_oracle_golden import _low_delay_fixture, check_low_delay_against_fixture
+    g, frames = _low_delay_fixture()
+    enc = T.GofEncoder(0, workers=2, iterations=10)
+    try:
+        frs = enc.upload(frames)
+        W, H = enc.phase_a(frs, constrained_pack=True)
+        a = []
+        for fr in frs:
+            img = fr.get_geometry_images()
+            img.update(patches=fr.get_patches()[0][fr.get_patch_order()], width=W, height=H, matches=fr.get_patch_matches())
+            a.append(img)
+        check_low_delay_against_fixture(g, a)
+    finally:
+        enc.close()

@@ -90,3 +90,25 @@ def test_host_orientation_strong_edge_thresholds(oracle, tau, tmp_path):
                str(tmp_path / "in.npz"), str(tmp_path / "out.npy")))
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, TMC2_ORIENT_TAU=tau))
     assert np.array_equal(bits(np.load(tmp_path / "out.npy")), bits(exp))
+
+
+@pytest.mark.parametrize("name,nframes", [("tiny", 4), ("small", 3)])
+def test_host_spatial_consistency_packing_matches_oracle(oracle, name, nframes):
+    """S10' (low-delay condition): the product's placement logic on plain records against the oracle's restatement of
+    spatialConsistencyPackFlexible, frame after frame (each frame is packed against the product's own previous result)."""
+    frames = [synth_cloud(name, f) for f in range(nframes)]
+    w = oracle.weight_normal(frames[0][0], 11, 0.6)
+    import oracle_binding as ob
+    sp = ob.seg_params(10, 11, w)
+    prev_list = None
+    for f, (xyz, rgb) in enumerate(frames):
+        seg = oracle.segment(xyz, rgb, sp)
+        if prev_list is None:
+            placed, order, _ = oracle.pack_flexible(seg["patches"], seg["occupancy"], 1280)
+        else:
+            placed, order, match, h = T.host_pack_spatial_consistency(seg["patches"], seg["occupancy"], prev_list, 1280)
+            ep, eo, em, eh = oracle.pack_spatial_consistency(seg["patches"], seg["occupancy"], prev_list, 1280)
+            assert h == eh and np.array_equal(order, eo) and np.array_equal(match, em) and (em >= 0).sum() >= 2
+            for k in ("u0", "v0", "patchOrientation"):
+                assert np.array_equal(placed[k], ep[k]), (f, k)
+        prev_list = placed[order]

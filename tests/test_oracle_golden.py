@@ -117,6 +117,46 @@ def test_oracle_gof_matches_reference_live(oracle, reference):
             assert np.array_equal(x[k], y[k]), k
 
 
+def _low_delay_fixture():
+    g = np.load(os.path.join(GOLD, "gof_tiny4_low_delay.npz"))
+    frames = [synth_cloud("tiny", f) for f in range(4)]
+    assert str(g["input_md5"]) == "".join(digest(x) + digest(c) for x, c in frames)
+    return g, frames
+
+
+def check_low_delay_against_fixture(g, a):
+    """Shared by the CPU (oracle) and GPU tiers: S0-S16 under the low-delay packing (S10') against the reference's fixture."""
+    assert [a[0]["width"], a[0]["height"]] == g["canvas"].tolist()
+    for i, pa in enumerate(a):
+        p = pa["patches"]
+        mat = np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        assert np.array_equal(mat, g["f%d_patches" % i]), i
+        assert np.array_equal(pa["matches"], g["f%d_matches" % i]), i
+        assert i == 0 or (pa["matches"] >= 0).sum() >= 2                      # the fixture does exercise the matching
+        assert np.array_equal(pa["block_to_patch"].astype(np.uint16), g["f%d_block_to_patch" % i])
+        for k in ("occupancy", "geo0", "geo1"):
+            assert digest(pa[k]) == str(g["f%d_%s_md5" % (i, k)]), k
+
+
+def test_oracle_low_delay_packing_matches_golden(oracle):
+    g, frames = _low_delay_fixture()
+    check_low_delay_against_fixture(g, oracle.phase_a(frames, 10, 11, 4, constrained_pack=True))
+
+
+def test_oracle_low_delay_packing_matches_reference_live(oracle, reference):
+    """A different GOF than the fixture, where the compiled reference is present."""
+    frames = [synth_cloud("small", f + 2) for f in range(3)]
+    ra = reference.phase_a(frames, 10, 11, 4, constrained_pack=True)
+    oa = oracle.phase_a(frames, 10, 11, 4, constrained_pack=True)
+    for x, y in zip(ra, oa):
+        assert np.array_equal(x["matches"], y["matches"])
+        for n in x["patches"].dtype.names:
+            if n not in ("depthOffset", "occOffset"):
+                assert np.array_equal(x["patches"][n], y["patches"][n]), n
+        for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+            assert np.array_equal(x[k], y[k]), k
+
+
 def _sparse_target_case(seed=0):
     """A dense source and a ~40x sparser target: every target collects dozens of backward candidates, many at equal
     distance -- the regime where the reference's std::sort (introsort, not stable beyond 16) decides the fp64 order."""
