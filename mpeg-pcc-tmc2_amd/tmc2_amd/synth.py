@@ -131,3 +131,23 @@ def synth_cloud(name="small", frame=0, height=None, bits=None, seed=None):
 
 def synth_gof(name, frame_count):
     return [synth_cloud(name, f) for f in range(frame_count)]
+
+
+def two_body_gof(name="tiny", frames=5, seed=0):
+    """A GOF of two bodies: one that stays put (its patches keep matching from frame to frame) and one that jumps to an
+    unrelated place every frame (its patches never match).  The inter-frame packers (low-delay spatial consistency,
+    global patch allocation) see long patch tracks AND a large unmatched remainder, which is what drives the global
+    patch allocation into its restart branches on small canvases."""
+    rng = np.random.default_rng(1000 + seed)
+    out = []
+    for f in range(frames):
+        a, ca = synth_cloud(name, f)
+        b, cb = synth_cloud(name, (7 * f + 3) % 11)
+        lo, hi = b.min(0).astype(np.int64), b.max(0).astype(np.int64)
+        while True:  # a random resting place whose bounding box is clear of the first body's
+            at = rng.integers(0, 1024 - (hi - lo))
+            if np.any(at + (hi - lo) < a.min(0)) or np.any(at > a.max(0)):
+                break
+        xyz = np.concatenate([a, (b + (at - lo)).astype(a.dtype)])
+        out.append((np.ascontiguousarray(xyz), np.ascontiguousarray(np.concatenate([ca, cb]))))
+    return out

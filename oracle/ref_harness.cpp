@@ -414,12 +414,14 @@ extern "C" {
 
 // constrainedPack != 0: cfg/condition/ctc-low-delay.cfg (the program default: frames after the first are packed by
 // spatialConsistencyPackFlexible against their predecessor)
+// constrainedPack == 2: additionally globalPatchAllocation = 1 (cfg/condition/ctc-random-access.cfg)
 int ref_gof_begin2( int frameCount, int iterations, int bits3dMinus1, int occPrecision, int minW, int minH,
                     int constrainedPack ) {
   Quiet quiet;
   g_gof.reset( new Gof() );
   setCtcParams( g_gof->params, iterations, bits3dMinus1, occPrecision, minW, minH );
-  g_gof->params.constrainedPack_ = constrainedPack != 0;
+  g_gof->params.constrainedPack_       = constrainedPack != 0;
+  g_gof->params.globalPatchAllocation_ = constrainedPack == 2 ? 1 : 0;
   g_gof->sources.setFrameCount( size_t( frameCount ) );
   return 0;
 }

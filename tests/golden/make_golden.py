@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "mpeg-pcc-tmc2_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_binding as ob  # noqa: E402
-from tmc2_amd.synth import synth_cloud  # noqa: E402
+from tmc2_amd.synth import synth_cloud, two_body_gof  # noqa: E402
 
 
 def digest(a):
@@ -91,7 +91,32 @@ def gof_low_delay():
     print("gof_tiny4_low_delay", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
+RANDOM_ACCESS_CANVAS = (128, 192)  # small enough that the allocation restarts its sub-context three different ways
+
+
+def gof_random_access():
+    """S0-S16 of a 6-frame GOF under the random-access packing (globalPatchAllocation = 1: performDataAdaptiveGPAMethod
+    re-packs the frames of a sub-context around the unions of their tracked patches), through the reference's own
+    generateSegments / placeSegments / performDataAdaptiveGPAMethod.  On this canvas the sequence takes the accepting
+    branch, the bad-packing restart and the unions-too-tall restart."""
+    ref = ob.Reference()
+    frames = two_body_gof("tiny", 6)
+    a = ref.phase_a(frames, 10, 11, 4, min_w=RANDOM_ACCESS_CANVAS[0], min_h=RANDOM_ACCESS_CANVAS[1], constrained_pack=2)
+    out = {"input_md5": np.array("".join(digest(x) + digest(c) for x, c in frames)),
+           "canvas": np.array([a[0]["width"], a[0]["height"]])}
+    for i, pa in enumerate(a):
+        p = pa["patches"]
+        out["f%d_patches" % i] = np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        out["f%d_matches" % i] = pa["matches"].astype(np.int32)
+        out["f%d_block_to_patch" % i] = pa["block_to_patch"].astype(np.uint16)
+        for k in ("occupancy", "geo0", "geo1"):
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pa[k]))
+    np.savez_compressed(os.path.join(HERE, "gof_twobody6_random_access.npz"), **out)
+    print("gof_twobody6_random_access", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
     gof()
     gof_low_delay()
+    gof_random_access()

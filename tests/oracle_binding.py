@@ -207,9 +207,37 @@ class Oracle:
                                             int(tiles_hor), C.c_double(ratio), _p(order), _p(match), C.byref(h))
         return p, order, match, h.value
 
+    def global_patch_allocation(self, per, min_w, min_h):
+        """S10' second half (random-access condition): GPA over the frames packed by the per-frame chain.
+        per: [(seg, placed, order, height)] -> [(list patches, occupancy pool, matches, tile width, tile height)]."""
+        L = self.L
+        L.orc_gpa_begin.restype = C.c_void_p
+        L.orc_gpa_occ_bytes.restype = C.c_int64
+        widths = [max(min_w // 16, int((placed["sizeU0"] + 1).max()) if len(placed) else 0) * 16 for _, placed, _, _ in per]
+        tw, th = max(widths + [min_w]), max([h for _, _, _, h in per] + [min_h])     # resizeTileGeometryVideo
+        h = C.c_void_p(L.orc_gpa_begin(len(per), int(min_w), int(min_h), 16))
+        for f, (seg, placed, order, _) in enumerate(per):
+            lst = np.ascontiguousarray(placed[order], dtype=PATCH_DTYPE)
+            occ = np.ascontiguousarray(seg["occupancy"], dtype=np.uint8)
+            m = np.ascontiguousarray(seg["matches"], dtype=np.int32)
+            L.orc_gpa_set_frame(h, f, _p(lst), len(lst), _p(occ), _p(m), int(tw), int(th))
+        L.orc_gpa_run(h)
+        out = []
+        for f, (seg, placed, order, _) in enumerate(per):
+            n = len(placed)
+            lst = np.zeros(n, PATCH_DTYPE)
+            occ = np.zeros(max(1, L.orc_gpa_occ_bytes(h, f)), np.uint8)
+            m = np.zeros(n, np.int32)
+            wh = np.zeros(2, np.int32)
+            L.orc_gpa_get_frame(h, f, _p(lst), _p(occ), _p(m), _p(wh))
+            out.append((lst, occ, m, int(wh[0]), int(wh[1])))
+        L.orc_gpa_free(h)
+        return out
+
     def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False):
-        """S0..S16 for a GOF given as [(xyz, rgb), ...]; mirrors Reference.phase_a.  constrained_pack: the low-delay
-        condition (frames after the first packed against their predecessor, S10')."""
+        """S0..S16 for a GOF given as [(xyz, rgb), ...]; mirrors Reference.phase_a.  constrained_pack: True = the low-delay
+        condition (frames after the first packed against their predecessor, S10'); 2 = the random-access condition
+        (the same chain followed by the global patch allocation)."""
         w = self.weight_normal(frames[0][0], bits3d, 0.6)
         sp = seg_params(iterations, bits3d, w)
         per = []
@@ -223,6 +251,17 @@ class Oracle:
                 placed, order, h = self.pack_flexible(seg["patches"], seg["occupancy"], min_w)
                 seg["matches"] = np.full(len(order), -1, np.int32)
             per.append((seg, placed, order, h))
+        if constrained_pack == 2:
+            gpa = self.global_patch_allocation(per, min_w, min_h)
+            tw, th = max([g[3] for g in gpa] + [min_w]), max([g[4] for g in gpa] + [min_h])    # resizeTileGeometryVideo
+            W, H = self.gof_canvas_size([th], tw, min_w, min_h)
+            out = []
+            for (seg, _, _, _), (lst, occ, m, _, _) in zip(per, gpa):
+                order = np.arange(len(lst), dtype=np.int32)
+                img = self.geometry_images(lst, order, seg["depth0"], seg["depth1"], W, H, 16, occ_precision)
+                img.update(patches=lst, width=W, height=H, matches=m)
+                out.append(img)
+            return out
         W, H = self.gof_canvas_size([x[3] for x in per], min_w, min_w, min_h)
         out = []
         for seg, placed, order, h in per:
@@ -339,7 +378,7 @@ class Reference:
         """S0..S16 through the reference's own PCCEncoder members (identity video codec)."""
         L = self.L
         L.ref_gof_begin2(len(frames), int(iterations), int(bits3d - 1), int(occ_precision), int(min_w), int(min_h),
-                         1 if constrained_pack else 0)
+                         int(constrained_pack))
         keep = []
         for i, (xyz, rgb) in enumerate(frames):
             xyz = _i16(xyz)

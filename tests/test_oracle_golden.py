@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from tmc2_amd.synth import synth_cloud
+from tmc2_amd.synth import synth_cloud, two_body_gof
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -149,6 +149,74 @@ def test_oracle_low_delay_packing_matches_reference_live(oracle, reference):
     ra = reference.phase_a(frames, 10, 11, 4, constrained_pack=True)
     oa = oracle.phase_a(frames, 10, 11, 4, constrained_pack=True)
     for x, y in zip(ra, oa):
+        assert np.array_equal(x["matches"], y["matches"])
+        for n in x["patches"].dtype.names:
+            if n not in ("depthOffset", "occOffset"):
+                assert np.array_equal(x["patches"][n], y["patches"][n]), n
+        for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+            assert np.array_equal(x[k], y[k]), k
+
+
+RANDOM_ACCESS_CANVAS = (128, 192)  # as in tests/golden/make_golden.py
+
+
+def _random_access_fixture():
+    g = np.load(os.path.join(GOLD, "gof_twobody6_random_access.npz"))
+    frames = two_body_gof("tiny", 6)
+    assert str(g["input_md5"]) == "".join(digest(x) + digest(c) for x, c in frames)
+    return g, frames
+
+
+def check_random_access_against_fixture(g, a):
+    """Shared by the CPU (oracle) and GPU tiers: S0-S16 under the global patch allocation (S10', random-access
+    condition) against the reference's fixture; the sequence accepts a sub-context, restarts on bad packing, restarts on
+    too-tall unions and accepts again, so matched patches exist in frames 1 and 5 only."""
+    assert [a[0]["width"], a[0]["height"]] == g["canvas"].tolist()
+    for i, pa in enumerate(a):
+        p = pa["patches"]
+        mat = np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        assert np.array_equal(mat, g["f%d_patches" % i]), i
+        assert np.array_equal(pa["matches"], g["f%d_matches" % i]), i
+        assert np.array_equal(pa["block_to_patch"].astype(np.uint16), g["f%d_block_to_patch" % i])
+        for k in ("occupancy", "geo0", "geo1"):
+            assert digest(pa[k]) == str(g["f%d_%s_md5" % (i, k)]), k
+    assert [int((pa["matches"] >= 0).sum()) for pa in a] == [0, 4, 0, 0, 0, 4]
+
+
+def test_oracle_random_access_packing_matches_golden(oracle):
+    g, frames = _random_access_fixture()
+    w, h = RANDOM_ACCESS_CANVAS
+    check_random_access_against_fixture(g, oracle.phase_a(frames, 10, 11, 4, min_w=w, min_h=h, constrained_pack=2))
+
+
+def _jumping(frames):
+    """every other frame displaced as a whole: nothing matches across the jump (the too-few-unions restart)"""
+    out = []
+    for f, (xyz, rgb) in enumerate(frames):
+        x = xyz.copy()
+        if f % 2:
+            x[:, 0] += 300
+            x[:, 2] += 150
+        out.append((x, rgb))
+    return out
+
+
+@pytest.mark.parametrize("case", ["accept", "bad_packing", "bad_height", "bad_count", "small"])
+def test_oracle_random_access_packing_matches_reference_live(oracle, reference, case):
+    """Other GOFs and canvases than the fixture, where the compiled reference is present: each of the allocation's
+    outcomes (accepted sub-contexts that keep growing; restarts because the re-packed frames overflow, because the
+    unions alone are too tall, because too few tracks survive)."""
+    frames, w, h = {
+        "accept": (two_body_gof("tiny", 5, seed=1), 256, 128),
+        "bad_packing": (two_body_gof("tiny", 6), 192, 160),
+        "bad_height": (two_body_gof("tiny", 6), 160, 160),
+        "bad_count": (_jumping([synth_cloud("tiny", f) for f in range(5)]), 512, 512),
+        "small": ([synth_cloud("small", f) for f in range(5)], 256, 176),
+    }[case]
+    ra = reference.phase_a(frames, 10, 11, 4, min_w=w, min_h=h, constrained_pack=2)
+    oa = oracle.phase_a(frames, 10, 11, 4, min_w=w, min_h=h, constrained_pack=2)
+    for x, y in zip(ra, oa):
+        assert (x["width"], x["height"]) == (y["width"], y["height"])
         assert np.array_equal(x["matches"], y["matches"])
         for n in x["patches"].dtype.names:
             if n not in ("depthOffset", "occOffset"):
