@@ -173,6 +173,18 @@ int tmc2_encoder_pack_spatial_consistency( tmc2_frame* f, tmc2_frame* previous, 
 /* per list position: the position of the matched patch in the previous frame's list (PCCPatch::getBestMatchIdx), -1 = none
  * (all -1 after tmc2_encoder_pack_flexible) */
 int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches );
+/* replaces: PCCEncoder::performDataAdaptiveGPAMethod (PccLibEncoder/source/PCCEncoder.cpp:6821-6971) with the members it
+ * drives (generateGlobalPatches :7022, unionPatchGenerationAndPacking :7059, packingFirstFrame :7228, performGPAPacking
+ * :7531, updatePatchInformation :7366), as placeSegments runs it after the per-frame packing chain when constrainedPack = 1
+ * and globalPatchAllocation = 1 (the CTC random-access condition).  frames[0..count): the frames of the GOF in order, each
+ * packed (tmc2_encoder_pack_flexible for the first, tmc2_encoder_pack_spatial_consistency for the others).  Patches tracked
+ * across the frames of a sub-context take the block size of the union of their track and one common position; every
+ * frame's list is reordered (tracked patches first, aligned across frames), patch.index becomes the list position,
+ * sizeU0 / sizeV0 / u0 / v0 / patchOrientation, the matches and the block-occupancy pool are rewritten; afterwards
+ * tmc2_frame_get_patches returns the records in list order and tmc2_frame_get_patch_order the identity.
+ * widths / heights (int32[count], may be NULL): the tile size of every frame for tmc2_encoder_canvas_size.          */
+int tmc2_encoder_global_patch_allocation( tmc2_frame** frames, int count, int minimumImageWidth, int minimumImageHeight,
+                                          int32_t* widths, int32_t* heights );
 /* packing order of the frame: order[listPosition] = patch index (the reference reorders the list itself) */
 int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order );
 /* replaces: resizeTileGeometryVideo + resizeGeometryVideo (PCCEncoder.cpp:5593-5632, 5546-5591): common GOF canvas */
@@ -228,6 +240,16 @@ int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );
 /* the placement logic behind tmc2_encoder_pack_spatial_consistency on plain records: patches by index (u0 / v0 /
  * patchOrientation out), their block-occupancy pool, the previous frame's patches in list order */
+/* the allocation behind tmc2_encoder_global_patch_allocation on plain records.  counts[frames]; patches / matches: all
+ * frames back to back, each IN LIST ORDER (in / out); occupancy + occupancyBase[f]: frame f's block-occupancy pool
+ * (patch.occOffset is relative to it); tileWidth / tileHeight: the common tile size after resizeTileGeometryVideo.
+ * Out: the rebuilt pools back to back in occupancyOut (frame f at occupancyOutBase[f]; occupancyOutBase[frames] = bytes
+ * needed -- TMC2_E_INVALID if that exceeds occupancyOutCapacity), the tile size of every frame.                      */
+int tmc2_host_global_patch_allocation( int frames, int32_t* counts, tmc2_patch* patches, const uint8_t* occupancy,
+                                       const int64_t* occupancyBase, int32_t* matches, int tileWidth, int tileHeight,
+                                       int minimumImageWidth, int minimumImageHeight, uint8_t* occupancyOut,
+                                       int64_t occupancyOutCapacity, int64_t* occupancyOutBase, int32_t* widths,
+                                       int32_t* heights );
 int tmc2_host_pack_spatial_consistency( tmc2_patch* patches, int count, const uint8_t* occupancy, const tmc2_patch* previous,
                                         int previousCount, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
                                         int32_t* order, int32_t* matches, int32_t* height );

@@ -317,6 +317,14 @@ int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );
 int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp );
 int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHor, double tileHeightToWidthRatio );
+// S10' second half (gpa.cpp): one frame of the GOF as the global patch allocation sees it
+struct GpaFrameIO {
+  std::vector<tmc2_patch> list;   // patches in list order (occOffset into occ)
+  std::vector<uint8_t>    occ;    // block-occupancy pool
+  std::vector<int32_t>    match;  // per list position: matched list position in the previous frame, -1
+  int                     width = 0, height = 0;  // tile size, pixels
+};
+int globalPatchAllocationCore( std::vector<GpaFrameIO>& frames, int minW, int minH, int occRes );
 int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null

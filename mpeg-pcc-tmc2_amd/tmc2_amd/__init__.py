@@ -5,9 +5,10 @@ tests, bench.py and __graft_entry__.py; it contains no algorithmic code and NO C
 compute call goes to the HIP library, which fails with TMC2_E_NO_DEVICE when no GPU is visible.
 """
 from .lib import (Tmc2Error, Context, Frame, SegmenterParams, Patch, load_library, library_path,
-                  host_kdtree_build, host_orient_normals, host_pack_spatial_consistency, ctc_params, encoder_canvas_size)
+                  host_kdtree_build, host_orient_normals, host_pack_spatial_consistency, host_global_patch_allocation,
+                  encoder_global_patch_allocation, ctc_params, encoder_canvas_size)
 from .synth import synth_cloud, synth_gof
 from .gof import GofEncoder, Sharder
 
 __all__ = ["Tmc2Error", "Context", "Frame", "SegmenterParams", "Patch", "load_library", "library_path",
-           "host_kdtree_build", "host_orient_normals", "host_pack_spatial_consistency", "ctc_params", "encoder_canvas_size", "synth_cloud", "synth_gof", "GofEncoder", "Sharder"]
+           "host_kdtree_build", "host_orient_normals", "host_pack_spatial_consistency", "host_global_patch_allocation", "encoder_global_patch_allocation", "ctc_params", "encoder_canvas_size", "synth_cloud", "synth_gof", "GofEncoder", "Sharder"]

@@ -185,9 +185,10 @@ class GofEncoder:
         return self._dispatch([(i % self.workers, (lambda fr=fr, i=i: fn(fr, i))) for i, fr in enumerate(frames)])
 
     def phase_a(self, frames, sharder=None, weight=None, constrained_pack=False):
-        """constrained_pack: the low-delay condition -- frames after the first are packed against their predecessor (S10',
-        a sequential chain over the GOF, microseconds per frame on the host; single-process only: the chain would cross
-        ranks)."""
+        """constrained_pack: True = the low-delay condition -- frames after the first are packed against their predecessor
+        (S10', a sequential chain over the GOF, microseconds per frame on the host; single-process only: the chain would
+        cross ranks); 2 = the random-access condition -- the same chain followed by the global patch allocation over the
+        GOF (tracked patches share one place in all frames of a sub-context)."""
         sharder = sharder or Sharder()
         if constrained_pack and sharder.world > 1:
             raise ValueError("constrained packing chains the frames of a GOF: run it in one process")
@@ -204,6 +205,12 @@ class GofEncoder:
             heights = [frames[0].encoder_pack_flexible(self.min_w, 2, 1.0)]
             for prev, fr in zip(frames[:-1], frames[1:]):
                 heights.append(fr.encoder_pack_spatial_consistency(prev, self.min_w, 2, 1.0))
+            if constrained_pack == 2:
+                widths, heights = lib.encoder_global_patch_allocation(frames, self.min_w, self.min_h)
+                W, H = lib.encoder_canvas_size([max(int(max(heights)), self.min_h)], max(int(max(widths)), self.min_w),
+                                               self.min_w, self.min_h)
+                self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
+                return W, H
         else:
             heights = self._per_worker(frames, segment_and_pack)
         gof_h = sharder.max_height(heights)

@@ -384,6 +384,45 @@ def host_pack_spatial_consistency(patches, occupancy, previous_list, preset_widt
     return p, order, match, h.value
 
 
+def encoder_global_patch_allocation(frames, min_w=1280, min_h=1280):
+    """S10' second half (random-access condition) over the packed frames of a GOF, in order; returns the tile
+    (widths, heights) per frame.  Afterwards every frame's patch records are in list order."""
+    L = load_library()
+    n = len(frames)
+    handles = (C.c_void_p * n)(*[fr.h for fr in frames])
+    w, h = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    _check(L.tmc2_encoder_global_patch_allocation(handles, n, int(min_w), int(min_h), _ptr(w), _ptr(h)))
+    return w, h
+
+
+def host_global_patch_allocation(lists, pools, matches, tile_w, tile_h, min_w=1280, min_h=1280):
+    """The allocation on plain records: per frame the patches in list order, their block-occupancy pool and matches.
+    Returns per frame (list, pool, matches, tile width, tile height)."""
+    L = load_library()
+    n = len(lists)
+    counts = np.array([len(x) for x in lists], np.int32)
+    patches = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=PATCH_DTYPE) for x in lists]), dtype=PATCH_DTYPE)
+    m = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int32) for x in matches]), dtype=np.int32)
+    pools = [np.ascontiguousarray(x, dtype=np.uint8) for x in pools]
+    base = np.zeros(n, np.int64)
+    base[1:] = np.cumsum([len(x) for x in pools])[:-1]
+    occ = np.ascontiguousarray(np.concatenate(pools)) if n else np.zeros(0, np.uint8)
+    # a patch can grow to the box of its track's union: never beyond the largest box of the GOF in either direction
+    cap = int(len(patches) * max(1, int(patches["sizeU0"].max(initial=1))) * max(1, int(patches["sizeV0"].max(initial=1))))
+    out, out_base = np.zeros(max(cap, 1), np.uint8), np.zeros(n + 1, np.int64)
+    w, h = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    _check(L.tmc2_host_global_patch_allocation(n, _ptr(counts), _ptr(patches), _ptr(occ), _ptr(base), _ptr(m), int(tile_w),
+                                               int(tile_h), int(min_w), int(min_h), _ptr(out), C.c_int64(cap), _ptr(out_base),
+                                               _ptr(w), _ptr(h)))
+    res, at = [], 0
+    for f in range(n):
+        c = int(counts[f])
+        res.append((patches[at:at + c].copy(), out[out_base[f]:out_base[f + 1] if f + 1 < n else out_base[n]].copy(),
+                    m[at:at + c].copy(), int(w[f]), int(h[f])))
+        at += c
+    return res
+
+
 def host_orient_normals(xyz, knn, normals):
     L = load_library()
     xyz = np.ascontiguousarray(xyz, dtype=np.int16)

@@ -237,3 +237,34 @@ def test_gpu_low_delay_packing_matches_golden_fixture():
         check_low_delay_against_fixture(g, a)
     finally:
         enc.close()
+
+
+def test_gpu_random_access_packing_matches_golden_fixture(oracle):
+    """S0-S16 under the random-access packing (S10': the per-frame chain followed by the global patch allocation over the
+    GOF) through the GOF orchestration, against the fixture generated from the unmodified reference; then S17-S22 on
+    those canvases against the oracle (tracked patches carry the enlarged block box of their union into the
+    reconstruction and the attribute images)."""
+    from test_oracle_golden import RANDOM_ACCESS_CANVAS, _random_access_fixture, check_random_access_against_fixture
+    g, frames = _random_access_fixture()
+    enc = T.GofEncoder(0, workers=2, iterations=10, min_w=RANDOM_ACCESS_CANVAS[0], min_h=RANDOM_ACCESS_CANVAS[1])
+    try:
+        frs = enc.upload(frames)
+        W, H = enc.phase_a(frs, constrained_pack=2)
+        a = []
+        for fr in frs:
+            img = fr.get_geometry_images()
+            patches, _, _, occ = fr.get_patches()
+            assert np.array_equal(fr.get_patch_order(), np.arange(len(patches)))      # the lists themselves were reordered
+            assert len(occ) == int((patches["sizeU0"] * patches["sizeV0"]).sum())    # pools rebuilt for the new boxes
+            img.update(patches=patches, width=W, height=H, matches=fr.get_patch_matches())
+            a.append(img)
+        check_random_access_against_fixture(g, a)
+        enc.phase_b(frs)
+        exp_b = oracle.phase_b(frames, a, 4)
+        for fr, eb in zip(frs, exp_b):
+            xyz, rgb, p2p = fr.get_reconstruction()
+            assert np.array_equal(xyz, eb["recon_xyz"]) and np.array_equal(rgb, eb["recon_rgb"])
+            assert np.array_equal(p2p, eb["point_to_pixel"])
+            assert np.array_equal(fr.get_attribute_images(), eb["attribute"])
+    finally:
+        enc.close()

@@ -112,3 +112,50 @@ def test_host_spatial_consistency_packing_matches_oracle(oracle, name, nframes):
             for k in ("u0", "v0", "patchOrientation"):
                 assert np.array_equal(placed[k], ep[k]), (f, k)
         prev_list = placed[order]
+
+
+@pytest.mark.parametrize("case", ["accept", "mixed", "bad_packing", "bad_height", "bad_count", "single"])
+def test_host_global_patch_allocation_matches_oracle(oracle, case):
+    """S10' (random-access condition): the product's global patch allocation on plain records against the oracle's
+    restatement of performDataAdaptiveGPAMethod, on GOFs / canvases that drive it through each of its outcomes."""
+    import oracle_binding as ob
+    from tmc2_amd.synth import two_body_gof
+    from test_oracle_golden import _jumping
+    frames, min_w, min_h = {
+        "accept": (two_body_gof("tiny", 5, seed=1), 256, 128),
+        "mixed": (two_body_gof("tiny", 6), 128, 192),
+        "bad_packing": (two_body_gof("tiny", 6), 192, 160),
+        "bad_height": (two_body_gof("tiny", 6), 160, 160),
+        "bad_count": (_jumping([synth_cloud("tiny", f) for f in range(5)]), 512, 512),
+        "single": ([synth_cloud("tiny", 0)], 256, 256),
+    }[case]
+    sp = ob.seg_params(10, 11, oracle.weight_normal(frames[0][0], 11, 0.6))
+    per = []
+    for xyz, rgb in frames:
+        seg = oracle.segment(xyz, rgb, sp)
+        if per:
+            _, pplaced, porder, _ = per[-1]
+            placed, order, match, h = oracle.pack_spatial_consistency(seg["patches"], seg["occupancy"], pplaced[porder], min_w)
+            seg["matches"] = match
+        else:
+            placed, order, h = oracle.pack_flexible(seg["patches"], seg["occupancy"], min_w)
+            seg["matches"] = np.full(len(order), -1, np.int32)
+        per.append((seg, placed, order, h))
+    exp = oracle.global_patch_allocation(per, min_w, min_h)
+    widths = [max(min_w // 16, int((placed["sizeU0"] + 1).max())) * 16 for _, placed, _, _ in per]
+    tw, th = max(widths + [min_w]), max([h for _, _, _, h in per] + [min_h])
+    got = T.host_global_patch_allocation([placed[order] for _, placed, order, _ in per], [seg["occupancy"] for seg, _, _, _ in per],
+                                         [seg["matches"] for seg, _, _, _ in per], tw, th, min_w, min_h)
+    assert len(got) == len(exp)
+    grew = False
+    for f, ((gl, go, gm, gw, gh), (el, eo, em, ew, eh)) in enumerate(zip(got, exp)):
+        assert (gw, gh) == (ew, eh), f
+        assert np.array_equal(gm, em), f
+        for n in el.dtype.names:
+            assert np.array_equal(gl[n], el[n]), (f, n)
+        assert np.array_equal(go, eo[:len(go)]) and len(go) == int((el["sizeU0"] * el["sizeV0"]).sum()), f
+        grew |= bool((np.sort(gl["sizeU0"] * gl["sizeV0"]) != np.sort(per[f][1]["sizeU0"] * per[f][1]["sizeV0"])).any())
+    if case in ("accept", "mixed"):
+        assert any((gm >= 0).any() for _, _, gm, _, _ in got)             # some sub-context spans several frames
+    if case == "accept":
+        assert grew                                                        # tracked patches took their union's box

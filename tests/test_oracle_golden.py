@@ -223,6 +223,10 @@ def test_oracle_random_access_packing_matches_reference_live(oracle, reference, 
                 assert np.array_equal(x["patches"][n], y["patches"][n]), n
         for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
             assert np.array_equal(x[k], y[k]), k
+    if case == "accept":   # S17-S22 on canvases whose tracked patches carry the enlarged block box of their union
+        for x, y in zip(reference.phase_b(frames, ra, 4), oracle.phase_b(frames, oa, 4)):
+            for k in x:
+                assert np.array_equal(x[k], y[k]), k
 
 
 def _sparse_target_case(seed=0):
