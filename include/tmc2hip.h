@@ -224,6 +224,32 @@ int     tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo,
 int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry );
 int tmc2_frame_device_attribute( tmc2_frame* f, void** attribute );
 
+/* ---- post-reconstruction tail (PCCEncoder::encode :571-719, PCCDecoder::decode :330-470) -------------------- */
+/* All of these work on the reconstruction left by tmc2_encoder_generate_attribute_images (PCCCodec::generatePointCloud on
+ * the resident, or decoded, occupancy / geometry canvases).  CTC settings: two maps in one stream, lossy attributes,
+ * flagGeometrySmoothing 1, gridSmoothing 1, attrTransferFilterType 1, flagColorSmoothing 0.
+ * replaces: PCCCodec::identifyBoundaryPoints (PccLibCommon/source/PCCCodec.cpp:268-327), as generatePointCloud runs it
+ * over all points when flagGeometrySmoothing is set (:955-976): PCCPointSet3::boundaryPointTypes_ becomes 0 / 1.     */
+int tmc2_codec_identify_boundary_points( tmc2_frame* f );
+/* replaces: PCCCodec::colorPointCloud (PCCCodec.cpp:1319-1460), branch "f < mapCount": every point takes the 16-bit colour
+ * of its pixel in the decoded attribute frame of its map.  attribute: uint16 [2 maps][3 channels][H][W] (host memory),
+ * i.e. context.getVideoAttributesMultiple()[0] frames 2f and 2f+1 after decoding + colour conversion.              */
+int tmc2_codec_color_point_cloud( tmc2_frame* f, const uint16_t* attribute );
+/* replaces: PCCCodec::smoothPointCloudPostprocess (PCCCodec.cpp:54-148, gridSmoothing branch: addGridCentroid :982,
+ * gridFiltering :1002, smoothPointCloudGrid :1067).  Boundary points that the trilinear blend of the cell centroids
+ * pulls further than the threshold are moved there; their boundary type becomes 3.  Runs
+ * tmc2_codec_identify_boundary_points first if that has not happened.                                                */
+int tmc2_codec_smooth_point_cloud_postprocess( tmc2_frame* f, int gridSize, double thresholdSmoothing );
+/* replaces: PCCPointSet3::transferColors16bitBP (PccLibCommon/source/PCCPointSet.cpp:1126-1470) with filterType 1 and the
+ * arguments of PCCEncoder.cpp:657-672 / PCCDecoder.cpp:416-431: source = the cloud before smoothing with its 16-bit
+ * colours, target = the smoothed cloud; only the moved points (boundary type 3) are recoloured.                     */
+int tmc2_codec_transfer_colors_16bit_bp( tmc2_frame* f );
+/* replaces: PCCPointSet3::convertYUV16ToRGB8 (PccLibCommon/include/PCCPointSet.h:133-166) */
+int tmc2_codec_convert_yuv16_to_rgb8( tmc2_frame* f );
+/* the finished cloud (any pointer may be NULL): positions int16[M][3] (smoothed once the smoothing ran), 16-bit colours
+ * uint16[M][3], 8-bit colours uint8[M][3], boundary types uint16[M]; M = tmc2_frame_recon_count                     */
+int tmc2_frame_get_post_reconstruction( tmc2_frame* f, int16_t* xyz, uint16_t* colors16, uint8_t* rgb, uint16_t* boundaryType );
+
 /* ---- PCCMetrics ------------------------------------------------------------------------------------ */
 /* replaces: PCCMetrics::compute for one frame (PccLibMetrics/source/PCCMetrics.cpp:324-375) with the defaults of
  * PCCMetricsParameters (dropDuplicates 2, neighborsProc 1, no Hausdorff): duplicate removal, normal copy / scaling,

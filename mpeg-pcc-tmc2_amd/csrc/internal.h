@@ -252,6 +252,12 @@ struct tmc2_frame {
   tmc2::DevBuf<uint32_t>  d_pointToPixel;       // x | y << 12 | layer << 24 | hasD1 << 25
   tmc2::DevBuf<uint8_t>   d_reconRgb;           // [M][4]
   tmc2::DevBuf<uint8_t>   d_attr;               // [2 maps][3 channels][H][W]
+  // post-reconstruction tail (post_reconstruct.hip): per reconstructed point
+  tmc2::DevBuf<uint8_t>   d_boundaryType;       // 0 inner, 1 boundary, 3 moved by the geometry smoothing
+  tmc2::DevBuf<uint64_t>  d_colors16;           // 16-bit colours as (c0, c1, c2, 0) packed in 8 bytes
+  tmc2::DevBuf<tmc2::Pt>  d_reconSmoothed;      // positions after the geometry smoothing
+  tmc2::DevBuf<uint8_t>   d_rgbPost;            // [M][4] 8-bit RGB of the finished cloud
+  bool                    haveBoundaryTypes = false, haveColors16 = false, haveSmoothed = false, haveRgbPost = false;
   tmc2::KdTreeHost        reconTree;
   tmc2::DevBuf<tmc2::Pt>  d_reconTreePts;
   tmc2::DevBuf<uint32_t>  d_reconPerm;

@@ -222,6 +222,11 @@ class GofEncoder:
         """S17-S22 on the resident (decoded == generated) occupancy / geometry canvases."""
         self._per_worker(frames, lambda fr: fr.encoder_generate_attribute_images())
 
+    def phase_c(self, frames, decoded_attribute, grid_size=8, threshold=64.0):
+        """The post-reconstruction tail of every frame (boundary points, 16-bit colours from the decoded attribute frames,
+        grid geometry smoothing, colour transfer onto the moved points, YUV -> RGB); decoded_attribute[i]: uint16 [2][3][H][W]."""
+        self.per_frame(frames, lambda fr, i: fr.codec_post_reconstruct(decoded_attribute[i], grid_size, threshold))
+
     def stage_ms(self):
         tot = {}
         for c in self.ctxs:

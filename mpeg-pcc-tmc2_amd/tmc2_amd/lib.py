@@ -340,6 +340,45 @@ class Frame:
         _check(self.L.tmc2_frame_get_reconstruction(self.h, _ptr(xyz), _ptr(rgb), _ptr(p2p)))
         return xyz, rgb, p2p
 
+    # post-reconstruction tail (PCCEncoder::encode :571-719 / PCCDecoder::decode :330-470)
+    def codec_identify_boundary_points(self):
+        _check(self.L.tmc2_codec_identify_boundary_points(self.h))
+
+    def codec_color_point_cloud(self, attribute16):
+        """attribute16: the decoded attribute frames of this frame, uint16 [2][3][H][W]."""
+        W, H, _ = self._canvas
+        att = np.ascontiguousarray(attribute16, dtype=np.uint16)
+        if att.shape != (2, 3, H, W):
+            raise ValueError("decoded attribute frames must be uint16 [2][3][%d][%d]" % (H, W))
+        _check(self.L.tmc2_codec_color_point_cloud(self.h, _ptr(att)))
+
+    def codec_smooth_point_cloud_postprocess(self, grid_size=8, threshold=64.0):
+        _check(self.L.tmc2_codec_smooth_point_cloud_postprocess(self.h, int(grid_size), C.c_double(threshold)))
+
+    def codec_transfer_colors_16bit_bp(self):
+        _check(self.L.tmc2_codec_transfer_colors_16bit_bp(self.h))
+
+    def codec_convert_yuv16_to_rgb8(self):
+        _check(self.L.tmc2_codec_convert_yuv16_to_rgb8(self.h))
+
+    def codec_post_reconstruct(self, attribute16, grid_size=8, threshold=64.0):
+        """The whole tail in the reference's order: boundary points, 16-bit colours from the decoded attribute frames, grid
+        geometry smoothing, colour transfer onto the moved points, YUV -> RGB."""
+        self.codec_identify_boundary_points()
+        self.codec_color_point_cloud(attribute16)
+        self.codec_smooth_point_cloud_postprocess(grid_size, threshold)
+        self.codec_transfer_colors_16bit_bp()
+        self.codec_convert_yuv16_to_rgb8()
+
+    def get_post_reconstruction(self, xyz=True, colors16=True, rgb=True, boundary=True):
+        self.L.tmc2_frame_recon_count.restype = C.c_int64
+        M = self.L.tmc2_frame_recon_count(self.h)
+        out = dict(xyz=np.zeros((M, 3), np.int16) if xyz else None, colors16=np.zeros((M, 3), np.uint16) if colors16 else None,
+                   rgb=np.zeros((M, 3), np.uint8) if rgb else None, boundary=np.zeros(M, np.uint16) if boundary else None)
+        _check(self.L.tmc2_frame_get_post_reconstruction(self.h, *[None if out[k] is None else _ptr(out[k])
+                                                                    for k in ("xyz", "colors16", "rgb", "boundary")]))
+        return {k: v for k, v in out.items() if v is not None}
+
     def get_attribute_images(self, out=None):
         W, H, _ = self._canvas
         if out is None:

@@ -151,3 +151,18 @@ def two_body_gof(name="tiny", frames=5, seed=0):
         xyz = np.concatenate([a, (b + (at - lo)).astype(a.dtype)])
         out.append((np.ascontiguousarray(xyz), np.ascontiguousarray(np.concatenate([ca, cb]))))
     return out
+
+
+def synth_decoded_attribute(attribute):
+    """Stand-in for the attribute video codec + colour conversion: the 8-bit RGB attribute canvases ([2][3][H][W]) as the
+    16-bit YUV 4:4:4 frames a decoder hands to the reconstruction (BT.709, full range, chroma centred at 32768), with a
+    small deterministic coding error on top."""
+    a = np.asarray(attribute, dtype=np.float64) / 255.0
+    r, g, b = a[:, 0], a[:, 1], a[:, 2]
+    y = 0.2126 * r + 0.7152 * g + 0.0722 * b
+    u = (b - y) / 1.8556
+    v = (r - y) / 1.5748
+    H, W = y.shape[-2:]
+    ripple = ((np.arange(H)[:, None] * 7 + np.arange(W)[None, :] * 13) % 11 - 5) * 48.0
+    out = np.stack([y * 65535.0 + ripple, u * 65535.0 + 32768.0 - ripple, v * 65535.0 + 32768.0 + ripple], 1)
+    return np.clip(np.rint(out), 0, 65535).astype(np.uint16)

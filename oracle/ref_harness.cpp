@@ -656,6 +656,96 @@ int ref_gof_get_attribute_images( int frame, uint8_t* out ) {
   return 0;
 }
 
+// ---- post-reconstruction tail of PCCEncoder::encode (:571-719; the decoder runs the same members, PCCDecoder.cpp:330-470) ----
+// boundary point types as generatePointCloud left them (identifyBoundaryPoints, PCCCodec.cpp:268-327)
+int ref_gof_get_boundary_types( int frame, uint16_t* out ) {
+  auto& rec = g_gof->reconstructs[size_t( frame )];
+  for ( size_t i = 0; i < rec.getPointCount(); ++i ) out[i] = rec.getBoundaryPointType( i );
+  return 0;
+}
+int ref_gof_get_partition( int frame, uint32_t* out ) {
+  auto& part = g_gof->partitions[size_t( frame )];
+  std::copy( part.begin(), part.end(), out );
+  return int( part.size() );
+}
+// stand-in for the attribute video codec + colour conversion: the "decoded" attribute frames of a point-cloud frame,
+// u16 [2 maps][3 channels][H][W]
+int ref_gof_set_decoded_attribute( int frame, const uint16_t* planes ) {
+  auto&  va = g_gof->context.getVideoAttributesMultiple()[0];
+  size_t o  = 0;
+  for ( size_t m = 0; m < 2; ++m ) {
+    auto& img = va.getFrame( 2 * size_t( frame ) + m );
+    for ( size_t c = 0; c < 3; ++c )
+      for ( auto& v : img.getChannel( c ) ) v = planes[o++];
+  }
+  return 0;
+}
+// colorPointCloud for every frame, then the post-processing loop (grid geometry smoothing, transferColors16bitBP with
+// attrTransferFilterType 1, convertYUV16ToRGB8), in the order and with the arguments of encode() :571-719
+int ref_gof_phase_c() {
+  Quiet quiet;
+  Gof&  G = *g_gof;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );
+  PCCEncoder& E       = G.encoder;
+  PCCContext& context = G.context;
+  GeneratePointCloudParameters gpcParams;
+  E.setGeneratePointCloudParameters( gpcParams, context );
+  std::vector<bool> absoluteT1List( E.params_.mapCountMinus1_ + 1, E.params_.absoluteT1_ );
+  for ( size_t frameIdx = 0; frameIdx < context.size(); frameIdx++ ) {
+    G.reconstructs[frameIdx].addColors();
+    G.reconstructs[frameIdx].addColors16bit();
+    size_t accTilePointCount = 0;
+    for ( size_t tileIdx = 0; tileIdx < context[frameIdx].getNumTilesInAtlasFrame(); tileIdx++ ) {
+      auto& tile        = context[frameIdx].getTile( tileIdx );
+      accTilePointCount = E.colorPointCloud( G.reconstructs[frameIdx], context, tile, absoluteT1List, 0, 1, accTilePointCount, gpcParams );
+    }
+  }
+  const bool isAttributes444 = static_cast<int>( E.params_.rawPointsPatch_ ) == 1;
+  for ( size_t frameIdx = 0; frameIdx < G.sources.getFrameCount(); frameIdx++ ) {
+    GeneratePointCloudParameters ppSEIParams;
+    E.setPostProcessingSeiParameters( ppSEIParams, context );
+    auto& reconstruct = G.reconstructs[frameIdx];
+    auto& partition   = G.partitions[frameIdx];
+    if ( E.params_.applyGeoSmoothingType_ != 0 && ppSEIParams.flagGeometrySmoothing_ ) {
+      PCCPointSet3 tempFrameBuffer = reconstruct;
+      if ( ppSEIParams.gridSmoothing_ ) E.smoothPointCloudPostprocess( reconstruct, E.params_.colorTransform_, ppSEIParams, partition );
+      if ( !ppSEIParams.pbfEnableFlag_ && E.params_.attrTransferFilterType_ == 1 )
+        tempFrameBuffer.transferColors16bitBP( reconstruct, E.params_.attrTransferFilterType_, int32_t( 0 ), isAttributes444, 8, 1,
+                                               true, true, true, false, 4, 4, 1000, 1000, 1000 * 256, 1000 * 256 );
+      else if ( !ppSEIParams.pbfEnableFlag_ )
+        return -2;  // the other transfer filters are not part of the CTC path
+    }
+    if ( E.params_.applyAttrSmoothingType_ != 0 && ppSEIParams.flagColorSmoothing_ ) return -3;  // off under the CTC
+    if ( !isAttributes444 )
+      reconstruct.convertYUV16ToRGB8();
+    else
+      reconstruct.copyRGB16ToRGB8();
+  }
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
+}
+// after phase_c: positions int16[M][3], 16-bit colours u16[M][3], 8-bit colours u8[M][3], boundary types u16[M]
+int ref_gof_get_post( int frame, int16_t* xyz, uint16_t* c16, uint8_t* rgb, uint16_t* btype ) {
+  auto& rec = g_gof->reconstructs[size_t( frame )];
+  for ( size_t i = 0; i < rec.getPointCount(); ++i ) {
+    const auto c = rec.getColor( i );
+    const auto d = rec.getColor16bit( i );
+    for ( int k = 0; k < 3; ++k ) {
+      xyz[3 * i + k] = rec[i][k];
+      c16[3 * i + k] = d[k];
+      rgb[3 * i + k] = c[k];
+    }
+    btype[i] = rec.getBoundaryPointType( i );
+  }
+  return 0;
+}
+
 // S18 alone: PCCPointSet3::transferColors (PCCPointSet.cpp:807-1124) with the arguments PCCEncoder::generateAttributeVideo
 // passes under the CTC (PCCEncoder.cpp:6679-6697)
 int ref_transfer_colors( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const int16_t* tgtXyz, size_t m, uint8_t* tgtRgb ) {

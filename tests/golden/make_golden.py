@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "mpeg-pcc-tmc2_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_binding as ob  # noqa: E402
-from tmc2_amd.synth import synth_cloud, two_body_gof  # noqa: E402
+from tmc2_amd.synth import synth_cloud, synth_decoded_attribute, two_body_gof  # noqa: E402
 
 
 def digest(a):
@@ -115,8 +115,33 @@ def gof_random_access():
     print("gof_twobody6_random_access", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
+def gof_post_reconstruction():
+    """The post-reconstruction tail (encode() :571-719) on the 2-frame GOF of gof_tiny2.npz, through the reference's own
+    colorPointCloud / smoothPointCloudPostprocess / transferColors16bitBP / convertYUV16ToRGB8.  The "decoded" attribute
+    frames are synth_decoded_attribute() of the generated attribute canvases (the generator is part of the repo)."""
+    ref = ob.Reference()
+    frames = [synth_cloud("tiny", f) for f in range(2)]
+    a = ref.phase_a(frames, 10, 11, 4)
+    b = ref.phase_b(frames, a, 4)
+    dec = [synth_decoded_attribute(x["attribute"]) for x in b]
+    c = ref.phase_c(b, dec)
+    out = {"input_md5": np.array("".join(digest(x) + digest(col) for x, col in frames)),
+           "decoded_md5": np.array("".join(digest(d) for d in dec))}
+    for i, pc in enumerate(c):
+        out["f%d_counts" % i] = np.array([len(pc["xyz"]), int((pc["boundary_before"] == 1).sum()), int((pc["boundary"] == 3).sum())])
+        out["f%d_boundary_before" % i] = np.packbits(pc["boundary_before"].astype(np.uint8))
+        out["f%d_moved" % i] = np.flatnonzero(pc["boundary"] == 3).astype(np.uint32)
+        out["f%d_moved_xyz" % i] = pc["xyz"][pc["boundary"] == 3]
+        out["f%d_moved_colors16" % i] = pc["colors16"][pc["boundary"] == 3]
+        for k in ("xyz", "colors16", "rgb", "boundary"):
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pc[k]))
+    np.savez_compressed(os.path.join(HERE, "gof_tiny2_post.npz"), **out)
+    print("gof_tiny2_post", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
     gof()
     gof_low_delay()
     gof_random_access()
+    gof_post_reconstruction()

@@ -329,6 +329,56 @@ class Oracle:
         return out
 
 
+    # ---- post-reconstruction tail ----
+    def identify_boundary_points(self, p2p, occ_video, W, H, occ_precision):
+        p2p = np.ascontiguousarray(p2p, dtype=np.uint32)
+        ov = np.ascontiguousarray(occ_video, dtype=np.uint8)
+        bt = np.zeros(len(p2p), np.uint16)
+        self.L.orc_identify_boundary_points(_p(p2p), C.c_int64(len(p2p)), _p(ov), int(W), int(H), int(occ_precision), _p(bt))
+        return bt
+
+    def color_point_cloud(self, p2p, attribute16):
+        p2p = np.ascontiguousarray(p2p, dtype=np.uint32)
+        att = np.ascontiguousarray(attribute16, dtype=np.uint16)
+        out = np.zeros((len(p2p), 3), np.uint16)
+        self.L.orc_color_point_cloud(_p(p2p), C.c_int64(len(p2p)), _p(att), int(att.shape[-1]), int(att.shape[-2]), _p(out))
+        return out
+
+    def smooth_point_cloud_grid(self, xyz, btype, partition, grid_size=8, threshold=64.0):
+        xyz = np.array(_i16(xyz), copy=True)
+        bt = np.array(btype, dtype=np.uint16, copy=True)
+        part = np.ascontiguousarray(partition, dtype=np.uint32)
+        self.L.orc_smooth_point_cloud_grid(_p(xyz), _p(bt), _p(part), C.c_int64(len(xyz)), int(grid_size), C.c_double(threshold))
+        return xyz, bt
+
+    def transfer_colors16_bp(self, src_xyz, src_c16, tgt_xyz, tgt_btype):
+        src_xyz, tgt_xyz = _i16(src_xyz), _i16(tgt_xyz)
+        src = np.ascontiguousarray(src_c16, dtype=np.uint16)
+        bt = np.ascontiguousarray(tgt_btype, dtype=np.uint16)
+        out = np.array(src, copy=True)
+        self.L.orc_transfer_colors16_bp(_p(src_xyz), _p(src), _p(tgt_xyz), _p(bt), C.c_int64(len(tgt_xyz)), _p(out))
+        return out
+
+    def convert_yuv16_to_rgb8(self, c16):
+        c16 = np.ascontiguousarray(c16, dtype=np.uint16)
+        out = np.zeros((len(c16), 3), np.uint8)
+        self.L.orc_convert_yuv16_to_rgb8(_p(c16), C.c_int64(len(c16)), _p(out))
+        return out
+
+    def phase_c(self, phase_a_out, phase_b_out, decoded_attribute, occ_precision=4):
+        """Post-reconstruction tail on top of phase_a() / phase_b() output; mirrors Reference.phase_c."""
+        out = []
+        for a, b, att in zip(phase_a_out, phase_b_out, decoded_attribute):
+            p2p = b["point_to_pixel"]
+            bt0 = self.identify_boundary_points(p2p, a["occ_video"], a["width"], a["height"], occ_precision)
+            part = (a["block_to_patch"][p2p[:, 1] // 16, p2p[:, 0] // 16] - 1).astype(np.uint32)
+            c16 = self.color_point_cloud(p2p, att)
+            xyz, bt = self.smooth_point_cloud_grid(b["recon_xyz"], bt0, part)
+            c16 = self.transfer_colors16_bp(b["recon_xyz"], c16, xyz, bt)
+            out.append(dict(boundary_before=bt0, partition=part, xyz=xyz, colors16=c16, rgb=self.convert_yuv16_to_rgb8(c16), boundary=bt))
+        return out
+
+
 class Reference:
     def __init__(self):
         self.L = C.CDLL(REF_PATH)
@@ -372,6 +422,29 @@ class Reference:
             att = np.zeros((2, 3, img["height"], img["width"]), np.uint8)
             assert L.ref_gof_get_attribute_images(i, _p(att)) == 0
             out.append(dict(recon_xyz=rec, recon_rgb=col, point_to_pixel=p2p, attribute=att))
+        return out
+
+    def phase_c(self, phase_b_out, decoded_attribute):
+        """Post-reconstruction tail (must follow phase_b() on the same GOF): colorPointCloud from the given "decoded"
+        attribute frames (u16 [2][3][H][W] per frame), grid geometry smoothing, transferColors16bitBP, convertYUV16ToRGB8."""
+        L = self.L
+        pre = []
+        for i, b in enumerate(phase_b_out):
+            M = len(b["recon_xyz"])
+            bt, part = np.zeros(M, np.uint16), np.zeros(M, np.uint32)
+            L.ref_gof_get_boundary_types(i, _p(bt))
+            assert L.ref_gof_get_partition(i, _p(part)) == M
+            att = np.ascontiguousarray(decoded_attribute[i], dtype=np.uint16)
+            L.ref_gof_set_decoded_attribute(i, _p(att))
+            pre.append((bt, part))
+        rc = L.ref_gof_phase_c()
+        assert rc == 0, rc
+        out = []
+        for i, b in enumerate(phase_b_out):
+            M = len(b["recon_xyz"])
+            xyz, c16, rgb, bt = np.zeros((M, 3), np.int16), np.zeros((M, 3), np.uint16), np.zeros((M, 3), np.uint8), np.zeros(M, np.uint16)
+            L.ref_gof_get_post(i, _p(xyz), _p(c16), _p(rgb), _p(bt))
+            out.append(dict(boundary_before=pre[i][0], partition=pre[i][1], xyz=xyz, colors16=c16, rgb=rgb, boundary=bt))
         return out
 
     def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False):

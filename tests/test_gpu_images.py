@@ -268,3 +268,53 @@ def test_gpu_random_access_packing_matches_golden_fixture(oracle):
             assert np.array_equal(fr.get_attribute_images(), eb["attribute"])
     finally:
         enc.close()
+
+
+def test_gpu_post_reconstruction_matches_golden_fixture(oracle):
+    """The post-reconstruction tail (boundary points, colorPointCloud, grid geometry smoothing, transferColors16bitBP,
+    convertYUV16ToRGB8) through the GOF orchestration, against the fixture generated from the unmodified reference."""
+    from test_oracle_golden import _post_fixture, check_post_reconstruction_against_fixture
+    g, frames, _, _, dec = _post_fixture(oracle)
+    enc = T.GofEncoder(0, workers=2, iterations=10)
+    try:
+        frs = enc.upload(frames)
+        enc.phase_a(frs)
+        enc.phase_b(frs)
+        for fr, d in zip(frs, dec):   # the canvases the stand-in decoder started from are the product's own
+            assert np.array_equal(T.synth_decoded_attribute(fr.get_attribute_images()), d)
+        before = []
+        for fr in frs:
+            fr.codec_identify_boundary_points()
+            before.append(fr.get_post_reconstruction(xyz=False, colors16=False, rgb=False)["boundary"])
+        enc.phase_c(frs, dec)
+        c = [dict(fr.get_post_reconstruction(), boundary_before=bb) for fr, bb in zip(frs, before)]
+        check_post_reconstruction_against_fixture(g, c)
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("name,prec", [("small", 4), ("small", 2), ("medium", 4)])
+def test_gpu_post_reconstruction_matches_oracle(gpu_ctx, oracle, name, prec):
+    xyz, rgb = synth_cloud(name, 1)
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.segmenter_compute(T.ctc_params(10, 11, fr.weight_normal(11, 0.6)))
+    h = fr.encoder_pack_flexible(1280, 2, 1.0)
+    W, H = T.encoder_canvas_size([h], 1280, 1280, 1280)
+    fr.encoder_generate_geometry_images(W, H, prec)
+    b = gpu_phase_b([fr])[0]
+    img = fr.get_geometry_images()
+    img.update(width=W, height=H)
+    dec = T.synth_decoded_attribute(b["attribute"])
+    exp = oracle.phase_c([img], [b], [dec], prec)[0]
+    fr.codec_identify_boundary_points()
+    assert np.array_equal(fr.get_post_reconstruction(xyz=False, colors16=False, rgb=False)["boundary"], exp["boundary_before"])
+    fr.codec_post_reconstruct(dec)
+    got = fr.get_post_reconstruction()
+    assert (got["boundary"] == 3).sum() > 100
+    for k in ("boundary", "xyz", "colors16", "rgb"):
+        assert np.array_equal(got[k], exp[k]), k
+    # idempotence: the tail starts from the reconstruction, not from its own output
+    fr.codec_post_reconstruct(dec)
+    again = fr.get_post_reconstruction()
+    for k in got:
+        assert np.array_equal(got[k], again[k]), k
