@@ -40,6 +40,7 @@ def parse():
                     help="where the k-d trees are built (auto: host when >= 8 frames are in flight per GPU, else device)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
+    ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
     return ap.parse_args()
@@ -226,6 +227,34 @@ def main():
     t0 = time.time()
     enc.ctxs[0].metrics_compute(clouds[0][0], clouds[0][1], rx, rc, frames[0].get_normals())
     out["metric_ms_per_frame"] = round(1000.0 * (time.time() - t0), 1)
+    # the post-reconstruction tail is outside the metric as well: one frame with the GPU to
+    # itself (stage times), then the whole GOF through the worker threads
+    if world == 1 and a.tail:
+        try:
+            dec0 = T.synth_decoded_attribute(frames[0].get_attribute_images())
+            enc.stage_reset()
+            frames[0].codec_post_reconstruct(dec0)            # warm-up (allocations)
+            enc.stage_reset()
+            t0 = time.time()
+            frames[0].codec_post_reconstruct(dec0)
+            solo = 1000.0 * (time.time() - t0)
+            tail_ms = enc.stage_ms()
+            post = frames[0].get_post_reconstruction(xyz=False, colors16=False, rgb=False)
+            W, H = step()                                     # (the one-frame run above left frame 0 on its own canvas)
+            bufs = host_out(W, H)
+            decs = [b[1].astype(np.uint16) << 8 for b in bufs]   # cheap stand-in frames for the throughput leg
+            enc.phase_c(frames, decs)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            enc.phase_c(frames, decs)
+            torch.cuda.synchronize()
+            gof = time.time() - t0
+            out["tail"] = {"ms_per_frame_alone": round(solo, 2), "gof_frames_per_s": round(len(frames) / gof, 2),
+                           "reconstructed_points": int(len(post["boundary"])), "boundary_points": int((post["boundary"] != 0).sum()),
+                           "moved_points": int((post["boundary"] == 3).sum()),
+                           "stage_ms_alone": {k: round(v, 3) for k, v in sorted(tail_ms.items()) if v > 0}}
+        except Exception as e:                                 # never lose the metric line over the side measurement
+            out["tail"] = {"error": repr(e)}
     if a.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations)
     print(json.dumps(out))
