@@ -224,6 +224,25 @@ int     tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo,
 int tmc2_frame_device_images( tmc2_frame* f, void** occupancy, void** occVideo, void** blockToPatch, void** geometry );
 int tmc2_frame_device_attribute( tmc2_frame* f, void** attribute );
 
+/* ---- colour-space conversion around the attribute video codec (PCCVideoEncoder::compress) -------------------------- */
+/* replaces: PCCInternalColorConverter<T>::convert( "RGB444ToYUV420_8_<f>" ) (PccLibColorConverter/source/
+ * PCCInternalColorConverter.cpp:355-378 -> convertRGB44ToYUV420 :406-424), which PCCVideoEncoder::compress
+ * (PccLibEncoder/source/PCCVideoEncoder.cpp:353) runs on the attribute video before the codec when no external converter is
+ * configured.  rgb: uint8 [3][H][W] (R, G, B planes); yuv420: one I420 frame, Y [H][W] then U, V [H/2][W/2].  Only the
+ * reference's default filter (4 = DF_GS) is built; others return TMC2_E_UNSUPPORTED.                                 */
+int tmc2_color_convert_rgb444_to_yuv420( tmc2_ctx* ctx, const uint8_t* rgb, int width, int height, int downsamplingFilter,
+                                         uint8_t* yuv420 );
+/* replaces: convert( "YUV420ToYUV444_8_<f>" ) (-> convertYUV420ToYUV444 :462-482) on the decoded video (PCCVideoEncoder.cpp:413;
+ * the decoder does the same): 8-bit I420 frame -> uint16 [3][H][W], 16-bit 4:4:4.  Only filter 0 (UF_F0, the default). */
+int tmc2_color_convert_yuv420_to_yuv444( tmc2_ctx* ctx, const uint8_t* yuv420, int width, int height, int upsamplingFilter,
+                                         uint16_t* yuv444 );
+/* the same two steps on a frame, without moving the source through the host: the resident attribute canvases as the two
+ * I420 frames the attribute video encoder reads (yuv420: [2 maps] x I420 frame), and the two decoded I420 frames as the
+ * 16-bit 4:4:4 planes that tmc2_codec_color_point_cloud( f, NULL ) then reads on the device                          */
+int tmc2_encoder_attribute_to_yuv420( tmc2_frame* f, int downsamplingFilter, uint8_t* yuv420 );
+int tmc2_codec_set_decoded_attribute_yuv420( tmc2_frame* f, const uint8_t* yuv420, int upsamplingFilter );
+int tmc2_frame_get_decoded_attribute( tmc2_frame* f, uint16_t* planes ); /* uint16 [2][3][H][W] */
+
 /* ---- post-reconstruction tail (PCCEncoder::encode :571-719, PCCDecoder::decode :330-470) -------------------- */
 /* All of these work on the reconstruction left by tmc2_encoder_generate_attribute_images (PCCCodec::generatePointCloud on
  * the resident, or decoded, occupancy / geometry canvases).  CTC settings: two maps in one stream, lossy attributes,
@@ -235,6 +254,7 @@ int tmc2_codec_identify_boundary_points( tmc2_frame* f );
  * of its pixel in the decoded attribute frame of its map.  attribute: uint16 [2 maps][3 channels][H][W] (host memory),
  * i.e. context.getVideoAttributesMultiple()[0] frames 2f and 2f+1 after decoding + colour conversion.              */
 int tmc2_codec_color_point_cloud( tmc2_frame* f, const uint16_t* attribute );
+/* attribute == NULL above: the frames tmc2_codec_set_decoded_attribute_yuv420 left on the device are used.             */
 /* replaces: PCCCodec::smoothPointCloudPostprocess (PCCCodec.cpp:54-148, gridSmoothing branch: addGridCentroid :982,
  * gridFiltering :1002, smoothPointCloudGrid :1067).  Boundary points that the trilinear blend of the cell centroids
  * pulls further than the threshold are moved there; their boundary type becomes 3.  Runs

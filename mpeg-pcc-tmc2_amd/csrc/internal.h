@@ -257,6 +257,8 @@ struct tmc2_frame {
   tmc2::DevBuf<uint64_t>  d_colors16;           // 16-bit colours as (c0, c1, c2, 0) packed in 8 bytes
   tmc2::DevBuf<tmc2::Pt>  d_reconSmoothed;      // positions after the geometry smoothing
   tmc2::DevBuf<uint8_t>   d_rgbPost;            // [M][4] 8-bit RGB of the finished cloud
+  tmc2::DevBuf<uint16_t>  d_attr16;             // decoded attribute frames, 16-bit 4:4:4: [2 maps][3 channels][H][W]
+  bool                    haveAttr16 = false;
   bool                    haveBoundaryTypes = false, haveColors16 = false, haveSmoothed = false, haveRgbPost = false;
   tmc2::KdTreeHost        reconTree;
   tmc2::DevBuf<tmc2::Pt>  d_reconTreePts;
@@ -332,6 +334,8 @@ struct GpaFrameIO {
 };
 int globalPatchAllocationCore( std::vector<GpaFrameIO>& frames, int minW, int minH, int occRes );
 int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision );
+int rgb444ToYuv420Device( tmc2_ctx* ctx, const uint8_t* d_rgb, int W, int H, int filter, uint8_t* d_yuv );
+int yuv420ToYuv444Device( tmc2_ctx* ctx, const uint8_t* d_yuv, int W, int H, int filter, uint16_t* d_out );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)

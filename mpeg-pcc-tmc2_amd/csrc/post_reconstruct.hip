@@ -369,20 +369,26 @@ int identifyBoundaryPoints( tmc2_frame* f ) {
   return TMC2_OK;
 }
 
-// attribute: host, u16 [2 maps][3 channels][H][W] -- the decoded attribute frames of this point-cloud frame
+// attribute: host, u16 [2 maps][3 channels][H][W] -- the decoded attribute frames of this point-cloud frame; NULL: the
+// frames already on the device (tmc2_codec_set_decoded_attribute_yuv420)
 int colorPointCloud( tmc2_frame* f, const uint16_t* attribute ) {
   TMC2_TRY( needReconstruction( f, "colorPointCloud" ) );
   tmc2_ctx*      ctx  = f->ctx;
   hipStream_t    s    = ctx->stream;
   const uint32_t M    = uint32_t( f->reconCount );
   const size_t   area = size_t( f->canvasW ) * f->canvasH;
-  DevBuf<uint16_t> d_att;
-  TMC2_TRY( d_att.alloc( 6 * area ) );
+  if ( attribute ) {
+    TMC2_TRY( f->d_attr16.alloc( 6 * area ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_attr16.p, attribute, 6 * area * sizeof( uint16_t ), hipMemcpyHostToDevice, s ) );
+    f->haveAttr16 = true;
+  } else if ( !f->haveAttr16 ) {
+    setError( "colorPointCloud: no decoded attribute frames (pass them, or tmc2_codec_set_decoded_attribute_yuv420 first)" );
+    return TMC2_E_STATE;
+  }
   TMC2_TRY( f->d_colors16.alloc( M ) );
-  TMC2_HIP( hipMemcpyAsync( d_att.p, attribute, 6 * area * sizeof( uint16_t ), hipMemcpyHostToDevice, s ) );
   const int sid = ctx->stageBegin( "color_point_cloud" );
-  hipLaunchKernelGGL( colorGatherKernel, dim3( ( M + 255 ) / 256 ), dim3( 256 ), 0, s, f->d_pointToPixel.p, M, d_att.p, f->canvasW,
-                      f->canvasH, reinterpret_cast<ushort4*>( f->d_colors16.p ) );
+  hipLaunchKernelGGL( colorGatherKernel, dim3( ( M + 255 ) / 256 ), dim3( 256 ), 0, s, f->d_pointToPixel.p, M, f->d_attr16.p,
+                      f->canvasW, f->canvasH, reinterpret_cast<ushort4*>( f->d_colors16.p ) );
   ctx->stageEnd( sid );
   TMC2_HIP( hipStreamSynchronize( s ) );  // the caller's buffer is free again
   TMC2_HIP( hipGetLastError() );
@@ -567,7 +573,7 @@ int tmc2_codec_identify_boundary_points( tmc2_frame* f ) {
   return tmc2::identifyBoundaryPoints( f );
 }
 int tmc2_codec_color_point_cloud( tmc2_frame* f, const uint16_t* attribute ) {
-  if ( !f || !attribute ) return TMC2_E_INVALID;
+  if ( !f ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   return tmc2::colorPointCloud( f, attribute );
 }

@@ -222,10 +222,22 @@ class GofEncoder:
         """S17-S22 on the resident (decoded == generated) occupancy / geometry canvases."""
         self._per_worker(frames, lambda fr: fr.encoder_generate_attribute_images())
 
-    def phase_c(self, frames, decoded_attribute, grid_size=8, threshold=64.0):
-        """The post-reconstruction tail of every frame (boundary points, 16-bit colours from the decoded attribute frames,
-        grid geometry smoothing, colour transfer onto the moved points, YUV -> RGB); decoded_attribute[i]: uint16 [2][3][H][W]."""
-        self.per_frame(frames, lambda fr, i: fr.codec_post_reconstruct(decoded_attribute[i], grid_size, threshold))
+    def phase_c(self, frames, decoded_attribute=None, grid_size=8, threshold=64.0, i420_out=None):
+        """What follows the attribute images, per frame: the colour-space conversion to the I420 frames the video encoder
+        reads, and the post-reconstruction tail (boundary points, 16-bit colours from the decoded attribute frames, grid
+        geometry smoothing, colour transfer onto the moved points, YUV -> RGB).
+        decoded_attribute[i]: uint16 [2][3][H][W], the decoded attribute frames after the inverse conversion; None: identity
+        video codec -- the I420 frames produced here are converted back on the device (i420_out[i], uint8 [2][H*W*3/2],
+        receives them if given)."""
+        if decoded_attribute is not None:
+            self.per_frame(frames, lambda fr, i: fr.codec_post_reconstruct(decoded_attribute[i], grid_size, threshold))
+            return
+
+        def chain(fr, i):
+            i420 = fr.encoder_attribute_to_yuv420(4, None if i420_out is None else i420_out[i])
+            fr.codec_set_decoded_attribute_yuv420(i420, 0)
+            fr.codec_post_reconstruct(None, grid_size, threshold)
+        self.per_frame(frames, chain)
 
     def stage_ms(self):
         tot = {}

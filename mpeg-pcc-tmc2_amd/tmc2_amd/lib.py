@@ -153,6 +153,24 @@ class Context:
         return out
 
     # PCCMetrics::compute (one frame)
+    # PCCInternalColorConverter (the attribute video's colour-space conversion)
+    def color_convert_rgb444_to_yuv420(self, rgb, downsampling_filter=4):
+        """rgb uint8 [3][H][W] -> (y [H][W], u, v [H/2][W/2])"""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        _, H, W = rgb.shape
+        out = np.zeros(W * H * 3 // 2, np.uint8)
+        _check(self.L.tmc2_color_convert_rgb444_to_yuv420(self.h, _ptr(rgb), int(W), int(H), int(downsampling_filter), _ptr(out)))
+        a = W * H
+        return out[:a].reshape(H, W), out[a:a + a // 4].reshape(H // 2, W // 2), out[a + a // 4:].reshape(H // 2, W // 2)
+
+    def color_convert_yuv420_to_yuv444(self, y, u, v, upsampling_filter=0):
+        """-> uint16 [3][H][W]"""
+        H, W = y.shape
+        src = np.concatenate([np.ascontiguousarray(a, dtype=np.uint8).reshape(-1) for a in (y, u, v)])
+        out = np.zeros((3, H, W), np.uint16)
+        _check(self.L.tmc2_color_convert_yuv420_to_yuv444(self.h, _ptr(src), int(W), int(H), int(upsampling_filter), _ptr(out)))
+        return out
+
     def metrics_compute(self, src_xyz, src_rgb, rec_xyz, rec_rgb, normals=None, resolution=1023.0):
         a = np.ascontiguousarray(src_xyz, np.int16)
         b = np.ascontiguousarray(src_rgb, np.uint8)
@@ -344,8 +362,34 @@ class Frame:
     def codec_identify_boundary_points(self):
         _check(self.L.tmc2_codec_identify_boundary_points(self.h))
 
-    def codec_color_point_cloud(self, attribute16):
-        """attribute16: the decoded attribute frames of this frame, uint16 [2][3][H][W]."""
+    def encoder_attribute_to_yuv420(self, downsampling_filter=4, out=None):
+        """The two attribute canvases as the I420 frames the video encoder reads: uint8 [2][H*W*3/2]."""
+        W, H, _ = self._canvas
+        if out is None:
+            out = np.zeros((2, W * H * 3 // 2), np.uint8)
+        _check(self.L.tmc2_encoder_attribute_to_yuv420(self.h, int(downsampling_filter), _ptr(out)))
+        return out
+
+    def codec_set_decoded_attribute_yuv420(self, yuv420, upsampling_filter=0):
+        """The two decoded I420 attribute frames (uint8 [2][H*W*3/2]) -> 16-bit 4:4:4 planes kept on the device."""
+        W, H, _ = self._canvas
+        src = np.ascontiguousarray(yuv420, dtype=np.uint8)
+        if src.size != 2 * (W * H * 3 // 2):
+            raise ValueError("decoded I420 frames must hold 2 x %d bytes" % (W * H * 3 // 2))
+        _check(self.L.tmc2_codec_set_decoded_attribute_yuv420(self.h, _ptr(src), int(upsampling_filter)))
+
+    def get_decoded_attribute(self):
+        W, H, _ = self._canvas
+        out = np.zeros((2, 3, H, W), np.uint16)
+        _check(self.L.tmc2_frame_get_decoded_attribute(self.h, _ptr(out)))
+        return out
+
+    def codec_color_point_cloud(self, attribute16=None):
+        """attribute16: the decoded attribute frames of this frame, uint16 [2][3][H][W]; None: those already on the device
+        (codec_set_decoded_attribute_yuv420)."""
+        if attribute16 is None:
+            _check(self.L.tmc2_codec_color_point_cloud(self.h, None))
+            return
         W, H, _ = self._canvas
         att = np.ascontiguousarray(attribute16, dtype=np.uint16)
         if att.shape != (2, 3, H, W):
@@ -361,7 +405,7 @@ class Frame:
     def codec_convert_yuv16_to_rgb8(self):
         _check(self.L.tmc2_codec_convert_yuv16_to_rgb8(self.h))
 
-    def codec_post_reconstruct(self, attribute16, grid_size=8, threshold=64.0):
+    def codec_post_reconstruct(self, attribute16=None, grid_size=8, threshold=64.0):
         """The whole tail in the reference's order: boundary points, 16-bit colours from the decoded attribute frames, grid
         geometry smoothing, colour transfer onto the moved points, YUV -> RGB."""
         self.codec_identify_boundary_points()

@@ -43,6 +43,7 @@
 #include "PCCFrameContext.h"
 #include "PCCGroupOfFrames.h"
 #include "PCCImage.h"
+#include "PCCInternalColorConverter.h"
 #include "PCCVideo.h"
 #include "PCCBitstream.h"
 #undef private
@@ -742,6 +743,56 @@ int ref_gof_get_post( int frame, int16_t* xyz, uint16_t* c16, uint8_t* rgb, uint
       rgb[3 * i + k] = c[k];
     }
     btype[i] = rec.getBoundaryPointType( i );
+  }
+  return 0;
+}
+
+// ---- colour-space conversion around the attribute video codec (PCCVideoEncoder::compress, PCCVideoEncoder.cpp:326-413, with
+// the internal converter: "RGB444ToYUV420_8_<downsamplingFilter>" before the codec, "YUV420ToYUV444_8_<upsamplingFilter>"
+// after it).  Attribute videos are PCCVideo<uint16_t, 3>.
+int ref_convert_rgb444_to_yuv420( const uint8_t* rgb, int W, int H, int filter, uint8_t* y, uint8_t* u, uint8_t* v ) {
+  Quiet                               quiet;
+  PCCVideo<uint16_t, 3>               video;
+  PCCInternalColorConverter<uint16_t> converter;
+  video.resize( 1 );
+  video[0].resize( size_t( W ), size_t( H ), PCCCOLORFORMAT::RGB444 );
+  for ( int c = 0; c < 3; ++c )
+    for ( size_t i = 0; i < size_t( W ) * H; ++i ) video[0][c][i] = rgb[size_t( c ) * W * H + i];
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  dup2( fileno( devnull ), 1 );
+  converter.convert( "RGB444ToYUV420_8_" + std::to_string( filter ), video );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  if ( video[0][0].size() != size_t( W ) * H || video[0][1].size() != size_t( W / 2 ) * ( H / 2 ) ) return -1;
+  for ( size_t i = 0; i < video[0][0].size(); ++i ) y[i] = uint8_t( video[0][0][i] );
+  for ( size_t i = 0; i < video[0][1].size(); ++i ) u[i] = uint8_t( video[0][1][i] ), v[i] = uint8_t( video[0][2][i] );
+  return 0;
+}
+int ref_convert_yuv420_to_yuv444( const uint8_t* y, const uint8_t* u, const uint8_t* v, int W, int H, int filter, uint16_t* out ) {
+  Quiet                               quiet;
+  PCCVideo<uint16_t, 3>               video, dst;
+  PCCInternalColorConverter<uint16_t> converter;
+  video.resize( 1 );
+  video[0].resize( size_t( W ), size_t( H ), PCCCOLORFORMAT::YUV420 );
+  if ( video[0][1].size() != size_t( W / 2 ) * ( H / 2 ) ) return -1;
+  for ( size_t i = 0; i < size_t( W ) * H; ++i ) video[0][0][i] = y[i];
+  for ( size_t i = 0; i < video[0][1].size(); ++i ) video[0][1][i] = u[i], video[0][2][i] = v[i];
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  dup2( fileno( devnull ), 1 );
+  converter.convert( "YUV420ToYUV444_8_" + std::to_string( filter ), video, dst );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  for ( int c = 0; c < 3; ++c ) {
+    if ( dst[0][c].size() != size_t( W ) * H ) return -1;
+    std::copy( dst[0][c].begin(), dst[0][c].end(), out + size_t( c ) * W * H );
   }
   return 0;
 }

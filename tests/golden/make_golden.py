@@ -139,9 +139,40 @@ def gof_post_reconstruction():
     print("gof_tiny2_post", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
+def gof_color_chain():
+    """The attribute video's way around an identity codec on the 2-frame GOF of gof_tiny2.npz, through the reference's own
+    PCCInternalColorConverter: RGB444 -> YUV420 (8 bits, downsampling filter 4) -> YUV444 (16 bits, upsampling filter 0),
+    then the post-reconstruction tail on those frames."""
+    ref = ob.Reference()
+    frames = [synth_cloud("tiny", f) for f in range(2)]
+    a = ref.phase_a(frames, 10, 11, 4)
+    b = ref.phase_b(frames, a, 4)
+    out = {"input_md5": np.array("".join(digest(x) + digest(col) for x, col in frames))}
+    dec = []
+    for i, pb in enumerate(b):
+        planes = []
+        for m in range(2):
+            y, u, v = ref.convert_rgb444_to_yuv420(pb["attribute"][m], 4)
+            yuv444 = ref.convert_yuv420_to_yuv444(y, u, v, 0)
+            out["f%d_m%d_yuv420_md5" % (i, m)] = np.array(digest(np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])))
+            out["f%d_m%d_yuv444_md5" % (i, m)] = np.array(digest(yuv444))
+            if i == 0 and m == 0:   # a readable corner next to the digests
+                out["f0_m0_u_rows"] = u[u.any(1)][:4].copy()
+            planes.append(yuv444)
+        dec.append(np.stack(planes))
+    c = ref.phase_c(b, dec)
+    for i, pc in enumerate(c):
+        out["f%d_moved" % i] = np.array(int((pc["boundary"] == 3).sum()))
+        for k in ("xyz", "colors16", "rgb", "boundary"):
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pc[k]))
+    np.savez_compressed(os.path.join(HERE, "gof_tiny2_color.npz"), **out)
+    print("gof_tiny2_color", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
     gof()
     gof_low_delay()
     gof_random_access()
     gof_post_reconstruction()
+    gof_color_chain()

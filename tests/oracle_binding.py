@@ -329,6 +329,28 @@ class Oracle:
         return out
 
 
+
+    # ---- colour-space conversion around the attribute video codec ----
+    _conv_prefix = "orc_"
+
+    def convert_rgb444_to_yuv420(self, rgb, filter=4):
+        """rgb u8 [3][H][W] -> (y u8 [H][W], u, v u8 [H/2][W/2])"""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        _, H, W = rgb.shape
+        y, u, v = np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)
+        rc = getattr(self.L, self._conv_prefix + "convert_rgb444_to_yuv420")(_p(rgb), int(W), int(H), int(filter), _p(y), _p(u), _p(v))
+        assert rc == 0, rc
+        return y, u, v
+
+    def convert_yuv420_to_yuv444(self, y, u, v, filter=0):
+        """-> u16 [3][H][W]"""
+        y, u, v = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v))
+        H, W = y.shape
+        out = np.zeros((3, H, W), np.uint16)
+        rc = getattr(self.L, self._conv_prefix + "convert_yuv420_to_yuv444")(_p(y), _p(u), _p(v), int(W), int(H), int(filter), _p(out))
+        assert rc == 0, rc
+        return out
+
     # ---- post-reconstruction tail (SURVEY 8f row 1) ----
     def identify_boundary_points(self, p2p, occ_video, W, H, occ_precision):
         p2p = np.ascontiguousarray(p2p, dtype=np.uint32)
@@ -422,6 +444,28 @@ class Reference:
             att = np.zeros((2, 3, img["height"], img["width"]), np.uint8)
             assert L.ref_gof_get_attribute_images(i, _p(att)) == 0
             out.append(dict(recon_xyz=rec, recon_rgb=col, point_to_pixel=p2p, attribute=att))
+        return out
+
+
+    # ---- colour-space conversion around the attribute video codec ----
+    _conv_prefix = "ref_"
+
+    def convert_rgb444_to_yuv420(self, rgb, filter=4):
+        """rgb u8 [3][H][W] -> (y u8 [H][W], u, v u8 [H/2][W/2])"""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        _, H, W = rgb.shape
+        y, u, v = np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)
+        rc = getattr(self.L, self._conv_prefix + "convert_rgb444_to_yuv420")(_p(rgb), int(W), int(H), int(filter), _p(y), _p(u), _p(v))
+        assert rc == 0, rc
+        return y, u, v
+
+    def convert_yuv420_to_yuv444(self, y, u, v, filter=0):
+        """-> u16 [3][H][W]"""
+        y, u, v = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v))
+        H, W = y.shape
+        out = np.zeros((3, H, W), np.uint16)
+        rc = getattr(self.L, self._conv_prefix + "convert_yuv420_to_yuv444")(_p(y), _p(u), _p(v), int(W), int(H), int(filter), _p(out))
+        assert rc == 0, rc
         return out
 
     def phase_c(self, phase_b_out, decoded_attribute):

@@ -1,4 +1,5 @@
 """GPU tier (-m gpu): packing + occupancy / geometry image generation (S10-S16) through the C-ABI."""
+import os
 import numpy as np
 import pytest
 
@@ -318,3 +319,68 @@ def test_gpu_post_reconstruction_matches_oracle(gpu_ctx, oracle, name, prec):
     again = fr.get_post_reconstruction()
     for k in got:
         assert np.array_equal(got[k], again[k]), k
+
+
+def test_gpu_color_chain_matches_golden_fixture(gpu_ctx):
+    """Attribute canvases -> I420 frames (what the video encoder reads) -> 16-bit 4:4:4 frames (what the reconstruction
+    reads) -> the post-reconstruction tail, all on the device, against the fixture produced by the reference's own
+    PCCInternalColorConverter and codec members (identity video codec in between)."""
+    from test_oracle_golden import GOLD, check_color_chain_against_fixture, digest
+    g = np.load(os.path.join(GOLD, "gof_tiny2_color.npz"))
+    frames = [synth_cloud("tiny", f) for f in range(2)]
+    assert str(g["input_md5"]) == "".join(digest(x) + digest(c) for x, c in frames)
+    frs = [gpu_ctx.frame(xyz, rgb) for xyz, rgb in frames]
+    p = T.ctc_params(10, 11, frs[0].weight_normal(11, 0.6))
+    heights = []
+    for fr in frs:
+        fr.segmenter_compute(p)
+        heights.append(fr.encoder_pack_flexible(1280, 2, 1.0))
+    W, H = T.encoder_canvas_size(heights, 1280, 1280, 1280)
+    for fr in frs:
+        fr.encoder_generate_geometry_images(W, H, 4)
+        fr.encoder_generate_attribute_images()
+    a = W * H
+
+    def split(frame420):
+        return frame420[:a].reshape(H, W), frame420[a:a + a // 4].reshape(H // 2, W // 2), frame420[a + a // 4:].reshape(H // 2, W // 2)
+
+    # (1) the context-level converters on host images
+    def tail_from_host(dec):
+        out = []
+        for fr, d in zip(frs, dec):
+            fr.codec_post_reconstruct(d)
+            out.append(fr.get_post_reconstruction())
+        return out
+    check_color_chain_against_fixture(g, gpu_ctx.color_convert_rgb444_to_yuv420, gpu_ctx.color_convert_yuv420_to_yuv444,
+                                      [fr.get_attribute_images() for fr in frs], tail_from_host)
+    # (2) the frame-level path: nothing but the I420 frames crosses the PCIe bus
+    for i, fr in enumerate(frs):
+        i420 = fr.encoder_attribute_to_yuv420(4)
+        for m in range(2):
+            assert digest(i420[m]) == str(g["f%d_m%d_yuv420_md5" % (i, m)])
+        fr.codec_set_decoded_attribute_yuv420(i420, 0)
+        dec = fr.get_decoded_attribute()
+        for m in range(2):
+            assert digest(dec[m]) == str(g["f%d_m%d_yuv444_md5" % (i, m)])
+        fr.codec_post_reconstruct(None)
+        pc = fr.get_post_reconstruction()
+        for k in ("xyz", "colors16", "rgb", "boundary"):
+            assert digest(np.ascontiguousarray(pc[k])) == str(g["f%d_%s_md5" % (i, k)]), (i, k)
+
+
+@pytest.mark.parametrize("kind,H,W", [("noise", 64, 96), ("noise", 66, 70), ("blocks", 256, 320), ("flat", 32, 48), ("noise", 1280, 1344)])
+def test_gpu_color_conversion_matches_oracle(gpu_ctx, oracle, kind, H, W):
+    rng = np.random.default_rng(H * 1000 + W)
+    if kind == "noise":
+        rgb = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    elif kind == "blocks":
+        rgb = np.kron(rng.integers(0, 256, (3, H // 16, W // 16), dtype=np.uint8), np.ones((16, 16), np.uint8))
+    else:
+        rgb = np.full((3, H, W), 255, np.uint8)
+    ey, eu, ev = oracle.convert_rgb444_to_yuv420(rgb)
+    gy, gu, gv = gpu_ctx.color_convert_rgb444_to_yuv420(rgb)
+    assert np.array_equal(gy, ey) and np.array_equal(gu, eu) and np.array_equal(gv, ev)
+    y2, u2, v2 = (rng.integers(0, 256, a.shape, dtype=np.uint8) for a in (ey, eu, ev))
+    assert np.array_equal(gpu_ctx.color_convert_yuv420_to_yuv444(y2, u2, v2), oracle.convert_yuv420_to_yuv444(y2, u2, v2))
+    with pytest.raises(T.Tmc2Error):
+        gpu_ctx.color_convert_rgb444_to_yuv420(rgb, downsampling_filter=2)     # only the reference's default filters are built

@@ -278,6 +278,60 @@ def test_oracle_post_reconstruction_matches_reference_live(oracle, reference, na
             assert np.array_equal(x[k], y[k]), k
 
 
+def check_color_chain_against_fixture(g, convert_down, convert_up, attributes, tail):
+    """Shared by the CPU (oracle) and GPU tiers: attribute canvases -> YUV420 (8 bits) -> YUV444 (16 bits) -> the tail,
+    against the fixture produced by the reference's PCCInternalColorConverter.  convert_down(rgb[3][H][W]) -> (y, u, v);
+    convert_up(y, u, v) -> u16 [3][H][W]; tail(list of u16 [2][3][H][W]) -> per frame dict(xyz, colors16, rgb, boundary)."""
+    dec = []
+    for i, att in enumerate(attributes):
+        planes = []
+        for m in range(2):
+            y, u, v = convert_down(att[m])
+            assert digest(np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])) == str(g["f%d_m%d_yuv420_md5" % (i, m)]), (i, m)
+            if i == 0 and m == 0:
+                assert np.array_equal(u[u.any(1)][:4], g["f0_m0_u_rows"])
+            yuv444 = convert_up(y, u, v)
+            assert digest(yuv444) == str(g["f%d_m%d_yuv444_md5" % (i, m)]), (i, m)
+            planes.append(yuv444)
+        dec.append(np.stack(planes))
+    for i, pc in enumerate(tail(dec)):
+        assert int((pc["boundary"] == 3).sum()) == int(g["f%d_moved" % i])
+        for k in ("xyz", "colors16", "rgb", "boundary"):
+            assert digest(np.ascontiguousarray(pc[k])) == str(g["f%d_%s_md5" % (i, k)]), (i, k)
+
+
+def test_oracle_color_chain_matches_golden(oracle):
+    g = np.load(os.path.join(GOLD, "gof_tiny2_color.npz"))
+    frames = [synth_cloud("tiny", f) for f in range(2)]
+    assert str(g["input_md5"]) == "".join(digest(x) + digest(c) for x, c in frames)
+    a = oracle.phase_a(frames, 10, 11, 4)
+    b = oracle.phase_b(frames, a, 4)
+    check_color_chain_against_fixture(g, oracle.convert_rgb444_to_yuv420, oracle.convert_yuv420_to_yuv444,
+                                      [x["attribute"] for x in b], lambda dec: oracle.phase_c(a, b, dec, 4))
+
+
+@pytest.mark.parametrize("kind,H,W", [("noise", 64, 96), ("ramps", 128, 128), ("noise", 66, 70), ("blocks", 256, 320), ("flat", 32, 48)])
+def test_oracle_color_conversion_matches_reference_live(oracle, reference, kind, H, W):
+    """Other images than the fixture's (white noise reaches every clamp), where the compiled reference is present."""
+    rng = np.random.default_rng(H * 1000 + W)
+    if kind == "noise":
+        rgb = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    elif kind == "ramps":
+        yy, xx = np.mgrid[0:H, 0:W]
+        rgb = np.stack([(xx * 2) % 256, (yy * 3) % 256, (xx + yy) % 256]).astype(np.uint8)
+    elif kind == "blocks":
+        rgb = np.kron(rng.integers(0, 256, (3, H // 16, W // 16), dtype=np.uint8), np.ones((16, 16), np.uint8))
+    else:
+        rgb = np.full((3, H, W), 255, np.uint8)
+    ry, ru, rv = reference.convert_rgb444_to_yuv420(rgb)
+    oy, ou, ov = oracle.convert_rgb444_to_yuv420(rgb)
+    assert np.array_equal(ry, oy) and np.array_equal(ru, ou) and np.array_equal(rv, ov)
+    assert np.array_equal(reference.convert_yuv420_to_yuv444(ry, ru, rv), oracle.convert_yuv420_to_yuv444(ry, ru, rv))
+    # decoded frames are not the encoder's own: any 4:2:0 content must convert alike
+    y2, u2, v2 = (rng.integers(0, 256, a.shape, dtype=np.uint8) for a in (ry, ru, rv))
+    assert np.array_equal(reference.convert_yuv420_to_yuv444(y2, u2, v2), oracle.convert_yuv420_to_yuv444(y2, u2, v2))
+
+
 def _sparse_target_case(seed=0):
     """A dense source and a ~40x sparser target: every target collects dozens of backward candidates, many at equal
     distance -- the regime where the reference's std::sort (introsort, not stable beyond 16) decides the fp64 order."""
