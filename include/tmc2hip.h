@@ -281,6 +281,21 @@ int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
                           const uint8_t* recRgb, uint64_t m, const double* srcNormals, double resolution, double* out,
                           int64_t* counts );
 
+/* ---- point-cloud ingest and conformance checksums (host; no device needed) ------------------------------------------- */
+/* replaces: PCCPointSet3::read (PccLibCommon/source/PCCPointSet.cpp:464-757) as PCCGroupOfFrames::load (PCCGroupOfFrames.cpp:
+ * 46-80) calls it per frame: ASCII and binary_little_endian PLY, x / y / z of 2, 4 or 8 bytes, uchar red / green / blue, float
+ * nx / ny / nz (binary bodies only, as in the reference); other vertex properties are skipped.  The cloud lands directly in
+ * the caller's buffers -- xyz int16[capacity][3], rgb uint8[capacity][3] (may be NULL), normals double[capacity][3] (NULL:
+ * not read) -- e.g. the page-locked staging the upload reads.  threads: parser threads (0 = 8).
+ * tmc2_ply_info only reads the header (pointCount, whether red/green/blue resp. float normals are present).          */
+int tmc2_ply_info( const char* path, int readNormals, uint64_t* pointCount, int* hasColors, int* hasNormals );
+int tmc2_ply_read( const char* path, int16_t* xyz, uint8_t* rgb, double* normals, uint64_t capacity, int threads,
+                   uint64_t* pointCount );
+/* replaces: PCCPointSet3::computeChecksum( reorderPoints ) / computeMd5 / reorder (PCCPointSet.cpp:222-305): the MD5 the
+ * conformance logs carry, over int16 positions then uint8 colours (rgb may be NULL); reorderPoints sorts by (x, y, z) and
+ * merges points that share a position (mean colour) first.                                                        */
+int tmc2_point_set_checksum( const int16_t* xyz, const uint8_t* rgb, uint64_t n, int reorderPoints, uint8_t digest[16] );
+
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );

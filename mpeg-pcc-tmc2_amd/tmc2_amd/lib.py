@@ -506,6 +506,42 @@ def host_global_patch_allocation(lists, pools, matches, tile_w, tile_h, min_w=12
     return res
 
 
+def ply_info(path, read_normals=False):
+    """(point count, has colours, has float normals) from the header of a PLY file."""
+    L = load_library()
+    n, c, m = C.c_uint64(), C.c_int(), C.c_int()
+    _check(L.tmc2_ply_info(str(path).encode(), int(bool(read_normals)), C.byref(n), C.byref(c), C.byref(m)))
+    return n.value, bool(c.value), bool(m.value)
+
+
+def ply_read(path, read_normals=False, threads=0, out=None):
+    """PCCPointSet3::read: (xyz int16[n][3], rgb uint8[n][3] or None, normals float64[n][3] or None).
+    out = (xyz, rgb) preallocated arrays (e.g. views of page-locked memory) to land the cloud in."""
+    L = load_library()
+    n, has_rgb, has_nrm = ply_info(path, read_normals)
+    if out is not None:
+        xyz, rgb = out
+        if len(xyz) < n or (rgb is not None and len(rgb) < n):
+            raise ValueError("buffers too small for %d points" % n)
+    else:
+        xyz, rgb = np.zeros((n, 3), np.int16), (np.zeros((n, 3), np.uint8) if has_rgb else None)
+    nrm = np.zeros((n, 3), np.float64) if has_nrm else None
+    cnt = C.c_uint64()
+    _check(L.tmc2_ply_read(str(path).encode(), _ptr(xyz), None if rgb is None or not has_rgb else _ptr(rgb),
+                           None if nrm is None else _ptr(nrm), C.c_uint64(len(xyz)), int(threads), C.byref(cnt)))
+    return xyz[:n], (rgb[:n] if rgb is not None and has_rgb else None), nrm
+
+
+def point_set_checksum(xyz, rgb=None, reorder=False):
+    """PCCPointSet3::computeChecksum: the 16 MD5 bytes."""
+    L = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.int16)
+    rgb = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+    d = np.zeros(16, np.uint8)
+    _check(L.tmc2_point_set_checksum(_ptr(xyz), None if rgb is None else _ptr(rgb), C.c_uint64(len(xyz)), int(bool(reorder)), _ptr(d)))
+    return d.tobytes()
+
+
 def host_orient_normals(xyz, knn, normals):
     L = load_library()
     xyz = np.ascontiguousarray(xyz, dtype=np.int16)

@@ -797,6 +797,49 @@ int ref_convert_yuv420_to_yuv444( const uint8_t* y, const uint8_t* u, const uint
   return 0;
 }
 
+// ---- ingest and checksums: PCCPointSet3::read (PCCPointSet.cpp:464-757), computeChecksum (:222-243) ----
+namespace {
+PCCPointSet3 g_ply;
+}
+// returns the point count (-1: read failed); flags bit 0 colours, bit 1 normals
+int64_t ref_ply_read( const char* path, int readNormals, int* flags ) {
+  Quiet quiet;
+  g_ply = PCCPointSet3();
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  dup2( fileno( devnull ), 1 );
+  const bool ok = g_ply.read( path, readNormals != 0 );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  if ( !ok ) return -1;
+  if ( flags ) *flags = ( g_ply.hasColors() ? 1 : 0 ) | ( g_ply.hasNormals() ? 2 : 0 );
+  return int64_t( g_ply.getPointCount() );
+}
+int ref_ply_get( int16_t* xyz, uint8_t* rgb, double* normals ) {
+  for ( size_t i = 0; i < g_ply.getPointCount(); ++i )
+    for ( int k = 0; k < 3; ++k ) {
+      xyz[3 * i + k] = g_ply[i][k];
+      if ( rgb && g_ply.hasColors() ) rgb[3 * i + k] = g_ply.getColor( i )[k];
+      if ( normals && g_ply.hasNormals() ) normals[3 * i + k] = g_ply.getNormals()[i][k];
+    }
+  return 0;
+}
+int ref_checksum( const int16_t* xyz, const uint8_t* rgb, size_t n, int reorderPoints, uint8_t* digest16 ) {
+  PCCPointSet3 pc;
+  if ( rgb ) pc.addColors();
+  pc.resize( n );
+  for ( size_t i = 0; i < n; ++i ) {
+    pc[i] = PCCPoint3D( xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] );
+    if ( rgb ) pc.setColor( i, PCCColor3B( rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] ) );
+  }
+  const auto d = pc.computeChecksum( reorderPoints != 0 );
+  std::copy( d.begin(), d.begin() + 16, digest16 );
+  return 0;
+}
+
 // S18 alone: PCCPointSet3::transferColors (PCCPointSet.cpp:807-1124) with the arguments PCCEncoder::generateAttributeVideo
 // passes under the CTC (PCCEncoder.cpp:6679-6697)
 int ref_transfer_colors( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const int16_t* tgtXyz, size_t m, uint8_t* tgtRgb ) {

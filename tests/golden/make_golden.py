@@ -169,6 +169,33 @@ def gof_color_chain():
     print("gof_tiny2_color", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
+def io_golden():
+    """PCCPointSet3::read on the PLY variants of tests/ply_cases.py and PCCPointSet3::computeChecksum, through the reference."""
+    import tempfile
+    from ply_cases import cases
+    ref = ob.Reference()
+    xyz, rgb = synth_cloud("tiny", 0)
+    xyz, rgb = xyz[:1500].copy(), rgb[:1500].copy()
+    out = {"input_md5": np.array(digest(xyz) + digest(rgb))}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, data in cases(xyz, rgb).items():
+            path = os.path.join(tmp, name + ".ply")
+            with open(path, "wb") as f:
+                f.write(data)
+            out[name + "_file_md5"] = np.array(hashlib.md5(data).hexdigest())
+            for rn in (0, 1):
+                got = ref.ply_read(path, bool(rn))
+                if name == "binary_short" and got[2] is not None:      # the property the file ends in is uninitialised there
+                    got = (got[0], got[1], got[2][:int(np.flatnonzero(got[0].any(1))[-1])])
+                out["%s_n%d" % (name, rn)] = np.array(["" if a is None else digest(a) for a in got])
+    big = np.concatenate([xyz, xyz[:300]]), np.concatenate([rgb, rgb[300:600]])
+    for reorder in (0, 1):
+        out["checksum_r%d" % reorder] = np.frombuffer(ref.checksum(big[0], big[1], bool(reorder)), np.uint8)
+        out["checksum_nocolor_r%d" % reorder] = np.frombuffer(ref.checksum(big[0], None, bool(reorder)), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "io_golden.npz"), **out)
+    print("io_golden", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()
     gof()
@@ -176,3 +203,4 @@ if __name__ == "__main__":
     gof_random_access()
     gof_post_reconstruction()
     gof_color_chain()
+    io_golden()

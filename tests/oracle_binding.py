@@ -468,6 +468,27 @@ class Reference:
         assert rc == 0, rc
         return out
 
+    def ply_read(self, path, read_normals=False):
+        """PCCPointSet3::read -> (xyz, rgb or None, normals or None), or None if the reference refuses the file."""
+        L = self.L
+        L.ref_ply_read.restype = C.c_int64
+        flags = C.c_int()
+        n = L.ref_ply_read(str(path).encode(), int(bool(read_normals)), C.byref(flags))
+        if n < 0:
+            return None
+        xyz = np.zeros((n, 3), np.int16)
+        rgb = np.zeros((n, 3), np.uint8) if flags.value & 1 else None
+        nrm = np.zeros((n, 3), np.float64) if flags.value & 2 else None
+        L.ref_ply_get(_p(xyz), None if rgb is None else _p(rgb), None if nrm is None else _p(nrm))
+        return xyz, rgb, nrm
+
+    def checksum(self, xyz, rgb=None, reorder=False):
+        xyz = _i16(xyz)
+        rgb = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+        d = np.zeros(16, np.uint8)
+        self.L.ref_checksum(_p(xyz), None if rgb is None else _p(rgb), C.c_size_t(len(xyz)), int(bool(reorder)), _p(d))
+        return d.tobytes()
+
     def phase_c(self, phase_b_out, decoded_attribute):
         """Post-reconstruction tail (must follow phase_b() on the same GOF): colorPointCloud from the given "decoded"
         attribute frames (u16 [2][3][H][W] per frame), grid geometry smoothing, transferColors16bitBP, convertYUV16ToRGB8."""

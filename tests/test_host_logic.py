@@ -159,3 +159,109 @@ def test_host_global_patch_allocation_matches_oracle(oracle, case):
         assert any((gm >= 0).any() for _, _, gm, _, _ in got)             # some sub-context spans several frames
     if case == "accept":
         assert grew                                                        # tracked patches took their union's box
+
+
+def _ply_inputs():
+    xyz, rgb = synth_cloud("tiny", 0)
+    return xyz[:1500].copy(), rgb[:1500].copy()
+
+
+@pytest.mark.parametrize("case", ["ascii_float", "ascii_mixed", "ascii_short", "binary_float_normals", "binary_mixed",
+                                  "binary_int32_named", "binary_short"])
+@pytest.mark.parametrize("read_normals", [False, True])
+def test_host_ply_read_matches_oracle_and_reference(tmp_path, case, read_normals):
+    """PCCPointSet3::read: the product's reader against the numpy restatement (oracle/port_io.py) and, where it is present,
+    the compiled reference, on every header / body variant the reference distinguishes."""
+    import importlib.util
+    from ply_cases import cases
+    spec = importlib.util.spec_from_file_location("port_io", os.path.join(os.path.dirname(__file__), "..", "oracle", "port_io.py"))
+    port_io = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(port_io)
+    xyz, rgb = _ply_inputs()
+    path = tmp_path / (case + ".ply")
+    path.write_bytes(cases(xyz, rgb)[case])
+    exp = port_io.ply_read(str(path), read_normals)
+    for threads in (1, 3, 8):
+        got = T.ply_read(str(path), read_normals, threads)
+        for g, e in zip(got, exp):
+            assert (g is None) == (e is None)
+            assert g is None or np.array_equal(g, e)
+    n, has_rgb, has_nrm = T.ply_info(str(path), read_normals)
+    assert n == len(exp[0]) and has_rgb == (exp[1] is not None) and has_nrm == (exp[2] is not None)
+    if case == "ascii_float":
+        assert np.array_equal(exp[0], xyz) and np.array_equal(exp[1], rgb)          # and it is the cloud that was written
+    import oracle_binding as ob
+    if os.path.exists(ob.REF_PATH):
+        ref = ob.Reference().ply_read(str(path), read_normals)
+        for k, (g, e) in enumerate(zip(got, ref)):
+            assert (g is None) == (e is None)
+            if g is not None and case == "binary_short" and k == 2:
+                cut = int(np.flatnonzero(g.any(1))[-1]) + 1      # the property the file ends in is an uninitialised local there
+                g, e = g[:cut], e[:cut]
+            assert g is None or np.array_equal(g, e)
+
+
+def test_host_ply_read_refuses_what_the_reference_misreads(tmp_path):
+    from ply_cases import cases
+    xyz, rgb = _ply_inputs()
+    files = cases(xyz, rgb)
+    bad = {"big_endian": files["binary_float_normals"].replace(b"binary_little_endian", b"binary_big_endian"),
+           "not_ply": b"plx\n" + files["ascii_float"][4:],
+           "no_coordinates": files["ascii_float"].replace(b"property float z", b"property float w"),
+           "unknown_type": files["ascii_float"].replace(b"property float x", b"property half x"),
+           "too_few_columns": files["ascii_float"].replace(b"end_header\n", b"end_header\n1 2\n", 1)}
+    for name, data in bad.items():
+        p = tmp_path / (name + ".ply")
+        p.write_bytes(data)
+        with pytest.raises(T.Tmc2Error):
+            T.ply_read(str(p))
+    with pytest.raises(T.Tmc2Error):
+        T.ply_read(str(tmp_path / "missing.ply"))
+
+
+@pytest.mark.parametrize("reorder", [False, True])
+@pytest.mark.parametrize("colors", [True, False])
+def test_host_checksum_matches_oracle_and_reference(reorder, colors):
+    """PCCPointSet3::computeChecksum: MD5 (own implementation) over positions and colours, with and without the reordering
+    that merges duplicate positions; against hashlib / numpy and, where present, the compiled reference."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("port_io", os.path.join(os.path.dirname(__file__), "..", "oracle", "port_io.py"))
+    port_io = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(port_io)
+    import oracle_binding as ob
+    xyz, rgb = synth_cloud("tiny", 1)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(len(xyz), 400)
+    xyz = np.concatenate([xyz, xyz[dup], xyz[dup[:100]]])                     # duplicate positions with other colours
+    rgb = np.concatenate([rgb, rng.integers(0, 256, (500, 3), dtype=np.uint8)])
+    perm = rng.permutation(len(xyz))
+    xyz, rgb = xyz[perm], rgb[perm]
+    for n in (0, 1, 9, 10, 11, 21, 22, len(xyz)):                             # lengths around the 64-byte MD5 block boundaries
+        c = rgb[:n] if colors else None
+        exp = port_io.checksum(xyz[:n], c, reorder)
+        assert T.point_set_checksum(xyz[:n], c, reorder) == exp, n
+        if os.path.exists(ob.REF_PATH) and n:
+            assert ob.Reference().checksum(xyz[:n], c, reorder) == exp, n
+
+
+def test_host_ply_read_and_checksum_match_golden_fixture(tmp_path):
+    """The same, against the fixture the unmodified reference produced (tests/golden/io_golden.npz)."""
+    import hashlib
+    from ply_cases import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "io_golden.npz"))
+    digest = lambda a: hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+    xyz, rgb = _ply_inputs()
+    assert str(g["input_md5"]) == digest(xyz) + digest(rgb)
+    for name, data in cases(xyz, rgb).items():
+        assert hashlib.md5(data).hexdigest() == str(g[name + "_file_md5"]), "tests/ply_cases.py drifted from the fixture"
+        path = tmp_path / (name + ".ply")
+        path.write_bytes(data)
+        for rn in (0, 1):
+            got = T.ply_read(str(path), bool(rn))
+            if name == "binary_short" and got[2] is not None:
+                got = (got[0], got[1], got[2][:int(np.flatnonzero(got[0].any(1))[-1])])
+            assert ["" if a is None else digest(a) for a in got] == g["%s_n%d" % (name, rn)].tolist(), (name, rn)
+    big = np.concatenate([xyz, xyz[:300]]), np.concatenate([rgb, rgb[300:600]])
+    for reorder in (0, 1):
+        assert T.point_set_checksum(big[0], big[1], bool(reorder)) == g["checksum_r%d" % reorder].tobytes()
+        assert T.point_set_checksum(big[0], None, bool(reorder)) == g["checksum_nocolor_r%d" % reorder].tobytes()
