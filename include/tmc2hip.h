@@ -243,6 +243,19 @@ int tmc2_encoder_attribute_to_yuv420( tmc2_frame* f, int downsamplingFilter, uin
 int tmc2_codec_set_decoded_attribute_yuv420( tmc2_frame* f, const uint8_t* yuv420, int upsamplingFilter );
 int tmc2_frame_get_decoded_attribute( tmc2_frame* f, uint16_t* planes ); /* uint16 [2][3][H][W] */
 
+/* ---- decoder side: reconstruction from what the bitstream carries --------------------------------------------------- */
+/* replaces what PCCDecoder::decode does per frame before the reconstruction (PccLibDecoder/source/PCCDecoder.cpp:333-349:
+ * generateOccupancyMap, generateBlockToPatchFromOccupancyMapVideo -- PCCCodec.cpp:1736-1775): a frame WITHOUT a source
+ * cloud, made of the decoded patch records in list order (u0, v0, sizeU0, sizeV0, patchOrientation, u1, v1, d1, the three
+ * axes and projectionMode are used), the decoded occupancy video (uint8 [(H/p)][(W/p)]) and the two decoded geometry
+ * maps (uint16 [2][H][W]).  Continue with tmc2_codec_generate_point_cloud and the tmc2_codec_* tail.                 */
+int tmc2_decoder_frame_create( tmc2_ctx* ctx, const tmc2_patch* patches, int count, int width, int height, int occupancyPrecision,
+                               const uint8_t* occVideo, const uint16_t* geometry, tmc2_frame** out );
+/* replaces: PCCCodec::generatePointCloud (PccLibCommon/source/PCCCodec.cpp:519-980) alone -- the reconstruction from the
+ * resident canvases without the encoder's colour transfer / attribute images (tmc2_encoder_generate_attribute_images runs it
+ * as its first step).  tmc2_frame_get_reconstruction( f, xyz, NULL, pointToPixel ) returns the points.             */
+int tmc2_codec_generate_point_cloud( tmc2_frame* f );
+
 /* ---- post-reconstruction tail (PCCEncoder::encode :571-719, PCCDecoder::decode :330-470) -------------------- */
 /* All of these work on the reconstruction left by tmc2_encoder_generate_attribute_images (PCCCodec::generatePointCloud on
  * the resident, or decoded, occupancy / geometry canvases).  CTC settings: two maps in one stream, lossy attributes,

@@ -352,7 +352,7 @@ uint64_t tmc2_frame_point_count( const tmc2_frame* f ) { return f ? f->n : 0; }
 int tmc2_frame_reset( tmc2_frame* f ) {
   if ( !f ) return TMC2_E_INVALID;
   f->haveTree = f->haveKnn = f->haveNormals = f->havePartition = f->haveMutual = false;
-  f->havePatches = f->havePacking = f->haveGeometryImages = f->haveAttributeImages = false;
+  f->havePatches = f->havePacking = f->haveGeometryImages = f->haveAttributeImages = f->haveReconstruction = false;
   f->haveBoundaryTypes = f->haveColors16 = f->haveSmoothed = f->haveRgbPost = f->haveAttr16 = false;
   f->patches.clear();
   f->packOrder.clear();

@@ -337,24 +337,20 @@ int transferColorsDevice( tmc2_ctx* ctx, const TreeDev& srcTree, const Pt* d_src
   return TMC2_OK;
 }
 
-int generateAttributeImages( tmc2_frame* f ) {
+// S17 + the k-d tree over the reconstruction: all the decoder needs before the post-reconstruction tail, and the first half
+// of the encoder's phase B
+int reconstructPointCloud( tmc2_frame* f ) {
   if ( !f->haveGeometryImages ) {
-    setError( "generateAttributeImages: geometry images missing" );
+    setError( "generatePointCloud: geometry images missing" );
     return TMC2_E_STATE;
   }
-  if ( f->d_rgb.count == 0 ) {
-    setError( "generateAttributeImages: the frame has no colours" );
-    return TMC2_E_STATE;
-  }
-  TMC2_TRY( f->ensureTree() );
-  f->haveAttributeImages = false;
+  f->haveReconstruction = f->haveAttributeImages = false;
   f->haveBoundaryTypes = f->haveColors16 = f->haveSmoothed = f->haveRgbPost = false;
   tmc2_ctx*    ctx = f->ctx;
   hipStream_t  s   = ctx->stream;
   const int    W = f->canvasW, H = f->canvasH, prec = f->occPrecision;
-  const size_t area = size_t( W ) * H;
   const dim3   blk( 256 );
-  const uint32_t tiles = f->tileCount, n = uint32_t( f->n );
+  const uint32_t tiles = f->tileCount;
   // ---- S17 ----------------------------------------------------------------------------------------------
   int sid = ctx->stageBegin( "reconstruct" );
   DevBuf<uint32_t> d_tileCount, d_tileOffset, d_small;
@@ -372,7 +368,7 @@ int generateAttributeImages( tmc2_frame* f ) {
   }
   if ( M == 0 ) {
     ctx->stageEnd( sid );
-    setError( "generateAttributeImages: empty reconstruction" );
+    setError( "generatePointCloud: empty reconstruction" );
     return TMC2_E_STATE;
   }
   TMC2_TRY( f->d_recon.alloc( M ) );
@@ -394,7 +390,7 @@ int generateAttributeImages( tmc2_frame* f ) {
     Pt*       hp = ctx->hostD.get<Pt>( M );
     uint32_t* hi = ctx->hostA.get<uint32_t>( M );
     if ( !hp || !hi ) {
-      setError( "generateAttributeImages: hipHostMalloc failed" );
+      setError( "generatePointCloud: hipHostMalloc failed" );
       return TMC2_E_HIP;
     }
     TMC2_HIP( hipMemcpyAsync( hp, f->d_recon.p, size_t( M ) * sizeof( Pt ), hipMemcpyDeviceToHost, s ) );
@@ -415,6 +411,30 @@ int generateAttributeImages( tmc2_frame* f ) {
                               hipMemcpyHostToDevice, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
   }
+  f->haveReconstruction = true;
+  return TMC2_OK;
+}
+
+int generateAttributeImages( tmc2_frame* f ) {
+  if ( !f->haveGeometryImages ) {
+    setError( "generateAttributeImages: geometry images missing" );
+    return TMC2_E_STATE;
+  }
+  if ( f->d_rgb.count == 0 ) {
+    setError( "generateAttributeImages: the frame has no colours" );
+    return TMC2_E_STATE;
+  }
+  TMC2_TRY( f->ensureTree() );
+  TMC2_TRY( reconstructPointCloud( f ) );
+  tmc2_ctx*    ctx = f->ctx;
+  hipStream_t  s   = ctx->stream;
+  const int    W = f->canvasW, H = f->canvasH, prec = f->occPrecision;
+  const size_t area = size_t( W ) * H;
+  const dim3   blk( 256 );
+  const uint32_t n = uint32_t( f->n ), M = uint32_t( f->reconCount );
+  int          sid = 0;
+  DevBuf<uint32_t> d_small;
+  TMC2_TRY( d_small.alloc( 8 ) );
   TreeDev rt;
   rt.ptsTree = f->d_reconTreePts.p;
   rt.perm    = f->d_reconPerm.p;
@@ -566,27 +586,37 @@ int tmc2_transfer_colors( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
   return TMC2_OK;
 }
 
+int tmc2_codec_generate_point_cloud( tmc2_frame* f ) {
+  if ( !f ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( f->ctx );
+  return tmc2::reconstructPointCloud( f );
+}
+
 int tmc2_encoder_generate_attribute_images( tmc2_frame* f ) {
   if ( !f ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   return tmc2::generateAttributeImages( f );
 }
 
-int64_t tmc2_frame_recon_count( tmc2_frame* f ) { return ( f && f->haveAttributeImages ) ? int64_t( f->reconCount ) : 0; }
+int64_t tmc2_frame_recon_count( tmc2_frame* f ) { return ( f && f->haveReconstruction ) ? int64_t( f->reconCount ) : 0; }
 
 int tmc2_frame_get_reconstruction( tmc2_frame* f, int16_t* xyz, uint8_t* rgb, uint32_t* pointToPixel ) {
-  if ( !f || !f->haveAttributeImages ) {
+  if ( !f || !f->haveReconstruction ) {
     tmc2::setError( "get_reconstruction: not generated" );
+    return TMC2_E_STATE;
+  }
+  if ( rgb && !f->haveAttributeImages ) {
+    tmc2::setError( "get_reconstruction: no transferred colours (tmc2_encoder_generate_attribute_images produces them)" );
     return TMC2_E_STATE;
   }
   tmc2::ApiScope scope( f->ctx );
   hipStream_t    s = f->ctx->stream;
   const size_t   M = f->reconCount;
   std::vector<tmc2::Pt>  pts( M );
-  std::vector<uint8_t>   c4( 4 * M );
+  std::vector<uint8_t>   c4( rgb ? 4 * M : 0 );
   std::vector<uint32_t>  pp( M );
   TMC2_HIP( hipMemcpyAsync( pts.data(), f->d_recon.p, M * sizeof( tmc2::Pt ), hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipMemcpyAsync( c4.data(), f->d_reconRgb.p, 4 * M, hipMemcpyDeviceToHost, s ) );
+  if ( rgb ) TMC2_HIP( hipMemcpyAsync( c4.data(), f->d_reconRgb.p, 4 * M, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipMemcpyAsync( pp.data(), f->d_pointToPixel.p, 4 * M, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   for ( size_t i = 0; i < M; ++i ) {

@@ -22,6 +22,8 @@
 //   * empty blocks copy their left neighbour's last column (first block column: the bottom row of the block
 //     above) IN RASTER BLOCK ORDER in the reference; that is a prefix "carry" along each pixel row, done by
 //     one lane per pixel row after the first block column has been resolved top-down.
+#include <memory>
+
 #include "internal.h"
 
 namespace tmc2 {
@@ -203,6 +205,91 @@ __global__ __launch_bounds__( 256 ) void groupDilateKernel( const uint8_t* __res
 
 }  // namespace
 
+// placement table + list of 16x16 patch blocks, both in packing order: what the raster and the reconstruction kernels index
+int uploadPlacement( tmc2_frame* f ) {
+  const int             P = int( f->patches.size() );
+  std::vector<PlaceDev> place;
+  place.resize( size_t( P ) );
+  std::vector<uint32_t> tilePatch;
+  for ( int k = 0; k < P; ++k ) {
+    const tmc2_patch& t = f->patches[size_t( f->packOrder[size_t( k )] )];
+    PlaceDev&         d = place[size_t( k )];
+    d.u0 = t.u0, d.v0 = t.v0, d.orient = t.patchOrientation;
+    d.sizeU = t.sizeU, d.sizeV = t.sizeV, d.sizeU0 = t.sizeU0, d.sizeV0 = t.sizeV0;
+    d.tileBase = int32_t( tilePatch.size() );
+    d.depthOff = t.depthOffset;
+    d.u1 = t.u1, d.v1 = t.v1, d.d1 = t.d1;
+    d.axN = t.normalAxis, d.axT = t.tangentAxis, d.axB = t.bitangentAxis, d.mode = t.projectionMode;
+    d.pad = 0;
+    if ( t.patchOrientation != 0 && t.patchOrientation != 1 ) {
+      setError( "patch orientation %d unsupported", t.patchOrientation );
+      return TMC2_E_UNSUPPORTED;
+    }
+    if ( t.sizeU0 < 0 || t.sizeV0 < 0 || t.u0 < 0 || t.v0 < 0 ) {
+      setError( "patch %d: negative block size or position", k );
+      return TMC2_E_INVALID;
+    }
+    tilePatch.insert( tilePatch.end(), size_t( t.sizeU0 ) * size_t( t.sizeV0 ), uint32_t( k ) );
+  }
+  hipStream_t s = f->ctx->stream;
+  TMC2_TRY( f->d_place.alloc( size_t( std::max( P, 1 ) ) ) );
+  TMC2_TRY( f->d_tilePatch.alloc( std::max<size_t>( tilePatch.size(), 1 ) ) );
+  if ( P ) {
+    TMC2_HIP( hipMemcpyAsync( f->d_place.p, place.data(), size_t( P ) * sizeof( PlaceDev ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( f->d_tilePatch.p, tilePatch.data(), tilePatch.size() * 4, hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );  // the staging vectors go out of scope
+  }
+  f->tileCount = uint32_t( tilePatch.size() );
+  return TMC2_OK;
+}
+
+// decoder side: a frame that has no source cloud, only what the bitstream carries -- patch records in list order, the
+// decoded occupancy video and the two decoded geometry maps.  blockToPatch is derived here (S13).
+int createDecoderFrame( tmc2_ctx* ctx, const tmc2_patch* patches, int count, int W, int H, int occPrecision, const uint8_t* occVideo,
+                        const uint16_t* geometry, tmc2_frame** out ) {
+  if ( W <= 0 || H <= 0 || W % 16 || H % 16 || occPrecision < 1 || 16 % occPrecision ) {
+    setError( "decoder_frame_create: unsupported geometry %dx%d, precision %d", W, H, occPrecision );
+    return TMC2_E_UNSUPPORTED;
+  }
+  std::unique_ptr<tmc2_frame> f( new tmc2_frame() );
+  f->ctx = ctx;
+  f->n   = 0;
+  f->patches.assign( patches, patches + count );
+  f->packOrder.resize( size_t( count ) );
+  for ( int k = 0; k < count; ++k ) {
+    f->packOrder[size_t( k )] = k;
+    const tmc2_patch& t = f->patches[size_t( k )];
+    const int bw = t.patchOrientation == 0 ? t.sizeU0 : t.sizeV0, bh = t.patchOrientation == 0 ? t.sizeV0 : t.sizeU0;
+    if ( t.u0 < 0 || t.v0 < 0 || ( t.u0 + bw ) * 16 > W || ( t.v0 + bh ) * 16 > H ) {
+      setError( "decoder_frame_create: patch %d lies outside the %dx%d canvas", k, W, H );
+      return TMC2_E_INVALID;
+    }
+  }
+  f->packMatch.assign( size_t( count ), -1 );
+  f->havePatches = f->havePacking = true;
+  hipStream_t  s    = ctx->stream;
+  const size_t area = size_t( W ) * H;
+  const int    Wv = W / occPrecision, Hv = H / occPrecision, Wb = W / 16, Hb = H / 16;
+  TMC2_TRY( uploadPlacement( f.get() ) );
+  TMC2_TRY( f->d_occVideo.alloc( size_t( Wv ) * Hv ) );
+  TMC2_TRY( f->d_blockToPatch.alloc( size_t( Wb ) * Hb ) );
+  TMC2_TRY( f->d_geo.alloc( 2 * area ) );
+  TMC2_TRY( f->d_occMap.alloc( area ) );
+  TMC2_HIP( hipMemcpyAsync( f->d_occVideo.p, occVideo, size_t( Wv ) * Hv, hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( f->d_geo.p, geometry, 2 * area * sizeof( uint16_t ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemsetAsync( f->d_occMap.p, 0, area, s ) );  // (the precise encoder-side map does not exist on this side)
+  const int sid = ctx->stageBegin( "block_to_patch" );
+  hipLaunchKernelGGL( blockToPatchKernel, dim3( ( Wb * Hb + 255 ) / 256 ), dim3( 256 ), 0, s, f->d_place.p, count, f->d_occVideo.p, Wb,
+                      Hb, Wv, occPrecision, f->d_blockToPatch.p );
+  ctx->stageEnd( sid );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  TMC2_HIP( hipGetLastError() );
+  f->canvasW = W, f->canvasH = H, f->occPrecision = occPrecision;
+  f->haveGeometryImages = true;
+  *out                  = f.release();
+  return TMC2_OK;
+}
+
 int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision ) {
   if ( !f->havePacking ) {
     setError( "generateGeometryImages: frame not packed" );
@@ -218,31 +305,11 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
   const int   P   = int( f->patches.size() );
   const size_t area = size_t( W ) * H;
   const int    Wv = W / occPrecision, Hv = H / occPrecision, Wb = W / 16, Hb = H / 16;
-  // placement table + tile list in packing order
-  std::vector<PlaceDev> place( P );
-  std::vector<uint32_t> tilePatch;
-  for ( int k = 0; k < P; ++k ) {
-    const tmc2_patch& t = f->patches[f->packOrder[k]];
-    PlaceDev&         d = place[k];
-    d.u0 = t.u0, d.v0 = t.v0, d.orient = t.patchOrientation;
-    d.sizeU = t.sizeU, d.sizeV = t.sizeV, d.sizeU0 = t.sizeU0, d.sizeV0 = t.sizeV0;
-    d.tileBase = int32_t( tilePatch.size() );
-    d.depthOff = t.depthOffset;
-    d.u1 = t.u1, d.v1 = t.v1, d.d1 = t.d1;
-    d.axN = t.normalAxis, d.axT = t.tangentAxis, d.axB = t.bitangentAxis, d.mode = t.projectionMode;
-    d.pad = 0;
-    if ( t.patchOrientation != 0 && t.patchOrientation != 1 ) {
-      setError( "generateGeometryImages: patch orientation %d unsupported", t.patchOrientation );
-      return TMC2_E_UNSUPPORTED;
-    }
-    tilePatch.insert( tilePatch.end(), size_t( t.sizeU0 ) * t.sizeV0, uint32_t( k ) );
-  }
+  TMC2_TRY( uploadPlacement( f ) );
   DevBuf<PlaceDev>& d_place     = f->d_place;
   DevBuf<uint32_t>& d_tilePatch = f->d_tilePatch;
   DevBuf<uint32_t>  d_err;
   DevBuf<uint8_t>  d_empty;
-  TMC2_TRY( d_place.alloc( std::max( P, 1 ) ) );
-  TMC2_TRY( d_tilePatch.alloc( std::max<size_t>( tilePatch.size(), 1 ) ) );
   TMC2_TRY( d_err.alloc( 1 ) );
   TMC2_TRY( d_empty.alloc( size_t( Wb ) * Hb ) );
   TMC2_TRY( f->d_occMap.alloc( area ) );
@@ -250,16 +317,12 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
   TMC2_TRY( f->d_blockToPatch.alloc( size_t( Wb ) * Hb ) );
   TMC2_TRY( f->d_geo.alloc( 2 * area ) );
   const int sid = ctx->stageBegin( "geometry_images" );
-  if ( P ) {
-    TMC2_HIP( hipMemcpyAsync( d_place.p, place.data(), size_t( P ) * sizeof( PlaceDev ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( d_tilePatch.p, tilePatch.data(), tilePatch.size() * 4, hipMemcpyHostToDevice, s ) );
-  }
   TMC2_HIP( hipMemsetAsync( d_err.p, 0, 4, s ) );
   TMC2_HIP( hipMemsetAsync( f->d_occMap.p, 0, area, s ) );
   TMC2_HIP( hipMemsetAsync( f->d_geo.p, 0, 2 * area * sizeof( uint16_t ), s ) );
   const dim3 blk( 256 );
-  if ( !tilePatch.empty() )
-    hipLaunchKernelGGL( rasterTileKernel, dim3( uint32_t( tilePatch.size() ) ), blk, 0, s, d_place.p, d_tilePatch.p,
+  if ( f->tileCount )
+    hipLaunchKernelGGL( rasterTileKernel, dim3( f->tileCount ), blk, 0, s, d_place.p, d_tilePatch.p,
                         f->d_depth0.p, f->d_depth1.p, W, H, f->d_occMap.p, f->d_geo.p, f->d_geo.p + area, d_err.p );
   hipLaunchKernelGGL( occVideoKernel, dim3( ( Wv * Hv + 255 ) / 256 ), blk, 0, s, f->d_occMap.p, W, Wv, Hv, occPrecision,
                       f->d_occVideo.p );
@@ -279,7 +342,6 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
     setError( "generateGeometryImages: a patch falls outside the %dx%d canvas (the reference exits with code 180)", W, H );
     return TMC2_E_INVALID;
   }
-  f->tileCount          = uint32_t( tilePatch.size() );
   f->canvasW            = W;
   f->canvasH            = H;
   f->occPrecision       = occPrecision;
@@ -295,6 +357,14 @@ int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height,
   if ( !f ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   return tmc2::generateGeometryImages( f, width, height, 16, occupancyPrecision );
+}
+
+int tmc2_decoder_frame_create( tmc2_ctx* ctx, const tmc2_patch* patches, int count, int width, int height, int occupancyPrecision,
+                               const uint8_t* occVideo, const uint16_t* geometry, tmc2_frame** out ) {
+  if ( !ctx || !out || count < 0 || ( count && !patches ) || !occVideo || !geometry ) return TMC2_E_INVALID;
+  *out = nullptr;
+  tmc2::ApiScope scope( ctx );
+  return tmc2::createDecoderFrame( ctx, patches, count, width, height, occupancyPrecision, occVideo, geometry, out );
 }
 
 int tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo, const uint16_t* geometry ) {

@@ -247,7 +247,7 @@ struct tmc2_frame {
   uint32_t                tileCount = 0;
   // phase B: reconstruction + attribute images
   uint64_t                reconCount = 0;
-  bool                    haveAttributeImages = false;
+  bool                    haveAttributeImages = false, haveReconstruction = false;
   tmc2::DevBuf<tmc2::Pt>  d_recon;              // reconstructed points (generatePointCloud order)
   tmc2::DevBuf<uint32_t>  d_pointToPixel;       // x | y << 12 | layer << 24 | hasD1 << 25
   tmc2::DevBuf<uint8_t>   d_reconRgb;           // [M][4]
@@ -291,6 +291,8 @@ int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint
                    uint32_t* d_dist, const char* stage );
 TreeDev frameTree( const tmc2_frame* f );
 int generateAttributeImages( tmc2_frame* f );
+int reconstructPointCloud( tmc2_frame* f );
+int uploadPlacement( tmc2_frame* f );
 int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int ensureMutualMask( tmc2_frame* f );  // k = 16 only

@@ -346,8 +346,8 @@ TreeDev reconTreeDev( const tmc2_frame* f ) {
   return rt;
 }
 int needReconstruction( tmc2_frame* f, const char* who ) {
-  if ( !f->haveAttributeImages || f->reconCount == 0 ) {
-    setError( "%s: the frame has no reconstruction (tmc2_encoder_generate_attribute_images first)", who );
+  if ( !f->haveReconstruction || f->reconCount == 0 ) {
+    setError( "%s: the frame has no reconstruction (tmc2_codec_generate_point_cloud or tmc2_encoder_generate_attribute_images first)", who );
     return TMC2_E_STATE;
   }
   return TMC2_OK;

@@ -153,6 +153,21 @@ class Context:
         return out
 
     # PCCMetrics::compute (one frame)
+    def decoder_frame(self, patches, width, height, occ_precision, occ_video, geometry):
+        """A frame without a source cloud: decoded patch records (list order), occupancy video, geometry maps [2][H][W]."""
+        pt = np.ascontiguousarray(patches, dtype=PATCH_DTYPE)
+        ov = np.ascontiguousarray(occ_video, dtype=np.uint8)
+        geo = np.ascontiguousarray(geometry, dtype=np.uint16)
+        if ov.shape != (height // occ_precision, width // occ_precision) or geo.shape != (2, height, width):
+            raise ValueError("decoded canvases do not match %dx%d at precision %d" % (width, height, occ_precision))
+        fr = Frame.__new__(Frame)
+        fr.L, fr.ctx, fr.h = self.L, self, C.c_void_p()
+        fr._xyz, fr._rgb, fr.n = None, None, 0
+        _check(self.L.tmc2_decoder_frame_create(self.h, _ptr(pt), len(pt), int(width), int(height), int(occ_precision), _ptr(ov),
+                                               _ptr(geo), C.byref(fr.h)))
+        fr._canvas = (int(width), int(height), int(occ_precision))
+        return fr
+
     # PCCInternalColorConverter (the attribute video's colour-space conversion)
     def color_convert_rgb444_to_yuv420(self, rgb, downsampling_filter=4):
         """rgb uint8 [3][H][W] -> (y [H][W], u, v [H/2][W/2])"""
@@ -351,12 +366,16 @@ class Frame:
     def encoder_generate_attribute_images(self):
         _check(self.L.tmc2_encoder_generate_attribute_images(self.h))
 
-    def get_reconstruction(self):
+    def get_reconstruction(self, colors=True):
         self.L.tmc2_frame_recon_count.restype = C.c_int64
         M = self.L.tmc2_frame_recon_count(self.h)
-        xyz, rgb, p2p = np.zeros((M, 3), np.int16), np.zeros((M, 3), np.uint8), np.zeros((M, 3), np.uint32)
-        _check(self.L.tmc2_frame_get_reconstruction(self.h, _ptr(xyz), _ptr(rgb), _ptr(p2p)))
+        xyz, rgb, p2p = np.zeros((M, 3), np.int16), (np.zeros((M, 3), np.uint8) if colors else None), np.zeros((M, 3), np.uint32)
+        _check(self.L.tmc2_frame_get_reconstruction(self.h, _ptr(xyz), None if rgb is None else _ptr(rgb), _ptr(p2p)))
         return xyz, rgb, p2p
+
+    def codec_generate_point_cloud(self):
+        """PCCCodec::generatePointCloud alone (no colour transfer, no attribute images)."""
+        _check(self.L.tmc2_codec_generate_point_cloud(self.h))
 
     # post-reconstruction tail (PCCEncoder::encode :571-719 / PCCDecoder::decode :330-470)
     def codec_identify_boundary_points(self):

@@ -384,3 +384,45 @@ def test_gpu_color_conversion_matches_oracle(gpu_ctx, oracle, kind, H, W):
     assert np.array_equal(gpu_ctx.color_convert_yuv420_to_yuv444(y2, u2, v2), oracle.convert_yuv420_to_yuv444(y2, u2, v2))
     with pytest.raises(T.Tmc2Error):
         gpu_ctx.color_convert_rgb444_to_yuv420(rgb, downsampling_filter=2)     # only the reference's default filters are built
+
+
+@pytest.mark.parametrize("name,prec", [("small", 4), ("small", 2)])
+def test_gpu_decoder_side_reconstruction(gpu_ctx, oracle, name, prec):
+    """The decoder's way to the finished cloud: a frame made of decoded patch records, occupancy video and geometry maps only
+    (no source cloud) -> generatePointCloud -> colour conversion of the decoded I420 attribute frames -> the tail; against the
+    oracle, and identical to what the encoder-side frame it was cut from produces."""
+    xyz, rgb = synth_cloud(name, 2)
+    enc = gpu_ctx.frame(xyz, rgb)
+    enc.segmenter_compute(T.ctc_params(10, 11, enc.weight_normal(11, 0.6)))
+    h = enc.encoder_pack_flexible(1280, 2, 1.0)
+    W, H = T.encoder_canvas_size([h], 1280, 1280, 1280)
+    enc.encoder_generate_geometry_images(W, H, prec)
+    enc.encoder_generate_attribute_images()
+    img = enc.get_geometry_images()
+    i420 = enc.encoder_attribute_to_yuv420(4)
+    patches = enc.get_patches()[0][enc.get_patch_order()]
+    sent = np.zeros(len(patches), patches.dtype)                     # only what the bitstream carries
+    for k in ("u0", "v0", "sizeU0", "sizeV0", "patchOrientation", "u1", "v1", "d1", "normalAxis", "tangentAxis", "bitangentAxis",
+              "projectionMode"):
+        sent[k] = patches[k]
+    sent["sizeU"], sent["sizeV"] = sent["sizeU0"] * 16, sent["sizeV0"] * 16      # (the decoder knows block sizes only)
+    dec = gpu_ctx.decoder_frame(sent, W, H, prec, img["occ_video"], np.stack([img["geo0"], img["geo1"]]))
+    assert np.array_equal(dec.get_geometry_images()["block_to_patch"], img["block_to_patch"])
+    dec.codec_generate_point_cloud()
+    rx, _, rp = dec.get_reconstruction(colors=False)
+    ex, _, ep = enc.get_reconstruction()
+    assert np.array_equal(rx, ex) and np.array_equal(rp, ep)
+    with pytest.raises(T.Tmc2Error):
+        dec.get_reconstruction(colors=True)                          # no colour transfer happened on this side
+    dec.codec_set_decoded_attribute_yuv420(i420, 0)
+    dec.codec_post_reconstruct(None)
+    got = dec.get_post_reconstruction()
+    enc.codec_set_decoded_attribute_yuv420(i420, 0)
+    enc.codec_post_reconstruct(None)
+    same = enc.get_post_reconstruction()
+    a = dict(img, width=W, height=H)
+    b = dict(recon_xyz=ex, point_to_pixel=ep)
+    exp = oracle.phase_c([a], [b], [dec.get_decoded_attribute()], prec)[0]
+    for k in ("xyz", "colors16", "rgb", "boundary"):
+        assert np.array_equal(got[k], exp[k]), k
+        assert np.array_equal(got[k], same[k]), k
