@@ -170,6 +170,9 @@ int tmc2_encoder_pack_flexible( tmc2_frame* f, int presetWidth, int numTilesHor,
  * in the previous frame's order and if possible at the previous position.  `previous` must be packed already.       */
 int tmc2_encoder_pack_spatial_consistency( tmc2_frame* f, tmc2_frame* previous, int presetWidth, int numTilesHor,
                                            double tileHeightToWidthRatio, int32_t* height );
+/* the tile size the packers left behind (what resizeTileGeometryVideo / resizeGeometryVideo look at): packFlexible keeps the
+ * preset width, spatialConsistencyPackFlexible and the global patch allocation set the width of the canvas they packed on */
+int tmc2_frame_get_packed_size( tmc2_frame* f, int32_t* width, int32_t* height );
 /* per list position: the position of the matched patch in the previous frame's list (PCCPatch::getBestMatchIdx), -1 = none
  * (all -1 after tmc2_encoder_pack_flexible) */
 int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches );

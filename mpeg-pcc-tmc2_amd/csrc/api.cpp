@@ -358,7 +358,7 @@ int tmc2_frame_reset( tmc2_frame* f ) {
   f->packOrder.clear();
   f->packMatch.clear();
   f->depthCount = f->occCount = 0;
-  f->rounds = f->packedHeight = 0;
+  f->rounds = f->packedHeight = f->packedWidth = 0;
   return TMC2_OK;
 }
 

@@ -118,7 +118,7 @@ class Allocator {
  private:
   std::vector<Tile>& T;
   const int          minW_, minH_, res_;
-  bool               runaway_ = false;
+  bool               runaway_ = false, outside_ = false;
   static constexpr int kRunawayRows = 1 << 20;
 
   void extent( Tile& t, const Layout& l ) const {
@@ -269,11 +269,20 @@ int Allocator::packUnions( const std::vector<Track>& tracks, int frameWidth, std
     Layout l;
     l.sizeU0 = U.sizeU0, l.sizeV0 = U.sizeV0, l.orient = U.orient;
     for ( ;; ) {
-      const bool bound = useRef && l.orient != kUnset;  // an inherited orientation is binding
-      if ( bound ? scanFixed( canvas, l ) : scanFree( canvas, l, U.sizeU0, U.sizeV0 ) ) break;
-      // nothing free at this height.  The reference leaves the orientation it tried last in place, and in a sub-context
-      // with a reference frame that orientation is binding for the taller canvas
-      if ( !bound ) l.orient = preferredOrientation( U.sizeU0, U.sizeV0, 1 );
+      // In a sub-context with a reference frame an orientation, once set, is binding -- and the reference SETS it by merely
+      // trying: a union without an inherited orientation gets both orientations at the first position only; if neither
+      // fits there, the one tried last stays and is the only one tried from the next position on, also after the canvas
+      // has been doubled.  Without a reference frame both orientations are tried everywhere.
+      bool found = false;
+      if ( useRef && l.orient == kUnset && canvas.width() > 0 && canvas.height() > 0 ) {
+        for ( int k = 0; k < 2 && !found; ++k ) {
+          const int o = preferredOrientation( U.sizeU0, U.sizeV0, k );
+          if ( canvas.accepts( l.sizeU0, l.sizeV0, 0, 0, o ) ) l.u0 = 0, l.v0 = 0, l.orient = o, found = true;
+        }
+        if ( !found ) l.orient = preferredOrientation( U.sizeU0, U.sizeV0, 1 );
+      }
+      if ( !found ) found = ( useRef && l.orient != kUnset ) ? scanFixed( canvas, l ) : scanFree( canvas, l, U.sizeU0, U.sizeV0 );
+      if ( found ) break;
       if ( canvas.height() > kRunawayRows ) {
         runaway_ = true;
         l.u0 = l.v0 = 0, l.orient = 0;
@@ -322,6 +331,13 @@ bool Allocator::completeFrames( int first, int end, const std::vector<UnionBox>&
       if ( !l.tracked() ) continue;
       const UnionBox& U = unions[size_t( l.track )];
       l.u0 = U.u0, l.v0 = U.v0, l.orient = U.orient;
+      {  // the unions were packed on the GOF-wide tile, this frame's canvas can be narrower: the reference writes outside its map
+        const int bw = l.orient == 0 ? l.sizeU0 : l.sizeV0, bh = l.orient == 0 ? l.sizeV0 : l.sizeU0;
+        if ( l.u0 + bw > canvas.width() || l.v0 + bh > canvas.height() ) {
+          outside_ = true;
+          return false;
+        }
+      }
       canvas.stamp( l.occ.data(), l.sizeU0, l.sizeU0, l.sizeV0, l.u0, l.v0, l.orient );
       extent( t, l );
     }
@@ -441,6 +457,10 @@ int Allocator::run() {
         T[fi].items[k].trial.track = int( k );
       }
       openSubContext( fi, first != 0 );
+      if ( runaway_ ) {
+        setError( "global patch allocation: a patch of frame %d cannot be placed at any canvas height", fi );
+        return TMC2_E_INVALID;
+      }
       keepTrial( first, end );
       dropTrial( first, end );
       T[fi].trialW = T[fi].trialH = 0;
@@ -462,6 +482,11 @@ int Allocator::run() {
     if ( runaway_ ) {
       setError( "global patch allocation: a patch of frame %d cannot be placed at any canvas height", fi );
       return TMC2_E_INVALID;
+    }
+    if ( outside_ ) {
+      setError( "global patch allocation: a union placed on the GOF-wide tile lies outside a frame's own canvas (sub-context ending "
+                "at frame %d; undefined in the reference)", fi );
+      return TMC2_E_UNSUPPORTED;
     }
     if ( !ok ) {
       // the kept layout of [first, end) stands; this frame opens the next sub-context
@@ -539,12 +564,8 @@ int globalPatchAllocationFrames( tmc2_frame** fr, int count, int minW, int minH,
     g.list.resize( f->patches.size() );
     g.match = f->packMatch;
     g.match.resize( f->patches.size(), -1 );
-    int w = minW / occRes;
-    for ( size_t k = 0; k < g.list.size(); ++k ) {
-      g.list[k] = f->patches[size_t( f->packOrder[k] )];
-      w         = std::max( w, g.list[k].sizeU0 + 1 );
-    }
-    tileW = std::max( tileW, w * occRes );
+    for ( size_t k = 0; k < g.list.size(); ++k ) g.list[k] = f->patches[size_t( f->packOrder[k] )];
+    tileW = std::max( tileW, f->packedWidth );  // (a frame packed by packFlexible kept the preset width, whatever its patches need)
     tileH = std::max( tileH, f->packedHeight );
     TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
   }
@@ -565,6 +586,7 @@ int globalPatchAllocationFrames( tmc2_frame** fr, int count, int minW, int minH,
       TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
     }
     f->packedHeight       = g.height;
+    f->packedWidth        = g.width;
     f->haveGeometryImages = f->haveAttributeImages = false;
     if ( widths ) widths[i] = g.width;
     if ( heights ) heights[i] = g.height;

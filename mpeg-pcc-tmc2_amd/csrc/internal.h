@@ -235,7 +235,7 @@ struct tmc2_frame {
   int                     growPools();         // make the pools hold depthCount / occCount entries (keeps content)
   // packing + canvases (phase A images)
   std::vector<int32_t>    packOrder;            // packing order: list position -> patch index
-  int                     packedHeight = 0;
+  int                     packedHeight = 0, packedWidth = 0;  // tile size as the reference's packers leave it
   bool                    havePacking = false, haveGeometryImages = false;
   int                     canvasW = 0, canvasH = 0, occPrecision = 0;
   tmc2::DevBuf<uint8_t>   d_occMap;             // W*H precise occupancy

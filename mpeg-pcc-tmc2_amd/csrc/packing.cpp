@@ -59,6 +59,7 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
   f->packMatch.assign( P, -1 );
   for ( int i = 0; i < P; ++i ) f->packOrder[i] = i;
   f->packedHeight = 0;
+  f->packedWidth  = presetWidth;
   f->havePacking  = true;
   if ( P == 0 ) return TMC2_OK;
   // per-block occupancy of the patches comes back from the device (a few KB)
@@ -100,7 +101,13 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
               placed             = true;
             }
           }
-      if ( !placed ) canvas.grow( canvas.height * 2 );
+      if ( !placed ) {
+        if ( canvas.height > ( size_t( 1 ) << 20 ) ) {
+          setError( "packFlexible: patch %d fits at no canvas height", f->packOrder[k] );
+          return TMC2_E_INVALID;
+        }
+        canvas.grow( canvas.height * 2 );
+      }
     }
     const uint8_t* o = occ.data() + p.occOffset;
     for ( int vb = 0; vb < p.sizeV0; ++vb )
@@ -114,6 +121,7 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
     heightBlocks = std::max( heightBlocks, size_t( p.v0 + ( p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0 ) ) );
   }
   f->packedHeight = int( heightBlocks ) * occRes;
+  f->packedWidth  = presetWidth;  // packFlexible works on a COPY of the tile width (PCCEncoder.cpp:2312): the tile keeps its own
   return TMC2_OK;
 }
 
@@ -218,7 +226,11 @@ int packSpatialConsistencyCore( tmc2_patch* pt, int P, const uint8_t* occ, const
               }
             }
       }
-      if ( !placed ) canvas.grow( canvas.height * 2 );
+      if ( !placed ) {
+        if ( canvas.height > ( size_t( 1 ) << 20 ) ) return -1;  // fits at no canvas height (e.g. the orientation inherited from the
+                                                                  // match makes it wider than the canvas): the reference spins here
+        canvas.grow( canvas.height * 2 );
+      }
     }
     const uint8_t* o = occ + p.occOffset;
     for ( int vb = 0; vb < p.sizeV0; ++vb )
@@ -253,6 +265,16 @@ int packSpatialConsistencyHost( tmc2_frame* f, tmc2_frame* prevFrame, int preset
   f->packedHeight = packSpatialConsistencyCore( f->patches.data(), P, occ.data(), prevList.data(), int( prevList.size() ),
                                                 presetWidth, occRes, numTilesHor, ratio, f->packOrder.data(),
                                                 f->packMatch.data() );
+  {  // spatialConsistencyPackFlexible updates the tile width through a reference (:1190, :1308): the canvas it packed on
+    int sizeU = presetWidth / occRes;
+    for ( auto& p : f->patches ) sizeU = std::max( sizeU, p.sizeU0 + 1 );
+    f->packedWidth = sizeU * occRes;
+  }
+  if ( f->packedHeight < 0 ) {
+    f->havePacking = false;
+    setError( "packSpatialConsistency: a patch fits at no canvas height" );
+    return TMC2_E_INVALID;
+  }
   return TMC2_OK;
 }
 
@@ -278,6 +300,16 @@ int tmc2_encoder_pack_spatial_consistency( tmc2_frame* f, tmc2_frame* previous, 
   return TMC2_OK;
 }
 
+int tmc2_frame_get_packed_size( tmc2_frame* f, int32_t* width, int32_t* height ) {
+  if ( !f || !f->havePacking ) {
+    tmc2::setError( "get_packed_size: frame not packed" );
+    return TMC2_E_STATE;
+  }
+  if ( width ) *width = f->packedWidth;
+  if ( height ) *height = f->packedHeight;
+  return TMC2_OK;
+}
+
 int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches ) {
   if ( !f || !matches || !f->havePacking ) {
     tmc2::setError( "get_patch_matches: frame not packed" );
@@ -295,6 +327,10 @@ int tmc2_host_pack_spatial_consistency( tmc2_patch* patches, int count, const ui
     return TMC2_E_INVALID;
   *height = tmc2::packSpatialConsistencyCore( patches, count, occupancy, previous, previousCount, presetWidth, 16, numTilesHor,
                                               tileHeightToWidthRatio, order, matches );
+  if ( *height < 0 ) {
+    tmc2::setError( "host_pack_spatial_consistency: a patch fits at no canvas height" );
+    return TMC2_E_INVALID;
+  }
   return TMC2_OK;
 }
 

@@ -214,7 +214,9 @@ class GofEncoder:
         else:
             heights = self._per_worker(frames, segment_and_pack)
         gof_h = sharder.max_height(heights)
-        W, H = lib.encoder_canvas_size([gof_h], self.min_w, self.min_w, self.min_h)
+        # the chained packer writes the width of its canvas back into the tile (a patch wider than the preset width widens it)
+        tile_w = max([self.min_w] + [fr.get_packed_size()[0] for fr in frames]) if constrained_pack else self.min_w
+        W, H = lib.encoder_canvas_size([gof_h], tile_w, self.min_w, self.min_h)
         self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
         return W, H
 

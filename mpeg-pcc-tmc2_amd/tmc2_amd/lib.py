@@ -337,6 +337,12 @@ class Frame:
                                                             C.c_double(ratio), C.byref(h)))
         return h.value
 
+    def get_packed_size(self):
+        """(width, height) of the tile as the packers left it."""
+        w, h = C.c_int32(), C.c_int32()
+        _check(self.L.tmc2_frame_get_packed_size(self.h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
     def get_patch_matches(self):
         m = np.zeros(self.L.tmc2_frame_patch_count(self.h), np.int32)
         _check(self.L.tmc2_frame_get_patch_matches(self.h, _ptr(m)))

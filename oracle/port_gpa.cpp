@@ -27,6 +27,8 @@
 namespace {
 enum { ORIENT_DEFAULT = 0, ORIENT_SWAP = 1 };
 constexpr size_t kNone = size_t( -1 );
+struct Runaway {};
+struct OutOfCanvas {};
 
 struct GpaData {
   bool                 isMatched = false, isGlobal = false;
@@ -51,6 +53,7 @@ struct WFrame {
 struct Gpa {
   std::vector<WFrame> frames;
   int                 minW, minH, occRes;
+  bool                undefined = false;
 };
 using Tracks = std::map<size_t, std::vector<std::pair<size_t, size_t>>>;  // track -> [(frame, patch position)]
 struct Union {
@@ -110,7 +113,8 @@ void mark( std::vector<uint8_t>& map, size_t stride, size_t rows, const GpaData&
            size_t occStride ) {
   for ( size_t vb = 0; vb < g.sizeV0; ++vb )
     for ( size_t ub = 0; ub < g.sizeU0; ++ub ) {
-      const int pos         = canvasBlock( ub, vb, g.u0, g.v0, g.orient, stride, rows );
+      const int pos = canvasBlock( ub, vb, g.u0, g.v0, g.orient, stride, rows );
+      if ( pos < 0 ) throw OutOfCanvas();  // the reference writes occupancyMap[-1] here
       map[size_t( pos )] = map[size_t( pos )] || occ[vb * occStride + ub];
     }
 }
@@ -155,6 +159,7 @@ void packingFirstFrame( Gpa& G, size_t fi, size_t frameWidth, bool hasRef ) {
           }
       }
       if ( !found ) {
+        if ( sizeV > ( size_t( 1 ) << 20 ) ) throw Runaway();  // nothing can be placed: the reference spins here
         sizeV *= 2;
         map.resize( sizeU * sizeV, 0 );
       }
@@ -245,6 +250,7 @@ size_t unionPatchGenerationAndPacking( Gpa& G, const Tracks& tracks, size_t fram
           }
         }
       if ( !found ) {
+        if ( sizeV > ( size_t( 1 ) << 20 ) ) throw Runaway();  // nothing can be placed: the reference spins here
         sizeV *= 2;
         map.resize( sizeU * sizeV, 0 );
       }
@@ -313,6 +319,7 @@ void packNonGlobal( Gpa& G, WPatch& q, const std::vector<WPatch>* prePatches, bo
         }
     }
     if ( !found ) {
+      if ( sizeV > ( size_t( 1 ) << 20 ) ) throw Runaway();
       sizeV *= 2;
       map.resize( sizeU * sizeV, 0 );
     }
@@ -405,6 +412,11 @@ void updatePatchInformation( Gpa& G, size_t first, size_t second ) {
         if ( !q.isGlobal ) cur.push_back( q );
     }
   }
+  for ( size_t fi = first; fi < second; ++fi )
+    if ( int32_t( G.frames[fi].patches.size() ) < globalCount ) {
+      G.undefined = true;  // the reference indexes past the end of the list here (a tracked patch lost its place)
+      return;
+    }
   for ( size_t fi = first; fi < second; ++fi ) {
     auto& cur = G.frames[fi].patches;
     for ( int32_t i = 0; i < globalCount; ++i ) {
@@ -492,6 +504,7 @@ void run( Gpa& G ) {
       startSub = true;
       --fi;  // this frame opens the next sub-context
       updatePatchInformation( G, preFirst, preSecond );
+      if ( G.undefined ) return;
     } else {
       for ( size_t j = curFirst; j < curSecond; ++j ) {
         WFrame& T = G.frames[j];
@@ -532,7 +545,15 @@ void orc_gpa_set_frame( void* h, int f, const orc_patch* list, int P, const uint
   F.width  = size_t( width );
   F.height = size_t( height );
 }
-void orc_gpa_run( void* h ) { run( *static_cast<Gpa*>( h ) ); }
+// returns 1 where the reference's behaviour is undefined (see updatePatchInformation), 0 otherwise
+int orc_gpa_run( void* h ) {
+  Gpa& G = *static_cast<Gpa*>( h );
+  try {
+    run( G );
+  } catch ( const Runaway& ) { return 2; }  // the reference never returns (a patch that fits at no canvas height)
+  catch ( const OutOfCanvas& ) { return 1; }  // a union placed on the wider GOF canvas does not fit this frame's own: undefined there
+  return G.undefined ? 1 : 0;
+}
 int64_t orc_gpa_occ_bytes( void* h, int f ) {
   int64_t n = 0;
   for ( auto& q : static_cast<Gpa*>( h )->frames[size_t( f )].patches ) n += int64_t( q.occ.size() );

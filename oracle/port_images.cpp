@@ -83,6 +83,7 @@ int orc_pack_flexible( orc_patch* patches, int P, const uint8_t* occupancy, int 
             if ( fits ) found = true;
           }
       if ( !found ) {
+        if ( sizeV > ( size_t( 1 ) << 20 ) ) return -2;  // nothing can be placed: the reference spins here
         sizeV *= 2;
         canvas.resize( sizeU * sizeV, 0 );
       }
@@ -200,6 +201,7 @@ int orc_pack_spatial_consistency( orc_patch* patches, int P, const uint8_t* occu
             }
       }
       if ( !found ) {
+        if ( sizeV > ( size_t( 1 ) << 20 ) ) return -2;  // nothing can be placed: the reference spins here
         sizeV *= 2;
         canvas.resize( sizeU * sizeV, 0 );
       }

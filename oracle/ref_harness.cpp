@@ -657,6 +657,82 @@ int ref_gof_get_attribute_images( int frame, uint8_t* out ) {
   return 0;
 }
 
+// ---- PCCEncoder::placeSegments (:4762-4835) on patch RECORDS instead of segmented clouds: the packers (packFlexible,
+// spatialConsistencyPackFlexible, resizeTileGeometryVideo, performDataAdaptiveGPAMethod, resizeGeometryVideo) see exactly the
+// fields they read -- block sizes, block occupancy, the (u1, v1, sizeU, sizeV) box and the view of every patch.  records:
+// all frames back to back, counts[f] each, in creation order; occupancy pool of frame f at occ + occBase[f].
+// constrainedPack as in ref_gof_begin2.  Read the result with ref_gof_get_patches / _patch_matches / _frame_size.
+int ref_place_records( int frames, const int32_t* counts, const orc_patch* records, const uint8_t* occ, const int64_t* occBase, int minW,
+                       int minH, int constrainedPack ) {
+  Quiet quiet;
+  g_gof.reset( new Gof() );
+  Gof& G = *g_gof;
+  setCtcParams( G.params, 10, 10, 4, minW, minH );
+  G.params.constrainedPack_       = constrainedPack != 0;
+  G.params.globalPatchAllocation_ = constrainedPack == 2 ? 1 : 0;
+  G.sources.setFrameCount( size_t( frames ) );
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );
+  PCCEncoder& E = G.encoder;
+  E.setLogger( G.logger );
+  E.setParameters( G.params );
+  PCCContext&             context = G.context;
+  static PCCBitstreamStat bitstreamStat;
+  context.setBitstreamStat( bitstreamStat );
+  context.addV3CParameterSet( 0 );
+  context.setActiveVpsId( 0 );
+  context.resizeAtlas( 1 );
+  context.setAtlasIndex( 0 );
+  context.resize( size_t( frames ) );
+  size_t at = 0;
+  for ( int f = 0; f < frames; ++f ) {
+    auto& fc = context.getFrames()[size_t( f )].getTitleFrameContext();
+    fc.setFrameIndex( size_t( f ) );
+    auto& patches = fc.getPatches();
+    patches.resize( size_t( counts[f] ) );
+    for ( int i = 0; i < counts[f]; ++i, ++at ) {
+      const orc_patch& r = records[at];
+      PCCPatch&        p = patches[size_t( i )];
+      p.setIndex( size_t( r.index ) );
+      p.setViewId( size_t( r.viewId ) );
+      p.setU1( size_t( r.u1 ) ), p.setV1( size_t( r.v1 ) ), p.setD1( size_t( r.d1 ) );
+      p.setSizeU( size_t( r.sizeU ) ), p.setSizeV( size_t( r.sizeV ) );
+      p.setSizeU0( size_t( r.sizeU0 ) ), p.setSizeV0( size_t( r.sizeV0 ) );
+      p.setOccupancyResolution( 16 );
+      p.setBestMatchIdx( -1 );
+      std::vector<bool> o( size_t( r.sizeU0 ) * size_t( r.sizeV0 ) );
+      for ( size_t k = 0; k < o.size(); ++k ) o[k] = occ[occBase[f] + r.occOffset + int64_t( k )] != 0;
+      p.setOccupancy( o );
+    }
+  }
+  E.params_.initializeContext( context );
+  E.placeSegments( G.sources, context );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
+}
+// block occupancy of the patches of a frame after placeSegments, list order, back to back
+int64_t ref_gof_get_patch_occupancy( int frame, uint8_t* out ) {
+  auto&   patches = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();
+  int64_t o       = 0;
+  for ( auto& p : patches )
+    for ( bool b : p.getOccupancy() ) {
+      if ( out ) out[o] = b ? 1 : 0;
+      ++o;
+    }
+  return o;
+}
+int ref_gof_tile_size( int frame, int* width, int* height ) {
+  auto& f = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext();
+  *width  = int( f.getWidth() );
+  *height = int( f.getHeight() );
+  return 0;
+}
+
 // ---- post-reconstruction tail of PCCEncoder::encode (:571-719; the decoder runs the same members, PCCDecoder.cpp:330-470) ----
 // boundary point types as generatePointCloud left them (identifyBoundaryPoints, PCCCodec.cpp:268-327)
 int ref_gof_get_boundary_types( int frame, uint16_t* out ) {

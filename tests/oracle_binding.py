@@ -203,9 +203,22 @@ class Oracle:
         order = np.zeros(len(p), np.int32)
         match = np.zeros(len(p), np.int32)
         h = C.c_int32()
-        self.L.orc_pack_spatial_consistency(_p(p), len(p), _p(occ), _p(prev), len(prev), int(preset_width), int(occ_res),
-                                            int(tiles_hor), C.c_double(ratio), _p(order), _p(match), C.byref(h))
+        rc = self.L.orc_pack_spatial_consistency(_p(p), len(p), _p(occ), _p(prev), len(prev), int(preset_width), int(occ_res),
+                                                 int(tiles_hor), C.c_double(ratio), _p(order), _p(match), C.byref(h))
+        if rc == -2:
+            return None       # a patch fits at no canvas height: the reference never returns
         return p, order, match, h.value
+
+    @staticmethod
+    def tile_size(per, min_w, min_h, chained=True):
+        """resizeTileGeometryVideo after the per-frame packing: the common tile of the GOF.  packFlexible works on a copy of
+        the tile width (PCCEncoder.cpp:2312), so a frame it packed keeps the preset width whatever its patches needed;
+        spatialConsistencyPackFlexible writes the width of its canvas back (:1190, :1308)."""
+        widths = [min_w]
+        for f, (_, placed, _, _) in enumerate(per):
+            if chained and f > 0 and len(placed):
+                widths.append(max(min_w // 16, int((placed["sizeU0"] + 1).max())) * 16)
+        return max(widths), max([h for _, _, _, h in per] + [min_h])
 
     def global_patch_allocation(self, per, min_w, min_h):
         """S10' second half (random-access condition): GPA over the frames packed by the per-frame chain.
@@ -213,15 +226,16 @@ class Oracle:
         L = self.L
         L.orc_gpa_begin.restype = C.c_void_p
         L.orc_gpa_occ_bytes.restype = C.c_int64
-        widths = [max(min_w // 16, int((placed["sizeU0"] + 1).max()) if len(placed) else 0) * 16 for _, placed, _, _ in per]
-        tw, th = max(widths + [min_w]), max([h for _, _, _, h in per] + [min_h])     # resizeTileGeometryVideo
+        tw, th = self.tile_size(per, min_w, min_h)
         h = C.c_void_p(L.orc_gpa_begin(len(per), int(min_w), int(min_h), 16))
         for f, (seg, placed, order, _) in enumerate(per):
             lst = np.ascontiguousarray(placed[order], dtype=PATCH_DTYPE)
             occ = np.ascontiguousarray(seg["occupancy"], dtype=np.uint8)
             m = np.ascontiguousarray(seg["matches"], dtype=np.int32)
             L.orc_gpa_set_frame(h, f, _p(lst), len(lst), _p(occ), _p(m), int(tw), int(th))
-        L.orc_gpa_run(h)
+        if L.orc_gpa_run(h):
+            L.orc_gpa_free(h)
+            return None       # undefined in the reference (a tracked patch without a place in the realigned lists), or it never returns
         out = []
         for f, (seg, placed, order, _) in enumerate(per):
             n = len(placed)
@@ -262,7 +276,7 @@ class Oracle:
                 img.update(patches=lst, width=W, height=H, matches=m)
                 out.append(img)
             return out
-        W, H = self.gof_canvas_size([x[3] for x in per], min_w, min_w, min_h)
+        W, H = self.gof_canvas_size([x[3] for x in per], self.tile_size(per, min_w, min_h, bool(constrained_pack))[0], min_w, min_h)
         out = []
         for seg, placed, order, h in per:
             img = self.geometry_images(placed, order, seg["depth0"], seg["depth1"], W, H, 16, occ_precision)
@@ -467,6 +481,32 @@ class Reference:
         rc = getattr(self.L, self._conv_prefix + "convert_yuv420_to_yuv444")(_p(y), _p(u), _p(v), int(W), int(H), int(filter), _p(out))
         assert rc == 0, rc
         return out
+
+    def place_records(self, gof, min_w, min_h, constrained_pack):
+        """PCCEncoder::placeSegments on patch records: gof = [(records by index, occupancy pool)] per frame.
+        -> (per frame (list patches, occupancy pool in list order, matches), (canvas width, canvas height))."""
+        L = self.L
+        counts = np.array([len(r) for r, _ in gof], np.int32)
+        recs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=PATCH_DTYPE) for r, _ in gof]), dtype=PATCH_DTYPE)
+        pools = [np.ascontiguousarray(o, dtype=np.uint8) for _, o in gof]
+        base = np.zeros(len(gof), np.int64)
+        base[1:] = np.cumsum([len(o) for o in pools])[:-1]
+        occ = np.ascontiguousarray(np.concatenate(pools))
+        L.ref_place_records(len(gof), _p(counts), _p(recs), _p(occ), _p(base), int(min_w), int(min_h), int(constrained_pack))
+        L.ref_gof_get_patch_occupancy.restype = C.c_int64
+        out = []
+        for f in range(len(gof)):
+            n = L.ref_gof_patch_count(f)
+            pt = np.zeros(n, PATCH_DTYPE)
+            L.ref_gof_get_patches(f, _p(pt))
+            m = np.zeros(n, np.int32)
+            L.ref_gof_get_patch_matches(f, _p(m))
+            o = np.zeros(max(1, L.ref_gof_get_patch_occupancy(f, None)), np.uint8)
+            L.ref_gof_get_patch_occupancy(f, _p(o))
+            out.append((pt, o, m))
+        w, h = C.c_int(), C.c_int()
+        L.ref_gof_frame_size(C.byref(w), C.byref(h))
+        return out, (w.value, h.value)
 
     def ply_read(self, path, read_normals=False):
         """PCCPointSet3::read -> (xyz, rgb or None, normals or None), or None if the reference refuses the file."""

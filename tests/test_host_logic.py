@@ -142,8 +142,7 @@ def test_host_global_patch_allocation_matches_oracle(oracle, case):
             seg["matches"] = np.full(len(order), -1, np.int32)
         per.append((seg, placed, order, h))
     exp = oracle.global_patch_allocation(per, min_w, min_h)
-    widths = [max(min_w // 16, int((placed["sizeU0"] + 1).max())) * 16 for _, placed, _, _ in per]
-    tw, th = max(widths + [min_w]), max([h for _, _, _, h in per] + [min_h])
+    tw, th = oracle.tile_size(per, min_w, min_h)
     got = T.host_global_patch_allocation([placed[order] for _, placed, order, _ in per], [seg["occupancy"] for seg, _, _, _ in per],
                                          [seg["matches"] for seg, _, _, _ in per], tw, th, min_w, min_h)
     assert len(got) == len(exp)
@@ -265,3 +264,81 @@ def test_host_ply_read_and_checksum_match_golden_fixture(tmp_path):
     for reorder in (0, 1):
         assert T.point_set_checksum(big[0], big[1], bool(reorder)) == g["checksum_r%d" % reorder].tobytes()
         assert T.point_set_checksum(big[0], None, bool(reorder)) == g["checksum_nocolor_r%d" % reorder].tobytes()
+
+
+def _random_patch_gof(rng, frames, patches, drift, churn):
+    """Random patch records (no point cloud behind them): boxes in the (u1, v1) plane of six views that drift from frame to
+    frame, some vanish, some appear; block occupancies with holes.  -> per frame (records by index, occupancy pool)."""
+    import oracle_binding as ob
+    base = [dict(view=int(rng.integers(0, 6)), u1=int(rng.integers(0, 600)), v1=int(rng.integers(0, 600)),
+                 su=int(rng.integers(4, 150)), sv=int(rng.integers(4, 150))) for _ in range(patches)]
+    out = []
+    for f in range(frames):
+        cur = []
+        for b in base:
+            if rng.random() < churn:
+                continue
+            cur.append(dict(b, u1=max(0, b["u1"] + int(rng.integers(-drift, drift + 1))), v1=max(0, b["v1"] + int(rng.integers(-drift, drift + 1))),
+                            su=max(2, b["su"] + int(rng.integers(-drift, drift + 1))), sv=max(2, b["sv"] + int(rng.integers(-drift, drift + 1)))))
+        for _ in range(int(rng.integers(0, 1 + int(patches * churn * 2)))):
+            cur.append(dict(view=int(rng.integers(0, 6)), u1=int(rng.integers(0, 600)), v1=int(rng.integers(0, 600)),
+                            su=int(rng.integers(4, 150)), sv=int(rng.integers(4, 150))))
+        rng.shuffle(cur)
+        rec = np.zeros(len(cur), ob.PATCH_DTYPE)
+        pool = []
+        for i, c in enumerate(cur):
+            u0, v0 = (c["su"] + 15) // 16, (c["sv"] + 15) // 16
+            occ = (rng.random((v0, u0)) < 0.8).astype(np.uint8)
+            occ[0, 0] = 1
+            rec[i]["index"], rec[i]["viewId"] = i, c["view"]
+            rec[i]["u1"], rec[i]["v1"], rec[i]["sizeU"], rec[i]["sizeV"] = c["u1"], c["v1"], c["su"], c["sv"]
+            rec[i]["sizeU0"], rec[i]["sizeV0"] = u0, v0
+            rec[i]["occOffset"] = sum(len(p) for p in pool)
+            pool.append(occ.reshape(-1))
+        out.append((rec, np.concatenate(pool) if pool else np.zeros(0, np.uint8)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_host_interframe_packers_random_patch_sets(oracle, seed):
+    """S10' on synthetic patch records: the spatial-consistency chain and the global patch allocation of the product against
+    the oracle on random GOFs -- drifting, vanishing and appearing patches on canvases from roomy to far too small, so that
+    every restart branch and the canvas doubling are hit many times."""
+    import oracle_binding as ob
+    rng = np.random.default_rng(1000 + seed)
+    frames = int(rng.integers(2, 7))
+    gof = _random_patch_gof(rng, frames, int(rng.integers(3, 40)), drift=int(rng.integers(0, 30)), churn=float(rng.choice([0.0, 0.1, 0.4])))
+    min_w = int(rng.choice([128, 256, 512, 1280]))
+    min_h = int(rng.choice([64, 128, 256, 512, 1280]))
+    per = []
+    for rec, occ in gof:
+        if per:
+            _, pplaced, porder, _ = per[-1]
+            exp_sc = oracle.pack_spatial_consistency(rec, occ, pplaced[porder], min_w)
+            if exp_sc is None:         # an inherited orientation makes a patch wider than the canvas: the reference spins
+                with pytest.raises(T.Tmc2Error):
+                    T.host_pack_spatial_consistency(rec, occ, pplaced[porder], min_w)
+                return
+            placed, order, match, h = T.host_pack_spatial_consistency(rec, occ, pplaced[porder], min_w)
+            ep, eo, em, eh = exp_sc
+            assert h == eh and np.array_equal(order, eo) and np.array_equal(match, em)
+            for k in ("u0", "v0", "patchOrientation"):
+                assert np.array_equal(placed[k], ep[k]), k
+        else:
+            placed, order, h = oracle.pack_flexible(rec, occ, min_w)
+            match = np.full(len(order), -1, np.int32)
+        per.append((dict(occupancy=occ, matches=match), placed, order, h))
+    exp = oracle.global_patch_allocation(per, min_w, min_h)
+    tw, th = oracle.tile_size(per, min_w, min_h)
+    args = ([placed[order] for _, placed, order, _ in per], [seg["occupancy"] for seg, _, _, _ in per],
+            [seg["matches"] for seg, _, _, _ in per], tw, th, min_w, min_h)
+    if exp is None:            # undefined in the reference: the product must refuse, not guess
+        with pytest.raises(T.Tmc2Error):
+            T.host_global_patch_allocation(*args)
+        return
+    got = T.host_global_patch_allocation(*args)
+    for f, ((gl, go, gm, gw, gh), (el, eo, em, ew, eh)) in enumerate(zip(got, exp)):
+        assert (gw, gh) == (ew, eh) and np.array_equal(gm, em), f
+        for n in el.dtype.names:
+            assert np.array_equal(gl[n], el[n]), (f, n)
+        assert np.array_equal(go, eo[:len(go)]), f

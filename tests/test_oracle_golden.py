@@ -345,3 +345,54 @@ def _sparse_target_case(seed=0):
 def test_oracle_transfer_colors_long_candidate_lists(oracle, reference):
     xyz, rgb, tgt = _sparse_target_case()
     assert np.array_equal(oracle.transfer_colors(xyz, rgb, tgt), reference.transfer_colors(xyz, rgb, tgt))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_oracle_interframe_packers_match_reference_on_random_patch_sets(oracle, reference, seed):
+    """PCCEncoder::placeSegments run by the reference on synthetic patch RECORDS (random boxes that drift, vanish and appear;
+    canvases from roomy to far too small) against the oracle's packFlexible / spatial-consistency chain / global patch
+    allocation: patch lists, placements, matches, block occupancies and the GOF canvas, in the low-delay and the
+    random-access condition.  GOFs on which the reference's behaviour is undefined or never returns (the oracle says which:
+    a union outside a frame's own canvas, a tracked patch without a place in the realigned lists, a patch wider than the
+    canvas in the orientation it inherits) are skipped -- the reference would take the process down."""
+    from test_host_logic import _random_patch_gof
+    rng = np.random.default_rng(1000 + seed)
+    frames = int(rng.integers(2, 7))
+    gof = _random_patch_gof(rng, frames, int(rng.integers(3, 40)), drift=int(rng.integers(0, 30)), churn=float(rng.choice([0.0, 0.1, 0.4])))
+    min_w = int(rng.choice([128, 256, 512, 1280]))
+    min_h = int(rng.choice([64, 128, 256, 512, 1280]))
+    per = []
+    for rec, occ in gof:
+        if per:
+            _, pplaced, porder, _ = per[-1]
+            step = oracle.pack_spatial_consistency(rec, occ, pplaced[porder], min_w)
+            if step is None:
+                pytest.skip("the reference never returns on this GOF")
+            placed, order, match, h = step
+        else:
+            placed, order, h = oracle.pack_flexible(rec, occ, min_w)
+            match = np.full(len(order), -1, np.int32)
+        per.append((dict(occupancy=occ, matches=match), placed, order, h))
+    fields = ("viewId", "u1", "v1", "sizeU", "sizeV", "sizeU0", "sizeV0", "u0", "v0", "patchOrientation")
+    # low-delay condition
+    got, canvas = reference.place_records(gof, min_w, min_h, 1)
+    assert tuple(oracle.gof_canvas_size([x[3] for x in per], oracle.tile_size(per, min_w, min_h)[0], min_w, min_h)) == canvas
+    for (seg, placed, order, _), (gl, go, gm) in zip(per, got):
+        el = placed[order]
+        for n in fields:
+            assert np.array_equal(el[n], gl[n]), n
+        assert np.array_equal(seg["matches"], gm)
+    # random-access condition
+    exp = oracle.global_patch_allocation(per, min_w, min_h)
+    if exp is None:
+        pytest.skip("undefined in the reference on this GOF")
+    got, canvas = reference.place_records(gof, min_w, min_h, 2)
+    tw, th = max([g[3] for g in exp] + [min_w]), max([g[4] for g in exp] + [min_h])
+    assert tuple(oracle.gof_canvas_size([th], tw, min_w, min_h)) == canvas
+    for (el, eo, em, _, _), (gl, go, gm) in zip(exp, got):
+        assert len(el) == len(gl)
+        for n in fields + ("index",):
+            assert np.array_equal(el[n], gl[n]), n
+        assert np.array_equal(em, gm)
+        k = int((el["sizeU0"] * el["sizeV0"]).sum())
+        assert np.array_equal(eo[:k], go[:k])
