@@ -315,6 +315,10 @@ int tmc2_point_set_checksum( const int16_t* xyz, const uint8_t* rgb, uint64_t n,
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );
+/* the placement logic behind tmc2_encoder_pack_flexible on plain records: patches by index (u0 / v0 / patchOrientation out),
+ * their block-occupancy pool; order = list order out */
+int tmc2_host_pack_flexible( tmc2_patch* patches, int count, const uint8_t* occupancy, int presetWidth, int numTilesHor,
+                             double tileHeightToWidthRatio, int32_t* order, int32_t* height );
 /* the placement logic behind tmc2_encoder_pack_spatial_consistency on plain records: patches by index (u0 / v0 /
  * patchOrientation out), their block-occupancy pool, the previous frame's patches in list order */
 /* the allocation behind tmc2_encoder_global_patch_allocation on plain records.  counts[frames]; patches / matches: all

@@ -49,26 +49,15 @@ struct BlockCanvas {
 };
 }  // namespace
 
-int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHor, double ratio ) {
-  if ( !f->havePatches ) {
-    setError( "packFlexible: no patches" );
-    return TMC2_E_STATE;
-  }
-  const int P = int( f->patches.size() );
-  f->packOrder.resize( P );
-  f->packMatch.assign( P, -1 );
-  for ( int i = 0; i < P; ++i ) f->packOrder[i] = i;
-  f->packedHeight = 0;
-  f->packedWidth  = presetWidth;
-  f->havePacking  = true;
-  if ( P == 0 ) return TMC2_OK;
-  // per-block occupancy of the patches comes back from the device (a few KB)
-  std::vector<uint8_t> occ( size_t( f->occCount ) );
-  TMC2_HIP( hipMemcpyAsync( occ.data(), f->d_occupancy.p, occ.size(), hipMemcpyDeviceToHost, f->ctx->stream ) );
-  TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
-  auto& pt = f->patches;
+// Core of S10 on plain records (no device involved).  pt: the frame's patches by index (u0 / v0 / orientation out); occ: their
+// block-occupancy pool; order: list order out (PCCPatch::gt).  Returns the frame height in pixels, -1 if a patch fits at no
+// canvas height.
+int packFlexibleCore( tmc2_patch* pt, int P, const uint8_t* occ, int presetWidth, int occRes, int numTilesHor, double ratio,
+                      int32_t* order ) {
+  for ( int i = 0; i < P; ++i ) order[i] = i;
+  if ( P == 0 ) return 0;
   // largest block dimension first, then the other dimension, then creation order (a total order)
-  std::sort( f->packOrder.begin(), f->packOrder.end(), [&]( int a, int b ) {
+  std::sort( order, order + P, [&]( int a, int b ) {
     const int aMax = std::max( pt[a].sizeU0, pt[a].sizeV0 ), aMin = std::min( pt[a].sizeU0, pt[a].sizeV0 );
     const int bMax = std::max( pt[b].sizeU0, pt[b].sizeV0 ), bMin = std::min( pt[b].sizeU0, pt[b].sizeV0 );
     if ( aMax != bMax ) return aMax > bMax;
@@ -76,14 +65,14 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
     return pt[a].index < pt[b].index;
   } );
   size_t sizeU = size_t( presetWidth / occRes );
-  for ( auto& p : pt ) sizeU = std::max( sizeU, size_t( p.sizeU0 + 1 ) );
-  size_t    sizeV = size_t( std::max( pt[f->packOrder[0]].sizeU0, pt[f->packOrder[0]].sizeV0 ) );
+  for ( int i = 0; i < P; ++i ) sizeU = std::max( sizeU, size_t( pt[i].sizeU0 + 1 ) );
+  size_t    sizeV = size_t( std::max( pt[order[0]].sizeU0, pt[order[0]].sizeV0 ) );
   const int tileH = int( ( int( sizeU ) / numTilesHor ) * ratio );
   sizeV           = std::max( sizeV, size_t( std::max( tileH, 0 ) ) );
   size_t      heightBlocks = sizeV;
   BlockCanvas canvas( sizeU, sizeV );
   for ( int k = 0; k < P; ++k ) {
-    tmc2_patch& p      = pt[f->packOrder[k]];
+    tmc2_patch& p      = pt[order[k]];
     const bool  wide   = p.sizeU0 > p.sizeV0;
     const int   first  = wide ? ORIENT_SWAP : ORIENT_DEFAULT;  // wide patches are tried upright first
     const int   second = wide ? ORIENT_DEFAULT : ORIENT_SWAP;
@@ -102,14 +91,11 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
             }
           }
       if ( !placed ) {
-        if ( canvas.height > ( size_t( 1 ) << 20 ) ) {
-          setError( "packFlexible: patch %d fits at no canvas height", f->packOrder[k] );
-          return TMC2_E_INVALID;
-        }
+        if ( canvas.height > ( size_t( 1 ) << 20 ) ) return -1;
         canvas.grow( canvas.height * 2 );
       }
     }
-    const uint8_t* o = occ.data() + p.occOffset;
+    const uint8_t* o = occ + p.occOffset;
     for ( int vb = 0; vb < p.sizeV0; ++vb )
       for ( int ub = 0; ub < p.sizeU0; ++ub )
         if ( o[vb * p.sizeU0 + ub] ) {
@@ -120,8 +106,32 @@ int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHo
         }
     heightBlocks = std::max( heightBlocks, size_t( p.v0 + ( p.patchOrientation == ORIENT_DEFAULT ? p.sizeV0 : p.sizeU0 ) ) );
   }
-  f->packedHeight = int( heightBlocks ) * occRes;
+  return int( heightBlocks ) * occRes;
+}
+
+int packFlexibleHost( tmc2_frame* f, int presetWidth, int occRes, int numTilesHor, double ratio ) {
+  if ( !f->havePatches ) {
+    setError( "packFlexible: no patches" );
+    return TMC2_E_STATE;
+  }
+  const int P = int( f->patches.size() );
+  f->packOrder.resize( P );
+  f->packMatch.assign( P, -1 );
+  for ( int i = 0; i < P; ++i ) f->packOrder[i] = i;
+  f->packedHeight = 0;
   f->packedWidth  = presetWidth;  // packFlexible works on a COPY of the tile width (PCCEncoder.cpp:2312): the tile keeps its own
+  f->havePacking  = true;
+  if ( P == 0 ) return TMC2_OK;
+  // per-block occupancy of the patches comes back from the device (a few KB)
+  std::vector<uint8_t> occ( size_t( f->occCount ) );
+  TMC2_HIP( hipMemcpyAsync( occ.data(), f->d_occupancy.p, occ.size(), hipMemcpyDeviceToHost, f->ctx->stream ) );
+  TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
+  f->packedHeight = packFlexibleCore( f->patches.data(), P, occ.data(), presetWidth, occRes, numTilesHor, ratio, f->packOrder.data() );
+  if ( f->packedHeight < 0 ) {
+    f->havePacking = false;
+    setError( "packFlexible: a patch fits at no canvas height" );
+    return TMC2_E_INVALID;
+  }
   return TMC2_OK;
 }
 
@@ -316,6 +326,18 @@ int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches ) {
     return TMC2_E_STATE;
   }
   for ( size_t k = 0; k < f->packOrder.size(); ++k ) matches[k] = k < f->packMatch.size() ? f->packMatch[k] : -1;
+  return TMC2_OK;
+}
+
+int tmc2_host_pack_flexible( tmc2_patch* patches, int count, const uint8_t* occupancy, int presetWidth, int numTilesHor,
+                             double tileHeightToWidthRatio, int32_t* order, int32_t* height ) {
+  if ( count < 0 || presetWidth <= 0 || numTilesHor <= 0 || !order || !height || ( count && ( !patches || !occupancy ) ) )
+    return TMC2_E_INVALID;
+  *height = tmc2::packFlexibleCore( patches, count, occupancy, presetWidth, 16, numTilesHor, tileHeightToWidthRatio, order );
+  if ( *height < 0 ) {
+    tmc2::setError( "host_pack_flexible: a patch fits at no canvas height" );
+    return TMC2_E_INVALID;
+  }
   return TMC2_OK;
 }
 

@@ -480,6 +480,17 @@ def host_kdtree_build(xyz):
     return perm, nodes.value, depth.value
 
 
+def host_pack_flexible(patches, occupancy, preset_width=1280, tiles_hor=2, ratio=1.0):
+    """(placed patches by index, order, height) -- the S10 placement on plain records."""
+    L = load_library()
+    p = np.array(patches, dtype=PATCH_DTYPE, order="C", copy=True)
+    occ = np.ascontiguousarray(occupancy, dtype=np.uint8)
+    order, h = np.zeros(len(p), np.int32), C.c_int32()
+    _check(L.tmc2_host_pack_flexible(_ptr(p), len(p), _ptr(occ), int(preset_width), int(tiles_hor), C.c_double(ratio), _ptr(order),
+                                     C.byref(h)))
+    return p, order, h.value
+
+
 def host_pack_spatial_consistency(patches, occupancy, previous_list, preset_width=1280, tiles_hor=2, ratio=1.0):
     """(placed patches by index, order, matches per list position, height) -- the S10' placement on plain records."""
     L = load_library()

@@ -325,9 +325,19 @@ def test_host_interframe_packers_random_patch_sets(oracle, seed):
             for k in ("u0", "v0", "patchOrientation"):
                 assert np.array_equal(placed[k], ep[k]), k
         else:
-            placed, order, h = oracle.pack_flexible(rec, occ, min_w)
+            placed, order, h = T.host_pack_flexible(rec, occ, min_w)
+            ep, eo, eh = oracle.pack_flexible(rec, occ, min_w)
+            assert h == eh and np.array_equal(order, eo)
+            for k in ("u0", "v0", "patchOrientation"):
+                assert np.array_equal(placed[k], ep[k]), k
             match = np.full(len(order), -1, np.int32)
         per.append((dict(occupancy=occ, matches=match), placed, order, h))
+    for rec, occ in gof[1:]:        # S10 on every frame on its own (the all-intra condition)
+        placed, order, h = T.host_pack_flexible(rec, occ, min_w)
+        ep, eo, eh = oracle.pack_flexible(rec, occ, min_w)
+        assert h == eh and np.array_equal(order, eo)
+        for k in ("u0", "v0", "patchOrientation"):
+            assert np.array_equal(placed[k], ep[k]), k
     exp = oracle.global_patch_allocation(per, min_w, min_h)
     tw, th = oracle.tile_size(per, min_w, min_h)
     args = ([placed[order] for _, placed, order, _ in per], [seg["occupancy"] for seg, _, _, _ in per],
