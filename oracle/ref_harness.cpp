@@ -823,6 +823,47 @@ int ref_gof_get_post( int frame, int16_t* xyz, uint16_t* c16, uint8_t* rgb, uint
   return 0;
 }
 
+// T3 + T4 on an arbitrary cloud (not one the pipeline produced): PCCCodec::smoothPointCloudPostprocess and
+// PCCPointSet3::transferColors16bitBP with the encoder's arguments (PCCEncoder.cpp:646-672).  xyz / btype / colors16 in and out.
+int ref_smooth_and_transfer( int16_t* xyz, uint16_t* btype, const uint32_t* partition, uint16_t* colors16, size_t M, int gridSize,
+                             double thresholdSmoothing ) {
+  Quiet        quiet;
+  PCCEncoder   E;
+  PCCPointSet3 rec;
+  rec.addColors();
+  rec.addColors16bit();
+  rec.resize( M );
+  std::vector<uint32_t> part( partition, partition + M );
+  for ( size_t i = 0; i < M; ++i ) {
+    rec[i] = PCCPoint3D( xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] );
+    rec.setColor16bit( i, PCCColor16bit( colors16[3 * i], colors16[3 * i + 1], colors16[3 * i + 2] ) );
+    rec.setBoundaryPointType( i, btype[i] );
+  }
+  GeneratePointCloudParameters pp;
+  pp.flagGeometrySmoothing_ = true;
+  pp.gridSmoothing_         = true;
+  pp.gridSize_              = size_t( gridSize );
+  pp.thresholdSmoothing_    = thresholdSmoothing;
+  pp.pbfEnableFlag_         = false;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  dup2( fileno( devnull ), 1 );
+  PCCPointSet3 temp = rec;
+  E.smoothPointCloudPostprocess( rec, COLOR_TRANSFORM_NONE, pp, part );
+  temp.transferColors16bitBP( rec, 1, int32_t( 0 ), false, 8, 1, true, true, true, false, 4, 4, 1000, 1000, 1000 * 256, 1000 * 256 );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  for ( size_t i = 0; i < M; ++i ) {
+    const auto d = rec.getColor16bit( i );
+    for ( int k = 0; k < 3; ++k ) xyz[3 * i + k] = rec[i][k], colors16[3 * i + k] = d[k];
+    btype[i] = rec.getBoundaryPointType( i );
+  }
+  return 0;
+}
+
 // ---- colour-space conversion around the attribute video codec (PCCVideoEncoder::compress, PCCVideoEncoder.cpp:326-413, with
 // the internal converter: "RGB444ToYUV420_8_<downsamplingFilter>" before the codec, "YUV420ToYUV444_8_<upsamplingFilter>"
 // after it).  Attribute videos are PCCVideo<uint16_t, 3>.

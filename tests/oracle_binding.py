@@ -508,6 +508,15 @@ class Reference:
         L.ref_gof_frame_size(C.byref(w), C.byref(h))
         return out, (w.value, h.value)
 
+    def smooth_and_transfer(self, xyz, btype, partition, colors16, grid_size=8, threshold=64.0):
+        """smoothPointCloudPostprocess + transferColors16bitBP on an arbitrary cloud -> (xyz, boundary types, colours16)."""
+        x = np.array(_i16(xyz), copy=True)
+        bt = np.array(btype, dtype=np.uint16, copy=True)
+        part = np.ascontiguousarray(partition, dtype=np.uint32)
+        c = np.array(colors16, dtype=np.uint16, copy=True, order="C")
+        self.L.ref_smooth_and_transfer(_p(x), _p(bt), _p(part), _p(c), C.c_size_t(len(x)), int(grid_size), C.c_double(threshold))
+        return x, bt, c
+
     def ply_read(self, path, read_normals=False):
         """PCCPointSet3::read -> (xyz, rgb or None, normals or None), or None if the reference refuses the file."""
         L = self.L

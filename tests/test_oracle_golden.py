@@ -396,3 +396,42 @@ def test_oracle_interframe_packers_match_reference_on_random_patch_sets(oracle, 
         assert np.array_equal(em, gm)
         k = int((el["sizeU0"] * el["sizeV0"]).sum())
         assert np.array_equal(eo[:k], go[:k])
+
+
+def random_tail_cloud(rng):
+    """Arbitrary clouds for the post-reconstruction tail (not ones the pipeline produced): noisy sheets, blobs full of duplicate
+    positions, dense cubes (long candidate lists with distance ties), sparse dust; random or region-wise patch ids; colours
+    from nearly uniform (every candidate passes the closeness test) to unrelated."""
+    kind = int(rng.integers(0, 4))
+    n = int(rng.integers(50, 4000))
+    if kind == 0:
+        base = rng.integers(8, 200, (n, 3))
+        base[:, 2] = base[:, 0] // 3 + rng.integers(0, 4, n)
+    elif kind == 1:
+        c = rng.integers(16, 300, (int(rng.integers(2, 12)), 3))
+        base = c[rng.integers(0, len(c), n)] + rng.integers(-6, 7, (n, 3))
+    elif kind == 2:
+        base = rng.integers(20, 20 + int(rng.integers(6, 30)), (n, 3))
+    else:
+        base = rng.integers(0, 1000, (n, 3))
+    xyz = np.clip(base, 0, 1023).astype(np.int16)
+    bt = (rng.random(n) < rng.choice([0.1, 0.5, 1.0])).astype(np.uint16)
+    part = rng.integers(0, int(rng.integers(1, 6)), n).astype(np.uint32)
+    if rng.random() < 0.5:
+        part = ((xyz[:, 0] // int(rng.integers(8, 64))) % 5).astype(np.uint32)
+    spread = int(rng.choice([5, 60, 30000]))
+    c16 = np.clip(32768 + rng.integers(-spread, spread + 1, (n, 3)), 0, 65535).astype(np.uint16)
+    return xyz, bt, part, c16
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_oracle_tail_matches_reference_on_random_clouds(oracle, reference, seed):
+    """smoothPointCloudPostprocess + transferColors16bitBP run by the reference on arbitrary clouds against the oracle: grid
+    sizes 4 / 8 / 16, thresholds from 1 to 64."""
+    rng = np.random.default_rng(7000 + seed)
+    xyz, bt, part, c16 = random_tail_cloud(rng)
+    gs, thr = int(rng.choice([8, 8, 8, 4, 16])), float(rng.choice([64, 64, 8, 1]))
+    rx, rb, rc = reference.smooth_and_transfer(xyz, bt, part, c16, gs, thr)
+    ox, ob_ = oracle.smooth_point_cloud_grid(xyz, bt, part, gs, thr)
+    assert np.array_equal(rx, ox) and np.array_equal(rb, ob_)
+    assert np.array_equal(rc, oracle.transfer_colors16_bp(xyz, c16, ox, ob_))
