@@ -352,3 +352,19 @@ def test_host_interframe_packers_random_patch_sets(oracle, seed):
         for n in el.dtype.names:
             assert np.array_equal(gl[n], el[n]), (f, n)
         assert np.array_equal(go, eo[:len(go)]), f
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_host_tree_and_orientation_on_degenerate_clouds(oracle, seed):
+    """The host-resident pieces of S1 / S3 on degenerate clouds (planes, lines, lattices, dust): tree permutation against
+    the oracle's nanoflann restatement, orientation against the oracle's spanning-tree walk (bit patterns)."""
+    from test_oracle_golden import degenerate_cloud
+    rng = np.random.default_rng(9000 + seed)
+    xyz = degenerate_cloud(rng)
+    if len(xyz) < 20:
+        pytest.skip("too few distinct points")
+    assert np.array_equal(T.host_kdtree_build(xyz)[0], oracle.kdtree_perm(xyz)[0])
+    if len(xyz) >= 16:
+        knn = oracle.knn_self(xyz, 16)
+        raw = oracle.compute_normals(xyz, knn)
+        assert np.array_equal(bits(T.host_orient_normals(xyz, knn, raw)), bits(oracle.orient_normals(xyz, knn, raw)))

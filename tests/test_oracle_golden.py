@@ -435,3 +435,72 @@ def test_oracle_tail_matches_reference_on_random_clouds(oracle, reference, seed)
     ox, ob_ = oracle.smooth_point_cloud_grid(xyz, bt, part, gs, thr)
     assert np.array_equal(rx, ox) and np.array_equal(rb, ob_)
     assert np.array_equal(rc, oracle.transfer_colors16_bp(xyz, c16, ox, ob_))
+
+
+def degenerate_cloud(rng):
+    """Clouds the pipeline is never fed in the other tests: dense cubes, planes (rank-deficient covariance), lines, dust, two
+    sheets two voxels apart, lattices (exact distance ties everywhere).  Unique positions, random order."""
+    kind, n = int(rng.integers(0, 6)), int(rng.integers(40, 3000))
+    if kind == 0:
+        base = rng.integers(0, 60, (n, 3))
+    elif kind == 1:
+        base = rng.integers(0, 400, (n, 3))
+        base[:, 2] = 7
+    elif kind == 2:
+        base = np.stack([np.arange(n), np.arange(n) // 2, np.full(n, 3)], 1)
+    elif kind == 3:
+        base = rng.integers(0, 1000, (n, 3))
+    elif kind == 4:
+        base = rng.integers(0, 120, (n, 3))
+        base[:, 1] = np.where(rng.random(n) < 0.5, 10, 12)
+    else:
+        base = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(max(1, n // 144))), -1).reshape(-1, 3) * int(rng.integers(1, 4))
+    xyz = np.unique(np.clip(base, 0, 2047).astype(np.int16), axis=0)
+    return np.ascontiguousarray(xyz[rng.permutation(len(xyz))])
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_oracle_segmenter_stages_match_reference_on_degenerate_clouds(oracle, reference, seed):
+    """S1-S5 stage by stage on degenerate clouds: k-NN lists (tie order), oriented normals (bit patterns), projection
+    weights, initial and refined partition."""
+    rng = np.random.default_rng(9000 + seed)
+    xyz = degenerate_cloud(rng)
+    if len(xyz) < 20:
+        pytest.skip("too few distinct points")
+    k = 16 if len(xyz) >= 16 else 8
+    assert np.array_equal(oracle.knn_self(xyz, k), reference.knn_self(xyz, k))
+    if k == 16:
+        nr = reference.normals(xyz, 16, True)
+        assert np.array_equal(bits(oracle.normals(xyz, 16, True)), bits(nr))
+        w = reference.weight_normal(xyz, 11, 0.6)
+        assert np.array_equal(oracle.weight_normal(xyz, 11, 0.6), w)
+        pr = reference.initial_segmentation(nr, w)
+        assert np.array_equal(oracle.initial_segmentation(nr, w), pr)
+        assert np.array_equal(oracle.refine_grid(xyz, nr, pr, 1024, 3.0, 4), reference.refine_grid(xyz, nr, pr, 1024, 3.0, 4))
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_oracle_patches_transfer_metrics_match_reference_on_degenerate_clouds(oracle, reference, seed):
+    """S0-S9 as a whole (patch records, depth maps, occupancy), S18 with duplicate targets, S23 with duplicates on the
+    reconstruction side -- on the same kind of clouds."""
+    import oracle_binding as ob
+    rng = np.random.default_rng(11000 + seed)
+    xyz = degenerate_cloud(rng)
+    if len(xyz) < 64:
+        pytest.skip("too few distinct points")
+    rgb = rng.integers(0, 256, (len(xyz), 3), dtype=np.uint8)
+    sp = ob.seg_params(int(rng.integers(1, 6)), 11, reference.weight_normal(xyz, 11, 0.6))
+    a, b = oracle.segment(xyz, rgb, sp), reference.segment(xyz, rgb, sp)
+    for k, y in b.items():
+        if isinstance(y, np.ndarray) and y.dtype.names:
+            for n in y.dtype.names:
+                assert n in ("depthOffset", "occOffset") or np.array_equal(a[k][n], y[n]), (k, n)
+        elif isinstance(y, np.ndarray):
+            assert a[k].shape == y.shape and np.array_equal(a[k], y), k
+    tgt = np.clip(xyz[rng.integers(0, len(xyz), len(xyz) // 2)] + rng.integers(-1, 2, (len(xyz) // 2, 3)), 0, 2047).astype(np.int16)
+    assert np.array_equal(oracle.transfer_colors(xyz, rgb, tgt), reference.transfer_colors(xyz, rgb, tgt))
+    rc = rng.integers(0, 256, (len(tgt), 3), dtype=np.uint8)
+    nrm = reference.normals(xyz, 16, True)
+    qa, ca = oracle.metrics(xyz, rgb, tgt, rc, nrm)
+    qb, cb = reference.metrics(xyz, rgb, tgt, rc, nrm)
+    assert np.array_equal(qa.view(np.uint64), qb.view(np.uint64)) and np.array_equal(ca, cb)
