@@ -1,0 +1,60 @@
+"""The reference-side binding (integration/tmc2hip_adaptor.*) is real code: it compiles against the reference's headers and
+its conversions rebuild exactly what the reference's own segmenter produces.  Needs oracle/_ref/libtmc2adaptor.so, i.e. the
+reference tree at build time (`make -C oracle ref`); skipped elsewhere."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import tmc2_amd as T
+from tmc2_amd.synth import synth_cloud
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ADAPTOR = os.path.join(ROOT, "oracle", "_ref", "libtmc2adaptor.so")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(ADAPTOR), reason="reference-side adaptor not built (no reference tree)")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def adaptor():
+    return C.CDLL(ADAPTOR)
+
+
+@pytest.mark.parametrize("name,frame,iterations", [("tiny", 0, 10), ("tiny", 3, 3), ("small", 1, 5)])
+def test_adaptor_rebuilds_the_reference_patch_list(adaptor, oracle, name, frame, iterations):
+    """Patch records + pools (here: the oracle's, bit-identical to what tmc2_frame_get_patches returns) -> toPCCPatches ->
+    compared getter by getter (indices, axes, boxes, counts, both depth maps, block occupancy) with the list the
+    reference's PCCPatchSegmenter3::compute appends for the same cloud; plus flatten(), the parameter mapping and the way
+    back to records."""
+    import oracle_binding as ob
+    xyz, rgb = synth_cloud(name, frame)
+    w = oracle.weight_normal(xyz, 11, 0.6)
+    seg = oracle.segment(xyz, rgb, ob.seg_params(iterations, 11, w))
+    params = T.ctc_params(iterations, 11, w)
+    rec = np.ascontiguousarray(seg["patches"], dtype=T.lib.PATCH_DTYPE)
+    d0, d1 = np.ascontiguousarray(seg["depth0"], np.int16), np.ascontiguousarray(seg["depth1"], np.int16)
+    occ = np.ascontiguousarray(seg["occupancy"], np.uint8)
+    x, c = np.ascontiguousarray(xyz, np.int16), np.ascontiguousarray(rgb, np.uint8)
+    bad = adaptor.adaptor_check_patches(_p(x), _p(c), C.c_size_t(len(x)), C.byref(params), _p(rec), len(rec), _p(d0), _p(d1), _p(occ))
+    assert bad == 0 and len(rec) > 3
+    rec2 = rec.copy()                                              # and the check does notice a difference
+    rec2["d1"][1] += 64
+    assert adaptor.adaptor_check_patches(_p(x), _p(c), C.c_size_t(len(x)), C.byref(params), _p(rec2), len(rec2), _p(d0), _p(d1),
+                                         _p(occ)) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("TMC2_ADAPTOR_GPU_TEST") != "1", reason="opt-in (TMC2_ADAPTOR_GPU_TEST=1): not yet run on a GPU")
+def test_adaptor_segmenter_compute_is_a_drop_in(adaptor):
+    """On an MI355X: tmc2hip::segmenterCompute (flatten -> C-ABI -> PCCPatch list) against the reference's own
+    PCCPatchSegmenter3::compute on the same PCCPointSet3."""
+    xyz, rgb = synth_cloud("small", 0)
+    frame = T.Context(0).frame(xyz, rgb)
+    params = T.ctc_params(10, 11, frame.weight_normal(11, 0.6))
+    x, c = np.ascontiguousarray(xyz, np.int16), np.ascontiguousarray(rgb, np.uint8)
+    assert adaptor.adaptor_check_segmenter_compute(0, _p(x), _p(c), C.c_size_t(len(x)), C.byref(params)) == 0
