@@ -307,6 +307,9 @@ int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
 int tmc2_ply_info( const char* path, int readNormals, uint64_t* pointCount, int* hasColors, int* hasNormals );
 int tmc2_ply_read( const char* path, int16_t* xyz, uint8_t* rgb, double* normals, uint64_t capacity, int threads,
                    uint64_t* pointCount );
+/* replaces: PCCPointSet3::write (PCCPointSet.cpp:359-462): the PLY file the reference writes for a reconstructed or decoded
+ * frame, byte for byte (ASCII or binary_little_endian; rgb / normals may be NULL)                                  */
+int tmc2_ply_write( const char* path, const int16_t* xyz, const uint8_t* rgb, const double* normals, uint64_t n, int asAscii );
 /* replaces: PCCPointSet3::computeChecksum( reorderPoints ) / computeMd5 / reorder (PCCPointSet.cpp:222-305): the MD5 the
  * conformance logs carry, over int16 positions then uint8 colours (rgb may be NULL); reorderPoints sorts by (x, y, z) and
  * merges points that share a position (mean colour) first.                                                        */

@@ -265,6 +265,7 @@ int packSpatialConsistencyHost( tmc2_frame* f, tmc2_frame* prevFrame, int preset
   f->packOrder.assign( P, 0 );
   f->packMatch.assign( P, -1 );
   f->packedHeight = 0;
+  f->packedWidth  = ( presetWidth / occRes ) * occRes;
   f->havePacking  = true;
   if ( P == 0 ) return TMC2_OK;
   std::vector<uint8_t> occ( size_t( f->occCount ) );

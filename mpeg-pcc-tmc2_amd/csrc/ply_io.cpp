@@ -556,6 +556,58 @@ int tmc2_ply_read( const char* path, int16_t* xyz, uint8_t* rgb, double* normals
   return TMC2_OK;
 }
 
+// PCCPointSet3::write (PCCPointSet.cpp:359-462): the file the reference writes for a reconstructed / decoded frame, byte for
+// byte -- header wording included (float coordinates even in ASCII files, the empty face element)
+int tmc2_ply_write( const char* path, const int16_t* xyz, const uint8_t* rgb, const double* normals, uint64_t n, int asAscii ) {
+  if ( !path || ( n && !xyz ) ) return TMC2_E_INVALID;
+  FILE* fp = fopen( path, "wb" );
+  if ( !fp ) {
+    tmc2::setError( "ply: cannot create %s", path );
+    return TMC2_E_INVALID;
+  }
+  std::string head = "ply\n";
+  head += asAscii ? "format ascii 1.0\n" : "format binary_little_endian 1.0\n";
+  head += "element vertex " + std::to_string( (unsigned long long)n ) + "\n";
+  head += "property float x\nproperty float y\nproperty float z\n";
+  if ( normals ) head += "property float nx\nproperty float ny\nproperty float nz\n";
+  if ( rgb ) head += "property uchar red\nproperty uchar green\nproperty uchar blue\n";
+  head += "element face 0\nproperty list uint8 int32 vertex_index\nend_header\n";
+  std::vector<char> out;
+  out.reserve( head.size() + size_t( n ) * ( asAscii ? 48 : 27 ) );
+  out.insert( out.end(), head.begin(), head.end() );
+  char buf[128];
+  for ( uint64_t i = 0; i < n; ++i ) {
+    if ( asAscii ) {
+      int len = snprintf( buf, sizeof( buf ), "%d %d %d", int( xyz[3 * i] ), int( xyz[3 * i + 1] ), int( xyz[3 * i + 2] ) );
+      out.insert( out.end(), buf, buf + len );
+      if ( normals ) {  // operator<<( float ) at precision max_digits10 of double: "%.17g" of the float's value
+        len = snprintf( buf, sizeof( buf ), " %.17g %.17g %.17g", double( float( normals[3 * i] ) ), double( float( normals[3 * i + 1] ) ),
+                        double( float( normals[3 * i + 2] ) ) );
+        out.insert( out.end(), buf, buf + len );
+      }
+      if ( rgb ) {
+        len = snprintf( buf, sizeof( buf ), " %d %d %d", int( rgb[3 * i] ), int( rgb[3 * i + 1] ), int( rgb[3 * i + 2] ) );
+        out.insert( out.end(), buf, buf + len );
+      }
+      out.push_back( '\n' );
+    } else {
+      float v[3] = {float( xyz[3 * i] ), float( xyz[3 * i + 1] ), float( xyz[3 * i + 2] )};
+      out.insert( out.end(), reinterpret_cast<char*>( v ), reinterpret_cast<char*>( v ) + 12 );
+      if ( normals ) {
+        float w[3] = {float( normals[3 * i] ), float( normals[3 * i + 1] ), float( normals[3 * i + 2] )};
+        out.insert( out.end(), reinterpret_cast<char*>( w ), reinterpret_cast<char*>( w ) + 12 );
+      }
+      if ( rgb ) out.insert( out.end(), rgb + 3 * i, rgb + 3 * i + 3 );
+    }
+  }
+  const bool ok = fwrite( out.data(), 1, out.size(), fp ) == out.size();
+  if ( fclose( fp ) != 0 || !ok ) {
+    tmc2::setError( "ply: writing %s failed", path );
+    return TMC2_E_INVALID;
+  }
+  return TMC2_OK;
+}
+
 int tmc2_point_set_checksum( const int16_t* xyz, const uint8_t* rgb, uint64_t n, int reorderPoints, uint8_t digest[16] ) {
   if ( ( n && !xyz ) || !digest ) return TMC2_E_INVALID;
   tmc2::Md5 md5;

@@ -568,6 +568,16 @@ def ply_read(path, read_normals=False, threads=0, out=None):
     return xyz[:n], (rgb[:n] if rgb is not None and has_rgb else None), nrm
 
 
+def ply_write(path, xyz, rgb=None, normals=None, ascii=True):
+    """PCCPointSet3::write, byte for byte."""
+    L = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.int16)
+    rgb = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+    nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+    _check(L.tmc2_ply_write(str(path).encode(), _ptr(xyz), None if rgb is None else _ptr(rgb), None if nrm is None else _ptr(nrm),
+                            C.c_uint64(len(xyz)), int(bool(ascii))))
+
+
 def point_set_checksum(xyz, rgb=None, reorder=False):
     """PCCPointSet3::computeChecksum: the 16 MD5 bytes."""
     L = load_library()

@@ -944,6 +944,18 @@ int ref_ply_get( int16_t* xyz, uint8_t* rgb, double* normals ) {
     }
   return 0;
 }
+int ref_ply_write( const char* path, const int16_t* xyz, const uint8_t* rgb, const double* normals, size_t n, int asAscii ) {
+  PCCPointSet3 pc;
+  if ( rgb ) pc.addColors();
+  if ( normals ) pc.addNormals();
+  pc.resize( n );
+  for ( size_t i = 0; i < n; ++i ) {
+    pc[i] = PCCPoint3D( xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] );
+    if ( rgb ) pc.setColor( i, PCCColor3B( rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] ) );
+    if ( normals ) pc.setNormal( i, PCCNormal3D( normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] ) );
+  }
+  return pc.write( path, asAscii != 0 ) ? 0 : -1;
+}
 int ref_checksum( const int16_t* xyz, const uint8_t* rgb, size_t n, int reorderPoints, uint8_t* digest16 ) {
   PCCPointSet3 pc;
   if ( rgb ) pc.addColors();

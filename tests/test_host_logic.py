@@ -368,3 +368,30 @@ def test_host_tree_and_orientation_on_degenerate_clouds(oracle, seed):
         knn = oracle.knn_self(xyz, 16)
         raw = oracle.compute_normals(xyz, knn)
         assert np.array_equal(bits(T.host_orient_normals(xyz, knn, raw)), bits(oracle.orient_normals(xyz, knn, raw)))
+
+
+@pytest.mark.parametrize("ascii_", [True, False])
+@pytest.mark.parametrize("with_rgb,with_normals", [(True, False), (True, True), (False, False)])
+def test_host_ply_write_is_byte_identical_to_the_reference(tmp_path, ascii_, with_rgb, with_normals):
+    """PCCPointSet3::write: the files the reference writes for reconstructed frames, byte for byte (where the compiled
+    reference is present), and the product's own reader gets the cloud back from them."""
+    import oracle_binding as ob
+    xyz, rgb = _ply_inputs()
+    rng = np.random.default_rng(2)
+    nrm = rng.normal(size=(len(xyz), 3)) if with_normals else None
+    mine = tmp_path / "mine.ply"
+    T.ply_write(str(mine), xyz, rgb if with_rgb else None, nrm, ascii_)
+    got = T.ply_read(str(mine), read_normals=True)
+    assert np.array_equal(got[0], xyz) and (not with_rgb or np.array_equal(got[1], rgb))
+    if with_normals and not ascii_:
+        assert np.array_equal(got[2], nrm.astype(np.float32).astype(np.float64))
+    if os.path.exists(ob.REF_PATH):
+        import ctypes as C
+        theirs = tmp_path / "theirs.ply"
+        L = ob.Reference().L
+        x = np.ascontiguousarray(xyz, np.int16)
+        c = np.ascontiguousarray(rgb, np.uint8) if with_rgb else None
+        n64 = None if nrm is None else np.ascontiguousarray(nrm, np.float64)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        assert L.ref_ply_write(str(theirs).encode(), p(x), p(c), p(n64), C.c_size_t(len(x)), int(ascii_)) == 0
+        assert mine.read_bytes() == theirs.read_bytes()
