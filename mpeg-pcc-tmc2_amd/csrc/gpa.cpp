@@ -587,7 +587,7 @@ int globalPatchAllocationFrames( tmc2_frame** fr, int count, int minW, int minH,
     }
     f->packedHeight       = g.height;
     f->packedWidth        = g.width;
-    f->haveGeometryImages = f->haveAttributeImages = false;
+    f->haveGeometryImages = f->haveAttributeImages = f->haveReconstruction = false;
     if ( widths ) widths[i] = g.width;
     if ( heights ) heights[i] = g.height;
   }

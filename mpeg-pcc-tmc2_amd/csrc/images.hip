@@ -300,6 +300,8 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
               occPrecision );
     return TMC2_E_UNSUPPORTED;
   }
+  // new canvases: whatever was derived from the old ones is stale
+  f->haveGeometryImages = f->haveAttributeImages = f->haveReconstruction = false;
   tmc2_ctx*   ctx = f->ctx;
   hipStream_t s   = ctx->stream;
   const int   P   = int( f->patches.size() );
