@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "PCCCommon.h"
+#include "PCCImage.h"
 #include "PCCPatch.h"
 #include "PCCPatchSegmenter.h"
 #include "PCCPointSet.h"
@@ -35,6 +36,19 @@ void toRecords( const std::vector<pcc::PCCPatch>& patches, std::vector<tmc2_patc
 // and sets u0 / v0 / patchOrientation / bestMatchIdx as packFlexible / spatialConsistencyPackFlexible leave them
 void applyPacking( const tmc2_patch* recordsByIndex, const int32_t* order, const int32_t* matches, int count,
                    std::vector<pcc::PCCPatch>& patches );
+
+// S11-S16 of one frame (tmc2_frame_get_geometry_images) -> the reference's containers: PCCFrameContext::occupancyMap_ and
+// blockToPatch_, the frame of the occupancy video, the two frames of the geometry video (formats and untouched planes as
+// generateOccupancyMapVideo / generateIntraImage leave them)
+void toFrameImages( const uint8_t* occupancy, const uint8_t* occVideo, const uint32_t* blockToPatch, const uint16_t* geometryD0,
+                    const uint16_t* geometryD1, size_t W, size_t H, size_t occupancyPrecision, std::vector<uint32_t>& occupancyMap,
+                    std::vector<size_t>& blockToPatchOut, pcc::PCCImage<uint8_t, 3>& occupancyFrame, pcc::PCCImage<uint16_t, 3>& d0,
+                    pcc::PCCImage<uint16_t, 3>& d1 );
+// S20-S22 (tmc2_frame_get_attribute_images, uint8 [2][3][H][W]) -> the two frames of the attribute video
+void toAttributeFrames( const uint8_t* attribute, size_t W, size_t H, pcc::PCCImage<uint16_t, 3>& t0, pcc::PCCImage<uint16_t, 3>& t1 );
+// S17 / S18 (tmc2_frame_get_reconstruction) -> the reconstructed cloud and PCCFrameContext::pointToPixel_
+void toReconstruction( const int16_t* xyz, const uint8_t* rgb, const uint32_t* pointToPixel, size_t n, pcc::PCCPointSet3& cloud,
+                       std::vector<pcc::PCCVector3<size_t>>& pointToPixelOut );
 
 // drop-in body of PCCPatchSegmenter3::compute (PCCPatchSegmenter.cpp:53-224) for the CTC lossy conditions: S1-S9 on the
 // device; the frame stays resident in *keep for the image-generation calls that follow.  Returns a tmc2 status.

@@ -44,6 +44,7 @@
 #include "PCCGroupOfFrames.h"
 #include "PCCImage.h"
 #include "PCCInternalColorConverter.h"
+#include "tmc2hip_adaptor.h"  // integration/: the reference-side conversions, checked below against the reference's own containers
 #include "PCCVideo.h"
 #include "PCCBitstream.h"
 #undef private
@@ -337,6 +338,7 @@ struct Gof {
   PCCGroupOfFrames     sources, reconstructs;
   PCCLogger            logger;
   std::vector<std::vector<uint32_t>> partitions;
+  std::vector<std::vector<uint32_t>> occupancyAfterPhaseA;  // (phase B overwrites the tiles' occupancy maps)
 };
 std::unique_ptr<Gof> g_gof;
 
@@ -497,6 +499,8 @@ int ref_gof_phase_a() {
   // identity codec: videoOccupancyMap stays as generated
   E.generateBlockToPatchFromOccupancyMapVideo( context, E.params_.occupancyResolution_, E.params_.occupancyPrecision_ );
   E.generateGeometryVideo( sources, context );
+  G.occupancyAfterPhaseA.clear();
+  for ( auto& fr : frames ) G.occupancyAfterPhaseA.push_back( fr.getTitleFrameContext().getOccupancyMap() );
   fflush( stdout );
   dup2( savedOut, 1 );
   close( savedOut );
@@ -912,6 +916,69 @@ int ref_convert_yuv420_to_yuv444( const uint8_t* y, const uint8_t* u, const uint
     std::copy( dst[0][c].begin(), dst[0][c].end(), out + size_t( c ) * W * H );
   }
   return 0;
+}
+
+// ---- integration/tmc2hip_convert.cpp against the containers the reference itself filled (after ref_gof_phase_a / _b) ----
+// The caller passes what the C-ABI getters return for frame `frame` (tmc2_frame_get_geometry_images,
+// tmc2_frame_get_attribute_images, tmc2_frame_get_reconstruction); the adaptor's conversions rebuild the reference's
+// containers from them, and every element / format / plane is compared with the GOF context.  Returns the number of
+// containers that differ (0 = a maintainer's write-back with these conversions leaves the context as the reference does).
+int ref_adaptor_check_frame( int frame, const uint8_t* occupancy, const uint8_t* occVideo, const uint32_t* blockToPatch,
+                             const uint16_t* geo0, const uint16_t* geo1, const uint8_t* attribute, const int16_t* recXyz,
+                             const uint8_t* recRgb, const uint32_t* pointToPixel, size_t recCount ) {
+  Gof&   G  = *g_gof;
+  auto&  fc = G.context.getFrames()[size_t( frame )].getTitleFrameContext();
+  size_t W = fc.getWidth(), H = fc.getHeight(), p = G.encoder.params_.occupancyPrecision_;
+  int    bad = 0;
+  auto   sameImage = []( auto& a, auto& b ) {
+    if ( a.getWidth() != b.getWidth() || a.getHeight() != b.getHeight() || a.getColorFormat() != b.getColorFormat() ) return false;
+    for ( size_t c = 0; c < 3; ++c )
+      if ( a.getChannel( c ) != b.getChannel( c ) ) return false;
+    return true;
+  };
+  {
+    std::vector<uint32_t>  om;
+    std::vector<size_t>    b2p;
+    PCCImage<uint8_t, 3>   ov;
+    PCCImage<uint16_t, 3>  d0, d1;
+    tmc2hip::toFrameImages( occupancy, occVideo, blockToPatch, geo0, geo1, W, H, p, om, b2p, ov, d0, d1 );
+    auto& vg = G.context.getVideoGeometryMultiple()[0];
+    // (phase B overwrites the tile's occupancy map with the upsampled occupancy video, PCCCodec.cpp:559-572: compare phase A's)
+    if ( !G.occupancyAfterPhaseA.empty() && om != G.occupancyAfterPhaseA[size_t( frame )] ) bad |= 1;
+    if ( b2p != fc.getBlockToPatch() ) bad |= 2;
+    if ( !sameImage( ov, G.context.getVideoOccupancyMap().getFrame( size_t( frame ) ) ) ) bad |= 4;
+    if ( !sameImage( d0, vg.getFrame( 2 * size_t( frame ) ) ) ) bad |= 8;
+    if ( !sameImage( d1, vg.getFrame( 2 * size_t( frame ) + 1 ) ) ) bad |= 16;
+  }
+  if ( attribute ) {
+    PCCImage<uint16_t, 3> t0, t1;
+    tmc2hip::toAttributeFrames( attribute, W, H, t0, t1 );
+    auto& va = G.context.getVideoAttributesMultiple()[0];
+    if ( !sameImage( t0, va.getFrame( 2 * size_t( frame ) ) ) ) bad |= 32;
+    if ( !sameImage( t1, va.getFrame( 2 * size_t( frame ) + 1 ) ) ) bad |= 64;
+  }
+  if ( recXyz ) {
+    PCCPointSet3                    cloud;
+    std::vector<PCCVector3<size_t>> p2p;
+    tmc2hip::toReconstruction( recXyz, recRgb, pointToPixel, recCount, cloud, p2p );
+    auto& rec = G.reconstructs[size_t( frame )];
+    if ( cloud.getPointCount() != rec.getPointCount() ) bad |= 128;
+    else
+      for ( size_t i = 0; i < rec.getPointCount(); ++i )
+        if ( cloud[i] != rec[i] || cloud.getColor( i ) != rec.getColor( i ) ) {
+          bad |= 128;
+          break;
+        }
+    auto& refP2p = fc.getPointToPixel();
+    if ( p2p.size() != refP2p.size() ) bad |= 256;
+    else
+      for ( size_t i = 0; i < p2p.size(); ++i )
+        if ( p2p[i][0] != refP2p[i][0] || p2p[i][1] != refP2p[i][1] || p2p[i][2] != refP2p[i][2] ) {
+          bad |= 256;
+          break;
+        }
+  }
+  return bad;
 }
 
 // ---- ingest and checksums: PCCPointSet3::read (PCCPointSet.cpp:464-757), computeChecksum (:222-243) ----

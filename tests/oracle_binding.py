@@ -517,6 +517,21 @@ class Reference:
         self.L.ref_smooth_and_transfer(_p(x), _p(bt), _p(part), _p(c), C.c_size_t(len(x)), int(grid_size), C.c_double(threshold))
         return x, bt, c
 
+    def adaptor_check_frame(self, frame, img, phase_b=None):
+        """integration/tmc2hip_convert.cpp on what the C-ABI getters return for a frame (img: occupancy, occ_video,
+        block_to_patch, geo0, geo1; phase_b: attribute, recon_xyz, recon_rgb, point_to_pixel) against the containers the reference
+        filled for that frame (after phase_a / phase_b on the same GOF).  Returns a bit mask of containers that differ."""
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        occ, ov, b2p = c(img["occupancy"], np.uint8), c(img["occ_video"], np.uint8), c(img["block_to_patch"], np.uint32)
+        g0, g1 = c(img["geo0"], np.uint16), c(img["geo1"], np.uint16)
+        if phase_b is None:
+            return self.L.ref_adaptor_check_frame(int(frame), _p(occ), _p(ov), _p(b2p), _p(g0), _p(g1), None, None, None, None,
+                                                  C.c_size_t(0))
+        att = c(phase_b["attribute"], np.uint8)
+        x, col, p2p = c(phase_b["recon_xyz"], np.int16), c(phase_b["recon_rgb"], np.uint8), c(phase_b["point_to_pixel"], np.uint32)
+        return self.L.ref_adaptor_check_frame(int(frame), _p(occ), _p(ov), _p(b2p), _p(g0), _p(g1), _p(att), _p(x), _p(col), _p(p2p),
+                                              C.c_size_t(len(x)))
+
     def ply_read(self, path, read_normals=False):
         """PCCPointSet3::read -> (xyz, rgb or None, normals or None), or None if the reference refuses the file."""
         L = self.L

@@ -48,6 +48,25 @@ def test_adaptor_rebuilds_the_reference_patch_list(adaptor, oracle, name, frame,
                                          _p(occ)) > 0
 
 
+@pytest.mark.parametrize("name,nframes,prec", [("tiny", 2, 4), ("small", 1, 2)])
+def test_adaptor_rebuilds_the_reference_frame_containers(oracle, reference, name, nframes, prec):
+    """The canvases, attribute frames and the reconstruction as the C-ABI getters return them (here: the oracle's,
+    bit-identical) -> toFrameImages / toAttributeFrames / toReconstruction -> compared with the containers the reference's own
+    encoder members filled for the same GOF: occupancy map, blockToPatch, the occupancy-video frame (format, chroma planes),
+    both geometry frames, both attribute frames, the reconstructed cloud with its colours, pointToPixel."""
+    frames = [synth_cloud(name, f) for f in range(nframes)]
+    ra = reference.phase_a(frames, 10, 11, prec)
+    oa = oracle.phase_a(frames, 10, 11, prec)
+    for f, img in enumerate(oa):
+        assert reference.adaptor_check_frame(f, img) == 0
+    reference.phase_b(frames, ra, prec)
+    ob_ = oracle.phase_b(frames, oa, prec)
+    for f, (img, b) in enumerate(zip(oa, ob_)):
+        assert reference.adaptor_check_frame(f, img, b) == 0
+    broken = dict(oa[0], geo1=oa[0]["geo1"] + 1)                      # and the check does notice a difference
+    assert reference.adaptor_check_frame(0, broken, ob_[0]) == 16
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(os.environ.get("TMC2_ADAPTOR_GPU_TEST") != "1", reason="opt-in (TMC2_ADAPTOR_GPU_TEST=1): not yet run on a GPU")
 def test_adaptor_segmenter_compute_is_a_drop_in(adaptor):
