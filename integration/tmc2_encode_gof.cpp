@@ -1,0 +1,234 @@
+// integration/tmc2_encode_gof.cpp -- a native host front end over the C-ABI of libtmc2hip.so (no reference code, no Python):
+// the image-generation half of PccAppEncoder for one GOF, with an identity video codec.
+//
+//   tmc2_encode_gof --in frame_%04d.ply --start 1051 --frames 32 --out /tmp/gof [--condition ai|ld|ra] [--device 0]
+//                   [--workers 16] [--iterations 10] [--bits 10] [--precision 4] [--min-width 1280] [--min-height 1280]
+//
+// Per frame (one host thread + one tmc2_ctx per in-flight frame, as the reference runs one TBB task per frame):
+//   PLY ingest -> S1-S9 patch generation -> packing (all-intra: per frame; low delay / random access: the chained packer, then
+//   the global patch allocation over the GOF) -> occupancy / geometry canvases -> reconstruction, colour transfer, attribute
+//   canvases -> I420 attribute frames (what the video encoder reads) -> identity codec -> 16-bit 4:4:4 -> post-reconstruction
+//   tail -> reconstructed PLY + conformance checksum.
+// Written to <out>_occupancy_WxH.yuv (8-bit 4:0:0 samples), <out>_geometry_WxH_16bit.yuv (two maps per frame, luma only),
+// <out>_attribute_WxH_8bit_p420.yuv (two maps per frame), <out>_rec_%04d.ply, <out>_checksums.txt.
+// Exits non-zero with the library's message when no MI355X is visible -- there is no CPU fallback.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tmc2hip.h"
+
+namespace {
+struct Options {
+  std::string in, out = "gof";
+  std::string condition = "ai";
+  int         start = 0, frames = 1, device = 0, workers = 8, iterations = 10, bits = 10, precision = 4, minW = 1280, minH = 1280;
+};
+[[noreturn]] void die( const std::string& what ) {
+  std::fprintf( stderr, "tmc2_encode_gof: %s: %s\n", what.c_str(), tmc2_last_error() );
+  std::exit( 2 );
+}
+#define CHECK( call )                    \
+  do {                                   \
+    if ( ( call ) != TMC2_OK ) die( #call ); \
+  } while ( 0 )
+
+void usage() {
+  std::puts( "usage: tmc2_encode_gof --in frame_%04d.ply [--start N] [--frames N] [--out prefix] [--condition ai|ld|ra] [--device N]\n"
+             "                       [--workers N] [--iterations N] [--bits N] [--precision N] [--min-width N] [--min-height N]" );
+}
+bool parse( int argc, char** argv, Options& o ) {
+  for ( int i = 1; i < argc; ++i ) {
+    const std::string a = argv[i];
+    auto              next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+    if ( a == "--in" ) o.in = next();
+    else if ( a == "--out" ) o.out = next();
+    else if ( a == "--condition" ) o.condition = next();
+    else if ( a == "--start" ) o.start = std::atoi( next() );
+    else if ( a == "--frames" ) o.frames = std::atoi( next() );
+    else if ( a == "--device" ) o.device = std::atoi( next() );
+    else if ( a == "--workers" ) o.workers = std::atoi( next() );
+    else if ( a == "--iterations" ) o.iterations = std::atoi( next() );
+    else if ( a == "--bits" ) o.bits = std::atoi( next() );
+    else if ( a == "--precision" ) o.precision = std::atoi( next() );
+    else if ( a == "--min-width" ) o.minW = std::atoi( next() );
+    else if ( a == "--min-height" ) o.minH = std::atoi( next() );
+    else if ( a == "--help" || a == "-h" ) return false;
+    else {
+      std::fprintf( stderr, "unknown option %s\n", a.c_str() );
+      return false;
+    }
+  }
+  return !o.in.empty() && o.frames > 0 && ( o.condition == "ai" || o.condition == "ld" || o.condition == "ra" );
+}
+
+// the CTC lossy settings (cfg/common/ctc-common.cfg + sequence cfg), as tmc2_amd.ctc_params
+tmc2_segmenter_params ctcParams( int iterations, int bits3D, const double w[3] ) {
+  tmc2_segmenter_params p{};
+  p.nnNormalEstimation = 16, p.normalOrientation = 1, p.gridBasedRefineSegmentation = 1, p.maxNNCountRefineSegmentation = 1024;
+  p.iterationCountRefineSegmentation = iterations, p.voxelDimensionRefineSegmentation = 4, p.searchRadiusRefineSegmentation = 192;
+  p.occupancyResolution = 16, p.enablePatchSplitting = 1, p.maxPatchSize = 1024, p.quantizerSizeX = 16, p.quantizerSizeY = 16;
+  p.minPointCountPerCCPatchSegmentation = 16, p.maxNNCountPatchSegmentation = 16, p.surfaceThickness = 4, p.mapCountMinus1 = 1;
+  p.minLevel = 64, p.maxAllowedDepth = 255, p.geometryBitDepth2D = 8, p.geometryBitDepth3D = bits3D;
+  p.maxAllowedDist2RawPointsDetection = 9, p.maxAllowedDist2RawPointsSelection = 1, p.lambdaRefineSegmentation = 3;
+  for ( int c = 0; c < 3; ++c ) p.weightNormal[c] = w[c];
+  return p;
+}
+
+struct Frame {
+  std::vector<int16_t> xyz;
+  std::vector<uint8_t> rgb;
+  uint64_t             n = 0;
+  tmc2_frame*          f = nullptr;
+  int32_t              height = 0;
+};
+
+// run fn( frameIndex ) for every frame on `workers` threads; worker w owns context w
+template <typename Fn>
+void forFrames( int frames, int workers, Fn fn ) {
+  std::atomic<int>         next( 0 );
+  std::vector<std::thread> pool;
+  for ( int w = 0; w < workers; ++w )
+    pool.emplace_back( [&, w] {
+      for ( int i = next++; i < frames; i = next++ ) fn( i, w );
+    } );
+  for ( auto& t : pool ) t.join();
+}
+}  // namespace
+
+int main( int argc, char** argv ) {
+  Options o;
+  if ( !parse( argc, argv, o ) ) {
+    usage();
+    return 1;
+  }
+  const int workers = std::max( 1, std::min( o.workers, o.frames ) );
+  // one context per worker: a HIP stream + allocator each; frame i lives on worker i % workers for its whole life
+  std::vector<tmc2_ctx*> ctx( size_t( workers ), nullptr );
+  for ( auto& c : ctx ) CHECK( tmc2_ctx_create( o.device, &c ) );
+  tmc2_set_host_parallelism( 16 );
+  tmc2_set_kdtree_placement( workers >= 8 ? 1 : 0 );
+
+  std::vector<Frame> gof( size_t( o.frames ) );
+  // ingest + upload (frame i on context i % workers; all later calls on that frame are ordered on that context)
+  forFrames( o.frames, workers, [&]( int i, int ) {
+    char path[4096];
+    std::snprintf( path, sizeof( path ), o.in.c_str(), o.start + i );
+    Frame& fr = gof[size_t( i )];
+    int    hasColors = 0;
+    CHECK( tmc2_ply_info( path, 0, &fr.n, &hasColors, nullptr ) );
+    if ( !hasColors || fr.n == 0 ) {
+      std::fprintf( stderr, "tmc2_encode_gof: %s has no colours or no points\n", path );
+      std::exit( 2 );
+    }
+    fr.xyz.resize( 3 * fr.n ), fr.rgb.resize( 3 * fr.n );
+    CHECK( tmc2_ply_read( path, fr.xyz.data(), fr.rgb.data(), nullptr, fr.n, 4, &fr.n ) );
+  } );
+  for ( int i = 0; i < o.frames; ++i )
+    CHECK( tmc2_frame_create( ctx[size_t( i % workers )], gof[size_t( i )].xyz.data(), gof[size_t( i )].rgb.data(), gof[size_t( i )].n,
+                              &gof[size_t( i )].f ) );
+
+  // S0 once per GOF on frame 0, then S1-S9 per frame
+  double w[3];
+  CHECK( tmc2_weight_normal( gof[0].f, o.bits + 1, 0.6, w ) );
+  const tmc2_segmenter_params params = ctcParams( o.iterations, o.bits + 1, w );
+  std::vector<std::thread>    pool;
+  auto perFrame = [&]( auto fn ) {  // frames of one worker in order, workers in parallel
+    pool.clear();
+    for ( int wk = 0; wk < workers; ++wk )
+      pool.emplace_back( [&, wk] {
+        for ( int i = wk; i < o.frames; i += workers ) fn( gof[size_t( i )], i );
+      } );
+    for ( auto& t : pool ) t.join();
+  };
+  const bool chained = o.condition != "ai";
+  perFrame( [&]( Frame& fr, int ) {
+    CHECK( tmc2_segmenter_compute( fr.f, &params ) );
+    if ( !chained ) CHECK( tmc2_encoder_pack_flexible( fr.f, o.minW, 2, 1.0, &fr.height ) );
+  } );
+  int32_t tileW = o.minW, gofH = 0;
+  if ( chained ) {  // a sequential chain over the GOF: microseconds per frame on the host
+    CHECK( tmc2_encoder_pack_flexible( gof[0].f, o.minW, 2, 1.0, &gof[0].height ) );
+    for ( int i = 1; i < o.frames; ++i )
+      CHECK( tmc2_encoder_pack_spatial_consistency( gof[size_t( i )].f, gof[size_t( i - 1 )].f, o.minW, 2, 1.0, &gof[size_t( i )].height ) );
+    if ( o.condition == "ra" ) {
+      std::vector<tmc2_frame*> fs;
+      for ( auto& fr : gof ) fs.push_back( fr.f );
+      std::vector<int32_t> widths( size_t( o.frames ) ), heights( size_t( o.frames ) );
+      CHECK( tmc2_encoder_global_patch_allocation( fs.data(), o.frames, o.minW, o.minH, widths.data(), heights.data() ) );
+      for ( int i = 0; i < o.frames; ++i ) gof[size_t( i )].height = heights[size_t( i )];
+    }
+    for ( auto& fr : gof ) {
+      int32_t pw = 0;
+      CHECK( tmc2_frame_get_packed_size( fr.f, &pw, nullptr ) );
+      tileW = std::max( tileW, pw );
+    }
+  }
+  for ( auto& fr : gof ) gofH = std::max( gofH, fr.height );
+  int32_t W = 0, H = 0;
+  CHECK( tmc2_encoder_canvas_size( &gofH, 1, tileW, o.minW, o.minH, &W, &H ) );
+  std::printf( "GOF canvas %d x %d, %d frames, condition %s\n", W, H, o.frames, o.condition.c_str() );
+
+  const size_t area = size_t( W ) * H, frame420 = area * 3 / 2, p = size_t( o.precision );
+  std::vector<std::vector<uint8_t>>  occVideo( size_t( o.frames ) ), i420( size_t( o.frames ) );
+  std::vector<std::vector<uint16_t>> geometry( size_t( o.frames ) );
+  std::vector<std::string>           checksums( size_t( o.frames ) );
+  perFrame( [&]( Frame& fr, int i ) {
+    CHECK( tmc2_encoder_generate_geometry_images( fr.f, W, H, o.precision ) );
+    occVideo[size_t( i )].resize( area / ( p * p ) );
+    geometry[size_t( i )].resize( 2 * area );
+    CHECK( tmc2_frame_get_geometry_images( fr.f, nullptr, occVideo[size_t( i )].data(), nullptr, geometry[size_t( i )].data(),
+                                           geometry[size_t( i )].data() + area ) );
+    // (a real encoder codes occupancy + geometry here and hands the decoded frames back: tmc2_frame_set_decoded_geometry)
+    CHECK( tmc2_encoder_generate_attribute_images( fr.f ) );
+    i420[size_t( i )].resize( 2 * frame420 );
+    CHECK( tmc2_encoder_attribute_to_yuv420( fr.f, 4, i420[size_t( i )].data() ) );
+    // (attribute video codec here) -- identity: the frames come straight back
+    CHECK( tmc2_codec_set_decoded_attribute_yuv420( fr.f, i420[size_t( i )].data(), 0 ) );
+    CHECK( tmc2_codec_identify_boundary_points( fr.f ) );
+    CHECK( tmc2_codec_color_point_cloud( fr.f, nullptr ) );
+    CHECK( tmc2_codec_smooth_point_cloud_postprocess( fr.f, 8, 64.0 ) );
+    CHECK( tmc2_codec_transfer_colors_16bit_bp( fr.f ) );
+    CHECK( tmc2_codec_convert_yuv16_to_rgb8( fr.f ) );
+    const size_t         M = size_t( tmc2_frame_recon_count( fr.f ) );
+    std::vector<int16_t> xyz( 3 * M );
+    std::vector<uint8_t> rgb( 3 * M );
+    CHECK( tmc2_frame_get_post_reconstruction( fr.f, xyz.data(), nullptr, rgb.data(), nullptr ) );
+    char path[4096];
+    std::snprintf( path, sizeof( path ), "%s_rec_%04d.ply", o.out.c_str(), o.start + i );
+    CHECK( tmc2_ply_write( path, xyz.data(), rgb.data(), nullptr, M, 1 ) );
+    uint8_t digest[16];
+    CHECK( tmc2_point_set_checksum( xyz.data(), rgb.data(), M, 0, digest ) );
+    char hex[33];
+    for ( int k = 0; k < 16; ++k ) std::snprintf( hex + 2 * k, 3, "%02x", digest[k] );
+    checksums[size_t( i )] = hex;
+  } );
+
+  auto writeAll = [&]( const std::string& name, auto&& writer ) {
+    FILE* fp = std::fopen( name.c_str(), "wb" );
+    if ( !fp ) {
+      std::fprintf( stderr, "tmc2_encode_gof: cannot create %s\n", name.c_str() );
+      std::exit( 2 );
+    }
+    writer( fp );
+    std::fclose( fp );
+  };
+  const std::string dims = std::to_string( W ) + "x" + std::to_string( H );
+  writeAll( o.out + "_occupancy_" + std::to_string( W / o.precision ) + "x" + std::to_string( H / o.precision ) + "_8bit_p400.yuv",
+            [&]( FILE* fp ) { for ( auto& v : occVideo ) std::fwrite( v.data(), 1, v.size(), fp ); } );
+  writeAll( o.out + "_geometry_" + dims + "_16bit_p400.yuv",
+            [&]( FILE* fp ) { for ( auto& v : geometry ) std::fwrite( v.data(), 2, v.size(), fp ); } );
+  writeAll( o.out + "_attribute_" + dims + "_8bit_p420.yuv",
+            [&]( FILE* fp ) { for ( auto& v : i420 ) std::fwrite( v.data(), 1, v.size(), fp ); } );
+  writeAll( o.out + "_checksums.txt", [&]( FILE* fp ) {
+    for ( int i = 0; i < o.frames; ++i ) std::fprintf( fp, "%04d %s\n", o.start + i, checksums[size_t( i )].c_str() );
+  } );
+  for ( auto& fr : gof ) tmc2_frame_destroy( fr.f );
+  for ( auto& c : ctx ) tmc2_ctx_destroy( c );
+  return 0;
+}

@@ -395,3 +395,30 @@ def test_host_ply_write_is_byte_identical_to_the_reference(tmp_path, ascii_, wit
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         assert L.ref_ply_write(str(theirs).encode(), p(x), p(c), p(n64), C.c_size_t(len(x)), int(ascii_)) == 0
         assert mine.read_bytes() == theirs.read_bytes()
+
+
+def test_native_front_end_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """integration/tmc2_encode_gof.cpp (a C++ host front end over the C-ABI, the whole GOF path) compiles against
+    include/tmc2hip.h alone and, on a machine without an MI355X, stops with the library's "no device" error instead of
+    computing anything on the CPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host toolchain")
+    subprocess.run(["make", "-C", os.path.join(root, "integration")], check=True, capture_output=True)
+    exe = os.path.join(root, "integration", "tmc2_encode_gof")
+    assert subprocess.run([exe, "--help"], capture_output=True).returncode == 1
+    xyz, rgb = synth_cloud("tiny", 0)
+    T.ply_write(str(tmp_path / "fr_0000.ply"), xyz, rgb)
+    r = subprocess.run([exe, "--in", str(tmp_path / "fr_%04d.ply"), "--frames", "1", "--out", str(tmp_path / "gof")],
+                       capture_output=True, text=True)
+    try:
+        import torch
+        gpu = torch.cuda.is_available()
+    except ImportError:
+        gpu = False
+    if gpu:
+        assert r.returncode == 0 and (tmp_path / "gof_checksums.txt").exists()
+    else:
+        assert r.returncode == 2 and "no HIP device" in r.stderr and not list(tmp_path.glob("gof_*"))
