@@ -297,6 +297,13 @@ int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
                           const uint8_t* recRgb, uint64_t m, const double* srcNormals, double resolution, double* out,
                           int64_t* counts );
 
+/* replaces: PCCMetrics::display / QualityMetrics::print (PCCMetrics.cpp:376-391, 230-279) for one frame: the text the CTC log
+ * parsers read, from the numbers of tmc2_metrics_compute (out[3][8], counts[2]), the point counts before duplicate removal
+ * and the peak value.  precision: that of the application's std::cout (PccAppEncoder / PccAppMetrics set 9).  text may be
+ * NULL to query the size (*needed, including the terminating 0).  Host only.                                       */
+int tmc2_metrics_display( const double* out, uint64_t sourcePoints, uint64_t reconstructPoints, const int64_t* counts,
+                          uint64_t resolution, int withC2p, int precision, char* text, uint64_t capacity, uint64_t* needed );
+
 /* ---- point-cloud ingest and conformance checksums (host; no device needed) ------------------------------------------- */
 /* replaces: PCCPointSet3::read (PccLibCommon/source/PCCPointSet.cpp:464-757) as PCCGroupOfFrames::load (PCCGroupOfFrames.cpp:
  * 46-80) calls it per frame: ASCII and binary_little_endian PLY, x / y / z of 2, 4 or 8 bytes, uchar red / green / blue, float

@@ -542,6 +542,20 @@ def host_global_patch_allocation(lists, pools, matches, tile_w, tile_h, min_w=12
     return res
 
 
+def metrics_display(out, source_points, reconstruct_points, counts, resolution=1023, with_c2p=True, precision=9):
+    """The text PCCMetrics::display() prints for one frame (what the CTC log parsers read)."""
+    L = load_library()
+    q = np.ascontiguousarray(out, dtype=np.float64)
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    need = C.c_uint64()
+    _check(L.tmc2_metrics_display(_ptr(q), C.c_uint64(int(source_points)), C.c_uint64(int(reconstruct_points)), _ptr(c),
+                                  C.c_uint64(int(resolution)), int(bool(with_c2p)), int(precision), None, C.c_uint64(0), C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(L.tmc2_metrics_display(_ptr(q), C.c_uint64(int(source_points)), C.c_uint64(int(reconstruct_points)), _ptr(c),
+                                  C.c_uint64(int(resolution)), int(bool(with_c2p)), int(precision), buf, C.c_uint64(need.value), None))
+    return buf.value.decode()
+
+
 def ply_info(path, read_normals=False):
     """(point count, has colours, has float normals) from the header of a PLY file."""
     L = load_library()

@@ -1107,6 +1107,55 @@ int ref_metrics( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const i
   return 0;
 }
 
+// the text PCCMetrics::display() prints for the same inputs, at the precision the applications give std::cout (9)
+int64_t ref_metrics_display( const int16_t* srcXyz, const uint8_t* srcRgb, size_t n, const int16_t* recXyz, const uint8_t* recRgb,
+                             size_t m, const double* srcNormals, double resolution, char* text, int64_t capacity ) {
+  PCCGroupOfFrames sources, recs, normals;
+  sources.setFrameCount( 1 );
+  recs.setFrameCount( 1 );
+  makeCloud( sources[0], srcXyz, srcRgb, n );
+  makeCloud( recs[0], recXyz, recRgb, m );
+  if ( srcNormals ) {
+    normals.setFrameCount( 1 );
+    makeCloud( normals[0], srcXyz, srcRgb, n );
+    normals[0].addNormals();
+    for ( size_t i = 0; i < n; ++i )
+      normals[0].setNormal( i, PCCNormal3D( srcNormals[3 * i], srcNormals[3 * i + 1], srcNormals[3 * i + 2] ) );
+  }
+  PCCMetricsParameters mp;
+  mp.resolution_ = size_t( resolution );
+  mp.computeC2p_ = srcNormals != nullptr;
+  PCCMetrics metrics;
+  metrics.setParameters( mp );
+  char  path[] = "/tmp/tmc2_ref_display_XXXXXX";
+  int   fd     = mkstemp( path );
+  fflush( stdout );
+  int savedOut = dup( 1 );
+  dup2( fd, 1 );
+  metrics.compute( sources, recs, normals );
+  fflush( stdout );
+  std::cout.flush();
+  ftruncate( fd, 0 );
+  lseek( fd, 0, SEEK_SET );
+  const auto oldPrecision = std::cout.precision( std::numeric_limits<float>::max_digits10 );
+  metrics.display();
+  std::cout.flush();
+  fflush( stdout );
+  std::cout.precision( oldPrecision );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  const int64_t size = lseek( fd, 0, SEEK_END );
+  lseek( fd, 0, SEEK_SET );
+  int64_t got = 0;
+  if ( size < capacity ) {
+    got       = read( fd, text, size_t( size ) );
+    text[got] = 0;
+  }
+  close( fd );
+  unlink( path );
+  return size;
+}
+
 // chroma planes of the geometry frames must stay zero (generateIntraImage :3932, dilate3DPadding on 3 channels)
 int ref_gof_geometry_chroma_nonzero( int frame ) {
   auto&  vg = g_gof->context.getVideoGeometryMultiple()[0];

@@ -422,3 +422,31 @@ def test_native_front_end_builds_and_fails_loudly_without_a_gpu(tmp_path):
         assert r.returncode == 0 and (tmp_path / "gof_checksums.txt").exists()
     else:
         assert r.returncode == 2 and "no HIP device" in r.stderr and not list(tmp_path.glob("gof_*"))
+
+
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_host_metrics_display_text_matches_the_reference(oracle, with_normals):
+    """PCCMetrics::display(): the log lines the CTC parsers read, rebuilt from the numbers the metric entry returns (here the
+    oracle's, bit-identical to tmc2_metrics_compute) -- against the reference's own stdout at the applications' precision."""
+    import ctypes as C
+    import oracle_binding as ob
+    if not os.path.exists(ob.REF_PATH):
+        pytest.skip("compiled reference not present")
+    xyz, rgb = synth_cloud("tiny", 0)
+    rng = np.random.default_rng(4)
+    rec = np.concatenate([xyz[:5000] + rng.integers(-1, 2, (5000, 3)).astype(np.int16), xyz[:300]])    # noise + duplicates
+    rec_rgb = rng.integers(0, 256, (len(rec), 3), dtype=np.uint8)
+    nrm = oracle.normals(xyz, 16, True) if with_normals else None
+    q, counts = oracle.metrics(xyz, rgb, rec, rec_rgb, nrm, 1023.0)
+    text = T.metrics_display(q, len(xyz), len(rec), counts, 1023, with_normals, 9)
+    L = ob.Reference().L
+    L.ref_metrics_display.restype = C.c_int64
+    p = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    buf = C.create_string_buffer(1 << 16)
+    x, c, rx, rc = (np.ascontiguousarray(a) for a in (xyz, rgb, rec, rec_rgb))
+    n64 = None if nrm is None else np.ascontiguousarray(nrm, np.float64)
+    size = L.ref_metrics_display(p(x), p(c), C.c_size_t(len(x)), p(rx), p(rc), C.c_size_t(len(rx)), p(n64), C.c_double(1023.0), buf,
+                                 C.c_int64(len(buf)))
+    assert 0 < size < len(buf)
+    assert text == buf.value.decode()
+    assert "mseF,PSNR (p2point): " in text and ("mse1      (p2plane)" in text) == with_normals
