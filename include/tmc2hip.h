@@ -322,6 +322,12 @@ int tmc2_ply_write( const char* path, const int16_t* xyz, const uint8_t* rgb, co
  * merges points that share a position (mean colour) first.                                                        */
 int tmc2_point_set_checksum( const int16_t* xyz, const uint8_t* rgb, uint64_t n, int reorderPoints, uint8_t digest[16] );
 
+/* replaces: PCCChecksum::write / read (PccLibMetrics/source/PCCChecksum.cpp:112-139): the ".checksum" file kept next to the
+ * bitstream, one line per frame.  digests: uint8[frames][16] (tmc2_point_set_checksum).  read: digests may be NULL to query
+ * the frame count.                                                                                                  */
+int tmc2_checksum_file_write( const char* path, const uint8_t* digests, uint64_t frames );
+int tmc2_checksum_file_read( const char* path, uint8_t* digests, uint64_t capacity, uint64_t* frames );
+
 /* ---- host-only pieces of the path (no device needed; used by the CPU test tier) -------------- */
 /* the nanoflann-identical tree builder behind tmc2_frame_create: perm = tree order -> original index */
 int tmc2_host_kdtree_build( const int16_t* xyz, uint64_t n, uint32_t* perm, uint64_t* nodeCount, int32_t* depth );

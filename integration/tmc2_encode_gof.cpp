@@ -10,7 +10,7 @@
 //   canvases -> I420 attribute frames (what the video encoder reads) -> identity codec -> 16-bit 4:4:4 -> post-reconstruction
 //   tail -> reconstructed PLY + conformance checksum.
 // Written to <out>_occupancy_WxH.yuv (8-bit 4:0:0 samples), <out>_geometry_WxH_16bit.yuv (two maps per frame, luma only),
-// <out>_attribute_WxH_8bit_p420.yuv (two maps per frame), <out>_rec_%04d.ply, <out>_checksums.txt.
+// <out>_attribute_WxH_8bit_p420.yuv (two maps per frame), <out>_rec_%04d.ply, <out>_checksums.txt, <out>.checksum (PCCChecksum::write).
 // Exits non-zero with the library's message when no MI355X is visible -- there is no CPU fallback.
 #include <algorithm>
 #include <atomic>
@@ -178,6 +178,7 @@ int main( int argc, char** argv ) {
   std::vector<std::vector<uint8_t>>  occVideo( size_t( o.frames ) ), i420( size_t( o.frames ) );
   std::vector<std::vector<uint16_t>> geometry( size_t( o.frames ) );
   std::vector<std::string>           checksums( size_t( o.frames ) );
+  std::vector<uint8_t>               digests( size_t( o.frames ) * 16 );
   perFrame( [&]( Frame& fr, int i ) {
     CHECK( tmc2_encoder_generate_geometry_images( fr.f, W, H, o.precision ) );
     occVideo[size_t( i )].resize( area / ( p * p ) );
@@ -202,7 +203,7 @@ int main( int argc, char** argv ) {
     char path[4096];
     std::snprintf( path, sizeof( path ), "%s_rec_%04d.ply", o.out.c_str(), o.start + i );
     CHECK( tmc2_ply_write( path, xyz.data(), rgb.data(), nullptr, M, 1 ) );
-    uint8_t digest[16];
+    uint8_t* digest = digests.data() + 16 * size_t( i );
     CHECK( tmc2_point_set_checksum( xyz.data(), rgb.data(), M, 0, digest ) );
     char hex[33];
     for ( int k = 0; k < 16; ++k ) std::snprintf( hex + 2 * k, 3, "%02x", digest[k] );
@@ -228,6 +229,7 @@ int main( int argc, char** argv ) {
   writeAll( o.out + "_checksums.txt", [&]( FILE* fp ) {
     for ( int i = 0; i < o.frames; ++i ) std::fprintf( fp, "%04d %s\n", o.start + i, checksums[size_t( i )].c_str() );
   } );
+  CHECK( tmc2_checksum_file_write( ( o.out + ".checksum" ).c_str(), digests.data(), uint64_t( o.frames ) ) );  // as PccAppEncoder
   for ( auto& fr : gof ) tmc2_frame_destroy( fr.f );
   for ( auto& c : ctx ) tmc2_ctx_destroy( c );
   return 0;

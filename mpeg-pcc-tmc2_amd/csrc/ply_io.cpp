@@ -608,6 +608,57 @@ int tmc2_ply_write( const char* path, const int16_t* xyz, const uint8_t* rgb, co
   return TMC2_OK;
 }
 
+// PCCChecksum::write / read (PccLibMetrics/source/PCCChecksum.cpp:112-139): the .checksum file next to the bitstream: the
+// number of frames, the checksum size (16), then 32 hex digits per frame.
+int tmc2_checksum_file_write( const char* path, const uint8_t* digests, uint64_t frames ) {
+  if ( !path || ( frames && !digests ) ) return TMC2_E_INVALID;
+  FILE* fp = fopen( path, "wb" );
+  if ( !fp ) {
+    tmc2::setError( "checksum file: cannot create %s", path );
+    return TMC2_E_INVALID;
+  }
+  fprintf( fp, "%llu\n%d\n", (unsigned long long)frames, frames ? 16 : 0 );
+  for ( uint64_t f = 0; f < frames; ++f ) {
+    for ( int k = 0; k < 16; ++k ) fprintf( fp, "%02x", digests[16 * f + uint64_t( k )] );
+    fputc( '\n', fp );
+  }
+  if ( fclose( fp ) != 0 ) return TMC2_E_INVALID;
+  return TMC2_OK;
+}
+int tmc2_checksum_file_read( const char* path, uint8_t* digests, uint64_t capacity, uint64_t* frames ) {
+  if ( !path || !frames ) return TMC2_E_INVALID;
+  FILE* fp = fopen( path, "rb" );
+  if ( !fp ) {
+    tmc2::setError( "checksum file: cannot open %s", path );
+    return TMC2_E_INVALID;
+  }
+  unsigned long long n = 0, size = 0;
+  if ( fscanf( fp, "%llu %llu", &n, &size ) != 2 || ( n && size < 16 ) ) {
+    fclose( fp );
+    tmc2::setError( "checksum file: corrupted header in %s", path );
+    return TMC2_E_INVALID;
+  }
+  *frames = n;
+  if ( n > capacity || ( n && !digests ) ) {
+    fclose( fp );
+    return digests ? TMC2_E_INVALID : TMC2_OK;
+  }
+  for ( unsigned long long f = 0; f < n; ++f )
+    for ( unsigned long long k = 0; k < size; ++k ) {
+      char     c[2];
+      unsigned v = 0;
+      if ( fscanf( fp, " %c%c", &c[0], &c[1] ) != 2 ) {
+        fclose( fp );
+        tmc2::setError( "checksum file: %s ends early", path );
+        return TMC2_E_INVALID;
+      }
+      for ( int d = 0; d < 2; ++d ) v = v * 16 + unsigned( ( c[d] + ( c[d] > '9' ? 9 : 0 ) ) & 0x0F );
+      if ( k < 16 ) digests[16 * f + k] = uint8_t( v );
+    }
+  fclose( fp );
+  return TMC2_OK;
+}
+
 int tmc2_point_set_checksum( const int16_t* xyz, const uint8_t* rgb, uint64_t n, int reorderPoints, uint8_t digest[16] ) {
   if ( ( n && !xyz ) || !digest ) return TMC2_E_INVALID;
   tmc2::Md5 md5;

@@ -556,6 +556,22 @@ def metrics_display(out, source_points, reconstruct_points, counts, resolution=1
     return buf.value.decode()
 
 
+def checksum_file_write(path, digests):
+    """PCCChecksum::write: digests = list of 16-byte MD5s, one per frame."""
+    L = load_library()
+    d = np.frombuffer(b"".join(digests), np.uint8).copy() if len(digests) else np.zeros(0, np.uint8)
+    _check(L.tmc2_checksum_file_write(str(path).encode(), _ptr(d) if len(d) else None, C.c_uint64(len(digests))))
+
+
+def checksum_file_read(path):
+    L = load_library()
+    n = C.c_uint64()
+    _check(L.tmc2_checksum_file_read(str(path).encode(), None, C.c_uint64(0), C.byref(n)))
+    d = np.zeros(16 * max(1, n.value), np.uint8)
+    _check(L.tmc2_checksum_file_read(str(path).encode(), _ptr(d), C.c_uint64(n.value), C.byref(n)))
+    return [d[16 * f:16 * f + 16].tobytes() for f in range(n.value)]
+
+
 def ply_info(path, read_normals=False):
     """(point count, has colours, has float normals) from the header of a PLY file."""
     L = load_library()

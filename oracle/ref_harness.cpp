@@ -44,6 +44,7 @@
 #include "PCCGroupOfFrames.h"
 #include "PCCImage.h"
 #include "PCCInternalColorConverter.h"
+#include "PCCChecksum.h"
 #include "tmc2hip_adaptor.h"  // integration/: the reference-side conversions, checked below against the reference's own containers
 #include "PCCVideo.h"
 #include "PCCBitstream.h"
@@ -1022,6 +1023,30 @@ int ref_ply_write( const char* path, const int16_t* xyz, const uint8_t* rgb, con
     if ( normals ) pc.setNormal( i, PCCNormal3D( normals[3 * i], normals[3 * i + 1], normals[3 * i + 2] ) );
   }
   return pc.write( path, asAscii != 0 ) ? 0 : -1;
+}
+// PCCChecksum::computeReconstructed + write for `frames` copies of clouds (xyz / rgb back to back, counts[f] points each);
+// the file lands at <streamPath without extension>.checksum
+int ref_checksum_file_write( const char* streamPath, const int16_t* xyz, const uint8_t* rgb, const int64_t* counts, int frames ) {
+  Quiet            quiet;
+  PCCGroupOfFrames gof;
+  gof.setFrameCount( size_t( frames ) );
+  size_t at = 0;
+  for ( int f = 0; f < frames; ++f ) {
+    makeCloud( gof[size_t( f )], xyz + 3 * at, rgb + 3 * at, size_t( counts[f] ) );
+    at += size_t( counts[f] );
+  }
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  dup2( fileno( devnull ), 1 );
+  PCCChecksum checksum;
+  checksum.computeReconstructed( gof );
+  checksum.write( streamPath );
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  return 0;
 }
 int ref_checksum( const int16_t* xyz, const uint8_t* rgb, size_t n, int reorderPoints, uint8_t* digest16 ) {
   PCCPointSet3 pc;

@@ -450,3 +450,23 @@ def test_host_metrics_display_text_matches_the_reference(oracle, with_normals):
     assert 0 < size < len(buf)
     assert text == buf.value.decode()
     assert "mseF,PSNR (p2point): " in text and ("mse1      (p2plane)" in text) == with_normals
+
+
+def test_host_checksum_file_is_byte_identical_to_the_reference(tmp_path):
+    """PCCChecksum::write: the .checksum file next to the bitstream (frame count, checksum size, one hex line per frame), and reading it back."""
+    import ctypes as C
+    import oracle_binding as ob
+    clouds = [synth_cloud("tiny", f) for f in range(3)]
+    digests = [T.point_set_checksum(x, c, False) for x, c in clouds]
+    mine = tmp_path / "mine.checksum"
+    T.checksum_file_write(str(mine), digests)
+    assert T.checksum_file_read(str(mine)) == digests
+    assert mine.read_text().split("\n")[:2] == ["3", "16"]
+    if os.path.exists(ob.REF_PATH):
+        L = ob.Reference().L
+        xyz = np.ascontiguousarray(np.concatenate([x for x, _ in clouds]), np.int16)
+        rgb = np.ascontiguousarray(np.concatenate([c for _, c in clouds]), np.uint8)
+        counts = np.array([len(x) for x, _ in clouds], np.int64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.ref_checksum_file_write(str(tmp_path / "theirs.bin").encode(), p(xyz), p(rgb), p(counts), 3)
+        assert mine.read_bytes() == (tmp_path / "theirs.checksum").read_bytes()
