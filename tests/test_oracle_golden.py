@@ -504,3 +504,34 @@ def test_oracle_patches_transfer_metrics_match_reference_on_degenerate_clouds(or
     qa, ca = oracle.metrics(xyz, rgb, tgt, rc, nrm)
     qb, cb = reference.metrics(xyz, rgb, tgt, rc, nrm)
     assert np.array_equal(qa.view(np.uint64), qb.view(np.uint64)) and np.array_equal(ca, cb)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 5])      # (the quick ones; the others take up to a minute each)
+def test_oracle_whole_path_matches_reference_on_degenerate_gofs(oracle, reference, seed):
+    """S0-S22, the colour conversion and the tail, end to end on GOFs of degenerate clouds, random packing condition (all-intra /
+    low delay / random access) and occupancy precision (4 / 2 / 1): a few seeds of tools/fuzz/fuzz_gof.py."""
+    rng = np.random.default_rng(13000 + seed)
+    frames = []
+    for _ in range(int(rng.integers(1, 4))):
+        xyz = degenerate_cloud(rng)
+        if len(xyz) < 64:
+            break
+        frames.append((xyz, rng.integers(0, 256, (len(xyz), 3), dtype=np.uint8)))
+    if not frames:
+        pytest.skip("too few distinct points")
+    prec, it = int(rng.choice([4, 2, 1])), int(rng.integers(1, 5))
+    mode = int(rng.choice([0, 1, 2])) if len(frames) > 1 else 0
+    oa = oracle.phase_a(frames, it, 11, prec, constrained_pack=mode)
+    ra = reference.phase_a(frames, it, 11, prec, constrained_pack=mode)
+    for x, y in zip(ra, oa):
+        assert (x["width"], x["height"]) == (y["width"], y["height"])
+        for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+            assert np.array_equal(x[k], y[k]), k
+    rb, ob_ = reference.phase_b(frames, ra, prec), oracle.phase_b(frames, oa, prec)
+    for x, y in zip(rb, ob_):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    dec = [np.stack([oracle.convert_yuv420_to_yuv444(*oracle.convert_rgb444_to_yuv420(b["attribute"][m])) for m in range(2)]) for b in rb]
+    for x, y in zip(reference.phase_c(rb, dec), oracle.phase_c(oa, ob_, dec, prec)):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
