@@ -409,6 +409,7 @@ def test_native_front_end_builds_and_fails_loudly_without_a_gpu(tmp_path):
     subprocess.run(["make", "-C", os.path.join(root, "integration")], check=True, capture_output=True)
     exe = os.path.join(root, "integration", "tmc2_encode_gof")
     assert subprocess.run([exe, "--help"], capture_output=True).returncode == 1
+    metrics_exe = os.path.join(root, "integration", "tmc2_metrics")
     xyz, rgb = synth_cloud("tiny", 0)
     T.ply_write(str(tmp_path / "fr_0000.ply"), xyz, rgb)
     r = subprocess.run([exe, "--in", str(tmp_path / "fr_%04d.ply"), "--frames", "1", "--out", str(tmp_path / "gof")],
@@ -418,10 +419,14 @@ def test_native_front_end_builds_and_fails_loudly_without_a_gpu(tmp_path):
         gpu = torch.cuda.is_available()
     except ImportError:
         gpu = False
+    m = subprocess.run([metrics_exe, "--uncompressedDataPath", str(tmp_path / "fr_%04d.ply"), "--reconstructedDataPath",
+                        str(tmp_path / "fr_%04d.ply")], capture_output=True, text=True)
     if gpu:
         assert r.returncode == 0 and (tmp_path / "gof_checksums.txt").exists()
+        assert m.returncode == 0 and "mseF,PSNR (p2point): inf" in m.stdout          # a cloud against itself
     else:
         assert r.returncode == 2 and "no HIP device" in r.stderr and not list(tmp_path.glob("gof_*"))
+        assert m.returncode == 2 and "no HIP device" in m.stderr and not m.stdout
 
 
 @pytest.mark.parametrize("with_normals", [True, False])
