@@ -1,0 +1,95 @@
+"""GPU tier, opt-in (TMC2_GPU_FUZZ=1): the HIP path against the oracle on the degenerate clouds and random patch sets the CPU
+tier fuzzes the oracle with (planes, lines, lattices, dust, duplicate-heavy blobs).  Written at the end of round 1 after the
+GPU budget was spent -- NOT yet run on a device, hence not part of the default `-m gpu` run; the first thing to run next."""
+import os
+
+import numpy as np
+import pytest
+
+import tmc2_amd as T
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("TMC2_GPU_FUZZ") != "1", reason="opt-in: TMC2_GPU_FUZZ=1 (not yet validated on a GPU)")]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gpu_segmenter_on_degenerate_clouds(gpu_ctx, oracle, seed):
+    import oracle_binding as ob
+    from test_oracle_golden import degenerate_cloud
+    rng = np.random.default_rng(9000 + seed)
+    xyz = degenerate_cloud(rng)
+    if len(xyz) < 64:
+        pytest.skip("too few distinct points")
+    rgb = rng.integers(0, 256, (len(xyz), 3), dtype=np.uint8)
+    fr = gpu_ctx.frame(xyz, rgb)
+    assert np.array_equal(fr.kdtree_order()[0], oracle.kdtree_perm(xyz)[0])
+    fr.normals_compute(16, 1)
+    assert np.array_equal(fr.get_adjacency(16), oracle.knn_self(xyz, 16))
+    assert np.array_equal(bits(fr.get_normals()), bits(oracle.normals(xyz, 16, True)))
+    w = fr.weight_normal(11, 0.6)
+    assert np.array_equal(w, oracle.weight_normal(xyz, 11, 0.6))
+    it = int(rng.integers(1, 6))
+    fr.segmenter_compute(T.ctc_params(it, 11, w))
+    seg = oracle.segment(xyz, rgb, ob.seg_params(it, 11, w))
+    patches, d0, d1, occ = fr.get_patches()
+    for n in seg["patches"].dtype.names:
+        assert n in ("depthOffset", "occOffset") or np.array_equal(patches[n], seg["patches"][n]), n
+    assert np.array_equal(d0, seg["depth0"]) and np.array_equal(d1, seg["depth1"]) and np.array_equal(occ, seg["occupancy"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_whole_path_on_degenerate_gofs(oracle, seed):
+    from test_oracle_golden import degenerate_cloud
+    rng = np.random.default_rng(13000 + seed)
+    frames = []
+    for _ in range(int(rng.integers(1, 4))):
+        xyz = degenerate_cloud(rng)
+        if len(xyz) < 64:
+            break
+        frames.append((xyz, rng.integers(0, 256, (len(xyz), 3), dtype=np.uint8)))
+    if not frames:
+        pytest.skip("too few distinct points")
+    prec, it = int(rng.choice([4, 2, 1])), int(rng.integers(1, 5))
+    mode = int(rng.choice([0, 1, 2])) if len(frames) > 1 else 0
+    oa = oracle.phase_a(frames, it, 11, prec, constrained_pack=mode)
+    ob_ = oracle.phase_b(frames, oa, prec)
+    enc = T.GofEncoder(0, workers=2, iterations=it, occ_precision=prec)
+    try:
+        frs = enc.upload(frames)
+        W, H = enc.phase_a(frs, constrained_pack={0: False, 1: True, 2: 2}[mode])
+        enc.phase_b(frs)
+        i420 = [np.zeros((2, W * H * 3 // 2), np.uint8) for _ in frs]
+        enc.phase_c(frs, i420_out=i420)
+        dec = [fr.get_decoded_attribute() for fr in frs]
+        oc = oracle.phase_c(oa, ob_, dec, prec)
+        for fr, a, b, c, d in zip(frs, oa, ob_, oc, dec):
+            assert (W, H) == (a["width"], a["height"])
+            img = fr.get_geometry_images()
+            for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+                assert np.array_equal(img[k], a[k]), k
+            assert np.array_equal(fr.get_attribute_images(), b["attribute"])
+            exp_dec = np.stack([oracle.convert_yuv420_to_yuv444(*oracle.convert_rgb444_to_yuv420(b["attribute"][m])) for m in range(2)])
+            assert np.array_equal(d, exp_dec)
+            post = fr.get_post_reconstruction()
+            for k in ("xyz", "colors16", "rgb", "boundary"):
+                assert np.array_equal(post[k], c[k]), k
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_gpu_tail_on_random_clouds(gpu_ctx, oracle, seed):
+    """The tail's kernels cannot be fed an arbitrary cloud through the C-ABI (they work on a frame's reconstruction); the
+    colour conversion can: white noise and block images of odd sizes."""
+    rng = np.random.default_rng(17000 + seed)
+    H, W = 2 * int(rng.integers(8, 200)), 2 * int(rng.integers(8, 200))
+    rgb = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    ey, eu, ev = oracle.convert_rgb444_to_yuv420(rgb)
+    gy, gu, gv = gpu_ctx.color_convert_rgb444_to_yuv420(rgb)
+    assert np.array_equal(gy, ey) and np.array_equal(gu, eu) and np.array_equal(gv, ev)
+    y2, u2, v2 = (rng.integers(0, 256, a.shape, dtype=np.uint8) for a in (ey, eu, ev))
+    assert np.array_equal(gpu_ctx.color_convert_yuv420_to_yuv444(y2, u2, v2), oracle.convert_yuv420_to_yuv444(y2, u2, v2))
