@@ -508,6 +508,20 @@ int Allocator::run() {
 // frames: per frame the patches IN LIST ORDER with their block-occupancy pool (rec.occOffset) and matches; tile sizes.
 // On return the lists are reordered, box sizes / placements / indices / matches rewritten, pools rebuilt.
 int globalPatchAllocationCore( std::vector<GpaFrameIO>& frames, int minW, int minH, int occRes ) {
+  // placeSegments runs the allocation only if the FIRST frame of the tile has patches (PCCEncoder.cpp:4812): otherwise the
+  // per-frame packing stands as it is (the pools still come back in list order, as on the allocating path)
+  if ( frames.empty() || frames[0].list.empty() ) {
+    for ( auto& io : frames ) {
+      std::vector<uint8_t> pool;
+      for ( auto& rec : io.list ) {
+        const uint8_t* o = io.occ.data() + rec.occOffset;
+        rec.occOffset    = int64_t( pool.size() );
+        pool.insert( pool.end(), o, o + size_t( rec.sizeU0 ) * rec.sizeV0 );
+      }
+      io.occ.swap( pool );
+    }
+    return TMC2_OK;
+  }
   std::vector<Tile> tiles( frames.size() );
   for ( size_t f = 0; f < frames.size(); ++f ) {
     GpaFrameIO& io = frames[f];

@@ -548,6 +548,8 @@ void orc_gpa_set_frame( void* h, int f, const orc_patch* list, int P, const uint
 // returns 1 where the reference's behaviour is undefined (see updatePatchInformation), 0 otherwise
 int orc_gpa_run( void* h ) {
   Gpa& G = *static_cast<Gpa*>( h );
+  // placeSegments runs the allocation only if the FIRST frame of the tile has patches (PCCEncoder.cpp:4812)
+  if ( G.frames.empty() || G.frames[0].patches.empty() ) return 0;
   try {
     run( G );
   } catch ( const Runaway& ) { return 2; }  // the reference never returns (a patch that fits at no canvas height)

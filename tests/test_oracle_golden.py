@@ -347,7 +347,8 @@ def test_oracle_transfer_colors_long_candidate_lists(oracle, reference):
     assert np.array_equal(oracle.transfer_colors(xyz, rgb, tgt), reference.transfer_colors(xyz, rgb, tgt))
 
 
-@pytest.mark.parametrize("seed", range(40))
+# (1574, 1727, 2141: GOFs whose FIRST frame has no patches -- the reference then leaves the global patch allocation out)
+@pytest.mark.parametrize("seed", list(range(40)) + [1574, 1727, 2141])
 def test_oracle_interframe_packers_match_reference_on_random_patch_sets(oracle, reference, seed):
     """PCCEncoder::placeSegments run by the reference on synthetic patch RECORDS (random boxes that drift, vanish and appear;
     canvases from roomy to far too small) against the oracle's packFlexible / spatial-consistency chain / global patch
