@@ -10,7 +10,7 @@
 // independent of k -- so one exact k=16 search per query serves all of them; a group that fills all 16 slots is
 // reported as unsupported instead of being approximated.
 // Device: the four query batches (exact nanoflann-order k-NN kernel), the per-recon-point ordered normal
-// accumulation, the per-point distortion terms.  Host: lexicographic de-duplication (a sort), the three tree builds,
+// accumulation, the per-point distortion terms.  Host: lexicographic de-duplication (a counting sort, lex_order.h), the three tree builds,
 // and the final ORDERED fp64 sums over the points (the reference accumulates sequentially; D1 is a sum of
 // integers and order-free, D2 and colour are not).
 #include <algorithm>
@@ -19,6 +19,7 @@
 #include <numeric>
 
 #include "internal.h"
+#include "lex_order.h"
 
 namespace tmc2 {
 namespace {
@@ -32,21 +33,21 @@ struct HostCloud {
   size_t               size() const { return xyz.size() / 3; }
 };
 
-HostCloud dedupLexicographic( const int16_t* xyz, const uint8_t* rgb, size_t n ) {
-  // key = x,y,z packed (coordinates < 2^15, non-negative); ties keep input order
-  std::vector<uint64_t> key( n );
-  for ( size_t i = 0; i < n; ++i )
-    key[i] = ( uint64_t( uint16_t( xyz[3 * i] ) ) << 48 ) | ( uint64_t( uint16_t( xyz[3 * i + 1] ) ) << 32 ) |
-             ( uint64_t( uint16_t( xyz[3 * i + 2] ) ) << 16 );
-  std::vector<uint32_t> order( n );
-  std::iota( order.begin(), order.end(), 0u );
-  std::stable_sort( order.begin(), order.end(), [&]( uint32_t a, uint32_t b ) { return key[a] < key[b]; } );
+HostCloud dedupLexicographic( const int16_t* xyz, const uint8_t* rgb, size_t n, std::vector<uint32_t>* orderOut = nullptr ) {
+  // (x, y, z) order, ties keep input order
+  std::vector<uint32_t> local;
+  std::vector<uint32_t>& order = orderOut ? *orderOut : local;
+  lexOrderStable( xyz, n, order );
+  auto same = [&]( uint32_t a, uint32_t b ) {
+    return xyz[3 * size_t( a )] == xyz[3 * size_t( b )] && xyz[3 * size_t( a ) + 1] == xyz[3 * size_t( b ) + 1] &&
+           xyz[3 * size_t( a ) + 2] == xyz[3 * size_t( b ) + 2];
+  };
   HostCloud c;
   c.xyz.reserve( 3 * n );
   c.rgb.reserve( 3 * n );
   for ( size_t i = 0; i < n; ) {
     size_t j = i + 1;
-    while ( j < n && key[order[j]] == key[order[i]] ) ++j;
+    while ( j < n && same( order[j], order[i] ) ) ++j;
     for ( int d = 0; d < 3; ++d ) c.xyz.push_back( xyz[3 * size_t( order[i] ) + d] );
     size_t s[3] = {0, 0, 0};
     for ( size_t k = i; k < j; ++k )
@@ -277,7 +278,8 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
   ApiScope    scope( ctx );
   hipStream_t s  = ctx->stream;
   const auto  t0 = std::chrono::steady_clock::now();
-  HostCloud   S = dedupLexicographic( srcXyz, srcRgb, n ), R = dedupLexicographic( recXyz, recRgb, m );
+  std::vector<uint32_t> srcOrder;
+  HostCloud   S = dedupLexicographic( srcXyz, srcRgb, n, &srcOrder ), R = dedupLexicographic( recXyz, recRgb, m );
   if ( counts ) counts[0] = int64_t( S.size() ), counts[1] = int64_t( R.size() );
   const bool withNormals = srcNormals != nullptr;
   if ( S.size() < size_t( K ) || R.size() < size_t( K ) ) {
@@ -289,17 +291,10 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
       setError( "metrics_compute: the source has duplicate positions; normals cannot be attached (the reference exits)" );
       return TMC2_E_INVALID;
     }
-    // copyNormals: the de-duplicated source is the lexicographic sort of the input
-    std::vector<uint64_t> key( n );
-    for ( size_t i = 0; i < n; ++i )
-      key[i] = ( uint64_t( uint16_t( srcXyz[3 * i] ) ) << 48 ) | ( uint64_t( uint16_t( srcXyz[3 * i + 1] ) ) << 32 ) |
-               ( uint64_t( uint16_t( srcXyz[3 * i + 2] ) ) << 16 );
-    std::vector<uint32_t> order( n );
-    std::iota( order.begin(), order.end(), 0u );
-    std::sort( order.begin(), order.end(), [&]( uint32_t a, uint32_t b ) { return key[a] < key[b]; } );
+    // copyNormals: the de-duplicated source is the lexicographic sort of the input (srcOrder)
     S.nrm.resize( 3 * n );
     for ( size_t i = 0; i < n; ++i )
-      for ( int d = 0; d < 3; ++d ) S.nrm[3 * i + d] = srcNormals[3 * size_t( order[i] ) + d];
+      for ( int d = 0; d < 3; ++d ) S.nrm[3 * i + d] = srcNormals[3 * size_t( srcOrder[i] ) + d];
   }
   DevCloud dS, dR, dN;  // de-duplicated source, de-duplicated reconstruction, normal cloud (original source order)
   TMC2_TRY( uploadCloud( ctx, S.xyz.data(), S.rgb.data(), withNormals ? S.nrm.data() : nullptr, S.size(), true, dS ) );

@@ -26,6 +26,7 @@
 #include <thread>
 
 #include "internal.h"
+#include "lex_order.h"
 
 namespace tmc2 {
 namespace {
@@ -670,13 +671,12 @@ int tmc2_point_set_checksum( const int16_t* xyz, const uint8_t* rgb, uint64_t n,
   }
   // PCCPointSet3::reorder( dropDuplicates ): positions in (x, y, z) order; with colours one point per position, its colour
   // the integer mean of the colours that share it -- without colours the reference keeps the duplicates
-  std::vector<uint32_t> order( n );
-  for ( uint64_t i = 0; i < n; ++i ) order[i] = uint32_t( i );
+  std::vector<uint32_t> order;
+  tmc2::lexOrderStable( xyz, size_t( n ), order );
   auto key = [&]( uint32_t i ) {
-    return ( uint64_t( uint16_t( xyz[3 * size_t( i )] ^ 0x8000 ) ) << 32 ) | ( uint64_t( uint16_t( xyz[3 * size_t( i ) + 1] ^ 0x8000 ) ) << 16 ) |
-           uint64_t( uint16_t( xyz[3 * size_t( i ) + 2] ^ 0x8000 ) );
+    return ( uint64_t( uint16_t( xyz[3 * size_t( i )] ) ) << 32 ) | ( uint64_t( uint16_t( xyz[3 * size_t( i ) + 1] ) ) << 16 ) |
+           uint64_t( uint16_t( xyz[3 * size_t( i ) + 2] ) );
   };
-  std::sort( order.begin(), order.end(), [&]( uint32_t a, uint32_t b ) { return key( a ) < key( b ); } );
   std::vector<int16_t> pos;
   std::vector<uint8_t> col;
   pos.reserve( size_t( n ) * 3 );

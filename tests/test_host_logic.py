@@ -241,6 +241,14 @@ def test_host_checksum_matches_oracle_and_reference(reorder, colors):
         assert T.point_set_checksum(xyz[:n], c, reorder) == exp, n
         if os.path.exists(ob.REF_PATH) and n:
             assert ob.Reference().checksum(xyz[:n], c, reorder) == exp, n
+    # the position order is a counting sort per coordinate: negative coordinates, a constant axis, one occupied position
+    for cloud in (rng.integers(-300, 300, (5000, 3)), rng.integers(0, 40, (5000, 3)) * [1, 0, 1] + [0, -7, 0], np.full((64, 3), 11)):
+        cloud = cloud.astype(np.int16)
+        c = rng.integers(0, 256, (len(cloud), 3), dtype=np.uint8) if colors else None
+        exp = port_io.checksum(cloud, c, reorder)
+        assert T.point_set_checksum(cloud, c, reorder) == exp
+        if os.path.exists(ob.REF_PATH):
+            assert ob.Reference().checksum(cloud, c, reorder) == exp
 
 
 def test_host_ply_read_and_checksum_match_golden_fixture(tmp_path):
