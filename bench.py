@@ -102,6 +102,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import numpy as np
     import tmc2_amd as T
+    if a.frames % world:
+        raise SystemExit("bench.py: --frames %d is not a multiple of the %d ranks (the canvas gather runs once per frame slot)" % (a.frames, world))
     my_indices = list(range(rank, a.frames, world))
     clouds = make_frames(a.workload, my_indices, a.gen_procs)         # before any GPU context exists (fork-safe)
     import torch
@@ -121,6 +123,7 @@ def main():
     n_points = sum(len(c[0]) for c in clouds)
 
     host_cache = {}
+    gather_cache = {}
 
     def host_out(W, H):
         """Host-side destination of the finished canvases (what the video encoder reads), allocated once: page-locked
@@ -146,13 +149,18 @@ def main():
             bufs = host_out(W, H)
             enc.per_frame(frames, lambda fr, i: (fr.get_geometry_images(bufs[i][0]), fr.get_attribute_images(bufs[i][1])))
         else:
-            for fr in frames:
-                g = sharder.gather(enc.device_tensor(fr, "geometry"))
-                o = sharder.gather(enc.device_tensor(fr, "occ_video"))
-                t = sharder.gather(enc.device_tensor(fr, "attribute"))
-                if rank == 0:
-                    for x in g + o + t:
-                        x.cpu()
+            # one gather per canvas kind and frame slot (every rank holds the same number of frames); rank 0 moves what
+            # arrives into page-locked host memory with asynchronous copies, completed by the synchronize of sync()
+            for i, fr in enumerate(frames):
+                for name in ("geometry", "occ_video", "attribute"):
+                    src = enc.device_tensor(fr, name)
+                    got = sharder.gather(src)
+                    if rank == 0:
+                        key = (i, name, tuple(src.shape))
+                        if key not in gather_cache:
+                            gather_cache[key] = torch.empty((world,) + tuple(src.shape), dtype=torch.uint8, pin_memory=True)
+                        for r, x in enumerate(got):
+                            gather_cache[key][r].copy_(x, non_blocking=True)
         return W, H
 
     def sync():
