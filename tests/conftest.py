@@ -4,7 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "mpeg-pcc-tmc2_amd"), os.path.join(ROOT, "tests")):
+# (TMC2_PACKAGE_DIR: a copy of the package next to another build of the library -- tools/asan_host.sh)
+for p in (os.environ.get("TMC2_PACKAGE_DIR") or os.path.join(ROOT, "mpeg-pcc-tmc2_amd"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
