@@ -542,6 +542,11 @@ def host_global_patch_allocation(lists, pools, matches, tile_w, tile_h, min_w=12
     return res
 
 
+def segmenter_params_check(params):
+    """Raises Tmc2Error for a parameter set outside what the path implements (the CTC lossy conditions are inside)."""
+    _check(load_library().tmc2_segmenter_params_check(C.byref(params)))
+
+
 def metrics_display(out, source_points, reconstruct_points, counts, resolution=1023, with_c2p=True, precision=9):
     """The text PCCMetrics::display() prints for one frame (what the CTC log parsers read)."""
     L = load_library()

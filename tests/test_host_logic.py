@@ -484,3 +484,17 @@ def test_host_checksum_file_is_byte_identical_to_the_reference(tmp_path):
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         L.ref_checksum_file_write(str(tmp_path / "theirs.bin").encode(), p(xyz), p(rgb), p(counts), 3)
         assert mine.read_bytes() == (tmp_path / "theirs.checksum").read_bytes()
+
+
+def test_segmenter_params_check_accepts_ctc_and_names_what_it_refuses():
+    """tmc2_segmenter_params_check: the CTC lossy parameter sets pass; options the path does not implement are refused
+    with a message instead of being computed differently from the reference."""
+    for it, bits in ((50, 10), (20, 11), (10, 11)):
+        T.segmenter_params_check(T.ctc_params(it, bits))
+    for field, value in (("nnNormalEstimation", 12), ("maxNNCountPatchSegmentation", 8), ("normalOrientation", 2),
+                         ("gridBasedRefineSegmentation", 0), ("occupancyResolution", 8), ("mapCountMinus1", 0)):
+        p = T.ctc_params()
+        setattr(p, field, value)
+        with pytest.raises(T.Tmc2Error) as e:
+            T.segmenter_params_check(p)
+        assert "params" in str(e.value)
