@@ -93,3 +93,23 @@ def test_gpu_tail_on_random_clouds(gpu_ctx, oracle, seed):
     assert np.array_equal(gy, ey) and np.array_equal(gu, eu) and np.array_equal(gv, ev)
     y2, u2, v2 = (rng.integers(0, 256, a.shape, dtype=np.uint8) for a in (ey, eu, ev))
     assert np.array_equal(gpu_ctx.color_convert_yuv420_to_yuv444(y2, u2, v2), oracle.convert_yuv420_to_yuv444(y2, u2, v2))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_gpu_color_conversion_on_random_sizes(gpu_ctx, oracle, seed):
+    """C1 / C2 on images from 2x2 upwards (every border clamp of the 15/16-tap filters inside the picture), contents as in
+    tools/fuzz/fuzz_color.py (which holds oracle == reference on them)."""
+    rng = np.random.default_rng(7000 + seed)
+    H, W = 2 * int(rng.integers(1, 80)), 2 * int(rng.integers(1, 80))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        rgb = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    elif kind == 1:
+        rgb = rng.choice(np.array([0, 255], np.uint8), (3, H, W))
+    else:
+        rgb = np.clip(rng.normal(128, 3, (3, H, W)), 0, 255).astype(np.uint8)
+    exp = oracle.convert_rgb444_to_yuv420(rgb)
+    got = gpu_ctx.color_convert_rgb444_to_yuv420(rgb)
+    assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (H, W, kind)
+    y, u, v = (rng.integers(0, 256, p.shape, dtype=np.uint8) for p in exp)
+    assert np.array_equal(gpu_ctx.color_convert_yuv420_to_yuv444(y, u, v), oracle.convert_yuv420_to_yuv444(y, u, v)), (H, W)
