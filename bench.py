@@ -15,7 +15,8 @@ Printed JSON (one line, rank 0): metric/value/unit as BASELINE.json, plus
   roofline     -- dominant GPU kernel of the timed region: algorithmic bytes per launch / mean launch duration
                   (HIP events on the launching stream, collected inside the timed region) against 8 TB/s HBM
   cpu_baseline -- the reference (oracle/_ref, kind "reference") or our restatement (kind "port") on the host,
-                  one frame of the same workload, one core
+                  one frame of the same workload, one core; "all_cores": the reference's per-frame parallelism, as one
+                  process per frame on up to 32 frames at once
 """
 import argparse
 import json
@@ -43,6 +44,7 @@ def parse():
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
+    ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -90,13 +92,75 @@ def cpu_baseline(workload, iterations):
     a = eng.phase_a(frames, iterations)
     eng.phase_b(frames, a)
     dt = time.time() - t
-    return {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "1 frame of %s (%d points), stages S0-S22 (patch generation + occupancy/geometry/attribute images), "
-                      "1 thread, %.1f s" % (workload, len(frames[0][0]), dt)}
+    res = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": 1, "kind": kind,
+           "sample": "1 frame of %s (%d points), stages S0-S22 (patch generation + occupancy/geometry/attribute images), "
+                     "1 thread, %.1f s" % (workload, len(frames[0][0]), dt)}
+    try:                                                       # a side figure: never lose the line over it
+        res["all_cores"] = cpu_baseline_all_cores(workload, iterations, dt)
+    except Exception as e:
+        res["all_cores"] = {"error": repr(e)}
+    return res
+
+
+def cpu_baseline_all_cores(workload, iterations, one_frame_seconds):
+    """The reference's own parallelism is one TBB task per frame of the GOF (PCCEncoder.cpp:4729-4750); oracle/_ref is
+    built without TBB, so the same thing is measured with one PROCESS per frame: P different frames at once, P = the
+    frames of a GOF bounded by the cores and the memory of the host; frames/s = P / wall time from a common start."""
+    import subprocess
+    import tempfile
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail_gb = 8.0
+    try:
+        with open("/proc/meminfo") as f:
+            avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
+    except Exception:
+        pass
+    procs = int(max(1, min(32, cores, avail_gb * 0.25 / 0.6)))      # a child peaks at ~0.45 GB on the longdress-like frame
+    if procs < 2:
+        return {"value": round(1.0 / one_frame_seconds, 5), "cores": 1, "sample": "single core host"}
+    with tempfile.TemporaryDirectory() as d:
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "%d,%s" % (i, d), "--workload", workload,
+                                  "--iterations", str(iterations)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(procs)]
+        limit = time.time() + 120 + 20 * one_frame_seconds
+        try:
+            while sum(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(procs)) < procs:
+                if time.time() > limit or any(k.poll() not in (None, 0) for k in kids):
+                    raise RuntimeError("a CPU baseline child failed before the start")
+                time.sleep(0.05)
+            t0 = time.time()
+            open(os.path.join(d, "go"), "w").close()
+            for k in kids:
+                k.wait(timeout=max(1.0, limit - time.time()))
+            wall = time.time() - t0
+            if any(k.returncode != 0 for k in kids):
+                raise RuntimeError("a CPU baseline child failed")
+        finally:
+            for k in kids:
+                if k.poll() is None:
+                    k.kill()
+    return {"value": round(procs / wall, 5), "unit": "frames/s", "cores": procs,
+            "sample": "%d frames of the GOF at once, one process per frame (the reference's per-frame TBB task), same stages, "
+                      "%.1f s wall on %d usable cores" % (procs, wall, cores)}
+
+
+def cpu_child(spec, workload, iterations):
+    index, d = spec.split(",", 1)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from tmc2_amd.synth import synth_cloud
+    frames = [synth_cloud(workload, int(index))]
+    eng = ob.Reference() if os.path.exists(ob.REF_PATH) else ob.Oracle()
+    open(os.path.join(d, "ready" + index), "w").close()
+    while not os.path.exists(os.path.join(d, "go")):
+        time.sleep(0.01)
+    a = eng.phase_a(frames, iterations)
+    eng.phase_b(frames, a)
 
 
 def main():
     a = parse()
+    if a.cpu_child:
+        return cpu_child(a.cpu_child, a.workload, a.iterations)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -263,7 +327,7 @@ def main():
                            "stage_ms_alone": {k: round(v, 3) for k, v in sorted(tail_ms.items()) if v > 0}}
         except Exception as e:                                 # never lose the metric line over the side measurement
             out["tail"] = {"error": repr(e)}
-    if a.cpu_baseline:
+    if a.cpu_baseline and world == 1:                          # rank 0 at N = 1 only (the contract of the bench line)
         out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations)
     print(json.dumps(out))
     if world > 1:
