@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
+    ap.add_argument("--packing", default="all-intra", choices=["all-intra", "low-delay", "random-access"],
+                    help="S10 condition: every frame on its own (the metric's configuration), the spatial-consistency chain, "
+                         "or the chain + global patch allocation (with several ranks the chain runs on rank 0 over the patch records)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -205,7 +208,8 @@ def main():
     def step():
         for fr in frames:
             fr.reset()
-        W, H = enc.phase_a(frames, sharder)
+        W, H = enc.phase_a(frames, sharder, constrained_pack={"all-intra": False, "low-delay": True, "random-access": 2}[a.packing],
+                           frame_count=a.frames)
         # identity video codec between the phases (HM/VTM on the host is outside the metric): phase B runs on the
         # resident canvases.  Finished canvases -> rank 0 -> host memory, where the video encoder reads them.
         enc.phase_b(frames)
@@ -280,9 +284,9 @@ def main():
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int32/f64", "data": "synthetic",
-        "config": {"workload": "%s-like synthetic, %d frames, %d points/frame avg, ctc-common + all-intra + r3 "
+        "config": {"workload": "%s-like synthetic, %d frames, %d points/frame avg, ctc-common + %s + r3 "
                                "(refine iterations %d, occupancyPrecision 4), canvas %dx%d" %
-                               (a.workload, a.frames, n_points // max(1, len(frames)), a.iterations, W, H),
+                               (a.workload, a.frames, n_points // max(1, len(frames)), a.packing, a.iterations, W, H),
                    "stages": "S0-S22: k-d tree, kNN, normals, orientation, segmentation, refinement, patches, packing, "
                              "occupancy + geometry images, dilation, reconstruction, colour transfer, attribute images, "
                              "push-pull padding (identity video codec between the phases); the D1/D2 metric (S23) is "

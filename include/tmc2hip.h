@@ -188,6 +188,16 @@ int tmc2_frame_get_patch_matches( tmc2_frame* f, int32_t* matches );
  * widths / heights (int32[count], may be NULL): the tile size of every frame for tmc2_encoder_canvas_size.          */
 int tmc2_encoder_global_patch_allocation( tmc2_frame** frames, int count, int minimumImageWidth, int minimumImageHeight,
                                           int32_t* widths, int32_t* heights );
+/* A frame sharded onto another rank takes part in the inter-frame packers through its patch RECORDS: they travel to the
+ * rank that runs the chain (tmc2_host_pack_flexible / _spatial_consistency / _global_patch_allocation on plain records,
+ * "gather to rank 0 of the per-frame patch table before packing"), the packed list comes back and is installed
+ * here -- what PCCEncoder::placeSegments leaves in the frame's PCCFrameContext (PCCEncoder.cpp:4790-4840).
+ * list[count]: the frame's patches in LIST order with u0 / v0 / patchOrientation (and, after the global patch allocation,
+ * rewritten index / sizeU0 / sizeV0) and occOffset into occupancy[occupancyBytes] (pool in list order); depthOffset must
+ * still point into this frame's own depth pools.  matches: int32[count] or NULL (none).  packedWidth / packedHeight: the
+ * tile size the packers left.  Afterwards the frame is in the state tmc2_encoder_global_patch_allocation leaves.      */
+int tmc2_frame_set_packing( tmc2_frame* f, const tmc2_patch* list, int count, const int32_t* matches, const uint8_t* occupancy,
+                            int64_t occupancyBytes, int packedWidth, int packedHeight );
 /* packing order of the frame: order[listPosition] = patch index (the reference reorders the list itself) */
 int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order );
 /* replaces: resizeTileGeometryVideo + resizeGeometryVideo (PCCEncoder.cpp:5593-5632, 5546-5591): common GOF canvas */

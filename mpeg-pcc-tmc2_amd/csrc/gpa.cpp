@@ -559,6 +559,25 @@ int globalPatchAllocationCore( std::vector<GpaFrameIO>& frames, int minW, int mi
   return TMC2_OK;
 }
 
+// a packed patch list (list order, pool in list order) becomes the frame's state: records on the host, pool re-uploaded
+int installPacking( tmc2_frame* f, const GpaFrameIO& g ) {
+  ApiScope scope( f->ctx );
+  f->patches   = g.list;  // list order from here on: the reference rewrites the patch indices to list positions
+  f->packMatch = g.match;
+  f->packOrder.resize( g.list.size() );
+  for ( size_t k = 0; k < g.list.size(); ++k ) f->packOrder[k] = int32_t( k );
+  f->occCount = int64_t( g.occ.size() );
+  TMC2_TRY( f->growPools() );
+  if ( f->occCount ) {
+    TMC2_HIP( hipMemcpyAsync( f->d_occupancy.p, g.occ.data(), g.occ.size(), hipMemcpyHostToDevice, f->ctx->stream ) );
+    TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
+  }
+  f->packedHeight       = g.height;
+  f->packedWidth        = g.width;
+  f->haveGeometryImages = f->haveAttributeImages = f->haveReconstruction = false;
+  return TMC2_OK;
+}
+
 // the frames of a GOF, each packed by the per-frame chain: pools come back from the devices (a few KB each), the
 // allocation runs, the rewritten lists / pools go back
 int globalPatchAllocationFrames( tmc2_frame** fr, int count, int minW, int minH, int occRes, int32_t* widths, int32_t* heights ) {
@@ -586,22 +605,8 @@ int globalPatchAllocationFrames( tmc2_frame** fr, int count, int minW, int minH,
   for ( auto& g : io ) g.width = tileW, g.height = tileH;
   TMC2_TRY( globalPatchAllocationCore( io, minW, minH, occRes ) );
   for ( int i = 0; i < count; ++i ) {
-    tmc2_frame* f = fr[i];
-    ApiScope    scope( f->ctx );
     GpaFrameIO& g = io[size_t( i )];
-    f->patches    = g.list;  // list order from here on: the reference rewrites the patch indices to list positions
-    f->packMatch  = g.match;
-    f->packOrder.resize( g.list.size() );
-    for ( size_t k = 0; k < g.list.size(); ++k ) f->packOrder[k] = int32_t( k );
-    f->occCount = int64_t( g.occ.size() );
-    TMC2_TRY( f->growPools() );
-    if ( f->occCount ) {
-      TMC2_HIP( hipMemcpyAsync( f->d_occupancy.p, g.occ.data(), g.occ.size(), hipMemcpyHostToDevice, f->ctx->stream ) );
-      TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );
-    }
-    f->packedHeight       = g.height;
-    f->packedWidth        = g.width;
-    f->haveGeometryImages = f->haveAttributeImages = f->haveReconstruction = false;
+    TMC2_TRY( installPacking( fr[i], g ) );
     if ( widths ) widths[i] = g.width;
     if ( heights ) heights[i] = g.height;
   }
@@ -618,6 +623,41 @@ int tmc2_encoder_global_patch_allocation( tmc2_frame** frames, int count, int mi
   for ( int i = 0; i < count; ++i )
     if ( !frames[i] ) return TMC2_E_INVALID;
   return tmc2::globalPatchAllocationFrames( frames, count, minimumImageWidth, minimumImageHeight, 16, widths, heights );
+}
+
+int tmc2_frame_set_packing( tmc2_frame* f, const tmc2_patch* list, int count, const int32_t* matches, const uint8_t* occupancy,
+                            int64_t occupancyBytes, int packedWidth, int packedHeight ) {
+  if ( !f || count < 0 || occupancyBytes < 0 || ( count && ( !list || !occupancy ) ) || packedWidth <= 0 || packedHeight < 0 )
+    return TMC2_E_INVALID;
+  if ( !f->havePatches ) {
+    tmc2::setError( "set_packing: the frame has no patches" );
+    return TMC2_E_STATE;
+  }
+  if ( size_t( count ) != f->patches.size() ) {
+    tmc2::setError( "set_packing: %d records for a frame of %zu patches (packing reorders and places, it does not add or drop)", count,
+                    f->patches.size() );
+    return TMC2_E_INVALID;
+  }
+  tmc2::GpaFrameIO g;
+  g.list.assign( list, list + count );
+  if ( matches )
+    g.match.assign( matches, matches + count );
+  else
+    g.match.assign( size_t( count ), -1 );
+  g.occ.assign( occupancy, occupancy + occupancyBytes );
+  g.width = packedWidth, g.height = packedHeight;
+  for ( int i = 0; i < count; ++i ) {
+    const tmc2_patch& p = list[i];
+    const int64_t     blocks = int64_t( p.sizeU0 ) * p.sizeV0, samples = int64_t( p.sizeU ) * p.sizeV;
+    if ( p.sizeU0 <= 0 || p.sizeV0 <= 0 || p.occOffset < 0 || p.occOffset + blocks > occupancyBytes || p.depthOffset < 0 ||
+         p.depthOffset + samples > f->depthCount || p.u0 < 0 || p.v0 < 0 ) {
+      tmc2::setError( "set_packing: record %d does not belong to this frame's pools", i );
+      return TMC2_E_INVALID;
+    }
+  }
+  TMC2_TRY( tmc2::installPacking( f, g ) );
+  f->havePacking = true;
+  return TMC2_OK;
 }
 
 int tmc2_host_global_patch_allocation( int frames, int32_t* counts, tmc2_patch* patches, const uint8_t* occupancy,

@@ -335,6 +335,7 @@ struct GpaFrameIO {
   int                     width = 0, height = 0;  // tile size, pixels
 };
 int globalPatchAllocationCore( std::vector<GpaFrameIO>& frames, int minW, int minH, int occRes );
+int installPacking( tmc2_frame* f, const GpaFrameIO& g );
 int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrecision );
 int rgb444ToYuv420Device( tmc2_ctx* ctx, const uint8_t* d_rgb, int W, int H, int filter, uint8_t* d_yuv );
 int yuv420ToYuv444Device( tmc2_ctx* ctx, const uint8_t* d_yuv, int W, int H, int filter, uint16_t* d_out );

@@ -54,6 +54,32 @@ class Sharder:
         self.dist.gather(raw, out, dst=0)
         return [o.view(tensor.dtype).view(tensor.shape) for o in out] if out is not None else None
 
+    def pack_gof_records(self, local_records, frame_count, mode, min_w, min_h, tiles_hor=2, ratio=1.0):
+        """The inter-frame packers over a GOF whose frames live on several ranks ("gather to rank 0 of the
+        per-frame patch table before packing").  local_records: (patch records, block-occupancy pool) of this rank's
+        frames, in the order of frames_of(frame_count) -- a few KB per frame.  Rank 0 runs the chain over the GOF in
+        frame order (lib.host_pack_gof_records) and every rank gets back the packed lists of its own frames:
+        [(patch list, pool, matches, tile width, tile height)], plus the tile sizes of ALL frames (for the GOF canvas)."""
+        if self.world == 1:
+            res = lib.host_pack_gof_records(local_records, mode, min_w, min_h, tiles_hor, ratio)
+            return res, [(r[3], r[4]) for r in res]
+        gathered = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(local_records, gathered, dst=0)
+        box = [None]
+        if self.rank == 0:
+            records = [None] * frame_count
+            for r, recs in enumerate(gathered):
+                for k, f in enumerate(self.frames_of(frame_count, r)):
+                    records[f] = recs[k]
+            try:
+                box[0] = lib.host_pack_gof_records(records, mode, min_w, min_h, tiles_hor, ratio)
+            except lib.Tmc2Error as e:                       # every rank must leave the collective, with the same error
+                box[0] = e
+        self.dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], Exception):
+            raise box[0]
+        return [box[0][f] for f in self.frames_of(frame_count)], [(r[3], r[4]) for r in box[0]]
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
@@ -184,14 +210,15 @@ class GofEncoder:
         """fn(frame, index) on the frame's own worker thread (e.g. the copies of finished canvases to host memory)."""
         return self._dispatch([(i % self.workers, (lambda fr=fr, i=i: fn(fr, i))) for i, fr in enumerate(frames)])
 
-    def phase_a(self, frames, sharder=None, weight=None, constrained_pack=False):
+    def phase_a(self, frames, sharder=None, weight=None, constrained_pack=False, frame_count=None, records_chain=False):
         """constrained_pack: True = the low-delay condition -- frames after the first are packed against their predecessor
-        (S10', a sequential chain over the GOF, microseconds per frame on the host; single-process only: the chain would
-        cross ranks); 2 = the random-access condition -- the same chain followed by the global patch allocation over the
-        GOF (tracked patches share one place in all frames of a sub-context)."""
+        (S10', a sequential chain over the GOF, microseconds per frame on the host); 2 = the random-access condition -- the same chain followed by the global patch allocation over the
+        GOF (tracked patches share one place in all frames of a sub-context).  With several ranks (frame f on rank
+        f mod world; frame_count = frames of the whole GOF) the chain runs on rank 0 over the gathered patch records and the
+        packed lists come back (records_chain=True forces that route in a single process)."""
         sharder = sharder or Sharder()
-        if constrained_pack and sharder.world > 1:
-            raise ValueError("constrained packing chains the frames of a GOF: run it in one process")
+        if constrained_pack and (sharder.world > 1 or records_chain):
+            return self._phase_a_sharded_chain(frames, sharder, weight, int(constrained_pack), frame_count)
         if weight is None:
             w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
             weight = sharder.broadcast_weight(w)
@@ -217,6 +244,24 @@ class GofEncoder:
         # the chained packer writes the width of its canvas back into the tile (a patch wider than the preset width widens it)
         tile_w = max([self.min_w] + [fr.get_packed_size()[0] for fr in frames]) if constrained_pack else self.min_w
         W, H = lib.encoder_canvas_size([gof_h], tile_w, self.min_w, self.min_h)
+        self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
+        return W, H
+
+    def _phase_a_sharded_chain(self, frames, sharder, weight, mode, frame_count):
+        frame_count = len(frames) * sharder.world if frame_count is None else frame_count
+        if weight is None:
+            w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
+            weight = sharder.broadcast_weight(w)
+        params = lib.ctc_params(self.iterations, self.bits3d, weight)
+        self._per_worker(frames, lambda fr: fr.segmenter_compute(params))
+        local = self._per_worker(frames, lambda fr: fr.get_patch_records())
+        mine, tiles = sharder.pack_gof_records(local, frame_count, mode, self.min_w, self.min_h)
+        self.per_frame(frames, lambda fr, i: fr.set_packing(mine[i][0], mine[i][2], mine[i][1], mine[i][3], mine[i][4]))
+        tile_w = max([self.min_w] + [t[0] for t in tiles])
+        tile_h = max([t[1] for t in tiles]) if tiles else 0
+        if mode == 2:
+            tile_h = max(tile_h, self.min_h)
+        W, H = lib.encoder_canvas_size([tile_h], tile_w, self.min_w, self.min_h)
         self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
         return W, H
 

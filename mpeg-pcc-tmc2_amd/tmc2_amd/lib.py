@@ -324,6 +324,23 @@ class Frame:
         return patches, d0, d1, occ
 
 
+    def get_patch_records(self):
+        """(patch records, block-occupancy pool) without the depth pools: what the inter-frame packers work on."""
+        cnt = self.L.tmc2_frame_patch_count(self.h)
+        dc, oc = C.c_int64(), C.c_int64()
+        _check(self.L.tmc2_frame_patch_pool_sizes(self.h, C.byref(dc), C.byref(oc)))
+        patches, occ = np.zeros(cnt, PATCH_DTYPE), np.zeros(oc.value, np.uint8)
+        _check(self.L.tmc2_frame_get_patches(self.h, _ptr(patches), None, None, _ptr(occ)))
+        return patches, occ
+
+    def set_packing(self, patch_list, matches, occupancy, packed_width, packed_height):
+        """Install a packed patch list (list order) computed elsewhere -- on the rank that runs the inter-frame chain."""
+        p = np.ascontiguousarray(patch_list, dtype=PATCH_DTYPE)
+        occ = np.ascontiguousarray(occupancy, dtype=np.uint8)
+        m = None if matches is None else np.ascontiguousarray(matches, dtype=np.int32)
+        _check(self.L.tmc2_frame_set_packing(self.h, _ptr(p), len(p), None if m is None else _ptr(m), _ptr(occ), C.c_int64(len(occ)),
+                                             int(packed_width), int(packed_height)))
+
     # PCCEncoder image generation, phase A
     def encoder_pack_flexible(self, preset_width=1280, tiles_hor=2, ratio=1.0):
         h = C.c_int32()
@@ -540,6 +557,29 @@ def host_global_patch_allocation(lists, pools, matches, tile_w, tile_h, min_w=12
                     m[at:at + c].copy(), int(w[f]), int(h[f])))
         at += c
     return res
+
+
+def host_pack_gof_records(records, mode, min_w=1280, min_h=1280, tiles_hor=2, ratio=1.0):
+    """PCCEncoder::placeSegments over the patch RECORDS of a GOF (no device): records[f] = (patches by index, occupancy
+    pool) of frame f.  mode 0: every frame on its own (packFlexible); 1: the low-delay chain (frame f against frame f-1);
+    2: the chain followed by the global patch allocation (random access).
+    Returns per frame (patch list in list order, pool the list's occOffsets point into, matches, tile width, tile height)."""
+    out, prev = [], None
+    for rec, occ in records:
+        occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        if prev is None or mode == 0:
+            placed, order, h = host_pack_flexible(rec, occ, min_w, tiles_hor, ratio)
+            match, w = np.full(len(order), -1, np.int32), int(min_w)       # packFlexible leaves the tile width alone
+        else:
+            placed, order, match, h = host_pack_spatial_consistency(rec, occ, prev, min_w, tiles_hor, ratio)
+            w = 16 * max([int(min_w) // 16] + [int(x) + 1 for x in placed["sizeU0"]])   # the chained packer writes its canvas width back
+        prev = placed[order]
+        out.append((prev, occ, match, w, int(h)))
+    if mode == 2 and out:
+        tile_w = max([int(min_w)] + [o[3] for o in out])
+        tile_h = max([int(min_h)] + [o[4] for o in out])
+        out = host_global_patch_allocation([o[0] for o in out], [o[1] for o in out], [o[2] for o in out], tile_w, tile_h, min_w, min_h)
+    return out
 
 
 def segmenter_params_check(params):

@@ -113,3 +113,36 @@ def test_gpu_color_conversion_on_random_sizes(gpu_ctx, oracle, seed):
     assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (H, W, kind)
     y, u, v = (rng.integers(0, 256, p.shape, dtype=np.uint8) for p in exp)
     assert np.array_equal(gpu_ctx.color_convert_yuv420_to_yuv444(y, u, v), oracle.convert_yuv420_to_yuv444(y, u, v)), (H, W)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gpu_packers_over_patch_records_equal_the_in_process_chain(oracle, mode):
+    """The route a multi-rank GOF takes through S10' (patch records -> the rank that runs the chain -> packed lists installed
+    with tmc2_frame_set_packing), forced in one process, against the in-process chain on the same frames: canvas, lists,
+    matches, geometry / occupancy canvases, and (mode 2) the fixture of the unmodified reference."""
+    from test_oracle_golden import RANDOM_ACCESS_CANVAS, _random_access_fixture, check_random_access_against_fixture
+    g, frames = _random_access_fixture()
+    enc = T.GofEncoder(0, workers=2, iterations=10, min_w=RANDOM_ACCESS_CANVAS[0], min_h=RANDOM_ACCESS_CANVAS[1])
+    try:
+        res = []
+        for records_chain in (False, True):
+            frs = enc.upload(frames)
+            W, H = enc.phase_a(frs, constrained_pack=mode if mode == 2 else True, records_chain=records_chain)
+            a = []
+            for fr in frs:
+                img = fr.get_geometry_images()
+                patches = fr.get_patches()[0][fr.get_patch_order()]
+                img.update(patches=patches, width=W, height=H, matches=fr.get_patch_matches())
+                a.append(img)
+            res.append(a)
+        for x, y in zip(*res):
+            assert (x["width"], x["height"]) == (y["width"], y["height"])
+            for n in ("u0", "v0", "patchOrientation", "sizeU0", "sizeV0", "u1", "v1", "sizeU", "sizeV", "viewId"):
+                assert np.array_equal(x["patches"][n], y["patches"][n]), n
+            assert np.array_equal(x["matches"], y["matches"])
+            for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+                assert np.array_equal(x[k], y[k]), k
+        if mode == 2:
+            check_random_access_against_fixture(g, res[1])
+    finally:
+        enc.close()

@@ -498,3 +498,44 @@ def test_segmenter_params_check_accepts_ctc_and_names_what_it_refuses():
         with pytest.raises(T.Tmc2Error) as e:
             T.segmenter_params_check(p)
         assert "params" in str(e.value)
+
+
+@pytest.mark.parametrize("seed", list(range(30)) + [1574])
+def test_host_pack_gof_records_matches_the_oracle_chain(oracle, seed):
+    """placeSegments over the patch records of a GOF (what rank 0 runs when the frames live on several ranks): the low-delay
+    chain and the random-access condition, lists / matches / pools / tile sizes against the oracle's packers."""
+    rng = np.random.default_rng(1000 + seed)
+    frames = int(rng.integers(2, 7))
+    gof = _random_patch_gof(rng, frames, int(rng.integers(3, 40)), drift=int(rng.integers(0, 30)), churn=float(rng.choice([0.0, 0.1, 0.4])))
+    min_w = int(rng.choice([128, 256, 512, 1280]))
+    min_h = int(rng.choice([64, 128, 256, 512, 1280]))
+    per = []
+    for rec, occ in gof:
+        if per:
+            step = oracle.pack_spatial_consistency(rec, occ, per[-1][1][per[-1][2]], min_w)
+            if step is None:
+                with pytest.raises(T.Tmc2Error):
+                    T.host_pack_gof_records(gof, 1, min_w, min_h)
+                return
+            placed, order, match, h = step
+        else:
+            placed, order, h = oracle.pack_flexible(rec, occ, min_w)
+            match = np.full(len(order), -1, np.int32)
+        per.append((dict(occupancy=occ, matches=match), placed, order, h))
+    got = T.host_pack_gof_records(gof, 1, min_w, min_h)
+    for (seg, placed, order, h), (gl, gpool, gm, gw, gh) in zip(per, got):
+        el = placed[order]
+        assert gh == h and np.array_equal(gm, seg["matches"])
+        assert all(np.array_equal(gl[n], el[n]) for n in el.dtype.names)
+        assert np.array_equal(gpool, seg["occupancy"])
+    assert max([min_w] + [g[3] for g in got]) == oracle.tile_size(per, min_w, min_h)[0]
+    exp = oracle.global_patch_allocation(per, min_w, min_h)
+    if exp is None:                                            # undefined / never returning in the reference: refused
+        with pytest.raises(T.Tmc2Error):
+            T.host_pack_gof_records(gof, 2, min_w, min_h)
+        return
+    got = T.host_pack_gof_records(gof, 2, min_w, min_h)
+    for (el, eo, em, ew, eh), (gl, go, gm, gw, gh) in zip(exp, got):
+        assert (gw, gh) == (ew, eh) and np.array_equal(gm, em)
+        assert all(np.array_equal(gl[n], el[n]) for n in el.dtype.names)
+        assert np.array_equal(go, eo[:len(go)])

@@ -68,3 +68,63 @@ def test_sharder_single_process_is_identity():
     assert np.array_equal(sh.broadcast_weight([1, 2, 3]), np.array([1.0, 2.0, 3.0]))
     t = torch.zeros(3)
     assert sh.gather(t)[0] is t
+
+
+def _gof_records(seed, frames):
+    from test_host_logic import _random_patch_gof
+    rng = np.random.default_rng(seed)
+    return _random_patch_gof(rng, frames, 25, drift=6, churn=0.1)
+
+
+def _pack_worker(rank, world, port, frame_count, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = Sharder(rank, world, dist, "cpu")
+    gof = _gof_records(seed, frame_count)                              # the same GOF on every rank; each keeps its own frames
+    local = [gof[f] for f in sh.frames_of(frame_count)]
+    out = {}
+    for mode in (1, 2):
+        mine, tiles = sh.pack_gof_records(local, frame_count, mode, 512, 512)
+        out[mode] = (sh.frames_of(frame_count), mine, tiles)
+    # a chain rank 0 refuses (here: a canvas of width 0) raises on EVERY rank: nobody is left waiting in the collective
+    try:
+        sh.pack_gof_records(local, frame_count, 1, 0, 512)
+        out["error"] = None
+    except Exception as e:
+        out["error"] = type(e).__name__
+    sh.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_inter_frame_packers_over_sharded_frames_world2_gloo():
+    """S10' with the frames of a GOF on two ranks: patch records gathered to rank 0, the chain / the global patch
+    allocation run there, the packed lists scattered back -- against the same chain in one process."""
+    import tmc2_amd as T
+    world, frames, seed = 2, 6, 77
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pack_worker, args=(r, world, port, frames, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gof = _gof_records(seed, frames)
+    for mode in (1, 2):
+        exp = T.host_pack_gof_records(gof, mode, 512, 512)
+        seen = []
+        for rank in range(world):
+            ids, mine, tiles = res[rank][mode]
+            assert tiles == [(e[3], e[4]) for e in exp]                 # every rank knows the tile sizes of the whole GOF
+            for f, got in zip(ids, mine):
+                seen.append(f)
+                for a, b in zip(got, exp[f]):
+                    assert np.array_equal(a, b), (mode, f)
+        assert sorted(seen) == list(range(frames))
+        if mode == 2:
+            assert any((e[2] >= 0).any() for e in exp)            # the GOF has tracked patches: the allocation did something
+    assert res[0]["error"] == res[1]["error"] == "Tmc2Error"
