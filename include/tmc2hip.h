@@ -360,6 +360,17 @@ int tmc2_host_global_patch_allocation( int frames, int32_t* counts, tmc2_patch* 
 int tmc2_host_pack_spatial_consistency( tmc2_patch* patches, int count, const uint8_t* occupancy, const tmc2_patch* previous,
                                         int previousCount, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
                                         int32_t* order, int32_t* matches, int32_t* height );
+/* replaces: PCCEncoder::placeSegments (PccLibEncoder/source/PCCEncoder.cpp:4790-4840) over the patch RECORDS of a whole GOF
+ * -- what the rank that holds the records of all frames runs when the frames themselves live on several GPUs.
+ * mode 0: packFlexible per frame; 1: frame f > 0 packed against frame f-1 (spatialConsistencyPackFlexible); 2: that chain
+ * followed by performDataAdaptiveGPAMethod.  counts[frames]; patches: all frames back to back, in: by index (occOffset
+ * into occupancy + occupancyBase[f]), out: in LIST order with placements (occOffset into occupancyOut +
+ * occupancyOutBase[f]); matches: out, per list position; widths / heights: the tile each frame is left with (may be NULL).
+ * The number of records per frame does not change.  occupancyOutBase has frames + 1 entries (the last = bytes used).    */
+int tmc2_host_place_segments( int frames, const int32_t* counts, tmc2_patch* patches, const uint8_t* occupancy,
+                              const int64_t* occupancyBase, int mode, int minimumImageWidth, int minimumImageHeight, int numTilesHor,
+                              double tileHeightToWidthRatio, int32_t* matches, uint8_t* occupancyOut, int64_t occupancyOutCapacity,
+                              int64_t* occupancyOutBase, int32_t* widths, int32_t* heights );
 /* the exact spanning-tree orientation behind tmc2_normals_orient (normals in/out, knn = [n][k]) */
 int tmc2_host_orient_normals( const int16_t* xyz, uint64_t n, const uint32_t* knn, int k, double* normals );
 

@@ -342,6 +342,87 @@ int tmc2_host_pack_flexible( tmc2_patch* patches, int count, const uint8_t* occu
   return TMC2_OK;
 }
 
+int tmc2_host_place_segments( int frames, const int32_t* counts, tmc2_patch* patches, const uint8_t* occupancy,
+                              const int64_t* occupancyBase, int mode, int minimumImageWidth, int minimumImageHeight, int numTilesHor,
+                              double tileHeightToWidthRatio, int32_t* matches, uint8_t* occupancyOut, int64_t occupancyOutCapacity,
+                              int64_t* occupancyOutBase, int32_t* widths, int32_t* heights ) {
+  if ( frames <= 0 || !counts || !occupancyBase || !occupancyOutBase || mode < 0 || mode > 2 || minimumImageWidth <= 0 ||
+       minimumImageHeight <= 0 || numTilesHor <= 0 )
+    return TMC2_E_INVALID;
+  const int                     occRes = 16;
+  std::vector<tmc2::GpaFrameIO> io;
+  io.resize( size_t( frames ) );
+  size_t at = 0;
+  for ( int f = 0; f < frames; ++f ) {
+    const int P = counts[f];
+    if ( P < 0 || ( P && ( !patches || !occupancy || !matches ) ) ) return TMC2_E_INVALID;
+    tmc2::GpaFrameIO&       g = io[size_t( f )];
+    std::vector<tmc2_patch> pt( patches + at, patches + at + P );
+    int64_t                 bytes = 0;
+    for ( auto& p : pt ) {
+      if ( p.sizeU0 <= 0 || p.sizeV0 <= 0 || p.occOffset < 0 ) {
+        tmc2::setError( "host_place_segments: frame %d holds a record without a block box", f );
+        return TMC2_E_INVALID;
+      }
+      bytes = std::max( bytes, p.occOffset + int64_t( p.sizeU0 ) * p.sizeV0 );
+    }
+    g.occ.assign( occupancy + occupancyBase[f], occupancy + occupancyBase[f] + bytes );
+    std::vector<int32_t> order( size_t( P ), 0 );
+    g.match.assign( size_t( P ), -1 );
+    const bool chained = mode > 0 && f > 0;
+    // packFlexible leaves the tile width alone (it works on a copy, PCCEncoder.cpp:2312); the chained packer writes the
+    // width of the canvas it packed on back into the tile (:1190, :1308)
+    g.width = minimumImageWidth;
+    if ( chained ) {
+      int sizeU = minimumImageWidth / occRes;
+      for ( auto& p : pt ) sizeU = std::max( sizeU, p.sizeU0 + 1 );
+      g.width = sizeU * occRes;
+    }
+    g.height = 0;
+    if ( P ) {
+      g.height = chained ? tmc2::packSpatialConsistencyCore( pt.data(), P, g.occ.data(), io[size_t( f ) - 1].list.data(),
+                                                             int( io[size_t( f ) - 1].list.size() ), minimumImageWidth, occRes, numTilesHor,
+                                                             tileHeightToWidthRatio, order.data(), g.match.data() )
+                         : tmc2::packFlexibleCore( pt.data(), P, g.occ.data(), minimumImageWidth, occRes, numTilesHor,
+                                                   tileHeightToWidthRatio, order.data() );
+      if ( g.height < 0 ) {
+        tmc2::setError( "host_place_segments: frame %d: a patch fits at no canvas height", f );
+        return TMC2_E_INVALID;
+      }
+    }
+    g.list.resize( size_t( P ) );
+    for ( int k = 0; k < P; ++k ) g.list[size_t( k )] = pt[size_t( order[size_t( k )] )];
+    at += size_t( P );
+  }
+  if ( mode == 2 ) {
+    int tileW = minimumImageWidth, tileH = minimumImageHeight;  // resizeTileGeometryVideo ran before the allocation
+    for ( auto& g : io ) tileW = std::max( tileW, g.width ), tileH = std::max( tileH, g.height );
+    for ( auto& g : io ) g.width = tileW, g.height = tileH;
+    TMC2_TRY( tmc2::globalPatchAllocationCore( io, minimumImageWidth, minimumImageHeight, occRes ) );
+  }
+  int64_t total = 0;
+  for ( auto& g : io ) total += int64_t( g.occ.size() );
+  occupancyOutBase[frames] = total;
+  if ( total > occupancyOutCapacity || ( total && !occupancyOut ) ) {
+    tmc2::setError( "host_place_segments: the occupancy pools need %lld bytes", (long long)total );
+    return TMC2_E_INVALID;
+  }
+  at           = 0;
+  int64_t base = 0;
+  for ( int f = 0; f < frames; ++f ) {
+    tmc2::GpaFrameIO& g = io[size_t( f )];
+    occupancyOutBase[f] = base;
+    std::copy( g.list.begin(), g.list.end(), patches + at );
+    std::copy( g.match.begin(), g.match.end(), matches + at );
+    if ( !g.occ.empty() ) std::memcpy( occupancyOut + base, g.occ.data(), g.occ.size() );
+    base += int64_t( g.occ.size() );
+    at += g.list.size();
+    if ( widths ) widths[f] = g.width;
+    if ( heights ) heights[f] = g.height;
+  }
+  return TMC2_OK;
+}
+
 int tmc2_host_pack_spatial_consistency( tmc2_patch* patches, int count, const uint8_t* occupancy, const tmc2_patch* previous,
                                         int previousCount, int presetWidth, int numTilesHor, double tileHeightToWidthRatio,
                                         int32_t* order, int32_t* matches, int32_t* height ) {

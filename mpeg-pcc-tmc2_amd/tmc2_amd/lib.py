@@ -560,26 +560,33 @@ def host_global_patch_allocation(lists, pools, matches, tile_w, tile_h, min_w=12
 
 
 def host_pack_gof_records(records, mode, min_w=1280, min_h=1280, tiles_hor=2, ratio=1.0):
-    """PCCEncoder::placeSegments over the patch RECORDS of a GOF (no device): records[f] = (patches by index, occupancy
-    pool) of frame f.  mode 0: every frame on its own (packFlexible); 1: the low-delay chain (frame f against frame f-1);
-    2: the chain followed by the global patch allocation (random access).
+    """PCCEncoder::placeSegments over the patch RECORDS of a GOF (tmc2_host_place_segments; no device): records[f] =
+    (patches by index, occupancy pool) of frame f.  mode 0: every frame on its own (packFlexible); 1: the low-delay chain
+    (frame f against frame f-1); 2: the chain followed by the global patch allocation (random access).
     Returns per frame (patch list in list order, pool the list's occOffsets point into, matches, tile width, tile height)."""
-    out, prev = [], None
-    for rec, occ in records:
-        occ = np.ascontiguousarray(occ, dtype=np.uint8)
-        if prev is None or mode == 0:
-            placed, order, h = host_pack_flexible(rec, occ, min_w, tiles_hor, ratio)
-            match, w = np.full(len(order), -1, np.int32), int(min_w)       # packFlexible leaves the tile width alone
-        else:
-            placed, order, match, h = host_pack_spatial_consistency(rec, occ, prev, min_w, tiles_hor, ratio)
-            w = 16 * max([int(min_w) // 16] + [int(x) + 1 for x in placed["sizeU0"]])   # the chained packer writes its canvas width back
-        prev = placed[order]
-        out.append((prev, occ, match, w, int(h)))
-    if mode == 2 and out:
-        tile_w = max([int(min_w)] + [o[3] for o in out])
-        tile_h = max([int(min_h)] + [o[4] for o in out])
-        out = host_global_patch_allocation([o[0] for o in out], [o[1] for o in out], [o[2] for o in out], tile_w, tile_h, min_w, min_h)
-    return out
+    L = load_library()
+    n = len(records)
+    if n == 0:
+        return []
+    counts = np.array([len(r) for r, _ in records], np.int32)
+    patches = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=PATCH_DTYPE) for r, _ in records]), dtype=PATCH_DTYPE)
+    pools = [np.ascontiguousarray(o, dtype=np.uint8) for _, o in records]
+    base = np.zeros(n, np.int64)
+    base[1:] = np.cumsum([len(x) for x in pools])[:-1]
+    occ = np.ascontiguousarray(np.concatenate(pools))
+    # (random access) a patch can grow to the box of its track's union: never beyond the largest box of the GOF in either direction
+    cap = int(len(patches) * max(1, int(patches["sizeU0"].max(initial=1))) * max(1, int(patches["sizeV0"].max(initial=1)))) if mode == 2 else len(occ)
+    out, out_base = np.zeros(max(cap, 1), np.uint8), np.zeros(n + 1, np.int64)
+    m = np.zeros(max(len(patches), 1), np.int32)
+    w, h = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    _check(L.tmc2_host_place_segments(n, _ptr(counts), _ptr(patches), _ptr(occ), _ptr(base), int(mode), int(min_w), int(min_h),
+                                      int(tiles_hor), C.c_double(ratio), _ptr(m), _ptr(out), C.c_int64(cap), _ptr(out_base), _ptr(w), _ptr(h)))
+    res, at = [], 0
+    for f in range(n):
+        c = int(counts[f])
+        res.append((patches[at:at + c].copy(), out[out_base[f]:out_base[f + 1]].copy(), m[at:at + c].copy(), int(w[f]), int(h[f])))
+        at += c
+    return res
 
 
 def segmenter_params_check(params):
