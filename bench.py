@@ -56,8 +56,16 @@ def _gen(arg):
     return synth_cloud(arg[0], arg[1])
 
 
+def under_profiler():
+    """rocprofv3 injects its tool library into every child; its signal handler deadlocks multiprocessing pools and would
+    trace the CPU baseline's subprocesses: side legs that start processes are left out under it."""
+    return any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+
+
 def make_frames(workload, indices, gen_procs=0):
     import multiprocessing as mp
+    if under_profiler():
+        gen_procs = 1
     procs = gen_procs or max(1, min(len(indices), (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 16))
     if procs == 1 or len(indices) < 2:
         return [_gen((workload, i)) for i in indices]
@@ -98,6 +106,8 @@ def cpu_baseline(workload, iterations):
     res = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": 1, "kind": kind,
            "sample": "1 frame of %s (%d points), stages S0-S22 (patch generation + occupancy/geometry/attribute images), "
                      "1 thread, %.1f s" % (workload, len(frames[0][0]), dt)}
+    if under_profiler():
+        return res
     try:                                                       # a side figure: never lose the line over it
         res["all_cores"] = cpu_baseline_all_cores(workload, iterations, dt)
     except Exception as e:
