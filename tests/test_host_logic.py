@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in tmc2hip.h but not exported: %s" % missing
 
 
+def test_every_declared_symbol_is_bound_and_documented():
+    """Each entry of include/tmc2hip.h has its ctypes binding (tmc2_amd/lib.py) and its reference counterpart in
+    INTEGRATION.md -- the drop-in boundary stays in step with its documentation."""
+    hdr = open(os.path.join(ROOT, "include", "tmc2hip.h")).read()
+    names = sorted(set(re.findall(r"\b(tmc2_[a-z0-9_]+)\s*\(", hdr)))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    binding = open(os.path.join(ROOT, "mpeg-pcc-tmc2_amd", "tmc2_amd", "lib.py")).read()
+    assert not [n for n in names if n not in doc], "not in INTEGRATION.md"
+    assert not [n for n in names if n not in binding], "not bound in lib.py"
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
