@@ -550,3 +550,17 @@ def test_host_pack_gof_records_matches_the_oracle_chain(oracle, seed):
         assert (gw, gh) == (ew, eh) and np.array_equal(gm, em)
         assert all(np.array_equal(gl[n], el[n]) for n in el.dtype.names)
         assert np.array_equal(go, eo[:len(go)])
+
+
+def test_bench_cpu_baseline_leg_reports_one_core_and_all_cores():
+    """bench.py's cpu_baseline leg (the checker timed as the reported baseline, never part of the product path): the
+    one-thread figure and the per-frame-process figure, on the smallest workload."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    res = bench.cpu_baseline("tiny", 2)
+    assert res["unit"] == "frames/s" and res["cores"] == 1 and res["value"] > 0 and res["kind"] in ("reference", "port")
+    allc = res["all_cores"]
+    assert "error" not in allc, allc
+    assert allc["value"] > 0 and 1 <= allc["cores"] <= 32
