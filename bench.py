@@ -56,6 +56,24 @@ def _gen(arg):
     return synth_cloud(arg[0], arg[1])
 
 
+def stream_copy_ceiling(torch, device, nbytes=1 << 30, repeats=10):
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    src.fill_(1)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(repeats):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / repeats
+    del src, dst
+    return {"GB/s": round(2.0 * nbytes / (ms * 1e-3) / 1e9, 1), "what": "device-to-device copy of %d MiB, read + written bytes" % (nbytes >> 20)}
+
+
 def under_profiler():
     """rocprofv3 injects its tool library into every child; its signal handler deadlocks multiprocessing pools and would
     trace the CPU baseline's subprocesses: side legs that start processes are left out under it."""
@@ -308,6 +326,12 @@ def main():
                      "alone_frac": round(s_ach / 8000.0, 5)},
         "stage_ms_per_frame": {k: round(v / (a.steps * len(frames)), 3) for k, v in sorted(ms.items())},
     }
+    # the measured ceiling next to the nominal 8 TB/s: a device-to-device copy of 1 GiB, bytes read +
+    # bytes written per second, with the GPU to itself (outside the timed region)
+    try:
+        out["roofline"]["stream_copy"] = stream_copy_ceiling(torch, "cuda:%d" % local)
+    except Exception as e:
+        out["roofline"]["stream_copy"] = {"error": repr(e)}
     # S23 is reported separately: one frame, D1 + D2 + colour, both directions
     rx, rc, _ = frames[0].get_reconstruction()
     t0 = time.time()
