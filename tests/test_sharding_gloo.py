@@ -128,3 +128,51 @@ def test_inter_frame_packers_over_sharded_frames_world2_gloo():
         if mode == 2:
             assert any((e[2] >= 0).any() for e in exp)            # the GOF has tracked patches: the allocation did something
     assert res[0]["error"] == res[1]["error"] == "Tmc2Error"
+
+
+def test_phase_a_records_route_orchestration_with_fake_frames():
+    """GofEncoder's records route through S10' (segment -> records -> chain on plain records -> install -> rasterise) with
+    the device calls faked: what is installed in every frame and the GOF canvas are those of the chain on plain records."""
+    import tmc2_amd as T
+    from tmc2_amd.gof import GofEncoder
+
+    gof = _gof_records(5, 4)
+
+    class FakeFrame:
+        def __init__(self, rec, occ):
+            self.rec, self.occ, self.installed, self.canvas = rec, occ, None, None
+
+        def weight_normal(self, bits, thr):
+            return np.array([1.0, 1.0, 1.0])
+
+        def segmenter_compute(self, params):
+            pass
+
+        def get_patch_records(self):
+            return self.rec, self.occ
+
+        def set_packing(self, patch_list, matches, occupancy, w, h):
+            self.installed = (patch_list, occupancy, matches, w, h)
+
+        def encoder_generate_geometry_images(self, W, H, prec):
+            self.canvas = (W, H, prec)
+
+    class FakeEncoder:
+        iterations, bits3d, min_w, min_h, occ_precision = 2, 10, 512, 512, 4
+
+        def _per_worker(self, frames, fn):
+            return [fn(fr) for fr in frames]
+
+        def per_frame(self, frames, fn):
+            return [fn(fr, i) for i, fr in enumerate(frames)]
+
+    for mode in (1, 2):
+        frames = [FakeFrame(r, o) for r, o in gof]
+        W, H = GofEncoder._phase_a_sharded_chain(FakeEncoder(), frames, Sharder(), None, mode, None)
+        exp = T.host_pack_gof_records(gof, mode, 512, 512)
+        for fr, e in zip(frames, exp):
+            assert fr.canvas == (W, H, 4)
+            for a, b in zip(fr.installed, e):
+                assert np.array_equal(a, b)
+        tile_h = max(e[4] for e in exp)
+        assert (W, H) == T.encoder_canvas_size([max(tile_h, 512) if mode == 2 else tile_h], max([512] + [e[3] for e in exp]), 512, 512)
