@@ -982,6 +982,38 @@ int ref_adaptor_check_frame( int frame, const uint8_t* occupancy, const uint8_t*
   return bad;
 }
 
+// integration/tmc2hip_convert.cpp, applyPacking: the records the product's packers return for a frame (by index, with
+// placements), its list order and matches, applied to a PCCPatch vector in creation order -- against the vector the
+// reference's own placeSegments left for that frame (after ref_place_records on the same records, all-intra or low-delay
+// condition: the global patch allocation also rewrites block boxes, which is more than a placement).  Bit mask of what differs.
+int ref_adaptor_check_packing( int frame, const tmc2_patch* recordsByIndex, const int32_t* order, const int32_t* matches, int count ) {
+  auto& theirs = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();
+  if ( size_t( count ) != theirs.size() ) return 1;
+  std::vector<PCCPatch> mine( static_cast<size_t>( count ) );
+  for ( int i = 0; i < count; ++i ) {  // the vector as the segmenter leaves it: creation order, nothing placed
+    const tmc2_patch& r = recordsByIndex[i];
+    PCCPatch&         p = mine[size_t( i )];
+    p.setIndex( size_t( r.index ) );
+    p.setViewId( size_t( r.viewId ) );
+    p.setU1( size_t( r.u1 ) ), p.setV1( size_t( r.v1 ) ), p.setD1( size_t( r.d1 ) );
+    p.setSizeU( size_t( r.sizeU ) ), p.setSizeV( size_t( r.sizeV ) );
+    p.setSizeU0( size_t( r.sizeU0 ) ), p.setSizeV0( size_t( r.sizeV0 ) );
+    p.setBestMatchIdx( -1 );
+  }
+  tmc2hip::applyPacking( recordsByIndex, order, matches, count, mine );
+  int bad = 0;
+  for ( int k = 0; k < count; ++k ) {
+    const PCCPatch &a = mine[size_t( k )], &b = theirs[size_t( k )];
+    if ( a.getIndex() != b.getIndex() || a.getViewId() != b.getViewId() || a.getU1() != b.getU1() || a.getV1() != b.getV1() ||
+         a.getSizeU0() != b.getSizeU0() || a.getSizeV0() != b.getSizeV0() )
+      bad |= 2;  // list order
+    if ( a.getU0() != b.getU0() || a.getV0() != b.getV0() ) bad |= 4;
+    if ( a.getPatchOrientation() != b.getPatchOrientation() ) bad |= 8;
+    if ( a.getBestMatchIdx() != b.getBestMatchIdx() ) bad |= 16;
+  }
+  return bad;
+}
+
 // ---- ingest and checksums: PCCPointSet3::read (PCCPointSet.cpp:464-757), computeChecksum (:222-243) ----
 namespace {
 PCCPointSet3 g_ply;

@@ -77,3 +77,32 @@ def test_adaptor_segmenter_compute_is_a_drop_in(adaptor):
     params = T.ctc_params(10, 11, frame.weight_normal(11, 0.6))
     x, c = np.ascontiguousarray(xyz, np.int16), np.ascontiguousarray(rgb, np.uint8)
     assert adaptor.adaptor_check_segmenter_compute(0, _p(x), _p(c), C.c_size_t(len(x)), C.byref(params)) == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("mode", [0, 1])
+def test_adaptor_apply_packing_rebuilds_the_reference_patch_lists(reference, seed, mode):
+    """applyPacking (integration/tmc2hip_convert.cpp): what the product's packers return for the frames of a GOF (records by
+    index with placements, list order, matches -- here from the host entries on random patch records) applied to PCCPatch
+    vectors in creation order gives the vectors PCCEncoder::placeSegments itself leaves, all-intra and low-delay."""
+    from test_host_logic import _random_patch_gof
+    rng = np.random.default_rng(4000 + seed)
+    gof = _random_patch_gof(rng, int(rng.integers(2, 6)), int(rng.integers(3, 30)), drift=int(rng.integers(0, 20)), churn=float(rng.choice([0.0, 0.2])))
+    min_w, min_h = int(rng.choice([256, 512, 1280])), int(rng.choice([256, 1280]))
+    per, prev = [], None
+    try:
+        for rec, occ in gof:
+            if prev is None or mode == 0:
+                placed, order, _ = T.host_pack_flexible(rec, occ, min_w)
+                match = np.full(len(order), -1, np.int32)
+            else:
+                placed, order, match, _ = T.host_pack_spatial_consistency(rec, occ, prev, min_w)
+            prev = placed[order]
+            per.append((placed, order, match))
+    except T.Tmc2Error:
+        pytest.skip("the reference never returns on this GOF")
+    reference.place_records(gof, min_w, min_h, mode)
+    for f, (placed, order, match) in enumerate(per):
+        placed = np.ascontiguousarray(placed, dtype=T.lib.PATCH_DTYPE)
+        order, match = np.ascontiguousarray(order, np.int32), np.ascontiguousarray(match, np.int32)
+        assert reference.L.ref_adaptor_check_packing(f, _p(placed), _p(order), _p(match), len(placed)) == 0, f
