@@ -37,6 +37,13 @@ void toRecords( const std::vector<pcc::PCCPatch>& patches, std::vector<tmc2_patc
 void applyPacking( const tmc2_patch* recordsByIndex, const int32_t* order, const int32_t* matches, int count,
                    std::vector<pcc::PCCPatch>& patches );
 
+// the packed LIST a GOF-level packer of the library returns for a frame (tmc2_host_place_segments, or tmc2_frame_get_patches
+// after tmc2_encoder_global_patch_allocation: records in list order, block occupancy at occupancy + occOffset): rebuilds
+// `patches` (in: creation order, as the segmenter left it) in list order with what performDataAdaptiveGPAMethod rewrites --
+// index, block box, block occupancy -- and the placement / best-match index.  A record names its patch by its depthOffset.
+void applyPackedList( const tmc2_patch* list, const int32_t* matches, const uint8_t* occupancy, int count,
+                      std::vector<pcc::PCCPatch>& patches );
+
 // S11-S16 of one frame (tmc2_frame_get_geometry_images) -> the reference's containers: PCCFrameContext::occupancyMap_ and
 // blockToPatch_, the frame of the occupancy video, the two frames of the geometry video (formats and untouched planes as
 // generateOccupancyMapVideo / generateIntraImage leave them)

@@ -81,6 +81,32 @@ void applyPacking( const tmc2_patch* recordsByIndex, const int32_t* order, const
   }
 }
 
+void applyPackedList( const tmc2_patch* list, const int32_t* matches, const uint8_t* occupancy, int count,
+                      std::vector<PCCPatch>& patches ) {
+  std::vector<PCCPatch> created;
+  created.swap( patches );
+  std::vector<int64_t> depthOffset( created.size() );  // as toRecords / tmc2_frame_get_patches number the depth pools
+  int64_t              at = 0;
+  for ( size_t i = 0; i < created.size(); ++i ) {
+    depthOffset[i] = at;
+    at += int64_t( created[i].getSizeU() * created[i].getSizeV() );
+  }
+  patches.reserve( size_t( count ) );
+  for ( int k = 0; k < count; ++k ) {
+    const tmc2_patch& r = list[k];
+    const size_t      i = size_t( std::lower_bound( depthOffset.begin(), depthOffset.end(), r.depthOffset ) - depthOffset.begin() );
+    patches.push_back( created[i] );
+    PCCPatch& q = patches.back();
+    q.setIndex( size_t( r.index ) );
+    q.setSizeU0( size_t( r.sizeU0 ) ), q.setSizeV0( size_t( r.sizeV0 ) );
+    q.setU0( size_t( r.u0 ) ), q.setV0( size_t( r.v0 ) ), q.setPatchOrientation( size_t( r.patchOrientation ) );
+    q.setBestMatchIdx( matches ? matches[k] : -1 );
+    std::vector<bool> blocks( size_t( r.sizeU0 ) * size_t( r.sizeV0 ) );
+    for ( size_t b = 0; b < blocks.size(); ++b ) blocks[b] = occupancy[r.occOffset + int64_t( b )] != 0;
+    q.setOccupancy( blocks );
+  }
+}
+
 void toFrameImages( const uint8_t* occupancy, const uint8_t* occVideo, const uint32_t* blockToPatch, const uint16_t* geometryD0,
                     const uint16_t* geometryD1, size_t W, size_t H, size_t occupancyPrecision, std::vector<uint32_t>& occupancyMap,
                     std::vector<size_t>& blockToPatchOut, PCCImage<uint8_t, 3>& occupancyFrame, PCCImage<uint16_t, 3>& d0,

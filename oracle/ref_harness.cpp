@@ -1014,6 +1014,40 @@ int ref_adaptor_check_packing( int frame, const tmc2_patch* recordsByIndex, cons
   return bad;
 }
 
+// the same for applyPackedList and the random-access condition (ref_place_records with constrainedPack = 2): index, block
+// box, block occupancy, placement, orientation, best-match index of every list position
+int ref_adaptor_check_packed_list( int frame, const tmc2_patch* createdRecords, int created, const tmc2_patch* list,
+                                   const int32_t* matches, const uint8_t* occupancy, int count ) {
+  auto& theirs = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();
+  if ( size_t( count ) != theirs.size() || count != created ) return 1;
+  std::vector<PCCPatch> mine( static_cast<size_t>( created ) );
+  for ( int i = 0; i < created; ++i ) {
+    const tmc2_patch& r = createdRecords[i];
+    PCCPatch&         p = mine[size_t( i )];
+    p.setIndex( size_t( r.index ) );
+    p.setViewId( size_t( r.viewId ) );
+    p.setU1( size_t( r.u1 ) ), p.setV1( size_t( r.v1 ) ), p.setD1( size_t( r.d1 ) );
+    p.setSizeU( size_t( r.sizeU ) ), p.setSizeV( size_t( r.sizeV ) );
+    p.setSizeU0( size_t( r.sizeU0 ) ), p.setSizeV0( size_t( r.sizeV0 ) );
+    p.setBestMatchIdx( -1 );
+  }
+  tmc2hip::applyPackedList( list, matches, occupancy, count, mine );
+  int bad = 0;
+  for ( int k = 0; k < count; ++k ) {
+    const PCCPatch &a = mine[size_t( k )], &b = theirs[size_t( k )];
+    if ( a.getViewId() != b.getViewId() || a.getU1() != b.getU1() || a.getV1() != b.getV1() || a.getSizeU() != b.getSizeU() ||
+         a.getSizeV() != b.getSizeV() )
+      bad |= 2;  // which patch sits at this list position
+    if ( a.getIndex() != b.getIndex() ) bad |= 32;
+    if ( a.getSizeU0() != b.getSizeU0() || a.getSizeV0() != b.getSizeV0() ) bad |= 64;
+    if ( a.getU0() != b.getU0() || a.getV0() != b.getV0() ) bad |= 4;
+    if ( a.getPatchOrientation() != b.getPatchOrientation() ) bad |= 8;
+    if ( a.getBestMatchIdx() != b.getBestMatchIdx() ) bad |= 16;
+    if ( a.getOccupancy() != b.getOccupancy() ) bad |= 128;
+  }
+  return bad;
+}
+
 // ---- ingest and checksums: PCCPointSet3::read (PCCPointSet.cpp:464-757), computeChecksum (:222-243) ----
 namespace {
 PCCPointSet3 g_ply;

@@ -106,3 +106,27 @@ def test_adaptor_apply_packing_rebuilds_the_reference_patch_lists(reference, see
         placed = np.ascontiguousarray(placed, dtype=T.lib.PATCH_DTYPE)
         order, match = np.ascontiguousarray(order, np.int32), np.ascontiguousarray(match, np.int32)
         assert reference.L.ref_adaptor_check_packing(f, _p(placed), _p(order), _p(match), len(placed)) == 0, f
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_adaptor_apply_packed_list_rebuilds_the_reference_lists_under_random_access(reference, seed):
+    """applyPackedList: the packed lists tmc2_host_place_segments returns under the random-access condition (chain + global
+    patch allocation) applied to PCCPatch vectors in creation order give what placeSegments / performDataAdaptiveGPAMethod
+    leave: which patch at which list position, rewritten index and block box, block occupancy, placement, best match."""
+    from test_host_logic import _random_patch_gof
+    rng = np.random.default_rng(4100 + seed)
+    gof = _random_patch_gof(rng, int(rng.integers(2, 6)), int(rng.integers(3, 30)), drift=int(rng.integers(0, 12)), churn=float(rng.choice([0.0, 0.1])))
+    for rec, _ in gof:                                           # records name their patch by the offset of its depth maps
+        rec["depthOffset"] = np.concatenate([[0], np.cumsum(rec["sizeU"].astype(np.int64) * rec["sizeV"])[:-1]]) if len(rec) else 0
+    min_w, min_h = int(rng.choice([256, 512, 1280])), int(rng.choice([256, 1280]))
+    try:
+        got = T.host_pack_gof_records(gof, 2, min_w, min_h)
+    except T.Tmc2Error:
+        pytest.skip("undefined in the reference (the library refuses)")
+    reference.place_records(gof, min_w, min_h, 2)
+    tracked = 0
+    for f, ((rec, _), (lst, pool, match, _, _)) in enumerate(zip(gof, got)):
+        rec = np.ascontiguousarray(rec, dtype=T.lib.PATCH_DTYPE)
+        lst, pool, match = np.ascontiguousarray(lst, dtype=T.lib.PATCH_DTYPE), np.ascontiguousarray(pool, np.uint8), np.ascontiguousarray(match, np.int32)
+        tracked += int((match >= 0).sum())
+        assert reference.L.ref_adaptor_check_packed_list(f, _p(rec), len(rec), _p(lst), _p(match), _p(pool), len(lst)) == 0, f
