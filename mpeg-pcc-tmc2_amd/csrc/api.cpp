@@ -54,6 +54,10 @@ ApiScope::ApiScope( tmc2_ctx* ctx ) : prev( g_tlsCtx ) {
 ApiScope::~ApiScope() { g_tlsCtx = prev; }
 
 int DevicePool::acquire( size_t bytes, void** out, size_t* got ) {
+  if ( bytes > ( size_t( 1 ) << 40 ) ) {  // 1 TiB: beyond any device; also what a wrapped n * sizeof( T ) looks like
+    setError( "device allocation of %zu bytes refused", bytes );
+    return TMC2_E_INVALID;
+  }
   const size_t cls = sizeClass( bytes );
   {
     std::lock_guard<std::mutex> g( lock );
@@ -363,9 +367,13 @@ int tmc2_frame_reset( tmc2_frame* f ) {
 }
 
 int tmc2_kdtree_search( tmc2_frame* f, const int16_t* queries, uint64_t nq, int k, uint32_t* idx, uint32_t* dist2 ) {
-  if ( !f || !queries || !idx || nq == 0 ) {
+  if ( !f || !queries || !idx || nq == 0 || nq > ( 1ull << 32 ) ) {
     setError( "kdtree_search: invalid argument" );
     return TMC2_E_INVALID;
+  }
+  if ( k != 1 && k != 4 && k != 8 && k != 16 ) {  // (the kernels are instantiated for these; checked before anything is sized by k)
+    setError( "kdtree_search: k = %d unsupported (1, 4, 8 or 16)", k );
+    return TMC2_E_UNSUPPORTED;
   }
   tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( f->ensureTree() );
@@ -479,7 +487,13 @@ int tmc2_frame_set_partition( tmc2_frame* f, const uint32_t* partition ) {
   if ( !f || !partition ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   std::vector<uint8_t> tmp( f->n );
-  for ( uint64_t i = 0; i < f->n; ++i ) tmp[i] = uint8_t( partition[i] );
+  for ( uint64_t i = 0; i < f->n; ++i ) {
+    if ( partition[i] > 5 ) {  // six projection planes: the labels index 6-bin histograms and the orientation table
+      setError( "set_partition: label %u of point %llu out of range (0..5)", partition[i], (unsigned long long)i );
+      return TMC2_E_INVALID;
+    }
+    tmp[i] = uint8_t( partition[i] );
+  }
   TMC2_TRY( f->d_partition.alloc( f->n ) );
   TMC2_HIP( hipMemcpyAsync( f->d_partition.p, tmp.data(), f->n, hipMemcpyHostToDevice, f->ctx->stream ) );
   TMC2_HIP( hipStreamSynchronize( f->ctx->stream ) );

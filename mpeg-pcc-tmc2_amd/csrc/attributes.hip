@@ -93,11 +93,11 @@ __global__ __launch_bounds__( 256 ) void reconTileKernel( const PlaceDev* __rest
   c[p.axB] = v + p.v1;
   c[p.axN] = c0;
   recon[off]        = Pt{int16_t( c[0] ), int16_t( c[1] ), int16_t( c[2] ), 0};
-  pointToPixel[off] = uint32_t( x ) | ( uint32_t( y ) << 12 ) | ( cnt == 2 ? 1u << 25 : 0u );
+  pointToPixel[off] = packPixel( x, y, 0, cnt == 2 );
   if ( cnt == 2 ) {
     c[p.axN]              = c1;
     recon[off + 1]        = Pt{int16_t( c[0] ), int16_t( c[1] ), int16_t( c[2] ), 0};
-    pointToPixel[off + 1] = uint32_t( x ) | ( uint32_t( y ) << 12 ) | ( 1u << 24 );
+    pointToPixel[off + 1] = packPixel( x, y, 1, false );
   }
 }
 
@@ -204,9 +204,9 @@ __global__ __launch_bounds__( 256 ) void attributeScatterKernel( const uint8_t* 
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= m ) return;
   const uint32_t pp = pointToPixel[i];
-  const size_t   px = size_t( ( pp >> 12 ) & 0xFFF ) * W + ( pp & 0xFFF ), plane = size_t( W ) * H;
+  const size_t   px = size_t( pixelY( pp ) ) * W + pixelX( pp ), plane = size_t( W ) * H;
   const uchar4   c  = reinterpret_cast<const uchar4*>( rgb4 )[i];
-  const bool     layer1 = ( pp >> 24 ) & 1, hasD1 = ( pp >> 25 ) & 1;
+  const bool     layer1 = pixelLayer( pp ), hasD1 = pixelHasD1( pp );
   if ( !layer1 ) {
     attr[px] = c.x, attr[plane + px] = c.y, attr[2 * plane + px] = c.z;
     if ( !hasD1 ) attr[3 * plane + px] = c.x, attr[4 * plane + px] = c.y, attr[5 * plane + px] = c.z;
@@ -623,7 +623,7 @@ int tmc2_frame_get_reconstruction( tmc2_frame* f, int16_t* xyz, uint8_t* rgb, ui
     if ( xyz ) xyz[3 * i] = pts[i].x, xyz[3 * i + 1] = pts[i].y, xyz[3 * i + 2] = pts[i].z;
     if ( rgb ) rgb[3 * i] = c4[4 * i], rgb[3 * i + 1] = c4[4 * i + 1], rgb[3 * i + 2] = c4[4 * i + 2];
     if ( pointToPixel )
-      pointToPixel[3 * i] = pp[i] & 0xFFF, pointToPixel[3 * i + 1] = ( pp[i] >> 12 ) & 0xFFF, pointToPixel[3 * i + 2] = ( pp[i] >> 24 ) & 1;
+      pointToPixel[3 * i] = tmc2::pixelX( pp[i] ), pointToPixel[3 * i + 1] = tmc2::pixelY( pp[i] ), pointToPixel[3 * i + 2] = tmc2::pixelLayer( pp[i] );
   }
   return TMC2_OK;
 }

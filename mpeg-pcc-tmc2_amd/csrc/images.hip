@@ -247,8 +247,8 @@ int uploadPlacement( tmc2_frame* f ) {
 // decoded occupancy video and the two decoded geometry maps.  blockToPatch is derived here (S13).
 int createDecoderFrame( tmc2_ctx* ctx, const tmc2_patch* patches, int count, int W, int H, int occPrecision, const uint8_t* occVideo,
                         const uint16_t* geometry, tmc2_frame** out ) {
-  if ( W <= 0 || H <= 0 || W % 16 || H % 16 || occPrecision < 1 || 16 % occPrecision ) {
-    setError( "decoder_frame_create: unsupported geometry %dx%d, precision %d", W, H, occPrecision );
+  if ( W <= 0 || H <= 0 || W % 16 || H % 16 || W > kMaxCanvasDim || H > kMaxCanvasDim || occPrecision < 1 || 16 % occPrecision ) {
+    setError( "decoder_frame_create: unsupported geometry %dx%d (at most %d a side), precision %d", W, H, kMaxCanvasDim, occPrecision );
     return TMC2_E_UNSUPPORTED;
   }
   std::unique_ptr<tmc2_frame> f( new tmc2_frame() );
@@ -259,8 +259,17 @@ int createDecoderFrame( tmc2_ctx* ctx, const tmc2_patch* patches, int count, int
   for ( int k = 0; k < count; ++k ) {
     f->packOrder[size_t( k )] = k;
     const tmc2_patch& t = f->patches[size_t( k )];
-    const int bw = t.patchOrientation == 0 ? t.sizeU0 : t.sizeV0, bh = t.patchOrientation == 0 ? t.sizeV0 : t.sizeU0;
-    if ( t.u0 < 0 || t.v0 < 0 || ( t.u0 + bw ) * 16 > W || ( t.v0 + bh ) * 16 > H ) {
+    // records come from a bitstream: everything the kernels index with is checked here (the axes address a 3-vector)
+    const int axes = ( 1 << t.normalAxis ) | ( 1 << t.tangentAxis ) | ( 1 << t.bitangentAxis );
+    if ( t.normalAxis < 0 || t.normalAxis > 2 || t.tangentAxis < 0 || t.tangentAxis > 2 || t.bitangentAxis < 0 ||
+         t.bitangentAxis > 2 || axes != 7 || t.projectionMode < 0 || t.projectionMode > 1 || t.patchOrientation < 0 ||
+         t.patchOrientation > 1 || t.sizeU0 <= 0 || t.sizeV0 <= 0 ) {
+      setError( "decoder_frame_create: patch %d: axes (%d, %d, %d) / projection mode %d / orientation %d / block size %dx%d invalid",
+                k, t.normalAxis, t.tangentAxis, t.bitangentAxis, t.projectionMode, t.patchOrientation, t.sizeU0, t.sizeV0 );
+      return TMC2_E_INVALID;
+    }
+    const int64_t bw = t.patchOrientation == 0 ? t.sizeU0 : t.sizeV0, bh = t.patchOrientation == 0 ? t.sizeV0 : t.sizeU0;
+    if ( t.u0 < 0 || t.v0 < 0 || ( int64_t( t.u0 ) + bw ) * 16 > W || ( int64_t( t.v0 ) + bh ) * 16 > H ) {
       setError( "decoder_frame_create: patch %d lies outside the %dx%d canvas", k, W, H );
       return TMC2_E_INVALID;
     }
@@ -295,13 +304,15 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
     setError( "generateGeometryImages: frame not packed" );
     return TMC2_E_STATE;
   }
-  if ( occRes != 16 || W % 16 || H % 16 || occPrecision < 1 || 16 % occPrecision ) {
-    setError( "generateGeometryImages: unsupported geometry %dx%d, occupancyResolution %d, precision %d", W, H, occRes,
-              occPrecision );
+  if ( occRes != 16 || W <= 0 || H <= 0 || W % 16 || H % 16 || W > kMaxCanvasDim || H > kMaxCanvasDim || occPrecision < 1 ||
+       16 % occPrecision ) {
+    setError( "generateGeometryImages: unsupported geometry %dx%d (at most %d a side), occupancyResolution %d, precision %d", W, H,
+              kMaxCanvasDim, occRes, occPrecision );
     return TMC2_E_UNSUPPORTED;
   }
   // new canvases: whatever was derived from the old ones is stale
-  f->haveGeometryImages = f->haveAttributeImages = f->haveReconstruction = false;
+  f->haveGeometryImages = false;
+  invalidateReconstruction( f );
   tmc2_ctx*   ctx = f->ctx;
   hipStream_t s   = ctx->stream;
   const int   P   = int( f->patches.size() );
@@ -381,7 +392,15 @@ int tmc2_frame_set_decoded_geometry( tmc2_frame* f, const uint8_t* occVideo, con
     TMC2_HIP( hipMemcpyAsync( f->d_occVideo.p, occVideo, area / ( size_t( f->occPrecision ) * f->occPrecision ),
                               hipMemcpyHostToDevice, s ) );
   if ( geometry ) TMC2_HIP( hipMemcpyAsync( f->d_geo.p, geometry, 2 * area * sizeof( uint16_t ), hipMemcpyHostToDevice, s ) );
+  if ( occVideo ) {  // block ownership derives from the DECODED occupancy video (PCCEncoder.cpp:168, PCCCodec.cpp:1736-1775)
+    const int Wb = f->canvasW / 16, Hb = f->canvasH / 16;
+    hipLaunchKernelGGL( tmc2::blockToPatchKernel, dim3( ( Wb * Hb + 255 ) / 256 ), dim3( 256 ), 0, s, f->d_place.p,
+                        int( f->patches.size() ), f->d_occVideo.p, Wb, Hb, f->canvasW / f->occPrecision, f->occPrecision,
+                        f->d_blockToPatch.p );
+  }
+  tmc2::invalidateReconstruction( f );  // whatever was reconstructed from the previous canvases is stale
   TMC2_HIP( hipStreamSynchronize( s ) );
+  TMC2_HIP( hipGetLastError() );
   return TMC2_OK;
 }
 

@@ -80,6 +80,10 @@ struct DevBuf {
     if ( pl ) {
       void*  q   = nullptr;
       size_t got = 0;
+      if ( n > ( size_t( 1 ) << 40 ) / sizeof( T ) ) {
+        setError( "device allocation of %zu elements refused", n );
+        return TMC2_E_INVALID;
+      }
       TMC2_TRY( pl->acquire( n * sizeof( T ), &q, &got ) );
       p     = reinterpret_cast<T*>( q );
       cls   = got;
@@ -117,6 +121,17 @@ struct KdTreeHost {
   void                  buildInPlace( Pt* pts, uint32_t* ind, size_t n );   // caller-owned storage; perm / ptsTree stay empty
 };
 
+
+// pointToPixel of a reconstructed point in one word: canvas x, y (15 bits each: canvases up to kMaxCanvasDim pixels a side,
+// enforced where a canvas size enters -- generateGeometryImages, the decoder frame), map layer, "a D1 point follows"
+constexpr int kMaxCanvasDim = 32767;
+__host__ __device__ __forceinline__ uint32_t packPixel( int x, int y, int layer, bool hasD1 ) {
+  return uint32_t( x ) | ( uint32_t( y ) << 15 ) | ( uint32_t( layer ) << 30 ) | ( hasD1 ? 1u << 31 : 0u );
+}
+__host__ __device__ __forceinline__ uint32_t pixelX( uint32_t p ) { return p & 0x7FFFu; }
+__host__ __device__ __forceinline__ uint32_t pixelY( uint32_t p ) { return ( p >> 15 ) & 0x7FFFu; }
+__host__ __device__ __forceinline__ uint32_t pixelLayer( uint32_t p ) { return ( p >> 30 ) & 1u; }
+__host__ __device__ __forceinline__ bool     pixelHasD1( uint32_t p ) { return ( p >> 31 ) != 0u; }
 
 // placement + projection of one patch on the device, in packing order (shared by the image kernels)
 struct PlaceDev {
@@ -249,7 +264,7 @@ struct tmc2_frame {
   uint64_t                reconCount = 0;
   bool                    haveAttributeImages = false, haveReconstruction = false;
   tmc2::DevBuf<tmc2::Pt>  d_recon;              // reconstructed points (generatePointCloud order)
-  tmc2::DevBuf<uint32_t>  d_pointToPixel;       // x | y << 12 | layer << 24 | hasD1 << 25
+  tmc2::DevBuf<uint32_t>  d_pointToPixel;       // tmc2::packPixel: x | y << 15 | layer << 30 | hasD1 << 31
   tmc2::DevBuf<uint8_t>   d_reconRgb;           // [M][4]
   tmc2::DevBuf<uint8_t>   d_attr;               // [2 maps][3 channels][H][W]
   // post-reconstruction tail (post_reconstruct.hip): per reconstructed point
@@ -292,6 +307,10 @@ int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint
 TreeDev frameTree( const tmc2_frame* f );
 int generateAttributeImages( tmc2_frame* f );
 int reconstructPointCloud( tmc2_frame* f );
+inline void invalidateReconstruction( tmc2_frame* f ) {  // new or replaced canvases: everything derived from them is stale
+  f->haveAttributeImages = f->haveReconstruction = false;
+  f->haveBoundaryTypes = f->haveColors16 = f->haveSmoothed = f->haveRgbPost = false;
+}
 int uploadPlacement( tmc2_frame* f );
 int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );

@@ -32,9 +32,9 @@ namespace tmc2 {
 namespace {
 
 __device__ __forceinline__ void unpackPixel( uint32_t p, int& x, int& y, int& layer ) {
-  x     = int( p & 0xFFFu );
-  y     = int( ( p >> 12 ) & 0xFFFu );
-  layer = int( ( p >> 24 ) & 1u );
+  x     = int( pixelX( p ) );
+  y     = int( pixelY( p ) );
+  layer = int( pixelLayer( p ) );
 }
 
 // ---- T1 ---------------------------------------------------------------------------------------------------

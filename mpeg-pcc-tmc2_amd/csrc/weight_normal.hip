@@ -42,7 +42,7 @@ __global__ __launch_bounds__( 256 ) void popcountKernel( const uint32_t* __restr
 }  // namespace
 
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] ) {
-  if ( bits < 1 || bits > 13 ) {
+  if ( bits < 3 || bits > 13 ) {  // (the bit planes are addressed by whole 32-bit words)
     setError( "weightNormal: geometryBitDepth3D=%d out of range", bits );
     return TMC2_E_INVALID;
   }

@@ -44,6 +44,15 @@ class Sharder:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
+    def sum_count(self, local_count):
+        """Frames of the whole GOF = sum over the ranks of the frames each holds."""
+        if self.world == 1:
+            return int(local_count)
+        import torch
+        t = torch.tensor([int(local_count)], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
     def gather(self, tensor):
         """Gather equally-shaped tensors to rank 0; returns the list on rank 0, None elsewhere."""
         if self.world == 1:
@@ -67,13 +76,16 @@ class Sharder:
         self.dist.gather_object(local_records, gathered, dst=0)
         box = [None]
         if self.rank == 0:
-            records = [None] * frame_count
-            for r, recs in enumerate(gathered):
-                for k, f in enumerate(self.frames_of(frame_count, r)):
-                    records[f] = recs[k]
-            try:
+            try:                                             # whatever goes wrong here, every rank must leave the
+                records = [None] * frame_count               # broadcast below, and with the same error
+                for r, recs in enumerate(gathered):
+                    mine = self.frames_of(frame_count, r)
+                    if len(recs) != len(mine):
+                        raise ValueError("rank %d sent %d frames, the GOF of %d frames gives it %d" % (r, len(recs), frame_count, len(mine)))
+                    for k, f in enumerate(mine):
+                        records[f] = recs[k]
                 box[0] = lib.host_pack_gof_records(records, mode, min_w, min_h, tiles_hor, ratio)
-            except lib.Tmc2Error as e:                       # every rank must leave the collective, with the same error
+            except Exception as e:
                 box[0] = e
         self.dist.broadcast_object_list(box, src=0)
         if isinstance(box[0], Exception):
@@ -229,9 +241,11 @@ class GofEncoder:
             return fr.encoder_pack_flexible(self.min_w, 2, 1.0)
         if constrained_pack:
             self._per_worker(frames, lambda fr: fr.segmenter_compute(params))
-            heights = [frames[0].encoder_pack_flexible(self.min_w, 2, 1.0)]
-            for prev, fr in zip(frames[:-1], frames[1:]):
-                heights.append(fr.encoder_pack_spatial_consistency(prev, self.min_w, 2, 1.0))
+            # the chain is sequential over the GOF; each call still runs on the worker thread that owns the frame's context
+            heights = self._dispatch([(0, lambda: frames[0].encoder_pack_flexible(self.min_w, 2, 1.0))])
+            for i in range(1, len(frames)):
+                heights += self._dispatch([(i % self.workers, lambda i=i: frames[i].encoder_pack_spatial_consistency(
+                    frames[i - 1], self.min_w, 2, 1.0))])
             if constrained_pack == 2:
                 widths, heights = lib.encoder_global_patch_allocation(frames, self.min_w, self.min_h)
                 W, H = lib.encoder_canvas_size([max(int(max(heights)), self.min_h)], max(int(max(widths)), self.min_w),
@@ -248,7 +262,8 @@ class GofEncoder:
         return W, H
 
     def _phase_a_sharded_chain(self, frames, sharder, weight, mode, frame_count):
-        frame_count = len(frames) * sharder.world if frame_count is None else frame_count
+        if frame_count is None:                              # (uneven shards: the ranks need not hold equally many frames)
+            frame_count = sharder.sum_count(len(frames))
         if weight is None:
             w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
             weight = sharder.broadcast_weight(w)

@@ -1,15 +1,11 @@
-"""GPU tier, opt-in (TMC2_GPU_FUZZ=1): the HIP path against the oracle on the degenerate clouds and random patch sets the CPU
-tier fuzzes the oracle with (planes, lines, lattices, dust, duplicate-heavy blobs).  Written at the end of round 1 after the
-GPU budget was spent -- NOT yet run on a device, hence not part of the default `-m gpu` run; the first thing to run next."""
-import os
-
+"""GPU tier: the HIP path against the oracle on the degenerate clouds and random patch sets the CPU tier fuzzes the
+oracle with (planes, lines, lattices, dust, duplicate-heavy blobs).  Part of the default `-m gpu` run."""
 import numpy as np
 import pytest
 
 import tmc2_amd as T
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("TMC2_GPU_FUZZ") != "1", reason="opt-in: TMC2_GPU_FUZZ=1 (not yet validated on a GPU)")]
+pytestmark = [pytest.mark.gpu]
 
 
 def bits(a):

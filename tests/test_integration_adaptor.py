@@ -68,7 +68,6 @@ def test_adaptor_rebuilds_the_reference_frame_containers(oracle, reference, name
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("TMC2_ADAPTOR_GPU_TEST") != "1", reason="opt-in (TMC2_ADAPTOR_GPU_TEST=1): not yet run on a GPU")
 def test_adaptor_segmenter_compute_is_a_drop_in(adaptor):
     """On an MI355X: tmc2hip::segmenterCompute (flatten -> C-ABI -> PCCPatch list) against the reference's own
     PCCPatchSegmenter3::compute on the same PCCPointSet3."""
