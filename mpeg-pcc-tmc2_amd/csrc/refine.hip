@@ -155,7 +155,7 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
                                                                double lambda, uint32_t* __restrict__ rowLen,
                                                                uint32_t* __restrict__ devLen, double* __restrict__ weight,
                                                                uint32_t stride, uint32_t* __restrict__ adjOff,
-                                                               uint32_t* __restrict__ adj ) {
+                                                               uint32_t* __restrict__ adj, uint32_t* __restrict__ totalLen ) {
   __shared__ uint32_t keysAll[4][kMaxBall];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t      v    = blockIdx.x * 4 + wave;
@@ -235,6 +235,7 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
   if ( lane == 0 ) {
     rowLen[v] = uint32_t( used );
     adjOff[v] = v * stride;
+    atomicAdd( totalLen, uint32_t( used ) );  // (size of the reverse rows)
     weight[v] = __ddiv_rn( lambda, double( nn ) );
     int dev   = 0;  // DEV candidates (Chebyshev <= 1) are exactly the entries with d2 <= 3: a prefix of the row
     while ( dev < used && ( keys[dev] >> 26 ) <= 3u ) ++dev;
@@ -551,6 +552,351 @@ __global__ __launch_bounds__( 256 ) void rescoreVoxelsKernel( const uint8_t* __r
   }
 }
 
+
+// ======================================================================================================================
+// Event-driven sweeps (the default path).  What the sweeps above recompute for every voxel every sweep is maintained
+// incrementally here, bit-exactly:
+//   * S[v] (the smoothed histogram) only changes when the histogram of a voxel in v's neighbourhood changes.  A voxel
+//     whose points moved PUSHES the difference to the voxels that list it (reverse neighbourhood rows, built once):
+//     integer adds, so the order is irrelevant.  Late sweeps change a few dozen histograms, not 70 K rows of 88 gathers.
+//     S is double-buffered: a sweep reads rec[cur] and pushes into rec[nxt], which the sweep's first kernel prepared as a
+//     copy of rec[cur] -- nobody reads a record that is being pushed into.
+//   * re-scoring a voxel is a pure function of S[v] (normals and weight are static): a voxel whose S has not changed
+//     since it was last re-scored keeps its labels, so only its edge class / ppi are refreshed (epochs, below).
+//   * the INDIRECT-edge closure (the one sequential coupling of a sweep): everything about it that is not sequential is
+//     done chip-wide first (closurePrepareKernel: every voxel's list of DEV neighbours it would mark, the marks of the
+//     voxels active at sweep start); the dependent rest runs in ONE workgroup with the active / frontier / marked
+//     bitmaps in LDS (closureLevelsKernel): a level of the chain costs one 16-byte load per frontier voxel, one voxel per
+//     thread, and the kernel hands the last one a compact work list (active + marked voxels).
+// Three launches per sweep: closurePrepareKernel (chip-wide), closureLevelsKernel (1 workgroup), sweepKernel (chip-wide
+// over the work list).
+//
+// rec[v] = { s0, s1, s2 : S[v] as packed u16 pairs (like hist), lastChange : id of the first S-state that holds the
+// current value }.  S-state t + 1 is what sweep t reads.  lastRescore[v] = id of the S-state v's labels were computed
+// from (0: never).  A voxel processed in sweep t is re-scored iff lastChange > lastRescore; pushes of sweep t stamp
+// lastChange = t + 2 (in the copy the next sweep reads).
+constexpr uint32_t kWorkActive = 0x80000000u;
+
+__global__ __launch_bounds__( 256 ) void smoothInitKernel( const uint4* __restrict__ hist, const uint32_t* __restrict__ adjOff,
+                                                            const uint32_t* __restrict__ rowLen,
+                                                            const uint32_t* __restrict__ adj, uint32_t V,
+                                                            uint4* __restrict__ rec ) {
+  const int      lane = threadIdx.x & 15;
+  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  if ( v >= V ) return;
+  const uint32_t* row = adj + adjOff[v];
+  const uint32_t  len = rowLen[v];
+  uint32_t        s0 = 0, s1 = 0, s2 = 0;
+  for ( uint32_t i = lane; i < len; i += 16 ) {
+    const uint4 h = hist[row[i]];
+    s0 += h.x;
+    s1 += h.y;
+    s2 += h.z;
+  }
+#pragma unroll
+  for ( int off = 8; off > 0; off >>= 1 ) {
+    s0 += __shfl_xor( s0, off, 64 );
+    s1 += __shfl_xor( s1, off, 64 );
+    s2 += __shfl_xor( s2, off, 64 );
+  }
+  if ( lane == 0 ) rec[v] = make_uint4( s0, s1, s2, 1u );
+}
+
+// reverse neighbourhood rows: radj[roff[u] ..] = the voxels v whose (truncated) row lists u
+__global__ __launch_bounds__( 256 ) void reverseCountKernel( const uint32_t* __restrict__ adjOff, const uint32_t* __restrict__ rowLen,
+                                                              const uint32_t* __restrict__ adj, uint32_t V,
+                                                              uint32_t* __restrict__ rcount ) {
+  const int      lane = threadIdx.x & 15;
+  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  if ( v >= V ) return;
+  const uint32_t* row = adj + adjOff[v];
+  const uint32_t  len = rowLen[v];
+  for ( uint32_t i = lane; i < len; i += 16 ) atomicAdd( &rcount[row[i]], 1u );
+}
+
+__global__ __launch_bounds__( 256 ) void reverseFillKernel( const uint32_t* __restrict__ adjOff, const uint32_t* __restrict__ rowLen,
+                                                             const uint32_t* __restrict__ adj, uint32_t V,
+                                                             const uint32_t* __restrict__ roff, uint32_t* __restrict__ cursor,
+                                                             uint32_t* __restrict__ radj ) {
+  const int      lane = threadIdx.x & 15;
+  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  if ( v >= V ) return;
+  const uint32_t* row = adj + adjOff[v];
+  const uint32_t  len = rowLen[v];
+  for ( uint32_t i = lane; i < len; i += 16 ) {
+    const uint32_t u                          = row[i];
+    radj[roff[u] + atomicAdd( &cursor[u], 1u )] = v;
+  }
+}
+
+__device__ __forceinline__ int argOfPacked( uint32_t s0, uint32_t s1, uint32_t s2 ) {
+  uint32_t b[6];
+  unpackHist( make_uint4( s0, s1, s2, 0 ), b );
+  int nz, a;
+  classify( b, nz, a );
+  return a;
+}
+
+// Chip-wide first step of a sweep, 32 lanes per voxel u (its DEV row, padded):
+//   out[u] = { count, the DEV neighbours u marks if it is active: NO_EDGE voxels whose ppi differs from arg(S[u]) };
+//   rec[nxt][u] = rec[cur][u]  (the copy this sweep's pushes go into);
+//   u active at sweep start: its bit in the active bitmap, its marks, and the larger-index voxels it activates (frontier).
+__global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
+                                                                const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
+                                                                const uint32_t* __restrict__ dev, uint32_t V,
+                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ gAct,
+                                                                uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
+  const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
+  const uint32_t lane = threadIdx.x & 31;
+  const int      half = ( threadIdx.x >> 5 ) & 1;
+  if ( u >= V ) return;
+  const uint4    r    = recCur[u];
+  const uint32_t v    = dev[size_t( u ) * 32 + lane];
+  const uint8_t  a    = uint8_t( argOfPacked( r.x, r.y, r.z ) );
+  const bool     pred = v != kDevPad && edge[v] == NO_EDGE && ppi[v] != a;
+  const uint32_t m    = uint32_t( __ballot( pred ) >> ( 32 * half ) );
+  if ( pred ) out[size_t( u ) * 32 + 1 + __popc( m & ( ( 1u << lane ) - 1u ) )] = v;
+  if ( lane == 0 ) {
+    out[size_t( u ) * 32] = uint32_t( __popc( m ) );
+    recNxt[u]             = r;
+  }
+  if ( edge[u] == NO_EDGE ) return;
+  if ( lane == 0 ) atomicOr( &gAct[u >> 5], 1u << ( u & 31 ) );
+  if ( pred ) {
+    atomicOr( &gMk[v >> 5], 1u << ( v & 31 ) );
+    if ( v > u ) {  // (v is a NO_EDGE voxel: only marks activate it, so "activated" and "frontier" coincide here)
+      atomicOr( &gAct[v >> 5], 1u << ( v & 31 ) );
+      atomicOr( &gFr[v >> 5], 1u << ( v & 31 ) );
+    }
+  }
+}
+
+// Wave-level compaction of a bitmap into a voxel list (whole 64-word chunks; a chunk that does not fit stays for the next
+// round and records where the complete part of the list ends: offsets are handed out in order, so everything below the
+// first failure is complete).  The caller zeroes *count, sets *valid = ~0 and synchronises before; returns the length.
+__device__ __forceinline__ uint32_t compactBitmap( uint32_t* __restrict__ bm, uint32_t W, uint32_t* __restrict__ list,
+                                                   uint32_t cap, uint32_t* count, uint32_t* valid ) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  for ( uint32_t chunk = wave; chunk * 64 < W; chunk += waves ) {
+    const uint32_t w    = chunk * 64 + lane;
+    uint32_t       bits = w < W ? bm[w] : 0u;
+    if ( !__ballot( bits != 0 ) ) continue;  // (most chunks of a late level are empty)
+    const uint32_t cnt = uint32_t( __popc( bits ) );
+    uint32_t       inc = cnt;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += t;
+    }
+    const uint32_t total = __shfl( inc, 63, 64 );
+    uint32_t       base  = 0;
+    if ( lane == 0 ) base = atomicAdd( count, total );
+    base = __shfl( base, 0, 64 );
+    if ( base + total <= cap ) {
+      if ( bits ) {
+        bm[w]        = 0;
+        uint32_t off = base + inc - cnt;
+        while ( bits ) {
+          list[off++] = 32 * w + uint32_t( __ffs( int( bits ) ) - 1 );
+          bits &= bits - 1;
+        }
+      }
+    } else if ( lane == 0 ) {
+      atomicMin( valid, base );
+    }
+  }
+  __syncthreads();
+  return min( *count, *valid );
+}
+
+// The dependent rest of the closure, one workgroup.  LDS: active | frontier | marked | scratch bitmaps (V bits each), list.
+// Hands the global bitmaps back empty, writes the work list of sweepKernel: every active voxel, then the voxels that were
+// only marked.
+__global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* __restrict__ out, uint32_t V, uint32_t listCap,
+                                                              uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr,
+                                                              uint32_t* __restrict__ gMk, uint32_t* __restrict__ work,
+                                                              uint32_t* __restrict__ workCount,
+                                                              unsigned long long* __restrict__ timing ) {
+  extern __shared__ uint32_t lds[];
+  // (test hook: timing[0..3] += ticks of load / compaction / voxel processing / list emission, [4] += rounds, [5] += voxels)
+  unsigned long long tick = timing ? wall_clock64() : 0ull, tLoad = 0, tCompact = 0, tProcess = 0, tEmit = 0, rounds = 0;
+#define TMC2_LAP( acc )                              \
+  if ( timing && threadIdx.x == 0 ) {                \
+    const unsigned long long now_ = wall_clock64();  \
+    acc += now_ - tick;                              \
+    tick = now_;                                     \
+  }
+  __shared__ uint32_t nList, nValid;
+  const uint32_t      W   = ( V + 31 ) / 32;
+  uint32_t *          act = lds, *fr = act + W, *mk = fr + W, *tmp = mk + W, *list = tmp + W;
+  for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
+    const uint32_t a = gAct[w], f = gFr[w], m = gMk[w];
+    act[w] = a, fr[w] = f, mk[w] = m, tmp[w] = a;
+    if ( a ) gAct[w] = 0;
+    if ( f ) gFr[w] = 0;
+    if ( m ) gMk[w] = 0;
+  }
+  uint32_t nWork = 0;  // (uniform: every thread keeps the same count)
+  // phase 0: list what is active already (active at sweep start, or activated by such a voxel);
+  // phase 1: the closure, level by level, listing what each level activates;  phase 2: the voxels that were only marked
+  for ( int phase = 0; phase < 3; ++phase ) {
+    bool first = true;
+    while ( true ) {
+      if ( threadIdx.x == 0 ) {
+        nList  = 0;
+        nValid = 0xFFFFFFFFu;
+      }
+      __syncthreads();
+      if ( phase == 0 && first ) { TMC2_LAP( tLoad ) }
+      const uint32_t n     = compactBitmap( phase == 0 ? tmp : ( phase == 1 ? fr : mk ), W, list, listCap, &nList, &nValid );
+      const bool     empty = nList == 0;
+      __syncthreads();  // (nList is reset at the top of the next round)
+      if ( phase == 1 ) { TMC2_LAP( tCompact ) } else { TMC2_LAP( tEmit ) }
+      if ( empty ) break;
+      // (the first frontier is part of what phase 0 listed; later ones are new)
+      if ( phase != 1 || !first ) {
+        for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) work[nWork + i] = list[i] | ( phase == 2 ? 0u : kWorkActive );
+        nWork += n;
+      }
+      first = false;
+      if ( phase != 1 ) continue;
+      ++rounds;
+      for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) {  // one voxel per thread: one 16-byte load per hop
+        const uint32_t  u    = list[i];
+        const uint32_t* row  = out + size_t( u ) * 32;
+        const uint4     head = reinterpret_cast<const uint4*>( row )[0];  // count + the first seven targets: one round
+        const uint4     more = reinterpret_cast<const uint4*>( row )[1];  // trip for all but the rarest voxels
+        for ( uint32_t k = 0; k < head.x; ++k ) {
+          const uint32_t v   = k == 0   ? head.y
+                               : k == 1 ? head.z
+                               : k == 2 ? head.w
+                               : k == 3 ? more.x
+                               : k == 4 ? more.y
+                               : k == 5 ? more.z
+                               : k == 6 ? more.w
+                                        : row[1 + k];
+          const uint32_t bit = 1u << ( v & 31 );
+          atomicOr( &mk[v >> 5], bit );
+          if ( v > u && !( atomicOr( &act[v >> 5], bit ) & bit ) ) atomicOr( &fr[v >> 5], bit );
+        }
+      }
+      __syncthreads();
+      TMC2_LAP( tProcess )
+    }
+    if ( phase == 1 ) {  // what is left to list: marked, but never active
+      for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) mk[w] &= ~act[w];
+    }
+  }
+  if ( threadIdx.x == 0 ) *workCount = nWork;
+  TMC2_LAP( tEmit )
+  if ( timing && threadIdx.x == 0 ) {
+    timing[0] += tLoad, timing[1] += tCompact, timing[2] += tProcess, timing[3] += tEmit, timing[4] += rounds, timing[5] += nWork;
+  }
+#undef TMC2_LAP
+}
+
+// The rest of a sweep for the voxels of the work list, 16 lanes each: decide, re-score if S changed since the labels were
+// computed, push the histogram difference to the reverse row, refresh edge class / ppi.
+__global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict__ work, const uint32_t* __restrict__ workCount,
+                                                       const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
+                                                       uint32_t* __restrict__ lastRescore, const double* __restrict__ weight,
+                                                       const uint32_t* __restrict__ pointStart,
+                                                       const uint32_t* __restrict__ pointList,
+                                                       const double* __restrict__ normals, const uint32_t* __restrict__ roff,
+                                                       const uint32_t* __restrict__ radj, uint8_t* __restrict__ edge,
+                                                       uint8_t* __restrict__ ppi, uint4* __restrict__ hist,
+                                                       uint8_t* __restrict__ partition, uint32_t* __restrict__ flags, int iter ) {
+  const int      sub    = threadIdx.x & 15;
+  const uint32_t groups = gridDim.x * 16, count = *workCount;
+  for ( uint32_t idx = blockIdx.x * 16 + ( threadIdx.x >> 4 ); idx < count; idx += groups ) {  // (uniform over the 16 lanes)
+    const uint32_t entry = work[idx], v = entry & ~kWorkActive;
+    const uint8_t  e0 = edge[v];
+    bool           p  = false;
+    uint32_t       b[6];
+    uint4          s  = make_uint4( 0, 0, 0, 0 );
+    if ( entry & kWorkActive ) {
+      s = recCur[v];
+      unpackHist( s, b );
+      p = true;
+      if ( ( e0 != NO_EDGE ? e0 : uint8_t( INDIRECT_EDGE ) ) != M_DIRECT_EDGE ) {
+        int nz, a;
+        classify( b, nz, a );
+        if ( nz == 1 && b[ppi[v]] > 0 ) p = false;
+      }
+    }
+    if ( !p ) {  // marked (every voxel of the list that was NO_EDGE at sweep start is) and not re-scored: INDIRECT from now on
+      if ( sub == 0 && e0 == NO_EDGE ) edge[v] = INDIRECT_EDGE;
+      continue;
+    }
+    uint4 h = hist[v];
+    if ( s.w > lastRescore[v] ) {
+      const double   w     = weight[v];
+      const uint32_t begin = pointStart[v], end = pointStart[v + 1];
+      uint32_t       h0 = 0, h1 = 0, h2 = 0, moved = 0;
+      for ( uint32_t q = begin + sub; q < end; q += 16 ) {
+        const uint32_t j  = pointList[q];
+        const double   nx = normals[3 * size_t( j )], ny = normals[3 * size_t( j ) + 1], nz = normals[3 * size_t( j ) + 2];
+        const double d[6] = {nx * 1.0 + ny * 0.0 + nz * 0.0,  nx * 0.0 + ny * 1.0 + nz * 0.0,
+                             nx * 0.0 + ny * 0.0 + nz * 1.0,  nx * -1.0 + ny * 0.0 + nz * 0.0,
+                             nx * 0.0 + ny * -1.0 + nz * 0.0, nx * 0.0 + ny * 0.0 + nz * -1.0};
+        int    best = 0;
+        double bs   = d[0] + w * double( b[0] );
+#pragma unroll
+        for ( int k = 1; k < 6; ++k ) {
+          const double sc = d[k] + w * double( b[k] );
+          if ( sc > bs ) {
+            bs   = sc;
+            best = k;
+          }
+        }
+        if ( partition[j] != uint8_t( best ) ) {
+          partition[j] = uint8_t( best );
+          ++moved;
+        }
+        const uint32_t one = 1u << ( 16 * ( best & 1 ) );
+        h0 += ( best >> 1 ) == 0 ? one : 0u;
+        h1 += ( best >> 1 ) == 1 ? one : 0u;
+        h2 += ( best >> 1 ) == 2 ? one : 0u;
+      }
+#pragma unroll
+      for ( int off = 8; off > 0; off >>= 1 ) {
+        h0 += __shfl_xor( h0, off, 64 );
+        h1 += __shfl_xor( h1, off, 64 );
+        h2 += __shfl_xor( h2, off, 64 );
+        moved += __shfl_xor( moved, off, 64 );
+      }
+      if ( sub == 0 ) lastRescore[v] = uint32_t( iter ) + 1u;
+      if ( moved ) {  // (a changed histogram needs a moved point)
+        // packed u16 pairs: the difference is added modulo 2^32 per word; every true field stays within 0 .. 65535, so
+        // borrows between the halves cancel in the final sums whatever the order of the adds
+        const uint32_t d0 = h0 - h.x, d1 = h1 - h.y, d2 = h2 - h.z;
+        if ( d0 | d1 | d2 ) {
+          const uint32_t rb = roff[v], re = roff[v + 1];
+          for ( uint32_t t = rb + sub; t < re; t += 16 ) {
+            uint32_t* tr = reinterpret_cast<uint32_t*>( recNxt + radj[t] );
+            if ( d0 ) atomicAdd( tr, d0 );
+            if ( d1 ) atomicAdd( tr + 1, d1 );
+            if ( d2 ) atomicAdd( tr + 2, d2 );
+            tr[3] = uint32_t( iter ) + 2u;
+          }
+        }
+        h = make_uint4( h0, h1, h2, 0 );
+        if ( sub == 0 ) {
+          hist[v] = h;
+          atomicAdd( &flags[2 * iter + 1], moved );  // (feeds the trace hook)
+        }
+      }
+    }
+    if ( sub == 0 ) {  // the voxel was processed: edge class and ppi follow its (new) histogram
+      unpackHist( h, b );
+      int nz, a;
+      classify( b, nz, a );
+      if ( e0 != S_DIRECT_EDGE ) edge[v] = ( nz == 1 ) ? uint8_t( NO_EDGE ) : uint8_t( M_DIRECT_EDGE );
+      ppi[v] = uint8_t( a );
+    }
+  }
+}
+
 }  // namespace
 
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
@@ -630,16 +976,17 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   TMC2_TRY( d_hist.alloc( size_t( V ) * 4 ) );
   TMC2_TRY( d_centre.alloc( V ) );
   TMC2_TRY( d_weight.alloc( V ) );
-  TMC2_TRY( d_state.alloc( size_t( V ) * 6 ) );
+  const size_t Vp = ( size_t( V ) + 63 ) & ~size_t( 63 );  // sub-arrays of the state block: whole, aligned 32-voxel words
+  TMC2_TRY( d_state.alloc( Vp * 6 ) );
   TMC2_TRY( d_activeBuf.alloc( V ) );
   TMC2_TRY( d_offsets.alloc( offsets.size() ) );
   TMC2_TRY( d_S.alloc( V ) );
-  uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + V, *d_arg = d_state.p + 2 * size_t( V ),
-          *d_marked = d_state.p + 4 * size_t( V ), *d_proc = d_state.p + 5 * size_t( V );
+  uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + Vp, *d_arg = d_state.p + 2 * Vp, *d_marked = d_state.p + 4 * Vp,
+          *d_proc = d_state.p + 5 * Vp;
   uint32_t* d_active = d_activeBuf.p;
   TMC2_HIP( hipMemsetAsync( d_count.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
   TMC2_HIP( hipMemsetAsync( d_hist.p, 0, size_t( V ) * 16, s ) );
-  TMC2_HIP( hipMemsetAsync( d_state.p, 0, size_t( V ) * 6, s ) );
+  TMC2_HIP( hipMemsetAsync( d_state.p, 0, Vp * 6, s ) );
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
@@ -665,23 +1012,108 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   }
   DevBuf<uint32_t> d_adj;
   TMC2_TRY( d_adj.alloc( size_t( V ) * stride ) );
+  TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 4, s ) );
   hipLaunchKernelGGL( neighbourhoodKernel, grdW, blk, 0, s, d_centre.p, d_count.p, table, g, V, d_offsets.p,
                       int( offsets.size() ), maxNNCount, lambda, d_rowLen.p, d_devLen.p, d_weight.p, stride, d_adjOff.p,
-                      d_adj.p );
+                      d_adj.p, d_small.p + 1 );
   hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
+  const uint32_t W = ( V + 31 ) / 32;
+  DevBuf<uint32_t> d_dev;
+  TMC2_TRY( d_dev.alloc( size_t( V ) * 32 ) );
+  const dim3 grdV32( ( V + 7 ) / 8 );
+  hipLaunchKernelGGL( devTableKernel, grdV32, blk, 0, s, d_adjOff.p, d_devLen.p, d_adj.p, V, d_dev.p );
+  // Which sweep loop: the event-driven one needs the closure's four bitmaps and a voxel list in the LDS of one workgroup
+  // (160 KB: up to ~ 290 K voxels; a vox11 frame has ~ 240 K).  Larger grids take the sweep-everything loop.
+  // (test hook TMC2_REFINE_SWEEPS=full forces that one)
+  const char*  sweepsEnv   = getenv( "TMC2_REFINE_SWEEPS" );
+  const size_t ldsRoom     = 160 * 1024 - 64;  // gfx950: 160 KB of LDS per workgroup (opt-in above 64 KB); static part: 8 bytes
+  const size_t ldsFixed    = 16 * size_t( W );
+  const bool   eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
+  if ( eventDriven ) {
+    uint32_t totalLen = 0;
+    TMC2_HIP( hipMemcpyAsync( &totalLen, d_small.p + 1, 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
+    DevBuf<uint32_t> d_roff, d_rcursor, d_radj, d_lastRescore, d_work, d_flags, d_out, d_gbits;
+    DevBuf<uint4>    d_rec;
+    TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
+    TMC2_TRY( d_rcursor.alloc( size_t( V ) + 1 ) );
+    TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
+    TMC2_TRY( d_lastRescore.alloc( V ) );
+    TMC2_TRY( d_work.alloc( size_t( V ) + 1 ) );  // [V]: the list's length
+    TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
+    TMC2_TRY( d_out.alloc( size_t( V ) * 32 ) );
+    TMC2_TRY( d_gbits.alloc( 3 * size_t( W ) ) );
+    TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
+    TMC2_HIP( hipMemsetAsync( d_rcursor.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
+    hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcursor.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_rcursor.p, d_roff.p, size_t( V ) + 1, nullptr ) );
+    TMC2_HIP( hipMemsetAsync( d_rcursor.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
+    hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
+                        d_radj.p );
+    hipLaunchKernelGGL( smoothInitKernel, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+                        d_rowLen.p, d_adj.p, V, d_rec.p );
+    TMC2_HIP( hipMemsetAsync( d_lastRescore.p, 0, size_t( V ) * 4, s ) );
+    TMC2_HIP( hipMemsetAsync( d_gbits.p, 0, 3 * size_t( W ) * 4, s ) );
+    TMC2_HIP( hipMemsetAsync( d_flags.p, 0, ( 2 * size_t( iterationCount ) + 2 ) * 4, s ) );
+    ctx->stageEnd( sidSetup );
+    TMC2_HIP( hipGetLastError() );
+    const int      sidSweep = ctx->stageBegin( "refine_sweeps" );
+    const uint32_t listCap  = uint32_t( std::min<size_t>( 8192, ( ldsRoom - ldsFixed ) / 4 ) );
+    const size_t   ldsBytes = ldsFixed + 4 * size_t( listCap );
+    if ( ldsBytes > 48 * 1024 )
+      TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureLevelsKernel ),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, int( ldsBytes ) ) );
+    const dim3 grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, size_t( 2 ) * ctx->cuCount ) ) );
+    DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure's tail spends its time
+    const bool                 wantTiming = getenv( "TMC2_REFINE_TIMING" ) != nullptr;
+    if ( wantTiming ) {
+      TMC2_TRY( d_timing.alloc( 8 ) );
+      TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64, s ) );
+    }
+    uint32_t *gAct = d_gbits.p, *gFr = d_gbits.p + W, *gMk = d_gbits.p + 2 * size_t( W );
+    for ( int iter = 0; iter < iterationCount; ++iter ) {
+      uint4 *recCur = d_rec.p + size_t( iter & 1 ) * V, *recNxt = d_rec.p + size_t( ( iter + 1 ) & 1 ) * V;
+      hipLaunchKernelGGL( closurePrepareKernel, grdV32, blk, 0, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, V, d_out.p, gAct,
+                          gFr, gMk );
+      hipLaunchKernelGGL( closureLevelsKernel, dim3( 1 ), dim3( 1024 ), ldsBytes, s, d_out.p, V, listCap, gAct, gFr, gMk,
+                          d_work.p, d_work.p + V, wantTiming ? d_timing.p : nullptr );
+      hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_work.p, d_work.p + V, recCur, recNxt, d_lastRescore.p,
+                          d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge, d_ppi,
+                          reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, d_flags.p, iter );
+    }
+    ctx->stageEnd( sidSweep );
+    TMC2_HIP( hipGetLastError() );
+    ctx->stageAddHostMs( "refine_sweeps_executed", double( iterationCount ) );  // (a count, not milliseconds)
+    if ( wantTiming ) {
+      unsigned long long t[8];
+      TMC2_HIP( hipMemcpyAsync( t, d_timing.p, 64, hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+      const double us = 0.01 / iterationCount;  // wall_clock64 ticks at 100 MHz
+      fprintf( stderr, "refine closure tail, per sweep: load %.1f us, compaction %.1f us, voxels %.1f us, lists %.1f us; %.1f levels, %.0f listed voxels (V = %u)\n",
+               t[0] * us, t[1] * us, t[2] * us, t[3] * us, double( t[4] ) / iterationCount, double( t[5] ) / iterationCount, V );
+    }
+    if ( getenv( "TMC2_REFINE_TRACE" ) ) {  // test hook: points moved per sweep
+      std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
+      TMC2_HIP( hipMemcpyAsync( h_flags.data(), d_flags.p, h_flags.size() * 4, hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+      fprintf( stderr, "refine: points moved per sweep:" );
+      for ( int m = 0; m < iterationCount; ++m ) fprintf( stderr, " %u", h_flags[2 * m + 1] );
+      fprintf( stderr, "\n" );
+    }
+    // (no synchronisation: the partition stays on the device and the next stage is queued behind the sweeps; the
+    // buffers go back to the context's pool, whose blocks are only ever reused by work queued on this same stream)
+    return TMC2_OK;
+  }
   ctx->stageEnd( sidSetup );
   TMC2_HIP( hipGetLastError() );
 
   const int sidSweep = ctx->stageBegin( "refine_sweeps" );
-  DevBuf<uint32_t> d_dev, d_out, d_bits;
-  const uint32_t   W = ( V + 31 ) / 32;
-  TMC2_TRY( d_dev.alloc( size_t( V ) * 32 ) );
+  DevBuf<uint32_t> d_out, d_bits;
   TMC2_TRY( d_out.alloc( size_t( V ) * 32 ) );
   TMC2_TRY( d_bits.alloc( 3 * size_t( W ) ) );
   uint32_t *d_activeBits = d_bits.p, *d_frontierBits = d_bits.p + W, *d_nextBits = d_bits.p + 2 * size_t( W );
   TMC2_HIP( hipMemsetAsync( d_bits.p, 0, 3 * size_t( W ) * 4, s ) );
-  const dim3 grdV32( ( V + 7 ) / 8 );
-  hipLaunchKernelGGL( devTableKernel, grdV32, blk, 0, s, d_adjOff.p, d_devLen.p, d_adj.p, V, d_dev.p );
   const size_t tailLds   = 3 * size_t( W ) * 4;
   // (test hook TMC2_REFINE_TAIL=global: take the global-memory tail regardless, the path of grids > 349 K voxels)
   const char*  tailEnv   = getenv( "TMC2_REFINE_TAIL" );

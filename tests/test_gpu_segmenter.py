@@ -128,8 +128,13 @@ def test_gpu_full_size_properties(gpu_ctx):
     assert (np.einsum("ij,ij->i", nrm, -p.astype(np.float64)) < 0).sum() <= (n + 1) // 2  # majority rule of S3
 
 
+@pytest.mark.parametrize("sweeps", ["event-driven", "full"])
 @pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 50), ("medium", 20)])
-def test_gpu_refine_matches_oracle(gpu_ctx, oracle, name, iters):
+def test_gpu_refine_matches_oracle(gpu_ctx, oracle, monkeypatch, name, iters, sweeps):
+    """Both sweep loops of S5: the event-driven one (default: incremental S, re-scoring only where S changed, closure
+    levels in one workgroup) and the sweep-everything one that grids beyond the LDS take (TMC2_REFINE_SWEEPS=full)."""
+    if sweeps == "full":
+        monkeypatch.setenv("TMC2_REFINE_SWEEPS", "full")
     xyz, rgb = synth_cloud(name)
     nrm = oracle.normals(xyz)
     w = oracle.weight_normal(xyz)
@@ -230,7 +235,7 @@ def test_gpu_refine_many_sweeps(gpu_ctx, oracle):
     nrm = oracle.normals(xyz)
     w = oracle.weight_normal(xyz)
     p0 = oracle.initial_segmentation(nrm, w)
-    for iters in (1, 2, 50):
+    for iters in (1, 2, 3, 50):
         fr = gpu_ctx.frame(xyz, rgb)
         fr.set_normals(nrm)
         fr.set_partition(p0)
@@ -256,7 +261,8 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch
 
 
 def test_gpu_refine_global_memory_tail(gpu_ctx, oracle, monkeypatch):
-    """Grids too large for the LDS bitmaps drain the closure tail through global memory: same partition."""
+    """Sweep-everything loop, grids too large for the LDS bitmaps: the closure tail drains through global memory."""
+    monkeypatch.setenv("TMC2_REFINE_SWEEPS", "full")
     monkeypatch.setenv("TMC2_REFINE_TAIL", "global")
     xyz, rgb = synth_cloud("small")
     nrm = oracle.normals(xyz)
