@@ -144,26 +144,29 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
 
 // ---- neighbourhoods ---------------------------------------------------------------------------------
 // One wavefront per voxel.  offsets[] = all integer (dx,dy,dz) with d2 < radius2, packed, any order.
-// Collect hits (d2 << 26 | voxel id) in LDS, bitonic-sort, cut after the cumulative member count reaches
-// maxNN; write row length, weight, DEV prefix length and the row itself (fixed stride).
-constexpr int kMaxBall = 2048;
+// Collect hits (d2 << idBits | voxel id) in LDS, bitonic-sort, cut after the cumulative member count reaches maxNN; write
+// row length, weight, the row itself (rows back to back: the wave reserves its slots from a cursor -- what a frame needs
+// is ~ maxNN / (points per voxel) entries per voxel, a fraction of the ball) and the DEV row: the members of the row
+// within Chebyshev distance devRange (1 for voxels of 4 and more, 2 for voxels of 2: PCCPatchSegmenter.cpp:1469-1492), in
+// row order, padded to devStride entries.
+constexpr uint32_t kDevPad = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restrict__ centre,
-                                                               const uint32_t* __restrict__ count,
-                                                               const uint32_t* __restrict__ table, Grid g, uint32_t V,
-                                                               const int* __restrict__ offsets, int nOffsets, int maxNN,
-                                                               double lambda, uint32_t* __restrict__ rowLen,
-                                                               uint32_t* __restrict__ devLen, double* __restrict__ weight,
-                                                               uint32_t stride, uint32_t* __restrict__ adjOff,
-                                                               uint32_t* __restrict__ adj, uint32_t* __restrict__ totalLen ) {
-  __shared__ uint32_t keysAll[4][kMaxBall];
+template <int CAP, int WAVES>
+__global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
+    const Pt* __restrict__ centre, const uint32_t* __restrict__ count, const uint32_t* __restrict__ table, Grid g, uint32_t V,
+    const int* __restrict__ offsets, int nOffsets, int maxNN, double lambda, int idBits, int devRange, uint32_t devStride,
+    uint32_t rowCapacity, uint32_t* __restrict__ rowLen, uint32_t* __restrict__ devLen, double* __restrict__ weight,
+    uint32_t* __restrict__ adjOff, uint32_t* __restrict__ adj, uint32_t* __restrict__ dev, uint32_t* __restrict__ rowCursor,
+    uint32_t* __restrict__ overflow ) {
+  __shared__ uint32_t keysAll[WAVES][CAP];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t      v    = blockIdx.x * 4 + wave;
+  const uint32_t      v    = blockIdx.x * WAVES + wave;
   uint32_t*           keys = keysAll[wave];
   if ( v >= V ) return;  // whole wave exits together (v is wave-uniform); no block-level barrier below
-  const Pt  c       = centre[v];
-  const int gridMax = 1 << g.gridShift;  // cell coordinates run 0..gridMax inclusive
-  int       hits    = 0;
+  const uint32_t idMask  = ( 1u << idBits ) - 1u;
+  const Pt       c       = centre[v];
+  const int      gridMax = 1 << g.gridShift;  // cell coordinates run 0..gridMax inclusive
+  int            hits    = 0;
   for ( int base = 0; base < nOffsets; base += 64 ) {
     const int o   = base + lane;
     uint32_t  key = 0xFFFFFFFFu;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
         const uint32_t u = table[cellKey( x, y, z, g.gridShift )];
         if ( u != 0xFFFFFFFFu ) {
           const Pt cu = centre[u];  // aliased keys: accept only the voxel whose centre really sits here
-          if ( cu.x == x && cu.y == y && cu.z == z ) key = ( uint32_t( dx * dx + dy * dy + dz * dz ) << 26 ) | u;
+          if ( cu.x == x && cu.y == y && cu.z == z ) key = ( uint32_t( dx * dx + dy * dy + dz * dz ) << idBits ) | u;
         }
       }
     }
@@ -213,7 +216,7 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
   bool     done    = false;
   for ( int base = 0; base < hits && !done; base += 64 ) {
     const int i   = base + lane;
-    uint32_t  cnt = ( i < hits ) ? ( count[keys[i] & 0x3FFFFFFu] & 0xFFu ) : 0u;
+    uint32_t  cnt = ( i < hits ) ? ( count[keys[i] & idMask] & 0xFFu ) : 0u;
     uint32_t  inc = cnt;
 #pragma unroll
     for ( int off = 1; off < 64; off <<= 1 ) {
@@ -232,19 +235,47 @@ __global__ __launch_bounds__( 256 ) void neighbourhoodKernel( const Pt* __restri
       nn      = running;
     }
   }
+  uint32_t rowBase = 0;
+  if ( lane == 0 ) rowBase = atomicAdd( rowCursor, uint32_t( used ) );  // (the final cursor = size of the reverse rows)
+  rowBase        = __shfl( rowBase, 0, 64 );
+  const bool fit = uint64_t( rowBase ) + uint32_t( used ) <= rowCapacity;
   if ( lane == 0 ) {
     rowLen[v] = uint32_t( used );
-    adjOff[v] = v * stride;
-    atomicAdd( totalLen, uint32_t( used ) );  // (size of the reverse rows)
+    adjOff[v] = fit ? rowBase : 0u;
     weight[v] = __ddiv_rn( lambda, double( nn ) );
-    int dev   = 0;  // DEV candidates (Chebyshev <= 1) are exactly the entries with d2 <= 3: a prefix of the row
-    while ( dev < used && ( keys[dev] >> 26 ) <= 3u ) ++dev;
-    devLen[v] = uint32_t( dev );
+    if ( !fit ) *overflow = 1u;  // the host repeats the pass with room for whole balls
   }
-  // rows at a fixed stride (the ball's size bounds their length): one pass, no offsets to prefix-sum, no second sort;
-  // the sweeps read only rowLen[v] entries of each, so the slack costs address space, not bandwidth
-  uint32_t* row = adj + size_t( v ) * stride;
-  for ( int i = lane; i < used; i += 64 ) row[i] = keys[i] & 0x3FFFFFFu;
+  if ( fit )
+    for ( int i = lane; i < used; i += 64 ) adj[size_t( rowBase ) + i] = keys[i] & idMask;
+  // DEV row.  Chebyshev distance <= R implies d2 <= 3 R^2: candidates are a prefix of the (sorted) row.
+  const uint32_t d2Max = uint32_t( 3 * devRange * devRange );
+  uint32_t*      drow  = dev + size_t( v ) * devStride;
+  uint32_t       nDev  = 0;
+  for ( int base = 0; base < used; base += 64 ) {
+    const int i   = base + lane;
+    bool      in  = false;
+    uint32_t  u   = 0;
+    const bool near = i < used && ( keys[i] >> idBits ) <= d2Max;
+    if ( near ) {
+      u           = keys[i] & idMask;
+      const Pt cu = centre[u];
+      in          = abs( int( cu.x ) - int( c.x ) ) <= devRange && abs( int( cu.y ) - int( c.y ) ) <= devRange &&
+           abs( int( cu.z ) - int( c.z ) ) <= devRange;
+    }
+    const unsigned long long m = __ballot( in );
+    if ( in ) {
+      const uint32_t pos = nDev + uint32_t( __popcll( m & ( ( 1ull << lane ) - 1ull ) ) );
+      if ( pos < devStride ) drow[pos] = u;
+    }
+    nDev += uint32_t( __popcll( m ) );
+    if ( !__ballot( near ) ) break;
+  }
+  if ( nDev > devStride ) {  // (cannot happen: (2 R + 1)^3 <= devStride by construction)
+    if ( lane == 0 ) *overflow = 2u;
+    nDev = devStride;
+  }
+  for ( uint32_t i = nDev + lane; i < devStride; i += 64 ) drow[i] = kDevPad;
+  if ( lane == 0 ) devLen[v] = nDev;
 }
 
 // ---- sweep kernels ----------------------------------------------------------------------------------
@@ -316,18 +347,6 @@ __global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__
 //            bitmaps in LDS, so a hop costs one global load (the 16-byte head of out[u]) instead of a chain of them.
 //            The tail has next to no parallelism, so one workgroup loses nothing, needs no cross-workgroup polling,
 //            terminates exactly when the frontier is empty, and leaves the rest of the chip to the other frames.
-constexpr uint32_t kDevPad = 0xFFFFFFFFu;
-
-// dev[u][0..31]: the DEV candidates of u (Chebyshev <= 1: a prefix of its neighbourhood row), padded.  Static.
-__global__ __launch_bounds__( 256 ) void devTableKernel( const uint32_t* __restrict__ adjOff, const uint32_t* __restrict__ devLen,
-                                                          const uint32_t* __restrict__ adj, uint32_t V,
-                                                          uint32_t* __restrict__ dev ) {
-  const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
-  const uint32_t lane = threadIdx.x & 31;
-  if ( u >= V ) return;
-  dev[size_t( u ) * 32 + lane] = lane < devLen[u] ? adj[adjOff[u] + lane] : kDevPad;
-}
-
 __global__ __launch_bounds__( 256 ) void closureRoundZeroKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
                                                                   const uint8_t* __restrict__ arg,
                                                                   const uint32_t* __restrict__ dev, uint32_t V,
@@ -637,38 +656,46 @@ __device__ __forceinline__ int argOfPacked( uint32_t s0, uint32_t s1, uint32_t s
   return a;
 }
 
-// Chip-wide first step of a sweep, 32 lanes per voxel u (its DEV row, padded):
+// Chip-wide first step of a sweep, 32 lanes per voxel u (its DEV row, padded to `stride` entries: 32 or 128):
 //   out[u] = { count, the DEV neighbours u marks if it is active: NO_EDGE voxels whose ppi differs from arg(S[u]) };
 //   rec[nxt][u] = rec[cur][u]  (the copy this sweep's pushes go into);
 //   u active at sweep start: its bit in the active bitmap, its marks, and the larger-index voxels it activates (frontier).
 __global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
                                                                 const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
-                                                                const uint32_t* __restrict__ dev, uint32_t V,
+                                                                const uint32_t* __restrict__ dev,
+                                                                const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t V,
                                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ gAct,
                                                                 uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
   const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
   const uint32_t lane = threadIdx.x & 31;
   const int      half = ( threadIdx.x >> 5 ) & 1;
   if ( u >= V ) return;
-  const uint4    r    = recCur[u];
-  const uint32_t v    = dev[size_t( u ) * 32 + lane];
-  const uint8_t  a    = uint8_t( argOfPacked( r.x, r.y, r.z ) );
-  const bool     pred = v != kDevPad && edge[v] == NO_EDGE && ppi[v] != a;
-  const uint32_t m    = uint32_t( __ballot( pred ) >> ( 32 * half ) );
-  if ( pred ) out[size_t( u ) * 32 + 1 + __popc( m & ( ( 1u << lane ) - 1u ) )] = v;
+  const uint4    r      = recCur[u];
+  const uint8_t  a      = uint8_t( argOfPacked( r.x, r.y, r.z ) );
+  const bool     active = edge[u] != NO_EDGE;
+  const uint32_t len    = devLen[u];
+  uint32_t       nOut   = 0;
   if ( lane == 0 ) {
-    out[size_t( u ) * 32] = uint32_t( __popc( m ) );
-    recNxt[u]             = r;
+    recNxt[u] = r;
+    if ( active ) atomicOr( &gAct[u >> 5], 1u << ( u & 31 ) );
   }
-  if ( edge[u] == NO_EDGE ) return;
-  if ( lane == 0 ) atomicOr( &gAct[u >> 5], 1u << ( u & 31 ) );
-  if ( pred ) {
-    atomicOr( &gMk[v >> 5], 1u << ( v & 31 ) );
-    if ( v > u ) {  // (v is a NO_EDGE voxel: only marks activate it, so "activated" and "frontier" coincide here)
-      atomicOr( &gAct[v >> 5], 1u << ( v & 31 ) );
-      atomicOr( &gFr[v >> 5], 1u << ( v & 31 ) );
+  for ( uint32_t base = 0; base < len; base += 32 ) {  // (uniform over the 32 lanes of the voxel)
+    const uint32_t v    = base + lane < len ? dev[size_t( u ) * stride + base + lane] : kDevPad;
+    const bool     pred = v != kDevPad && edge[v] == NO_EDGE && ppi[v] != a;
+    const uint32_t m    = uint32_t( __ballot( pred ) >> ( 32 * half ) );
+    if ( pred ) {
+      out[size_t( u ) * stride + 1 + nOut + __popc( m & ( ( 1u << lane ) - 1u ) )] = v;
+      if ( active ) {
+        atomicOr( &gMk[v >> 5], 1u << ( v & 31 ) );
+        if ( v > u ) {  // (v is a NO_EDGE voxel: only marks activate it, so "activated" and "frontier" coincide here)
+          atomicOr( &gAct[v >> 5], 1u << ( v & 31 ) );
+          atomicOr( &gFr[v >> 5], 1u << ( v & 31 ) );
+        }
+      }
     }
+    nOut += uint32_t( __popc( m ) );
   }
+  if ( lane == 0 ) out[size_t( u ) * stride] = nOut;
 }
 
 // Wave-level compaction of a bitmap into a voxel list (whole 64-word chunks; a chunk that does not fit stays for the next
@@ -712,7 +739,8 @@ __device__ __forceinline__ uint32_t compactBitmap( uint32_t* __restrict__ bm, ui
 // The dependent rest of the closure, one workgroup.  LDS: active | frontier | marked | scratch bitmaps (V bits each), list.
 // Hands the global bitmaps back empty, writes the work list of sweepKernel: every active voxel, then the voxels that were
 // only marked.
-__global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* __restrict__ out, uint32_t V, uint32_t listCap,
+__global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* __restrict__ out, uint32_t stride, uint32_t V,
+                                                                uint32_t listCap,
                                                               uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr,
                                                               uint32_t* __restrict__ gMk, uint32_t* __restrict__ work,
                                                               uint32_t* __restrict__ workCount,
@@ -731,14 +759,15 @@ __global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* _
   uint32_t *          act = lds, *fr = act + W, *mk = fr + W, *tmp = mk + W, *list = tmp + W;
   for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
     const uint32_t a = gAct[w], f = gFr[w], m = gMk[w];
-    act[w] = a, fr[w] = f, mk[w] = m, tmp[w] = a;
+    act[w] = a, fr[w] = f, mk[w] = m, tmp[w] = a & ~f;
     if ( a ) gAct[w] = 0;
     if ( f ) gFr[w] = 0;
     if ( m ) gMk[w] = 0;
   }
   uint32_t nWork = 0;  // (uniform: every thread keeps the same count)
-  // phase 0: list what is active already (active at sweep start, or activated by such a voxel);
-  // phase 1: the closure, level by level, listing what each level activates;  phase 2: the voxels that were only marked
+  // phase 0: list the voxels active at sweep start (their marks are made already);  phase 1: the closure, level by level,
+  // listing the voxels of each level (the first one: what the voxels of phase 0 activated);  phase 2: the voxels that
+  // were only marked.  Every voxel is listed once, whatever the number of rounds a full list splits a level into.
   for ( int phase = 0; phase < 3; ++phase ) {
     bool first = true;
     while ( true ) {
@@ -753,17 +782,14 @@ __global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* _
       __syncthreads();  // (nList is reset at the top of the next round)
       if ( phase == 1 ) { TMC2_LAP( tCompact ) } else { TMC2_LAP( tEmit ) }
       if ( empty ) break;
-      // (the first frontier is part of what phase 0 listed; later ones are new)
-      if ( phase != 1 || !first ) {
-        for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) work[nWork + i] = list[i] | ( phase == 2 ? 0u : kWorkActive );
-        nWork += n;
-      }
+      for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) work[nWork + i] = list[i] | ( phase == 2 ? 0u : kWorkActive );
+      nWork += n;
       first = false;
       if ( phase != 1 ) continue;
       ++rounds;
       for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) {  // one voxel per thread: one 16-byte load per hop
         const uint32_t  u    = list[i];
-        const uint32_t* row  = out + size_t( u ) * 32;
+        const uint32_t* row  = out + size_t( u ) * stride;
         const uint4     head = reinterpret_cast<const uint4*>( row )[0];  // count + the first seven targets: one round
         const uint4     more = reinterpret_cast<const uint4*>( row )[1];  // trip for all but the rarest voxels
         for ( uint32_t k = 0; k < head.x; ++k ) {
@@ -904,8 +930,8 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     setError( "refineSegmentationGridBased: normals / partition missing" );
     return TMC2_E_STATE;
   }
-  if ( voxDim < 4 || ( voxDim & ( voxDim - 1 ) ) ) {
-    setError( "refineSegmentationGridBased: voxelDimensionRefineSegmentation=%d unsupported (power of two >= 4)", voxDim );
+  if ( voxDim < 2 || ( voxDim & ( voxDim - 1 ) ) ) {  // (the CTC sequences use 4 -- longdress, basketball -- and 2 -- loot, redandblack, soldier)
+    setError( "refineSegmentationGridBased: voxelDimensionRefineSegmentation=%d unsupported (power of two >= 2)", voxDim );
     return TMC2_E_UNSUPPORTED;
   }
   if ( iterationCount < 1 ) iterationCount = 1;  // the reference loop is do { } while ( ++iter < count )
@@ -938,10 +964,13 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
           if ( dx * dx + dy * dy + dz * dz < r2 )
             offsets.push_back( ( dx + 128 ) | ( ( dy + 128 ) << 8 ) | ( ( dz + 128 ) << 16 ) );
   }
-  if ( offsets.size() > size_t( kMaxBall ) || r2 >= 64 ) {
+  if ( offsets.size() > 4096 || r2 > 128 ) {  // (search radius 192: r2 = 48 with voxels of 4, 96 with voxels of 2 -> 3 911 cells)
     setError( "refineSegmentationGridBased: search radius %d too large for the LDS neighbourhood tile", searchRadius );
     return TMC2_E_UNSUPPORTED;
   }
+  const int      devRange  = voxDim >= 4 ? 1 : 2;  // PCCPatchSegmenter.cpp:1471
+  const uint32_t devStride = devRange == 1 ? 32u : 128u;
+  const int      idBits    = r2 <= 64 ? 26 : 25;   // neighbourhood sort key: d2 above, voxel id below
   const int sidSetup = ctx->stageBegin( "refine_setup" );
   if ( ctx->gridTable.count < g.tableSize ) {
     TMC2_TRY( ctx->gridTable.alloc( g.tableSize ) );
@@ -993,7 +1022,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
   hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
                       d_hist.p );
-  const dim3 grdV( ( V + 255 ) / 256 ), grdW( ( V + 3 ) / 4 ), grdV16( ( V + 15 ) / 16 );  // one wave / 16 lanes per voxel
+  const dim3 grdV( ( V + 255 ) / 256 ), grdV16( ( V + 15 ) / 16 );  // 16 lanes per voxel
   // points grouped by voxel, for the re-scoring pass
   DevBuf<uint32_t> d_pointStart, d_pointList, d_cursor;
   TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
@@ -1004,24 +1033,52 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   hipLaunchKernelGGL( voxelPointListKernel, grdN, blk, 0, s, d_vid.p, d_pointStart.p, n, d_cursor.p, d_pointList.p );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
                       d_edge, d_ppi, d_active );
-  // neighbourhoods
-  const uint32_t stride = ( uint32_t( offsets.size() ) + 31u ) & ~31u;
-  if ( uint64_t( V ) * stride > 0xFFFFFFFFull ) {
-    setError( "refineSegmentationGridBased: %u voxels x %u ball cells exceed the neighbourhood table", V, stride );
+  // neighbourhoods.  Rows back to back; room for twice the expected mean row (maxNN / points per voxel) -- the rare frame
+  // that needs more repeats the pass with room for whole balls.  (test hook TMC2_REFINE_ROWCAP=tiny forces the repeat)
+  if ( ( uint64_t( V ) >> idBits ) != 0 ) {
+    setError( "refineSegmentationGridBased: %u voxels exceed the neighbourhood sort key", V );
     return TMC2_E_UNSUPPORTED;
   }
-  DevBuf<uint32_t> d_adj;
-  TMC2_TRY( d_adj.alloc( size_t( V ) * stride ) );
-  TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 4, s ) );
-  hipLaunchKernelGGL( neighbourhoodKernel, grdW, blk, 0, s, d_centre.p, d_count.p, table, g, V, d_offsets.p,
-                      int( offsets.size() ), maxNNCount, lambda, d_rowLen.p, d_devLen.p, d_weight.p, stride, d_adjOff.p,
-                      d_adj.p, d_small.p + 1 );
-  hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
   const uint32_t W = ( V + 31 ) / 32;
-  DevBuf<uint32_t> d_dev;
-  TMC2_TRY( d_dev.alloc( size_t( V ) * 32 ) );
+  DevBuf<uint32_t> d_adj, d_dev;
+  TMC2_TRY( d_dev.alloc( size_t( V ) * devStride ) );
+  const size_t ball     = offsets.size();
+  const char*  capEnv   = getenv( "TMC2_REFINE_ROWCAP" );
+  size_t       perVoxel = std::min<size_t>( ball, 2 * size_t( maxNNCount > 0 ? maxNNCount : 1 ) * V / std::max<uint32_t>( n, 1u ) + 32 );
+  if ( capEnv && capEnv[0] == 't' ) perVoxel = 1;
+  uint32_t totalLen = 0;
+  for ( int attempt = 0;; ++attempt ) {
+    const uint64_t capacity = uint64_t( V ) * perVoxel;
+    if ( capacity > 0xFFFFFFFFull ) {
+      setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
+      return TMC2_E_UNSUPPORTED;
+    }
+    TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
+    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 8, s ) );  // [1] row cursor, [2] overflow
+#define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
+  hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
+                      d_count.p, table, g, V, d_offsets.p, int( ball ), maxNNCount, lambda, idBits, devRange, devStride,       \
+                      uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
+                      d_small.p + 2 )
+    if ( ball <= 2048 )
+      TMC2_NEIGHBOURHOOD( 2048, 4 );
+    else
+      TMC2_NEIGHBOURHOOD( 4096, 2 );
+#undef TMC2_NEIGHBOURHOOD
+    uint32_t res[2] = {0, 0};
+    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    TMC2_HIP( hipGetLastError() );
+    totalLen = res[0];
+    if ( res[1] == 0 ) break;
+    if ( res[1] != 1 || attempt > 0 ) {
+      setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
+      return TMC2_E_HIP;
+    }
+    perVoxel = ball;
+  }
+  hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
   const dim3 grdV32( ( V + 7 ) / 8 );
-  hipLaunchKernelGGL( devTableKernel, grdV32, blk, 0, s, d_adjOff.p, d_devLen.p, d_adj.p, V, d_dev.p );
   // Which sweep loop: the event-driven one needs the closure's four bitmaps and a voxel list in the LDS of one workgroup
   // (160 KB: up to ~ 290 K voxels; a vox11 frame has ~ 240 K).  Larger grids take the sweep-everything loop.
   // (test hook TMC2_REFINE_SWEEPS=full forces that one)
@@ -1030,9 +1087,6 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   const size_t ldsFixed    = 16 * size_t( W );
   const bool   eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
   if ( eventDriven ) {
-    uint32_t totalLen = 0;
-    TMC2_HIP( hipMemcpyAsync( &totalLen, d_small.p + 1, 4, hipMemcpyDeviceToHost, s ) );
-    TMC2_HIP( hipStreamSynchronize( s ) );
     // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
     DevBuf<uint32_t> d_roff, d_rcursor, d_radj, d_lastRescore, d_work, d_flags, d_out, d_gbits;
     DevBuf<uint4>    d_rec;
@@ -1042,7 +1096,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     TMC2_TRY( d_lastRescore.alloc( V ) );
     TMC2_TRY( d_work.alloc( size_t( V ) + 1 ) );  // [V]: the list's length
     TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
-    TMC2_TRY( d_out.alloc( size_t( V ) * 32 ) );
+    TMC2_TRY( d_out.alloc( size_t( V ) * devStride ) );
     TMC2_TRY( d_gbits.alloc( 3 * size_t( W ) ) );
     TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
     TMC2_HIP( hipMemsetAsync( d_rcursor.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
@@ -1059,7 +1113,9 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     ctx->stageEnd( sidSetup );
     TMC2_HIP( hipGetLastError() );
     const int      sidSweep = ctx->stageBegin( "refine_sweeps" );
-    const uint32_t listCap  = uint32_t( std::min<size_t>( 8192, ( ldsRoom - ldsFixed ) / 4 ) );
+    // (test hook TMC2_REFINE_LISTCAP: a short voxel list, so that small frames split their levels over several rounds too)
+    const char*    listEnv  = getenv( "TMC2_REFINE_LISTCAP" );
+    const uint32_t listCap  = uint32_t( std::min<size_t>( listEnv ? std::max( 2048, atoi( listEnv ) ) : 8192, ( ldsRoom - ldsFixed ) / 4 ) );
     const size_t   ldsBytes = ldsFixed + 4 * size_t( listCap );
     if ( ldsBytes > 48 * 1024 )
       TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureLevelsKernel ),
@@ -1074,9 +1130,9 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     uint32_t *gAct = d_gbits.p, *gFr = d_gbits.p + W, *gMk = d_gbits.p + 2 * size_t( W );
     for ( int iter = 0; iter < iterationCount; ++iter ) {
       uint4 *recCur = d_rec.p + size_t( iter & 1 ) * V, *recNxt = d_rec.p + size_t( ( iter + 1 ) & 1 ) * V;
-      hipLaunchKernelGGL( closurePrepareKernel, grdV32, blk, 0, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, V, d_out.p, gAct,
-                          gFr, gMk );
-      hipLaunchKernelGGL( closureLevelsKernel, dim3( 1 ), dim3( 1024 ), ldsBytes, s, d_out.p, V, listCap, gAct, gFr, gMk,
+      hipLaunchKernelGGL( closurePrepareKernel, grdV32, blk, 0, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p, devStride,
+                          V, d_out.p, gAct, gFr, gMk );
+      hipLaunchKernelGGL( closureLevelsKernel, dim3( 1 ), dim3( 1024 ), ldsBytes, s, d_out.p, devStride, V, listCap, gAct, gFr, gMk,
                           d_work.p, d_work.p + V, wantTiming ? d_timing.p : nullptr );
       hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_work.p, d_work.p + V, recCur, recNxt, d_lastRescore.p,
                           d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge, d_ppi,
@@ -1104,6 +1160,10 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     // (no synchronisation: the partition stays on the device and the next stage is queued behind the sweeps; the
     // buffers go back to the context's pool, whose blocks are only ever reused by work queued on this same stream)
     return TMC2_OK;
+  }
+  if ( devRange != 1 ) {
+    setError( "refineSegmentationGridBased: %u voxels of %d: beyond the event-driven sweep loop", V, voxDim );
+    return TMC2_E_UNSUPPORTED;
   }
   ctx->stageEnd( sidSetup );
   TMC2_HIP( hipGetLastError() );

@@ -167,9 +167,9 @@ class GofEncoder:
     sockets instead of wherever the scheduler happens to wake them."""
 
     def __init__(self, device=0, workers=4, iterations=50, bits3d=11, occ_precision=4, min_w=1280, min_h=1280,
-                 timing=True, pin=True, first_domain=0):
+                 timing=True, pin=True, first_domain=0, vox_dim=4):
         self.device, self.workers = device, workers
-        self.iterations, self.bits3d, self.occ_precision = iterations, bits3d, occ_precision
+        self.iterations, self.bits3d, self.occ_precision, self.vox_dim = iterations, bits3d, occ_precision, vox_dim
         self.min_w, self.min_h = min_w, min_h
         doms = l3_domains() if pin and workers > 1 and os.environ.get("TMC2_PIN", "1") != "0" else []
         cpus = [None] * workers
@@ -234,7 +234,7 @@ class GofEncoder:
         if weight is None:
             w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
             weight = sharder.broadcast_weight(w)
-        params = lib.ctc_params(self.iterations, self.bits3d, weight)
+        params = lib.ctc_params(self.iterations, self.bits3d, weight, self.vox_dim)
 
         def segment_and_pack(fr):
             fr.segmenter_compute(params)
@@ -267,7 +267,7 @@ class GofEncoder:
         if weight is None:
             w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
             weight = sharder.broadcast_weight(w)
-        params = lib.ctc_params(self.iterations, self.bits3d, weight)
+        params = lib.ctc_params(self.iterations, self.bits3d, weight, self.vox_dim)
         self._per_worker(frames, lambda fr: fr.segmenter_compute(params))
         local = self._per_worker(frames, lambda fr: fr.get_patch_records())
         mine, tiles = sharder.pack_gof_records(local, frame_count, mode, self.min_w, self.min_h)

@@ -47,15 +47,17 @@ PATCH_DTYPE = np.dtype([(n, t) for n, t in [(f[0], np.int32) for f in Patch._fie
                         [("depthOffset", np.int64), ("occOffset", np.int64)]])
 
 
-def ctc_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0)):
-    """CTC lossy settings (cfg/common/ctc-common.cfg + sequence cfg)."""
+def ctc_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0), vox_dim=4):
+    """CTC lossy settings (cfg/common/ctc-common.cfg + sequence cfg).  Per sequence: iterations 50
+    (longdress), 20 (basketball_player), 10 (the others); vox_dim = voxelDimensionRefineSegmentation: 4, but 2 for loot,
+    redandblack and soldier."""
     p = SegmenterParams()
     p.nnNormalEstimation = 16
     p.normalOrientation = 1
     p.gridBasedRefineSegmentation = 1
     p.maxNNCountRefineSegmentation = 1024
     p.iterationCountRefineSegmentation = iterations
-    p.voxelDimensionRefineSegmentation = 4
+    p.voxelDimensionRefineSegmentation = vox_dim
     p.searchRadiusRefineSegmentation = 192
     p.occupancyResolution = 16
     p.enablePatchSplitting = 1

@@ -430,6 +430,12 @@ int ref_gof_begin2( int frameCount, int iterations, int bits3dMinus1, int occPre
   return 0;
 }
 
+// sequence-level setting of cfg/sequence/{loot,redandblack,soldier}_vox10.cfg (2; the common value is 4); after ref_gof_begin*
+int ref_gof_set_voxel_dimension_refine( int voxDim ) {
+  g_gof->params.voxelDimensionRefineSegmentation_ = size_t( voxDim );
+  return 0;
+}
+
 // per list position: position of the matched patch in the previous frame's list, or -1
 int ref_gof_get_patch_matches( int frame, int32_t* out ) {
   auto& patches = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();

@@ -196,7 +196,73 @@ def io_golden():
     print("io_golden", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
+# BASELINE.json configurations at their real sizes and settings (cfg/common/ctc-common.cfg + cfg/sequence/<name>.cfg +
+# cfg/condition + cfg/rate): (iterationCountRefineSegmentation, voxelDimensionRefineSegmentation, geometry3dCoordinatesBitdepth
+# + 1, occupancyPrecision, minimumImageWidth, minimumImageHeight, constrainedPack / globalPatchAllocation)
+FULL_SIZE_CASES = {
+    # config 2: longdress_vox10, ctc-all-intra, r3
+    "longdress_vox10_ai_r3": dict(workload="longdress_vox10", frames=1, iterations=50, vox_dim=4, bits3d=11, precision=4,
+                                  min_w=1280, min_h=1280, pack=0),
+    # config 3: the other 8i sequences, ctc-all-intra, r3 (voxels of 2 for the refinement; redandblack's taller minimum canvas)
+    "loot_vox10_ai_r3": dict(workload="loot_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4,
+                             min_w=1280, min_h=1280, pack=0),
+    "redandblack_vox10_ai_r3": dict(workload="redandblack_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4,
+                                    min_w=1280, min_h=1344, pack=0),
+    "soldier_vox10_ai_r3": dict(workload="soldier_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4,
+                                min_w=1280, min_h=1280, pack=0),
+    # config 4: basketball_player_vox11, ctc-random-access, r5
+    "basketball_player_vox11_ra_r5": dict(workload="basketball_player_vox11", frames=1, iterations=20, vox_dim=4, bits3d=12,
+                                          precision=2, min_w=2560, min_h=1280, pack=2),
+    # the random-access packing chain (spatial consistency + global patch allocation) on the real 1280 canvas
+    "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4,
+                                       min_w=1280, min_h=1280, pack=2),
+}
+FULL_SIZE_PHASE_A = ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1")
+FULL_SIZE_PHASE_B = ("recon_xyz", "recon_rgb", "point_to_pixel", "attribute")
+
+
+def full_size_digests(a, b):
+    """What the fixture keeps of a GOF: canvas size, and per frame the patch count, the reconstructed point count and the MD5
+    of every canvas / cloud (the same bytes PCCVideoEncoder.cpp:389-396 and PCCEncoder.cpp:620-626 log per picture / cloud)."""
+    out = {"canvas": np.array([a[0]["width"], a[0]["height"]])}
+    for i, (pa, pb) in enumerate(zip(a, b)):
+        out["f%d_counts" % i] = np.array([len(pa["patches"]), len(pb["recon_xyz"])])
+        p = pa["patches"]
+        out["f%d_patches_md5" % i] = np.array(digest(np.stack([p[n] for n in p.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)))
+        for k in FULL_SIZE_PHASE_A:
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(np.ascontiguousarray(pa[k]).astype(pa[k].dtype)))
+        for k in FULL_SIZE_PHASE_B:
+            out["f%d_%s_md5" % (i, k)] = np.array(digest(pb[k]))
+    return out
+
+
+def full_size(only=None):
+    """MD5 fixtures at BASELINE size from the unmodified reference: minutes of CPU time, kilobytes of fixture."""
+    import time
+    ref = ob.Reference()
+    path = os.path.join(HERE, "full_size.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name, c in FULL_SIZE_CASES.items():
+        if only and name not in only:
+            continue
+        t = time.time()
+        frames = [synth_cloud(c["workload"], f) for f in range(c["frames"])]
+        a = ref.phase_a(frames, c["iterations"], c["bits3d"], c["precision"], c["min_w"], c["min_h"], c["pack"], c["vox_dim"])
+        b = ref.phase_b(frames, a, c["precision"])
+        d = full_size_digests(a, b)
+        d["input_md5"] = np.array("".join(digest(x) + digest(col) for x, col in frames))
+        for k in [k for k in out if k.startswith(name + "/")]:
+            del out[k]
+        out.update({name + "/" + k: v for k, v in d.items()})
+        np.savez_compressed(path, **out)
+        print(name, [len(f[0]) for f in frames], "canvas", d["canvas"], "counts", [d["f%d_counts" % i].tolist() for i in range(c["frames"])],
+              "%.0f s" % (time.time() - t), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "full_size":
+        full_size(sys.argv[2:])
+        sys.exit(0)
     main()
     gof()
     gof_low_delay()

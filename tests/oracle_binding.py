@@ -28,8 +28,8 @@ PATCH_DTYPE = np.dtype([(n, np.int32) for n in (
     "eomAndD1Count", "u0", "v0", "patchOrientation")] + [("depthOffset", np.int64), ("occOffset", np.int64)])
 
 
-def seg_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0)):
-    p = SegParams(16, 1, 1, 1024, iterations, 4, 192, 16, 1, 1024, 16, 16, 16, 16, 4, 1, 64, 255, 8, bits3d, 9.0, 1.0,
+def seg_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0), vox_dim=4):
+    p = SegParams(16, 1, 1, 1024, iterations, vox_dim, 192, 16, 1, 1024, 16, 16, 16, 16, 4, 1, 64, 255, 8, bits3d, 9.0, 1.0,
                   3.0)
     p.weightNormal[0], p.weightNormal[1], p.weightNormal[2] = [float(x) for x in weight]
     return p
@@ -248,12 +248,12 @@ class Oracle:
         L.orc_gpa_free(h)
         return out
 
-    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False):
+    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False, vox_dim=4):
         """S0..S16 for a GOF given as [(xyz, rgb), ...]; mirrors Reference.phase_a.  constrained_pack: True = the low-delay
         condition (frames after the first packed against their predecessor, S10'); 2 = the random-access condition
         (the same chain followed by the global patch allocation)."""
         w = self.weight_normal(frames[0][0], bits3d, 0.6)
-        sp = seg_params(iterations, bits3d, w)
+        sp = seg_params(iterations, bits3d, w, vox_dim)
         per = []
         for xyz, rgb in frames:
             seg = self.segment(xyz, rgb, sp)
@@ -576,11 +576,12 @@ class Reference:
             out.append(dict(boundary_before=pre[i][0], partition=pre[i][1], xyz=xyz, colors16=c16, rgb=rgb, boundary=bt))
         return out
 
-    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False):
+    def phase_a(self, frames, iterations=10, bits3d=11, occ_precision=4, min_w=1280, min_h=1280, constrained_pack=False, vox_dim=4):
         """S0..S16 through the reference's own PCCEncoder members (identity video codec)."""
         L = self.L
         L.ref_gof_begin2(len(frames), int(iterations), int(bits3d - 1), int(occ_precision), int(min_w), int(min_h),
                          int(constrained_pack))
+        L.ref_gof_set_voxel_dimension_refine(int(vox_dim))
         keep = []
         for i, (xyz, rgb) in enumerate(frames):
             xyz = _i16(xyz)

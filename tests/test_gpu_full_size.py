@@ -1,0 +1,84 @@
+"""BASELINE.json configurations at their real sizes and CTC settings: the HIP path against MD5 fixtures generated from the
+unmodified reference (tests/golden/full_size.npz, tests/golden/make_golden.py full_size) -- every canvas, the reconstructed
+cloud, its colours and pointToPixel, the patch lists, bit for bit.  (The same bytes the reference logs per picture / per cloud
+under CONFORMANCE_TRACE: PCCVideoEncoder.cpp:389-396, PCCEncoder.cpp:620-626.)"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import tmc2_amd as T
+from tmc2_amd.synth import synth_cloud
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "full_size.npz")
+
+# (kept in step with tests/golden/make_golden.py FULL_SIZE_CASES; the fixture's input_md5 pins the synthetic input)
+CASES = {
+    "longdress_vox10_ai_r3": dict(workload="longdress_vox10", frames=1, iterations=50, vox_dim=4, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
+    "loot_vox10_ai_r3": dict(workload="loot_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
+    "redandblack_vox10_ai_r3": dict(workload="redandblack_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1344, pack=0),
+    "soldier_vox10_ai_r3": dict(workload="soldier_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
+    "basketball_player_vox11_ra_r5": dict(workload="basketball_player_vox11", frames=1, iterations=20, vox_dim=4, bits3d=12, precision=2, min_w=2560, min_h=1280, pack=2),
+    "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=2),
+}
+
+
+def digest(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def fixture(name):
+    g = np.load(FIXTURE)
+    return {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "/")}
+
+
+def check_against_fixture(g, W, H, per_frame):
+    """per_frame: [(patch list in list order, geometry images dict, (recon xyz, rgb, pointToPixel), attribute images)]"""
+    assert (W, H) == tuple(int(x) for x in g["canvas"])
+    for i, (patches, img, (rx, rc, p2p), att) in enumerate(per_frame):
+        assert [len(patches), len(rx)] == g["f%d_counts" % i].tolist(), i
+        flat = np.stack([patches[n] for n in patches.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        assert digest(flat) == str(g["f%d_patches_md5" % i]), "patch list of frame %d" % i
+        for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+            assert digest(img[k]) == str(g["f%d_%s_md5" % (i, k)]), "%s of frame %d" % (k, i)
+        for k, v in (("recon_xyz", rx), ("recon_rgb", rc), ("point_to_pixel", p2p), ("attribute", att)):
+            assert digest(v) == str(g["f%d_%s_md5" % (i, k)]), "%s of frame %d" % (k, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_gpu_full_size_matches_golden(name):
+    c, g = CASES[name], fixture(name)
+    if not g:
+        pytest.fail("fixture of %s missing from tests/golden/full_size.npz" % name)
+    frames = [synth_cloud(c["workload"], f) for f in range(c["frames"])]
+    assert "".join(digest(x) + digest(col) for x, col in frames) == str(g["input_md5"]), "synthetic input differs from the fixture's"
+    enc = T.GofEncoder(0, workers=min(2, len(frames)), iterations=c["iterations"], bits3d=c["bits3d"], occ_precision=c["precision"],
+                       min_w=c["min_w"], min_h=c["min_h"], vox_dim=c["vox_dim"])
+    try:
+        frs = enc.upload(frames)
+        W, H = enc.phase_a(frs, constrained_pack={0: False, 1: True, 2: 2}[c["pack"]])
+        enc.phase_b(frs)
+        per = []
+        for fr in frs:
+            patches = fr.get_patches()[0][fr.get_patch_order()]
+            per.append((patches, fr.get_geometry_images(), fr.get_reconstruction(), fr.get_attribute_images()))
+        check_against_fixture(g, W, H, per)
+    finally:
+        enc.close()
+
+
+def test_oracle_full_size_matches_golden(oracle):
+    """CPU tier: the restatement against the same fixture at BASELINE size (one case: the suite stays within minutes)."""
+    name = "loot_vox10_ai_r3"
+    c, g = CASES[name], fixture(name)
+    if not g:
+        pytest.skip("fixture of %s not generated yet" % name)
+    frames = [synth_cloud(c["workload"], f) for f in range(c["frames"])]
+    assert "".join(digest(x) + digest(col) for x, col in frames) == str(g["input_md5"])
+    a = oracle.phase_a(frames, c["iterations"], c["bits3d"], c["precision"], c["min_w"], c["min_h"], c["pack"], c["vox_dim"])
+    b = oracle.phase_b(frames, a, c["precision"])
+    per = [(pa["patches"], pa, (pb["recon_xyz"], pb["recon_rgb"], pb["point_to_pixel"]), pb["attribute"]) for pa, pb in zip(a, b)]
+    check_against_fixture(g, a[0]["width"], a[0]["height"], per)

@@ -146,6 +146,52 @@ def test_gpu_refine_matches_oracle(gpu_ctx, oracle, monkeypatch, name, iters, sw
     assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=iters))
 
 
+@pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 10), ("medium", 10)])
+def test_gpu_refine_voxels_of_two(gpu_ctx, oracle, name, iters):
+    """voxelDimensionRefineSegmentation = 2 (cfg/sequence/{loot,redandblack,soldier}_vox10.cfg): search ball of 3 911 cells,
+    rows of ~ 250 voxels, INDIRECT-edge candidates within Chebyshev distance 2 (up to 125, not a prefix of the row)."""
+    xyz, rgb = synth_cloud(name)
+    nrm = oracle.normals(xyz)
+    p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, iters, 2, 192)
+    exp = oracle.refine_grid(xyz, nrm, p0, iterations=iters, vox_dim=2)
+    assert np.array_equal(fr.get_partition(), exp) and not np.array_equal(exp, p0)
+
+
+@pytest.mark.parametrize("vox_dim", [4, 2])
+def test_gpu_refine_row_capacity_retry(gpu_ctx, oracle, monkeypatch, vox_dim):
+    """The neighbourhood rows lie back to back in a table sized for twice the expected mean row; a frame that needs more
+    repeats the pass with room for whole balls (forced here)."""
+    monkeypatch.setenv("TMC2_REFINE_ROWCAP", "tiny")
+    xyz, rgb = synth_cloud("small")
+    nrm = oracle.normals(xyz)
+    p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, 10, vox_dim, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10, vox_dim=vox_dim))
+
+
+@pytest.mark.parametrize("vox_dim", [4, 2])
+def test_gpu_refine_levels_split_over_rounds(gpu_ctx, oracle, monkeypatch, vox_dim):
+    """The closure's level walk keeps its frontier in a voxel list of bounded length; a level (or the set of voxels active at
+    sweep start) that does not fit is split over several rounds.  A short list makes a medium frame do what a full-size
+    frame does with the real one: every voxel must still be listed -- and processed -- exactly once."""
+    monkeypatch.setenv("TMC2_REFINE_LISTCAP", "2048")
+    xyz, rgb = synth_cloud("medium")
+    nrm = oracle.normals(xyz)
+    p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+    fr = gpu_ctx.frame(xyz, rgb)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, 6, vox_dim, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=6, vox_dim=vox_dim))
+
+
 def test_gpu_refine_key_aliasing(gpu_ctx, oracle):
     """Coordinates at the top of the range make the reference's voxel key alias; identity is the key."""
     xyz, _ = synth_cloud("small")
