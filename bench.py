@@ -12,11 +12,15 @@ rank 0 (RCCL over xGMI).  The point arrays are resident in HBM before the timed 
 k-d tree build to the finished, host-resident canvases on rank 0 is inside it.
 
 Printed JSON (one line, rank 0): metric/value/unit as BASELINE.json, plus
-  roofline     -- dominant GPU kernel of the timed region: algorithmic bytes per launch / mean launch duration
-                  (HIP events on the launching stream, collected inside the timed region) against 8 TB/s HBM
-  cpu_baseline -- the reference (oracle/_ref, kind "reference") or our restatement (kind "port") on the host,
-                  one frame of the same workload, one core; "all_cores": the reference's per-frame parallelism, as one
-                  process per frame on up to 32 frames at once
+  roofline     -- the dominant GPU step of the timed region, chosen over ALL timed stages by GPU time with the GPU to
+                  itself: algorithmic bytes per launch (SURVEY.md 8d formulas, with the V and L of this very run) / mean
+                  launch duration (HIP events on the launching stream, inside the timed region) against 8 TB/s HBM;
+                  "path" = the contract figure of the whole path, B_alg per frame x frames/s / peak; "stages" = achieved
+                  GB/s of every stage whose algorithmic bytes are defined
+  cpu_baseline -- the unmodified reference (oracle/_ref, kind "reference") or our restatement (kind "port") on the host
+                  cores of this box: "value" = one frame, one thread (what MPEG's anchors use); "all_cores_value" = a GOF
+                  through the reference's own TBB path (ENABLE_TBB build with its vendored TBB: frames in parallel, points
+                  and voxels in parallel inside a frame), --nbThread = the physical cores
 """
 import argparse
 import json
@@ -47,7 +51,6 @@ def parse():
     ap.add_argument("--packing", default="all-intra", choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition: every frame on its own (the metric's configuration), the spatial-consistency chain, "
                          "or the chain + global patch allocation (with several ranks the chain runs on rank 0 over the patch records)")
-    ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -91,28 +94,52 @@ def make_frames(workload, indices, gen_procs=0):
         return pool.map(_gen, [(workload, i) for i in indices])
 
 
-# algorithmic HBM bytes of one launch of each kernel that can dominate (DESIGN.md section "kernels")
-def algorithmic_bytes(kernel, n_points):
-    per_point = {
-        "knn_self": 8 + 64,                 # 8 B point in, 16 x 4 B neighbour ids out
-        "knn8_recon_in_source": 8 + 64,     # per reconstructed point (M ~ 1.05 N): point in, 8 ids + 8 distances out
-        "knn1_source_in_recon": 8 + 8,
-        "normals": 64 + 24,                 # neighbour ids in, fp64 normal out (neighbour positions are cache hits)
-        "k:ccMutualMask": 64 + 2,           # own adjacency row in, 16-bit mask out (neighbour rows are cache hits)
-        "k:ccUnion": 64 + 2 + 1 + 1 + 4,    # row, mask, plane, raw flag, parent
-        "k:ccRelax": 64 + 2 + 1 + 1 + 4,    # per sweep
-        "initial_segmentation": 24 + 1,
+# Algorithmic HBM bytes per frame of each timed stage (N points, M reconstructed points, V refinement
+# voxels, L mean neighbourhood row, A canvas pixels, p occupancy precision).  A stage that runs several times per frame
+# (the refine sweeps: I times) is quoted per run.
+def algorithmic_bytes(stage, N, M=0, V=0, L=0.0, A=0, p=4):
+    table = {
+        "knn_self": (8 + 64) * N,                       # point in, 16 x 4 B neighbour ids out (S1 + S2 + S6 share the lists)
+        "normals": (64 + 24) * N,                       # neighbour ids in, fp64 normal out
+        "initial_segmentation": (24 + 1) * N,
+        "refine_setup": 14 * N + 4 * V * L,             # voxel keys + radius adjacency
+        "refine_sweep": 4 * V * L + 24 * V + 26 * N,    # one sweep: adjacency, histograms r/w, normals + partition
+        "k:ccMutualMask": (64 + 2) * N,
+        "k:ccUnion": (64 + 2 + 1 + 1 + 4) * N,
+        "k:ccRelax": (64 + 2 + 1 + 1 + 4) * N,
+        "knn8_recon_in_source": (8 + 64) * M,           # per reconstructed point: point in, 8 ids + 8 distances out
+        "knn1_source_in_recon": (8 + 8) * N,
+        "geometry_images": A * (1 + 1.0 / (p * p)) + 12 * A,
+        "reconstruct": 5 * A + 16 * M,
+        "attribute_images": 6 * A + 16 * A,             # scatter + push-pull + group dilation
     }
-    return per_point.get(kernel, 0) * n_points
+    return float(table.get(stage, 0))
 
 
-def cpu_baseline(workload, iterations):
-    """One frame of the same workload through the CPU checker (test infrastructure, used here only as the
-    reported baseline): the unmodified reference if oracle/_ref travelled with the repo, else our restatement."""
+def path_bytes(N, M, V, L, I, A, p):
+    """B_alg of the whole path S0-S22 per frame, with this run's V, L, canvas."""
+    return (94 * N + 25 * N + 14 * N + 4 * V * L + I * (4 * V * L + 24 * V + 26 * N) + 102 * N
+            + A * (1 + 1.0 / (p * p)) + 12 * A + 5 * A + 16 * M + 13 * N + 45 * M + 6 * A + 16 * A)
+
+
+def physical_cores():
+    try:
+        seen = set()
+        for cpu in os.sched_getaffinity(0):
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+                seen.add(f.read().strip())
+        return max(1, len(seen))
+    except (OSError, AttributeError):
+        return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(workload, iterations, gof):
+    """The same workload through the CPU checker (test infrastructure, used here only as the reported baseline): the
+    unmodified reference if oracle/_ref travelled with the repo, else our restatement.  One frame on one thread; then a GOF
+    through the reference's own TBB path on all physical cores (its ENABLE_TBB build with the vendored TBB)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    from tmc2_amd.synth import synth_cloud
-    frames = [synth_cloud(workload, 0)]
+    frames = gof[:1]
     if os.path.exists(ob.REF_PATH):
         eng, kind = ob.Reference(), "reference"
     else:
@@ -124,74 +151,32 @@ def cpu_baseline(workload, iterations):
     res = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": 1, "kind": kind,
            "sample": "1 frame of %s (%d points), stages S0-S22 (patch generation + occupancy/geometry/attribute images), "
                      "1 thread, %.1f s" % (workload, len(frames[0][0]), dt)}
-    if under_profiler():
+    if under_profiler() or not os.path.exists(ob.REF_TBB_PATH):
         return res
     try:                                                       # a side figure: never lose the line over it
-        res["all_cores"] = cpu_baseline_all_cores(workload, iterations, dt)
-    except Exception as e:
-        res["all_cores"] = {"error": repr(e)}
-    return res
-
-
-def cpu_baseline_all_cores(workload, iterations, one_frame_seconds):
-    """The reference's own parallelism is one TBB task per frame of the GOF (PCCEncoder.cpp:4729-4750); oracle/_ref is
-    built without TBB, so the same thing is measured with one PROCESS per frame: P different frames at once, P = the
-    frames of a GOF bounded by the cores and the memory of the host; frames/s = P / wall time from a common start."""
-    import subprocess
-    import tempfile
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    avail_gb = 8.0
-    try:
+        cores = physical_cores()
+        avail_gb = 8.0
         with open("/proc/meminfo") as f:
             avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
-    except Exception:
-        pass
-    procs = int(max(1, min(32, cores, avail_gb * 0.25 / 0.6)))      # a child peaks at ~0.45 GB on the longdress-like frame
-    if procs < 2:
-        return {"value": round(1.0 / one_frame_seconds, 5), "cores": 1, "sample": "single core host"}
-    with tempfile.TemporaryDirectory() as d:
-        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "%d,%s" % (i, d), "--workload", workload,
-                                  "--iterations", str(iterations)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(procs)]
-        limit = time.time() + 120 + 20 * one_frame_seconds
-        try:
-            while sum(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(procs)) < procs:
-                if time.time() > limit or any(k.poll() not in (None, 0) for k in kids):
-                    raise RuntimeError("a CPU baseline child failed before the start")
-                time.sleep(0.05)
-            t0 = time.time()
-            open(os.path.join(d, "go"), "w").close()
-            for k in kids:
-                k.wait(timeout=max(1.0, limit - time.time()))
-            wall = time.time() - t0
-            if any(k.returncode != 0 for k in kids):
-                raise RuntimeError("a CPU baseline child failed")
-        finally:
-            for k in kids:
-                if k.poll() is None:
-                    k.kill()
-    return {"value": round(procs / wall, 5), "unit": "frames/s", "cores": procs,
-            "sample": "%d frames of the GOF at once, one process per frame (the reference's per-frame TBB task), same stages, "
-                      "%.1f s wall on %d usable cores" % (procs, wall, cores)}
-
-
-def cpu_child(spec, workload, iterations):
-    index, d = spec.split(",", 1)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_binding as ob
-    from tmc2_amd.synth import synth_cloud
-    frames = [synth_cloud(workload, int(index))]
-    eng = ob.Reference() if os.path.exists(ob.REF_PATH) else ob.Oracle()
-    open(os.path.join(d, "ready" + index), "w").close()
-    while not os.path.exists(os.path.join(d, "go")):
-        time.sleep(0.01)
-    a = eng.phase_a(frames, iterations)
-    eng.phase_b(frames, a)
+        nfr = int(max(1, min(len(gof), avail_gb * 0.5 / 1.2)))              # ~1.2 GB per frame inside the reference's containers
+        gof = gof[:nfr]                                                      # (the frames of the timed GOF, generated already)
+        eng = ob.Reference(tbb=True, nb_thread=cores)
+        t = time.time()
+        a = eng.phase_a(gof, iterations)
+        eng.phase_b(gof, a)
+        wall = time.time() - t
+        res["all_cores_value"] = round(nfr / wall, 5)
+        res["all_cores"] = cores
+        res["all_cores_sample"] = ("%d frames of the GOF through the reference's own TBB path (ENABLE_TBB build, vendored TBB, "
+                                   "--nbThread=%d = physical cores of this host: frames in parallel, points / voxels in parallel "
+                                   "inside a frame), same stages, %.1f s wall" % (nfr, cores, wall))
+    except Exception as e:
+        res["all_cores_error"] = repr(e)
+    return res
 
 
 def main():
     a = parse()
-    if a.cpu_child:
-        return cpu_child(a.cpu_child, a.workload, a.iterations)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -208,7 +193,9 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     sharder = T.Sharder(rank, world, dist, "cuda:%d" % local)
-    workers = a.workers or max(1, min(len(clouds), 32, (os.cpu_count() or 8) // world))
+    # one hardware queue per in-flight frame (GPU_MAX_HW_QUEUES = 16, tmc2_amd/lib.py): streams that share a queue serialise
+    # behind each other, and 16 frames in flight keep the chip busy (measured: 12 -> 62, 16 -> 73, 20 -> 68, 24 -> 55, 32 -> 64 frames/s)
+    workers = a.workers or max(1, min(len(clouds), 16, (os.cpu_count() or 8) // world))
     T.load_library().tmc2_set_host_parallelism(max(1, a.host_steps // world))
     # many frames in flight and idle host cores: the (exact) host k-d tree builder leaves the GPU to the other stages
     kd_mode = {"device": 0, "host": 1, "adaptive": 2}.get(a.kdtree, 1 if workers >= 8 else 0)
@@ -290,18 +277,49 @@ def main():
     enc.phase_a(frames[:1], sharder=T.Sharder())
     enc.phase_b(frames[:1])
     solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
-    timed = ("knn_self", "normals", "initial_segmentation", "knn8_recon_in_source", "knn1_source_in_recon")
-    gpu_kernels = {k: v for k, v in solo_ms.items() if (k.startswith("k:") or k in timed) and ms.get(k, 0.0) > 0}
-    dom = max(gpu_kernels, key=gpu_kernels.get)
-    launches = max(1, calls.get(dom, 1))
-    avg_ms = ms[dom] / launches
-    pts_per_launch = n_points / max(1, len(frames))
-    achieved = algorithmic_bytes(dom, pts_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    s_avg = solo_ms[dom] / max(1, solo_calls.get(dom, 1))
-    s_ach = algorithmic_bytes(dom, len(clouds[0][0])) / (s_avg * 1e-3) / 1e9
-    traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), if this kernel is in them
+    n_frames = max(1, len(frames))
+    N = n_points / n_frames
+    M = float(frames[0].recon_count())
+    V = solo_ms.get("refine_voxels", 0.0) / max(1, solo_calls.get("refine_voxels", 1))
+    L = (solo_ms.get("refine_row_entries", 0.0) / max(1, solo_calls.get("refine_row_entries", 1))) / V if V else 0.0
+    A, I = float(W * H), a.iterations
+
+    def stage_view(name):
+        """(in-flight ms per launch, alone ms per launch, launches in the timed region, algorithmic bytes per launch)"""
+        if name == "refine_sweep":                         # one of the I sweeps of the refine_sweeps stage
+            fl, al, n_l = ms.get("refine_sweeps", 0.0), solo_ms.get("refine_sweeps", 0.0), calls.get("refine_sweeps", 0) * I
+            return fl / max(1, n_l), al / max(1, solo_calls.get("refine_sweeps", 1) * I), n_l, algorithmic_bytes(name, N, M, V, L, A)
+        if name == "patches":                              # S7-S9: connected components + per-patch build, all rounds
+            fl = ms.get("patches_cc", 0.0) + ms.get("patches_build", 0.0)
+            al = solo_ms.get("patches_cc", 0.0) + solo_ms.get("patches_build", 0.0)
+            n_l = calls.get("patches_build", 0)
+            return fl / max(1, n_l), al / max(1, solo_calls.get("patches_build", 1)), n_l, 102.0 * N
+        n_l = calls.get(name, 0)
+        return (ms.get(name, 0.0) / max(1, n_l), solo_ms.get(name, 0.0) / max(1, solo_calls.get(name, 1)), n_l,
+                algorithmic_bytes(name, N, M, V, L, A))
+
+    names = ["knn_self", "normals", "initial_segmentation", "refine_setup", "refine_sweep", "patches", "k:ccMutualMask",
+             "k:ccUnion", "k:ccRelax", "geometry_images", "reconstruct", "knn8_recon_in_source", "knn1_source_in_recon",
+             "attribute_images"]
+    per_stage, alone_total = {}, {}
+    for nm in names:
+        fl, al, n_l, by = stage_view(nm)
+        if n_l == 0 or al <= 0 or by <= 0:
+            continue
+        runs_per_frame = n_l / float(a.steps * n_frames)
+        alone_total[nm] = al * runs_per_frame             # GPU time per frame with the GPU to itself
+        per_stage[nm] = {"alone_ms": round(al, 4), "in_flight_ms": round(fl, 4), "runs_per_frame": round(runs_per_frame, 2),
+                         "MB": round(by / 1e6, 2), "alone_GB/s": round(by / (al * 1e-3) / 1e9, 1),
+                         "in_flight_GB/s": round(by / (fl * 1e-3) / 1e9, 1) if fl > 0 else None}
+    dom = max(alone_total, key=alone_total.get)
+    avg_ms, s_avg, launches, dom_bytes = stage_view(dom)
+    achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    s_ach = dom_bytes / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
+    fps = a.frames * a.steps / dt
+    b_alg = path_bytes(N, M, V, L, I, A, 4)
+    traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json), if this step is in them
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pmc = json.load(f)
         if dom in pmc.get("stages", {}) and a.workload == pmc.get("workload"):
             traffic = pmc["stages"][dom]["hbm_bytes_per_launch"]
@@ -323,7 +341,14 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                      "launches": launches, "alone_avg_launch_ms": round(s_avg, 4), "alone_achieved": round(s_ach, 2),
-                     "alone_frac": round(s_ach / 8000.0, 5)},
+                     "alone_frac": round(s_ach / 8000.0, 5),
+                     "algorithmic_MB_per_launch": round(dom_bytes / 1e6, 2),
+                     "what": "the dominant GPU step by time with the GPU to itself, over every timed stage with a contract byte "
+                             "count (SURVEY.md 8d); refine_sweep = one of the %d sweeps of S5 = 4VL + 24V + 26N bytes" % I,
+                     "N": int(N), "M": int(M), "V": int(V), "L": round(L, 1),
+                     "path": {"B_alg_GB_per_frame": round(b_alg / 1e9, 3), "achieved": round(b_alg * fps / 1e9, 1),
+                              "frac": round(b_alg * fps / 1e9 / 8000.0, 5)},
+                     "stages": per_stage},
         "stage_ms_per_frame": {k: round(v / (a.steps * len(frames)), 3) for k, v in sorted(ms.items())},
     }
     # the measured ceiling next to the nominal 8 TB/s: a device-to-device copy of 1 GiB, bytes read +
@@ -366,7 +391,9 @@ def main():
         except Exception as e:                                 # never lose the metric line over the side measurement
             out["tail"] = {"error": repr(e)}
     if a.cpu_baseline and world == 1:                          # rank 0 at N = 1 only (the contract of the bench line)
-        out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations)
+        out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations, clouds)
+        if out["cpu_baseline"].get("all_cores_value"):
+            out["cpu_baseline"]["gpu_over_all_cores"] = round(out["value"] / out["cpu_baseline"]["all_cores_value"], 2)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1140,7 +1140,9 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     }
     ctx->stageEnd( sidSweep );
     TMC2_HIP( hipGetLastError() );
-    ctx->stageAddHostMs( "refine_sweeps_executed", double( iterationCount ) );  // (a count, not milliseconds)
+    ctx->stageAddHostMs( "refine_sweeps_executed", double( iterationCount ) );  // (counts, not milliseconds: what the
+    ctx->stageAddHostMs( "refine_voxels", double( V ) );                        //  roofline of a sweep is quoted on,
+    ctx->stageAddHostMs( "refine_row_entries", double( totalLen ) );            //  V and L = entries / V)
     if ( wantTiming ) {
       unsigned long long t[8];
       TMC2_HIP( hipMemcpyAsync( t, d_timing.p, 64, hipMemcpyDeviceToHost, s ) );

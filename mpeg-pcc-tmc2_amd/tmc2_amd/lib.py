@@ -391,6 +391,11 @@ class Frame:
     def encoder_generate_attribute_images(self):
         _check(self.L.tmc2_encoder_generate_attribute_images(self.h))
 
+    def recon_count(self):
+        """Points of the reconstructed cloud (0 before the reconstruction)."""
+        self.L.tmc2_frame_recon_count.restype = C.c_int64
+        return int(self.L.tmc2_frame_recon_count(self.h))
+
     def get_reconstruction(self, colors=True):
         self.L.tmc2_frame_recon_count.restype = C.c_int64
         M = self.L.tmc2_frame_recon_count(self.h)

@@ -436,6 +436,21 @@ int ref_gof_set_voxel_dimension_refine( int voxDim ) {
   return 0;
 }
 
+// --nbThread of PccAppEncoder: the width of the reference's TBB arenas (frames of a GOF in generateSegments, points and
+// voxels inside normal estimation / segmentation, ...).  Only the ENABLE_TBB build (libtmc2ref_tbb.so) runs anything in
+// parallel; results do not depend on it.  After ref_gof_begin*.
+int ref_gof_set_nb_thread( int nbThread ) {
+  g_gof->params.nbThread_ = size_t( nbThread );
+  return 0;
+}
+int ref_built_with_tbb() {
+#if defined( ENABLE_TBB )
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 // per list position: position of the matched patch in the previous frame's list, or -1
 int ref_gof_get_patch_matches( int frame, int32_t* out ) {
   auto& patches = g_gof->context.getFrames()[size_t( frame )].getTitleFrameContext().getPatches();

@@ -38,6 +38,7 @@ def seg_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0), vox_dim=4):
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libtmc2ref.so")
+REF_TBB_PATH = os.path.join(ROOT, "oracle", "_ref", "libtmc2ref_tbb.so")   # the same sources with ENABLE_TBB + the vendored TBB
 
 
 def _p(a):
@@ -416,8 +417,13 @@ class Oracle:
 
 
 class Reference:
-    def __init__(self):
-        self.L = C.CDLL(REF_PATH)
+    """The unmodified reference compiled in place (oracle/Makefile).  tbb=True: the ENABLE_TBB build with the vendored TBB;
+    nb_thread = the reference's --nbThread (width of its TBB arenas) for the GOF entry points."""
+
+    def __init__(self, tbb=False, nb_thread=1):
+        self.L = C.CDLL(REF_TBB_PATH if tbb else REF_PATH)
+        self.nb_thread = int(nb_thread)
+        assert bool(self.L.ref_built_with_tbb()) == bool(tbb)
 
     def transfer_colors(self, src_xyz, src_rgb, tgt_xyz):
         src_xyz, tgt_xyz = _i16(src_xyz), _i16(tgt_xyz)
@@ -582,6 +588,7 @@ class Reference:
         L.ref_gof_begin2(len(frames), int(iterations), int(bits3d - 1), int(occ_precision), int(min_w), int(min_h),
                          int(constrained_pack))
         L.ref_gof_set_voxel_dimension_refine(int(vox_dim))
+        L.ref_gof_set_nb_thread(self.nb_thread)
         keep = []
         for i, (xyz, rgb) in enumerate(frames):
             xyz = _i16(xyz)

@@ -554,13 +554,35 @@ def test_host_pack_gof_records_matches_the_oracle_chain(oracle, seed):
 
 def test_bench_cpu_baseline_leg_reports_one_core_and_all_cores():
     """bench.py's cpu_baseline leg (the checker timed as the reported baseline, never part of the product path): the
-    one-thread figure and the per-frame-process figure, on the smallest workload."""
+    one-thread figure and, flat next to it, the figure of a GOF through the reference's own TBB path (its ENABLE_TBB build)
+    on the physical cores, on the smallest workload."""
     import importlib.util
+    import oracle_binding as ob
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    res = bench.cpu_baseline("tiny", 2)
+    from tmc2_amd.synth import synth_cloud
+    res = bench.cpu_baseline("tiny", 2, [synth_cloud("tiny", f) for f in range(4)])
     assert res["unit"] == "frames/s" and res["cores"] == 1 and res["value"] > 0 and res["kind"] in ("reference", "port")
-    allc = res["all_cores"]
-    assert "error" not in allc, allc
-    assert allc["value"] > 0 and 1 <= allc["cores"] <= 32
+    if os.path.exists(ob.REF_TBB_PATH):
+        assert "all_cores_error" not in res, res
+        assert res["all_cores_value"] > 0 and res["all_cores"] == bench.physical_cores() and "TBB" in res["all_cores_sample"]
+
+
+def test_reference_tbb_build_gives_the_serial_results(reference):
+    """oracle/_ref/libtmc2ref_tbb.so (ENABLE_TBB + the vendored TBB, what bench.py times as the all-core baseline) against the
+    serial build on a small GOF: frames in parallel, points / voxels in parallel inside a frame, same bytes."""
+    import oracle_binding as ob
+    if not os.path.exists(ob.REF_TBB_PATH):
+        pytest.skip("oracle/_ref/libtmc2ref_tbb.so not built")
+    from tmc2_amd.synth import synth_cloud
+    frames = [synth_cloud("tiny", f) for f in range(3)]
+    par = ob.Reference(tbb=True, nb_thread=4)
+    a1, a4 = reference.phase_a(frames, 4, 11, 4), None
+    b1 = reference.phase_b(frames, a1, 4)
+    a4 = par.phase_a(frames, 4, 11, 4)
+    b4 = par.phase_b(frames, a4, 4)
+    for x, y in zip(a1, a4):
+        assert all(np.array_equal(x[k], y[k]) for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"))
+    for x, y in zip(b1, b4):
+        assert all(np.array_equal(x[k], y[k]) for k in ("recon_xyz", "recon_rgb", "point_to_pixel", "attribute"))
