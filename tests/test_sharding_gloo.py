@@ -158,7 +158,7 @@ def test_phase_a_records_route_orchestration_with_fake_frames():
             self.canvas = (W, H, prec)
 
     class FakeEncoder:
-        iterations, bits3d, min_w, min_h, occ_precision = 2, 10, 512, 512, 4
+        iterations, bits3d, min_w, min_h, occ_precision, vox_dim = 2, 10, 512, 512, 4, 4
 
         def _per_worker(self, frames, fn):
             return [fn(fr) for fr in frames]
