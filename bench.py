@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
+    ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--packing", default="all-intra", choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition: every frame on its own (the metric's configuration), the spatial-consistency chain, "
                          "or the chain + global patch allocation (with several ranks the chain runs on rank 0 over the patch records)")
@@ -158,7 +159,7 @@ def cpu_baseline(workload, iterations, gof):
         avail_gb = 8.0
         with open("/proc/meminfo") as f:
             avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
-        nfr = int(max(1, min(len(gof), avail_gb * 0.5 / 1.2)))              # ~1.2 GB per frame inside the reference's containers
+        nfr = int(max(1, min(len(gof), 16, avail_gb * 0.5 / 1.2)))          # bounded sample; ~1.2 GB per frame inside the reference's containers
         gof = gof[:nfr]                                                      # (the frames of the timed GOF, generated already)
         eng = ob.Reference(tbb=True, nb_thread=cores)
         t = time.time()
@@ -172,11 +173,75 @@ def cpu_baseline(workload, iterations, gof):
                                    "inside a frame), same stages, %.1f s wall" % (nfr, cores, wall))
     except Exception as e:
         res["all_cores_error"] = repr(e)
+    try:
+        fp = cpu_baseline_frame_processes(workload, iterations, dt)
+        res["frame_processes_value"], res["frame_processes"], res["frame_processes_sample"] = fp["value"], fp["cores"], fp["sample"]
+    except Exception as e:
+        res["frame_processes_error"] = repr(e)
     return res
+
+
+def cpu_baseline_frame_processes(workload, iterations, one_frame_seconds):
+    """An upper bound on what frame-level parallelism alone can give the reference on this host (its own TBB path also runs
+    the frames of a GOF side by side, PCCEncoder.cpp:4729-4750, but serialises parts of the path): the serial build, one
+    PROCESS per frame, P different frames at once, frames/s = P / wall time from a common start."""
+    import subprocess
+    import tempfile
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail_gb = 8.0
+    try:
+        with open("/proc/meminfo") as f:
+            avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
+    except Exception:
+        pass
+    procs = int(max(1, min(32, cores, avail_gb * 0.25 / 0.6)))      # a child peaks at ~0.45 GB on the longdress-like frame
+    if procs < 2:
+        return {"value": round(1.0 / one_frame_seconds, 5), "cores": 1, "sample": "single core host"}
+    with tempfile.TemporaryDirectory() as d:
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "%d,%s" % (i, d), "--workload", workload,
+                                  "--iterations", str(iterations)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(procs)]
+        limit = time.time() + 120 + 20 * one_frame_seconds
+        try:
+            while sum(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(procs)) < procs:
+                if time.time() > limit or any(k.poll() not in (None, 0) for k in kids):
+                    raise RuntimeError("a CPU baseline child failed before the start")
+                time.sleep(0.05)
+            t0 = time.time()
+            open(os.path.join(d, "go"), "w").close()
+            for k in kids:
+                k.wait(timeout=max(1.0, limit - time.time()))
+            wall = time.time() - t0
+            if any(k.returncode != 0 for k in kids):
+                raise RuntimeError("a CPU baseline child failed")
+        finally:
+            for k in kids:
+                if k.poll() is None:
+                    k.kill()
+    return {"value": round(procs / wall, 5), "unit": "frames/s", "cores": procs,
+            "sample": "%d frames of the GOF at once, one process of the serial build per frame, same stages, "
+                      "%.1f s wall on %d usable hardware threads" % (procs, wall, cores)}
+
+
+def cpu_child(spec, workload, iterations):
+    index, d = spec.split(",", 1)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from tmc2_amd.synth import synth_cloud
+    frames = [synth_cloud(workload, int(index))]
+    eng = ob.Reference() if os.path.exists(ob.REF_PATH) else ob.Oracle()
+    open(os.path.join(d, "ready" + index), "w").close()
+    while not os.path.exists(os.path.join(d, "go")):
+        time.sleep(0.01)
+    a = eng.phase_a(frames, iterations)
+    eng.phase_b(frames, a)
+
+
 
 
 def main():
     a = parse()
+    if a.cpu_child:
+        return cpu_child(a.cpu_child, a.workload, a.iterations)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -392,8 +457,9 @@ def main():
             out["tail"] = {"error": repr(e)}
     if a.cpu_baseline and world == 1:                          # rank 0 at N = 1 only (the contract of the bench line)
         out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations, clouds)
-        if out["cpu_baseline"].get("all_cores_value"):
-            out["cpu_baseline"]["gpu_over_all_cores"] = round(out["value"] / out["cpu_baseline"]["all_cores_value"], 2)
+        for key in ("all_cores_value", "frame_processes_value"):
+            if out["cpu_baseline"].get(key):
+                out["cpu_baseline"]["gpu_over_" + key[:-6]] = round(out["value"] / out["cpu_baseline"][key], 2)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -567,6 +567,8 @@ def test_bench_cpu_baseline_leg_reports_one_core_and_all_cores():
     if os.path.exists(ob.REF_TBB_PATH):
         assert "all_cores_error" not in res, res
         assert res["all_cores_value"] > 0 and res["all_cores"] == bench.physical_cores() and "TBB" in res["all_cores_sample"]
+    assert "frame_processes_error" not in res, res
+    assert res["frame_processes_value"] > 0 and 1 <= res["frame_processes"] <= 32
 
 
 def test_reference_tbb_build_gives_the_serial_results(reference):
