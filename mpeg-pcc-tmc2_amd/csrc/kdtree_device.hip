@@ -23,6 +23,10 @@
 // levels.  Per-node quantities that cost a handful of loads (split rule, sweep limits) are re-derived per point rather
 // than materialised by extra per-node launches.  Termination needs the host only from the level on at which the tree
 // CAN end (10 * 2^level >= n), and then once per three levels (launches past the last level find nothing to do).
+// The level passes only carry the top of the tree: a segment of at most kRetire points is RETIRED at the level it appears
+// and finished later by one wavefront with its points in LDS (finishSubtreesKernel): nodes down to kLaneMax points by the
+// wave together (the same closed-form sweeps, ranks from ballots), smaller ones by single lanes running nanoflann's
+// recursion literally.  A 0.84 M-point frame takes ~ 12 levels of passes instead of ~ 24.
 // (A single persistent launch with grid-wide barriers was measured too: on this multi-XCD part every barrier is an L2
 // write-back + invalidate per workgroup, ~45 us per pass, and the builds of concurrent frames serialise.  Separate
 // launches leave the gaps of one frame to the passes of the others.)
@@ -39,6 +43,9 @@ constexpr int      kWaves     = kBlock / 64;
 constexpr int      kScanTile  = kBlock * 8;
 constexpr int      kLeafMax   = 10;
 constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kernels
+constexpr int      kRetire    = 1024;  // segments of at most this many points leave the level passes (one wavefront each)
+constexpr int      kLaneMax   = 32;    // ... and inside a wavefront's subtree, nodes of at most this many points go to single lanes
+constexpr int      kSmallMax  = 128;   // such nodes are handed to the lanes in batches of at most this many
 
 struct BuildSeg {
   uint32_t begin, end;    // range in tree order
@@ -50,6 +57,13 @@ struct BuildSeg {
   int32_t  cut;
   uint32_t mid;           // begin + idx: first point of the right child
   uint32_t slot;          // next-level slot of the left child (right = slot + 1)
+};
+
+// a segment handed to finishSubtreesKernel: its slice of the tree-order arrays, its (allocated) node id, loose box, level
+struct RetiredSeg {
+  uint32_t begin, end, node, level;
+  int16_t  lo[3], hi[3];
+  int32_t  root;  // 1: the root of the whole tree (its loose box is its tight range)
 };
 
 struct BuildArgs {
@@ -64,6 +78,9 @@ struct BuildArgs {
   uint32_t* nodeCount;
   int32_t*  rootBox;    // [6]
   uint32_t* levels;     // out: number of levels
+  RetiredSeg* retired;  // [n / (kRetire / 2) + 2]: every retired segment has a parent of more than kRetire points
+  uint32_t*   retiredCount;
+  uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
 };
 
 __device__ __forceinline__ int coordOf( const Pt p, int d ) { return d == 0 ? p.x : ( d == 1 ? p.y : p.z ); }
@@ -302,7 +319,15 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
     }
     int     cutDim;
     int32_t cut;
-    if ( splitRule( q, cutDim, cut ) ) {
+    const uint32_t cnt = q->end - q->begin;
+    if ( cnt > uint32_t( kLeafMax ) && cnt <= uint32_t( kRetire ) ) {  // the rest of this subtree is built in LDS
+      RetiredSeg r;
+      r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
+      r.root  = q->parent == kNone ? 1 : 0;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
+      a.retired[atomicAdd( a.retiredCount, 1u )] = r;
+      q->split = 0;
+    } else if ( splitRule( q, cutDim, cut ) ) {
       q->split = 1, q->cutDim = uint8_t( cutDim ), q->cut = cut;
     } else {
       KdNode nd;
@@ -323,7 +348,8 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
         if ( s != kNone ) {
           int     cutDim;
           int32_t cut;
-          if ( splitRule( cur + s, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
+          const BuildSeg* q = cur + s;
+          if ( q->end - q->begin > uint32_t( kRetire ) && splitRule( q, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
         }
       }
       v[k] = f;
@@ -552,6 +578,308 @@ __global__ __launch_bounds__( kBlock ) void swapTwoKernel( BuildArgs a, uint32_t
   }
 }
 
+
+// ---- the retired subtrees, one wavefront each, points in LDS ----------------------------------------------------------------
+struct SubNode {  // a node of the subtree waiting to be processed (wave stack / small-node list / lane stack)
+  uint16_t begin, end;  // range inside the segment
+  uint32_t node;        // node id (allocated by the parent)
+  int16_t  lo[3], hi[3];
+  uint16_t depth;       // levels below the segment's root
+};
+
+struct SplitRule {
+  int     dim;
+  int32_t cut;
+};
+// nanoflann's middleSplit_ on a loose box and the tight ranges of the points (as splitRule() above / kdtree_build.cpp)
+__device__ __forceinline__ SplitRule splitOf( const int16_t ( &lo )[3], const int16_t ( &hi )[3], const int32_t ( &mn )[3],
+                                              const int32_t ( &mx )[3] ) {
+  const int32_t maxSpan = max( int32_t( hi[0] ) - lo[0], max( int32_t( hi[1] ) - lo[1], int32_t( hi[2] ) - lo[2] ) );
+  SplitRule     r;
+  r.dim              = 0;
+  int32_t bestSpread = -1;
+#pragma unroll
+  for ( int d = 0; d < 3; ++d ) {
+    if ( double( int32_t( hi[d] ) - lo[d] ) > ( 1.0 - 0.00001 ) * double( maxSpan ) ) {
+      const int32_t spread = mx[d] - mn[d];
+      if ( spread > bestSpread ) {
+        bestSpread = spread;
+        r.dim      = d;
+      }
+    }
+  }
+  const int32_t l = r.dim == 0 ? lo[0] : ( r.dim == 1 ? lo[1] : lo[2] ), h = r.dim == 0 ? hi[0] : ( r.dim == 1 ? hi[1] : hi[2] );
+  const int32_t a = r.dim == 0 ? mn[0] : ( r.dim == 1 ? mn[1] : mn[2] ), b = r.dim == 0 ? mx[0] : ( r.dim == 1 ? mx[1] : mx[2] );
+  r.cut           = min( max( ( l + h ) / 2, a ), b );
+  return r;
+}
+
+__device__ __forceinline__ void waveFence() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); }
+
+// One sweep of the two-pass partition by a wavefront, on P[0..count) / perm[0..count) in LDS: left class = "value < c", nL of
+// them.  The i-th misplaced element from the left swaps with the i-th misplaced element from the right (ranks from ballots).
+__device__ __forceinline__ void waveSweep( Pt* P, uint32_t* perm, uint32_t count, uint32_t nL, int dim, int32_t c, uint16_t* lst,
+                                           int lane ) {
+  uint16_t* fromLeft  = lst;
+  uint16_t* fromRight = lst + nL + 1;
+  uint32_t  m         = 0;
+  for ( uint32_t i0 = 0; i0 < nL; i0 += 64 ) {
+    const uint32_t i = i0 + lane;
+    const bool     f = i < nL && coordOf( P[i], dim ) >= c;
+    const unsigned long long b = __ballot( f );
+    if ( f ) fromLeft[m + __popcll( b & ( ( 1ull << lane ) - 1ull ) )] = uint16_t( i );
+    m += uint32_t( __popcll( b ) );
+  }
+  uint32_t m2 = 0;
+  for ( uint32_t top = count; top > nL; ) {  // descending: lane 0 holds the highest position of the chunk
+    const uint32_t span = min( 64u, top - nL );
+    const bool     in   = uint32_t( lane ) < span;
+    const uint32_t j    = in ? top - 1u - uint32_t( lane ) : 0u;
+    const bool     f    = in && coordOf( P[j], dim ) < c;
+    const unsigned long long b = __ballot( f );
+    if ( f ) fromRight[m2 + __popcll( b & ( ( 1ull << lane ) - 1ull ) )] = uint16_t( j );
+    m2 += uint32_t( __popcll( b ) );
+    top -= span;
+  }
+  waveFence();
+  for ( uint32_t t = lane; t < m; t += 64 ) {  // (m == m2: every misplaced element on one side has its partner on the other)
+    const uint32_t x = fromLeft[t], y = fromRight[t];
+    const Pt       px = P[x], py = P[y];
+    const uint32_t ix = perm[x], iy = perm[y];
+    P[x] = py, P[y] = px, perm[x] = iy, perm[y] = ix;
+  }
+  waveFence();
+}
+
+// nanoflann's divideTree on P[b..e) by ONE lane (literal two-pass planeSplit with std::swap semantics), explicit stack.
+__device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t globalBegin, KdNode* __restrict__ nodes,
+                             uint32_t* __restrict__ nodeCount, uint32_t& maxDepth, uint32_t* __restrict__ refuse ) {
+  SubNode stack[40];  // a node of at most kLaneMax points is at most kLaneMax - kLeafMax levels deep
+  int     sp  = 0;
+  stack[sp++] = root;
+  while ( sp > 0 ) {
+    const SubNode  q     = stack[--sp];
+    const uint32_t count = uint32_t( q.end ) - q.begin;
+    maxDepth             = max( maxDepth, uint32_t( q.depth ) );
+    if ( count <= uint32_t( kLeafMax ) ) {
+      KdNode nd;
+      nd.a = int32_t( globalBegin + q.begin ), nd.b = int32_t( globalBegin + q.end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
+      nodes[q.node] = nd;
+      continue;
+    }
+    Pt*      pts = P + q.begin;
+    uint32_t* id = perm + q.begin;
+    int32_t  mn[3] = {pts[0].x, pts[0].y, pts[0].z}, mx[3] = {pts[0].x, pts[0].y, pts[0].z};
+    for ( uint32_t i = 1; i < count; ++i ) {
+      const Pt p = pts[i];
+      mn[0] = min( mn[0], int32_t( p.x ) ), mx[0] = max( mx[0], int32_t( p.x ) );
+      mn[1] = min( mn[1], int32_t( p.y ) ), mx[1] = max( mx[1], int32_t( p.y ) );
+      mn[2] = min( mn[2], int32_t( p.z ) ), mx[2] = max( mx[2], int32_t( p.z ) );
+    }
+    const SplitRule r = splitOf( q.lo, q.hi, mn, mx );
+    // planeSplit (nanoflann.hpp:1154-1181): two Hoare sweeps with swaps
+    uint32_t left = 0, right = count - 1;
+    for ( ;; ) {
+      while ( left <= right && coordOf( pts[left], r.dim ) < r.cut ) ++left;
+      while ( right && left <= right && coordOf( pts[right], r.dim ) >= r.cut ) --right;
+      if ( left > right || !right ) break;
+      const Pt       tp = pts[left];
+      const uint32_t ti = id[left];
+      pts[left] = pts[right], id[left] = id[right], pts[right] = tp, id[right] = ti;
+      ++left;
+      --right;
+    }
+    const uint32_t lim1 = left;
+    right               = count - 1;
+    for ( ;; ) {
+      while ( left <= right && coordOf( pts[left], r.dim ) <= r.cut ) ++left;
+      while ( right && left <= right && coordOf( pts[right], r.dim ) > r.cut ) --right;
+      if ( left > right || !right ) break;
+      const Pt       tp = pts[left];
+      const uint32_t ti = id[left];
+      pts[left] = pts[right], id[left] = id[right], pts[right] = tp, id[right] = ti;
+      ++left;
+      --right;
+    }
+    const uint32_t lim2 = left, half = count / 2;
+    const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
+    int32_t        lmax = int32_t( 0x80000000 ), rmin = 0x7FFFFFFF;  // tight ranges of the children on the cut dimension
+    for ( uint32_t i = 0; i < idx; ++i ) lmax = max( lmax, coordOf( pts[i], r.dim ) );
+    for ( uint32_t i = idx; i < count; ++i ) rmin = min( rmin, coordOf( pts[i], r.dim ) );
+    const uint32_t id0 = atomicAdd( nodeCount, 2u );
+    KdNode         nd;
+    nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( lmax ), nd.divhigh = int16_t( rmin ), nd.dim = r.dim;
+    nodes[q.node] = nd;
+    SubNode l = q, rr = q;
+    l.end = uint16_t( q.begin + idx ), l.node = id0, l.depth = uint16_t( q.depth + 1 );
+    rr.begin = uint16_t( q.begin + idx ), rr.node = id0 + 1, rr.depth = uint16_t( q.depth + 1 );
+    const int16_t cut = int16_t( r.cut );
+    if ( r.dim == 0 ) l.hi[0] = cut, rr.lo[0] = cut;
+    if ( r.dim == 1 ) l.hi[1] = cut, rr.lo[1] = cut;
+    if ( r.dim == 2 ) l.hi[2] = cut, rr.lo[2] = cut;
+    if ( sp > 37 ) {  // (cannot happen for kLaneMax points; never write past the stack)
+      atomicMax( refuse, 0x10000u );
+      return;
+    }
+    stack[sp++] = rr;
+    stack[sp++] = l;
+  }
+}
+
+constexpr int kFinishWaves = 2;  // (32 KB of LDS per workgroup: several workgroups per CU)
+
+__global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( BuildArgs a ) {
+  __shared__ Pt       sP[kFinishWaves][kRetire];
+  __shared__ uint32_t sPerm[kFinishWaves][kRetire];
+  __shared__ uint16_t sList[kFinishWaves][kRetire + 4];
+  __shared__ SubNode  sStack[kFinishWaves][kMaxLevels + 2];
+  __shared__ SubNode  sSmall[kFinishWaves][kSmallMax];
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t total = *a.retiredCount;
+  Pt*            P     = sP[wave];
+  uint32_t*      perm  = sPerm[wave];
+  uint16_t*      lst   = sList[wave];
+  SubNode*       stack = sStack[wave];
+  SubNode*       small = sSmall[wave];
+  uint32_t       maxDepth = 0;
+  for ( uint32_t s = blockIdx.x * kFinishWaves + wave; s < total; s += gridDim.x * kFinishWaves ) {  // (uniform per wave)
+    const RetiredSeg seg = a.retired[s];
+    const uint32_t   cnt = seg.end - seg.begin;
+    for ( uint32_t i = lane; i < cnt; i += 64 ) {
+      P[i]    = a.P[seg.begin + i];
+      perm[i] = a.perm[seg.begin + i];
+    }
+    waveFence();
+    int sp = 0, nSmall = 0;
+    if ( lane == 0 ) {
+      SubNode r;
+      r.begin = 0, r.end = uint16_t( cnt ), r.node = seg.node, r.depth = 0;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = seg.lo[d], r.hi[d] = seg.hi[d];
+      stack[0] = r;
+    }
+    sp = 1;
+    bool isRoot = seg.root != 0;
+    waveFence();
+    while ( sp > 0 ) {
+      const SubNode  q     = stack[--sp];
+      const uint32_t count = uint32_t( q.end ) - q.begin;
+      if ( uint32_t( q.depth ) + seg.level >= uint32_t( kMaxLevels ) - 1u ) {  // deeper than the k-NN traversal stack: refused
+        if ( lane == 0 ) atomicMax( a.finishDepth, 0x10000u );
+        break;
+      }
+      if ( nSmall == kSmallMax ) {  // (a degenerate subtree can shed hundreds of tiny nodes: the lanes take them in batches)
+        waveFence();
+        uint32_t d = 0;
+        for ( int t = lane; t < nSmall; t += 64 ) laneSubtree( P, perm, small[t], seg.begin, a.nodes, a.nodeCount, d, a.finishDepth );
+#pragma unroll
+        for ( int off = 32; off > 0; off >>= 1 ) d = max( d, __shfl_xor( d, off, 64 ) );
+        maxDepth = max( maxDepth, d );
+        nSmall   = 0;
+        waveFence();
+      }
+      if ( count <= uint32_t( kLaneMax ) && !isRoot ) {  // (the tree's root needs its tight range as loose box: handled below)
+        if ( lane == 0 ) small[nSmall] = q;
+        ++nSmall;
+        continue;
+      }
+      Pt*       pts = P + q.begin;
+      uint32_t* id  = perm + q.begin;
+      // tight ranges
+      int mn0 = 0x7FFFFFFF, mn1 = mn0, mn2 = mn0, mx0 = int( 0x80000000 ), mx1 = mx0, mx2 = mx0;
+      for ( uint32_t i = lane; i < count; i += 64 ) {
+        const Pt p = pts[i];
+        mn0 = min( mn0, int( p.x ) ), mx0 = max( mx0, int( p.x ) );
+        mn1 = min( mn1, int( p.y ) ), mx1 = max( mx1, int( p.y ) );
+        mn2 = min( mn2, int( p.z ) ), mx2 = max( mx2, int( p.z ) );
+      }
+#pragma unroll
+      for ( int off = 32; off > 0; off >>= 1 ) {
+        mn0 = min( mn0, __shfl_xor( mn0, off, 64 ) ), mn1 = min( mn1, __shfl_xor( mn1, off, 64 ) ), mn2 = min( mn2, __shfl_xor( mn2, off, 64 ) );
+        mx0 = max( mx0, __shfl_xor( mx0, off, 64 ) ), mx1 = max( mx1, __shfl_xor( mx1, off, 64 ) ), mx2 = max( mx2, __shfl_xor( mx2, off, 64 ) );
+      }
+      const int32_t mn[3] = {mn0, mn1, mn2}, mx[3] = {mx0, mx1, mx2};
+      int16_t       lo[3], hi[3];
+      for ( int d = 0; d < 3; ++d ) lo[d] = isRoot ? int16_t( mn[d] ) : q.lo[d], hi[d] = isRoot ? int16_t( mx[d] ) : q.hi[d];
+      if ( isRoot && lane == 0 )
+        for ( int d = 0; d < 3; ++d ) a.rootBox[d] = mn[d], a.rootBox[3 + d] = mx[d];
+      isRoot = false;
+      if ( count <= uint32_t( kLeafMax ) ) {  // (only a root of at most kLeafMax points gets here)
+        if ( lane == 0 ) {
+          KdNode nd;
+          nd.a = int32_t( seg.begin + q.begin ), nd.b = int32_t( seg.begin + q.end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
+          a.nodes[q.node] = nd;
+        }
+        maxDepth = max( maxDepth, uint32_t( q.depth ) );
+        continue;
+      }
+      if ( count <= uint32_t( kLaneMax ) ) {  // a small root: to the lanes, with its loose box resolved
+        if ( lane == 0 ) {
+          SubNode t = q;
+          for ( int d = 0; d < 3; ++d ) t.lo[d] = lo[d], t.hi[d] = hi[d];
+          small[nSmall] = t;
+        }
+        ++nSmall;
+        continue;
+      }
+      const SplitRule r = splitOf( lo, hi, mn, mx );
+      // class counts of both sweeps in one pass
+      uint32_t lt = 0, le = 0;
+      for ( uint32_t i = lane; i < count; i += 64 ) {
+        const int32_t x = coordOf( pts[i], r.dim );
+        lt += uint32_t( x < r.cut ), le += uint32_t( x <= r.cut );
+      }
+#pragma unroll
+      for ( int off = 32; off > 0; off >>= 1 ) lt += __shfl_xor( lt, off, 64 ), le += __shfl_xor( le, off, 64 );
+      waveSweep( pts, id, count, lt, r.dim, r.cut, lst, lane );
+      waveSweep( pts + lt, id + lt, count - lt, le - lt, r.dim, r.cut + 1, lst, lane );
+      const uint32_t half = count / 2, idx = lt > half ? lt : ( le < half ? le : half );
+      int            lmax = int( 0x80000000 ), rmin = 0x7FFFFFFF;
+      for ( uint32_t i = lane; i < count; i += 64 ) {
+        const int x = coordOf( pts[i], r.dim );
+        if ( i < idx ) lmax = max( lmax, x ); else rmin = min( rmin, x );
+      }
+#pragma unroll
+      for ( int off = 32; off > 0; off >>= 1 ) lmax = max( lmax, __shfl_xor( lmax, off, 64 ) ), rmin = min( rmin, __shfl_xor( rmin, off, 64 ) );
+      uint32_t id0 = 0;
+      if ( lane == 0 ) id0 = atomicAdd( a.nodeCount, 2u );
+      id0 = __shfl( id0, 0, 64 );
+      if ( lane == 0 ) {
+        KdNode nd;
+        nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( lmax ), nd.divhigh = int16_t( rmin ), nd.dim = r.dim;
+        a.nodes[q.node] = nd;
+        SubNode l, rr;
+        l.begin = q.begin, l.end = uint16_t( q.begin + idx ), l.node = id0, l.depth = uint16_t( q.depth + 1 );
+        rr.begin = uint16_t( q.begin + idx ), rr.end = q.end, rr.node = id0 + 1, rr.depth = uint16_t( q.depth + 1 );
+        for ( int d = 0; d < 3; ++d ) l.lo[d] = rr.lo[d] = lo[d], l.hi[d] = rr.hi[d] = hi[d];
+        const int16_t cut = int16_t( r.cut );
+        if ( r.dim == 0 ) l.hi[0] = cut, rr.lo[0] = cut;
+        if ( r.dim == 1 ) l.hi[1] = cut, rr.lo[1] = cut;
+        if ( r.dim == 2 ) l.hi[2] = cut, rr.lo[2] = cut;
+        stack[sp]     = rr;
+        stack[sp + 1] = l;
+      }
+      sp += 2;
+      maxDepth = max( maxDepth, uint32_t( q.depth ) );
+      waveFence();
+    }
+    // the small nodes, one lane each
+    waveFence();
+    uint32_t laneDepth = 0;
+    for ( int t = lane; t < nSmall; t += 64 ) laneSubtree( P, perm, small[t], seg.begin, a.nodes, a.nodeCount, laneDepth, a.finishDepth );
+#pragma unroll
+    for ( int off = 32; off > 0; off >>= 1 ) laneDepth = max( laneDepth, __shfl_xor( laneDepth, off, 64 ) );
+    maxDepth = max( maxDepth, laneDepth );
+    waveFence();
+    for ( uint32_t i = lane; i < cnt; i += 64 ) {
+      a.P[seg.begin + i]    = P[i];
+      a.perm[seg.begin + i] = perm[i];
+    }
+    waveFence();
+    if ( lane == 0 ) atomicMax( a.finishDepth, seg.level + maxDepth + 1u );  // levels down to the deepest node of this subtree
+    maxDepth = 0;
+  }
+}
+
 }  // namespace
 
 // Builds the tree of d_pts[0..n) on the context's stream.  Outputs: points and permutation in tree order, node records
@@ -569,8 +897,11 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( maxNode ) );
-  DevBuf<uint32_t> d_work, d_small;
-  DevBuf<BuildSeg> d_segs;
+  DevBuf<uint32_t>   d_work, d_small;
+  DevBuf<BuildSeg>   d_segs;
+  DevBuf<RetiredSeg> d_retired;
+  const size_t       maxRetired = size_t( n ) / ( kLeafMax + 1 ) + 2;  // (retired segments are disjoint and hold > kLeafMax points)
+  TMC2_TRY( d_retired.alloc( maxRetired ) );
   TMC2_TRY( d_work.alloc( 4 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, list, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
@@ -584,6 +915,9 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.nodeCount = d_small.p + kMaxLevels + 1;
   a.levels    = d_small.p + kMaxLevels + 2;
   a.rootBox   = reinterpret_cast<int32_t*>( d_small.p + kMaxLevels + 8 );
+  a.retired      = d_retired.p;
+  a.retiredCount = d_small.p + kMaxLevels + 3;
+  a.finishDepth  = d_small.p + kMaxLevels + 4;
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
   hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
@@ -592,7 +926,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   for ( uint32_t level = 0; level < uint32_t( kMaxLevels ) && found < 0; ) {
     // levels that cannot be the last are queued back to back; afterwards three at a time per read-back
     uint32_t chunkEnd = level + 1;
-    while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kLeafMax ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
+    while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kRetire ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
     if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 3, kMaxLevels );
     for ( ; level < chunkEnd; ++level ) {
       hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
@@ -621,6 +955,20 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   depth = found;
   const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
+  const uint32_t retired = out[kMaxLevels + 3];
+  if ( retired ) {  // the subtrees below the level passes: one wavefront each
+    const uint32_t blocks = std::min<uint32_t>( ( retired + kFinishWaves - 1 ) / kFinishWaves, 64u * uint32_t( ctx->cuCount ) );
+    hipLaunchKernelGGL( finishSubtreesKernel, dim3( blocks ), dim3( 64 * kFinishWaves ), 0, s, a );
+    TMC2_HIP( hipGetLastError() );
+    uint32_t fin = 0;
+    TMC2_HIP( hipMemcpyAsync( &fin, a.finishDepth, 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    if ( fin >= uint32_t( kMaxLevels ) ) {
+      setError( "kdtree: more than %d levels", kMaxLevels - 1 );
+      return TMC2_E_UNSUPPORTED;
+    }
+    depth = std::max( depth, int( fin ) );
+  }
   return TMC2_OK;
 }
 
