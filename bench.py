@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--workers", type=int, default=0, help="concurrent frames per GPU (0 = auto)")
     ap.add_argument("--host-steps", type=int, default=16, help="max concurrent host-resident steps (tree build, orientation)")
     ap.add_argument("--kdtree", default="auto", choices=["auto", "device", "host", "adaptive"],
-                    help="where the k-d trees are built (auto: host when >= 8 frames are in flight per GPU, else device)")
+                    help="where the k-d trees are built (auto = device)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
@@ -263,7 +263,9 @@ def main():
     workers = a.workers or max(1, min(len(clouds), 16, (os.cpu_count() or 8) // world))
     T.load_library().tmc2_set_host_parallelism(max(1, a.host_steps // world))
     # many frames in flight and idle host cores: the (exact) host k-d tree builder leaves the GPU to the other stages
-    kd_mode = {"device": 0, "host": 1, "adaptive": 2}.get(a.kdtree, 1 if workers >= 8 else 0)
+    # (round 1 preferred host builds above 8 frames in flight; with the subtree-finishing device build the device wins:
+    #  16 frames in flight, measured: device 85, host 75 frames/s -- and the host cores stay free)
+    kd_mode = {"device": 0, "host": 1, "adaptive": 2}.get(a.kdtree, 0)
     T.load_library().tmc2_set_kdtree_placement(kd_mode)
     enc = T.GofEncoder(local, workers, a.iterations, 11, 4, 1280, 1280, timing=True, first_domain=rank * workers)
     frames = enc.upload(clouds)                          # inputs resident in HBM

@@ -228,11 +228,8 @@ __device__ __forceinline__ int mean4w( int p1, int w1, int p2, int w2, int p3, i
 }
 
 // six planes (2 maps x 3 channels) of size W*H each, plane stride = W*H
-__global__ __launch_bounds__( 256 ) void pushPullMipKernel( const uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W,
-                                                             int H, uint8_t* __restrict__ mip, uint8_t* __restrict__ mipOcc, int w,
-                                                             int h ) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= w * h ) return;
+__device__ __forceinline__ void pushPullMipPixel( int i, const uint8_t* img, const uint8_t* occ, int W, int H, uint8_t* mip,
+                                                  uint8_t* mipOcc, int w, int h ) {
   const int  x = i % w, y = i / w, X = 2 * x, Y = 2 * y;
   const bool i2 = X + 1 < W, i3 = Y + 1 < H;
   const int  w1 = occ[size_t( Y ) * W + X] ? 255 : 0;
@@ -253,11 +250,16 @@ __global__ __launch_bounds__( 256 ) void pushPullMipKernel( const uint8_t* __res
     mip[size_t( p ) * w * h + i] = v;
   }
 }
-
-__global__ __launch_bounds__( 256 ) void pushPullFillKernel( uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W, int H,
-                                                              const uint8_t* __restrict__ mip, int w, int h ) {
+__global__ __launch_bounds__( 256 ) void pushPullMipKernel( const uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W,
+                                                             int H, uint8_t* __restrict__ mip, uint8_t* __restrict__ mipOcc, int w,
+                                                             int h ) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= W * H || occ[i] ) return;
+  if ( i < w * h ) pushPullMipPixel( i, img, occ, W, H, mip, mipOcc, w, h );
+}
+
+__device__ __forceinline__ void pushPullFillPixel( int i, uint8_t* img, const uint8_t* occ, int W, int H, const uint8_t* mip, int w,
+                                                   int h ) {
+  if ( occ[i] ) return;
   const int  X = i % W, Y = i / W, x = X >> 1, y = Y >> 1;
   const int  dx = ( X & 1 ) ? 1 : -1, dy = ( Y & 1 ) ? 1 : -1;
   const bool hx = dx < 0 ? x > 0 : x < w - 1, hy = dy < 0 ? y > 0 : y < h - 1;
@@ -271,11 +273,14 @@ __global__ __launch_bounds__( 256 ) void pushPullFillKernel( uint8_t* __restrict
     img[size_t( p ) * W * H + i] = uint8_t( mean4w( v, 144, vx, hx ? 48 : 0, vy, hy ? 48 : 0, vd, ( hx && hy ) ? 16 : 0 ) );
   }
 }
-
-__global__ __launch_bounds__( 256 ) void pushPullBlurKernel( const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                              const uint8_t* __restrict__ occ, int W, int H ) {
+__global__ __launch_bounds__( 256 ) void pushPullFillKernel( uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W, int H,
+                                                              const uint8_t* __restrict__ mip, int w, int h ) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= W * H || occ[i] ) return;
+  if ( i < W * H ) pushPullFillPixel( i, img, occ, W, H, mip, w, h );
+}
+
+__device__ __forceinline__ void pushPullBlurPixel( int i, const uint8_t* src, uint8_t* dst, const uint8_t* occ, int W, int H ) {
+  if ( occ[i] ) return;
   const int x = i % W, y = i / W;
   const int x1 = x > 0 ? x - 1 : x, y1 = y > 0 ? y - 1 : y, x2 = x < W - 1 ? x + 1 : x, y2 = y < H - 1 ? y + 1 : y;
 #pragma unroll
@@ -284,6 +289,58 @@ __global__ __launch_bounds__( 256 ) void pushPullBlurKernel( const uint8_t* __re
     const int      sum = s[size_t( y1 ) * W + x1] + s[size_t( y1 ) * W + x2] + s[size_t( y2 ) * W + x1] + s[size_t( y2 ) * W + x2] +
                     s[size_t( y ) * W + x1] + s[size_t( y ) * W + x2] + s[size_t( y1 ) * W + x] + s[size_t( y2 ) * W + x];
     dst[size_t( p ) * W * H + i] = uint8_t( ( sum + 4 ) >> 3 );
+  }
+}
+__global__ __launch_bounds__( 256 ) void pushPullBlurKernel( const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                              const uint8_t* __restrict__ occ, int W, int H ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i < W * H ) pushPullBlurPixel( i, src, dst, occ, W, H );
+}
+
+// The coarse end of the pyramid in ONE workgroup: the levels of at most kPushPullSmall pixels -- their mip maps on the way
+// down, and on the way up the fill, the ping-pong partner's copy and the 4, 5, ... blur iterations of every level.  That is
+// ~ 60 of the ~ 100 launches of the padding, each over a few hundred to a few thousand pixels; between the steps a
+// workgroup barrier does what a kernel boundary did (the images are tiny: L1 / L2 resident, one CU).
+constexpr int kPushPullSmall  = 160 * 160;
+constexpr int kPushPullLevels = 16;
+struct PushPullLevels {
+  int      count;                   // levels of the pyramid, 0 = the canvas
+  int      first;                   // the first (finest) level handled here: every level >= first has at most kPushPullSmall pixels
+  int      w[kPushPullLevels], h[kPushPullLevels];
+  uint8_t *img[kPushPullLevels], *tmp[kPushPullLevels], *occ[kPushPullLevels];
+};
+__global__ __launch_bounds__( 1024 ) void pushPullCoarseLevelsKernel( PushPullLevels L ) {
+  // down: mip maps of the levels first + 1 .. count - 1 (level `first` itself was produced by the launch before)
+  for ( int l = L.first + 1; l < L.count; ++l ) {
+    const int cnt = L.w[l] * L.h[l];
+    for ( int i = threadIdx.x; i < cnt; i += blockDim.x )
+      pushPullMipPixel( i, L.img[l - 1], L.occ[l - 1], L.w[l - 1], L.h[l - 1], L.img[l], L.occ[l], L.w[l], L.h[l] );
+    __syncthreads();
+  }
+  // up: fill level l - 1 from level l, then iters blur passes between the level's two buffers (host loop of
+  // generateAttributeImages, same order, same buffers)
+  int iters = 4;
+  for ( int l = L.count - 1; l > L.first; --l ) {
+    const int fw = L.w[l - 1], fh = L.h[l - 1], cnt = fw * fh;
+    uint8_t * img = L.img[l - 1], *tmp = L.tmp[l - 1];
+    const uint8_t* occ = L.occ[l - 1];
+    for ( int i = threadIdx.x; i < cnt; i += blockDim.x ) pushPullFillPixel( i, img, occ, fw, fh, L.img[l], L.w[l], L.h[l] );
+    __syncthreads();
+    for ( int i = threadIdx.x; i < 6 * cnt; i += blockDim.x ) tmp[i] = img[i];
+    __syncthreads();
+    uint8_t *src = img, *dst = tmp;
+    for ( int it = 0; it < iters; ++it ) {
+      for ( int i = threadIdx.x; i < cnt; i += blockDim.x ) pushPullBlurPixel( i, src, dst, occ, fw, fh );
+      __syncthreads();
+      uint8_t* t = src;
+      src        = dst;
+      dst        = t;
+    }
+    if ( src != img ) {  // odd iteration count: the result sits in the partner buffer -- the level's image from now on
+      L.img[l - 1] = src;
+      L.tmp[l - 1] = img;
+    }
+    iters = min( iters + 1, 16 );
   }
 }
 
@@ -488,13 +545,31 @@ int generateAttributeImages( tmc2_frame* f ) {
       lv[l].occ = p, p += ( a + 15 ) & ~size_t( 15 );
     }
   }
-  for ( size_t l = 1; l < lv.size(); ++l ) {
+  // the coarse end of the pyramid (levels of at most kPushPullSmall pixels) goes through ONE launch
+  size_t firstSmall = lv.size();
+  if ( lv.size() <= size_t( kPushPullLevels ) )
+    for ( size_t l = 1; l < lv.size(); ++l )
+      if ( lv[l].w * lv[l].h <= kPushPullSmall ) {
+        firstSmall = l;
+        break;
+      }
+  for ( size_t l = 1; l < lv.size() && l <= firstSmall; ++l ) {
     const int cnt = lv[l].w * lv[l].h;
     hipLaunchKernelGGL( pushPullMipKernel, dim3( ( cnt + 255 ) / 256 ), blk, 0, s, lv[l - 1].img, lv[l - 1].occ, lv[l - 1].w,
                         lv[l - 1].h, lv[l].img, lv[l].occ, lv[l].w, lv[l].h );
   }
   int iters = 4;
-  for ( size_t l = lv.size() - 1; l >= 1; --l ) {
+  if ( firstSmall + 1 < lv.size() ) {
+    PushPullLevels L;
+    L.count = int( lv.size() ), L.first = int( firstSmall );
+    for ( size_t l = 0; l < lv.size(); ++l ) L.w[l] = lv[l].w, L.h[l] = lv[l].h, L.img[l] = lv[l].img, L.tmp[l] = lv[l].tmp, L.occ[l] = lv[l].occ;
+    hipLaunchKernelGGL( pushPullCoarseLevelsKernel, dim3( 1 ), dim3( 1024 ), 0, s, L );
+    for ( size_t l = lv.size() - 1; l > firstSmall; --l ) {  // (what the kernel did to the buffers of the levels it filled)
+      if ( iters & 1 ) std::swap( lv[l - 1].img, lv[l - 1].tmp );
+      iters = std::min( iters + 1, 16 );
+    }
+  }
+  for ( size_t l = std::min( firstSmall, lv.size() - 1 ); l >= 1; --l ) {
     Level&    fine = lv[l - 1];
     const int cnt  = fine.w * fine.h;
     const dim3 grd( ( cnt + 255 ) / 256 );

@@ -205,6 +205,7 @@ struct tmc2_ctx {
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
+  std::map<uint32_t, int>       kdLevelHint;     // levels of level passes the last device k-d tree of ~ this size took (by n >> 15)
   hipStream_t                   stream = nullptr;
   std::vector<tmc2::StageTimer> stages;
   std::vector<hipEvent_t>       freeEvents;

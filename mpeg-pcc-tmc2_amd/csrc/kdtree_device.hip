@@ -45,7 +45,7 @@ constexpr int      kLeafMax   = 10;
 constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kernels
 constexpr int      kRetire    = 1024;  // segments of at most this many points leave the level passes (one wavefront each)
 constexpr int      kLaneMax   = 32;    // ... and inside a wavefront's subtree, nodes of at most this many points go to single lanes
-constexpr int      kSmallMax  = 128;   // such nodes are handed to the lanes in batches of at most this many
+constexpr int      kSmallMax  = 64;    // such nodes are handed to the lanes in batches of at most this many
 
 struct BuildSeg {
   uint32_t begin, end;    // range in tree order
@@ -81,6 +81,7 @@ struct BuildArgs {
   RetiredSeg* retired;  // [n / (kRetire / 2) + 2]: every retired segment has a parent of more than kRetire points
   uint32_t*   retiredCount;
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
+  uint32_t*   ticket;       // "last block done" counter of the prefix sums
 };
 
 __device__ __forceinline__ int coordOf( const Pt p, int d ) { return d == 0 ? p.x : ( d == 1 ? p.y : p.z ); }
@@ -122,13 +123,12 @@ __device__ __forceinline__ uint32_t prefixAt( const uint32_t* __restrict__ loc, 
 }
 
 // one block: exclusive scan of the tile totals in place, grand total to sums[tiles]
-__global__ __launch_bounds__( kBlock ) void scanTileTotalsKernel( uint32_t* __restrict__ sums, uint32_t tiles ) {
-  __shared__ uint32_t waveSum[kWaves];
+__device__ __forceinline__ void scanTileTotals( uint32_t* __restrict__ sums, uint32_t tiles, uint32_t* waveSum ) {
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t            carry = 0;
   for ( uint32_t base = 0; base < tiles; base += kBlock ) {
     const uint32_t i   = base + threadIdx.x;
-    const uint32_t v   = i < tiles ? sums[i] : 0u;
+    const uint32_t v   = i < tiles ? __hip_atomic_load( &sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) : 0u;
     uint32_t       inc = v;
 #pragma unroll
     for ( int off = 1; off < 64; off <<= 1 ) {
@@ -144,6 +144,24 @@ __global__ __launch_bounds__( kBlock ) void scanTileTotalsKernel( uint32_t* __re
     __syncthreads();
   }
   if ( threadIdx.x == 0 ) sums[tiles] = carry;
+}
+
+// The block that finishes LAST scans the tile totals all blocks have written (saves a one-block launch per prefix sum).
+// Hand-off without cache maintenance: the totals are written through (agent-scope stores, drained before the block takes its
+// ticket) and the last block reads them past its L1 (agent-scope loads) -- 4 bytes per block, no L2 write-back.
+__device__ __forceinline__ void storeTileTotal( uint32_t* slot, uint32_t v ) {
+  __hip_atomic_store( slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+}
+__device__ __forceinline__ void lastBlockScansTotals( uint32_t* __restrict__ sums, uint32_t tiles, uint32_t* ticket,
+                                                      uint32_t* waveSum ) {
+  __shared__ uint32_t isLast;
+  __syncthreads();  // (the thread that stored the block's total has drained it)
+  if ( threadIdx.x == 0 ) isLast = atomicAdd( ticket, 1u ) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if ( !isLast ) return;
+  if ( threadIdx.x == 0 ) *ticket = 0;  // (for the next prefix sum; ordered before it by the kernel boundary)
+  scanTileTotals( sums, tiles, waveSum );
 }
 
 // first sweep of a segment, from the first prefix sum: #L (= lim1), prefix at begin and at begin + lim1
@@ -370,9 +388,10 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
       if ( base + k < n ) a.loc1[base + k] = offset;
       offset += v[k];
     }
-    if ( threadIdx.x == kBlock - 1 ) a.tile1[tile] = offset;
+    if ( threadIdx.x == kBlock - 1 ) storeTileTotal( &a.tile1[tile], offset );
     __syncthreads();
   }
+  lastBlockScansTotals( a.tile1, tiles, a.ticket, waveSum );
 }
 
 __global__ __launch_bounds__( kBlock ) void publishOneKernel( BuildArgs a, uint32_t level ) {
@@ -477,9 +496,10 @@ __global__ __launch_bounds__( kBlock ) void flagTwoKernel( BuildArgs a, uint32_t
       if ( base + k < n ) a.loc2[base + k] = offset;
       offset += v[k];
     }
-    if ( threadIdx.x == kBlock - 1 ) a.tile2[tile] = offset;
+    if ( threadIdx.x == kBlock - 1 ) storeTileTotal( &a.tile2[tile], offset );
     __syncthreads();
   }
+  lastBlockScansTotals( a.tile2, tiles, a.ticket, waveSum );
 }
 
 __global__ __launch_bounds__( kBlock ) void childrenPublishKernel( BuildArgs a, uint32_t level ) {
@@ -918,24 +938,30 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.retired      = d_retired.p;
   a.retiredCount = d_small.p + kMaxLevels + 3;
   a.finishDepth  = d_small.p + kMaxLevels + 4;
+  a.ticket       = d_small.p + kMaxLevels + 5;
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
   hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
   uint32_t out[kMaxLevels + 16];
   int      found = -1;
+  // How many levels the passes run is only known on the device.  Frames of a sequence are alike: the count of the last tree
+  // of about this size (kept in the context) is queued back to back and then checked; without it, the levels that cannot be
+  // the last; afterwards two at a time per read-back (launches past the last level find nothing to do).
+  int& hint = ctx->kdLevelHint[n >> 15];
   for ( uint32_t level = 0; level < uint32_t( kMaxLevels ) && found < 0; ) {
-    // levels that cannot be the last are queued back to back; afterwards three at a time per read-back
     uint32_t chunkEnd = level + 1;
-    while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kRetire ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
-    if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 3, kMaxLevels );
+    if ( level == 0 && hint > 0 ) {
+      chunkEnd = uint32_t( std::min( hint, kMaxLevels ) );
+    } else {
+      while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kRetire ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
+      if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 2, kMaxLevels );
+    }
     for ( ; level < chunkEnd; ++level ) {
       hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( decideFlagKernel, grdT, blk, 0, s, a, level );
-      hipLaunchKernelGGL( scanTileTotalsKernel, dim3( 1 ), blk, 0, s, a.tile1, tiles );
       hipLaunchKernelGGL( publishOneKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( swapOneKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( flagTwoKernel, grdT, blk, 0, s, a, level );
-      hipLaunchKernelGGL( scanTileTotalsKernel, dim3( 1 ), blk, 0, s, a.tile2, tiles );
       hipLaunchKernelGGL( childrenPublishKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( swapTwoKernel, grdE, blk, 0, s, a, level );
     }
@@ -953,6 +979,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
     return TMC2_E_UNSUPPORTED;
   }
   depth = found;
+  hint  = std::max( found, 1 );
   const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
   const uint32_t retired = out[kMaxLevels + 3];

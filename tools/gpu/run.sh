@@ -1,5 +1,9 @@
 cd /root/repo
 export TMPDIR=/tmp
-(time timeout -s ABRT 400 python -X faulthandler -m pytest tests/test_gpu_segmenter.py tests/test_gpu_fuzz.py tests/test_gpu_metrics.py -m gpu -q --timeout 120 -x 2>&1 | tail -40) > gpurun_out/r02_pytest11.log 2>&1
-timeout 300 python bench.py --steps 2 --warmup 1 --frames 1 --workers 1 --kdtree device --cpu-baseline 0 --tail 0 > gpurun_out/r02_solo7.json 2> gpurun_out/r02_solo7.err
-timeout 300 python bench.py --steps 4 --warmup 2 --cpu-baseline 0 --tail 0 --kdtree device > gpurun_out/r02_bench6_device.json 2> gpurun_out/r02_bench6_device.err
+(time timeout -s ABRT 500 python -X faulthandler -m pytest tests/test_gpu_images.py tests/test_gpu_segmenter.py -m gpu -q --timeout 150 2>&1 | tail -30) > gpurun_out/r02_pytest13.log 2>&1
+timeout 300 python bench.py --steps 5 --warmup 2 --cpu-baseline 0 --tail 0 > gpurun_out/r02_bench8.json 2> gpurun_out/r02_bench8.err
+cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/r02_prof_solo9 -- python /root/repo/bench.py --steps 3 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 > /root/repo/gpurun_out/r02_prof_solo9.log 2>&1
+cd /root/repo
+DB=$(find gpurun_out/r02_prof_solo9 -name '*.db' | head -1)
+python profiles/summarise_rocpd.py $DB "bench.py --steps 3 --warmup 1 --frames 1 --workers 1 (one frame in flight, device k-d trees)" > gpurun_out/r02_solo9_kernels.txt 2>&1
+rm -rf gpurun_out/r02_prof_solo9
