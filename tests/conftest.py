@@ -10,6 +10,12 @@ for p in (os.environ.get("TMC2_PACKAGE_DIR") or os.path.join(ROOT, "mpeg-pcc-tmc
         sys.path.insert(0, p)
 
 
+try:                       # torch brings its own HIP runtime: when both it and libtmc2hip.so live in one process (the zero-copy
+    import torch  # noqa: F401  canvas views of the multi-GPU gather), torch's must be loaded first or it finds no device
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
