@@ -238,6 +238,32 @@ def cpu_child(spec, workload, iterations):
 
 
 
+def host_slots(host_steps, world, frames_per_rank):
+    """Concurrent host-resident steps (the orientation walk; host k-d tree builds if selected) of ONE rank: the node's budget
+    split over the ranks, but never fewer than the frames a rank has in flight need to make progress side by side
+    (at most 4): 8 ranks x 4 frames must not queue behind 2 slots each."""
+    return int(max(min(max(frames_per_rank, 1), 4), host_steps // max(world, 1)))
+
+
+def gather_canvases(enc, frames, sharder, cache, pin=True):
+    """The N > 1 tail of a step: the finished canvases of every frame slot go to rank 0 (one gather per canvas kind and
+    slot: every rank holds the same number of frames), which moves what arrives into (page-locked) host memory with
+    asynchronous copies -- completed by the synchronize after the timed steps.  Returns rank 0's buffers
+    {(slot, kind): uint8 tensor [world, ...]} (the frame of slot i on rank r is GOF frame r + i * world)."""
+    import torch
+    for i, fr in enumerate(frames):
+        for name in ("geometry", "occ_video", "attribute"):
+            src = enc.device_tensor(fr, name)
+            got = sharder.gather(src)
+            if sharder.rank == 0:
+                key = (i, name)
+                if key not in cache or cache[key].shape[1:] != src.shape:
+                    cache[key] = torch.empty((sharder.world,) + tuple(src.shape), dtype=torch.uint8, pin_memory=pin)
+                for r, x in enumerate(got):
+                    cache[key][r].copy_(x, non_blocking=True)
+    return cache
+
+
 def main():
     a = parse()
     if a.cpu_child:
@@ -261,7 +287,8 @@ def main():
     # one hardware queue per in-flight frame (GPU_MAX_HW_QUEUES = 16, tmc2_amd/lib.py): streams that share a queue serialise
     # behind each other, and 16 frames in flight keep the chip busy (measured: 12 -> 62, 16 -> 73, 20 -> 68, 24 -> 55, 32 -> 64 frames/s)
     workers = a.workers or max(1, min(len(clouds), 16, (os.cpu_count() or 8) // world))
-    T.load_library().tmc2_set_host_parallelism(max(1, a.host_steps // world))
+    slots = host_slots(a.host_steps, world, min(len(clouds), workers))
+    T.load_library().tmc2_set_host_parallelism(slots)
     # many frames in flight and idle host cores: the (exact) host k-d tree builder leaves the GPU to the other stages
     # (round 1 preferred host builds above 8 frames in flight; with the subtree-finishing device build the device wins:
     #  16 frames in flight, measured: device 85, host 75 frames/s -- and the host cores stay free)
@@ -299,18 +326,7 @@ def main():
             bufs = host_out(W, H)
             enc.per_frame(frames, lambda fr, i: (fr.get_geometry_images(bufs[i][0]), fr.get_attribute_images(bufs[i][1])))
         else:
-            # one gather per canvas kind and frame slot (every rank holds the same number of frames); rank 0 moves what
-            # arrives into page-locked host memory with asynchronous copies, completed by the synchronize of sync()
-            for i, fr in enumerate(frames):
-                for name in ("geometry", "occ_video", "attribute"):
-                    src = enc.device_tensor(fr, name)
-                    got = sharder.gather(src)
-                    if rank == 0:
-                        key = (i, name, tuple(src.shape))
-                        if key not in gather_cache:
-                            gather_cache[key] = torch.empty((world,) + tuple(src.shape), dtype=torch.uint8, pin_memory=True)
-                        for r, x in enumerate(got):
-                            gather_cache[key][r].copy_(x, non_blocking=True)
+            gather_canvases(enc, frames, sharder, gather_cache)
         return W, H
 
     def sync():
@@ -404,7 +420,7 @@ def main():
                              "occupancy + geometry images, dilation, reconstruction, colour transfer, attribute images, "
                              "push-pull padding (identity video codec between the phases); the D1/D2 metric (S23) is "
                              "reported separately (metric_ms_per_frame)",
-                   "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "parallelism": "frames f%%%d" % world},
+                   "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "host_step_slots_per_gpu": slots, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                      "launches": launches, "alone_avg_launch_ms": round(s_avg, 4), "alone_achieved": round(s_ach, 2),

@@ -176,3 +176,80 @@ def test_phase_a_records_route_orchestration_with_fake_frames():
                 assert np.array_equal(a, b)
         tile_h = max(e[4] for e in exp)
         assert (W, H) == T.encoder_canvas_size([max(tile_h, 512) if mode == 2 else tile_h], max([512] + [e[3] for e in exp]), 512, 512)
+
+
+# ---- bench.py's own N > 1 code path, before the driver's 8-GPU run: gloo, faked frames, world 2 and 8 ----------------------
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+class _FakeFrame:
+    def __init__(self, gof_index):
+        self.gof_index = gof_index
+
+
+class _FakeEncoder:
+    """What bench.gather_canvases needs of a GofEncoder: byte views of a frame's finished canvases (here: CPU tensors whose
+    bytes name the frame and the canvas kind)."""
+    SHAPES = {"geometry": (2, 8, 6, 2), "occ_video": (2, 3, 1), "attribute": (2, 3, 8, 6, 1)}
+
+    def device_tensor(self, frame, name):
+        kind = list(self.SHAPES).index(name)
+        return torch.full(self.SHAPES[name], (frame.gof_index * 3 + kind) % 251, dtype=torch.uint8)
+
+
+def _bench_gather_worker(rank, world, port, frame_count, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bench = _load_bench()
+    sh = Sharder(rank, world, dist, "cpu")
+    frames = [_FakeFrame(f) for f in sh.frames_of(frame_count)]
+    cache = {}
+    for _ in range(2):                                                   # two steps: the second one reuses rank 0's buffers
+        bench.gather_canvases(_FakeEncoder(), frames, sh, cache, pin=False)
+    sh.barrier()
+    if rank == 0:
+        q.put({k: v.numpy().copy() for k, v in cache.items()})            # (plain arrays: nothing shared outlives the process)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_gather_branch_world_2_and_8_gloo(world):
+    """The exact tail of bench.py's step() for N > 1 (bench.gather_canvases: one gather per canvas kind and frame slot to rank
+    0, copies into its host buffers) with 32 frames over 2 and over 8 ranks: rank 0 ends up with every frame's canvases in
+    the slot its (rank, index) names."""
+    frames = 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_gather_worker, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    per_rank = frames // world
+    assert sorted(got) == sorted((i, name) for i in range(per_rank) for name in _FakeEncoder.SHAPES)
+    for (slot, name), buf in got.items():
+        assert tuple(buf.shape) == (world,) + _FakeEncoder.SHAPES[name]
+        kind = list(_FakeEncoder.SHAPES).index(name)
+        for r in range(world):
+            gof_index = r + slot * world                                 # frame f lives on rank f % world, slot f // world
+            assert int(buf[r].min()) == int(buf[r].max()) == (gof_index * 3 + kind) % 251, (slot, name, r)
+
+
+def test_bench_host_slot_budget_per_rank():
+    """--host-steps is a node budget; a rank never gets fewer slots than its in-flight frames need to progress side by side."""
+    bench = _load_bench()
+    assert bench.host_slots(16, 1, 16) == 16
+    assert bench.host_slots(16, 2, 16) == 8
+    assert bench.host_slots(16, 8, 4) == 4          # 16 // 8 = 2 would serialise four frames behind two slots
+    assert bench.host_slots(16, 8, 1) == 2
+    assert bench.host_slots(0, 8, 4) == 4
