@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
+    ap.add_argument("--rendezvous", default="phases", choices=["one", "phases"],
+                    help="all-intra: phases = the frames of the GOF meet after segmentation + packing, after phase A and after "
+                         "phase B (default: frames in the same phase share the chip better -- measured 90 against 79 frames/s); "
+                         "one = every frame runs its whole chain on its worker, the GOF meets once (GofEncoder.encode_all_intra)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--packing", default="all-intra", choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition: every frame on its own (the metric's configuration), the spatial-consistency chain, "
@@ -298,7 +302,8 @@ def main():
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
 
-    host_cache = {}
+    import threading
+    host_cache, host_lock = {}, threading.Lock()
     gather_cache = {}
 
     def host_out(W, H):
@@ -307,7 +312,8 @@ def main():
         def pinned(shape, dtype):
             t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8, pin_memory=True)
             return t.numpy().view(dtype).reshape(shape)
-        if (W, H) not in host_cache:
+        with host_lock:                                         # (called from the worker threads)
+          if (W, H) not in host_cache:
             host_cache[(W, H)] = [(dict(occupancy=pinned((H, W), np.uint8), occ_video=pinned((H // 4, W // 4), np.uint8),
                                         block_to_patch=pinned((H // 16, W // 16), np.uint32),
                                         geo0=pinned((H, W), np.uint16), geo1=pinned((H, W), np.uint16)),
@@ -317,6 +323,17 @@ def main():
     def step():
         for fr in frames:
             fr.reset()
+        if a.packing == "all-intra" and a.rendezvous == "one":
+            # every frame runs its whole chain on its worker; one rendezvous per GOF (the common canvas size is verified at
+            # the end: GofEncoder.encode_all_intra).  Finished canvases -> host memory (N = 1) / rank 0 (N > 1).
+            def to_host(fr, i, size):
+                bufs = host_out(size[0], size[1])
+                fr.get_geometry_images(bufs[i][0])
+                fr.get_attribute_images(bufs[i][1])
+            W, H = enc.encode_all_intra(frames, sharder, finish=to_host if world == 1 else None)
+            if world > 1:
+                gather_canvases(enc, frames, sharder, gather_cache)
+            return W, H
         W, H = enc.phase_a(frames, sharder, constrained_pack={"all-intra": False, "low-delay": True, "random-access": 2}[a.packing],
                            frame_count=a.frames)
         # identity video codec between the phases (HM/VTM on the host is outside the metric): phase B runs on the

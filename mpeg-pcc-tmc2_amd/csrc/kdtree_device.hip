@@ -19,8 +19,9 @@
 //   * children: node ids and next-level slots from atomic counters (ids are arbitrary: the traversal follows explicit
 //     child ids; only the ROOT must be node 0), loose boxes handed down, and each child reports its tight range to
 //     the parent's divlow / divhigh when it is measured at the next level.
-// A level is nine short launches (two of them single-block scans of the tile totals) over <= n points, a tree ~25
-// levels.  Per-node quantities that cost a handful of loads (split rule, sweep limits) are re-derived per point rather
+// A level is five short launches over <= n points (ranges; split rule + flags + prefix sum; first swaps; second flags +
+// prefix sum; children + second swaps -- the tile totals of a prefix sum are scanned by the block that finishes last, a
+// misplaced element finds its partner by binary search in the prefix sums).  Per-node quantities that cost a handful of loads (split rule, sweep limits) are re-derived per point rather
 // than materialised by extra per-node launches.  Termination needs the host only from the level on at which the tree
 // CAN end (10 * 2^level >= n), and then once per three levels (launches past the last level find nothing to do).
 // The level passes only carry the top of the tree: a segment of at most kRetire points is RETIRED at the level it appears
@@ -73,7 +74,7 @@ struct BuildArgs {
   uint32_t *perm, *seg;
   BuildSeg *segA, *segB;
   KdNode*   nodes;
-  uint32_t *loc1, *loc2, *tile1, *tile2, *list;  // tile1 / tile2: [tiles + 1] tile totals, scanned in place (+ total)
+  uint32_t *loc1, *loc2, *tile1, *tile2;  // tile1 / tile2: [tiles + 1] tile totals, scanned in place (+ total)
   uint32_t* counts;     // [kMaxLevels + 1] segments per level
   uint32_t* nodeCount;
   int32_t*  rootBox;    // [6]
@@ -190,6 +191,24 @@ __device__ __forceinline__ Sweep sweepTwo( const BuildSeg* q, uint32_t lim1Pos, 
   s.rm              = prefixAt( loc2, sums2, tiles, s.edge, n );
   s.m               = s.rm - s.rb;
   return s;
+}
+
+// The partner of a misplaced left-hand element of a sweep: the misplaced right-hand element of the same rank counted from
+// the right end, i.e. the k-th (k = m - 1 - rank, from 0) element of [edge, end) that is NOT flagged.  With h(t) = number of
+// unflagged elements in [edge, t) (from the prefix sum of the flags), it sits at t - 1 for the smallest t with h(t) >= k + 1:
+// a binary search over the prefix sums instead of a published position list (one launch less per sweep).
+__device__ __forceinline__ uint32_t partnerOf( const uint32_t* __restrict__ loc, const uint32_t* sums, uint32_t tiles, uint32_t n,
+                                               uint32_t edge, uint32_t end, uint32_t rm, uint32_t k ) {
+  uint32_t lo = edge + 1, hi = end;
+  while ( lo < hi ) {
+    const uint32_t mid = lo + ( hi - lo ) / 2;
+    const uint32_t h   = ( mid - edge ) - ( prefixAt( loc, sums, tiles, mid, n ) - rm );
+    if ( h >= k + 1 )
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  return lo - 1;
 }
 
 __global__ __launch_bounds__( kBlock ) void initKernel( BuildArgs a ) {
@@ -394,31 +413,6 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
   lastBlockScansTotals( a.tile1, tiles, a.ticket, waveSum );
 }
 
-__global__ __launch_bounds__( kBlock ) void publishOneKernel( BuildArgs a, uint32_t level ) {
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  // ---- pass 3: first sweep, misplaced right-hand elements publish their position by rank from the right ----
-  for ( uint32_t i = gtid; i < n; i += gsize ) {
-    const uint32_t s = a.seg[i];
-    if ( s == kNone ) continue;
-    const BuildSeg* q = cur + s;
-    if ( !q->split ) continue;
-    const Sweep w = sweepOne( q, a.loc1, sums1, tiles, n );
-    if ( i < w.edge || w.m == 0 ) continue;
-    if ( coordOf( a.P[i], q->cutDim ) >= q->cut ) continue;
-    const uint32_t rightBefore = ( a.loc1[i] + sums1[i / kScanTile] ) - w.rm;  // flagged in [edge, i)
-    a.list[w.b + ( w.m - 1 - ( ( i - w.edge ) - rightBefore ) )] = i;
-  }
-}
-
 __global__ __launch_bounds__( kBlock ) void swapOneKernel( BuildArgs a, uint32_t level ) {
   const uint32_t n = a.n, tiles = a.tiles;
   const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,7 +435,7 @@ __global__ __launch_bounds__( kBlock ) void swapOneKernel( BuildArgs a, uint32_t
     const Pt pi = a.P[i];
     if ( coordOf( pi, q->cutDim ) < q->cut ) continue;
     const uint32_t r  = ( a.loc1[i] + sums1[i / kScanTile] ) - w.rb;
-    const uint32_t j  = a.list[w.b + r];
+    const uint32_t j  = partnerOf( a.loc1, sums1, tiles, n, w.edge, q->end, w.rm, w.m - 1u - r );
     const Pt       pj = a.P[j];
     a.P[i]            = pj;
     a.P[j]            = pi;
@@ -502,19 +496,10 @@ __global__ __launch_bounds__( kBlock ) void flagTwoKernel( BuildArgs a, uint32_t
   lastBlockScansTotals( a.tile2, tiles, a.ticket, waveSum );
 }
 
-__global__ __launch_bounds__( kBlock ) void childrenPublishKernel( BuildArgs a, uint32_t level ) {
+// per segment of a level: lim2, the balance rule, the node record and the two children (next level's segments)
+__device__ __forceinline__ void createChildren( const BuildArgs& a, uint32_t level, BuildSeg* cur, BuildSeg* other, uint32_t count,
+                                                const uint32_t* sums1, const uint32_t* sums2, uint32_t gtid, uint32_t gsize ) {
   const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  // ---- pass 6: per segment: lim2, the balance rule, the node record and the two children;
-  //              per point  : second sweep, publish ------------------------------------------------------------
   for ( uint32_t s = gtid; s < count; s += gsize ) {
     BuildSeg* q = cur + s;
     if ( !q->split ) continue;
@@ -549,19 +534,6 @@ __global__ __launch_bounds__( kBlock ) void childrenPublishKernel( BuildArgs a, 
     other[sl]     = l;
     other[sl + 1] = r;
   }
-  for ( uint32_t i = gtid; i < n; i += gsize ) {
-    const uint32_t s = a.seg[i];
-    if ( s == kNone ) continue;
-    const BuildSeg* q = cur + s;
-    if ( !q->split ) continue;
-    const uint32_t lim1Pos = sweepOne( q, a.loc1, sums1, tiles, n ).edge;
-    if ( i < lim1Pos ) continue;
-    const Sweep w = sweepTwo( q, lim1Pos, a.loc2, sums2, tiles, n );
-    if ( i < w.edge || w.m == 0 ) continue;
-    if ( coordOf( a.P[i], q->cutDim ) > q->cut ) continue;
-    const uint32_t rightBefore = ( a.loc2[i] + sums2[i / kScanTile] ) - w.rm;
-    a.list[w.b + ( w.m - 1 - ( ( i - w.edge ) - rightBefore ) )] = i;
-  }
 }
 
 __global__ __launch_bounds__( kBlock ) void swapTwoKernel( BuildArgs a, uint32_t level ) {
@@ -575,6 +547,8 @@ __global__ __launch_bounds__( kBlock ) void swapTwoKernel( BuildArgs a, uint32_t
   const uint32_t* sums1 = a.tile1;
   const uint32_t* sums2 = a.tile2;
   (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
+  // ---- pass 6: the children of every split segment (independent of the swaps below: it reads the prefix sums only)
+  createChildren( a, level, cur, other, count, sums1, sums2, gtid, gsize );
   // ---- pass 7: second sweep, swap --------------------------------------------------------------------------------
   for ( uint32_t i = gtid; i < n; i += gsize ) {
     const uint32_t s = a.seg[i];
@@ -588,7 +562,7 @@ __global__ __launch_bounds__( kBlock ) void swapTwoKernel( BuildArgs a, uint32_t
     const Pt pi = a.P[i];
     if ( coordOf( pi, q->cutDim ) <= q->cut ) continue;
     const uint32_t r  = ( a.loc2[i] + sums2[i / kScanTile] ) - w.rb;
-    const uint32_t j  = a.list[w.b + r];
+    const uint32_t j  = partnerOf( a.loc2, sums2, tiles, n, w.edge, q->end, w.rm, w.m - 1u - r );
     const Pt       pj = a.P[j];
     a.P[i]            = pj;
     a.P[j]            = pi;
@@ -922,14 +896,14 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   DevBuf<RetiredSeg> d_retired;
   const size_t       maxRetired = size_t( n ) / ( kLeafMax + 1 ) + 2;  // (retired segments are disjoint and hold > kLeafMax points)
   TMC2_TRY( d_retired.alloc( maxRetired ) );
-  TMC2_TRY( d_work.alloc( 4 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, list, tile totals x 2
+  TMC2_TRY( d_work.alloc( 3 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
   TMC2_HIP( hipMemsetAsync( d_small.p, 0, ( kMaxLevels + 16 ) * 4, s ) );
   BuildArgs a;
   a.pts = d_pts, a.n = n, a.tiles = tiles, a.P = d_ptsTree.p, a.perm = d_perm.p;
-  a.seg = d_work.p, a.loc1 = d_work.p + n, a.loc2 = d_work.p + 2 * size_t( n ), a.list = d_work.p + 3 * size_t( n );
-  a.tile1 = d_work.p + 4 * size_t( n ), a.tile2 = a.tile1 + tiles + 1;
+  a.seg = d_work.p, a.loc1 = d_work.p + n, a.loc2 = d_work.p + 2 * size_t( n );
+  a.tile1 = d_work.p + 3 * size_t( n ), a.tile2 = a.tile1 + tiles + 1;
   a.segA = d_segs.p, a.segB = d_segs.p + maxSegs, a.nodes = d_nodes.p;
   a.counts    = d_small.p;
   a.nodeCount = d_small.p + kMaxLevels + 1;
@@ -959,10 +933,8 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
     for ( ; level < chunkEnd; ++level ) {
       hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( decideFlagKernel, grdT, blk, 0, s, a, level );
-      hipLaunchKernelGGL( publishOneKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( swapOneKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( flagTwoKernel, grdT, blk, 0, s, a, level );
-      hipLaunchKernelGGL( childrenPublishKernel, grdE, blk, 0, s, a, level );
       hipLaunchKernelGGL( swapTwoKernel, grdE, blk, 0, s, a, level );
     }
     TMC2_HIP( hipGetLastError() );

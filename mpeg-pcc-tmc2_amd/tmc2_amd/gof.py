@@ -261,6 +261,40 @@ class GofEncoder:
         self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
         return W, H
 
+    def encode_all_intra(self, frames, sharder=None, weight=None, finish=None):
+        """Phase A + phase B of a GOF under the all-intra condition with ONE rendezvous.  The frames are independent but for
+        the common canvas: its height is the maximum over the GOF of the packed heights (resizeGeometryVideo,
+        PCCEncoder.cpp:5546-5591), never below the minimum canvas -- which is what every frame of the CTC sequences packs
+        into.  So every frame runs its whole chain (segment, pack, rasterise, reconstruct, colour, attribute images, then
+        `finish(frame, index)`, e.g. the copy of its canvases to the host) on its own worker with the canvas size ITS OWN
+        height gives; when all are done the real size is settled (max over the ranks) and a frame whose guess was short
+        rasterises again on the right canvas.  Same bytes as phase_a() + phase_b(); no worker waits for another mid-GOF."""
+        sharder = sharder or Sharder()
+        if weight is None:
+            w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
+            weight = sharder.broadcast_weight(w)
+        params = lib.ctc_params(self.iterations, self.bits3d, weight, self.vox_dim)
+
+        def images(fr, i, size):
+            fr.encoder_generate_geometry_images(size[0], size[1], self.occ_precision)
+            fr.encoder_generate_attribute_images()
+            if finish is not None:
+                finish(fr, i, size)
+
+        def chain(fr, i):
+            fr.segmenter_compute(params)
+            h = fr.encoder_pack_flexible(self.min_w, 2, 1.0)
+            size = lib.encoder_canvas_size([h], self.min_w, self.min_w, self.min_h)
+            images(fr, i, size)
+            return h, size
+        done = self.per_frame(frames, chain)
+        gof_h = sharder.max_height([h for h, _ in done])
+        size = lib.encoder_canvas_size([gof_h], self.min_w, self.min_w, self.min_h)
+        redo = [(i, fr) for i, (fr, (_, guess)) in enumerate(zip(frames, done)) if tuple(guess) != tuple(size)]
+        if redo:
+            self._dispatch([(i % self.workers, (lambda fr=fr, i=i: images(fr, i, size))) for i, fr in redo])
+        return size
+
     def _phase_a_sharded_chain(self, frames, sharder, weight, mode, frame_count):
         if frame_count is None:                              # (uneven shards: the ranks need not hold equally many frames)
             frame_count = sharder.sum_count(len(frames))

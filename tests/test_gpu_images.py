@@ -189,6 +189,31 @@ def test_gpu_gof_encoder_worker_threads(oracle, placement):
         T.load_library().tmc2_set_host_parallelism(16)
 
 
+@pytest.mark.parametrize("min_w,min_h", [(1280, 1280), (256, 64)])
+def test_gpu_all_intra_single_rendezvous(oracle, min_w, min_h):
+    """GofEncoder.encode_all_intra: every frame runs S1-S22 on its worker with the canvas its own packed height gives, the common
+    size is settled at the end and frames that guessed short rasterise again.  On the 256-wide canvas the frames of this GOF pack
+    to different heights (the redo path); 1280 x 1280 is the CTC case (no redo).  Same canvases as the oracle either way."""
+    frames = [synth_cloud("tiny", f) for f in range(4)] + [synth_cloud("small", 0)]
+    enc = T.GofEncoder(0, workers=3, iterations=4, min_w=min_w, min_h=min_h)
+    try:
+        frs = enc.upload(frames)
+        seen = []
+        W, H = enc.encode_all_intra(frs, finish=lambda fr, i, size: seen.append((i, tuple(size))))
+        exp_a = oracle.phase_a(frames, 4, 11, 4, min_w, min_h)
+        exp_b = oracle.phase_b(frames, exp_a, 4)
+        assert (W, H) == (exp_a[0]["width"], exp_a[0]["height"])
+        assert {i for i, s in seen if s == (W, H)} == set(range(len(frames)))     # every frame finished on the final canvas
+        assert (len(seen) > len(frames)) == (min_w == 256)                        # ... on the narrow one some only at the second attempt
+        for fr, ea, eb in zip(frs, exp_a, exp_b):
+            img = fr.get_geometry_images()
+            for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"):
+                assert np.array_equal(img[k], ea[k]), k
+            assert np.array_equal(fr.get_attribute_images(), eb["attribute"])
+    finally:
+        enc.close()
+
+
 def test_gpu_vox11_full_path_properties(gpu_ctx):
     """basketball_player_vox11-size frame (3.0 M points, 11-bit geometry, BASELINE configs[1..]): the whole path S0-S22 with
     the CTC settings of that sequence (20 refine iterations, 12-bit 3-D range) -- size-dependent tables (2^33-bit voxel
