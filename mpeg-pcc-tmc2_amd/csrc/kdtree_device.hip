@@ -44,8 +44,14 @@ constexpr int      kWaves     = kBlock / 64;
 constexpr int      kScanTile  = kBlock * 8;
 constexpr int      kLeafMax   = 10;
 constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kernels
-constexpr int      kRetire    = 1024;  // segments of at most this many points leave the level passes (one wavefront each)
-constexpr int      kLaneMax   = 32;    // ... and inside a wavefront's subtree, nodes of at most this many points go to single lanes
+#ifndef TMC2_KD_RETIRE
+#define TMC2_KD_RETIRE 1024
+#endif
+#ifndef TMC2_KD_LANEMAX
+#define TMC2_KD_LANEMAX 32
+#endif
+constexpr int      kRetire    = TMC2_KD_RETIRE;   // segments of at most this many points leave the level passes (one wavefront each)
+constexpr int      kLaneMax   = TMC2_KD_LANEMAX;  // ... and inside a wavefront's subtree, nodes of at most this many points go to single lanes
 constexpr int      kSmallMax  = 64;    // such nodes are handed to the lanes in batches of at most this many
 
 struct BuildSeg {
@@ -648,7 +654,7 @@ __device__ __forceinline__ void waveSweep( Pt* P, uint32_t* perm, uint32_t count
 // nanoflann's divideTree on P[b..e) by ONE lane (literal two-pass planeSplit with std::swap semantics), explicit stack.
 __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t globalBegin, KdNode* __restrict__ nodes,
                              uint32_t* __restrict__ nodeCount, uint32_t& maxDepth, uint32_t* __restrict__ refuse ) {
-  SubNode stack[40];  // a node of at most kLaneMax points is at most kLaneMax - kLeafMax levels deep
+  SubNode stack[kLaneMax + 8];  // a node of at most kLaneMax points is at most kLaneMax - kLeafMax levels deep
   int     sp  = 0;
   stack[sp++] = root;
   while ( sp > 0 ) {
@@ -711,7 +717,7 @@ __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t
     if ( r.dim == 0 ) l.hi[0] = cut, rr.lo[0] = cut;
     if ( r.dim == 1 ) l.hi[1] = cut, rr.lo[1] = cut;
     if ( r.dim == 2 ) l.hi[2] = cut, rr.lo[2] = cut;
-    if ( sp > 37 ) {  // (cannot happen for kLaneMax points; never write past the stack)
+    if ( sp > kLaneMax + 5 ) {  // (cannot happen for kLaneMax points; never write past the stack)
       atomicMax( refuse, 0x10000u );
       return;
     }
@@ -720,7 +726,7 @@ __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t
   }
 }
 
-constexpr int kFinishWaves = 2;  // (32 KB of LDS per workgroup: several workgroups per CU)
+constexpr int kFinishWaves = kRetire <= 512 ? 4 : 2;  // (< 64 KB of LDS per workgroup: several workgroups per CU)
 
 __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( BuildArgs a ) {
   __shared__ Pt       sP[kFinishWaves][kRetire];

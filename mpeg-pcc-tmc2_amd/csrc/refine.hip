@@ -925,6 +925,20 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
 
 }  // namespace
 
+// Opt-in to more than 48 KB of dynamic LDS, once per device and kernel: hipFuncSetAttribute mutates runtime-wide kernel
+// state, and every in-flight frame's host thread comes through here at the same time.
+static int allowLargeLds( const void* kernel, size_t bytes, int device ) {
+  static std::mutex                                 lock;
+  static std::map<std::pair<const void*, int>, int> granted;
+  std::lock_guard<std::mutex>                       g( lock );
+  int& have = granted[{kernel, device}];
+  if ( int( bytes ) <= have ) return TMC2_OK;
+  const int want = 160 * 1024 - 64;  // the whole LDS of a gfx950 CU: asked for once, whatever this frame needs
+  TMC2_HIP( hipFuncSetAttribute( kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want ) );
+  have = want;
+  return TMC2_OK;
+}
+
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
   if ( !f->haveNormals || !f->havePartition ) {
     setError( "refineSegmentationGridBased: normals / partition missing" );
@@ -1117,9 +1131,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     const char*    listEnv  = getenv( "TMC2_REFINE_LISTCAP" );
     const uint32_t listCap  = uint32_t( std::min<size_t>( listEnv ? std::max( 2048, atoi( listEnv ) ) : 8192, ( ldsRoom - ldsFixed ) / 4 ) );
     const size_t   ldsBytes = ldsFixed + 4 * size_t( listCap );
-    if ( ldsBytes > 48 * 1024 )
-      TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureLevelsKernel ),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, int( ldsBytes ) ) );
+    if ( ldsBytes > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureLevelsKernel ), ldsBytes, ctx->device ) );
     const dim3 grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, size_t( 2 ) * ctx->cuCount ) ) );
     DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure's tail spends its time
     const bool                 wantTiming = getenv( "TMC2_REFINE_TIMING" ) != nullptr;
@@ -1180,9 +1192,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   // (test hook TMC2_REFINE_TAIL=global: take the global-memory tail regardless, the path of grids > 349 K voxels)
   const char*  tailEnv   = getenv( "TMC2_REFINE_TAIL" );
   const bool   tailInLds = tailLds <= 128 * 1024 && !( tailEnv && tailEnv[0] == 'g' );
-  if ( tailInLds && tailLds > 48 * 1024 )
-    TMC2_HIP( hipFuncSetAttribute( reinterpret_cast<const void*>( closureTailKernel ),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, int( tailLds ) ) );
+  if ( tailInLds && tailLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureTailKernel ), tailLds, ctx->device ) );
   DevBuf<uint32_t> d_flags;  // [0] fixpoint reached; [2k + 1] sweep k moved a point; [2k + 2] sweep k changed a voxel state
   TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
   TMC2_HIP( hipMemsetAsync( d_flags.p, 0, ( 2 * size_t( iterationCount ) + 2 ) * 4, s ) );

@@ -2,7 +2,7 @@
 into HBM bytes per launch of the kernels bench.py reports a roofline for.
 Corrections (MI355X_MICROARCH.md, "HBM"): both counters come back in KiB-sized units of 1024 B... see `unit` below; on gfx950
 FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled.  WRITE_SIZE is used as reported (uncalibrated).
-usage: python profiles/pmc_traffic.py <fetch_dir> <write_dir> <workload> > profiles/r01_pmc_traffic.json"""
+usage: python profiles/pmc_traffic.py <fetch_dir> <write_dir> <workload> > profiles/r02_pmc_traffic.json"""
 import csv
 import glob
 import json
@@ -14,6 +14,8 @@ STAGE_OF = {"knnKernel<16, true, true>": "knn_self", "knnKernel<8, false, true>"
             "knnKernel<1, false, true>": "knn1_source_in_recon", "normalsKernel<16>": "normals",
             "ccUnionKernel<16>": "k:ccUnion", "ccRelaxKernel<16>": "k:ccRelax", "ccMutualMaskKernel<16>": "k:ccMutualMask",
             "initialSegmentationKernel": "initial_segmentation"}
+# stages that are several kernels per run: bytes per run = sum over the kernels of (bytes per launch x launches per run)
+COMPOSITE = {"refine_sweep": {"closurePrepareKernel": 1, "closureLevelsKernel": 1, "sweepKernel": 1}}
 
 
 def per_kernel(directory, counter):
@@ -42,5 +44,13 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = rec
     if k in STAGE_OF:
         out["stages"][STAGE_OF[k]] = rec
+for stage, parts in COMPOSITE.items():
+    if all(k in out["kernels"] for k in parts):
+        rec = {"fetch_bytes_per_launch": 0, "write_bytes_per_launch": 0, "hbm_bytes_per_launch": 0,
+               "launches": min(out["kernels"][k]["launches"] for k in parts), "kernels": sorted(parts)}
+        for k, per_run in parts.items():
+            for f in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch"):
+                rec[f] += per_run * out["kernels"][k][f]
+        out["stages"][stage] = rec
 json.dump(out, sys.stdout, indent=1)
 print()
