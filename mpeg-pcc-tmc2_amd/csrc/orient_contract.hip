@@ -21,19 +21,25 @@ namespace {
 
 __device__ __forceinline__ uint32_t ufPriority( uint32_t x ) { return x * 2654435761u; }  // odd multiplier: a bijection
 
+// The kernels below that read a point's own k-NN row (16 ids = 64 bytes) and dot-product row (16 doubles = 128 bytes) give the
+// point 16 lanes, lane j holding edge j: a wavefront reads four rows back to back (fully coalesced) instead of 64 rows
+// at a stride, which thrashed L1 / L2 (round-1 counters: 6 - 13 x the algorithmic bytes reached HBM).  The per-point
+// results are ballots over the 16 lanes.
+__device__ __forceinline__ uint32_t ballot16( bool pred, int lane ) {  // the 16 lanes of this point, as bits 0 .. 15
+  return uint32_t( __ballot( pred ) >> ( lane & 48 ) ) & 0xFFFFu;
+}
+
 // bit j: knn[u][j] is a mutual strong neighbour of u (mutual bits: ensureMutualMask, shared with S7)
 template <int K>
 __global__ __launch_bounds__( 256 ) void strongMutualMaskKernel( const uint16_t* __restrict__ mutual, const double* __restrict__ edgeDot,
                                                                   uint32_t n, double tau, uint16_t* __restrict__ mask ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u >= n ) return;
-  uint32_t m = mutual[u], out = 0;
-  while ( m ) {
-    const int j = __ffs( int( m ) ) - 1;
-    m &= m - 1;
-    if ( fabs( edgeDot[size_t( u ) * K + j] ) >= tau ) out |= 1u << j;
-  }
-  mask[u] = uint16_t( out );
+  static_assert( K == 16, "16 lanes per point" );
+  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const bool     in = u < n;
+  const bool     strong = in && ( ( mutual[u] >> j ) & 1u ) && fabs( edgeDot[size_t( u ) * K + j] ) >= tau;
+  const uint32_t out    = ballot16( strong, lane );
+  if ( in && j == 0 ) mask[u] = uint16_t( out );
 }
 
 // Initial forest without a single atomic: every point hooks itself under the mutual strong neighbour of smallest hashed
@@ -44,23 +50,32 @@ template <int K>
 __global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
                                                            const uint16_t* __restrict__ mask, uint32_t n,
                                                            uint32_t* __restrict__ word, uint32_t* __restrict__ count ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i == n ) count[n] = 0;
-  if ( i >= n ) return;
-  count[i]      = 0;
-  uint32_t best = i, bestPrio = ufPriority( i ), parity = 0;
-  uint32_t m    = mask[i];
-  while ( m ) {
-    const int j = __ffs( int( m ) ) - 1;
-    m &= m - 1;
-    const uint32_t v = knn[size_t( i ) * K + j];
-    if ( ufPriority( v ) < bestPrio ) {
-      best     = v;
-      bestPrio = ufPriority( v );
-      parity   = edgeDot[size_t( i ) * K + j] < 0.0 ? 1u : 0u;
-    }
+  static_assert( K == 16, "16 lanes per point" );
+  const uint32_t i = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  const int      j = threadIdx.x & 15;
+  if ( i > n ) return;  // (uniform over the 16 lanes of a point)
+  if ( i == n ) {
+    if ( j == 0 ) count[n] = 0;
+    return;
   }
-  word[i] = ( best << 1 ) | ( best == i ? 0u : parity );
+  // candidate of this lane: neighbour j if it is a mutual strong one, else the point itself (first minimum wins below, as
+  // the sequential scan over the set bits in ascending j did: strict "<" kept the earliest)
+  const bool     cand = ( mask[i] >> j ) & 1u;
+  const uint32_t v    = cand ? knn[size_t( i ) * K + j] : i;
+  uint32_t       prio = cand ? ufPriority( v ) : 0xFFFFFFFFu;
+  uint32_t       best = v, parity = cand && edgeDot[size_t( i ) * K + j] < 0.0 ? 1u : 0u;
+  uint32_t       slot = uint32_t( j );
+#pragma unroll
+  for ( int off = 8; off > 0; off >>= 1 ) {  // minimum of (priority, j) over the 16 lanes
+    const uint32_t op = __shfl_xor( prio, off, 64 ), ob = __shfl_xor( best, off, 64 ), oq = __shfl_xor( parity, off, 64 ),
+                   os = __shfl_xor( slot, off, 64 );
+    if ( op < prio || ( op == prio && os < slot ) ) prio = op, best = ob, parity = oq, slot = os;
+  }
+  if ( j == 0 ) {
+    count[i] = 0;
+    if ( prio >= ufPriority( i ) ) best = i;  // (no mutual strong neighbour of smaller priority: its own root)
+    word[i] = ( best << 1 ) | ( best == i ? 0u : parity );
+  }
 }
 
 // root of x and the parity of x relative to it; halves the path on the way
@@ -125,24 +140,27 @@ __global__ __launch_bounds__( 256 ) void verifyCountKernel( const uint32_t* __re
                                                              const uint8_t* __restrict__ parity, uint32_t n,
                                                              uint32_t* __restrict__ count, uint16_t* __restrict__ crossMask,
                                                              uint32_t* __restrict__ bad ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u >= n ) return;
-  const uint32_t ru = root[u], m = mask[u];
-  const uint32_t pu = parity[u];
-  uint32_t       cross = 0;  // bit j: edge j leaves the cluster (kept for the scatter pass: no second round of gathers)
-  bool           wrong = false;
-#pragma unroll
-  for ( int j = 0; j < K; ++j ) {
-    const uint32_t v = knn[size_t( u ) * K + j];
-    if ( root[v] != ru ) cross |= 1u << j;
-    if ( ( m >> j ) & 1u ) {
+  static_assert( K == 16, "16 lanes per point" );
+  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const bool     in = u < n;
+  bool           isCross = false, wrong = false;
+  uint32_t       ru = 0;
+  if ( in ) {
+    ru                 = root[u];
+    const uint32_t v   = knn[size_t( u ) * K + j];
+    isCross            = root[v] != ru;
+    if ( ( mask[u] >> j ) & 1u ) {
       const uint32_t s = edgeDot[size_t( u ) * K + j] < 0.0 ? 1u : 0u;
-      wrong |= ( pu ^ parity[v] ) != s;
+      wrong            = ( uint32_t( parity[u] ) ^ parity[v] ) != s;
     }
   }
-  crossMask[u] = uint16_t( cross );
-  if ( cross ) atomicAdd( &count[ru], uint32_t( __popc( cross ) ) );
-  if ( wrong ) *bad = 1u;
+  const uint32_t cross = ballot16( isCross, lane );  // bit j: edge j leaves the cluster (kept for the scatter pass)
+  if ( __ballot( wrong ) && lane == 0 ) *bad = 1u;
+  if ( in && j == 0 ) {
+    crossMask[u] = uint16_t( cross );
+    if ( cross ) atomicAdd( &count[ru], uint32_t( __popc( cross ) ) );
+  }
 }
 
 template <int K>
@@ -150,17 +168,17 @@ __global__ __launch_bounds__( 256 ) void scatterCrossKernel( const uint32_t* __r
                                                               const uint32_t* __restrict__ root, const uint32_t* __restrict__ off,
                                                               const uint16_t* __restrict__ crossMask, uint32_t n,
                                                               uint32_t* __restrict__ cursor, OrientCrossEdge* __restrict__ edges ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u >= n ) return;
-  uint32_t m = crossMask[u];
+  static_assert( K == 16, "16 lanes per point" );
+  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  const int      j = threadIdx.x & 15;
+  if ( u >= n ) return;  // (uniform over the 16 lanes of a point)
+  const uint32_t m = crossMask[u];
   if ( !m ) return;
-  const uint32_t ru = root[u];
-  uint32_t       at = off[ru] + atomicAdd( &cursor[ru], uint32_t( __popc( m ) ) );
-  while ( m ) {
-    const int j = __ffs( int( m ) ) - 1;
-    m &= m - 1;
-    edges[at++] = OrientCrossEdge{u, knn[size_t( u ) * K + j], edgeDot[size_t( u ) * K + j]};
-  }
+  uint32_t at = 0;
+  if ( j == 0 ) at = off[root[u]] + atomicAdd( &cursor[root[u]], uint32_t( __popc( m ) ) );
+  at = __shfl( at, ( threadIdx.x & 63 ) & 48, 64 );
+  if ( ( m >> j ) & 1u )  // (edges of a point in ascending j, as the sequential scan over the set bits wrote them)
+    edges[at + __popc( m & ( ( 1u << j ) - 1u ) )] = OrientCrossEdge{u, knn[size_t( u ) * K + j], edgeDot[size_t( u ) * K + j]};
 }
 
 __global__ __launch_bounds__( 256 ) void clusterSignsKernel( const uint32_t* __restrict__ root, const uint8_t* __restrict__ parity,
@@ -227,17 +245,18 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   TMC2_TRY( d_mask.alloc( n ) );
   TMC2_TRY( d_root.alloc( n ) );
   TMC2_TRY( d_parity.alloc( n ) );
-  const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 ), grdN1( ( n + 256 ) / 256 );
+  const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
   TMC2_HIP( hipMemsetAsync( d_small.p, 0, 16, s ) );
   TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( n ) * 4, s ) );
   TMC2_TRY( ensureMutualMask( f ) );
-  hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );
-  hipLaunchKernelGGL( initWordsKernel<16>, grdN1, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, d_count.p );
+  const dim3 grdN16( ( n + 15 ) / 16 ), grdN16p( ( n + 16 ) / 16 );  // 16 lanes per point (... and one more "point" for count[n])
+  hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN16, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );
+  hipLaunchKernelGGL( initWordsKernel<16>, grdN16p, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, d_count.p );
   hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p );
   hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p );
   DevBuf<uint16_t> d_crossMask;
   TMC2_TRY( d_crossMask.alloc( n ) );
-  hipLaunchKernelGGL( verifyCountKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_parity.p, n,
+  hipLaunchKernelGGL( verifyCountKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_parity.p, n,
                       d_count.p, d_crossMask.p, d_small.p );
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
   uint32_t head[2] = {0, 0};
@@ -247,7 +266,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   const uint32_t   E = head[1];
   DevBuf<OrientCrossEdge> d_edges;
   TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
-  hipLaunchKernelGGL( scatterCrossKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_root.p, d_off.p, d_crossMask.p, n,
+  hipLaunchKernelGGL( scatterCrossKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_root.p, d_off.p, d_crossMask.p, n,
                       d_cursor.p, d_edges.p );
   uint32_t*        h_root   = ctx->hostA.get<uint32_t>( 2 * size_t( n ) + 2 );  // root | off
   uint8_t*         h_parity = ctx->hostC.get<uint8_t>( 2 * size_t( n ) );       // parity | (cluster signs, see the caller)
