@@ -9,54 +9,26 @@
 // RESULT order (needed only where the reference sums fp64 normals in result order) is the k-d tree visiting order,
 // independent of k -- so one exact k=16 search per query serves all of them; a group that fills all 16 slots is
 // reported as unsupported instead of being approximated.
-// Device: the four query batches (exact nanoflann-order k-NN kernel), the per-recon-point ordered normal
-// accumulation, the per-point distortion terms.  Host: lexicographic de-duplication (a counting sort, lex_order.h), the three tree builds,
-// and the final ORDERED fp64 sums over the points (the reference accumulates sequentially; D1 is a sum of
-// integers and order-free, D2 and colour are not).
+// Everything runs on the device: the lexicographic de-duplication (a stable radix sort of (x, y, z) keys -- hipCUB's device
+// radix sort is the one library primitive used -- then run heads, a prefix sum and one thread per distinct position that
+// averages the colours of its run), the tree builds, the four query batches (exact nanoflann-order k-NN kernel), the
+// per-recon-point ordered normal accumulation, the per-point distortion terms and the final sums.  D1 is a sum of
+// integers (exact in fp64, order-free): a parallel 64-bit reduction.  D2 and the colour errors are fp64 sums whose value
+// depends on the order: four lanes walk the terms in the reference's order (one dependent add per point each) while the
+// rest of the workgroup streams the next chunk into LDS.  Only the 3 x 8 results cross PCIe on the way back.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <numeric>
 
+#include <hipcub/hipcub.hpp>
+
 #include "internal.h"
-#include "lex_order.h"
 
 namespace tmc2 {
 namespace {
 
 constexpr int K = 16;
-
-struct HostCloud {
-  std::vector<int16_t> xyz;
-  std::vector<uint8_t> rgb;
-  std::vector<double>  nrm;
-  size_t               size() const { return xyz.size() / 3; }
-};
-
-HostCloud dedupLexicographic( const int16_t* xyz, const uint8_t* rgb, size_t n, std::vector<uint32_t>* orderOut = nullptr ) {
-  // (x, y, z) order, ties keep input order
-  std::vector<uint32_t> local;
-  std::vector<uint32_t>& order = orderOut ? *orderOut : local;
-  lexOrderStable( xyz, n, order );
-  auto same = [&]( uint32_t a, uint32_t b ) {
-    return xyz[3 * size_t( a )] == xyz[3 * size_t( b )] && xyz[3 * size_t( a ) + 1] == xyz[3 * size_t( b ) + 1] &&
-           xyz[3 * size_t( a ) + 2] == xyz[3 * size_t( b ) + 2];
-  };
-  HostCloud c;
-  c.xyz.reserve( 3 * n );
-  c.rgb.reserve( 3 * n );
-  for ( size_t i = 0; i < n; ) {
-    size_t j = i + 1;
-    while ( j < n && same( order[j], order[i] ) ) ++j;
-    for ( int d = 0; d < 3; ++d ) c.xyz.push_back( xyz[3 * size_t( order[i] ) + d] );
-    size_t s[3] = {0, 0, 0};
-    for ( size_t k = i; k < j; ++k )
-      for ( int d = 0; d < 3; ++d ) s[d] += rgb[3 * size_t( order[k] ) + d];
-    for ( int d = 0; d < 3; ++d ) c.rgb.push_back( uint8_t( s[d] / ( j - i ) ) );
-    i = j;
-  }
-  return c;
-}
 
 // a cloud + its tree on the device
 struct DevCloud {
@@ -74,29 +46,104 @@ struct DevCloud {
     t.depth = tree.depth, t.n = n;
     return t;
   }
+  int buildTree( tmc2_ctx* ctx ) { return buildKdTreeDevice( ctx, pts.p, n, ptsTree, perm, nodes, tree.lo, tree.hi, tree.depth ); }
+  // this cloud's tree as queried with the points of `q` (whose own tree gives their bounding box: the packed LDS-stack
+  // traversal of the k-NN kernel needs every query coordinate within [-4096, 12287])
+  TreeDev devFor( const DevCloud& q ) const {
+    TreeDev t        = dev();
+    t.queriesBounded = true;
+    for ( int d = 0; d < 3; ++d ) t.queriesBounded = t.queriesBounded && q.tree.lo[d] >= -4096 && q.tree.hi[d] <= 12287;
+    return t;
+  }
 };
 
-int uploadCloud( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, const double* nrm, size_t n, bool withTree,
-                 DevCloud& dc ) {
-  hipStream_t s = ctx->stream;
-  dc.n          = n;
-  std::vector<Pt> pts( n );
-  for ( size_t i = 0; i < n; ++i ) pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0};
-  TMC2_TRY( dc.pts.alloc( n ) );
-  TMC2_HIP( hipMemcpyAsync( dc.pts.p, pts.data(), n * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
-  std::vector<uint8_t> c4;
-  if ( withTree ) TMC2_TRY( buildKdTreeDevice( ctx, dc.pts.p, n, dc.ptsTree, dc.perm, dc.nodes, dc.tree.lo, dc.tree.hi, dc.tree.depth ) );
-  if ( rgb ) {
-    c4.resize( 4 * n );
-    for ( size_t i = 0; i < n; ++i ) c4[4 * i] = rgb[3 * i], c4[4 * i + 1] = rgb[3 * i + 1], c4[4 * i + 2] = rgb[3 * i + 2], c4[4 * i + 3] = 0;
-    TMC2_TRY( dc.rgb4.alloc( 4 * n ) );
-    TMC2_HIP( hipMemcpyAsync( dc.rgb4.p, c4.data(), 4 * n, hipMemcpyHostToDevice, s ) );
+// ---- PCCPointSet3::removeDuplicate on the device ---------------------------------------------------------------------------
+// (x, y, z) order = ascending 48-bit key (coordinates biased to unsigned); the sort is stable, so the first element of a
+// run of equal keys is the duplicate with the smallest input index -- the one the reference keeps the position of.
+__global__ __launch_bounds__( 256 ) void positionKeysKernel( const int16_t* __restrict__ xyz, uint32_t n, uint64_t* __restrict__ key,
+                                                              uint32_t* __restrict__ index ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n ) return;
+  const uint64_t x = uint16_t( int( xyz[3 * size_t( i )] ) + 32768 ), y = uint16_t( int( xyz[3 * size_t( i ) + 1] ) + 32768 ),
+                 z = uint16_t( int( xyz[3 * size_t( i ) + 2] ) + 32768 );
+  key[i]   = ( x << 32 ) | ( y << 16 ) | z;
+  index[i] = i;
+}
+__global__ __launch_bounds__( 256 ) void runHeadKernel( const uint64_t* __restrict__ key, uint32_t n, uint32_t* __restrict__ head ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i < n ) head[i] = ( i == 0 || key[i] != key[i - 1] ) ? 1u : 0u;
+}
+// one thread per run: position of its first element, colour = integer mean over the run (removeDuplicate :188-206)
+__global__ __launch_bounds__( 256 ) void emitDistinctKernel( const uint64_t* __restrict__ key, const uint32_t* __restrict__ index,
+                                                              const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank,
+                                                              const uint8_t* __restrict__ rgb, uint32_t n, Pt* __restrict__ pts,
+                                                              uint8_t* __restrict__ rgb4, uint32_t* __restrict__ first ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n || !head[i] ) return;
+  const uint64_t k = key[i];
+  uint32_t       r = 0, g = 0, b = 0, c = 0;
+  for ( uint32_t j = i; j < n && key[j] == k; ++j ) {
+    const size_t o = 3 * size_t( index[j] );
+    r += rgb[o], g += rgb[o + 1], b += rgb[o + 2];
+    ++c;
   }
-  if ( nrm ) {
-    TMC2_TRY( dc.nrm.alloc( 3 * n ) );
-    TMC2_HIP( hipMemcpyAsync( dc.nrm.p, nrm, 3 * n * sizeof( double ), hipMemcpyHostToDevice, s ) );
-  }
-  TMC2_HIP( hipStreamSynchronize( s ) );  // staging vectors go out of scope
+  const uint32_t u = rank[i];
+  pts[u]           = Pt{int16_t( int( ( k >> 32 ) & 0xFFFF ) - 32768 ), int16_t( int( ( k >> 16 ) & 0xFFFF ) - 32768 ),
+              int16_t( int( k & 0xFFFF ) - 32768 ), 0};
+  reinterpret_cast<uchar4*>( rgb4 )[u] = make_uchar4( (unsigned char)( r / c ), (unsigned char)( g / c ), (unsigned char)( b / c ), 0 );
+  first[u]                             = index[i];
+}
+__global__ __launch_bounds__( 256 ) void rawPointsKernel( const int16_t* __restrict__ xyz, uint32_t n, Pt* __restrict__ pts ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i < n ) pts[i] = Pt{xyz[3 * size_t( i )], xyz[3 * size_t( i ) + 1], xyz[3 * size_t( i ) + 2], 0};
+}
+__global__ __launch_bounds__( 256 ) void gatherPointsKernel( const Pt* __restrict__ pts, const uint32_t* __restrict__ which, uint32_t n,
+                                                              Pt* __restrict__ out ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i < n ) out[i] = pts[which[i]];
+}
+__global__ __launch_bounds__( 256 ) void gatherNormalsKernel( const double* __restrict__ nrm, const uint32_t* __restrict__ first,
+                                                               uint32_t n, double* __restrict__ out ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n ) return;
+  const size_t o = 3 * size_t( first[i] );
+  out[3 * size_t( i )] = nrm[o], out[3 * size_t( i ) + 1] = nrm[o + 1], out[3 * size_t( i ) + 2] = nrm[o + 2];
+}
+
+// d_xyz / d_rgb: the cloud as the caller gave it (int16[n][3], uint8[n][3]) -> the distinct positions in (x, y, z) order with
+// averaged colours; first[u] = input index of the duplicate whose position / normal the reference keeps
+int removeDuplicatesDevice( tmc2_ctx* ctx, const int16_t* d_xyz, const uint8_t* d_rgb, uint32_t n, DevCloud& out,
+                            DevBuf<uint32_t>& d_first ) {
+  hipStream_t      s = ctx->stream;
+  DevBuf<uint64_t> d_keyIn, d_keyOut;
+  DevBuf<uint32_t> d_idxIn, d_idxOut, d_head, d_rank, d_total;
+  DevBuf<uint8_t>  d_tmp;
+  TMC2_TRY( d_keyIn.alloc( n ) );
+  TMC2_TRY( d_keyOut.alloc( n ) );
+  TMC2_TRY( d_idxIn.alloc( n ) );
+  TMC2_TRY( d_idxOut.alloc( n ) );
+  TMC2_TRY( d_head.alloc( n ) );
+  TMC2_TRY( d_rank.alloc( n ) );
+  TMC2_TRY( d_total.alloc( 1 ) );
+  const dim3 blk( 256 ), grd( ( n + 255 ) / 256 );
+  hipLaunchKernelGGL( positionKeysKernel, grd, blk, 0, s, d_xyz, n, d_keyIn.p, d_idxIn.p );
+  size_t tmpBytes = 0;
+  TMC2_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, tmpBytes, d_keyIn.p, d_keyOut.p, d_idxIn.p, d_idxOut.p, int( n ), 0, 48, s ) );
+  TMC2_TRY( d_tmp.alloc( tmpBytes + 16 ) );
+  TMC2_HIP( hipcub::DeviceRadixSort::SortPairs( d_tmp.p, tmpBytes, d_keyIn.p, d_keyOut.p, d_idxIn.p, d_idxOut.p, int( n ), 0, 48, s ) );
+  hipLaunchKernelGGL( runHeadKernel, grd, blk, 0, s, d_keyOut.p, n, d_head.p );
+  TMC2_TRY( exclusiveScanU32( ctx, d_head.p, d_rank.p, n, d_total.p ) );
+  uint32_t distinct = 0;
+  TMC2_HIP( hipMemcpyAsync( &distinct, d_total.p, 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  out.n = distinct;
+  TMC2_TRY( out.pts.alloc( distinct ) );
+  TMC2_TRY( out.rgb4.alloc( 4 * size_t( distinct ) ) );
+  TMC2_TRY( d_first.alloc( distinct ) );
+  hipLaunchKernelGGL( emitDistinctKernel, grd, blk, 0, s, d_keyOut.p, d_idxOut.p, d_head.p, d_rank.p, d_rgb, n, out.pts.p,
+                      out.rgb4.p, d_first.p );
+  TMC2_HIP( hipGetLastError() );
+  TMC2_HIP( hipStreamSynchronize( s ) );  // (the temporaries go back to the pool)
   return TMC2_OK;
 }
 
@@ -232,6 +279,47 @@ __global__ __launch_bounds__( 256 ) void distortionTermsKernel( const Pt* __rest
   t[4]           = double( float( dv * dv ) );
 }
 
+// ---- the sums over the points ---------------------------------------------------------------------------------------------
+// terms[a][0] (squared distances: integers) are summed as 64-bit integers by everybody; terms[a][1 .. 4] (D2 and the three
+// colour errors) in the reference's order, a = 0, 1, 2, ...: lanes 0 .. 3 of the first wave add one column each from LDS,
+// chunk by chunk, while the other waves fetch the next chunk.  out[0 .. 4] = the five sums as doubles.
+constexpr int kSumChunk = 1024;
+__global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __restrict__ terms, uint32_t n, double* __restrict__ out ) {
+  __shared__ double             buf[2][kSumChunk * 4];
+  __shared__ unsigned long long d1Total;
+  if ( threadIdx.x == 0 ) d1Total = 0;
+  const uint32_t     chunks = ( n + kSumChunk - 1 ) / kSumChunk;
+  double             acc    = 0.0;  // (lanes 0 .. 3: one ordered sum each)
+  unsigned long long d1     = 0;
+  auto               fetch  = [&]( uint32_t c, int slot ) {
+    const uint32_t a = c * kSumChunk + threadIdx.x;
+    if ( a < n ) {
+      const double* t = terms + 5 * size_t( a );
+      d1 += (unsigned long long)t[0];
+#pragma unroll
+      for ( int k = 0; k < 4; ++k ) buf[slot][4 * threadIdx.x + k] = t[1 + k];
+    }
+  };
+  if ( chunks ) fetch( 0, 0 );
+  __syncthreads();
+  for ( uint32_t c = 0; c < chunks; ++c ) {
+    const int slot = int( c & 1 );
+    if ( threadIdx.x >= 64 ) {
+      if ( c + 1 < chunks ) fetch( c + 1, slot ^ 1 );
+    } else if ( threadIdx.x < 4 ) {
+      const uint32_t cnt = min( uint32_t( kSumChunk ), n - c * kSumChunk );
+      for ( uint32_t j = 0; j < cnt; ++j ) acc += buf[slot][4 * j + threadIdx.x];
+    }
+    __syncthreads();
+    if ( threadIdx.x < 64 && c + 1 < chunks ) fetch( c + 1, slot ^ 1 );  // (the first wave's share of the next chunk)
+    __syncthreads();
+  }
+  atomicAdd( &d1Total, d1 );
+  __syncthreads();
+  if ( threadIdx.x == 0 ) out[0] = double( d1Total );
+  if ( threadIdx.x < 4 ) out[1 + threadIdx.x] = acc;
+}
+
 double psnr( double dist, double p, double factor ) { return 10 * std::log10( ( factor * p * p ) / dist ); }
 
 int quality( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, double resolution, double* out,
@@ -239,21 +327,20 @@ int quality( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNorma
   hipStream_t      s = ctx->stream;
   const uint32_t   nA = uint32_t( A.n );
   DevBuf<uint32_t> d_idx, d_dist;
-  DevBuf<double>   d_terms;
+  DevBuf<double>   d_terms, d_sums;
   TMC2_TRY( d_idx.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_dist.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_terms.alloc( size_t( nA ) * 5 ) );
-  TMC2_TRY( launchKnnTree( ctx, B.dev(), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
+  TMC2_TRY( d_sums.alloc( 8 ) );
+  TMC2_TRY( launchKnnTree( ctx, B.devFor( A ), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
   const int sid = ctx->stageBegin( "metrics_terms" );
   hipLaunchKernelGGL( distortionTermsKernel, dim3( ( nA + 255 ) / 256 ), dim3( 256 ), 0, s, A.pts.p, A.rgb4.p, B.pts.p, B.rgb4.p,
                       withNormals ? B.nrm.p : (const double*)nullptr, d_idx.p, d_dist.p, nA, d_terms.p, d_error );
+  hipLaunchKernelGGL( orderedSumsKernel, dim3( 1 ), dim3( 1024 ), 0, s, d_terms.p, nA, d_sums.p );
   ctx->stageEnd( sid );
-  std::vector<double> terms( size_t( nA ) * 5 );
-  TMC2_HIP( hipMemcpyAsync( terms.data(), d_terms.p, terms.size() * sizeof( double ), hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
   double sse[5] = {0, 0, 0, 0, 0};
-  for ( size_t a = 0; a < nA; ++a )  // the reference's accumulation order
-    for ( int k = 0; k < 5; ++k ) sse[k] += terms[5 * a + k];
+  TMC2_HIP( hipMemcpyAsync( sse, d_sums.p, sizeof( sse ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
   const double num = double( nA );
   out[0]           = sse[0] / num;
   out[1]           = psnr( out[0], resolution, 3 );
@@ -277,37 +364,57 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
   }
   ApiScope    scope( ctx );
   hipStream_t s  = ctx->stream;
-  const auto  t0 = std::chrono::steady_clock::now();
-  std::vector<uint32_t> srcOrder;
-  HostCloud   S = dedupLexicographic( srcXyz, srcRgb, n, &srcOrder ), R = dedupLexicographic( recXyz, recRgb, m );
-  if ( counts ) counts[0] = int64_t( S.size() ), counts[1] = int64_t( R.size() );
+  const int   sidPrep = ctx->stageBegin( "metrics_prepare" );
+  // the clouds as given, to the device (9 bytes per point each way; fp64 normals: 24 per source point)
+  DevBuf<int16_t> d_srcXyz, d_recXyz;
+  DevBuf<uint8_t> d_srcRgb, d_recRgb;
+  DevBuf<double>  d_srcNrm;
+  TMC2_TRY( d_srcXyz.alloc( 3 * size_t( n ) ) );
+  TMC2_TRY( d_srcRgb.alloc( 3 * size_t( n ) ) );
+  TMC2_TRY( d_recXyz.alloc( 3 * size_t( m ) ) );
+  TMC2_TRY( d_recRgb.alloc( 3 * size_t( m ) ) );
+  TMC2_HIP( hipMemcpyAsync( d_srcXyz.p, srcXyz, 6 * size_t( n ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_srcRgb.p, srcRgb, 3 * size_t( n ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_recXyz.p, recXyz, 6 * size_t( m ), hipMemcpyHostToDevice, s ) );
+  TMC2_HIP( hipMemcpyAsync( d_recRgb.p, recRgb, 3 * size_t( m ), hipMemcpyHostToDevice, s ) );
   const bool withNormals = srcNormals != nullptr;
-  if ( S.size() < size_t( K ) || R.size() < size_t( K ) ) {
+  if ( withNormals ) {
+    TMC2_TRY( d_srcNrm.alloc( 3 * size_t( n ) ) );
+    TMC2_HIP( hipMemcpyAsync( d_srcNrm.p, srcNormals, 3 * size_t( n ) * sizeof( double ), hipMemcpyHostToDevice, s ) );
+  }
+  DevCloud         dS, dR, dN;  // de-duplicated source, de-duplicated reconstruction, normal cloud (original source order)
+  DevBuf<uint32_t> d_firstS, d_firstR;
+  TMC2_TRY( removeDuplicatesDevice( ctx, d_srcXyz.p, d_srcRgb.p, uint32_t( n ), dS, d_firstS ) );
+  TMC2_TRY( removeDuplicatesDevice( ctx, d_recXyz.p, d_recRgb.p, uint32_t( m ), dR, d_firstR ) );
+  if ( counts ) counts[0] = int64_t( dS.n ), counts[1] = int64_t( dR.n );
+  if ( dS.n < size_t( K ) || dR.n < size_t( K ) ) {
     setError( "metrics_compute: clouds smaller than %d points unsupported", K );
     return TMC2_E_UNSUPPORTED;
   }
+  const dim3 blk( 256 );
   if ( withNormals ) {
-    if ( S.size() != n ) {
+    if ( dS.n != n ) {
       setError( "metrics_compute: the source has duplicate positions; normals cannot be attached (the reference exits)" );
       return TMC2_E_INVALID;
     }
-    // copyNormals: the de-duplicated source is the lexicographic sort of the input (srcOrder)
-    S.nrm.resize( 3 * n );
-    for ( size_t i = 0; i < n; ++i )
-      for ( int d = 0; d < 3; ++d ) S.nrm[3 * i + d] = srcNormals[3 * size_t( srcOrder[i] ) + d];
+    // copyNormals: the de-duplicated source is the lexicographic sort of the input
+    TMC2_TRY( dS.nrm.alloc( 3 * size_t( n ) ) );
+    hipLaunchKernelGGL( gatherNormalsKernel, dim3( uint32_t( ( n + 255 ) / 256 ) ), blk, 0, s, d_srcNrm.p, d_firstS.p, uint32_t( n ),
+                        dS.nrm.p );
   }
-  DevCloud dS, dR, dN;  // de-duplicated source, de-duplicated reconstruction, normal cloud (original source order)
-  TMC2_TRY( uploadCloud( ctx, S.xyz.data(), S.rgb.data(), withNormals ? S.nrm.data() : nullptr, S.size(), true, dS ) );
-  TMC2_TRY( uploadCloud( ctx, R.xyz.data(), R.rgb.data(), nullptr, R.size(), true, dR ) );
-  ctx->stageAddHostMs( "metrics_host_prepare", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count() );
+  TMC2_TRY( dS.buildTree( ctx ) );
+  TMC2_TRY( dR.buildTree( ctx ) );
+  ctx->stageEnd( sidPrep );
   DevBuf<uint32_t> d_error;
   TMC2_TRY( d_error.alloc( 1 ) );
   TMC2_HIP( hipMemsetAsync( d_error.p, 0, 4, s ) );
-  const dim3 blk( 256 );
   if ( withNormals ) {
     // scaleNormals
-    const uint32_t mR = uint32_t( R.size() ), nS = uint32_t( n );
-    TMC2_TRY( uploadCloud( ctx, srcXyz, nullptr, srcNormals, n, false, dN ) );
+    const uint32_t mR = uint32_t( dR.n ), nS = uint32_t( n );
+    dN.n = n;  // the normal cloud: the source in its original order (no duplicates: checked above)
+    TMC2_TRY( dN.pts.alloc( n ) );
+    hipLaunchKernelGGL( rawPointsKernel, dim3( uint32_t( ( n + 255 ) / 256 ) ), blk, 0, s, d_srcXyz.p, uint32_t( n ), dN.pts.p );
+    const double* d_nrmN = d_srcNrm.p;
     DevBuf<uint32_t> d_idx, d_dist, d_count, d_offset, d_cursor, d_voters, d_total;
     TMC2_TRY( d_idx.alloc( size_t( nS ) * K ) );
     TMC2_TRY( d_dist.alloc( size_t( nS ) * K ) );
@@ -316,7 +423,7 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
     TMC2_TRY( d_cursor.alloc( mR ) );
     TMC2_TRY( d_total.alloc( 1 ) );
     TMC2_TRY( dR.nrm.alloc( 3 * size_t( mR ) ) );
-    TMC2_TRY( launchKnnTree( ctx, dR.dev(), dN.pts.p, nS, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
+    TMC2_TRY( launchKnnTree( ctx, dR.devFor( dS ), dN.pts.p, nS, K, d_idx.p, d_dist.p, "metrics_knn16" ) );  // (dN = the points of dS)
     TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( mR ) * 4, s ) );
     TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( mR ) * 4, s ) );
     hipLaunchKernelGGL( votesCountKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, nS, d_count.p, d_error.p );
@@ -329,28 +436,25 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
     TMC2_TRY( d_voters.alloc( std::max( total, 1u ) ) );
     hipLaunchKernelGGL( votesFillKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, nS, d_offset.p, d_cursor.p,
                         d_voters.p );
-    hipLaunchKernelGGL( votesReduceKernel, dim3( ( mR + 255 ) / 256 ), blk, 0, s, d_count.p, d_offset.p, d_voters.p, dN.nrm.p, mR,
+    hipLaunchKernelGGL( votesReduceKernel, dim3( ( mR + 255 ) / 256 ), blk, 0, s, d_count.p, d_offset.p, d_voters.p, d_nrmN, mR,
                         dR.nrm.p );
     std::vector<uint32_t> orphans;
     for ( uint32_t r = 0; r < mR; ++r )
       if ( h_count[r] == 0 ) orphans.push_back( r );
     if ( !orphans.empty() ) {
       // these query the tree of the NORMAL cloud (original source order)
-      DevCloud dNT;
-      TMC2_TRY( uploadCloud( ctx, srcXyz, nullptr, nullptr, n, true, dNT ) );
+      TMC2_TRY( dN.buildTree( ctx ) );
       const uint32_t   nO = uint32_t( orphans.size() );
-      std::vector<Pt>  q( nO );
-      for ( uint32_t o = 0; o < nO; ++o ) q[o] = Pt{R.xyz[3 * size_t( orphans[o] )], R.xyz[3 * size_t( orphans[o] ) + 1], R.xyz[3 * size_t( orphans[o] ) + 2], 0};
       DevBuf<Pt>       d_q;
       DevBuf<uint32_t> d_orph, d_oi, d_od;
       TMC2_TRY( d_q.alloc( nO ) );
       TMC2_TRY( d_orph.alloc( nO ) );
       TMC2_TRY( d_oi.alloc( size_t( nO ) * K ) );
       TMC2_TRY( d_od.alloc( size_t( nO ) * K ) );
-      TMC2_HIP( hipMemcpyAsync( d_q.p, q.data(), size_t( nO ) * sizeof( Pt ), hipMemcpyHostToDevice, s ) );
       TMC2_HIP( hipMemcpyAsync( d_orph.p, orphans.data(), size_t( nO ) * 4, hipMemcpyHostToDevice, s ) );
-      TMC2_TRY( launchKnnTree( ctx, dNT.dev(), d_q.p, nO, K, d_oi.p, d_od.p, "metrics_knn16" ) );
-      hipLaunchKernelGGL( orphanNormalsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, d_orph.p, nO, d_oi.p, d_od.p, dN.nrm.p,
+      hipLaunchKernelGGL( gatherPointsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, dR.pts.p, d_orph.p, nO, d_q.p );
+      TMC2_TRY( launchKnnTree( ctx, dN.devFor( dR ), d_q.p, nO, K, d_oi.p, d_od.p, "metrics_knn16" ) );
+      hipLaunchKernelGGL( orphanNormalsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, d_orph.p, nO, d_oi.p, d_od.p, d_nrmN,
                           dR.nrm.p, d_error.p );
       TMC2_HIP( hipStreamSynchronize( s ) );
     }
