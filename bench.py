@@ -45,6 +45,7 @@ def parse():
                     help="where the k-d trees are built (auto = device)")
     ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
+    ap.add_argument("--ingest", type=int, default=1, help="0 skips the (untimed) PLY ingest measurement")
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
@@ -247,6 +248,37 @@ def host_slots(host_steps, world, frames_per_rank):
     split over the ranks, but never fewer than the frames a rank has in flight need to make progress side by side
     (at most 4): 8 ranks x 4 frames must not queue behind 2 slots each."""
     return int(max(min(max(frames_per_rank, 1), 4), host_steps // max(world, 1)))
+
+
+def ingest_leg(T, torch, ctx, cloud):
+    """PLY file -> page-locked host arrays (tmc2_ply_read) -> frame resident in HBM (tmc2_frame_create), per format."""
+    import tempfile
+    import numpy as np
+    xyz, rgb = cloud
+    n = len(xyz)
+    res = {"points": int(n), "what": "PCCPointSet3::read replacement: file (page cache) -> page-locked buffers -> frame in HBM; "
+                                     "ms per frame, one frame at a time; threads = parser threads"}
+    hx = torch.empty((n, 3), dtype=torch.int16, pin_memory=True).numpy()
+    hc = torch.empty((n, 3), dtype=torch.uint8, pin_memory=True).numpy()
+    with tempfile.TemporaryDirectory() as d:
+        for name, ascii_ in (("ascii", True), ("binary", False)):
+            path = os.path.join(d, name + ".ply")
+            T.ply_write(path, xyz, rgb, None, ascii=ascii_)
+            size = os.path.getsize(path)
+            for threads in (1, 16):
+                T.ply_read(path, threads=threads, out=(hx, hc))          # warm (page cache, allocations)
+                t0 = time.time()
+                T.ply_read(path, threads=threads, out=(hx, hc))
+                t1 = time.time()
+                fr = ctx.frame(hx, hc)
+                torch.cuda.synchronize()
+                t2 = time.time()
+                del fr
+                res["%s_threads%d" % (name, threads)] = {"file_MB": round(size / 1e6, 1), "parse_ms": round(1e3 * (t1 - t0), 2),
+                                                         "upload_ms": round(1e3 * (t2 - t1), 2),
+                                                         "parse_MB_per_s": round(size / 1e6 / (t1 - t0), 1)}
+        assert np.array_equal(hx, xyz) and np.array_equal(hc, rgb)
+    return res
 
 
 def gather_canvases(enc, frames, sharder, cache, pin=True):
@@ -490,6 +522,13 @@ def main():
                            "stage_ms_alone": {k: round(v, 3) for k, v in sorted(tail_ms.items()) if v > 0}}
         except Exception as e:                                 # never lose the metric line over the side measurement
             out["tail"] = {"error": repr(e)}
+    # PLY ingest, outside the metric too: one frame written as the reference writes it (ASCII,
+    # as the 8i / Owlii content ships, and binary), read straight into page-locked buffers, uploaded and bound to a frame
+    if world == 1 and a.ingest:
+        try:
+            out["ingest"] = ingest_leg(T, torch, enc.ctxs[0], clouds[0])
+        except Exception as e:
+            out["ingest"] = {"error": repr(e)}
     if a.cpu_baseline and world == 1:                          # rank 0 at N = 1 only (the contract of the bench line)
         out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations, clouds)
         for key in ("all_cores_value", "frame_processes_value"):

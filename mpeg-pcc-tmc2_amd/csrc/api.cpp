@@ -188,7 +188,7 @@ void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   {
     ApiScope scope( ctx );
     ctx->gridTable.release();
-    ctx->scratchU32.release();
+    ctx->scanState.release();
     ctx->voxelBitmap.release();
   }
   if ( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );

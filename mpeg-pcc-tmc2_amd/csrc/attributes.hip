@@ -297,6 +297,71 @@ __global__ __launch_bounds__( 256 ) void pushPullBlurKernel( const uint8_t* __re
   if ( i < W * H ) pushPullBlurPixel( i, src, dst, occ, W, H );
 }
 
+// One level of the way up in ONE launch: the fill from the coarser level and all `iters` blur passes, a 96 x 96 tile of one
+// plane per workgroup, in LDS.  The tile is loaded with a margin of `iters` pixels (clipped to the image): a blur pass reads
+// the 8 neighbours, so what a pass computes next to a cut edge of the region is wrong one pixel further in per pass -- and
+// after `iters` passes has just not reached the tile.  Coordinates clamp at the region's edges, which are the image's edges
+// wherever the clamp is the reference's.  Occupied pixels never change; only unoccupied pixels of the tile are written, and no
+// workgroup reads a pixel another one writes (unoccupied pixels are computed from the coarser level, not loaded).
+constexpr int kPushPullTile = 96, kPushPullSpan = 128, kPushPullMaxIters = ( kPushPullSpan - kPushPullTile ) / 2;
+__global__ __launch_bounds__( 1024 ) void pushPullFillBlurKernel( uint8_t* __restrict__ img, const uint8_t* __restrict__ occ, int W,
+                                                                   int H, const uint8_t* __restrict__ mip, int w, int h, int iters,
+                                                                   int tilesX ) {
+  __shared__ uint8_t sOcc[kPushPullSpan * kPushPullSpan];
+  __shared__ uint8_t sBuf[2][kPushPullSpan * kPushPullSpan];
+  const int      X0 = ( blockIdx.x % tilesX ) * kPushPullTile, Y0 = ( blockIdx.x / tilesX ) * kPushPullTile;
+  const int      RX0 = max( X0 - iters, 0 ), RY0 = max( Y0 - iters, 0 );
+  const int      RW = min( X0 + kPushPullTile + iters, W ) - RX0, RH = min( Y0 + kPushPullTile + iters, H ) - RY0;
+  uint8_t*       plane = img + size_t( blockIdx.y ) * W * H;
+  const uint8_t* m     = mip + size_t( blockIdx.y ) * w * h;
+  for ( int i = threadIdx.x; i < kPushPullSpan * RH; i += 1024 ) {
+    const int rx = i & ( kPushPullSpan - 1 ), ry = i >> 7;
+    if ( rx >= RW ) continue;
+    const int     X = RX0 + rx, Y = RY0 + ry;
+    const size_t  g = size_t( Y ) * W + X;
+    const uint8_t o = occ[g];
+    uint8_t       v;
+    if ( o ) {
+      v = plane[g];
+    } else {  // pushPullFillPixel, this plane
+      const int  x = X >> 1, y = Y >> 1, dx = ( X & 1 ) ? 1 : -1, dy = ( Y & 1 ) ? 1 : -1;
+      const bool hx = dx < 0 ? x > 0 : x < w - 1, hy = dy < 0 ? y > 0 : y < h - 1;
+      const int  c  = m[size_t( y ) * w + x];
+      const int  vx = hx ? m[size_t( y ) * w + x + dx] : 0;
+      const int  vy = hy ? m[size_t( y + dy ) * w + x] : 0;
+      const int  vd = ( hx && hy ) ? m[size_t( y + dy ) * w + x + dx] : 0;
+      v             = uint8_t( mean4w( c, 144, vx, hx ? 48 : 0, vy, hy ? 48 : 0, vd, ( hx && hy ) ? 16 : 0 ) );
+    }
+    sOcc[i]    = o;
+    sBuf[0][i] = v;
+    sBuf[1][i] = v;
+  }
+  __syncthreads();
+  int cur = 0;
+  for ( int it = 0; it < iters; ++it ) {
+    const uint8_t* src = sBuf[cur];
+    uint8_t*       dst = sBuf[cur ^ 1];
+    for ( int i = threadIdx.x; i < kPushPullSpan * RH; i += 1024 ) {
+      const int rx = i & ( kPushPullSpan - 1 ), ry = i >> 7;
+      if ( rx >= RW || sOcc[i] ) continue;
+      const int l = rx > 0 ? -1 : 0, r = rx < RW - 1 ? 1 : 0;
+      const int u = ry > 0 ? -kPushPullSpan : 0, d = ry < RH - 1 ? kPushPullSpan : 0;
+      const int sum = src[i + u + l] + src[i + u + r] + src[i + d + l] + src[i + d + r] + src[i + l] + src[i + r] + src[i + u] +
+                      src[i + d];
+      dst[i] = uint8_t( ( sum + 4 ) >> 3 );
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const uint8_t* res = sBuf[cur];
+  for ( int i = threadIdx.x; i < kPushPullSpan * RH; i += 1024 ) {
+    const int rx = i & ( kPushPullSpan - 1 ), ry = i >> 7;
+    const int X = RX0 + rx, Y = RY0 + ry;
+    if ( rx >= RW || sOcc[i] || X < X0 || X >= X0 + kPushPullTile || Y < Y0 || Y >= Y0 + kPushPullTile ) continue;
+    plane[size_t( Y ) * W + X] = res[i];
+  }
+}
+
 // The coarse end of the pyramid in ONE workgroup: the levels of at most kPushPullSmall pixels -- their mip maps on the way
 // down, and on the way up the fill, the ping-pong partner's copy and the 4, 5, ... blur iterations of every level.  That is
 // ~ 60 of the ~ 100 launches of the padding, each over a few hundred to a few thousand pixels; between the steps a
@@ -379,9 +444,7 @@ int transferColorsDevice( tmc2_ctx* ctx, const TreeDev& srcTree, const Pt* d_src
   TMC2_TRY( launchKnnTree( ctx, srcTree, d_tgtPts, M, 8, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
   TMC2_TRY( launchKnnTree( ctx, tgtTree, d_srcPts, n, 1, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
   const int sid = ctx->stageBegin( "transfer_colors" );
-  TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( M ) * 4, s ) );
-  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( M ) * 4, s ) );
-  TMC2_HIP( hipMemsetAsync( d_error, 0, 4, s ) );
+  TMC2_TRY( fillRegions( ctx, {{d_count.p, size_t( M ) * 4, 0}, {d_cursor.p, size_t( M ) * 4, 0}, {d_error, 4, 0}} ) );
   const dim3 grdM( ( M + 255 ) / 256 ), grdN( ( n + 255 ) / 256 );
   hipLaunchKernelGGL( forwardColorKernel, grdM, blk, 0, s, d_idx8.p, d_dist8.p, d_srcRgb4, M, d_fwd.p );
   hipLaunchKernelGGL( backwardCountKernel, grdN, blk, 0, s, d_idx1.p, n, d_count.p );
@@ -573,6 +636,13 @@ int generateAttributeImages( tmc2_frame* f ) {
     Level&    fine = lv[l - 1];
     const int cnt  = fine.w * fine.h;
     const dim3 grd( ( cnt + 255 ) / 256 );
+    if ( iters <= kPushPullMaxIters ) {  // fill + every blur pass of the level: one launch, tiles in LDS
+      const int tilesX = ( fine.w + kPushPullTile - 1 ) / kPushPullTile, tilesY = ( fine.h + kPushPullTile - 1 ) / kPushPullTile;
+      hipLaunchKernelGGL( pushPullFillBlurKernel, dim3( tilesX * tilesY, 6 ), dim3( 1024 ), 0, s, fine.img, fine.occ, fine.w, fine.h,
+                          lv[l].img, lv[l].w, lv[l].h, iters, tilesX );
+      iters = std::min( iters + 1, 16 );
+      continue;
+    }
     hipLaunchKernelGGL( pushPullFillKernel, grd, blk, 0, s, fine.img, fine.occ, fine.w, fine.h, lv[l].img, lv[l].w, lv[l].h );
     TMC2_HIP( hipMemcpyAsync( fine.tmp, fine.img, size_t( 6 ) * cnt, hipMemcpyDeviceToDevice, s ) );
     uint8_t *src = fine.img, *dst = fine.tmp;

@@ -330,9 +330,7 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
   TMC2_TRY( f->d_blockToPatch.alloc( size_t( Wb ) * Hb ) );
   TMC2_TRY( f->d_geo.alloc( 2 * area ) );
   const int sid = ctx->stageBegin( "geometry_images" );
-  TMC2_HIP( hipMemsetAsync( d_err.p, 0, 4, s ) );
-  TMC2_HIP( hipMemsetAsync( f->d_occMap.p, 0, area, s ) );
-  TMC2_HIP( hipMemsetAsync( f->d_geo.p, 0, 2 * area * sizeof( uint16_t ), s ) );
+  TMC2_TRY( fillRegions( ctx, {{d_err.p, 4, 0}, {f->d_occMap.p, area, 0}, {f->d_geo.p, 2 * area * sizeof( uint16_t ), 0}} ) );
   const dim3 blk( 256 );
   if ( f->tileCount )
     hipLaunchKernelGGL( rasterTileKernel, dim3( f->tileCount ), blk, 0, s, d_place.p, d_tilePatch.p,

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -203,7 +204,8 @@ struct tmc2_ctx {
   tmc2::PinnedBuf               hostA, hostB, hostC, hostD, hostE;  // staging for the host-side steps
   std::vector<int32_t>          orientScratch;                      // per-vertex state of the orientation walk
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
-  tmc2::DevBuf<uint32_t>        scratchU32;      // small scan / flag scratch
+  tmc2::DevBuf<unsigned long long> scanState;    // look-back state of exclusiveScanU32: [0] tile tickets, [1 + t] tile t (epoch-tagged)
+  uint32_t                      scanEpoch = 0, scanTickets = 0;
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
   std::map<uint32_t, int>       kdLevelHint;     // levels of level passes the last device k-d tree of ~ this size took (by n >> 15)
   hipStream_t                   stream = nullptr;
@@ -365,4 +367,11 @@ int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot
 int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,
                        DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
 int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );
+// several device regions set to a byte value each in ONE launch (instead of one hipMemsetAsync per buffer)
+struct FillRegion {
+  void*   p;
+  size_t  bytes;
+  uint8_t value;
+};
+int fillRegions( tmc2_ctx* ctx, std::initializer_list<FillRegion> regions );
 }  // namespace tmc2

@@ -246,8 +246,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   TMC2_TRY( d_root.alloc( n ) );
   TMC2_TRY( d_parity.alloc( n ) );
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
-  TMC2_HIP( hipMemsetAsync( d_small.p, 0, 16, s ) );
-  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( n ) * 4, s ) );
+  TMC2_TRY( fillRegions( ctx, {{d_small.p, 16, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
   TMC2_TRY( ensureMutualMask( f ) );
   const dim3 grdN16( ( n + 15 ) / 16 ), grdN16p( ( n + 16 ) / 16 );  // 16 lanes per point (... and one more "point" for count[n])
   hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN16, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );

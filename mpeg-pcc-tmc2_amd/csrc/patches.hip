@@ -213,7 +213,8 @@ template <int K>
 __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
                                                          const uint8_t* __restrict__ partition,
                                                          const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
-                                                         uint32_t n, uint32_t* __restrict__ lab, uint32_t* __restrict__ changed ) {
+                                                         uint32_t n, uint32_t* __restrict__ lab, uint32_t* __restrict__ changed,
+                                                         uint32_t token ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n || !raw[u] ) return;
   uint32_t m = ~uint32_t( mutual[u] ) & ( ( 1u << K ) - 1u );
@@ -234,7 +235,23 @@ __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restri
          atomicMin( &lab[rv], lu ) > lu )
       any = true;
   }
-  if ( any ) *changed = 1;
+  if ( any ) *changed = token;  // (which sweep changed something last: nothing to clear between sweeps)
+}
+
+// start of a round's per-patch accumulators: bounding box {min 3 x INT_MAX, max 3 x 0 -- the reference starts its max at 0},
+// minimum (u, v), the two resampling counters; and this round's count of points still raw
+__global__ __launch_bounds__( 256 ) void patchBoundsInitKernel( uint32_t P, int32_t* __restrict__ bbox, int32_t* __restrict__ minUv,
+                                                                 int32_t* __restrict__ patchStat, uint32_t* __restrict__ rawCount ) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( p == 0 ) *rawCount = 0;
+  if ( p >= P ) return;
+#pragma unroll
+  for ( int d = 0; d < 3; ++d ) {
+    bbox[6 * p + d]     = 0x7FFFFFFF;
+    bbox[6 * p + 3 + d] = 0;
+  }
+  minUv[2 * p] = minUv[2 * p + 1] = 0x7F7F7F7F;
+  patchStat[2 * p] = patchStat[2 * p + 1] = 0;
 }
 
 __global__ __launch_bounds__( 256 ) void ccLabelKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
@@ -635,7 +652,6 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   while ( ( 1 << bitmapBits ) <= int( f->geoMax ) ) ++bitmapBits;
   const size_t bitmapWords = ( size_t( 1 ) << ( 3 * bitmapBits ) ) >> 5;
   TMC2_TRY( ctx->voxelBitmap.alloc( bitmapWords ) );
-  TMC2_HIP( hipMemsetAsync( ctx->voxelBitmap.p, 0, bitmapWords * 4, s ) );
 
   DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_lab;
   DevBuf<uint8_t>  d_raw;
@@ -655,14 +671,16 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_TRY( d_small.alloc( 16 ) );
   TMC2_TRY( d_offsets.alloc( offsets.size() ) );
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemsetAsync( d_raw.p, 1, n, s ) );
-  TMC2_HIP( hipMemsetAsync( d_dist.p, 0xFF, size_t( n ) * 4, s ) );
+  TMC2_TRY( fillRegions( ctx, {{ctx->voxelBitmap.p, bitmapWords * 4, 0},
+                               {d_raw.p, n, 1},
+                               {d_dist.p, size_t( n ) * 4, 0xFF},
+                               {d_small.p, 64, 0}} ) );
 
   f->patches.clear();
   f->depthCount = 0;
   f->occCount   = 0;
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
-  uint32_t   rawCount = n;
+  uint32_t   rawCount = n, relaxToken = 0;
   int        rounds   = 0;
   TMC2_TRY( ensureMutualMask( f ) );  // usually there already: the orientation (S3) needs the same bits
   DevBuf<uint16_t>& d_mutual = f->d_mutual;
@@ -678,29 +696,28 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
       ctx->stageEnd( kt );
       hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p );
     }
-    for ( int guard = 0; guard < 1 << 20; ++guard ) {
-      // a few sweeps per host round-trip; the flag is cleared before the LAST sweep of the batch only,
-      // so "unchanged" means the final sweep of the batch changed nothing (= fixpoint)
-      const int kt = ctx->stageBegin( "k:ccRelax" );
-      for ( int b = 0; b < 3; ++b ) {
-        if ( b == 2 ) TMC2_HIP( hipMemsetAsync( d_small.p, 0, 4, s ) );
-        hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
-                            d_parent.p, n, d_lab.p, d_small.p );
-      }
-      ctx->stageEnd( kt );
-      uint32_t changed = 0;
-      TMC2_HIP( hipMemcpyAsync( &changed, d_small.p, 4, hipMemcpyDeviceToHost, s ) );
-      TMC2_HIP( hipStreamSynchronize( s ) );
-      if ( !changed ) break;
-    }
-    hipLaunchKernelGGL( ccLabelKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p );
-    hipLaunchKernelGGL( ccCountKernel, grdN, blk, 0, s, d_label.p, n, d_ccCount.p );
-    hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
-                        uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );
-    TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 1 ) );
+    // a few sweeps, then -- speculatively -- the labelling and the seed count, and ONE round trip for both answers: "did the
+    // last sweep of the batch still change a label" (then sweep on and label again) and the number of patches
     uint32_t P = 0;
-    TMC2_HIP( hipMemcpyAsync( &P, d_small.p + 1, 4, hipMemcpyDeviceToHost, s ) );
-    TMC2_HIP( hipStreamSynchronize( s ) );
+    for ( int guard = 0; guard < 1 << 20; ++guard ) {
+      const int kt = ctx->stageBegin( "k:ccRelax" );
+      for ( int b = 0; b < 3; ++b )
+        hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
+                            d_parent.p, n, d_lab.p, d_small.p, ++relaxToken );
+      ctx->stageEnd( kt );
+      hipLaunchKernelGGL( ccLabelKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p );
+      hipLaunchKernelGGL( ccCountKernel, grdN, blk, 0, s, d_label.p, n, d_ccCount.p );
+      hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
+                          uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );
+      TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 1 ) );
+      uint32_t answer[2] = {0, 0};
+      TMC2_HIP( hipMemcpyAsync( answer, d_small.p, 8, hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+      P = answer[1];
+      if ( answer[0] != relaxToken ) break;
+      // (ccCount is an accumulation: start it over before labelling again)
+      TMC2_HIP( hipMemsetAsync( d_ccCount.p, 0, size_t( n ) * 4, s ) );
+    }
     ctx->stageEnd( sid );
     if ( P == 0 ) break;
     // ---- S8 -----------------------------------------------------------------------------------------
@@ -712,18 +729,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     TMC2_TRY( d_patches.alloc( P ) );
     hipLaunchKernelGGL( ccAssignKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p, d_rank.p, f->d_partition.p,
                         uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_pointPatch.p, d_patchView.p );
-    {
-      std::vector<int32_t> init( 6 * size_t( P ) );
-      for ( uint32_t p = 0; p < P; ++p )
-        for ( int d = 0; d < 3; ++d ) {
-          init[6 * p + d]     = 0x7FFFFFFF;
-          init[6 * p + 3 + d] = 0;  // the reference starts its max at 0
-        }
-      TMC2_HIP( hipMemcpyAsync( d_bbox.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, s ) );
-      TMC2_HIP( hipMemsetAsync( d_minUv.p, 0x7F, 2 * size_t( P ) * 4, s ) );
-      TMC2_HIP( hipMemsetAsync( d_patchStat.p, 0, 2 * size_t( P ) * 4, s ) );
-      TMC2_HIP( hipStreamSynchronize( s ) );  // init vector goes out of scope
-    }
+    hipLaunchKernelGGL( patchBoundsInitKernel, dim3( ( P + 255 ) / 256 ), blk, 0, s, P, d_bbox.p, d_minUv.p, d_patchStat.p,
+                        d_small.p + 2 );
     if ( sp->enablePatchSplitting )
       hipLaunchKernelGGL( patchMinUvKernel, grdN, blk, 0, s, f->d_pts.p, d_pointPatch.p, d_patchView.p, n, d_minUv.p );
     hipLaunchKernelGGL( patchTrimBboxKernel, grdN, blk, 0, s, f->d_pts.p, d_patchView.p, d_minUv.p,
@@ -803,7 +810,6 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     std::vector<int32_t> h_stat( 2 * size_t( P ) );
     TMC2_HIP( hipMemcpyAsync( h_stat.data(), d_patchStat.p, h_stat.size() * 4, hipMemcpyDeviceToHost, s ) );
     // ---- S9 -----------------------------------------------------------------------------------------
-    TMC2_HIP( hipMemsetAsync( d_small.p + 2, 0, 4, s ) );
     hipLaunchKernelGGL( rawDistanceKernel, grdN, blk, 0, s, f->d_pts.p, n, ctx->voxelBitmap.p, bitmapBits, d_offsets.p,
                         int( offsets.size() ), thrSel, d_dist.p, d_raw.p, d_small.p + 2 );
     TMC2_HIP( hipMemcpyAsync( &rawCount, d_small.p + 2, 4, hipMemcpyDeviceToHost, s ) );

@@ -660,16 +660,11 @@ __device__ __forceinline__ int argOfPacked( uint32_t s0, uint32_t s1, uint32_t s
 //   out[u] = { count, the DEV neighbours u marks if it is active: NO_EDGE voxels whose ppi differs from arg(S[u]) };
 //   rec[nxt][u] = rec[cur][u]  (the copy this sweep's pushes go into);
 //   u active at sweep start: its bit in the active bitmap, its marks, and the larger-index voxels it activates (frontier).
-__global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                                const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
-                                                                const uint32_t* __restrict__ dev,
-                                                                const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t V,
-                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ gAct,
-                                                                uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
-  const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
-  const uint32_t lane = threadIdx.x & 31;
-  const int      half = ( threadIdx.x >> 5 ) & 1;
-  if ( u >= V ) return;
+__device__ __forceinline__ void prepareVoxel( uint32_t u, uint32_t lane, int half, const uint8_t* __restrict__ edge,
+                                              const uint8_t* __restrict__ ppi, const uint4* __restrict__ recCur,
+                                              uint4* __restrict__ recNxt, const uint32_t* __restrict__ dev,
+                                              const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t* __restrict__ out,
+                                              uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
   const uint4    r      = recCur[u];
   const uint8_t  a      = uint8_t( argOfPacked( r.x, r.y, r.z ) );
   const bool     active = edge[u] != NO_EDGE;
@@ -696,6 +691,17 @@ __global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __
     nOut += uint32_t( __popc( m ) );
   }
   if ( lane == 0 ) out[size_t( u ) * stride] = nOut;
+}
+__global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
+                                                                const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
+                                                                const uint32_t* __restrict__ dev,
+                                                                const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t V,
+                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ gAct,
+                                                                uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
+  const uint32_t u = blockIdx.x * 8 + ( threadIdx.x >> 5 );
+  if ( u >= V ) return;
+  prepareVoxel( u, threadIdx.x & 31, ( threadIdx.x >> 5 ) & 1, edge, ppi, recCur, recNxt, dev, devLen, stride, out, gAct, gFr,
+                       gMk );
 }
 
 // Wave-level compaction of a bitmap into a voxel list (whole 64-word chunks; a chunk that does not fit stays for the next
@@ -739,12 +745,10 @@ __device__ __forceinline__ uint32_t compactBitmap( uint32_t* __restrict__ bm, ui
 // The dependent rest of the closure, one workgroup.  LDS: active | frontier | marked | scratch bitmaps (V bits each), list.
 // Hands the global bitmaps back empty, writes the work list of sweepKernel: every active voxel, then the voxels that were
 // only marked.
-__global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* __restrict__ out, uint32_t stride, uint32_t V,
-                                                                uint32_t listCap,
-                                                              uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr,
-                                                              uint32_t* __restrict__ gMk, uint32_t* __restrict__ work,
-                                                              uint32_t* __restrict__ workCount,
-                                                              unsigned long long* __restrict__ timing ) {
+__device__ __forceinline__ void walkLevels( const uint32_t* __restrict__ out, uint32_t stride, uint32_t V, uint32_t listCap,
+                                            uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk,
+                                            uint32_t* __restrict__ work, uint32_t* __restrict__ workCount,
+                                            unsigned long long* __restrict__ timing ) {
   extern __shared__ uint32_t lds[];
   // (test hook: timing[0..3] += ticks of load / compaction / voxel processing / list emission, [4] += rounds, [5] += voxels)
   unsigned long long tick = timing ? wall_clock64() : 0ull, tLoad = 0, tCompact = 0, tProcess = 0, tEmit = 0, rounds = 0;
@@ -790,8 +794,8 @@ __global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* _
       for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) {  // one voxel per thread: one 16-byte load per hop
         const uint32_t  u    = list[i];
         const uint32_t* row  = out + size_t( u ) * stride;
-        const uint4     head = reinterpret_cast<const uint4*>( row )[0];  // count + the first seven targets: one round
-        const uint4     more = reinterpret_cast<const uint4*>( row )[1];  // trip for all but the rarest voxels
+        const uint4 head = reinterpret_cast<const uint4*>( row )[0];  // count + the first seven targets: one round
+        const uint4 more = reinterpret_cast<const uint4*>( row )[1];  // trip for all but the rarest voxels
         for ( uint32_t k = 0; k < head.x; ++k ) {
           const uint32_t v   = k == 0   ? head.y
                                : k == 1 ? head.z
@@ -819,6 +823,13 @@ __global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* _
     timing[0] += tLoad, timing[1] += tCompact, timing[2] += tProcess, timing[3] += tEmit, timing[4] += rounds, timing[5] += nWork;
   }
 #undef TMC2_LAP
+}
+__global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* __restrict__ out, uint32_t stride, uint32_t V,
+                                                                uint32_t listCap, uint32_t* __restrict__ gAct,
+                                                                uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk,
+                                                                uint32_t* __restrict__ work, uint32_t* __restrict__ workCount,
+                                                                unsigned long long* __restrict__ timing ) {
+  walkLevels( out, stride, V, listCap, gAct, gFr, gMk, work, workCount, timing );
 }
 
 // The rest of a sweep for the voxels of the work list, 16 lanes each: decide, re-score if S changed since the labels were
@@ -1027,9 +1038,36 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + Vp, *d_arg = d_state.p + 2 * Vp, *d_marked = d_state.p + 4 * Vp,
           *d_proc = d_state.p + 5 * Vp;
   uint32_t* d_active = d_activeBuf.p;
-  TMC2_HIP( hipMemsetAsync( d_count.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
-  TMC2_HIP( hipMemsetAsync( d_hist.p, 0, size_t( V ) * 16, s ) );
-  TMC2_HIP( hipMemsetAsync( d_state.p, 0, Vp * 6, s ) );
+  // every buffer of this stage that starts from zeros, in one launch (the event-driven loop's among them)
+  const uint32_t W = ( V + 31 ) / 32;
+  // Which sweep loop: the event-driven one needs the closure's four bitmaps and a voxel list in the LDS of one workgroup
+  // (160 KB: up to ~ 290 K voxels; a vox11 frame has ~ 240 K).  Larger grids take the sweep-everything loop.
+  // (test hook TMC2_REFINE_SWEEPS=full forces that one)
+  const char*  sweepsEnv   = getenv( "TMC2_REFINE_SWEEPS" );
+  const size_t ldsRoom     = 160 * 1024 - 64;  // gfx950: 160 KB of LDS per workgroup (opt-in above 64 KB); static part: 8 bytes
+  const size_t ldsFixed    = 16 * size_t( W );
+  const bool   eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
+  DevBuf<uint32_t> d_pointStart, d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits;
+  TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
+  TMC2_TRY( d_pointList.alloc( n ) );
+  TMC2_TRY( d_cursor.alloc( V ) );
+  TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
+  if ( eventDriven ) {
+    TMC2_TRY( d_rcount.alloc( size_t( V ) + 1 ) );
+    TMC2_TRY( d_rcursor.alloc( size_t( V ) + 1 ) );
+    TMC2_TRY( d_lastRescore.alloc( V ) );
+    TMC2_TRY( d_gbits.alloc( 3 * size_t( W ) ) );
+  }
+  TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( V ) + 1 ) * 4, 0},
+                               {d_hist.p, size_t( V ) * 16, 0},
+                               {d_state.p, Vp * 6, 0},
+                               {d_cursor.p, size_t( V ) * 4, 0},
+                               {d_small.p + 1, 8, 0},  // [1] row cursor, [2] overflow
+                               {d_flags.p, ( 2 * size_t( iterationCount ) + 2 ) * 4, 0},
+                               {d_rcount.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
+                               {d_rcursor.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
+                               {d_lastRescore.p, eventDriven ? size_t( V ) * 4 : 0, 0},
+                               {d_gbits.p, eventDriven ? 3 * size_t( W ) * 4 : 0, 0}} ) );
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
@@ -1038,11 +1076,6 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
                       d_hist.p );
   const dim3 grdV( ( V + 255 ) / 256 ), grdV16( ( V + 15 ) / 16 );  // 16 lanes per voxel
   // points grouped by voxel, for the re-scoring pass
-  DevBuf<uint32_t> d_pointStart, d_pointList, d_cursor;
-  TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
-  TMC2_TRY( d_pointList.alloc( n ) );
-  TMC2_TRY( d_cursor.alloc( V ) );
-  TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( V ) * 4, s ) );
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_pointStart.p, size_t( V ) + 1, nullptr ) );
   hipLaunchKernelGGL( voxelPointListKernel, grdN, blk, 0, s, d_vid.p, d_pointStart.p, n, d_cursor.p, d_pointList.p );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
@@ -1053,7 +1086,6 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     setError( "refineSegmentationGridBased: %u voxels exceed the neighbourhood sort key", V );
     return TMC2_E_UNSUPPORTED;
   }
-  const uint32_t W = ( V + 31 ) / 32;
   DevBuf<uint32_t> d_adj, d_dev;
   TMC2_TRY( d_dev.alloc( size_t( V ) * devStride ) );
   const size_t ball     = offsets.size();
@@ -1068,7 +1100,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
       return TMC2_E_UNSUPPORTED;
     }
     TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
-    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 8, s ) );  // [1] row cursor, [2] overflow
+    if ( attempt > 0 ) TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 8, s ) );  // [1] row cursor, [2] overflow
 #define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
   hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
                       d_count.p, table, g, V, d_offsets.p, int( ball ), maxNNCount, lambda, idBits, devRange, devStride,       \
@@ -1093,37 +1125,21 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   }
   hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
   const dim3 grdV32( ( V + 7 ) / 8 );
-  // Which sweep loop: the event-driven one needs the closure's four bitmaps and a voxel list in the LDS of one workgroup
-  // (160 KB: up to ~ 290 K voxels; a vox11 frame has ~ 240 K).  Larger grids take the sweep-everything loop.
-  // (test hook TMC2_REFINE_SWEEPS=full forces that one)
-  const char*  sweepsEnv   = getenv( "TMC2_REFINE_SWEEPS" );
-  const size_t ldsRoom     = 160 * 1024 - 64;  // gfx950: 160 KB of LDS per workgroup (opt-in above 64 KB); static part: 8 bytes
-  const size_t ldsFixed    = 16 * size_t( W );
-  const bool   eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
   if ( eventDriven ) {
     // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
-    DevBuf<uint32_t> d_roff, d_rcursor, d_radj, d_lastRescore, d_work, d_flags, d_out, d_gbits;
+    DevBuf<uint32_t> d_roff, d_radj, d_work, d_out;
     DevBuf<uint4>    d_rec;
     TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
-    TMC2_TRY( d_rcursor.alloc( size_t( V ) + 1 ) );
     TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
-    TMC2_TRY( d_lastRescore.alloc( V ) );
     TMC2_TRY( d_work.alloc( size_t( V ) + 1 ) );  // [V]: the list's length
     TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
     TMC2_TRY( d_out.alloc( size_t( V ) * devStride ) );
-    TMC2_TRY( d_gbits.alloc( 3 * size_t( W ) ) );
-    TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
-    TMC2_HIP( hipMemsetAsync( d_rcursor.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
-    hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcursor.p );
-    TMC2_TRY( exclusiveScanU32( ctx, d_rcursor.p, d_roff.p, size_t( V ) + 1, nullptr ) );
-    TMC2_HIP( hipMemsetAsync( d_rcursor.p, 0, ( size_t( V ) + 1 ) * 4, s ) );
+    hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcount.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_rcount.p, d_roff.p, size_t( V ) + 1, nullptr ) );
     hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
                         d_radj.p );
     hipLaunchKernelGGL( smoothInitKernel, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
                         d_rowLen.p, d_adj.p, V, d_rec.p );
-    TMC2_HIP( hipMemsetAsync( d_lastRescore.p, 0, size_t( V ) * 4, s ) );
-    TMC2_HIP( hipMemsetAsync( d_gbits.p, 0, 3 * size_t( W ) * 4, s ) );
-    TMC2_HIP( hipMemsetAsync( d_flags.p, 0, ( 2 * size_t( iterationCount ) + 2 ) * 4, s ) );
     ctx->stageEnd( sidSetup );
     TMC2_HIP( hipGetLastError() );
     const int      sidSweep = ctx->stageBegin( "refine_sweeps" );
@@ -1193,9 +1209,7 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   const char*  tailEnv   = getenv( "TMC2_REFINE_TAIL" );
   const bool   tailInLds = tailLds <= 128 * 1024 && !( tailEnv && tailEnv[0] == 'g' );
   if ( tailInLds && tailLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureTailKernel ), tailLds, ctx->device ) );
-  DevBuf<uint32_t> d_flags;  // [0] fixpoint reached; [2k + 1] sweep k moved a point; [2k + 2] sweep k changed a voxel state
-  TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
-  TMC2_HIP( hipMemsetAsync( d_flags.p, 0, ( 2 * size_t( iterationCount ) + 2 ) * 4, s ) );
+  // d_flags: [0] fixpoint reached; [2k + 1] sweep k moved a point; [2k + 2] sweep k changed a voxel state
   for ( int iter = 0; iter < iterationCount; ++iter ) {
     if ( iter == 0 )
       hipLaunchKernelGGL( smoothKernel<false>, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
