@@ -10,6 +10,10 @@
 #include <vector>
 
 #include "PCCCommon.h"
+#include "PCCContext.h"
+#include "PCCEncoderParameters.h"
+#include "PCCFrameContext.h"
+#include "PCCGroupOfFrames.h"
 #include "PCCImage.h"
 #include "PCCPatch.h"
 #include "PCCPatchSegmenter.h"
@@ -61,5 +65,41 @@ void toReconstruction( const int16_t* xyz, const uint8_t* rgb, const uint32_t* p
 // device; the frame stays resident in *keep for the image-generation calls that follow.  Returns a tmc2 status.
 int segmenterCompute( tmc2_ctx* ctx, const pcc::PCCPointSet3& geometry, size_t frameIndex,
                       const pcc::PCCPatchSegmenter3Parameters& params, std::vector<pcc::PCCPatch>& patches, tmc2_frame** keep );
+
+// ---- the seams of PCCEncoder::encode (PCCEncoder.cpp:85-424) for the CTC lossy conditions, over the reference's own
+// containers: the bodies a maintainer puts behind generateSegments / placeSegments / generateGeometryVideo (with the occupancy
+// steps before it) / generateAttributeVideo (with generatePointCloud before and the padding after it).  encode() keeps calling
+// them in its order; every frame of the GOF stays resident in HBM between the calls.  One object per encode() call.
+// (Shown on one library context; an encoder that runs its frames as TBB tasks holds one context per task, INTEGRATION.md.)
+class EncoderDropIn {
+ public:
+  explicit EncoderDropIn( int device );
+  ~EncoderDropIn();
+  EncoderDropIn( const EncoderDropIn& ) = delete;
+  EncoderDropIn& operator=( const EncoderDropIn& ) = delete;
+  // false: no device / parameter set not mirrored -- the caller keeps the reference's own bodies
+  bool accepts( const pcc::PCCEncoderParameters& params );
+  // generateSegments( sources, context ) :4672-4760: S0 on frame 0, S1-S9 per frame; patches appended to every frame's context
+  int generateSegments( const pcc::PCCGroupOfFrames& sources, pcc::PCCContext& context, const pcc::PCCEncoderParameters& params );
+  // placeSegments( sources, context ) :4762-4840: all-intra, low-delay (constrainedPack) and random-access (+ globalPatchAllocation
+  // 1) conditions; lists reordered, placements / matches written, tile and atlas frame sizes set
+  int placeSegments( pcc::PCCContext& context, const pcc::PCCEncoderParameters& params );
+  // generateOccupancyMap + generateOccupancyMapVideo + generateBlockToPatchFromOccupancyMapVideo + generateGeometryVideo
+  // (:3767, :806, PCCCodec.cpp:1736, :3894 with padding and group dilation): S11-S16
+  int generateGeometryVideo( pcc::PCCContext& context, const pcc::PCCEncoderParameters& params );
+  // generatePointCloud per frame + generateAttributeVideo + dilateSmoothedPushPull + attribute group dilation (encode()
+  // :313-424): S17-S22, on the resident (= losslessly "decoded") geometry; decodedGeometry: see tmc2_frame_set_decoded_geometry
+  int generateAttributeVideo( pcc::PCCContext& context, pcc::PCCGroupOfFrames& reconstructs, const pcc::PCCEncoderParameters& params );
+  const char* lastError() const { return tmc2_last_error(); }
+
+ private:
+  void                     release();
+  tmc2_ctx*                ctx_ = nullptr;
+  std::vector<tmc2_frame*> frames_;
+  int                      width_ = 0, height_ = 0;
+};
+
+// PCCEncoderParameters -> tmc2_segmenter_params (weightNormal left 1, 1, 1); false if the set uses what the library refuses
+bool toParams( const pcc::PCCEncoderParameters& params, tmc2_segmenter_params& out );
 
 }  // namespace tmc2hip

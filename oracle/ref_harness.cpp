@@ -471,20 +471,14 @@ int ref_gof_set_frame( int i, const int16_t* xyz, const uint8_t* rgb, size_t n )
   return 0;
 }
 
-// S0-S16 in the order of PCCEncoder::encode :85-172
-int ref_gof_phase_a() {
-  Quiet quiet;
-  Gof&  G = *g_gof;
-  fflush( stdout );
-  FILE* devnull  = fopen( "/dev/null", "w" );
-  int   savedOut = dup( 1 );
-  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );  // the reference also uses printf
+// what PccAppEncoder::compressVideo (PccAppEncoder.cpp:1042-1044) and the head of PCCEncoder::encode (:85-130) do before the
+// first seam
+static void gofPreEncode( Gof& G ) {
   PCCEncoder& E = G.encoder;
   E.setLogger( G.logger );
   E.setParameters( G.params );
   PCCContext& context = G.context;
   auto&       sources = G.sources;
-  // what PccAppEncoder::compressVideo does before encode() (PccAppEncoder.cpp:1042-1044)
   static PCCBitstreamStat bitstreamStat;
   context.setBitstreamStat( bitstreamStat );
   context.addV3CParameterSet( 0 );
@@ -505,17 +499,38 @@ int ref_gof_phase_a() {
     fc.setLog2PatchQuantizerSizeX( E.params_.log2QuantizerSizeX_ );
     fc.setLog2PatchQuantizerSizeY( E.params_.log2QuantizerSizeY_ );
   }
-  E.generateSegments( sources, context );
-  E.params_.initializeContext( context );
-  E.placeSegments( sources, context );
-  size_t atlasIndex = context.getAtlasIndex();
-  auto&  sps        = context.getVps();
+}
+// encode() between placeSegments and generateOccupancyMap
+static void gofAfterPlacement( Gof& G ) {
+  PCCContext& context    = G.context;
+  auto&       frames     = context.getFrames();
+  size_t      atlasIndex = context.getAtlasIndex();
+  auto&       sps        = context.getVps();
   sps.setFrameWidth( atlasIndex, static_cast<uint16_t>( frames[0].getAtlasFrameWidth() ) );
   sps.setFrameHeight( atlasIndex, static_cast<uint16_t>( frames[0].getAtlasFrameHeight() ) );
   for ( auto& asps : context.getAtlasSequenceParameterSetList() ) {
     asps.setFrameHeight( sps.getFrameHeight( atlasIndex ) );
     asps.setFrameWidth( sps.getFrameWidth( atlasIndex ) );
   }
+}
+
+// S0-S16 in the order of PCCEncoder::encode :85-172
+int ref_gof_phase_a() {
+  Quiet quiet;
+  Gof&  G = *g_gof;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );  // the reference also uses printf
+  PCCEncoder& E = G.encoder;
+  gofPreEncode( G );
+  PCCContext& context = G.context;
+  auto&       sources = G.sources;
+  auto&       frames  = context.getFrames();
+  E.generateSegments( sources, context );
+  E.params_.initializeContext( context );
+  E.placeSegments( sources, context );
+  gofAfterPlacement( G );
   E.generateOccupancyMap( context, true );
   E.generateOccupancyMapVideo( sources, context );
   // identity codec: videoOccupancyMap stays as generated
@@ -1002,6 +1017,134 @@ int ref_adaptor_check_frame( int frame, const uint8_t* occupancy, const uint8_t*
   }
   return bad;
 }
+
+#ifdef TMC2_WITH_DROPIN
+// ---- needs an MI355X (only built into oracle/_ref/libtmc2adaptor.so, which links the product library) --------------------------
+// The GOF of g_gof once more, over a second PCCContext, in encode()'s order -- but with every seam of the hot path answered by
+// integration/tmc2hip_adaptor.cpp's EncoderDropIn (the product, through the C-ABI) instead of the reference's member:
+// generateSegments, placeSegments, generateOccupancyMap .. generateGeometryVideo, generatePointCloud .. the attribute padding.
+// What encode() does in between (parameter set / context initialisation, sizes into the VPS / ASPS, allocOneLayerData) is the
+// reference's own code on both sides.  Compared with what the reference's members left in g_gof (ref_gof_phase_a and
+// ref_gof_phase_b must have run): bit mask of the containers that differ; negative = a status of the library.
+//   1 patch lists (every getter the packers, the image generation and the bitstream writer read), 2 tile / atlas frame sizes,
+//   4 occupancy maps, 8 blockToPatch, 16 occupancy video, 32 geometry video, 64 attribute video, 128 reconstructed clouds,
+//   256 pointToPixel, 512 sizes written to the VPS / ASPS, 1024 matched-patch counts
+// (PCCPatch::patchType_ is not compared: the packers write it, nothing in the reference reads it)
+int ref_gof_dropin_check( int device ) {
+  Quiet quiet;
+  Gof&  A = *g_gof;
+  Gof   B;
+  B.params  = A.params;
+  B.sources = A.sources;
+  fflush( stdout );
+  FILE* devnull  = fopen( "/dev/null", "w" );
+  int   savedOut = dup( 1 );
+  if ( !getenv( "TMC2_REF_VERBOSE" ) ) dup2( fileno( devnull ), 1 );
+  int status = 0;
+  {
+    gofPreEncode( B );
+    PCCEncoder&            E = B.encoder;
+    tmc2hip::EncoderDropIn D( device );
+    if ( !D.accepts( E.params_ ) ) status = -1000;
+    if ( status == 0 ) status = D.generateSegments( B.sources, B.context, E.params_ );
+    if ( status == 0 ) {
+      E.params_.initializeContext( B.context );
+      status = D.placeSegments( B.context, E.params_ );
+    }
+    if ( status == 0 ) {
+      gofAfterPlacement( B );
+      status = D.generateGeometryVideo( B.context, E.params_ );
+    }
+    if ( status == 0 ) {
+      B.context.allocOneLayerData();
+      status = D.generateAttributeVideo( B.context, B.reconstructs, E.params_ );
+    }
+    if ( status != 0 ) fprintf( stderr, "ref_gof_dropin_check: status %d: %s\n", status, D.lastError() );
+  }
+  fflush( stdout );
+  dup2( savedOut, 1 );
+  close( savedOut );
+  fclose( devnull );
+  if ( status != 0 ) return status < 0 ? status : -status;
+  int   bad = 0;
+  auto& fa = A.context.getFrames();
+  auto& fb = B.context.getFrames();
+  auto  sameImage = []( auto& a, auto& b ) {
+    if ( a.getWidth() != b.getWidth() || a.getHeight() != b.getHeight() || a.getColorFormat() != b.getColorFormat() ) return false;
+    for ( size_t c = 0; c < 3; ++c )
+      if ( a.getChannel( c ) != b.getChannel( c ) ) return false;
+    return true;
+  };
+  if ( fa.size() != fb.size() ) return 1 << 20;
+  for ( size_t f = 0; f < fa.size(); ++f ) {
+    auto& ta = fa[f].getTitleFrameContext();
+    auto& tb = fb[f].getTitleFrameContext();
+    auto& pa = ta.getPatches();
+    auto& pb = tb.getPatches();
+    if ( pa.size() != pb.size() ) {
+      bad |= 1;
+    } else {
+      for ( size_t i = 0; i < pa.size(); ++i ) {
+        const PCCPatch &a = pa[i], &b = pb[i];
+#define SAME( getter ) ( a.getter() == b.getter() )
+        if ( !( SAME( getIndex ) && SAME( getViewId ) && SAME( getNormalAxis ) && SAME( getTangentAxis ) && SAME( getBitangentAxis ) &&
+                SAME( getProjectionMode ) && SAME( getU1 ) && SAME( getV1 ) && SAME( getD1 ) && SAME( getSizeU ) && SAME( getSizeV ) &&
+                SAME( getSizeD ) && SAME( getSizeDPixel ) && SAME( getSizeU0 ) && SAME( getSizeV0 ) && SAME( getPatchSize2DXInPixel ) &&
+                SAME( getPatchSize2DYInPixel ) && SAME( getOccupancyResolution ) && SAME( getD0Count ) && SAME( getEOMandD1Count ) &&
+                SAME( getEOMCount ) && SAME( getLodScaleX ) && SAME( getLodScaleY ) && SAME( getU0 ) && SAME( getV0 ) &&
+                SAME( getPatchOrientation ) && SAME( getBestMatchIdx ) && SAME( getAxisOfAdditionalPlane ) &&
+                a.getDepth( 0 ) == b.getDepth( 0 ) && a.getDepth( 1 ) == b.getDepth( 1 ) && a.getOccupancy() == b.getOccupancy() ) )
+          bad |= 1;
+#undef SAME
+      }
+    }
+    if ( ta.getNumMatchedPatches() != tb.getNumMatchedPatches() ) bad |= 1024;
+    if ( ta.getWidth() != tb.getWidth() || ta.getHeight() != tb.getHeight() ||
+         fa[f].getAtlasFrameWidth() != fb[f].getAtlasFrameWidth() || fa[f].getAtlasFrameHeight() != fb[f].getAtlasFrameHeight() ||
+         fa[f].getNumPartitionWidth() != fb[f].getNumPartitionWidth() ||
+         ( fa[f].getNumPartitionWidth() > 0 && ( fa[f].getPartitionWidth( 0 ) != fb[f].getPartitionWidth( 0 ) ||
+                                                 fa[f].getPartitionHeight( 0 ) != fb[f].getPartitionHeight( 0 ) ) ) )
+      bad |= 2;
+    // (phase B overwrites the tile's occupancy map with the upsampled occupancy video: the reference side kept phase A's)
+    if ( A.occupancyAfterPhaseA[f] != tb.getOccupancyMap() ) bad |= 4;
+    if ( ta.getBlockToPatch() != tb.getBlockToPatch() ) bad |= 8;
+    if ( !sameImage( A.context.getVideoOccupancyMap().getFrame( f ), B.context.getVideoOccupancyMap().getFrame( f ) ) ) bad |= 16;
+    for ( size_t m = 0; m < 2; ++m ) {
+      if ( !sameImage( A.context.getVideoGeometryMultiple()[0].getFrame( 2 * f + m ), B.context.getVideoGeometryMultiple()[0].getFrame( 2 * f + m ) ) )
+        bad |= 32;
+      if ( !sameImage( A.context.getVideoAttributesMultiple()[0].getFrame( 2 * f + m ), B.context.getVideoAttributesMultiple()[0].getFrame( 2 * f + m ) ) )
+        bad |= 64;
+    }
+    auto& ra = A.reconstructs[f];
+    auto& rb = B.reconstructs[f];
+    if ( ra.getPointCount() != rb.getPointCount() ) {
+      bad |= 128;
+    } else {
+      for ( size_t i = 0; i < ra.getPointCount(); ++i )
+        if ( ra[i] != rb[i] || ra.getColor( i ) != rb.getColor( i ) ) {
+          bad |= 128;
+          break;
+        }
+    }
+    auto& qa = ta.getPointToPixel();
+    auto& qb = tb.getPointToPixel();
+    if ( qa.size() != qb.size() ) {
+      bad |= 256;
+    } else {
+      for ( size_t i = 0; i < qa.size(); ++i )
+        if ( qa[i][0] != qb[i][0] || qa[i][1] != qb[i][1] || qa[i][2] != qb[i][2] ) {
+          bad |= 256;
+          break;
+        }
+    }
+  }
+  const size_t atlas = A.context.getAtlasIndex();
+  if ( A.context.getVps().getFrameWidth( atlas ) != B.context.getVps().getFrameWidth( atlas ) ||
+       A.context.getVps().getFrameHeight( atlas ) != B.context.getVps().getFrameHeight( atlas ) )
+    bad |= 512;
+  return bad;
+}
+#endif
 
 // integration/tmc2hip_convert.cpp, applyPacking: the records the product's packers return for a frame (by index, with
 // placements), its list order and matches, applied to a PCCPatch vector in creation order -- against the vector the

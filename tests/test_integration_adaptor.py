@@ -78,6 +78,30 @@ def test_adaptor_segmenter_compute_is_a_drop_in(adaptor):
     assert adaptor.adaptor_check_segmenter_compute(0, _p(x), _p(c), C.c_size_t(len(x)), C.byref(params)) == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,name,nframes", [(0, "small", 2), (1, "tiny", 4), (2, "tiny", 4), (2, "small", 3)])
+def test_adaptor_encoder_seams_are_drop_ins(adaptor, mode, name, nframes):
+    """On an MI355X: the reference's own encode() order over its own PCCContext, with every seam of the hot path
+    (generateSegments, placeSegments, generateOccupancyMap .. generateGeometryVideo, generatePointCloud ..
+    generateAttributeVideo + padding) answered by integration/tmc2hip_adaptor.cpp's EncoderDropIn -- the product behind the
+    C-ABI -- next to the same GOF through the reference's members: patch lists, sizes, occupancy maps, blockToPatch, the three
+    videos, the reconstructed clouds and pointToPixel compared container by container.  mode: all-intra, low-delay (chained
+    packing), random-access (+ global patch allocation)."""
+    L = adaptor
+    frames = [synth_cloud(name, f) for f in range(nframes)]
+    assert L.ref_gof_begin2(len(frames), 10, 10, 4, 1280, 1280, mode) == 0
+    keep = []
+    for i, (xyz, rgb) in enumerate(frames):
+        x, c = np.ascontiguousarray(xyz, np.int16), np.ascontiguousarray(rgb, np.uint8)
+        keep.append((x, c))
+        L.ref_gof_set_frame(i, _p(x), _p(c), C.c_size_t(len(x)))
+    assert L.ref_gof_phase_a() == 0 and L.ref_gof_phase_b() == 0
+    mask = L.ref_gof_dropin_check(0)
+    assert mask >= 0, mask
+    assert mask & 0x3FF == 0, "containers that differ: %#x" % mask
+    assert mask & 0x400 == 0, "matched-patch counts differ"
+
+
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("mode", [0, 1])
 def test_adaptor_apply_packing_rebuilds_the_reference_patch_lists(reference, seed, mode):
