@@ -363,6 +363,10 @@ int tmc2_frame_reset( tmc2_frame* f ) {
   f->packMatch.clear();
   f->depthCount = f->occCount = 0;
   f->rounds = f->packedHeight = f->packedWidth = 0;
+  {
+    tmc2::ApiScope scope( f->ctx );
+    f->refineJob.reset();
+  }
   return TMC2_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <functional>
@@ -229,6 +230,10 @@ struct tmc2_frame {
   tmc2::KdTreeHost     tree;
   bool                 haveTree = false;
   int                  ensureTree();  // builds + uploads the k-d tree on first use (S1 belongs to the timed path)
+  // device work that needs the points only and may run while the host walks the orientation graph (S3): called by the
+  // orientation step right before its sequential host part, when set (tmc2_segmenter_compute: the refine step's geometry)
+  std::function<int()>  beforeHostWalk;
+  std::shared_ptr<void> refineJob;  // the refine step's geometry, prepared ahead (refine.hip)
   // device side
   tmc2::DevBuf<tmc2::Pt>     d_pts;       // original order
   tmc2::DevBuf<tmc2::Pt>     d_ptsTree;   // tree order
@@ -362,6 +367,8 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
 int rgb444ToYuv420Device( tmc2_ctx* ctx, const uint8_t* d_rgb, int W, int H, int filter, uint8_t* d_yuv );
 int yuv420ToYuv444Device( tmc2_ctx* ctx, const uint8_t* d_yuv, int W, int H, int filter, uint16_t* d_out );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
+// the point-only half of it ahead of time (voxels, neighbourhood rows): queued, not waited for; refineGridBased picks it up
+int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
 int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,

@@ -582,6 +582,7 @@ int orientNormalsHost( tmc2_frame* f ) {
     TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );
     ctx->stageEnd( sid );
     if ( contracted ) {
+      if ( f->beforeHostWalk ) TMC2_TRY( f->beforeHostWalk() );  // device work that overlaps the walk
       int8_t*               clusterSign = ctx->hostC.get<int8_t>( 2 * n ) + n;  // second half: the first holds the parities (g.parity)
       std::vector<uint32_t> seeds;
       uint32_t*             component = reinterpret_cast<uint32_t*>( ctx->hostB.get<uint32_t>( n ) );

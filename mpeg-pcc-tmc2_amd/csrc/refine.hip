@@ -950,21 +950,76 @@ static int allowLargeLds( const void* kernel, size_t bytes, int device ) {
   return TMC2_OK;
 }
 
-int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
-  if ( !f->haveNormals || !f->havePartition ) {
-    setError( "refineSegmentationGridBased: normals / partition missing" );
-    return TMC2_E_STATE;
+// refineSegmentationGridBased in two halves.  geometry(): everything that depends on the points alone -- voxels, points grouped
+// by voxel, neighbourhood rows -- queued without waiting for the last result; a frame's host thread runs it BEFORE the
+// sequential orientation walk (S3), so the device builds the rows while the host walks.  finish(): the rest (histograms of
+// the initial partition, sweeps).  The dense voxel table stays filled in between (no other stage of the frame's context
+// uses it); a job dropped half-way empties it again.
+struct RefineJob {
+  // parameters
+  int    maxNNCount = 0, iterationCount = 0, voxDim = 0, searchRadius = 0;
+  double lambda = 0.0;
+  // state between the halves
+  tmc2_frame*      frame = nullptr;
+  tmc2_ctx*        ctx   = nullptr;
+  hipStream_t      s     = nullptr;
+  uint32_t         n = 0, V = 0, W = 0, devStride = 32, totalLen = 0;
+  int              devRange = 1, idBits = 26;
+  Grid             g{};
+  std::vector<int> offsets;
+  uint32_t*        table = nullptr;
+  bool             tableFilled = false, eventDriven = false;
+  size_t           Vp = 0, ldsRoom = 0, ldsFixed = 0, ball = 0, perVoxel = 0;
+  uint64_t         capacity = 0;
+  uint32_t         res[2] = {0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag
+  DevBuf<uint32_t> d_key, d_flag, d_vid, d_small, d_count, d_rowLen, d_devLen, d_adjOff, d_hist, d_activeBuf, d_pointStart,
+      d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev;
+  DevBuf<Pt>      d_centre;
+  DevBuf<double>  d_weight;
+  DevBuf<uint8_t> d_state;  // edge | ppi | arg | marked | proc, V bytes each
+  DevBuf<int>     d_offsets;
+  DevBuf<uint4>   d_S;
+  bool matches( int nn, double l, int it, int vd, int sr ) const {
+    return nn == maxNNCount && l == lambda && it == iterationCount && vd == voxDim && sr == searchRadius;
   }
+  int  geometry( tmc2_frame* f );
+  int  finish();
+  void launchNeighbourhood();
+  ~RefineJob();
+};
+
+RefineJob::~RefineJob() {
+  if ( tableFilled && table && d_key.p ) {  // dropped between the halves: hand the context's table back empty
+    ApiScope scope( ctx );
+    hipLaunchKernelGGL( tableCleanKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, s, d_key.p, n, table );
+    (void)hipStreamSynchronize( s );  // (the buffers go back to the pool when the members are destroyed)
+  }
+}
+
+void RefineJob::launchNeighbourhood() {
+#define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
+  hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
+                      d_count.p, table, g, V, d_offsets.p, int( ball ), maxNNCount, lambda, idBits, devRange, devStride,       \
+                      uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
+                      d_small.p + 2 )
+  if ( ball <= 2048 )
+    TMC2_NEIGHBOURHOOD( 2048, 4 );
+  else
+    TMC2_NEIGHBOURHOOD( 4096, 2 );
+#undef TMC2_NEIGHBOURHOOD
+}
+
+int RefineJob::geometry( tmc2_frame* f ) {
   if ( voxDim < 2 || ( voxDim & ( voxDim - 1 ) ) ) {  // (the CTC sequences use 4 -- longdress, basketball -- and 2 -- loot, redandblack, soldier)
     setError( "refineSegmentationGridBased: voxelDimensionRefineSegmentation=%d unsupported (power of two >= 2)", voxDim );
     return TMC2_E_UNSUPPORTED;
   }
   if ( iterationCount < 1 ) iterationCount = 1;  // the reference loop is do { } while ( ++iter < count )
-  tmc2_ctx*      ctx = f->ctx;
-  hipStream_t    s   = ctx->stream;
-  const uint32_t n   = uint32_t( f->n );
+  frame = f;
+  ctx   = f->ctx;
+  s     = ctx->stream;
+  n     = uint32_t( f->n );
   // grid geometry (PCCPatchSegmenter.cpp:1397-1413)
-  Grid   g;
   size_t geoRange = 1;
   for ( size_t i = size_t( f->geoMax - 1 ); i != 0; i >>= 1, geoRange <<= 1 ) {}
   g.voxShift = 0;
@@ -979,7 +1034,6 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     return TMC2_E_UNSUPPORTED;
   }
   const int r2 = searchRadius >> g.voxShift;
-  std::vector<int> offsets;
   {
     int R = 0;
     while ( R * R < r2 ) ++R;
@@ -993,36 +1047,28 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     setError( "refineSegmentationGridBased: search radius %d too large for the LDS neighbourhood tile", searchRadius );
     return TMC2_E_UNSUPPORTED;
   }
-  const int      devRange  = voxDim >= 4 ? 1 : 2;  // PCCPatchSegmenter.cpp:1471
-  const uint32_t devStride = devRange == 1 ? 32u : 128u;
-  const int      idBits    = r2 <= 64 ? 26 : 25;   // neighbourhood sort key: d2 above, voxel id below
+  devRange  = voxDim >= 4 ? 1 : 2;  // PCCPatchSegmenter.cpp:1471
+  devStride = devRange == 1 ? 32u : 128u;
+  idBits    = r2 <= 64 ? 26 : 25;   // neighbourhood sort key: d2 above, voxel id below
   const int sidSetup = ctx->stageBegin( "refine_setup" );
   if ( ctx->gridTable.count < g.tableSize ) {
     TMC2_TRY( ctx->gridTable.alloc( g.tableSize ) );
     TMC2_HIP( hipMemsetAsync( ctx->gridTable.p, 0xFF, size_t( g.tableSize ) * 4, s ) );
   }
-  uint32_t* table = ctx->gridTable.p;
-  DevBuf<uint32_t> d_key, d_flag, d_vid, d_small;
+  table = ctx->gridTable.p;
   TMC2_TRY( d_key.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
   TMC2_TRY( d_vid.alloc( n ) );
   TMC2_TRY( d_small.alloc( 16 ) );  // [0] voxel count, [1] adjacency size, [2] closure flag
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
+  tableFilled = true;
   hipLaunchKernelGGL( voxelKeyKernel, grdN, blk, 0, s, f->d_pts.p, n, g, d_key.p, table );
   hipLaunchKernelGGL( firstFlagKernel, grdN, blk, 0, s, d_key.p, table, n, d_flag.p );
   DevBuf<uint32_t> d_rank;
   TMC2_TRY( d_rank.alloc( n ) );
   TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p ) );
-  uint32_t V = 0;
   TMC2_HIP( hipMemcpyAsync( &V, d_small.p, 4, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
-  DevBuf<uint32_t> d_count, d_rowLen, d_devLen, d_adjOff, d_hist;
-  DevBuf<Pt>       d_centre;
-  DevBuf<double>   d_weight;
-  DevBuf<uint8_t>  d_state;  // edge | ppi | arg | marked | proc, V bytes each
-  DevBuf<uint32_t> d_activeBuf;
-  DevBuf<int>      d_offsets;
-  DevBuf<uint4>    d_S;
   TMC2_TRY( d_count.alloc( size_t( V ) + 1 ) );  // (+1: scanned into the point-list offsets)
   TMC2_TRY( d_rowLen.alloc( V ) );
   TMC2_TRY( d_devLen.alloc( V ) );
@@ -1030,24 +1076,20 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   TMC2_TRY( d_hist.alloc( size_t( V ) * 4 ) );
   TMC2_TRY( d_centre.alloc( V ) );
   TMC2_TRY( d_weight.alloc( V ) );
-  const size_t Vp = ( size_t( V ) + 63 ) & ~size_t( 63 );  // sub-arrays of the state block: whole, aligned 32-voxel words
+  Vp = ( size_t( V ) + 63 ) & ~size_t( 63 );  // sub-arrays of the state block: whole, aligned 32-voxel words
   TMC2_TRY( d_state.alloc( Vp * 6 ) );
   TMC2_TRY( d_activeBuf.alloc( V ) );
   TMC2_TRY( d_offsets.alloc( offsets.size() ) );
   TMC2_TRY( d_S.alloc( V ) );
-  uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + Vp, *d_arg = d_state.p + 2 * Vp, *d_marked = d_state.p + 4 * Vp,
-          *d_proc = d_state.p + 5 * Vp;
-  uint32_t* d_active = d_activeBuf.p;
   // every buffer of this stage that starts from zeros, in one launch (the event-driven loop's among them)
-  const uint32_t W = ( V + 31 ) / 32;
+  W = ( V + 31 ) / 32;
   // Which sweep loop: the event-driven one needs the closure's four bitmaps and a voxel list in the LDS of one workgroup
   // (160 KB: up to ~ 290 K voxels; a vox11 frame has ~ 240 K).  Larger grids take the sweep-everything loop.
   // (test hook TMC2_REFINE_SWEEPS=full forces that one)
-  const char*  sweepsEnv   = getenv( "TMC2_REFINE_SWEEPS" );
-  const size_t ldsRoom     = 160 * 1024 - 64;  // gfx950: 160 KB of LDS per workgroup (opt-in above 64 KB); static part: 8 bytes
-  const size_t ldsFixed    = 16 * size_t( W );
-  const bool   eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
-  DevBuf<uint32_t> d_pointStart, d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits;
+  const char* sweepsEnv = getenv( "TMC2_REFINE_SWEEPS" );
+  ldsRoom     = 160 * 1024 - 64;  // gfx950: 160 KB of LDS per workgroup (opt-in above 64 KB); static part: 8 bytes
+  ldsFixed    = 16 * size_t( W );
+  eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
   TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
   TMC2_TRY( d_pointList.alloc( n ) );
   TMC2_TRY( d_cursor.alloc( V ) );
@@ -1072,48 +1114,47 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
   hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
-  hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
-                      d_hist.p );
-  const dim3 grdV( ( V + 255 ) / 256 ), grdV16( ( V + 15 ) / 16 );  // 16 lanes per voxel
   // points grouped by voxel, for the re-scoring pass
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_pointStart.p, size_t( V ) + 1, nullptr ) );
   hipLaunchKernelGGL( voxelPointListKernel, grdN, blk, 0, s, d_vid.p, d_pointStart.p, n, d_cursor.p, d_pointList.p );
-  hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
-                      d_edge, d_ppi, d_active );
   // neighbourhoods.  Rows back to back; room for twice the expected mean row (maxNN / points per voxel) -- the rare frame
   // that needs more repeats the pass with room for whole balls.  (test hook TMC2_REFINE_ROWCAP=tiny forces the repeat)
   if ( ( uint64_t( V ) >> idBits ) != 0 ) {
     setError( "refineSegmentationGridBased: %u voxels exceed the neighbourhood sort key", V );
     return TMC2_E_UNSUPPORTED;
   }
-  DevBuf<uint32_t> d_adj, d_dev;
   TMC2_TRY( d_dev.alloc( size_t( V ) * devStride ) );
-  const size_t ball     = offsets.size();
-  const char*  capEnv   = getenv( "TMC2_REFINE_ROWCAP" );
-  size_t       perVoxel = std::min<size_t>( ball, 2 * size_t( maxNNCount > 0 ? maxNNCount : 1 ) * V / std::max<uint32_t>( n, 1u ) + 32 );
+  ball                = offsets.size();
+  const char* capEnv  = getenv( "TMC2_REFINE_ROWCAP" );
+  perVoxel            = std::min<size_t>( ball, 2 * size_t( maxNNCount > 0 ? maxNNCount : 1 ) * V / std::max<uint32_t>( n, 1u ) + 32 );
   if ( capEnv && capEnv[0] == 't' ) perVoxel = 1;
-  uint32_t totalLen = 0;
+  capacity = uint64_t( V ) * perVoxel;
+  if ( capacity > 0xFFFFFFFFull ) {
+    setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
+    return TMC2_E_UNSUPPORTED;
+  }
+  TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
+  launchNeighbourhood();
+  TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );  // (read in finish(), after a synchronisation)
+  ctx->stageEnd( sidSetup );
+  TMC2_HIP( hipGetLastError() );
+  return TMC2_OK;
+}
+
+int RefineJob::finish() {
+  tmc2_frame* f = frame;
+  if ( !f->haveNormals || !f->havePartition ) {
+    setError( "refineSegmentationGridBased: normals / partition missing" );
+    return TMC2_E_STATE;
+  }
+  const int  sidSetup = ctx->stageBegin( "refine_setup" );
+  const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
+  uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + Vp, *d_arg = d_state.p + 2 * Vp, *d_marked = d_state.p + 4 * Vp,
+          *d_proc = d_state.p + 5 * Vp;
+  uint32_t* d_active = d_activeBuf.p;
+  const dim3 grdV( ( V + 255 ) / 256 ), grdV16( ( V + 15 ) / 16 );  // 16 lanes per voxel
   for ( int attempt = 0;; ++attempt ) {
-    const uint64_t capacity = uint64_t( V ) * perVoxel;
-    if ( capacity > 0xFFFFFFFFull ) {
-      setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
-      return TMC2_E_UNSUPPORTED;
-    }
-    TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
-    if ( attempt > 0 ) TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 8, s ) );  // [1] row cursor, [2] overflow
-#define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
-  hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
-                      d_count.p, table, g, V, d_offsets.p, int( ball ), maxNNCount, lambda, idBits, devRange, devStride,       \
-                      uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
-                      d_small.p + 2 )
-    if ( ball <= 2048 )
-      TMC2_NEIGHBOURHOOD( 2048, 4 );
-    else
-      TMC2_NEIGHBOURHOOD( 4096, 2 );
-#undef TMC2_NEIGHBOURHOOD
-    uint32_t res[2] = {0, 0};
-    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );
-    TMC2_HIP( hipStreamSynchronize( s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );  // (usually long done: the orientation walk ran in between)
     TMC2_HIP( hipGetLastError() );
     totalLen = res[0];
     if ( res[1] == 0 ) break;
@@ -1121,9 +1162,23 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
       setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
       return TMC2_E_HIP;
     }
-    perVoxel = ball;
+    perVoxel = ball;  // room for whole balls
+    capacity = uint64_t( V ) * perVoxel;
+    if ( capacity > 0xFFFFFFFFull ) {
+      setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
+      return TMC2_E_UNSUPPORTED;
+    }
+    TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
+    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 8, s ) );  // [1] row cursor, [2] overflow
+    launchNeighbourhood();
+    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );
   }
   hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
+  tableFilled = false;
+  hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
+                      d_hist.p );
+  hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
+                      d_edge, d_ppi, d_active );
   const dim3 grdV32( ( V + 7 ) / 8 );
   if ( eventDriven ) {
     // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
@@ -1251,6 +1306,36 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
     }
   }
   return TMC2_OK;
+}
+
+// the first half ahead of time (tmc2_segmenter_compute runs it before the orientation walk); kept with the frame
+int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
+  auto job             = std::make_shared<RefineJob>();
+  job->maxNNCount      = maxNNCount;
+  job->lambda          = lambda;
+  job->iterationCount  = iterationCount;
+  job->voxDim          = voxDim;
+  job->searchRadius    = searchRadius;
+  f->refineJob.reset();
+  TMC2_TRY( job->geometry( f ) );
+  f->refineJob = job;
+  return TMC2_OK;
+}
+
+int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
+  if ( !f->haveNormals || !f->havePartition ) {
+    setError( "refineSegmentationGridBased: normals / partition missing" );
+    return TMC2_E_STATE;
+  }
+  std::shared_ptr<RefineJob> job = std::static_pointer_cast<RefineJob>( f->refineJob );
+  f->refineJob.reset();
+  if ( !job || !job->matches( maxNNCount, lambda, iterationCount < 1 ? 1 : iterationCount, voxDim, searchRadius ) ) {
+    job.reset();
+    TMC2_TRY( refinePrepareGeometry( f, maxNNCount, lambda, iterationCount, voxDim, searchRadius ) );
+    job = std::static_pointer_cast<RefineJob>( f->refineJob );
+    f->refineJob.reset();
+  }
+  return job->finish();
 }
 
 }  // namespace tmc2

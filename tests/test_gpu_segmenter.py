@@ -236,6 +236,23 @@ def test_gpu_segment_patches_matches_oracle(gpu_ctx, oracle, name, iters):
     _assert_patches_equal(fr.get_patches(), oracle.segment_patches(xyz, rgb, knn, part, _to_oracle_params(p)))
 
 
+@pytest.mark.parametrize("rowcap", [None, "tiny"])
+def test_gpu_segmenter_compute_with_refine_geometry_ahead(gpu_ctx, oracle, monkeypatch, rowcap):
+    """TMC2_REFINE_OVERLAP=1: the refine step's point-only half (voxels, neighbourhood rows) is queued before the orientation's
+    host walk and picked up afterwards -- also when the neighbourhood pass has to be repeated with more room."""
+    monkeypatch.setenv("TMC2_REFINE_OVERLAP", "1")
+    if rowcap:
+        monkeypatch.setenv("TMC2_REFINE_ROWCAP", rowcap)
+    xyz, rgb = synth_cloud("small", 2)
+    fr = gpu_ctx.frame(xyz, rgb)
+    p = T.ctc_params(10, 11, fr.weight_normal(11, 0.6))
+    fr.segmenter_compute(p)
+    exp = oracle.segment(xyz, rgb, _to_oracle_params(p))
+    _assert_patches_equal(fr.get_patches(), exp)
+    fr.segmenter_compute(p)                                   # and again on the same frame (nothing stale is picked up)
+    _assert_patches_equal(fr.get_patches(), exp)
+
+
 @pytest.mark.parametrize("name,frame,iters", [("small", 1, 50), ("medium", 2, 10)])
 def test_gpu_segmenter_compute_matches_oracle(gpu_ctx, oracle, name, frame, iters):
     """PCCPatchSegmenter3::compute end to end (S1..S9) through the C-ABI."""
