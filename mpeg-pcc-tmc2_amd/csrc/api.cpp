@@ -4,9 +4,32 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
+#include <map>
 #include <memory>
+#include <mutex>
 
 #include "internal.h"
+
+namespace tmc2 {
+// Opt-in to more than 48 KB of dynamic LDS, once per device and kernel: hipFuncSetAttribute mutates runtime-wide kernel
+// state, and every in-flight frame's host thread comes through here at the same time.
+int allowLargeLds( const void* kernel, size_t bytes, int device, size_t staticBytes ) {
+  static std::mutex                                 lock;
+  static std::map<std::pair<const void*, int>, int> granted;
+  std::lock_guard<std::mutex>                       g( lock );
+  int& have = granted[{kernel, device}];
+  if ( int( bytes ) <= have ) return TMC2_OK;
+  // the whole LDS of a gfx950 CU less the kernel's static part: asked for once, whatever this frame needs
+  const int want = 160 * 1024 - int( ( staticBytes + 63 ) & ~size_t( 63 ) );
+  if ( int( bytes ) > want ) {
+    setError( "%zu bytes of dynamic LDS requested (+ %zu static): more than a gfx950 workgroup has", bytes, staticBytes );
+    return TMC2_E_INVALID;
+  }
+  TMC2_HIP( hipFuncSetAttribute( kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want ) );
+  have = want;
+  return TMC2_OK;
+}
+}  // namespace tmc2
 
 namespace tmc2 {
 

@@ -373,6 +373,8 @@ int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int ite
 int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
 int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,
                        DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
+// opt-in to more than 48 KB of dynamic LDS for a kernel (once per device and kernel, serialised)
+int allowLargeLds( const void* kernel, size_t bytes, int device, size_t staticBytes = 64 );
 int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );
 // several device regions set to a byte value each in ONE launch (instead of one hipMemsetAsync per buffer)
 struct FillRegion {

@@ -27,7 +27,9 @@
 // The level passes only carry the top of the tree: a segment of at most kRetire points is RETIRED at the level it appears
 // and finished later by one wavefront with its points in LDS (finishSubtreesKernel): nodes down to kLaneMax points by the
 // wave together (the same closed-form sweeps, ranks from ballots), smaller ones by single lanes running nanoflann's
-// recursion literally.  A 0.84 M-point frame takes ~ 12 levels of passes instead of ~ 24.
+// recursion literally.  In between, a segment of at most kSplitMax points goes to ONE workgroup (splitSegmentsKernel: points in
+// LDS, a wavefront per node, depth by depth) that cuts it into retired pieces.  A 0.84 M-point frame takes ~ 10 levels of
+// passes instead of ~ 24, one splitting and one finishing launch.
 // (A single persistent launch with grid-wide barriers was measured too: on this multi-XCD part every barrier is an L2
 // write-back + invalidate per workgroup, ~45 us per pass, and the builds of concurrent frames serialise.  Separate
 // launches leave the gaps of one frame to the passes of the others.)
@@ -53,6 +55,16 @@ constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kern
 constexpr int      kRetire    = TMC2_KD_RETIRE;   // segments of at most this many points leave the level passes (one wavefront each)
 constexpr int      kLaneMax   = TMC2_KD_LANEMAX;  // ... and inside a wavefront's subtree, nodes of at most this many points go to single lanes
 constexpr int      kSmallMax  = 64;    // such nodes are handed to the lanes in batches of at most this many
+#ifndef TMC2_KD_SPLITMAX
+#define TMC2_KD_SPLITMAX 8192
+#endif
+// Between the two: a segment of more than kRetire and at most kSplitMax points also leaves the level passes -- one workgroup
+// splits it in LDS (a wavefront per node, level by level) until its pieces are at most kRetire points and joins them to the
+// retired list (splitSegmentsKernel).  Five launches per level are worth it while a level holds hundreds of thousands of points
+// in a few segments; the 0.84 M-point frame needs 15 levels to get every segment below 1 024 points, 10 to get below 8 192.
+constexpr int      kSplitMax  = TMC2_KD_SPLITMAX > TMC2_KD_RETIRE ? TMC2_KD_SPLITMAX : TMC2_KD_RETIRE;
+constexpr int      kSplitWaves = 8;
+constexpr int      kSplitNodes = 2 * ( kSplitMax / kRetire ) + 4;  // nodes of more than kRetire points at one depth of such a segment
 
 struct BuildSeg {
   uint32_t begin, end;    // range in tree order
@@ -87,6 +99,8 @@ struct BuildArgs {
   uint32_t* levels;     // out: number of levels
   RetiredSeg* retired;  // [n / (kRetire / 2) + 2]: every retired segment has a parent of more than kRetire points
   uint32_t*   retiredCount;
+  RetiredSeg* big;      // segments of more than kRetire and at most kSplitMax points (splitSegmentsKernel)
+  uint32_t*   bigCount;
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
   uint32_t*   ticket;       // "last block done" counter of the prefix sums
 };
@@ -370,6 +384,13 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
       for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
       a.retired[atomicAdd( a.retiredCount, 1u )] = r;
       q->split = 0;
+    } else if ( cnt > uint32_t( kRetire ) && cnt <= uint32_t( kSplitMax ) ) {  // split further by one workgroup in LDS
+      RetiredSeg r;
+      r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
+      r.root  = q->parent == kNone ? 1 : 0;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
+      a.big[atomicAdd( a.bigCount, 1u )] = r;
+      q->split = 0;
     } else if ( splitRule( q, cutDim, cut ) ) {
       q->split = 1, q->cutDim = uint8_t( cutDim ), q->cut = cut;
     } else {
@@ -392,7 +413,7 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
           int     cutDim;
           int32_t cut;
           const BuildSeg* q = cur + s;
-          if ( q->end - q->begin > uint32_t( kRetire ) && splitRule( q, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
+          if ( q->end - q->begin > uint32_t( kSplitMax ) && splitRule( q, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
         }
       }
       v[k] = f;
@@ -651,6 +672,60 @@ __device__ __forceinline__ void waveSweep( Pt* P, uint32_t* perm, uint32_t count
   waveFence();
 }
 
+// tight ranges of pts[0..count) on the three dimensions, by a wavefront
+__device__ __forceinline__ void waveTightRange( const Pt* pts, uint32_t count, int lane, int32_t ( &mn )[3], int32_t ( &mx )[3] ) {
+  int mn0 = 0x7FFFFFFF, mn1 = mn0, mn2 = mn0, mx0 = int( 0x80000000 ), mx1 = mx0, mx2 = mx0;
+  for ( uint32_t i = lane; i < count; i += 64 ) {
+    const Pt p = pts[i];
+    mn0 = min( mn0, int( p.x ) ), mx0 = max( mx0, int( p.x ) );
+    mn1 = min( mn1, int( p.y ) ), mx1 = max( mx1, int( p.y ) );
+    mn2 = min( mn2, int( p.z ) ), mx2 = max( mx2, int( p.z ) );
+  }
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) {
+    mn0 = min( mn0, __shfl_xor( mn0, off, 64 ) ), mn1 = min( mn1, __shfl_xor( mn1, off, 64 ) ), mn2 = min( mn2, __shfl_xor( mn2, off, 64 ) );
+    mx0 = max( mx0, __shfl_xor( mx0, off, 64 ) ), mx1 = max( mx1, __shfl_xor( mx1, off, 64 ) ), mx2 = max( mx2, __shfl_xor( mx2, off, 64 ) );
+  }
+  mn[0] = mn0, mn[1] = mn1, mn[2] = mn2, mx[0] = mx0, mx[1] = mx1, mx[2] = mx2;
+}
+
+// One node of more than kLeafMax points split by a wavefront on its slice of the LDS arrays: nanoflann's middleSplit_ +
+// planeSplit (both sweeps) + the balance rule; returns the rule, the size of the left child and the tight ranges of the two
+// children on the cut dimension (the parent's divlow / divhigh).
+struct NodeSplit {
+  SplitRule rule;
+  uint32_t  idx;
+  int       lmax, rmin;
+};
+__device__ __forceinline__ NodeSplit waveSplitNode( Pt* pts, uint32_t* id, uint32_t count, const int16_t ( &lo )[3],
+                                                    const int16_t ( &hi )[3], const int32_t ( &mn )[3], const int32_t ( &mx )[3],
+                                                    uint16_t* lst, int lane ) {
+  NodeSplit ns;
+  ns.rule           = splitOf( lo, hi, mn, mx );
+  const SplitRule r = ns.rule;
+  // class counts of both sweeps in one pass
+  uint32_t lt = 0, le = 0;
+  for ( uint32_t i = lane; i < count; i += 64 ) {
+    const int32_t x = coordOf( pts[i], r.dim );
+    lt += uint32_t( x < r.cut ), le += uint32_t( x <= r.cut );
+  }
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) lt += __shfl_xor( lt, off, 64 ), le += __shfl_xor( le, off, 64 );
+  waveSweep( pts, id, count, lt, r.dim, r.cut, lst, lane );
+  waveSweep( pts + lt, id + lt, count - lt, le - lt, r.dim, r.cut + 1, lst, lane );
+  const uint32_t half = count / 2;
+  ns.idx              = lt > half ? lt : ( le < half ? le : half );
+  int lmax = int( 0x80000000 ), rmin = 0x7FFFFFFF;
+  for ( uint32_t i = lane; i < count; i += 64 ) {
+    const int x = coordOf( pts[i], r.dim );
+    if ( i < ns.idx ) lmax = max( lmax, x ); else rmin = min( rmin, x );
+  }
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) lmax = max( lmax, __shfl_xor( lmax, off, 64 ) ), rmin = min( rmin, __shfl_xor( rmin, off, 64 ) );
+  ns.lmax = lmax, ns.rmin = rmin;
+  return ns;
+}
+
 // nanoflann's divideTree on P[b..e) by ONE lane (literal two-pass planeSplit with std::swap semantics), explicit stack.
 __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t globalBegin, KdNode* __restrict__ nodes,
                              uint32_t* __restrict__ nodeCount, uint32_t& maxDepth, uint32_t* __restrict__ refuse ) {
@@ -784,20 +859,8 @@ __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( Bui
       }
       Pt*       pts = P + q.begin;
       uint32_t* id  = perm + q.begin;
-      // tight ranges
-      int mn0 = 0x7FFFFFFF, mn1 = mn0, mn2 = mn0, mx0 = int( 0x80000000 ), mx1 = mx0, mx2 = mx0;
-      for ( uint32_t i = lane; i < count; i += 64 ) {
-        const Pt p = pts[i];
-        mn0 = min( mn0, int( p.x ) ), mx0 = max( mx0, int( p.x ) );
-        mn1 = min( mn1, int( p.y ) ), mx1 = max( mx1, int( p.y ) );
-        mn2 = min( mn2, int( p.z ) ), mx2 = max( mx2, int( p.z ) );
-      }
-#pragma unroll
-      for ( int off = 32; off > 0; off >>= 1 ) {
-        mn0 = min( mn0, __shfl_xor( mn0, off, 64 ) ), mn1 = min( mn1, __shfl_xor( mn1, off, 64 ) ), mn2 = min( mn2, __shfl_xor( mn2, off, 64 ) );
-        mx0 = max( mx0, __shfl_xor( mx0, off, 64 ) ), mx1 = max( mx1, __shfl_xor( mx1, off, 64 ) ), mx2 = max( mx2, __shfl_xor( mx2, off, 64 ) );
-      }
-      const int32_t mn[3] = {mn0, mn1, mn2}, mx[3] = {mx0, mx1, mx2};
+      int32_t mn[3], mx[3];
+      waveTightRange( pts, count, lane, mn, mx );
       int16_t       lo[3], hi[3];
       for ( int d = 0; d < 3; ++d ) lo[d] = isRoot ? int16_t( mn[d] ) : q.lo[d], hi[d] = isRoot ? int16_t( mx[d] ) : q.hi[d];
       if ( isRoot && lane == 0 )
@@ -821,25 +884,10 @@ __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( Bui
         ++nSmall;
         continue;
       }
-      const SplitRule r = splitOf( lo, hi, mn, mx );
-      // class counts of both sweeps in one pass
-      uint32_t lt = 0, le = 0;
-      for ( uint32_t i = lane; i < count; i += 64 ) {
-        const int32_t x = coordOf( pts[i], r.dim );
-        lt += uint32_t( x < r.cut ), le += uint32_t( x <= r.cut );
-      }
-#pragma unroll
-      for ( int off = 32; off > 0; off >>= 1 ) lt += __shfl_xor( lt, off, 64 ), le += __shfl_xor( le, off, 64 );
-      waveSweep( pts, id, count, lt, r.dim, r.cut, lst, lane );
-      waveSweep( pts + lt, id + lt, count - lt, le - lt, r.dim, r.cut + 1, lst, lane );
-      const uint32_t half = count / 2, idx = lt > half ? lt : ( le < half ? le : half );
-      int            lmax = int( 0x80000000 ), rmin = 0x7FFFFFFF;
-      for ( uint32_t i = lane; i < count; i += 64 ) {
-        const int x = coordOf( pts[i], r.dim );
-        if ( i < idx ) lmax = max( lmax, x ); else rmin = min( rmin, x );
-      }
-#pragma unroll
-      for ( int off = 32; off > 0; off >>= 1 ) lmax = max( lmax, __shfl_xor( lmax, off, 64 ) ), rmin = min( rmin, __shfl_xor( rmin, off, 64 ) );
+      const NodeSplit ns   = waveSplitNode( pts, id, count, lo, hi, mn, mx, lst, lane );
+      const SplitRule r    = ns.rule;
+      const uint32_t  idx  = ns.idx;
+      const int       lmax = ns.lmax, rmin = ns.rmin;
       uint32_t id0 = 0;
       if ( lane == 0 ) id0 = atomicAdd( a.nodeCount, 2u );
       id0 = __shfl( id0, 0, 64 );
@@ -880,6 +928,101 @@ __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( Bui
   }
 }
 
+// ---- segments of kRetire .. kSplitMax points: one workgroup each, points in LDS, one wavefront per node, depth by depth ----
+__global__ __launch_bounds__( 64 * kSplitWaves ) void splitSegmentsKernel( BuildArgs a ) {
+  extern __shared__ unsigned char splitLds[];
+  Pt*       P       = reinterpret_cast<Pt*>( splitLds );
+  uint32_t* perm    = reinterpret_cast<uint32_t*>( P + kSplitMax );
+  uint16_t* scratch = reinterpret_cast<uint16_t*>( perm + kSplitMax );  // [2 * kSplitMax]: a node's sweep lists at 2 * its begin
+  __shared__ SubNode  sNode[2][kSplitNodes];
+  __shared__ uint32_t sCount[2];
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t total = *a.bigCount;
+  for ( uint32_t s = blockIdx.x; s < total; s += gridDim.x ) {
+    const RetiredSeg seg = a.big[s];
+    const uint32_t   cnt = seg.end - seg.begin;
+    for ( uint32_t i = threadIdx.x; i < cnt; i += blockDim.x ) {
+      P[i]    = a.P[seg.begin + i];
+      perm[i] = a.perm[seg.begin + i];
+    }
+    if ( threadIdx.x == 0 ) {
+      SubNode r;
+      r.begin = 0, r.end = uint16_t( cnt ), r.node = seg.node, r.depth = 0;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = seg.lo[d], r.hi[d] = seg.hi[d];
+      sNode[0][0] = r;
+      sCount[0] = 1, sCount[1] = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for ( uint32_t depth = 0;; ++depth ) {
+      const uint32_t nCur = sCount[cur];
+      if ( nCur == 0 ) break;
+      for ( uint32_t t = wave; t < nCur; t += kSplitWaves ) {  // (uniform per wave)
+        const SubNode  q     = sNode[cur][t];
+        const uint32_t count = uint32_t( q.end ) - q.begin;
+        if ( uint32_t( q.depth ) + seg.level >= uint32_t( kMaxLevels ) - 2u ) {  // deeper than the k-NN traversal stack: refused
+          if ( lane == 0 ) atomicMax( a.finishDepth, 0x10000u );
+          continue;
+        }
+        Pt*       pts = P + q.begin;
+        uint32_t* id  = perm + q.begin;
+        int32_t   mn[3], mx[3];
+        waveTightRange( pts, count, lane, mn, mx );
+        const bool isRoot = seg.root != 0 && depth == 0;  // the tree's root: its loose box is its tight range
+        int16_t    lo[3], hi[3];
+        for ( int d = 0; d < 3; ++d ) lo[d] = isRoot ? int16_t( mn[d] ) : q.lo[d], hi[d] = isRoot ? int16_t( mx[d] ) : q.hi[d];
+        if ( isRoot && lane == 0 )
+          for ( int d = 0; d < 3; ++d ) a.rootBox[d] = mn[d], a.rootBox[3 + d] = mx[d];
+        const NodeSplit ns = waveSplitNode( pts, id, count, lo, hi, mn, mx, scratch + 2 * size_t( q.begin ), lane );
+        if ( lane == 0 ) {
+          const uint32_t id0 = atomicAdd( a.nodeCount, 2u );
+          KdNode         nd;
+          nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( ns.lmax ), nd.divhigh = int16_t( ns.rmin ),
+          nd.dim = ns.rule.dim;
+          a.nodes[q.node] = nd;
+          SubNode child[2];
+          child[0].begin = q.begin, child[0].end = uint16_t( q.begin + ns.idx ), child[0].node = id0;
+          child[1].begin = uint16_t( q.begin + ns.idx ), child[1].end = q.end, child[1].node = id0 + 1;
+          for ( int c = 0; c < 2; ++c ) {
+            child[c].depth = uint16_t( q.depth + 1 );
+            for ( int d = 0; d < 3; ++d ) child[c].lo[d] = lo[d], child[c].hi[d] = hi[d];
+          }
+          const int16_t cut = int16_t( ns.rule.cut );
+          if ( ns.rule.dim == 0 ) child[0].hi[0] = cut, child[1].lo[0] = cut;
+          if ( ns.rule.dim == 1 ) child[0].hi[1] = cut, child[1].lo[1] = cut;
+          if ( ns.rule.dim == 2 ) child[0].hi[2] = cut, child[1].lo[2] = cut;
+          for ( int c = 0; c < 2; ++c ) {
+            const uint32_t cc = uint32_t( child[c].end ) - child[c].begin, level = seg.level + child[c].depth;
+            if ( cc <= uint32_t( kLeafMax ) ) {
+              KdNode leaf;
+              leaf.a = int32_t( seg.begin + child[c].begin ), leaf.b = int32_t( seg.begin + child[c].end ), leaf.divlow = leaf.divhigh = 0,
+              leaf.dim = -1;
+              a.nodes[child[c].node] = leaf;
+              atomicMax( a.finishDepth, level + 1u );
+            } else if ( cc <= uint32_t( kRetire ) ) {
+              RetiredSeg r;
+              r.begin = seg.begin + child[c].begin, r.end = seg.begin + child[c].end, r.node = child[c].node, r.level = level, r.root = 0;
+              for ( int d = 0; d < 3; ++d ) r.lo[d] = child[c].lo[d], r.hi[d] = child[c].hi[d];
+              a.retired[atomicAdd( a.retiredCount, 1u )] = r;
+            } else {
+              sNode[cur ^ 1][atomicAdd( &sCount[cur ^ 1], 1u )] = child[c];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if ( threadIdx.x == 0 ) sCount[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+    for ( uint32_t i = threadIdx.x; i < cnt; i += blockDim.x ) {
+      a.P[seg.begin + i]    = P[i];
+      a.perm[seg.begin + i] = perm[i];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // Builds the tree of d_pts[0..n) on the context's stream.  Outputs: points and permutation in tree order, node records
@@ -899,9 +1042,10 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   TMC2_TRY( d_nodes.alloc( maxNode ) );
   DevBuf<uint32_t>   d_work, d_small;
   DevBuf<BuildSeg>   d_segs;
-  DevBuf<RetiredSeg> d_retired;
+  DevBuf<RetiredSeg> d_retired, d_big;
   const size_t       maxRetired = size_t( n ) / ( kLeafMax + 1 ) + 2;  // (retired segments are disjoint and hold > kLeafMax points)
   TMC2_TRY( d_retired.alloc( maxRetired ) );
+  TMC2_TRY( d_big.alloc( size_t( n ) / ( kRetire + 1 ) + 2 ) );  // (disjoint segments of more than kRetire points)
   TMC2_TRY( d_work.alloc( 3 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
@@ -919,6 +1063,8 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.retiredCount = d_small.p + kMaxLevels + 3;
   a.finishDepth  = d_small.p + kMaxLevels + 4;
   a.ticket       = d_small.p + kMaxLevels + 5;
+  a.big          = d_big.p;
+  a.bigCount     = d_small.p + kMaxLevels + 6;
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
   hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
@@ -933,7 +1079,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
     if ( level == 0 && hint > 0 ) {
       chunkEnd = uint32_t( std::min( hint, kMaxLevels ) );
     } else {
-      while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kRetire ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
+      while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kSplitMax ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
       if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 2, kMaxLevels );
     }
     for ( ; level < chunkEnd; ++level ) {
@@ -960,7 +1106,15 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   hint  = std::max( found, 1 );
   const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
-  const uint32_t retired = out[kMaxLevels + 3];
+  const uint32_t big = out[kMaxLevels + 6];
+  if ( big ) {  // segments between the two thresholds: one workgroup each, their pieces join the retired list
+    const size_t lds = size_t( kSplitMax ) * ( sizeof( Pt ) + 4 + 4 );
+    if ( lds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( splitSegmentsKernel ), lds, ctx->device,
+                                                     sizeof( SubNode ) * 2 * kSplitNodes + 64 ) );
+    hipLaunchKernelGGL( splitSegmentsKernel, dim3( std::min<uint32_t>( big, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kSplitWaves ), lds, s, a );
+  }
+  // (its pieces: typically 2 * kSplitMax / kRetire per segment; the finishing kernel strides over whatever the list holds)
+  const uint32_t retired = out[kMaxLevels + 3] + big * uint32_t( 2 * kSplitMax / kRetire );
   if ( retired ) {  // the subtrees below the level passes: one wavefront each
     const uint32_t blocks = std::min<uint32_t>( ( retired + kFinishWaves - 1 ) / kFinishWaves, 64u * uint32_t( ctx->cuCount ) );
     hipLaunchKernelGGL( finishSubtreesKernel, dim3( blocks ), dim3( 64 * kFinishWaves ), 0, s, a );

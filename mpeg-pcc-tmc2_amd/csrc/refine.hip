@@ -936,20 +936,6 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
 
 }  // namespace
 
-// Opt-in to more than 48 KB of dynamic LDS, once per device and kernel: hipFuncSetAttribute mutates runtime-wide kernel
-// state, and every in-flight frame's host thread comes through here at the same time.
-static int allowLargeLds( const void* kernel, size_t bytes, int device ) {
-  static std::mutex                                 lock;
-  static std::map<std::pair<const void*, int>, int> granted;
-  std::lock_guard<std::mutex>                       g( lock );
-  int& have = granted[{kernel, device}];
-  if ( int( bytes ) <= have ) return TMC2_OK;
-  const int want = 160 * 1024 - 64;  // the whole LDS of a gfx950 CU: asked for once, whatever this frame needs
-  TMC2_HIP( hipFuncSetAttribute( kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want ) );
-  have = want;
-  return TMC2_OK;
-}
-
 // refineSegmentationGridBased in two halves.  geometry(): everything that depends on the points alone -- voxels, points grouped
 // by voxel, neighbourhood rows -- queued without waiting for the last result; a frame's host thread runs it BEFORE the
 // sequential orientation walk (S3), so the device builds the rows while the host walks.  finish(): the rest (histograms of
@@ -1211,12 +1197,15 @@ int RefineJob::finish() {
       TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64, s ) );
     }
     uint32_t *gAct = d_gbits.p, *gFr = d_gbits.p + W, *gMk = d_gbits.p + 2 * size_t( W );
+    // (test hook TMC2_REFINE_WALK_THREADS: the size of the level walk's one workgroup)
+    const char* walkEnv     = getenv( "TMC2_REFINE_WALK_THREADS" );
+    const int   walkThreads = walkEnv ? std::min( 1024, std::max( 64, atoi( walkEnv ) & ~63 ) ) : 1024;
     for ( int iter = 0; iter < iterationCount; ++iter ) {
       uint4 *recCur = d_rec.p + size_t( iter & 1 ) * V, *recNxt = d_rec.p + size_t( ( iter + 1 ) & 1 ) * V;
       hipLaunchKernelGGL( closurePrepareKernel, grdV32, blk, 0, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p, devStride,
                           V, d_out.p, gAct, gFr, gMk );
-      hipLaunchKernelGGL( closureLevelsKernel, dim3( 1 ), dim3( 1024 ), ldsBytes, s, d_out.p, devStride, V, listCap, gAct, gFr, gMk,
-                          d_work.p, d_work.p + V, wantTiming ? d_timing.p : nullptr );
+      hipLaunchKernelGGL( closureLevelsKernel, dim3( 1 ), dim3( walkThreads ), ldsBytes, s, d_out.p, devStride, V, listCap, gAct, gFr,
+                          gMk, d_work.p, d_work.p + V, wantTiming ? d_timing.p : nullptr );
       hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_work.p, d_work.p + V, recCur, recNxt, d_lastRescore.p,
                           d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge, d_ppi,
                           reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, d_flags.p, iter );

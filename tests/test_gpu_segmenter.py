@@ -79,7 +79,8 @@ def test_gpu_knn_edge_cases(gpu_ctx, oracle):
         gpu_ctx.frame(xyz[:5]).kdtree_search(xyz[:5], 16)                         # k > n is an error, not UB
 
 
-@pytest.mark.parametrize("case", ["tiny", "small", "medium", "longdress_vox10", "line", "plane", "duplicates", "eleven"])
+@pytest.mark.parametrize("case", ["tiny", "small", "medium", "longdress_vox10", "line", "plane", "duplicates", "eleven",
+                                  "root3000", "root8192", "n8193", "dense20000"])
 def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, case):
     """The level-parallel device build must leave exactly the permutation of nanoflann's recursive build (the oracle's
     restatement for the small clouds, the library's host builder -- itself pinned to the oracle on CPU -- for all)."""
@@ -92,6 +93,12 @@ def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, case):
         xyz = np.repeat(rng.integers(0, 1024, (40, 3)).astype(np.int16), 300, axis=0)
     elif case == "eleven":                           # smallest cloud that splits
         xyz = rng.integers(0, 1024, (11, 3)).astype(np.int16)
+    elif case in ("root3000", "root8192"):           # the whole tree is one segment for the in-LDS splitting kernel
+        xyz = rng.integers(0, 1024, (int(case[4:]), 3)).astype(np.int16)
+    elif case == "n8193":                            # one level pass, then two such segments
+        xyz = rng.integers(0, 512, (8193, 3)).astype(np.int16)
+    elif case == "dense20000":                       # many equal coordinates: unbalanced pieces, tiny children next to big ones
+        xyz = rng.integers(0, 12, (20000, 3)).astype(np.int16)
     else:
         xyz, _ = synth_cloud(case)
     fr = gpu_ctx.frame(xyz)
