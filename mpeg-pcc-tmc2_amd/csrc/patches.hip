@@ -254,18 +254,15 @@ __global__ __launch_bounds__( 256 ) void patchBoundsInitKernel( uint32_t P, int3
   patchStat[2 * p] = patchStat[2 * p + 1] = 0;
 }
 
-__global__ __launch_bounds__( 256 ) void ccLabelKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
-                                                         const uint32_t* __restrict__ lab, uint32_t n,
-                                                         uint32_t* __restrict__ label ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u < n ) label[u] = raw[u] ? lab[parent[u]] : kNoLabel;
-}
-
-__global__ __launch_bounds__( 256 ) void ccCountKernel( const uint32_t* __restrict__ label, uint32_t n,
-                                                         uint32_t* __restrict__ ccCount ) {
+// label of every point still raw (the label of its group), and the size of every component (one atomic per run of equal
+// labels in a wavefront)
+__global__ __launch_bounds__( 256 ) void ccLabelCountKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
+                                                              const uint32_t* __restrict__ lab, uint32_t n,
+                                                              uint32_t* __restrict__ label, uint32_t* __restrict__ ccCount ) {
   const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
   const int      lane = threadIdx.x & 63;
-  const uint32_t l    = i < n ? label[i] : kNoLabel;
+  const uint32_t l    = ( i < n && raw[i] ) ? lab[parent[i]] : kNoLabel;
+  if ( i < n ) label[i] = l;
   unsigned long long todo = __ballot( l != kNoLabel );
   while ( todo ) {
     const int                leader = __ffsll( (long long)todo ) - 1;
@@ -655,7 +652,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
 
   DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_lab;
   DevBuf<uint8_t>  d_raw;
-  DevBuf<int32_t>  d_pointPatch, d_patchView, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
+  DevBuf<int32_t>  d_pointPatch, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
   DevBuf<int>      d_offsets;
   DevBuf<PatchDev> d_patches;
   DevBuf<unsigned long long> d_map64;
@@ -705,8 +702,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
         hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
                             d_parent.p, n, d_lab.p, d_small.p, ++relaxToken );
       ctx->stageEnd( kt );
-      hipLaunchKernelGGL( ccLabelKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p );
-      hipLaunchKernelGGL( ccCountKernel, grdN, blk, 0, s, d_label.p, n, d_ccCount.p );
+      hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p, d_ccCount.p );
       hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
                           uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );
       TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 1 ) );
@@ -722,22 +718,23 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     if ( P == 0 ) break;
     // ---- S8 -----------------------------------------------------------------------------------------
     sid = ctx->stageBegin( "patches_build" );
-    TMC2_TRY( d_patchView.alloc( P ) );
     TMC2_TRY( d_minUv.alloc( 2 * size_t( P ) ) );
-    TMC2_TRY( d_bbox.alloc( 6 * size_t( P ) ) );
-    TMC2_TRY( d_patchStat.alloc( 2 * size_t( P ) ) );
+    TMC2_TRY( d_bbox.alloc( 7 * size_t( P ) ) );           // boxes, then the views: one copy to the host
+    TMC2_TRY( d_patchStat.alloc( 2 * size_t( P ) + 1 ) );  // counters, then the round's count of points still raw: one copy
+    int32_t*  d_view     = d_bbox.p + 6 * size_t( P );
+    uint32_t* d_rawCount = reinterpret_cast<uint32_t*>( d_patchStat.p + 2 * size_t( P ) );
     TMC2_TRY( d_patches.alloc( P ) );
     hipLaunchKernelGGL( ccAssignKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p, d_rank.p, f->d_partition.p,
-                        uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_pointPatch.p, d_patchView.p );
+                        uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_pointPatch.p, d_view );
     hipLaunchKernelGGL( patchBoundsInitKernel, dim3( ( P + 255 ) / 256 ), blk, 0, s, P, d_bbox.p, d_minUv.p, d_patchStat.p,
-                        d_small.p + 2 );
+                        d_rawCount );
     if ( sp->enablePatchSplitting )
-      hipLaunchKernelGGL( patchMinUvKernel, grdN, blk, 0, s, f->d_pts.p, d_pointPatch.p, d_patchView.p, n, d_minUv.p );
-    hipLaunchKernelGGL( patchTrimBboxKernel, grdN, blk, 0, s, f->d_pts.p, d_patchView.p, d_minUv.p,
+      hipLaunchKernelGGL( patchMinUvKernel, grdN, blk, 0, s, f->d_pts.p, d_pointPatch.p, d_view, n, d_minUv.p );
+    hipLaunchKernelGGL( patchTrimBboxKernel, grdN, blk, 0, s, f->d_pts.p, d_view, d_minUv.p,
                         sp->enablePatchSplitting, sp->maxPatchSize, n, d_pointPatch.p, d_bbox.p );
-    std::vector<int32_t> h_bbox( 6 * size_t( P ) ), h_view( P );
+    std::vector<int32_t> h_bbox( 7 * size_t( P ) );
     TMC2_HIP( hipMemcpyAsync( h_bbox.data(), d_bbox.p, h_bbox.size() * 4, hipMemcpyDeviceToHost, s ) );
-    TMC2_HIP( hipMemcpyAsync( h_view.data(), d_patchView.p, size_t( P ) * 4, hipMemcpyDeviceToHost, s ) );
+    const int32_t* h_view = h_bbox.data() + 6 * size_t( P );
     TMC2_HIP( hipStreamSynchronize( s ) );
     // patch geometry on the host (P is a few hundred): axes, sizes, depth origin, pool offsets, tile list
     static const int       AX[3][3] = {{0, 2, 1}, {1, 2, 0}, {2, 0, 1}};
@@ -807,13 +804,13 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     hipLaunchKernelGGL( patchResampleTileKernel, dim3( tiles ), blk, 0, s, d_patches.p, d_tilePatch.p, roundDepthBase,
                         occRes, d_d0tmp.p, d_d1tmp.p, bitmapBits, ctx->voxelBitmap.p, f->d_depth0.p, f->d_depth1.p,
                         f->d_occupancy.p, d_patchStat.p );
-    std::vector<int32_t> h_stat( 2 * size_t( P ) );
-    TMC2_HIP( hipMemcpyAsync( h_stat.data(), d_patchStat.p, h_stat.size() * 4, hipMemcpyDeviceToHost, s ) );
+    std::vector<int32_t> h_stat( 2 * size_t( P ) + 1 );  // (copied after the raw-point update below: its count rides along)
     // ---- S9 -----------------------------------------------------------------------------------------
     hipLaunchKernelGGL( rawDistanceKernel, grdN, blk, 0, s, f->d_pts.p, n, ctx->voxelBitmap.p, bitmapBits, d_offsets.p,
-                        int( offsets.size() ), thrSel, d_dist.p, d_raw.p, d_small.p + 2 );
-    TMC2_HIP( hipMemcpyAsync( &rawCount, d_small.p + 2, 4, hipMemcpyDeviceToHost, s ) );
+                        int( offsets.size() ), thrSel, d_dist.p, d_raw.p, d_rawCount );
+    TMC2_HIP( hipMemcpyAsync( h_stat.data(), d_patchStat.p, h_stat.size() * 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    rawCount = uint32_t( h_stat[2 * size_t( P )] );
     ctx->stageEnd( sid );
     for ( uint32_t p = 0; p < P; ++p ) {
       tmc2_patch& T = f->patches[patchBase + p];
