@@ -178,12 +178,59 @@ def cpu_baseline(workload, iterations, gof):
                                    "inside a frame), same stages, %.1f s wall" % (nfr, cores, wall))
     except Exception as e:
         res["all_cores_error"] = repr(e)
+    try:                                                       # the CLI's wall time next to the stage sum
+        res["cli"] = cpu_baseline_cli(frames[0], iterations, dt)
+    except Exception as e:
+        res["cli"] = {"error": repr(e)}
     try:
         fp = cpu_baseline_frame_processes(workload, iterations, dt)
         res["frame_processes_value"], res["frame_processes"], res["frame_processes_sample"] = fp["value"], fp["cores"], fp["sample"]
     except Exception as e:
         res["frame_processes_error"] = repr(e)
     return res
+
+
+CLI_STUB = """#!/bin/sh
+# identity "video codec" behind the reference's HMAPP wrapper (PCCHMAppVideoEncoder.cpp:59-90): reconstruction = input
+for a in "$@"; do case $a in --InputFile=*) IN=${a#*=};; --ReconFile=*) REC=${a#*=};; --BitstreamFile=*) BIN=${a#*=};; esac; done
+cp "$IN" "$REC"; printf '\\000\\000\\000\\001\\100\\001\\014\\001' > "$BIN"
+"""
+
+
+def cpu_baseline_cli(frame, iterations, stage_seconds):
+    """The reference's own command-line encoder (oracle/_ref/PccAppEncoder, built from the unmodified sources) on ONE frame of
+    the workload, whole encode() with an identity "video codec" behind its HMAPP wrapper, one thread: wall time end to end
+    (PLY read, the path, colour conversion, the post-reconstruction tail, bitstream) next to the time of the path's stages
+    alone.  CTC parameters from tests/golden/cli_ctc_args.json (the cfg files of the reference flattened into options: the
+    reference tree does not exist on the GPU box)."""
+    import subprocess
+    import tempfile
+    import tmc2_amd as T
+    app = os.path.join(ROOT, "oracle", "_ref", "PccAppEncoder")
+    if not os.path.exists(app):
+        return {"error": "oracle/_ref/PccAppEncoder not built"}
+    with open(os.path.join(ROOT, "tests", "golden", "cli_ctc_args.json")) as f:
+        args = json.load(f)["args"]
+    with tempfile.TemporaryDirectory() as d:
+        stub = os.path.join(d, "stub.sh")
+        with open(stub, "w") as f:
+            f.write(CLI_STUB)
+        os.chmod(stub, 0o755)
+        T.ply_write(os.path.join(d, "in_0000.ply"), frame[0], frame[1], None, ascii=True)     # (the 8i content ships as ASCII)
+        cmd = [app] + args + ["--uncompressedDataPath=" + os.path.join(d, "in_%04d.ply"), "--startFrameNumber=0", "--frameCount=1",
+                              "--groupOfFramesSize=1", "--iterationCountRefineSegmentation=%d" % iterations,
+                              "--videoEncoderOccupancyCodecId=HMAPP", "--videoEncoderGeometryCodecId=HMAPP",
+                              "--videoEncoderAttributeCodecId=HMAPP", "--videoEncoderOccupancyPath=" + stub,
+                              "--videoEncoderGeometryPath=" + stub, "--videoEncoderAttributePath=" + stub, "--nbThread=1",
+                              "--computeMetrics=0", "--computeChecksum=0", "--compressedStreamPath=" + os.path.join(d, "S.bin")]
+        t = time.time()
+        r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        wall = time.time() - t
+        if r.returncode != 0 or not os.path.exists(os.path.join(d, "S.bin")):
+            return {"error": "PccAppEncoder exited with %d" % r.returncode, "tail": r.stdout.decode(errors="replace")[-300:]}
+    return {"wall_s": round(wall, 2), "path_stages_s": round(stage_seconds, 2), "path_share": round(stage_seconds / wall, 3),
+            "what": "PccAppEncoder (unmodified reference, ENABLE_TBB build, --nbThread=1), 1 frame, whole encode() with an identity "
+                    "video codec: end-to-end wall time; path_stages_s = the same frame through the path's stages alone"}
 
 
 def cpu_baseline_frame_processes(workload, iterations, one_frame_seconds):

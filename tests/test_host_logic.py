@@ -569,6 +569,10 @@ def test_bench_cpu_baseline_leg_reports_one_core_and_all_cores():
         assert res["all_cores_value"] > 0 and res["all_cores"] == bench.physical_cores() and "TBB" in res["all_cores_sample"]
     assert "frame_processes_error" not in res, res
     assert res["frame_processes_value"] > 0 and 1 <= res["frame_processes"] <= 32
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "PccAppEncoder")):
+        # the reference's CLI end to end on one frame, from the flattened CTC options alone (no cfg folder at run time)
+        assert "error" not in res["cli"], res["cli"]
+        assert res["cli"]["wall_s"] > 0 and 0 < res["cli"]["path_share"]
 
 
 def test_reference_tbb_build_gives_the_serial_results(reference):
