@@ -538,9 +538,13 @@ def main():
         out["roofline"]["stream_copy"] = {"error": repr(e)}
     # S23 is reported separately: one frame, D1 + D2 + colour, both directions
     rx, rc, _ = frames[0].get_reconstruction()
+    nrm0 = frames[0].get_normals()
+    enc.ctxs[0].metrics_compute(clouds[0][0], clouds[0][1], rx, rc, nrm0)        # warm (allocations)
+    enc.ctxs[0].stage_reset()
     t0 = time.time()
-    enc.ctxs[0].metrics_compute(clouds[0][0], clouds[0][1], rx, rc, frames[0].get_normals())
+    enc.ctxs[0].metrics_compute(clouds[0][0], clouds[0][1], rx, rc, nrm0)
     out["metric_ms_per_frame"] = round(1000.0 * (time.time() - t0), 1)
+    out["metric_stage_ms"] = {k: round(v, 3) for k, v in sorted(enc.ctxs[0].stage_ms().items()) if v > 0}
     # the post-reconstruction tail is outside the metric as well: one frame with the GPU to
     # itself (stage times), then the whole GOF through the worker threads
     if world == 1 and a.tail:

@@ -281,23 +281,34 @@ __global__ __launch_bounds__( 256 ) void distortionTermsKernel( const Pt* __rest
 
 // ---- the sums over the points ---------------------------------------------------------------------------------------------
 // terms[a][0] (squared distances: integers) are summed as 64-bit integers by everybody; terms[a][1 .. 4] (D2 and the three
-// colour errors) in the reference's order, a = 0, 1, 2, ...: lanes 0 .. 3 of the first wave add one column each from LDS,
-// chunk by chunk, while the other waves fetch the next chunk.  out[0 .. 4] = the five sums as doubles.
-constexpr int kSumChunk = 1024;
-__global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __restrict__ terms, uint32_t n, double* __restrict__ out ) {
-  __shared__ double             buf[2][kSumChunk * 4];
-  __shared__ unsigned long long d1Total;
-  if ( threadIdx.x == 0 ) d1Total = 0;
-  const uint32_t     chunks = ( n + kSumChunk - 1 ) / kSumChunk;
-  double             acc    = 0.0;  // (lanes 0 .. 3: one ordered sum each)
-  unsigned long long d1     = 0;
-  auto               fetch  = [&]( uint32_t c, int slot ) {
-    const uint32_t a = c * kSumChunk + threadIdx.x;
-    if ( a < n ) {
-      const double* t = terms + 5 * size_t( a );
-      d1 += (unsigned long long)t[0];
+// colour errors) in the reference's order, a = 0, 1, 2, ...  Both directions of the metric in one launch: eight ordered sums,
+// one per lane 0 .. 7 of the first wave (a dependent fp64 add costs a wave the same whether one lane or eight take part),
+// column-major in LDS so that a lane fetches two consecutive terms per load, chunk by chunk while the other waves fetch the
+// next chunk.  out[0 .. 4] = the five sums of direction A as doubles, out[5 .. 9] = of direction B.
+constexpr int kSumChunk = 1024, kSumStride = kSumChunk + 2;  // (columns 16 bytes apart in the LDS banks: the eight lanes read side by side)
+__global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __restrict__ termsA, uint32_t nA,
+                                                              const double* __restrict__ termsB, uint32_t nB,
+                                                              double* __restrict__ out ) {
+  extern __shared__ double buf[];  // [2 slots][8 columns][kSumStride]
+  __shared__ unsigned long long d1Total[2];
+  if ( threadIdx.x < 2 ) d1Total[threadIdx.x] = 0;
+  const uint32_t     chunks = ( max( nA, nB ) + kSumChunk - 1 ) / kSumChunk;
+  double             acc    = 0.0;  // (lanes 0 .. 7: one ordered sum each)
+  unsigned long long d1A = 0, d1B = 0;
+  auto               fetch = [&]( uint32_t c, int slot ) {
+    const uint32_t a   = c * kSumChunk + threadIdx.x;
+    double*        col = buf + size_t( slot ) * 8 * kSumStride + threadIdx.x;
+    if ( a < nA ) {
+      const double* t = termsA + 5 * size_t( a );
+      d1A += (unsigned long long)t[0];
 #pragma unroll
-      for ( int k = 0; k < 4; ++k ) buf[slot][4 * threadIdx.x + k] = t[1 + k];
+      for ( int k = 0; k < 4; ++k ) col[k * kSumStride] = t[1 + k];
+    }
+    if ( a < nB ) {
+      const double* t = termsB + 5 * size_t( a );
+      d1B += (unsigned long long)t[0];
+#pragma unroll
+      for ( int k = 0; k < 4; ++k ) col[( 4 + k ) * kSumStride] = t[1 + k];
     }
   };
   if ( chunks ) fetch( 0, 0 );
@@ -306,49 +317,54 @@ __global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __res
     const int slot = int( c & 1 );
     if ( threadIdx.x >= 64 ) {
       if ( c + 1 < chunks ) fetch( c + 1, slot ^ 1 );
-    } else if ( threadIdx.x < 4 ) {
-      const uint32_t cnt = min( uint32_t( kSumChunk ), n - c * kSumChunk );
-      for ( uint32_t j = 0; j < cnt; ++j ) acc += buf[slot][4 * j + threadIdx.x];
+    } else if ( threadIdx.x < 8 ) {
+      const uint32_t n     = threadIdx.x < 4 ? nA : nB, first = c * kSumChunk;
+      const uint32_t cnt   = first < n ? min( uint32_t( kSumChunk ), n - first ) : 0u;
+      const double*  col   = buf + ( size_t( slot ) * 8 + threadIdx.x ) * kSumStride;
+      const double2* pairs = reinterpret_cast<const double2*>( col );
+      uint32_t       j     = 0;
+      for ( ; j + 8 <= cnt; j += 8 ) {  // the loads ahead of the (dependent) adds
+        const double2 a = pairs[j / 2], b = pairs[j / 2 + 1], d = pairs[j / 2 + 2], e = pairs[j / 2 + 3];
+        acc += a.x, acc += a.y, acc += b.x, acc += b.y, acc += d.x, acc += d.y, acc += e.x, acc += e.y;
+      }
+      for ( ; j < cnt; ++j ) acc += col[j];
     }
     __syncthreads();
     if ( threadIdx.x < 64 && c + 1 < chunks ) fetch( c + 1, slot ^ 1 );  // (the first wave's share of the next chunk)
     __syncthreads();
   }
-  atomicAdd( &d1Total, d1 );
+  atomicAdd( &d1Total[0], d1A );
+  atomicAdd( &d1Total[1], d1B );
   __syncthreads();
-  if ( threadIdx.x == 0 ) out[0] = double( d1Total );
-  if ( threadIdx.x < 4 ) out[1 + threadIdx.x] = acc;
+  if ( threadIdx.x < 2 ) out[5 * threadIdx.x] = double( d1Total[threadIdx.x] );
+  if ( threadIdx.x < 8 ) out[5 * ( threadIdx.x / 4 ) + 1 + ( threadIdx.x & 3 )] = acc;
 }
 
 double psnr( double dist, double p, double factor ) { return 10 * std::log10( ( factor * p * p ) / dist ); }
 
-int quality( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, double resolution, double* out,
-             uint32_t* d_error ) {
-  hipStream_t      s = ctx->stream;
+// per-point terms of one direction (A's points against their nearest neighbours in B)
+int qualityTerms( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, DevBuf<double>& d_terms, uint32_t* d_error ) {
+  hipStream_t      s  = ctx->stream;
   const uint32_t   nA = uint32_t( A.n );
   DevBuf<uint32_t> d_idx, d_dist;
-  DevBuf<double>   d_terms, d_sums;
   TMC2_TRY( d_idx.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_dist.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_terms.alloc( size_t( nA ) * 5 ) );
-  TMC2_TRY( d_sums.alloc( 8 ) );
   TMC2_TRY( launchKnnTree( ctx, B.devFor( A ), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
   const int sid = ctx->stageBegin( "metrics_terms" );
   hipLaunchKernelGGL( distortionTermsKernel, dim3( ( nA + 255 ) / 256 ), dim3( 256 ), 0, s, A.pts.p, A.rgb4.p, B.pts.p, B.rgb4.p,
                       withNormals ? B.nrm.p : (const double*)nullptr, d_idx.p, d_dist.p, nA, d_terms.p, d_error );
-  hipLaunchKernelGGL( orderedSumsKernel, dim3( 1 ), dim3( 1024 ), 0, s, d_terms.p, nA, d_sums.p );
   ctx->stageEnd( sid );
-  double sse[5] = {0, 0, 0, 0, 0};
-  TMC2_HIP( hipMemcpyAsync( sse, d_sums.p, sizeof( sse ), hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
-  const double num = double( nA );
-  out[0]           = sse[0] / num;
-  out[1]           = psnr( out[0], resolution, 3 );
-  out[2]           = withNormals ? sse[1] / num : 0.0;
-  out[3]           = withNormals ? psnr( out[2], resolution, 3 ) : 0.0;
+  return TMC2_OK;
+}
+
+void qualityFromSums( const double* sse, double num, bool withNormals, double resolution, double* out ) {
+  out[0] = sse[0] / num;
+  out[1] = psnr( out[0], resolution, 3 );
+  out[2] = withNormals ? sse[1] / num : 0.0;
+  out[3] = withNormals ? psnr( out[2], resolution, 3 ) : 0.0;
   for ( int i = 0; i < 3; ++i ) out[4 + i] = sse[2 + i] / num;
   out[7] = psnr( out[4], 1.0, 1.0 );
-  return TMC2_OK;
 }
 
 }  // namespace
@@ -459,8 +475,23 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
       TMC2_HIP( hipStreamSynchronize( s ) );
     }
   }
-  TMC2_TRY( quality( ctx, dS, dR, withNormals, resolution, out, d_error.p ) );
-  TMC2_TRY( quality( ctx, dR, dS, withNormals, resolution, out + 8, d_error.p ) );
+  {
+    DevBuf<double> d_termsS, d_termsR, d_sums;
+    TMC2_TRY( d_sums.alloc( 16 ) );
+    TMC2_TRY( qualityTerms( ctx, dS, dR, withNormals, d_termsS, d_error.p ) );
+    TMC2_TRY( qualityTerms( ctx, dR, dS, withNormals, d_termsR, d_error.p ) );
+    const int    sid = ctx->stageBegin( "metrics_sums" );
+    const size_t lds = size_t( 2 ) * 8 * kSumStride * sizeof( double );
+    TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( orderedSumsKernel ), lds, ctx->device ) );
+    hipLaunchKernelGGL( orderedSumsKernel, dim3( 1 ), dim3( 1024 ), lds, s, d_termsS.p, uint32_t( dS.n ), d_termsR.p, uint32_t( dR.n ),
+                        d_sums.p );
+    ctx->stageEnd( sid );
+    double sse[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TMC2_HIP( hipMemcpyAsync( sse, d_sums.p, sizeof( sse ), hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    qualityFromSums( sse, double( dS.n ), withNormals, resolution, out );
+    qualityFromSums( sse + 5, double( dR.n ), withNormals, resolution, out + 8 );
+  }
   for ( int i = 0; i < 8; ++i ) {
     const bool isPsnr = ( i == 1 || i == 3 || i == 7 );
     out[16 + i]       = isPsnr ? std::min( out[i], out[8 + i] ) : std::max( out[i], out[8 + i] );
