@@ -12,6 +12,7 @@ db() { find "$1" -name "*_results.db" | head -1; }
 # 1. kernel trace, one frame in flight
 rm -rf $OUT/prof_solo; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_solo -- $SOLO > $OUT/${TAG}_prof_solo.log 2>&1
 python $REPO/profiles/summarise_rocpd.py "$(db $OUT/prof_solo)" "$SOLO  (one frame in flight)" > $OUT/${TAG}_kernel_stats_one_frame.txt
+python $REPO/profiles/occupancy_rocpd.py "$(db $OUT/prof_solo)" 3 > $OUT/${TAG}_occupancy_one_frame.txt
 # 2. kernel trace, the default bench (16 frames in flight)
 rm -rf $OUT/prof_full; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_full -- $FULL > $OUT/${TAG}_prof_full.log 2>&1
 python $REPO/profiles/summarise_rocpd.py "$(db $OUT/prof_full)" "$FULL  (32-frame GOF, 16 frames in flight)" > $OUT/${TAG}_kernel_stats_default_bench.txt

@@ -1,4 +1,7 @@
 cd /root/repo
-export TMPDIR=/tmp
-(time timeout -s ABRT 300 python -X faulthandler -m pytest tests/test_gpu_metrics.py tests/test_gpu_images.py -m gpu -q -x --timeout 200 -k "metric" 2>&1 | tail -6) > gpurun_out/r02_pytest25.log 2>&1
-timeout 300 python bench.py --steps 2 --warmup 1 --cpu-baseline 0 --tail 0 --ingest 0 > gpurun_out/r02_metric2.json 2> gpurun_out/r02_metric2.err
+REPO=$(pwd); OUT=$REPO/gpurun_out; export TMPDIR=/tmp
+SOLO="python $REPO/bench.py --steps 2 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 --ingest 0"
+cd /tmp
+rm -rf $OUT/prof_solo; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_solo -- $SOLO > $OUT/r02_prof_solo.log 2>&1
+python $REPO/profiles/occupancy_rocpd.py "$(find $OUT/prof_solo -name '*_results.db' | head -1)" 3 > $OUT/r02_occupancy_one_frame.txt
+rm -rf $OUT/prof_solo
