@@ -21,5 +21,5 @@ python $REPO/profiles/concurrency_rocpd.py "$(db $OUT/prof_full)" 0.3 > $OUT/${T
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_$c; timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $SOLO > $OUT/${TAG}_pmc_$c.log 2>&1
 done
-python $REPO/profiles/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE "longdress_vox10-like, one frame" > $OUT/${TAG}_pmc_traffic.json
+python $REPO/profiles/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE "longdress_vox10" > $OUT/${TAG}_pmc_traffic.json
 rm -rf $OUT/prof_solo $OUT/prof_full $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE   # (only the summaries travel back)

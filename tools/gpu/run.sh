@@ -1,7 +1,5 @@
 cd /root/repo
-REPO=$(pwd); OUT=$REPO/gpurun_out; export TMPDIR=/tmp
-SOLO="python $REPO/bench.py --steps 2 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 --ingest 0"
-cd /tmp
-rm -rf $OUT/prof_solo; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_solo -- $SOLO > $OUT/r02_prof_solo.log 2>&1
-python $REPO/profiles/occupancy_rocpd.py "$(find $OUT/prof_solo -name '*_results.db' | head -1)" 3 > $OUT/r02_occupancy_one_frame.txt
-rm -rf $OUT/prof_solo
+export TMPDIR=/tmp
+(time timeout -s ABRT 600 python -X faulthandler -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -8) > gpurun_out/r02_pytest_final.log 2>&1
+(time timeout 900 python bench.py > gpurun_out/bench_r02_final.json 2> gpurun_out/bench_r02_final.err) > gpurun_out/bench_r02_final.time 2>&1
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r02_smoke.log 2>&1
