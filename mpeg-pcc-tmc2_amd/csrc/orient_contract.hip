@@ -79,15 +79,24 @@ __global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __rest
 }
 
 // root of x and the parity of x relative to it; halves the path on the way
+// (the climb reads through the XCD's L2 -- workgroup-scope loads, a view possibly behind the other XCDs': a link read there is
+// still a link of the forest with its parity -- and only "is this a root" goes to the coherent level, climbing on if it is not)
 __device__ __forceinline__ uint32_t parityFind( uint32_t* word, uint32_t x, uint32_t& parity ) {
   uint32_t acc = 0;
+  for ( ;; ) {
+    const uint32_t w = __hip_atomic_load( &word[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    const uint32_t p = w >> 1;
+    if ( p == x ) break;
+    const uint32_t wp = __hip_atomic_load( &word[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    const uint32_t gp = wp >> 1;
+    if ( gp != p ) __hip_atomic_store( &word[x], ( gp << 1 ) | ( ( w ^ wp ) & 1u ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    acc ^= w & 1u;
+    x = p;
+  }
   for ( ;; ) {
     const uint32_t w = __hip_atomic_load( &word[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     const uint32_t p = w >> 1;
     if ( p == x ) break;
-    const uint32_t wp = __hip_atomic_load( &word[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-    const uint32_t gp = wp >> 1;
-    if ( gp != p ) __hip_atomic_store( &word[x], ( gp << 1 ) | ( ( w ^ wp ) & 1u ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     acc ^= w & 1u;
     x = p;
   }

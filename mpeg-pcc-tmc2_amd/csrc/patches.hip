@@ -141,15 +141,22 @@ __global__ __launch_bounds__( 256 ) void ccInitKernel( const uint32_t* __restric
 
 // a parent always has a smaller priority than its child, so the forest stays acyclic and a stale read during find
 // is still an ancestor-or-self of the truth
+// The climb reads through the XCD's L2 (workgroup-scope loads: the view of this XCD, possibly behind the other seven -- still
+// ancestors); only the last step, "is this really a root", goes to the coherent level and climbs on from there if it is not.
+// An agent-scope load per hop is a trip past the L2 for every link of every path.
 __device__ __forceinline__ uint32_t ufFind( uint32_t* parent, uint32_t x ) {
-  uint32_t p = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  uint32_t p = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
   while ( p != x ) {
-    const uint32_t g = __hip_atomic_load( &parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    const uint32_t g = __hip_atomic_load( &parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
     if ( g != p ) __hip_atomic_store( &parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );  // path halving
     x = p;
     p = g;
   }
-  return x;
+  for ( ;; ) {
+    const uint32_t q = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( q == x ) return x;
+    x = q;
+  }
 }
 
 template <int K>

@@ -167,24 +167,43 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   const Pt       c       = centre[v];
   const int      gridMax = 1 << g.gridShift;  // cell coordinates run 0..gridMax inclusive
   int            hits    = 0;
-  for ( int base = 0; base < nOffsets; base += 64 ) {
-    const int o   = base + lane;
-    uint32_t  key = 0xFFFFFFFFu;
-    if ( o < nOffsets ) {
-      const int packed = offsets[o];
-      const int dx = ( packed & 0xFF ) - 128, dy = ( ( packed >> 8 ) & 0xFF ) - 128, dz = ( ( packed >> 16 ) & 0xFF ) - 128;
-      const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
-      if ( x >= 0 && y >= 0 && z >= 0 && x <= gridMax && y <= gridMax && z <= gridMax ) {
-        const uint32_t u = table[cellKey( x, y, z, g.gridShift )];
-        if ( u != 0xFFFFFFFFu ) {
-          const Pt cu = centre[u];  // aliased keys: accept only the voxel whose centre really sits here
-          if ( cu.x == x && cu.y == y && cu.z == z ) key = ( uint32_t( dx * dx + dy * dy + dz * dz ) << idBits ) | u;
+  // The ball's cells in batches of kBatch x 64: all table look-ups of a batch are issued before the first one is needed, then
+  // all centre look-ups of its hits (two dependent round trips per batch instead of two per 64 cells: the kernel is bound by
+  // exactly this latency).  The order of the hits does not matter: they are sorted below.
+  constexpr int kBatch = 8;
+  for ( int base = 0; base < nOffsets; base += 64 * kBatch ) {
+    uint32_t u[kBatch], d2[kBatch], cell[kBatch];
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k ) {
+      const int o = base + 64 * k + lane;
+      u[k]        = 0xFFFFFFFFu;
+      d2[k] = cell[k] = 0;
+      if ( o < nOffsets ) {
+        const int packed = offsets[o];
+        const int dx = ( packed & 0xFF ) - 128, dy = ( ( packed >> 8 ) & 0xFF ) - 128, dz = ( ( packed >> 16 ) & 0xFF ) - 128;
+        const int x = c.x + dx, y = c.y + dy, z = c.z + dz;
+        if ( x >= 0 && y >= 0 && z >= 0 && x <= gridMax && y <= gridMax && z <= gridMax ) {
+          u[k]    = table[cellKey( x, y, z, g.gridShift )];
+          d2[k]   = uint32_t( dx * dx + dy * dy + dz * dz );
+          cell[k] = uint32_t( x ) | ( uint32_t( y ) << 10 ) | ( uint32_t( z ) << 20 );  // (cell coordinates are at most 512)
         }
       }
     }
-    const unsigned long long m = __ballot( key != 0xFFFFFFFFu );
-    if ( key != 0xFFFFFFFFu ) keys[hits + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = key;
-    hits += __popcll( m );
+    uint32_t key[kBatch];
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k ) {
+      key[k] = 0xFFFFFFFFu;
+      if ( u[k] != 0xFFFFFFFFu ) {
+        const Pt cu = centre[u[k]];  // aliased keys: accept only the voxel whose centre really sits here
+        if ( ( uint32_t( cu.x ) | ( uint32_t( cu.y ) << 10 ) | ( uint32_t( cu.z ) << 20 ) ) == cell[k] ) key[k] = ( d2[k] << idBits ) | u[k];
+      }
+    }
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k ) {
+      const unsigned long long m = __ballot( key[k] != 0xFFFFFFFFu );
+      if ( key[k] != 0xFFFFFFFFu ) keys[hits + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = key[k];
+      hits += __popcll( m );
+    }
   }
   // pad to a power of two and sort ascending (wave-private LDS: no barrier needed beyond wave lockstep,
   // but LDS visibility between lanes needs the s_waitcnt the compiler inserts for __syncthreads-free code:
