@@ -47,10 +47,10 @@ __device__ __forceinline__ int coordOf( const Pt p, int axis ) { return axis == 
 // A body-sized patch still receives one report per wave (thousands per address): look before the atomic -- the running
 // value is monotone, so a stale read can only cause a redundant atomic, never a missed one.
 __device__ __forceinline__ void lazyAtomicMin( int32_t* a, int v ) {
-  if ( v < __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( a, v );
+  if ( v < __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMin( a, v );
 }
 __device__ __forceinline__ void lazyAtomicMax( int32_t* a, int v ) {
-  if ( v > __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( a, v );
+  if ( v > __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMax( a, v );
 }
 __device__ __forceinline__ int waveMinMasked( int v, bool mine ) {
   v = mine ? v : 0x7FFFFFFF;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __r
     const uint32_t           key    = __shfl( r, leader, 64 );
     const unsigned long long same   = __ballot( seed && r == key );
     // lanes are in index order, so the leader (lowest lane of its group) holds the group's smallest index in the wave
-    if ( lane == leader && __hip_atomic_load( &lab[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) > u )
+    if ( lane == leader && __hip_atomic_load( &lab[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) > u )
       atomicMin( &lab[key], u );
     todo &= ~same;
   }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restri
   uint32_t m = ~uint32_t( mutual[u] ) & ( ( 1u << K ) - 1u );
   if ( !m ) return;
   const uint32_t ru = parent[u];
-  const uint32_t lu = __hip_atomic_load( &lab[ru], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  const uint32_t lu = __hip_atomic_load( &lab[ru], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
   if ( lu == kNoLabel ) return;
   const uint8_t   pu  = partition[u];
   const uint32_t* row = knn + size_t( u ) * K;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restri
     const uint32_t v = row[j];
     if ( v == u || !raw[v] || partition[v] != pu ) continue;
     const uint32_t rv = parent[v];
-    if ( rv != ru && __hip_atomic_load( &lab[rv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) > lu &&
+    if ( rv != ru && __hip_atomic_load( &lab[rv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) > lu &&
          atomicMin( &lab[rv], lu ) > lu )
       any = true;
   }
