@@ -205,6 +205,46 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       hits += __popcll( m );
     }
   }
+  // Only the head of the sorted list is ever used: the row ends where the running member count reaches maxNN.  The squared
+  // distance takes few values, so the cut is found BEFORE sorting -- member totals per distance (LDS atomics into the unused
+  // tail of the key array), a wave scan over them -- and the hits beyond the distance the cut falls in are dropped: the
+  // sort below handles ~ 100-150 keys instead of the 300-400 voxels of the whole ball.
+  {
+    uint32_t* bins = keys + CAP - 160;  // (the host checks that the ball leaves this room)
+    for ( int b = lane; b < 128; b += 64 ) bins[b] = 0;
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    for ( int i = lane; i < hits; i += 64 ) {
+      const uint32_t key = keys[i];
+      atomicAdd( &bins[min( key >> idBits, 127u )], count[key & idMask] & 0xFFu );
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    const uint32_t b0 = bins[2 * lane], b1 = bins[2 * lane + 1];
+    uint32_t       inc = b0 + b1;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += t;
+    }
+    const uint32_t           before  = inc - ( b0 + b1 );
+    const unsigned long long reached = __ballot( inc >= uint32_t( maxNN ) );
+    uint32_t                 cutoff  = 127;  // (fewer members than maxNN in the whole ball: everything stays)
+    if ( reached ) {
+      const int first = __ffsll( (long long)reached ) - 1;
+      cutoff          = 2u * uint32_t( first ) + ( __shfl( before + b0, first, 64 ) >= uint32_t( maxNN ) ? 0u : 1u );
+    }
+    int kept = 0;
+    for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
+      const int      i    = base + lane;
+      const uint32_t key  = i < hits ? keys[i] : 0xFFFFFFFFu;
+      const bool     stay = i < hits && ( key >> idBits ) <= cutoff;
+      const unsigned long long m = __ballot( stay );
+      __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+      if ( stay ) keys[kept + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = key;
+      kept += __popcll( m );
+    }
+    hits = kept;
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  }
   // pad to a power of two and sort ascending (wave-private LDS: no barrier needed beyond wave lockstep,
   // but LDS visibility between lanes needs the s_waitcnt the compiler inserts for __syncthreads-free code:
   // use __builtin_amdgcn_wave_barrier to keep the order of LDS operations)
@@ -1007,7 +1047,7 @@ void RefineJob::launchNeighbourhood() {
                       d_count.p, table, g, V, d_offsets.p, int( ball ), maxNNCount, lambda, idBits, devRange, devStride,       \
                       uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
                       d_small.p + 2 )
-  if ( ball <= 2048 )
+  if ( ball <= 2048 - 160 )
     TMC2_NEIGHBOURHOOD( 2048, 4 );
   else
     TMC2_NEIGHBOURHOOD( 4096, 2 );
@@ -1048,7 +1088,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
           if ( dx * dx + dy * dy + dz * dz < r2 )
             offsets.push_back( ( dx + 128 ) | ( ( dy + 128 ) << 8 ) | ( ( dz + 128 ) << 16 ) );
   }
-  if ( offsets.size() > 4096 || r2 > 128 ) {  // (search radius 192: r2 = 48 with voxels of 4, 96 with voxels of 2 -> 3 911 cells)
+  if ( offsets.size() > 4096 - 160 || r2 > 128 ) {  // (the neighbourhood kernel keeps 160 words of its 2048 / 4096 for its own use)  // (search radius 192: r2 = 48 with voxels of 4, 96 with voxels of 2 -> 3 911 cells)
     setError( "refineSegmentationGridBased: search radius %d too large for the LDS neighbourhood tile", searchRadius );
     return TMC2_E_UNSUPPORTED;
   }
