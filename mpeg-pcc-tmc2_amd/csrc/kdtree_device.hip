@@ -727,8 +727,12 @@ __device__ __forceinline__ NodeSplit waveSplitNode( Pt* pts, uint32_t* id, uint3
 }
 
 // nanoflann's divideTree on P[b..e) by ONE lane (literal two-pass planeSplit with std::swap semantics), explicit stack.
+// Node ids come from the one global counter in chunks of kLaneIdChunk (an atomic per node on a single address, ~ 10 ns each,
+// ~ 130 K per tree, was most of the finishing kernel); what is left of the last chunk stays unused (host: maxNode).
+constexpr uint32_t kLaneIdChunk = 16;
 __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t globalBegin, KdNode* __restrict__ nodes,
                              uint32_t* __restrict__ nodeCount, uint32_t& maxDepth, uint32_t* __restrict__ refuse ) {
+  uint32_t idNext = 0, idEnd = 0;
   SubNode stack[kLaneMax + 8];  // a node of at most kLaneMax points is at most kLaneMax - kLeafMax levels deep
   int     sp  = 0;
   stack[sp++] = root;
@@ -781,7 +785,12 @@ __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t
     int32_t        lmax = int32_t( 0x80000000 ), rmin = 0x7FFFFFFF;  // tight ranges of the children on the cut dimension
     for ( uint32_t i = 0; i < idx; ++i ) lmax = max( lmax, coordOf( pts[i], r.dim ) );
     for ( uint32_t i = idx; i < count; ++i ) rmin = min( rmin, coordOf( pts[i], r.dim ) );
-    const uint32_t id0 = atomicAdd( nodeCount, 2u );
+    if ( idNext == idEnd ) {
+      idNext = atomicAdd( nodeCount, kLaneIdChunk );
+      idEnd  = idNext + kLaneIdChunk;
+    }
+    const uint32_t id0 = idNext;
+    idNext += 2;
     KdNode         nd;
     nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( lmax ), nd.divhigh = int16_t( rmin ), nd.dim = r.dim;
     nodes[q.node] = nd;
@@ -802,7 +811,25 @@ __device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t
 }
 
 constexpr int kFinishWaves = kRetire <= 512 ? 4 : 2;  // (< 64 KB of LDS per workgroup: several workgroups per CU)
-
+// (node ids of the nodes a wavefront splits together: in chunks as well)
+constexpr uint32_t kIdChunk      = 256;
+constexpr uint32_t kFinishBlocks = 1024;  // at most this many workgroups: what the chunks can waste is bounded (host: maxNode)
+struct IdRange {
+  uint32_t next, end;
+};
+__device__ __forceinline__ uint32_t reserveIds( IdRange& r, uint32_t k, uint32_t* __restrict__ nodeCount, int lane ) {  // (wave-uniform)
+  if ( r.next + k > r.end ) {
+    const uint32_t take = max( k, kIdChunk );
+    uint32_t       base = 0;
+    if ( lane == 0 ) base = atomicAdd( nodeCount, take );
+    base   = __shfl( base, 0, 64 );
+    r.next = base;
+    r.end  = base + take;
+  }
+  const uint32_t first = r.next;
+  r.next += k;
+  return first;
+}
 __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( BuildArgs a ) {
   __shared__ Pt       sP[kFinishWaves][kRetire];
   __shared__ uint32_t sPerm[kFinishWaves][kRetire];
@@ -817,6 +844,7 @@ __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( Bui
   SubNode*       stack = sStack[wave];
   SubNode*       small = sSmall[wave];
   uint32_t       maxDepth = 0;
+  IdRange        ids{0, 0};
   for ( uint32_t s = blockIdx.x * kFinishWaves + wave; s < total; s += gridDim.x * kFinishWaves ) {  // (uniform per wave)
     const RetiredSeg seg = a.retired[s];
     const uint32_t   cnt = seg.end - seg.begin;
@@ -888,9 +916,7 @@ __global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( Bui
       const SplitRule r    = ns.rule;
       const uint32_t  idx  = ns.idx;
       const int       lmax = ns.lmax, rmin = ns.rmin;
-      uint32_t id0 = 0;
-      if ( lane == 0 ) id0 = atomicAdd( a.nodeCount, 2u );
-      id0 = __shfl( id0, 0, 64 );
+      const uint32_t id0 = reserveIds( ids, 2u, a.nodeCount, lane );
       if ( lane == 0 ) {
         KdNode nd;
         nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( lmax ), nd.divhigh = int16_t( rmin ), nd.dim = r.dim;
@@ -1036,7 +1062,10 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   hipStream_t    s       = ctx->stream;
   const uint32_t tiles   = ( n + kScanTile - 1 ) / kScanTile;
   const size_t   maxSegs = 2 * ( size_t( n ) / ( kLeafMax + 1 ) + 1 ) + 2;
-  const size_t   maxNode = 2 * size_t( n ) + 2;
+  // 2 n + 2 nodes at most.  The finishing kernel takes ids in chunks: a wavefront leaves at most one chunk of kIdChunk unused;
+  // a lane at most kLaneIdChunk - 2 per node of 11 .. kLaneMax points it builds the subtree of (at most n / 11 of those).
+  const size_t   maxNode = 2 * size_t( n ) + 2 + size_t( kIdChunk ) * kFinishWaves * kFinishBlocks +
+                         ( size_t( n ) / ( kLeafMax + 1 ) + 1 ) * ( kLaneIdChunk - 2 );
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( maxNode ) );
@@ -1116,7 +1145,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   // (its pieces: typically 2 * kSplitMax / kRetire per segment; the finishing kernel strides over whatever the list holds)
   const uint32_t retired = out[kMaxLevels + 3] + big * uint32_t( 2 * kSplitMax / kRetire );
   if ( retired ) {  // the subtrees below the level passes: one wavefront each
-    const uint32_t blocks = std::min<uint32_t>( ( retired + kFinishWaves - 1 ) / kFinishWaves, 64u * uint32_t( ctx->cuCount ) );
+    const uint32_t blocks = std::min<uint32_t>( ( retired + kFinishWaves - 1 ) / kFinishWaves, kFinishBlocks );
     hipLaunchKernelGGL( finishSubtreesKernel, dim3( blocks ), dim3( 64 * kFinishWaves ), 0, s, a );
     TMC2_HIP( hipGetLastError() );
     uint32_t fin = 0;

@@ -162,7 +162,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t      v    = blockIdx.x * WAVES + wave;
   uint32_t*           keys = keysAll[wave];
-  if ( v >= V ) return;  // whole wave exits together (v is wave-uniform); no block-level barrier below
+  if ( v >= V ) {  // whole wave exits together (v is wave-uniform); the barriers below count the waves still running
+    if ( lane == 0 ) keys[CAP - 2] = 0;
+    return;
+  }
   const uint32_t idMask  = ( 1u << idBits ) - 1u;
   const Pt       c       = centre[v];
   const int      gridMax = 1 << g.gridShift;  // cell coordinates run 0..gridMax inclusive
@@ -294,9 +297,18 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       nn      = running;
     }
   }
-  uint32_t rowBase = 0;
-  if ( lane == 0 ) rowBase = atomicAdd( rowCursor, uint32_t( used ) );  // (the final cursor = size of the reverse rows)
-  rowBase        = __shfl( rowBase, 0, 64 );
+  // the row's place in the table: ONE reservation per workgroup (70 K voxels queueing on a single address otherwise); the
+  // bookkeeping words sit in the unused tail of the key arrays (a workgroup's LDS is exactly a fifth of the CU's)
+  if ( lane == 0 ) keys[CAP - 2] = uint32_t( used );
+  __syncthreads();  // (waves of the last workgroup that have no voxel have left: they wrote a zero)
+  if ( threadIdx.x == 0 ) {
+    uint32_t total = 0;
+    for ( int w = 0; w < WAVES; ++w ) total += keysAll[w][CAP - 2];
+    keysAll[0][CAP - 1] = atomicAdd( rowCursor, total );  // (the final cursor = size of the reverse rows)
+  }
+  __syncthreads();
+  uint32_t rowBase = keysAll[0][CAP - 1];
+  for ( int w = 0; w < wave; ++w ) rowBase += keysAll[w][CAP - 2];
   const bool fit = uint64_t( rowBase ) + uint32_t( used ) <= rowCapacity;
   if ( lane == 0 ) {
     rowLen[v] = uint32_t( used );
