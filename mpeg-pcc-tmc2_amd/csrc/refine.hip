@@ -991,7 +991,7 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
         h = make_uint4( h0, h1, h2, 0 );
         if ( sub == 0 ) {
           hist[v] = h;
-          atomicAdd( &flags[2 * iter + 1], moved );  // (feeds the trace hook)
+          if ( flags ) atomicAdd( &flags[2 * iter + 1], moved );  // (only for the trace hook: thousands of atomics on one word otherwise)
         }
       }
     }
@@ -1263,6 +1263,7 @@ int RefineJob::finish() {
     const dim3 grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, size_t( 2 ) * ctx->cuCount ) ) );
     DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure's tail spends its time
     const bool                 wantTiming = getenv( "TMC2_REFINE_TIMING" ) != nullptr;
+    const bool                 wantTrace  = getenv( "TMC2_REFINE_TRACE" ) != nullptr;
     if ( wantTiming ) {
       TMC2_TRY( d_timing.alloc( 8 ) );
       TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64, s ) );
@@ -1279,7 +1280,7 @@ int RefineJob::finish() {
                           gMk, d_work.p, d_work.p + V, wantTiming ? d_timing.p : nullptr );
       hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_work.p, d_work.p + V, recCur, recNxt, d_lastRescore.p,
                           d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge, d_ppi,
-                          reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, d_flags.p, iter );
+                          reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
     }
     ctx->stageEnd( sidSweep );
     TMC2_HIP( hipGetLastError() );
@@ -1294,7 +1295,7 @@ int RefineJob::finish() {
       fprintf( stderr, "refine closure tail, per sweep: load %.1f us, compaction %.1f us, voxels %.1f us, lists %.1f us; %.1f levels, %.0f listed voxels (V = %u)\n",
                t[0] * us, t[1] * us, t[2] * us, t[3] * us, double( t[4] ) / iterationCount, double( t[5] ) / iterationCount, V );
     }
-    if ( getenv( "TMC2_REFINE_TRACE" ) ) {  // test hook: points moved per sweep
+    if ( wantTrace ) {  // test hook: points moved per sweep
       std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
       TMC2_HIP( hipMemcpyAsync( h_flags.data(), d_flags.p, h_flags.size() * 4, hipMemcpyDeviceToHost, s ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
