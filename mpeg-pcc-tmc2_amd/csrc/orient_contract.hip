@@ -166,9 +166,23 @@ __global__ __launch_bounds__( 256 ) void verifyCountKernel( const uint32_t* __re
   }
   const uint32_t cross = ballot16( isCross, lane );  // bit j: edge j leaves the cluster (kept for the scatter pass)
   if ( __ballot( wrong ) && lane == 0 ) *bad = 1u;
+  if ( in && j == 0 ) crossMask[u] = uint16_t( cross );
+  // A smooth body part is ONE cluster of 100 K points: tens of thousands of reports on one counter, ~ 10 ns each, were most of
+  // this kernel.  The 16 points of a workgroup are neighbours in index order and mostly share their cluster: the first of
+  // them with a given root reports for all.
+  __shared__ uint32_t sRoot[16], sCross[16];
+  const int p = threadIdx.x >> 4;
+  if ( j == 0 ) sRoot[p] = in ? ru : 0xFFFFFFFFu, sCross[p] = in ? uint32_t( __popc( cross ) ) : 0u;
+  __syncthreads();
   if ( in && j == 0 ) {
-    crossMask[u] = uint16_t( cross );
-    if ( cross ) atomicAdd( &count[ru], uint32_t( __popc( cross ) ) );
+    bool     first = true;
+    uint32_t total = 0;
+    for ( int q = 0; q < 16; ++q ) {
+      if ( sRoot[q] != ru ) continue;
+      if ( q < p ) first = false;
+      total += sCross[q];
+    }
+    if ( first && total ) atomicAdd( &count[ru], total );
   }
 }
 
@@ -179,12 +193,37 @@ __global__ __launch_bounds__( 256 ) void scatterCrossKernel( const uint32_t* __r
                                                               uint32_t* __restrict__ cursor, OrientCrossEdge* __restrict__ edges ) {
   static_assert( K == 16, "16 lanes per point" );
   const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15;
-  if ( u >= n ) return;  // (uniform over the 16 lanes of a point)
-  const uint32_t m = crossMask[u];
-  if ( !m ) return;
+  const int      j = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const bool     in = u < n;
+  const uint32_t m  = in ? crossMask[u] : 0u;
+  // one reservation per (workgroup, cluster), as the counts were reported (verifyCountKernel): the first point of the
+  // workgroup with a given root reserves for all, the others take their share in index order
+  __shared__ uint32_t sRoot[16], sCross[16], sBase[16];
+  const uint32_t ru = in ? root[u] : 0xFFFFFFFFu;
+  if ( j == 0 ) sRoot[p] = ru, sCross[p] = uint32_t( __popc( m ) );
+  __syncthreads();
+  if ( j == 0 && m ) {
+    bool     first = true;
+    uint32_t total = 0;
+    for ( int q = 0; q < 16; ++q ) {
+      if ( sRoot[q] != ru || !sCross[q] ) continue;
+      if ( q < p ) first = false;
+      total += sCross[q];
+    }
+    if ( first ) sBase[p] = off[ru] + atomicAdd( &cursor[ru], total );
+  }
+  __syncthreads();
+  if ( !m ) return;  // (uniform over the 16 lanes of a point)
   uint32_t at = 0;
-  if ( j == 0 ) at = off[root[u]] + atomicAdd( &cursor[root[u]], uint32_t( __popc( m ) ) );
+  if ( j == 0 ) {
+    int lead = p;
+    for ( int q = 0; q < p; ++q ) {
+      if ( sRoot[q] != ru || !sCross[q] ) continue;
+      if ( lead == p ) lead = q;  // the first point of this root that has cross edges made the reservation
+      at += sCross[q];
+    }
+    at += sBase[lead];
+  }
   at = __shfl( at, ( threadIdx.x & 63 ) & 48, 64 );
   if ( ( m >> j ) & 1u )  // (edges of a point in ascending j, as the sequential scan over the set bits wrote them)
     edges[at + __popc( m & ( ( 1u << j ) - 1u ) )] = OrientCrossEdge{u, knn[size_t( u ) * K + j], edgeDot[size_t( u ) * K + j]};

@@ -1,5 +1,4 @@
 cd /root/repo
 export TMPDIR=/tmp
-(time timeout -s ABRT 600 python -X faulthandler -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -8) > gpurun_out/r02_pytest_final.log 2>&1
-(time timeout 900 python bench.py > gpurun_out/bench_r02_final.json 2> gpurun_out/bench_r02_final.err) > gpurun_out/bench_r02_final.time 2>&1
-bash profiles/collect.sh r02
+(timeout -s ABRT 100 python -X faulthandler -m pytest tests/test_gpu_segmenter.py tests/test_gpu_full_size.py -m gpu -q -x --timeout 60 -k "orient or full_size or segmenter_compute or normals" 2>&1 | tail -5) > gpurun_out/r02_pytest33.log 2>&1
+timeout 60 python bench.py --steps 4 --warmup 1 --cpu-baseline 0 --tail 0 --ingest 0 > gpurun_out/r02_bench33.json 2> gpurun_out/r02_bench33.err
