@@ -290,6 +290,50 @@ def cpu_child(spec, workload, iterations):
 
 
 
+VERIFY_CASE = "longdress_vox10_ai_r3_gof32"   # tests/golden/full_size.npz (make_golden.py full_size): MD5s from the unmodified reference
+
+
+def verify_frames(a, frames, indices, W, H, host_bufs):
+    """After the timed loop, outside the timing: every frame this rank holds, exactly as the LAST timed step left it, against
+    the per-frame MD5 fixture of the unmodified reference (patch list, occupancy map / video, blockToPatch, both geometry
+    layers, reconstructed cloud, its colours, pointToPixel, both attribute layers).  At N = 1 the canvases digested are the
+    ones in the page-locked host buffers -- the bytes the video encoder would read.  Returns (verdict, detail): True / False,
+    or None when the run is not the fixture's configuration (other workload / frame count / iterations / packing)."""
+    import hashlib
+    import numpy as np
+    if not (a.workload == "longdress_vox10" and a.frames == 32 and a.iterations == 50 and a.packing == "all-intra"):
+        return None, "no reference fixture for this configuration"
+    path = os.path.join(ROOT, "tests", "golden", "full_size.npz")
+    try:
+        g = np.load(path)
+        g = {k[len(VERIFY_CASE) + 1:]: g[k] for k in g.files if k.startswith(VERIFY_CASE + "/")}
+    except OSError:
+        g = {}
+    if not g:
+        return None, "fixture %s missing" % VERIFY_CASE
+
+    def md5(x):
+        return hashlib.md5(np.ascontiguousarray(x).tobytes()).hexdigest()
+    if (W, H) != tuple(int(x) for x in g["canvas"]):
+        return False, "canvas %dx%d, reference %s" % (W, H, g["canvas"].tolist())
+    bad = []
+    for slot, (fr, i) in enumerate(zip(frames, indices)):
+        patches = fr.get_patches()[0][fr.get_patch_order()]
+        rx, rc, p2p = fr.get_reconstruction()
+        if host_bufs is not None:
+            img, att = host_bufs[slot]
+        else:
+            img, att = fr.get_geometry_images(), fr.get_attribute_images()
+        if [len(patches), len(rx)] != g["f%d_counts" % i].tolist():
+            bad.append("frame %d: %d patches / %d points, reference %s" % (i, len(patches), len(rx), g["f%d_counts" % i].tolist()))
+            continue
+        flat = np.stack([patches[n] for n in patches.dtype.names if n not in ("depthOffset", "occOffset")], 1).astype(np.int32)
+        got = {"patches": flat, "recon_xyz": rx, "recon_rgb": rc, "point_to_pixel": p2p, "attribute": att}
+        got.update({k: img[k] for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1")})
+        bad += ["frame %d: %s" % (i, k) for k, v in got.items() if md5(v) != str(g["f%d_%s_md5" % (i, k)])]
+    return (not bad), ("%d frames x 10 digests equal the reference's" % len(frames) if not bad else "; ".join(bad[:8]))
+
+
 def host_slots(host_steps, world, frames_per_rank):
     """Concurrent host-resident steps (the orientation walk; host k-d tree builds if selected) of ONE rank: the node's budget
     split over the ranks, but never fewer than the frames a rank has in flight need to make progress side by side
@@ -442,11 +486,21 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    ms, calls = enc.stage_ms(), enc.stage_calls()
+    # parity of what was just timed (outside the timing): every frame of every rank against the reference's MD5s
+    try:
+        verdict, detail = verify_frames(a, frames, my_indices, W, H, host_out(W, H) if world == 1 else None)
+    except Exception as e:
+        verdict, detail = False, "verification failed to run: %r" % (e,)
+    if world > 1:
+        t = torch.tensor([-1 if verdict is None else int(bool(verdict))], dtype=torch.int32, device="cuda:%d" % local)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if verdict is not None or int(t.item()) >= 0:
+            verdict = bool(int(t.item()) > 0) and verdict is not False
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    ms, calls = enc.stage_ms(), enc.stage_calls()
     # The timed region runs 32 frames at once: their launches share the chip and queue behind each other, so a kernel's
     # event-bracketed time in the region says how long it was in flight, not how much of the GPU it needs.  The kernel the
     # roofline is reported for is therefore chosen by its time with the GPU to itself (one frame, outside the timing);
@@ -509,6 +563,7 @@ def main():
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int32/f64", "data": "synthetic",
+        "verified": verdict, "verified_detail": detail,
         "config": {"workload": "%s-like synthetic, %d frames, %d points/frame avg, ctc-common + %s + r3 "
                                "(refine iterations %d, occupancyPrecision 4), canvas %dx%d" %
                                (a.workload, a.frames, n_points // max(1, len(frames)), a.packing, a.iterations, W, H),

@@ -304,6 +304,18 @@ int kdtreePlacement() {
   }
   return v;
 }
+int unionPrecheck() {
+  const char* e = getenv( "TMC2_UF_PRECHECK" );
+  return e ? ( e[0] != '0' ) : 1;
+}
+bool unionAgentScope() {
+  const char* e = getenv( "TMC2_UF_SCOPE" );
+  return e && e[0] == 'a';
+}
+bool unionCheck() {
+  const char* e = getenv( "TMC2_UF_CHECK" );
+  return e && e[0] == '1';
+}
 void setKdtreePlacement( int mode ) { g_kdtreeOnHost.store( mode < 0 || mode > 2 ? 0 : mode, std::memory_order_relaxed ); }
 }  // namespace tmc2
 

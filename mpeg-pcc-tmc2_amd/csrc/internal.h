@@ -124,6 +124,23 @@ struct KdTreeHost {
 };
 
 
+// ---- loads that tolerate a stale value ------------------------------------------------------------------------------
+// Words that only move one way (union-find links: always to a member of the same set of smaller priority; running minima /
+// maxima; relaxed labels) may be read from a view that lags behind the other XCDs': a stale value costs a detour or a
+// redundant atomic, never a wrong answer, as long as the view is no older than the kernel's start (tools/gpu/stale_view.hip
+// measures exactly that on the device; the soak test re-runs the GOF with every such load at agent scope).  Workgroup scope
+// = served by the CU's L1 / the XCD's L2; agent scope = a trip past the L2 on every use (gfx942 / gfx950: the L2s of the
+// XCDs are not coherent with each other, caches are written back / invalidated at kernel boundaries).
+// This is the ONE place the scope is chosen.  agent = true: the formally clean form (TMC2_UF_SCOPE=agent).
+#if defined( __HIP_DEVICE_COMPILE__ ) && !defined( __gfx950__ ) && !defined( __gfx942__ )
+#error "loadStaleOk: the stale-view argument is written for the gfx942 / gfx950 cache hierarchy"
+#endif
+template <typename T>
+__device__ __forceinline__ T loadStaleOk( const T* p, bool agent = false ) {
+  return agent ? __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT )
+               : __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+}
+
 // pointToPixel of a reconstructed point in one word: canvas x, y (15 bits each: canvases up to kMaxCanvasDim pixels a side,
 // enforced where a canvas size enters -- generateGeometryImages, the decoder frame), map layer, "a D1 point follows"
 constexpr int kMaxCanvasDim = 32767;
@@ -371,6 +388,11 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
 int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
+// union passes (S3 contraction, S7 components): answer "same set already?" from the CU's possibly stale view before any
+// find / compare-and-swap (TMC2_UF_PRECHECK=0 switches it off); TMC2_UF_CHECK=1: debug invariants after every union pass
+int  unionPrecheck();
+bool unionCheck();
+bool unionAgentScope();  // TMC2_UF_SCOPE=agent: every load of the union passes at agent scope (the formally clean form)
 int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,
                        DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
 // opt-in to more than 48 KB of dynamic LDS for a kernel (once per device and kernel, serialised)

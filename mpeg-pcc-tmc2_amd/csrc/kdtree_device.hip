@@ -315,9 +315,9 @@ __global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t l
           BuildSeg* q = cur + blockSeg;
           int32_t*  slot = threadIdx.x < 3 ? &q->mn[threadIdx.x] : &q->mx[threadIdx.x - 3];
           if ( threadIdx.x < 3 ) {
-            if ( v < __hip_atomic_load( slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMin( slot, v );
+            if ( v < loadStaleOk( slot ) ) atomicMin( slot, v );
           } else {
-            if ( v > __hip_atomic_load( slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMax( slot, v );
+            if ( v > loadStaleOk( slot ) ) atomicMax( slot, v );
           }
         }
       }
@@ -339,12 +339,12 @@ __global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t l
     if ( s != kNone && ( lane == 0 || ps != s ) ) {
       // near the root thousands of waves report to the same record: look first, most have nothing to add
       BuildSeg* q = cur + s;
-      if ( mnx < __hip_atomic_load( &q->mn[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMin( &q->mn[0], mnx );
-      if ( mny < __hip_atomic_load( &q->mn[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMin( &q->mn[1], mny );
-      if ( mnz < __hip_atomic_load( &q->mn[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMin( &q->mn[2], mnz );
-      if ( mxx > __hip_atomic_load( &q->mx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMax( &q->mx[0], mxx );
-      if ( mxy > __hip_atomic_load( &q->mx[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMax( &q->mx[1], mxy );
-      if ( mxz > __hip_atomic_load( &q->mx[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMax( &q->mx[2], mxz );
+      if ( mnx < loadStaleOk( &q->mn[0] ) ) atomicMin( &q->mn[0], mnx );
+      if ( mny < loadStaleOk( &q->mn[1] ) ) atomicMin( &q->mn[1], mny );
+      if ( mnz < loadStaleOk( &q->mn[2] ) ) atomicMin( &q->mn[2], mnz );
+      if ( mxx > loadStaleOk( &q->mx[0] ) ) atomicMax( &q->mx[0], mxx );
+      if ( mxy > loadStaleOk( &q->mx[1] ) ) atomicMax( &q->mx[1], mxy );
+      if ( mxz > loadStaleOk( &q->mx[2] ) ) atomicMax( &q->mx[2], mxz );
     }
   }
 }

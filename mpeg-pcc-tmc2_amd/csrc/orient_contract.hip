@@ -81,13 +81,13 @@ __global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __rest
 // root of x and the parity of x relative to it; halves the path on the way
 // (the climb reads through the XCD's L2 -- workgroup-scope loads, a view possibly behind the other XCDs': a link read there is
 // still a link of the forest with its parity -- and only "is this a root" goes to the coherent level, climbing on if it is not)
-__device__ __forceinline__ uint32_t parityFind( uint32_t* word, uint32_t x, uint32_t& parity ) {
+__device__ __forceinline__ uint32_t parityFind( uint32_t* word, uint32_t x, uint32_t& parity, bool agent ) {
   uint32_t acc = 0;
   for ( ;; ) {
-    const uint32_t w = __hip_atomic_load( &word[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    const uint32_t w = loadStaleOk( &word[x], agent );
     const uint32_t p = w >> 1;
     if ( p == x ) break;
-    const uint32_t wp = __hip_atomic_load( &word[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    const uint32_t wp = loadStaleOk( &word[p], agent );
     const uint32_t gp = wp >> 1;
     if ( gp != p ) __hip_atomic_store( &word[x], ( gp << 1 ) | ( ( w ^ wp ) & 1u ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     acc ^= w & 1u;
@@ -104,10 +104,33 @@ __device__ __forceinline__ uint32_t parityFind( uint32_t* word, uint32_t x, uint
   return x;
 }
 
+// "Are a and b in one cluster already?" from this CU's possibly stale view, without a store or an atomic (the same walk as
+// ufSameSetStale in patches.hip: the end of larger priority climbs; true is final because every word ever stored links two
+// members of one cluster, false only sends the caller to the coherent loop).  Whether the parities along the two paths agree
+// with the edge is not this walk's business: verifyCountKernel checks every mutual strong edge on the settled forest.
+__device__ __forceinline__ bool paritySameSetStale( const uint32_t* word, uint32_t a, uint32_t b, bool agent ) {
+  uint32_t pa = ufPriority( a ), pb = ufPriority( b );
+  for ( ;; ) {
+    if ( a == b ) return true;
+    if ( pa < pb ) {
+      const uint32_t t = a;
+      a                = b;
+      b                = t;
+      const uint32_t q = pa;
+      pa               = pb;
+      pb               = q;
+    }
+    const uint32_t up = loadStaleOk( &word[a], agent ) >> 1;
+    if ( up == a ) return false;
+    a  = up;
+    pa = ufPriority( a );
+  }
+}
+
 template <int K>
 __global__ __launch_bounds__( 256 ) void parityUnionKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
                                                              const uint16_t* __restrict__ mask, uint32_t n,
-                                                             uint32_t* __restrict__ word ) {
+                                                             uint32_t* __restrict__ word, int precheck, bool agent ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n ) return;
   uint32_t m = mask[u];
@@ -116,10 +139,11 @@ __global__ __launch_bounds__( 256 ) void parityUnionKernel( const uint32_t* __re
     m &= m - 1;
     const uint32_t v = knn[size_t( u ) * K + j];
     if ( v > u ) continue;  // every mutual edge is seen from both ends: the larger one acts
+    if ( precheck && paritySameSetStale( word, u, v, agent ) ) continue;
     const uint32_t s = edgeDot[size_t( u ) * K + j] < 0.0 ? 1u : 0u;  // 1: the two normals must get opposite signs
     for ( ;; ) {
       uint32_t pa, pb;
-      uint32_t a = parityFind( word, u, pa ), b = parityFind( word, v, pb );
+      uint32_t a = parityFind( word, u, pa, agent ), b = parityFind( word, v, pb, agent );
       if ( a == b ) break;  // (whether the parities agree with s is checked afterwards, on the settled forest)
       if ( ufPriority( a ) < ufPriority( b ) ) {
         const uint32_t t = a;
@@ -132,12 +156,43 @@ __global__ __launch_bounds__( 256 ) void parityUnionKernel( const uint32_t* __re
   }
 }
 
+// Debug invariants of the settled forest (TMC2_UF_CHECK=1): links fall in priority; both ends of every mutual strong edge
+// have one root (agent-scope climbs only).  bad[0] = broken links, bad[1] = split edges.
+template <int K>
+__global__ __launch_bounds__( 256 ) void parityCheckKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mask,
+                                                             uint32_t n, uint32_t* word, uint32_t* __restrict__ bad ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u >= n ) return;
+  auto rootOf = [&]( uint32_t x ) {
+    for ( uint32_t hops = 0; hops <= n; ++hops ) {
+      const uint32_t q = __hip_atomic_load( &word[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) >> 1;
+      if ( q == x ) return x;
+      if ( q >= n || ufPriority( q ) >= ufPriority( x ) ) return 0xFFFFFFFFu;
+      x = q;
+    }
+    return 0xFFFFFFFFu;
+  };
+  const uint32_t ru = rootOf( u );
+  if ( ru == 0xFFFFFFFFu ) {
+    atomicAdd( &bad[0], 1u );
+    return;
+  }
+  uint32_t m = mask[u];
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    const uint32_t v = knn[size_t( u ) * K + j];
+    if ( v > u ) continue;
+    if ( rootOf( v ) != ru ) atomicAdd( &bad[1], 1u );
+  }
+}
+
 __global__ __launch_bounds__( 256 ) void flattenKernel( uint32_t n, uint32_t* __restrict__ word, uint32_t* __restrict__ root,
-                                                         uint8_t* __restrict__ parity ) {
+                                                         uint8_t* __restrict__ parity, bool agent ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n ) return;
   uint32_t       p;
-  const uint32_t r = parityFind( word, u, p );
+  const uint32_t r = parityFind( word, u, p, agent );
   root[u]          = r;
   parity[u]        = uint8_t( p );
 }
@@ -299,8 +354,18 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   const dim3 grdN16( ( n + 15 ) / 16 ), grdN16p( ( n + 16 ) / 16 );  // 16 lanes per point (... and one more "point" for count[n])
   hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN16, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );
   hipLaunchKernelGGL( initWordsKernel<16>, grdN16p, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, d_count.p );
-  hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p );
-  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p );
+  hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, unionPrecheck(), unionAgentScope() );
+  if ( unionCheck() ) {  // debug invariants (soak tests): costs a round trip
+    uint32_t bad[2] = {0, 0};
+    hipLaunchKernelGGL( parityCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mask.p, n, d_word.p, d_small.p + 2 );
+    TMC2_HIP( hipMemcpyAsync( bad, d_small.p + 2, 8, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    if ( bad[0] | bad[1] ) {
+      setError( "orientNormals: union-find invariant broken (%u bad links, %u split edges)", bad[0], bad[1] );
+      return TMC2_E_HIP;
+    }
+  }
+  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p, unionAgentScope() );
   DevBuf<uint16_t> d_crossMask;
   TMC2_TRY( d_crossMask.alloc( n ) );
   hipLaunchKernelGGL( verifyCountKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_parity.p, n,

@@ -47,10 +47,10 @@ __device__ __forceinline__ int coordOf( const Pt p, int axis ) { return axis == 
 // A body-sized patch still receives one report per wave (thousands per address): look before the atomic -- the running
 // value is monotone, so a stale read can only cause a redundant atomic, never a missed one.
 __device__ __forceinline__ void lazyAtomicMin( int32_t* a, int v ) {
-  if ( v < __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMin( a, v );
+  if ( v < loadStaleOk( a ) ) atomicMin( a, v );
 }
 __device__ __forceinline__ void lazyAtomicMax( int32_t* a, int v ) {
-  if ( v > __hip_atomic_load( a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) ) atomicMax( a, v );
+  if ( v > loadStaleOk( a ) ) atomicMax( a, v );
 }
 __device__ __forceinline__ int waveMinMasked( int v, bool mine ) {
   v = mine ? v : 0x7FFFFFFF;
@@ -144,10 +144,10 @@ __global__ __launch_bounds__( 256 ) void ccInitKernel( const uint32_t* __restric
 // The climb reads through the XCD's L2 (workgroup-scope loads: the view of this XCD, possibly behind the other seven -- still
 // ancestors); only the last step, "is this really a root", goes to the coherent level and climbs on from there if it is not.
 // An agent-scope load per hop is a trip past the L2 for every link of every path.
-__device__ __forceinline__ uint32_t ufFind( uint32_t* parent, uint32_t x ) {
-  uint32_t p = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+__device__ __forceinline__ uint32_t ufFind( uint32_t* parent, uint32_t x, bool agent ) {
+  uint32_t p = loadStaleOk( &parent[x], agent );
   while ( p != x ) {
-    const uint32_t g = __hip_atomic_load( &parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    const uint32_t g = loadStaleOk( &parent[p], agent );
     if ( g != p ) __hip_atomic_store( &parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );  // path halving
     x = p;
     p = g;
@@ -159,11 +159,36 @@ __device__ __forceinline__ uint32_t ufFind( uint32_t* parent, uint32_t x ) {
   }
 }
 
+// "Are a and b in one set already?" answered from this CU's possibly stale view, without a store or an atomic: the two
+// climbs advance the end of LARGER priority (priorities fall strictly along every link ever written, so the end of smaller
+// priority cannot lie below the other one's path) and meet at a common ancestor if the view has one.  true is final -- every
+// word ever stored in parent[] links two members of one set and sets only grow; false only means "not known here", and the
+// caller goes on to the coherent find / compare-and-swap loop.  Most mutual edges join points that ccInitKernel (or an
+// earlier union) has put into one tree already: they end here, a few L1 / L2 hits each.
+__device__ __forceinline__ bool ufSameSetStale( const uint32_t* parent, uint32_t a, uint32_t b, bool agent ) {
+  uint32_t pa = ufPriority( a ), pb = ufPriority( b );
+  for ( ;; ) {
+    if ( a == b ) return true;
+    if ( pa < pb ) {
+      const uint32_t t = a;
+      a                = b;
+      b                = t;
+      const uint32_t q = pa;
+      pa               = pb;
+      pb               = q;
+    }
+    const uint32_t up = loadStaleOk( &parent[a], agent );
+    if ( up == a ) return false;  // a root of larger priority than b: nothing above it in this view
+    a  = up;
+    pa = ufPriority( a );
+  }
+}
+
 template <int K>
 __global__ __launch_bounds__( 256 ) void ccUnionKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
                                                          const uint8_t* __restrict__ partition,
                                                          const uint8_t* __restrict__ raw, uint32_t n,
-                                                         uint32_t* __restrict__ parent ) {
+                                                         uint32_t* __restrict__ parent, int precheck, bool agent ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n || !raw[u] ) return;
   uint32_t m = mutual[u];
@@ -175,10 +200,11 @@ __global__ __launch_bounds__( 256 ) void ccUnionKernel( const uint32_t* __restri
     m &= m - 1;
     const uint32_t v = row[j];
     if ( v > u || !raw[v] || partition[v] != pu ) continue;  // every mutual edge is seen from both ends: larger one acts
+    if ( precheck && ufSameSetStale( parent, u, v, agent ) ) continue;
     uint32_t a = u, b = v;
     while ( true ) {
-      a = ufFind( parent, a );
-      b = ufFind( parent, b );
+      a = ufFind( parent, a, agent );
+      b = ufFind( parent, b, agent );
       if ( a == b ) break;
       if ( ufPriority( a ) < ufPriority( b ) ) {
         const uint32_t t = a;
@@ -190,15 +216,51 @@ __global__ __launch_bounds__( 256 ) void ccUnionKernel( const uint32_t* __restri
   }
 }
 
+// Debug invariants of the settled forest (TMC2_UF_CHECK=1, the soak tests): every link goes to a raw point of the same plane
+// and of smaller priority; the two ends of every eligible mutual edge have one root.  Climbs at agent scope only (the
+// coherent truth, no stale view involved).  bad[0] = broken links, bad[1] = edges whose ends ended up in different sets.
+template <int K>
+__global__ __launch_bounds__( 256 ) void ccCheckKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
+                                                         const uint8_t* __restrict__ partition, const uint8_t* __restrict__ raw,
+                                                         uint32_t n, uint32_t* parent, uint32_t* __restrict__ bad ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u >= n || !raw[u] ) return;
+  auto rootOf = [&]( uint32_t x ) {
+    for ( uint32_t hops = 0; hops <= n; ++hops ) {
+      const uint32_t q = __hip_atomic_load( &parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( q == x ) return x;
+      if ( q >= n || ufPriority( q ) >= ufPriority( x ) ) return 0xFFFFFFFFu;
+      x = q;
+    }
+    return 0xFFFFFFFFu;
+  };
+  const uint32_t p = __hip_atomic_load( &parent[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  if ( p != u && ( p >= n || !raw[p] || partition[p] != partition[u] || ufPriority( p ) >= ufPriority( u ) ) ) atomicAdd( &bad[0], 1u );
+  const uint32_t ru = rootOf( u );
+  if ( ru == 0xFFFFFFFFu ) {
+    atomicAdd( &bad[0], 1u );
+    return;
+  }
+  uint32_t m = mutual[u];
+  while ( m ) {
+    const int j = __ffs( int( m ) ) - 1;
+    m &= m - 1;
+    const uint32_t v = knn[size_t( u ) * K + j];
+    if ( v > u || !raw[v] || partition[v] != partition[u] ) continue;
+    if ( rootOf( v ) != ru ) atomicAdd( &bad[1], 1u );
+  }
+}
+
 __global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ dist,
                                                                uint32_t thrDetection, uint32_t n,
-                                                               uint32_t* __restrict__ parent, uint32_t* __restrict__ lab ) {
+                                                               uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
+                                                               bool agent ) {
   const uint32_t u    = blockIdx.x * blockDim.x + threadIdx.x;
   const int      lane = threadIdx.x & 63;
   uint32_t       r    = kNoLabel;
   bool           seed = false;
   if ( u < n && raw[u] ) {
-    r = ufFind( parent, u );
+    r = ufFind( parent, u, agent );
     __hip_atomic_store( &parent[u], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     seed = dist[u] > thrDetection;
   }
@@ -209,7 +271,7 @@ __global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __r
     const uint32_t           key    = __shfl( r, leader, 64 );
     const unsigned long long same   = __ballot( seed && r == key );
     // lanes are in index order, so the leader (lowest lane of its group) holds the group's smallest index in the wave
-    if ( lane == leader && __hip_atomic_load( &lab[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) > u )
+    if ( lane == leader && loadStaleOk( &lab[key], agent ) > u )
       atomicMin( &lab[key], u );
     todo &= ~same;
   }
@@ -221,13 +283,13 @@ __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restri
                                                          const uint8_t* __restrict__ partition,
                                                          const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
                                                          uint32_t n, uint32_t* __restrict__ lab, uint32_t* __restrict__ changed,
-                                                         uint32_t token ) {
+                                                         uint32_t token, bool agent ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n || !raw[u] ) return;
   uint32_t m = ~uint32_t( mutual[u] ) & ( ( 1u << K ) - 1u );
   if ( !m ) return;
   const uint32_t ru = parent[u];
-  const uint32_t lu = __hip_atomic_load( &lab[ru], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+  const uint32_t lu = loadStaleOk( &lab[ru], agent );
   if ( lu == kNoLabel ) return;
   const uint8_t   pu  = partition[u];
   const uint32_t* row = knn + size_t( u ) * K;
@@ -238,7 +300,7 @@ __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restri
     const uint32_t v = row[j];
     if ( v == u || !raw[v] || partition[v] != pu ) continue;
     const uint32_t rv = parent[v];
-    if ( rv != ru && __hip_atomic_load( &lab[rv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) > lu &&
+    if ( rv != ru && loadStaleOk( &lab[rv], agent ) > lu &&
          atomicMin( &lab[rv], lu ) > lu )
       any = true;
   }
@@ -687,7 +749,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   uint32_t   rawCount = n, relaxToken = 0;
   int        rounds   = 0;
   TMC2_TRY( ensureMutualMask( f ) );  // usually there already: the orientation (S3) needs the same bits
-  DevBuf<uint16_t>& d_mutual = f->d_mutual;
+  DevBuf<uint16_t>& d_mutual   = f->d_mutual;
+  const bool        agentScope = unionAgentScope();
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );
@@ -696,9 +759,21 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     {
       const int kt = ctx->stageBegin( "k:ccUnion" );
       hipLaunchKernelGGL( ccUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
-                          d_parent.p );
+                          d_parent.p, unionPrecheck(), agentScope );
       ctx->stageEnd( kt );
-      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p );
+      if ( unionCheck() ) {  // debug invariants (soak tests): costs a round trip
+        uint32_t bad[2] = {0, 0};
+        TMC2_HIP( hipMemsetAsync( d_small.p + 8, 0, 8, s ) );
+        hipLaunchKernelGGL( ccCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
+                            d_parent.p, d_small.p + 8 );
+        TMC2_HIP( hipMemcpyAsync( bad, d_small.p + 8, 8, hipMemcpyDeviceToHost, s ) );
+        TMC2_HIP( hipStreamSynchronize( s ) );
+        if ( bad[0] | bad[1] ) {
+          setError( "segmentPatches: union-find invariant broken in round %d (%u bad links, %u split edges)", rounds, bad[0], bad[1] );
+          return TMC2_E_HIP;
+        }
+      }
+      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p, agentScope );
     }
     // a few sweeps, then -- speculatively -- the labelling and the seed count, and ONE round trip for both answers: "did the
     // last sweep of the batch still change a label" (then sweep on and label again) and the number of patches
@@ -707,7 +782,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
       const int kt = ctx->stageBegin( "k:ccRelax" );
       for ( int b = 0; b < 3; ++b )
         hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
-                            d_parent.p, n, d_lab.p, d_small.p, ++relaxToken );
+                            d_parent.p, n, d_lab.p, d_small.p, ++relaxToken, agentScope );
       ctx->stageEnd( kt );
       hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p, d_ccCount.p );
       hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,

@@ -213,6 +213,9 @@ FULL_SIZE_CASES = {
     # config 4: basketball_player_vox11, ctc-random-access, r5
     "basketball_player_vox11_ra_r5": dict(workload="basketball_player_vox11", frames=1, iterations=20, vox_dim=4, bits3d=12,
                                           precision=2, min_w=2560, min_h=1280, pack=2),
+    # config 2 as the bench runs it: the whole 32-frame GOF (the condition bench.py times, 16 frames in flight on the GPU)
+    "longdress_vox10_ai_r3_gof32": dict(workload="longdress_vox10", frames=32, iterations=50, vox_dim=4, bits3d=11, precision=4,
+                                        min_w=1280, min_h=1280, pack=0),
     # the random-access packing chain (spatial consistency + global patch allocation) on the real 1280 canvas
     "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4,
                                        min_w=1280, min_h=1280, pack=2),
