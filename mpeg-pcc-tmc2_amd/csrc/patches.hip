@@ -253,16 +253,20 @@ __global__ __launch_bounds__( 256 ) void ccCheckKernel( const uint32_t* __restri
 
 __global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ dist,
                                                                uint32_t thrDetection, uint32_t n,
-                                                               uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
-                                                               bool agent ) {
+                                                               uint32_t* __restrict__ parent, uint32_t* __restrict__ root,
+                                                               uint32_t* __restrict__ lab, bool agent ) {
   const uint32_t u    = blockIdx.x * blockDim.x + threadIdx.x;
   const int      lane = threadIdx.x & 63;
   uint32_t       r    = kNoLabel;
   bool           seed = false;
   if ( u < n && raw[u] ) {
-    r = ufFind( parent, u, agent );
-    __hip_atomic_store( &parent[u], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-    seed = dist[u] > thrDetection;
+    // The flat view goes to its OWN array.  Writing r into parent[u] raced with the path-halving stores of the finds that
+    // pass through u at the same moment: a halving store issued from a stale view (parent[u] = some ancestor) could land after
+    // this one and leave parent[u] short of the root -- and the kernels below read the array as flat.  Rare while the union
+    // pass had compressed nearly every path, frequent once most edges end in the store-free pre-check.
+    r       = ufFind( parent, u, agent );
+    root[u] = r;
+    seed    = dist[u] > thrDetection;
   }
   // a body-sized group has hundreds of thousands of members: one atomic per wave and group, and only if it can lower
   unsigned long long todo = __ballot( seed );
@@ -277,7 +281,7 @@ __global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __r
   }
 }
 
-// one relaxation sweep over the one-way edges between groups (parent[] is flat here)
+// one relaxation sweep over the one-way edges between groups (parent = the flat roots ccFlattenSeedKernel wrote)
 template <int K>
 __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
                                                          const uint8_t* __restrict__ partition,
@@ -719,7 +723,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   const size_t bitmapWords = ( size_t( 1 ) << ( 3 * bitmapBits ) ) >> 5;
   TMC2_TRY( ctx->voxelBitmap.alloc( bitmapWords ) );
 
-  DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_lab;
+  DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_root, d_lab;
   DevBuf<uint8_t>  d_raw;
   DevBuf<int32_t>  d_pointPatch, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
   DevBuf<int>      d_offsets;
@@ -727,6 +731,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   DevBuf<unsigned long long> d_map64;
   TMC2_TRY( d_label.alloc( n ) );
   TMC2_TRY( d_parent.alloc( n ) );
+  TMC2_TRY( d_root.alloc( n ) );
   TMC2_TRY( d_lab.alloc( n ) );
   TMC2_TRY( d_ccCount.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
@@ -773,7 +778,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
           return TMC2_E_HIP;
         }
       }
-      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_lab.p, agentScope );
+      hipLaunchKernelGGL( ccFlattenSeedKernel, grdN, blk, 0, s, d_raw.p, d_dist.p, thrDet, n, d_parent.p, d_root.p, d_lab.p,
+                          agentScope );
     }
     // a few sweeps, then -- speculatively -- the labelling and the seed count, and ONE round trip for both answers: "did the
     // last sweep of the batch still change a label" (then sweep on and label again) and the number of patches
@@ -782,9 +788,9 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
       const int kt = ctx->stageBegin( "k:ccRelax" );
       for ( int b = 0; b < 3; ++b )
         hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
-                            d_parent.p, n, d_lab.p, d_small.p, ++relaxToken, agentScope );
+                            d_root.p, n, d_lab.p, d_small.p, ++relaxToken, agentScope );
       ctx->stageEnd( kt );
-      hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_parent.p, d_lab.p, n, d_label.p, d_ccCount.p );
+      hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_root.p, d_lab.p, n, d_label.p, d_ccCount.p );
       hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
                           uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );
       TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 1 ) );

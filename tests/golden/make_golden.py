@@ -216,6 +216,10 @@ FULL_SIZE_CASES = {
     # config 2 as the bench runs it: the whole 32-frame GOF (the condition bench.py times, 16 frames in flight on the GPU)
     "longdress_vox10_ai_r3_gof32": dict(workload="longdress_vox10", frames=32, iterations=50, vox_dim=4, bits3d=11, precision=4,
                                         min_w=1280, min_h=1280, pack=0),
+    # config 4 with a real GOF: the global patch allocation (performDataAdaptiveGPAMethod, PCCEncoder.cpp:6821-6971) on the
+    # 2560-wide, occupancyPrecision-2 canvas BASELINE names (one frame alone leaves it degenerate)
+    "basketball_player_vox11_ra_r5_gof4": dict(workload="basketball_player_vox11", frames=4, iterations=20, vox_dim=4, bits3d=12,
+                                               precision=2, min_w=2560, min_h=1280, pack=2),
     # the random-access packing chain (spatial consistency + global patch allocation) on the real 1280 canvas
     "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4,
                                        min_w=1280, min_h=1280, pack=2),

@@ -21,6 +21,7 @@ CASES = {
     "redandblack_vox10_ai_r3": dict(workload="redandblack_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1344, pack=0),
     "soldier_vox10_ai_r3": dict(workload="soldier_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
     "basketball_player_vox11_ra_r5": dict(workload="basketball_player_vox11", frames=1, iterations=20, vox_dim=4, bits3d=12, precision=2, min_w=2560, min_h=1280, pack=2),
+    "basketball_player_vox11_ra_r5_gof4": dict(workload="basketball_player_vox11", frames=4, iterations=20, vox_dim=4, bits3d=12, precision=2, min_w=2560, min_h=1280, pack=2),
     "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=2),
 }
 
