@@ -550,13 +550,33 @@ def main():
     s_ach = dom_bytes / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
     fps = a.frames * a.steps / dt
     b_alg = path_bytes(N, M, V, L, I, A, 4)
-    traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json), if this step is in them
+    # HBM bytes per launch from the PMC passes of profiles/collect.sh (FETCH_SIZE / WRITE_SIZE need their own runs under
+    # rocprofv3, so they cannot be taken here): used only if they were collected from THESE kernel sources -- the file carries
+    # a sha1 over mpeg-pcc-tmc2_amd/csrc, recomputed here; counters of other code are dropped, not quoted
+    traffic, traffic_note = None, "no PMC file"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import glob
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        with open(latest) as f:
             pmc = json.load(f)
-        if dom in pmc.get("stages", {}) and a.workload == pmc.get("workload"):
-            traffic = pmc["stages"][dom]["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+        stamp = None
+        if pmc.get("source_sha1"):
+            import hashlib
+            h = hashlib.sha1()
+            csrc = os.path.join(ROOT, "mpeg-pcc-tmc2_amd", "csrc")
+            for name in sorted(os.listdir(csrc)):
+                if name.endswith((".hip", ".cpp", ".h")):
+                    with open(os.path.join(csrc, name), "rb") as f:
+                        h.update(name.encode() + b"\0" + f.read())
+            stamp = h.hexdigest()
+        if stamp is None or stamp != pmc.get("source_sha1"):
+            traffic_note = "%s is of other kernel sources (sha1 %s, here %s): dropped" % (os.path.basename(latest), str(pmc.get("source_sha1"))[:12], str(stamp)[:12])
+        elif dom in pmc.get("stages", {}) and a.workload == pmc.get("workload"):
+            traffic, traffic_note = pmc["stages"][dom]["hbm_bytes_per_launch"], "%s (same kernel sources, sha1 %s)" % (os.path.basename(latest), stamp[:12])
+        else:
+            traffic_note = "%s has no entry for %s" % (os.path.basename(latest), dom)
+    except (OSError, ValueError, KeyError, IndexError):
         pass
     out = {
         "metric": "encoder patch+image-gen frames/sec, longdress_vox10 32-frame GOF",
@@ -573,7 +593,7 @@ def main():
                              "reported separately (metric_ms_per_frame)",
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "host_step_slots_per_gpu": slots, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+                     "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": round(avg_ms, 4),
                      "launches": launches, "alone_avg_launch_ms": round(s_avg, 4), "alone_achieved": round(s_ach, 2),
                      "alone_frac": round(s_ach / 8000.0, 5),
                      "algorithmic_MB_per_launch": round(dom_bytes / 1e6, 2),
@@ -592,14 +612,52 @@ def main():
     except Exception as e:
         out["roofline"]["stream_copy"] = {"error": repr(e)}
     # S23 is reported separately: one frame, D1 + D2 + colour, both directions
-    rx, rc, _ = frames[0].get_reconstruction()
-    nrm0 = frames[0].get_normals()
-    enc.ctxs[0].metrics_compute(clouds[0][0], clouds[0][1], rx, rc, nrm0)        # warm (allocations)
+    # (tmc2_metrics_compute_frame: source, normals and reconstruction are the frame's resident arrays -- nothing is uploaded)
+    enc.per_frame(frames[:1], lambda fr, i: fr.metrics_compute(0, True))             # warm (allocations)
     enc.ctxs[0].stage_reset()
     t0 = time.time()
-    enc.ctxs[0].metrics_compute(clouds[0][0], clouds[0][1], rx, rc, nrm0)
+    q, qc = enc.per_frame(frames[:1], lambda fr, i: fr.metrics_compute(0, True))[0]
     out["metric_ms_per_frame"] = round(1000.0 * (time.time() - t0), 1)
     out["metric_stage_ms"] = {k: round(v, 3) for k, v in sorted(enc.ctxs[0].stage_ms().items()) if v > 0}
+    out["metric_frame0"] = {"d1_psnr": round(float(q[2, 1]), 4), "d2_psnr": round(float(q[2, 3]), 4), "y_psnr": round(float(q[2, 7]), 4),
+                            "points": [int(qc[0]), int(qc[1])]}
+    try:                                                       # ... and against the reference's doubles where the fixture has them
+        g = np.load(os.path.join(ROOT, "tests", "golden", "full_size.npz"))
+        key = "longdress_vox10_ai_r3/f0_metrics"
+        if a.workload == "longdress_vox10" and a.iterations == 50 and key in g.files:
+            out["metric_frame0"]["equals_reference"] = bool(np.array_equal(q.view(np.uint64), g[key].view(np.uint64)))
+    except OSError:
+        pass
+    # What ONE rank of the 8-GPU run does (the driver's SCALE run is the only real measurement; this is its single-GPU proxy):
+    # 32 / 8 = 4 frames, 4 in flight, the same stages -- the wall time of that step bounds the 8-GPU step from below (the
+    # gather of the finished canvases to rank 0 comes on top), so 32 frames / that time is what the node can reach at most.
+    if world == 1 and len(frames) >= 4:
+        try:
+            sub = frames[:4]
+
+            def rank_step():
+                for fr in sub:
+                    fr.reset()
+                w_, h_ = enc.phase_a(sub, sharder=T.Sharder())
+                enc.phase_b(sub)
+                b4 = host_out(w_, h_)
+                enc.per_frame(sub, lambda fr, i: (fr.get_geometry_images(b4[i][0]), fr.get_attribute_images(b4[i][1])))
+            rank_step()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            reps = 5
+            for _ in range(reps):
+                rank_step()
+            torch.cuda.synchronize()
+            ms4 = 1000.0 * (time.time() - t0) / reps
+            out["per_rank_proxy"] = {"frames": 4, "workers": 4, "ms": round(ms4, 2),
+                                     "predicted_n8_frames_per_s": round(a.frames / (ms4 * 1e-3), 1),
+                                     "predicted_n8_speedup": round(a.frames / (ms4 * 1e-3) / out["value"], 2),
+                                     "what": "one rank's share of the 8-GPU run on this GPU alone: 4 frames, 4 in flight, full path, "
+                                             "canvases to host; upper bound for N = 8 = frames / this time (no gather, no skew)"}
+            step()                                             # (leave the frames as a full step leaves them)
+        except Exception as e:
+            out["per_rank_proxy"] = {"error": repr(e)}
     # the post-reconstruction tail is outside the metric as well: one frame with the GPU to
     # itself (stage times), then the whole GOF through the worker threads
     if world == 1 and a.tail:

@@ -307,6 +307,18 @@ int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* s
                           const uint8_t* recRgb, uint64_t m, const double* srcNormals, double resolution, double* out,
                           int64_t* counts );
 
+/* The same for a frame whose clouds are resident in HBM already (nothing is uploaded): source = the frame's points and colours
+ * (and, with useNormals, its normals: tmc2_normals_compute / tmc2_frame_set_normals); reconstruction = which 0: what
+ * tmc2_encoder_generate_attribute_images left (PCCCodec::generatePointCloud + transferColors), which 1: the finished cloud
+ * of the post-reconstruction tail (tmc2_codec_smooth_point_cloud_postprocess .. tmc2_codec_convert_yuv16_to_rgb8: smoothed positions, final colours) -- what PccAppEncoder / PccAppDecoder hand to
+ * PCCMetrics::compute (PccAppEncoder.cpp, metrics.compute( sources, reconstructs, normals ): PCCMetrics.cpp:324-375).        */
+int tmc2_metrics_compute_frame( tmc2_frame* frame, int which, int useNormals, double resolution, double* out, int64_t* counts );
+/* ... and for a frame that has no source cloud (the decoder side, tmc2_decoder_frame_create: PccAppDecoder reads the uncompressed
+ * frames and their normals from PLY files and calls PCCMetrics::compute on them and the decoded clouds, PccAppDecoder.cpp): the
+ * source comes from the host (as for tmc2_metrics_compute), the reconstruction is the frame's resident one (which: as above).   */
+int tmc2_metrics_compute_frame_source( tmc2_frame* frame, int which, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n,
+                                       const double* srcNormals, double resolution, double* out, int64_t* counts );
+
 /* replaces: PCCMetrics::display / QualityMetrics::print (PCCMetrics.cpp:376-391, 230-279) for one frame: the text the CTC log
  * parsers read, from the numbers of tmc2_metrics_compute (out[3][8], counts[2]), the point counts before duplicate removal
  * and the peak value.  precision: that of the application's std::cout (PccAppEncoder / PccAppMetrics set 9).  text may be

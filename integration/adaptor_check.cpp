@@ -4,9 +4,26 @@
 // reference objects; never part of the product.
 #include <unistd.h>
 
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <list>
+#include <map>
+#include <memory>
+#include <queue>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
 
+#define private public  // (QualityMetrics keeps its numbers private: the check reads them next to the drop-in's)
+#include "PCCMetrics.h"
+#undef private
 #include "tmc2hip_adaptor.h"
 
 using namespace pcc;
@@ -210,5 +227,111 @@ int adaptor_check_segmenter_compute( int device, const int16_t* xyz, const uint8
   tmc2_ctx_destroy( ctx );
   if ( r != TMC2_OK ) return -20 + r;
   return comparePatchLists( ref, got );
+}
+
+// needs an MI355X: tmc2hip::MetricsDropIn in the place of the PCCMetrics object -- setParameters, compute( sources, reconstructs,
+// normals ), display() -- against the reference's own object on the same groups of frames: the 24 numbers of every frame (raw
+// doubles) and the text display() prints, at the precision the applications set.  0 = identical; bit 0: numbers, bit 1: counts,
+// bit 2: text.
+int adaptor_check_metrics( int device, int frames, const int16_t* srcXyz, const uint8_t* srcRgb, const int64_t* n, const int16_t* recXyz,
+                           const uint8_t* recRgb, const int64_t* m, const double* srcNormals, double resolution ) {
+  PCCGroupOfFrames sources, recs, normals;
+  sources.setFrameCount( size_t( frames ) );
+  recs.setFrameCount( size_t( frames ) );
+  if ( srcNormals ) normals.setFrameCount( size_t( frames ) );
+  size_t so = 0, ro = 0;
+  for ( int f = 0; f < frames; ++f ) {
+    makeCloud( sources[size_t( f )], srcXyz + 3 * so, srcRgb + 3 * so, size_t( n[f] ) );
+    makeCloud( recs[size_t( f )], recXyz + 3 * ro, recRgb + 3 * ro, size_t( m[f] ) );
+    if ( srcNormals ) {
+      auto& nc = normals[size_t( f )];
+      makeCloud( nc, srcXyz + 3 * so, srcRgb + 3 * so, size_t( n[f] ) );
+      nc.addNormals();
+      for ( size_t i = 0; i < size_t( n[f] ); ++i )
+        nc.setNormal( i, PCCNormal3D( srcNormals[3 * ( so + i )], srcNormals[3 * ( so + i ) + 1], srcNormals[3 * ( so + i ) + 2] ) );
+    }
+    so += size_t( n[f] ), ro += size_t( m[f] );
+  }
+  PCCMetricsParameters mp;
+  mp.computeMetrics_ = true;
+  mp.resolution_     = size_t( resolution );
+  mp.computeC2p_     = srcNormals != nullptr;
+  auto captured = [&]( auto&& body ) {  // what `body` writes to stdout
+    char path[] = "/tmp/tmc2_adaptor_metrics_XXXXXX";
+    int  fd     = mkstemp( path );
+    fflush( stdout );
+    std::cout.flush();
+    int saved = dup( 1 );
+    dup2( fd, 1 );
+    const auto old = std::cout.precision( std::numeric_limits<float>::max_digits10 );
+    body();
+    std::cout.flush();
+    fflush( stdout );
+    std::cout.precision( old );
+    dup2( saved, 1 );
+    close( saved );
+    std::string text( size_t( lseek( fd, 0, SEEK_END ) ), '\0' );
+    lseek( fd, 0, SEEK_SET );
+    if ( !text.empty() && read( fd, &text[0], text.size() ) != ssize_t( text.size() ) ) text.clear();
+    close( fd );
+    unlink( path );
+    return text;
+  };
+  PCCMetrics ref;
+  ref.setParameters( mp );
+  {
+    Quiet quiet;
+    ref.compute( sources, recs, normals );
+  }
+  const std::string refText = captured( [&] { ref.display(); } );
+  tmc2hip::MetricsDropIn got( device );
+  if ( !got.accepts( mp ) ) return -10;
+  got.setParameters( mp );
+  const int rc = got.compute( sources, recs, normals );
+  if ( rc != TMC2_OK ) return -20 + rc;
+  const std::string gotText = captured( [&] { got.display(); } );
+  int bad = 0;
+  if ( got.results().size() != size_t( frames ) ) return 1 << 20;
+  for ( int f = 0; f < frames; ++f ) {
+    const QualityMetrics* q[3] = {&ref.quality1_[size_t( f )], &ref.quality2_[size_t( f )], &ref.qualityF_[size_t( f )]};
+    for ( int i = 0; i < 3; ++i ) {
+      const double want[8] = {q[i]->c2cMse_,      q[i]->c2cPsnr_,     q[i]->c2pMse_,      q[i]->c2pPsnr_,
+                              q[i]->colorMse_[0], q[i]->colorMse_[1], q[i]->colorMse_[2], q[i]->colorPsnr_[0]};
+      if ( memcmp( want, got.results()[size_t( f )].data() + 8 * i, sizeof( want ) ) != 0 ) bad |= 1;
+    }
+  }
+  if ( refText != gotText ) {
+    bad |= 4;
+    fprintf( stderr, "adaptor_check_metrics: display() differs\n--- reference\n%s--- drop-in\n%s", refText.c_str(), gotText.c_str() );
+  }
+  return bad;
+}
+
+// needs an MI355X: tmc2hip::KdTreeDropIn against PCCKdTree on the same cloud and queries: indices (incl. the order among
+// equidistant neighbours) and squared distances of every result.  Returns the number of queries whose result rows differ.
+int adaptor_check_kdtree( int device, const int16_t* xyz, size_t n, const int16_t* queries, size_t nq, int k ) {
+  PCCPointSet3 cloud;
+  cloud.resize( n );
+  for ( size_t i = 0; i < n; ++i ) cloud[i] = PCCPoint3D( xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] );
+  PCCKdTree             ref( cloud );
+  tmc2hip::KdTreeDropIn got( device );
+  if ( got.init( cloud ) != TMC2_OK ) return -10;
+  std::vector<PCCPoint3D> q( nq );
+  for ( size_t i = 0; i < nq; ++i ) q[i] = PCCPoint3D( queries[3 * i], queries[3 * i + 1], queries[3 * i + 2] );
+  std::vector<PCCNNResult> rows;
+  if ( got.searchBatch( q, size_t( k ), rows ) != TMC2_OK ) return -20;
+  int         bad = 0;
+  PCCNNResult want, one;
+  for ( size_t i = 0; i < nq; ++i ) {
+    ref.search( q[i], size_t( k ), want );
+    bool same = rows[i].size() == want.size();
+    for ( size_t j = 0; same && j < want.size(); ++j ) same = rows[i].indices( j ) == want.indices( j ) && rows[i].dist( j ) == want.dist( j );
+    if ( i < 4 ) {  // and the one-point signature
+      if ( got.search( q[i], size_t( k ), one ) != TMC2_OK ) return -30;
+      for ( size_t j = 0; same && j < want.size(); ++j ) same = one.indices( j ) == want.indices( j ) && one.dist( j ) == want.dist( j );
+    }
+    bad += same ? 0 : 1;
+  }
+  return bad;
 }
 }

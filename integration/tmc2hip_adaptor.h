@@ -103,3 +103,78 @@ class EncoderDropIn {
 bool toParams( const pcc::PCCEncoderParameters& params, tmc2_segmenter_params& out );
 
 }  // namespace tmc2hip
+
+// ---- the remaining seams of SURVEY.md 8(b), as classes with the interface of the object they stand in for -----------------
+#include <array>
+#include <string>
+
+#include "PCCKdTree.h"
+#include "PCCMetrics.h"
+#include "PCCMetricsParameters.h"
+
+namespace tmc2hip {
+
+// Stands in for the PCCMetrics object of PccAppEncoder / PccAppDecoder / PccAppMetrics (the same three calls:
+// setParameters, compute( sources, reconstructs, normals ), display -- PCCMetrics.h:93-101, PCCMetrics.cpp:324-391) for
+// the default PCCMetricsParameters (dropDuplicates 2, neighborsProc 1, no Hausdorff, no reflectance): every frame through
+// tmc2_metrics_compute on the device, the text of display() through tmc2_metrics_display.
+class MetricsDropIn {
+ public:
+  explicit MetricsDropIn( int device );
+  ~MetricsDropIn();
+  MetricsDropIn( const MetricsDropIn& ) = delete;
+  MetricsDropIn& operator=( const MetricsDropIn& ) = delete;
+  bool accepts( const pcc::PCCMetricsParameters& params ) const;  // false: keep the reference's object
+  void setParameters( const pcc::PCCMetricsParameters& params ) { params_ = params; }
+  int  compute( const pcc::PCCGroupOfFrames& sources, const pcc::PCCGroupOfFrames& reconstructs, const pcc::PCCGroupOfFrames& normals );
+  int  display();  // the reference's text, on stdout
+  // per frame: q[3][8] (rows A->B, B->A, symmetric; columns c2cMse, c2cPsnr, c2pMse, c2pPsnr, colorMse Y U V, colorPsnr Y)
+  const std::vector<std::array<double, 24>>& results() const { return q_; }
+
+ private:
+  tmc2_ctx*                            ctx_ = nullptr;
+  pcc::PCCMetricsParameters            params_;
+  std::vector<std::array<double, 24>>  q_;
+  std::vector<std::array<int64_t, 2>>  counts_;
+  std::vector<std::array<uint64_t, 2>> points_;
+  std::vector<bool>                    withC2p_;
+};
+
+// The per-frame finish of PCCDecoder::decode (PCCDecoder.cpp:325-470; the encoder's own reconstruction loop :571-719 is the
+// same code) for the CTC lossy conditions, one tile per frame: occupancy map and blockToPatch from the decoded occupancy
+// video, generatePointCloud, colorPointCloud from the decoded (colour-converted, 16-bit 4:4:4) attribute frames, grid
+// geometry smoothing, transferColors16bitBP onto the moved points, convertYUV16ToRGB8 -- on the device, from the reference's
+// own containers, into `reconstruct` (positions, 16-bit and 8-bit colours, boundary point types).
+class DecoderDropIn {
+ public:
+  explicit DecoderDropIn( int device );
+  ~DecoderDropIn();
+  DecoderDropIn( const DecoderDropIn& ) = delete;
+  DecoderDropIn& operator=( const DecoderDropIn& ) = delete;
+  int reconstructFrame( pcc::PCCContext& context, size_t frameIdx, size_t occupancyPrecision, size_t gridSize, double thresholdSmoothing,
+                        pcc::PCCPointSet3& reconstruct );
+  const char* lastError() const { return tmc2_last_error(); }
+
+ private:
+  tmc2_ctx* ctx_ = nullptr;
+};
+
+// Stands in for PCCKdTree (PCCKdTree.h:85-100) where a caller asks for the neighbours of MANY points of one cloud: the tree
+// stays in HBM (tmc2_frame), a batch of queries is one tmc2_kdtree_search.  search() keeps the reference's one-point
+// signature (a batch of one); searchBatch is what a ported caller uses.  Same results, same order on ties.
+class KdTreeDropIn {
+ public:
+  explicit KdTreeDropIn( int device );
+  ~KdTreeDropIn();
+  KdTreeDropIn( const KdTreeDropIn& ) = delete;
+  KdTreeDropIn& operator=( const KdTreeDropIn& ) = delete;
+  int  init( const pcc::PCCPointSet3& pointCloud );
+  int  search( const pcc::PCCPoint3D& point, size_t num_results, pcc::PCCNNResult& results ) const;
+  int  searchBatch( const std::vector<pcc::PCCPoint3D>& points, size_t num_results, std::vector<pcc::PCCNNResult>& results ) const;
+
+ private:
+  tmc2_ctx*   ctx_   = nullptr;
+  tmc2_frame* frame_ = nullptr;
+};
+
+}  // namespace tmc2hip

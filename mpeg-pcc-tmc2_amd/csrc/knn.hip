@@ -224,7 +224,8 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
     case 4: TMC2_LAUNCH_K( 4 ); break;
     case 8: TMC2_LAUNCH_K( 8 ); break;
     case 16: TMC2_LAUNCH_K( 16 ); break;
-    default: setError( "k=%d not instantiated (1, 4, 8, 16)", k ); return TMC2_E_UNSUPPORTED;
+    case 32: TMC2_LAUNCH_K( 32 ); break;  // (the metric's wide search: the reference's last attempt asks for 30)
+    default: setError( "k=%d not instantiated (1, 4, 8, 16, 32)", k ); return TMC2_E_UNSUPPORTED;
   }
 #undef TMC2_LAUNCH_K
   TMC2_HIP( hipGetLastError() );

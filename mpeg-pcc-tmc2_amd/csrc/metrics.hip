@@ -4,31 +4,38 @@
 // QualityMetrics::compute (:73-229) and operator+ (:289-322), with PCCPointSet3::removeDuplicate
 // (PccLibCommon/source/PCCPointSet.cpp:169-220), copyNormals (:2282-2320) and scaleNormals (:2322-2380).
 //
-// Every neighbour query of the metric asks for "all points at the minimum distance" (k grows 5,10,..30 until the
-// k-th result is farther than the first).  That set is canonical as long as it has fewer than k members, and its
-// RESULT order (needed only where the reference sums fp64 normals in result order) is the k-d tree visiting order,
-// independent of k -- so one exact k=16 search per query serves all of them; a group that fills all 16 slots is
-// reported as unsupported instead of being approximated.
-// Everything runs on the device: the lexicographic de-duplication (a stable radix sort of (x, y, z) keys -- hipCUB's device
-// radix sort is the one library primitive used -- then run heads, a prefix sum and one thread per distinct position that
-// averages the colours of its run), the tree builds, the four query batches (exact nanoflann-order k-NN kernel), the
-// per-recon-point ordered normal accumulation, the per-point distortion terms and the final sums.  D1 is a sum of
-// integers (exact in fp64, order-free): a parallel 64-bit reduction.  D2 and the colour errors are fp64 sums whose value
-// depends on the order: four lanes walk the terms in the reference's order (one dependent add per point each) while the
-// rest of the workgroup streams the next chunk into LDS.  Only the 3 x 8 results cross PCIe on the way back.
+// Every neighbour query of the metric asks for "all points at the minimum distance" (k grows 5, 10, .. 30 until the k-th result
+// is farther than the first; PCCMetrics.cpp:91-96, PCCPointSet.cpp:2340-2346, 2362-2368).  A search for k results returns the
+// first k entries of the search for any K > k (the k-d tree visiting order does not depend on the bound: DESIGN.md section 2), so
+// one exact search serves all of them: K = 16 first -- the group then has fewer than 16 members in practice -- and, where some
+// query's 16 results are all equidistant, the whole metric again with K = 32, of which the first 30 count: exactly the
+// reference's last attempt.
+// Everything runs on the device: the lexicographic de-duplication (an own stable LSD radix sort of re-based (x, y, z) keys, then
+// run heads, a prefix sum and one thread per distinct position that averages the colours of its run), the tree builds, the
+// four query batches (exact nanoflann-order k-NN kernel), the per-recon-point ordered normal accumulation, the per-point
+// distortion terms and the final sums.  D1 is a sum of integers (exact in fp64, order-free): a parallel 64-bit reduction.  D2
+// and the colour errors are fp64 sums whose value depends on the order: lanes walk the terms in the reference's order (one
+// dependent add per point each) while the rest of the workgroup streams the next chunk into LDS.  Only the 3 x 8 results cross
+// PCIe on the way back.  The clouds come either from the host (tmc2_metrics_compute) or straight from a frame's resident
+// arrays (tmc2_metrics_compute_frame: no upload at all).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <numeric>
-
-#include <hipcub/hipcub.hpp>
 
 #include "internal.h"
 
 namespace tmc2 {
 namespace {
 
-constexpr int K = 16;
+// a cloud as its owner keeps it: positions as int16 triples `xyzStride` int16 apart, colours as byte triples `rgbStride` bytes
+// apart (host arrays: 3 / 3; a frame's Pt / rgb4 arrays: 4 / 4), both on the device
+struct CloudView {
+  const int16_t* xyz;
+  const uint8_t* rgb;
+  uint32_t       n;
+  int            xyzStride, rgbStride;
+};
 
 // a cloud + its tree on the device
 struct DevCloud {
@@ -58,17 +65,115 @@ struct DevCloud {
 };
 
 // ---- PCCPointSet3::removeDuplicate on the device ---------------------------------------------------------------------------
-// (x, y, z) order = ascending 48-bit key (coordinates biased to unsigned); the sort is stable, so the first element of a
-// run of equal keys is the duplicate with the smallest input index -- the one the reference keeps the position of.
-__global__ __launch_bounds__( 256 ) void positionKeysKernel( const int16_t* __restrict__ xyz, uint32_t n, uint64_t* __restrict__ key,
-                                                              uint32_t* __restrict__ index ) {
+// (x, y, z) order = ascending key with the coordinates re-based to the cloud's bounding box (x in the top bits); the sort is
+// stable, so the first element of a run of equal keys is the duplicate with the smallest input index -- the one the reference
+// keeps the position of.
+struct KeyBase {
+  int      lo[3];
+  uint32_t bitsY, bitsZ, bits;  // widths of the y and z fields, total key width
+};
+__global__ __launch_bounds__( 256 ) void boundsKernel( CloudView c, int* __restrict__ box /* [6] min, max */ ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n ) return;
-  const uint64_t x = uint16_t( int( xyz[3 * size_t( i )] ) + 32768 ), y = uint16_t( int( xyz[3 * size_t( i ) + 1] ) + 32768 ),
-                 z = uint16_t( int( xyz[3 * size_t( i ) + 2] ) + 32768 );
-  key[i]   = ( x << 32 ) | ( y << 16 ) | z;
+  int            mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {int( 0x80000000 ), int( 0x80000000 ), int( 0x80000000 )};
+  if ( i < c.n ) {
+#pragma unroll
+    for ( int d = 0; d < 3; ++d ) mn[d] = mx[d] = c.xyz[size_t( i ) * c.xyzStride + d];
+  }
+#pragma unroll
+  for ( int d = 0; d < 3; ++d ) {
+#pragma unroll
+    for ( int off = 32; off > 0; off >>= 1 ) mn[d] = min( mn[d], __shfl_xor( mn[d], off, 64 ) ), mx[d] = max( mx[d], __shfl_xor( mx[d], off, 64 ) );
+  }
+  if ( ( threadIdx.x & 63 ) == 0 ) {
+#pragma unroll
+    for ( int d = 0; d < 3; ++d ) {
+      if ( mn[d] < loadStaleOk( &box[d] ) ) atomicMin( &box[d], mn[d] );
+      if ( mx[d] > loadStaleOk( &box[3 + d] ) ) atomicMax( &box[3 + d], mx[d] );
+    }
+  }
+}
+__global__ __launch_bounds__( 256 ) void positionKeysKernel( CloudView c, KeyBase kb, uint64_t* __restrict__ key, uint32_t* __restrict__ index ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= c.n ) return;
+  const int16_t* q = c.xyz + size_t( i ) * c.xyzStride;
+  const uint64_t x = uint64_t( int( q[0] ) - kb.lo[0] ), y = uint64_t( int( q[1] ) - kb.lo[1] ), z = uint64_t( int( q[2] ) - kb.lo[2] );
+  key[i]   = ( x << ( kb.bitsY + kb.bitsZ ) ) | ( y << kb.bitsZ ) | z;
   index[i] = i;
 }
+
+// Stable LSD radix sort, 8 bits per pass, tiles of kSortTile keys per workgroup: per-tile digit counts (radixCountKernel), one
+// prefix sum over counts[digit][tile] (digit-major: the exclusive sum IS the digit's base plus the tiles before), then the
+// scatter: a tile is ranked in sub-tiles of 256 keys -- within a wavefront the lanes holding the same digit find each other
+// with eight ballots, the waves' counts are prefixed through LDS, running per-digit offsets carry over the sub-tiles.
+constexpr int kSortTile = 2048;
+__global__ __launch_bounds__( 256 ) void radixCountKernel( const uint64_t* __restrict__ key, uint32_t n, int shift, uint32_t tiles,
+                                                            uint32_t* __restrict__ counts ) {
+  __shared__ uint32_t bins[256];
+  bins[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kSortTile;
+  for ( uint32_t i = base + threadIdx.x; i < min( n, base + uint32_t( kSortTile ) ); i += 256 ) atomicAdd( &bins[( key[i] >> shift ) & 0xFF], 1u );
+  __syncthreads();
+  counts[size_t( threadIdx.x ) * tiles + blockIdx.x] = bins[threadIdx.x];
+}
+__global__ __launch_bounds__( 256 ) void radixScatterKernel( const uint64_t* __restrict__ keyIn, const uint32_t* __restrict__ idxIn,
+                                                              uint32_t n, int shift, uint32_t tiles,
+                                                              const uint32_t* __restrict__ bases, uint64_t* __restrict__ keyOut,
+                                                              uint32_t* __restrict__ idxOut ) {
+  __shared__ uint32_t running[256], waveCount[4][256];
+  const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  running[threadIdx.x] = bases[size_t( threadIdx.x ) * tiles + blockIdx.x];
+  const uint32_t base = blockIdx.x * kSortTile, end = min( n, base + uint32_t( kSortTile ) );
+  for ( uint32_t sub = base; sub < end; sub += 256 ) {
+#pragma unroll
+    for ( int w = 0; w < 4; ++w ) waveCount[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i     = sub + threadIdx.x;
+    const bool     valid = i < end;
+    const uint64_t k     = valid ? keyIn[i] : 0;
+    const uint32_t d     = uint32_t( k >> shift ) & 0xFF;
+    unsigned long long peers = __ballot( valid );
+#pragma unroll
+    for ( int bit = 0; bit < 8; ++bit ) {
+      const unsigned long long m = __ballot( ( d >> bit ) & 1u );
+      peers &= ( ( d >> bit ) & 1u ) ? m : ~m;
+    }
+    const uint32_t rankInWave = uint32_t( __popcll( peers & ( ( 1ull << lane ) - 1ull ) ) );
+    if ( valid && rankInWave == 0 ) waveCount[wave][d] = uint32_t( __popcll( peers ) );
+    __syncthreads();
+    if ( valid ) {
+      uint32_t at = running[d] + rankInWave;
+      for ( int w = 0; w < wave; ++w ) at += waveCount[w][d];
+      keyOut[at] = k;
+      idxOut[at] = idxIn[i];
+    }
+    __syncthreads();
+    running[threadIdx.x] += waveCount[0][threadIdx.x] + waveCount[1][threadIdx.x] + waveCount[2][threadIdx.x] + waveCount[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+// keys / payload of `a` sorted; the result is in (keyA, idxA) or (keyB, idxB): returns which through *inA
+int radixSortPairs( tmc2_ctx* ctx, uint64_t* keyA, uint32_t* idxA, uint64_t* keyB, uint32_t* idxB, uint32_t n, uint32_t bits, bool* inA ) {
+  hipStream_t      s     = ctx->stream;
+  const uint32_t   tiles = ( n + kSortTile - 1 ) / kSortTile;
+  DevBuf<uint32_t> d_counts;
+  TMC2_TRY( d_counts.alloc( size_t( 256 ) * tiles ) );
+  bool fromA = true;
+  for ( uint32_t shift = 0; shift < bits; shift += 8 ) {
+    uint64_t* kin  = fromA ? keyA : keyB;
+    uint32_t* iin  = fromA ? idxA : idxB;
+    uint64_t* kout = fromA ? keyB : keyA;
+    uint32_t* iout = fromA ? idxB : idxA;
+    hipLaunchKernelGGL( radixCountKernel, dim3( tiles ), dim3( 256 ), 0, s, kin, n, int( shift ), tiles, d_counts.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_counts.p, d_counts.p, size_t( 256 ) * tiles, nullptr ) );
+    hipLaunchKernelGGL( radixScatterKernel, dim3( tiles ), dim3( 256 ), 0, s, kin, iin, n, int( shift ), tiles, d_counts.p, kout, iout );
+    fromA = !fromA;
+  }
+  TMC2_HIP( hipGetLastError() );
+  *inA = fromA;
+  return TMC2_OK;
+}
+
 __global__ __launch_bounds__( 256 ) void runHeadKernel( const uint64_t* __restrict__ key, uint32_t n, uint32_t* __restrict__ head ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i < n ) head[i] = ( i == 0 || key[i] != key[i - 1] ) ? 1u : 0u;
@@ -76,26 +181,28 @@ __global__ __launch_bounds__( 256 ) void runHeadKernel( const uint64_t* __restri
 // one thread per run: position of its first element, colour = integer mean over the run (removeDuplicate :188-206)
 __global__ __launch_bounds__( 256 ) void emitDistinctKernel( const uint64_t* __restrict__ key, const uint32_t* __restrict__ index,
                                                               const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank,
-                                                              const uint8_t* __restrict__ rgb, uint32_t n, Pt* __restrict__ pts,
-                                                              uint8_t* __restrict__ rgb4, uint32_t* __restrict__ first ) {
+                                                              CloudView c, Pt* __restrict__ pts, uint8_t* __restrict__ rgb4,
+                                                              uint32_t* __restrict__ first ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i >= n || !head[i] ) return;
+  if ( i >= c.n || !head[i] ) return;
   const uint64_t k = key[i];
-  uint32_t       r = 0, g = 0, b = 0, c = 0;
-  for ( uint32_t j = i; j < n && key[j] == k; ++j ) {
-    const size_t o = 3 * size_t( index[j] );
-    r += rgb[o], g += rgb[o + 1], b += rgb[o + 2];
-    ++c;
+  uint32_t       r = 0, g = 0, b = 0, cnt = 0;
+  for ( uint32_t j = i; j < c.n && key[j] == k; ++j ) {
+    const uint8_t* col = c.rgb + size_t( index[j] ) * c.rgbStride;
+    r += col[0], g += col[1], b += col[2];
+    ++cnt;
   }
   const uint32_t u = rank[i];
-  pts[u]           = Pt{int16_t( int( ( k >> 32 ) & 0xFFFF ) - 32768 ), int16_t( int( ( k >> 16 ) & 0xFFFF ) - 32768 ),
-              int16_t( int( k & 0xFFFF ) - 32768 ), 0};
-  reinterpret_cast<uchar4*>( rgb4 )[u] = make_uchar4( (unsigned char)( r / c ), (unsigned char)( g / c ), (unsigned char)( b / c ), 0 );
+  const int16_t* q = c.xyz + size_t( index[i] ) * c.xyzStride;
+  pts[u]           = Pt{q[0], q[1], q[2], 0};
+  reinterpret_cast<uchar4*>( rgb4 )[u] = make_uchar4( (unsigned char)( r / cnt ), (unsigned char)( g / cnt ), (unsigned char)( b / cnt ), 0 );
   first[u]                             = index[i];
 }
-__global__ __launch_bounds__( 256 ) void rawPointsKernel( const int16_t* __restrict__ xyz, uint32_t n, Pt* __restrict__ pts ) {
+__global__ __launch_bounds__( 256 ) void rawPointsKernel( CloudView c, Pt* __restrict__ pts ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i < n ) pts[i] = Pt{xyz[3 * size_t( i )], xyz[3 * size_t( i ) + 1], xyz[3 * size_t( i ) + 2], 0};
+  if ( i >= c.n ) return;
+  const int16_t* q = c.xyz + size_t( i ) * c.xyzStride;
+  pts[i]           = Pt{q[0], q[1], q[2], 0};
 }
 __global__ __launch_bounds__( 256 ) void gatherPointsKernel( const Pt* __restrict__ pts, const uint32_t* __restrict__ which, uint32_t n,
                                                               Pt* __restrict__ out ) {
@@ -110,65 +217,79 @@ __global__ __launch_bounds__( 256 ) void gatherNormalsKernel( const double* __re
   out[3 * size_t( i )] = nrm[o], out[3 * size_t( i ) + 1] = nrm[o + 1], out[3 * size_t( i ) + 2] = nrm[o + 2];
 }
 
-// d_xyz / d_rgb: the cloud as the caller gave it (int16[n][3], uint8[n][3]) -> the distinct positions in (x, y, z) order with
-// averaged colours; first[u] = input index of the duplicate whose position / normal the reference keeps
-int removeDuplicatesDevice( tmc2_ctx* ctx, const int16_t* d_xyz, const uint8_t* d_rgb, uint32_t n, DevCloud& out,
-                            DevBuf<uint32_t>& d_first ) {
+// the cloud as its owner keeps it -> the distinct positions in (x, y, z) order with averaged colours; first[u] = input index of
+// the duplicate whose position / normal the reference keeps
+int removeDuplicatesDevice( tmc2_ctx* ctx, const CloudView& c, DevCloud& out, DevBuf<uint32_t>& d_first ) {
   hipStream_t      s = ctx->stream;
-  DevBuf<uint64_t> d_keyIn, d_keyOut;
-  DevBuf<uint32_t> d_idxIn, d_idxOut, d_head, d_rank, d_total;
-  DevBuf<uint8_t>  d_tmp;
-  TMC2_TRY( d_keyIn.alloc( n ) );
-  TMC2_TRY( d_keyOut.alloc( n ) );
-  TMC2_TRY( d_idxIn.alloc( n ) );
-  TMC2_TRY( d_idxOut.alloc( n ) );
+  const uint32_t   n = c.n;
+  DevBuf<uint64_t> d_keyA, d_keyB;
+  DevBuf<uint32_t> d_idxA, d_idxB, d_head, d_rank, d_small;
+  TMC2_TRY( d_keyA.alloc( n ) );
+  TMC2_TRY( d_keyB.alloc( n ) );
+  TMC2_TRY( d_idxA.alloc( n ) );
+  TMC2_TRY( d_idxB.alloc( n ) );
   TMC2_TRY( d_head.alloc( n ) );
   TMC2_TRY( d_rank.alloc( n ) );
-  TMC2_TRY( d_total.alloc( 1 ) );
+  TMC2_TRY( d_small.alloc( 8 ) );  // [0 .. 5] bounding box, [6] distinct positions
   const dim3 blk( 256 ), grd( ( n + 255 ) / 256 );
-  hipLaunchKernelGGL( positionKeysKernel, grd, blk, 0, s, d_xyz, n, d_keyIn.p, d_idxIn.p );
-  size_t tmpBytes = 0;
-  TMC2_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, tmpBytes, d_keyIn.p, d_keyOut.p, d_idxIn.p, d_idxOut.p, int( n ), 0, 48, s ) );
-  TMC2_TRY( d_tmp.alloc( tmpBytes + 16 ) );
-  TMC2_HIP( hipcub::DeviceRadixSort::SortPairs( d_tmp.p, tmpBytes, d_keyIn.p, d_keyOut.p, d_idxIn.p, d_idxOut.p, int( n ), 0, 48, s ) );
-  hipLaunchKernelGGL( runHeadKernel, grd, blk, 0, s, d_keyOut.p, n, d_head.p );
-  TMC2_TRY( exclusiveScanU32( ctx, d_head.p, d_rank.p, n, d_total.p ) );
+  int        box[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, int( 0x80000000 ), int( 0x80000000 ), int( 0x80000000 )};
+  TMC2_HIP( hipMemcpyAsync( d_small.p, box, sizeof( box ), hipMemcpyHostToDevice, s ) );
+  hipLaunchKernelGGL( boundsKernel, grd, blk, 0, s, c, reinterpret_cast<int*>( d_small.p ) );
+  TMC2_HIP( hipMemcpyAsync( box, d_small.p, sizeof( box ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  KeyBase  kb{};
+  uint32_t width[3];
+  for ( int d = 0; d < 3; ++d ) {
+    kb.lo[d] = box[d];
+    width[d] = 1;
+    while ( ( uint64_t( 1 ) << width[d] ) <= uint64_t( box[3 + d] - box[d] ) ) ++width[d];
+  }
+  kb.bitsY = width[1], kb.bitsZ = width[2], kb.bits = width[0] + width[1] + width[2];
+  hipLaunchKernelGGL( positionKeysKernel, grd, blk, 0, s, c, kb, d_keyA.p, d_idxA.p );
+  bool inA = true;
+  TMC2_TRY( radixSortPairs( ctx, d_keyA.p, d_idxA.p, d_keyB.p, d_idxB.p, n, kb.bits, &inA ) );
+  const uint64_t* key = inA ? d_keyA.p : d_keyB.p;
+  const uint32_t* idx = inA ? d_idxA.p : d_idxB.p;
+  hipLaunchKernelGGL( runHeadKernel, grd, blk, 0, s, key, n, d_head.p );
+  TMC2_TRY( exclusiveScanU32( ctx, d_head.p, d_rank.p, n, d_small.p + 6 ) );
   uint32_t distinct = 0;
-  TMC2_HIP( hipMemcpyAsync( &distinct, d_total.p, 4, hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( &distinct, d_small.p + 6, 4, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   out.n = distinct;
   TMC2_TRY( out.pts.alloc( distinct ) );
   TMC2_TRY( out.rgb4.alloc( 4 * size_t( distinct ) ) );
   TMC2_TRY( d_first.alloc( distinct ) );
-  hipLaunchKernelGGL( emitDistinctKernel, grd, blk, 0, s, d_keyOut.p, d_idxOut.p, d_head.p, d_rank.p, d_rgb, n, out.pts.p,
-                      out.rgb4.p, d_first.p );
+  hipLaunchKernelGGL( emitDistinctKernel, grd, blk, 0, s, key, idx, d_head.p, d_rank.p, c, out.pts.p, out.rgb4.p, d_first.p );
   TMC2_HIP( hipGetLastError() );
   TMC2_HIP( hipStreamSynchronize( s ) );  // (the temporaries go back to the pool)
   return TMC2_OK;
 }
 
-// size of the minimum-distance group of one 16-NN row (leading entries equal to the first distance)
-__device__ __forceinline__ int groupSize( const uint32_t* dist ) {
+// size of the minimum-distance group of one K-NN row (leading entries equal to the first distance), at most cap: 16 in the
+// first attempt (a full group raises the flag that sends the whole metric to the second one), 30 of K = 32 in the second
+__device__ __forceinline__ int groupSize( const uint32_t* dist, int cap ) {
   int g = 1;
-  while ( g < K && dist[g] == dist[0] ) ++g;
+  while ( g < cap && dist[g] == dist[0] ) ++g;
   return g;
 }
+constexpr int kMaxGroup = 30;  // num_results_max of the reference
+__host__ __device__ __forceinline__ int groupCap( int K ) { return K == 16 ? 16 : kMaxGroup; }
 
 // scaleNormals, pass 1: every source point votes for its nearest reconstructed points
-__global__ __launch_bounds__( 256 ) void votesCountKernel( const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+__global__ __launch_bounds__( 256 ) void votesCountKernel( const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist, int K,
                                                             uint32_t n, uint32_t* __restrict__ count, uint32_t* __restrict__ error ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  const int g = groupSize( dist + size_t( i ) * K );
-  if ( g == K ) *error = 1;
+  const int g = groupSize( dist + size_t( i ) * K, groupCap( K ) );
+  if ( K == 16 && g == K ) *error = 1;
   for ( int j = 0; j < g; ++j ) atomicAdd( &count[idx[size_t( i ) * K + j]], 1u );
 }
-__global__ __launch_bounds__( 256 ) void votesFillKernel( const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+__global__ __launch_bounds__( 256 ) void votesFillKernel( const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist, int K,
                                                            uint32_t n, const uint32_t* __restrict__ offset,
                                                            uint32_t* __restrict__ cursor, uint32_t* __restrict__ voters ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  const int g = groupSize( dist + size_t( i ) * K );
+  const int g = groupSize( dist + size_t( i ) * K, groupCap( K ) );
   for ( int j = 0; j < g; ++j ) {
     const uint32_t r             = idx[size_t( i ) * K + j];
     voters[offset[r] + atomicAdd( &cursor[r], 1u )] = i;
@@ -203,13 +324,13 @@ __global__ __launch_bounds__( 256 ) void votesReduceKernel( const uint32_t* __re
 }
 // reconstructed points nobody voted for: mean normal of their own nearest source points, in RESULT order
 __global__ __launch_bounds__( 256 ) void orphanNormalsKernel( const uint32_t* __restrict__ orphan, uint32_t nOrphan,
-                                                               const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
+                                                               const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist, int K,
                                                                const double* __restrict__ srcNormals,
                                                                double* __restrict__ recNormals, uint32_t* __restrict__ error ) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if ( o >= nOrphan ) return;
-  const int g = groupSize( dist + size_t( o ) * K );
-  if ( g == K ) *error = 1;
+  const int g = groupSize( dist + size_t( o ) * K, groupCap( K ) );
+  if ( K == 16 && g == K ) *error = 1;
   double x = 0.0, y = 0.0, z = 0.0;
   for ( int j = 0; j < g; ++j ) {
     const size_t s = idx[size_t( o ) * K + j];
@@ -231,14 +352,14 @@ __global__ __launch_bounds__( 256 ) void distortionTermsKernel( const Pt* __rest
                                                                  const Pt* __restrict__ ptsB, const uint8_t* __restrict__ rgbB,
                                                                  const double* __restrict__ nrmB,
                                                                  const uint32_t* __restrict__ idx, const uint32_t* __restrict__ dist,
-                                                                 uint32_t nA, double* __restrict__ terms /* [nA][5] */,
+                                                                 int K, uint32_t nA, double* __restrict__ terms /* [nA][5] */,
                                                                  uint32_t* __restrict__ error ) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   if ( a >= nA ) return;
   const uint32_t* d = dist + size_t( a ) * K;
-  const int       g = groupSize( d );
-  if ( g == K ) *error = 1;
-  uint32_t same[K];
+  const int       g = groupSize( d, groupCap( K ) );
+  if ( K == 16 && g == K ) *error = 1;
+  uint32_t same[kMaxGroup];
   for ( int j = 0; j < g; ++j ) same[j] = idx[size_t( a ) * K + j];
   for ( int j = 1; j < g; ++j ) {  // ascending index
     const uint32_t v = same[j];
@@ -343,17 +464,18 @@ __global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __res
 double psnr( double dist, double p, double factor ) { return 10 * std::log10( ( factor * p * p ) / dist ); }
 
 // per-point terms of one direction (A's points against their nearest neighbours in B)
-int qualityTerms( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, DevBuf<double>& d_terms, uint32_t* d_error ) {
+int qualityTerms( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, int K, DevBuf<double>& d_terms,
+                  uint32_t* d_error ) {
   hipStream_t      s  = ctx->stream;
   const uint32_t   nA = uint32_t( A.n );
   DevBuf<uint32_t> d_idx, d_dist;
   TMC2_TRY( d_idx.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_dist.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_terms.alloc( size_t( nA ) * 5 ) );
-  TMC2_TRY( launchKnnTree( ctx, B.devFor( A ), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn16" ) );
+  TMC2_TRY( launchKnnTree( ctx, B.devFor( A ), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn" ) );
   const int sid = ctx->stageBegin( "metrics_terms" );
   hipLaunchKernelGGL( distortionTermsKernel, dim3( ( nA + 255 ) / 256 ), dim3( 256 ), 0, s, A.pts.p, A.rgb4.p, B.pts.p, B.rgb4.p,
-                      withNormals ? B.nrm.p : (const double*)nullptr, d_idx.p, d_dist.p, nA, d_terms.p, d_error );
+                      withNormals ? B.nrm.p : (const double*)nullptr, d_idx.p, d_dist.p, K, nA, d_terms.p, d_error );
   ctx->stageEnd( sid );
   return TMC2_OK;
 }
@@ -367,70 +489,52 @@ void qualityFromSums( const double* sse, double num, bool withNormals, double re
   out[7] = psnr( out[4], 1.0, 1.0 );
 }
 
-}  // namespace
-}  // namespace tmc2
+struct StageScope {  // closes a stage on every way out
+  tmc2_ctx* ctx;
+  int       id;
+  ~StageScope() { ctx->stageEnd( id ); }
+};
 
-extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n,
-                                     const int16_t* recXyz, const uint8_t* recRgb, uint64_t m, const double* srcNormals,
-                                     double resolution, double* out, int64_t* counts ) {
-  using namespace tmc2;
-  if ( !ctx || !srcXyz || !srcRgb || !recXyz || !recRgb || !out || n == 0 || m == 0 ) {
-    setError( "metrics_compute: invalid argument" );
-    return TMC2_E_INVALID;
-  }
-  ApiScope    scope( ctx );
-  hipStream_t s  = ctx->stream;
-  const int   sidPrep = ctx->stageBegin( "metrics_prepare" );
-  // the clouds as given, to the device (9 bytes per point each way; fp64 normals: 24 per source point)
-  DevBuf<int16_t> d_srcXyz, d_recXyz;
-  DevBuf<uint8_t> d_srcRgb, d_recRgb;
-  DevBuf<double>  d_srcNrm;
-  TMC2_TRY( d_srcXyz.alloc( 3 * size_t( n ) ) );
-  TMC2_TRY( d_srcRgb.alloc( 3 * size_t( n ) ) );
-  TMC2_TRY( d_recXyz.alloc( 3 * size_t( m ) ) );
-  TMC2_TRY( d_recRgb.alloc( 3 * size_t( m ) ) );
-  TMC2_HIP( hipMemcpyAsync( d_srcXyz.p, srcXyz, 6 * size_t( n ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( d_srcRgb.p, srcRgb, 3 * size_t( n ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( d_recXyz.p, recXyz, 6 * size_t( m ), hipMemcpyHostToDevice, s ) );
-  TMC2_HIP( hipMemcpyAsync( d_recRgb.p, recRgb, 3 * size_t( m ), hipMemcpyHostToDevice, s ) );
-  const bool withNormals = srcNormals != nullptr;
-  if ( withNormals ) {
-    TMC2_TRY( d_srcNrm.alloc( 3 * size_t( n ) ) );
-    TMC2_HIP( hipMemcpyAsync( d_srcNrm.p, srcNormals, 3 * size_t( n ) * sizeof( double ), hipMemcpyHostToDevice, s ) );
-  }
+// PCCMetrics::compute for one frame from clouds resident on the device.  d_srcNormals: fp64[src.n][3] or null.
+// *overflow = true: some query's K results were all equidistant (K = 16 only): the caller repeats with K = 32.
+int metricsDevice( tmc2_ctx* ctx, const CloudView& src, const CloudView& rec, const double* d_srcNormals, double resolution, int K,
+                   double* out, int64_t* counts, bool* overflow ) {
+  hipStream_t s = ctx->stream;
+  *overflow     = false;
   DevCloud         dS, dR, dN;  // de-duplicated source, de-duplicated reconstruction, normal cloud (original source order)
   DevBuf<uint32_t> d_firstS, d_firstR;
-  TMC2_TRY( removeDuplicatesDevice( ctx, d_srcXyz.p, d_srcRgb.p, uint32_t( n ), dS, d_firstS ) );
-  TMC2_TRY( removeDuplicatesDevice( ctx, d_recXyz.p, d_recRgb.p, uint32_t( m ), dR, d_firstR ) );
-  if ( counts ) counts[0] = int64_t( dS.n ), counts[1] = int64_t( dR.n );
-  if ( dS.n < size_t( K ) || dR.n < size_t( K ) ) {
-    setError( "metrics_compute: clouds smaller than %d points unsupported", K );
-    return TMC2_E_UNSUPPORTED;
-  }
-  const dim3 blk( 256 );
-  if ( withNormals ) {
-    if ( dS.n != n ) {
-      setError( "metrics_compute: the source has duplicate positions; normals cannot be attached (the reference exits)" );
-      return TMC2_E_INVALID;
+  const bool       withNormals = d_srcNormals != nullptr;
+  const dim3       blk( 256 );
+  {
+    StageScope prep{ctx, ctx->stageBegin( "metrics_prepare" )};
+    TMC2_TRY( removeDuplicatesDevice( ctx, src, dS, d_firstS ) );
+    TMC2_TRY( removeDuplicatesDevice( ctx, rec, dR, d_firstR ) );
+    if ( counts ) counts[0] = int64_t( dS.n ), counts[1] = int64_t( dR.n );
+    if ( dS.n < size_t( K ) || dR.n < size_t( K ) ) {
+      setError( "metrics_compute: clouds smaller than %d points unsupported", K );
+      return TMC2_E_UNSUPPORTED;
     }
-    // copyNormals: the de-duplicated source is the lexicographic sort of the input
-    TMC2_TRY( dS.nrm.alloc( 3 * size_t( n ) ) );
-    hipLaunchKernelGGL( gatherNormalsKernel, dim3( uint32_t( ( n + 255 ) / 256 ) ), blk, 0, s, d_srcNrm.p, d_firstS.p, uint32_t( n ),
-                        dS.nrm.p );
+    if ( withNormals ) {
+      if ( dS.n != src.n ) {
+        setError( "metrics_compute: the source has duplicate positions; normals cannot be attached (the reference exits)" );
+        return TMC2_E_INVALID;
+      }
+      // copyNormals: the de-duplicated source is the lexicographic sort of the input
+      TMC2_TRY( dS.nrm.alloc( 3 * size_t( src.n ) ) );
+      hipLaunchKernelGGL( gatherNormalsKernel, dim3( ( src.n + 255 ) / 256 ), blk, 0, s, d_srcNormals, d_firstS.p, src.n, dS.nrm.p );
+    }
+    TMC2_TRY( dS.buildTree( ctx ) );
+    TMC2_TRY( dR.buildTree( ctx ) );
   }
-  TMC2_TRY( dS.buildTree( ctx ) );
-  TMC2_TRY( dR.buildTree( ctx ) );
-  ctx->stageEnd( sidPrep );
   DevBuf<uint32_t> d_error;
   TMC2_TRY( d_error.alloc( 1 ) );
   TMC2_HIP( hipMemsetAsync( d_error.p, 0, 4, s ) );
   if ( withNormals ) {
     // scaleNormals
-    const uint32_t mR = uint32_t( dR.n ), nS = uint32_t( n );
-    dN.n = n;  // the normal cloud: the source in its original order (no duplicates: checked above)
-    TMC2_TRY( dN.pts.alloc( n ) );
-    hipLaunchKernelGGL( rawPointsKernel, dim3( uint32_t( ( n + 255 ) / 256 ) ), blk, 0, s, d_srcXyz.p, uint32_t( n ), dN.pts.p );
-    const double* d_nrmN = d_srcNrm.p;
+    const uint32_t mR = uint32_t( dR.n ), nS = src.n;
+    dN.n = nS;  // the normal cloud: the source in its original order (no duplicates: checked above)
+    TMC2_TRY( dN.pts.alloc( nS ) );
+    hipLaunchKernelGGL( rawPointsKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, src, dN.pts.p );
     DevBuf<uint32_t> d_idx, d_dist, d_count, d_offset, d_cursor, d_voters, d_total;
     TMC2_TRY( d_idx.alloc( size_t( nS ) * K ) );
     TMC2_TRY( d_dist.alloc( size_t( nS ) * K ) );
@@ -439,10 +543,9 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
     TMC2_TRY( d_cursor.alloc( mR ) );
     TMC2_TRY( d_total.alloc( 1 ) );
     TMC2_TRY( dR.nrm.alloc( 3 * size_t( mR ) ) );
-    TMC2_TRY( launchKnnTree( ctx, dR.devFor( dS ), dN.pts.p, nS, K, d_idx.p, d_dist.p, "metrics_knn16" ) );  // (dN = the points of dS)
-    TMC2_HIP( hipMemsetAsync( d_count.p, 0, size_t( mR ) * 4, s ) );
-    TMC2_HIP( hipMemsetAsync( d_cursor.p, 0, size_t( mR ) * 4, s ) );
-    hipLaunchKernelGGL( votesCountKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, nS, d_count.p, d_error.p );
+    TMC2_TRY( launchKnnTree( ctx, dR.devFor( dS ), dN.pts.p, nS, K, d_idx.p, d_dist.p, "metrics_knn" ) );  // (dN = the points of dS)
+    TMC2_TRY( fillRegions( ctx, {{d_count.p, size_t( mR ) * 4, 0}, {d_cursor.p, size_t( mR ) * 4, 0}} ) );
+    hipLaunchKernelGGL( votesCountKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, K, nS, d_count.p, d_error.p );
     TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, mR, d_total.p ) );
     uint32_t total = 0;
     TMC2_HIP( hipMemcpyAsync( &total, d_total.p, 4, hipMemcpyDeviceToHost, s ) );
@@ -450,9 +553,9 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
     TMC2_HIP( hipMemcpyAsync( h_count.data(), d_count.p, size_t( mR ) * 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
     TMC2_TRY( d_voters.alloc( std::max( total, 1u ) ) );
-    hipLaunchKernelGGL( votesFillKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, nS, d_offset.p, d_cursor.p,
+    hipLaunchKernelGGL( votesFillKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, K, nS, d_offset.p, d_cursor.p,
                         d_voters.p );
-    hipLaunchKernelGGL( votesReduceKernel, dim3( ( mR + 255 ) / 256 ), blk, 0, s, d_count.p, d_offset.p, d_voters.p, d_nrmN, mR,
+    hipLaunchKernelGGL( votesReduceKernel, dim3( ( mR + 255 ) / 256 ), blk, 0, s, d_count.p, d_offset.p, d_voters.p, d_srcNormals, mR,
                         dR.nrm.p );
     std::vector<uint32_t> orphans;
     for ( uint32_t r = 0; r < mR; ++r )
@@ -469,8 +572,8 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
       TMC2_TRY( d_od.alloc( size_t( nO ) * K ) );
       TMC2_HIP( hipMemcpyAsync( d_orph.p, orphans.data(), size_t( nO ) * 4, hipMemcpyHostToDevice, s ) );
       hipLaunchKernelGGL( gatherPointsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, dR.pts.p, d_orph.p, nO, d_q.p );
-      TMC2_TRY( launchKnnTree( ctx, dN.devFor( dR ), d_q.p, nO, K, d_oi.p, d_od.p, "metrics_knn16" ) );
-      hipLaunchKernelGGL( orphanNormalsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, d_orph.p, nO, d_oi.p, d_od.p, d_nrmN,
+      TMC2_TRY( launchKnnTree( ctx, dN.devFor( dR ), d_q.p, nO, K, d_oi.p, d_od.p, "metrics_knn" ) );
+      hipLaunchKernelGGL( orphanNormalsKernel, dim3( ( nO + 255 ) / 256 ), blk, 0, s, d_orph.p, nO, d_oi.p, d_od.p, K, d_srcNormals,
                           dR.nrm.p, d_error.p );
       TMC2_HIP( hipStreamSynchronize( s ) );
     }
@@ -478,17 +581,24 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
   {
     DevBuf<double> d_termsS, d_termsR, d_sums;
     TMC2_TRY( d_sums.alloc( 16 ) );
-    TMC2_TRY( qualityTerms( ctx, dS, dR, withNormals, d_termsS, d_error.p ) );
-    TMC2_TRY( qualityTerms( ctx, dR, dS, withNormals, d_termsR, d_error.p ) );
+    TMC2_TRY( qualityTerms( ctx, dS, dR, withNormals, K, d_termsS, d_error.p ) );
+    TMC2_TRY( qualityTerms( ctx, dR, dS, withNormals, K, d_termsR, d_error.p ) );
     const int    sid = ctx->stageBegin( "metrics_sums" );
     const size_t lds = size_t( 2 ) * 8 * kSumStride * sizeof( double );
     TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( orderedSumsKernel ), lds, ctx->device ) );
     hipLaunchKernelGGL( orderedSumsKernel, dim3( 1 ), dim3( 1024 ), lds, s, d_termsS.p, uint32_t( dS.n ), d_termsR.p, uint32_t( dR.n ),
                         d_sums.p );
     ctx->stageEnd( sid );
-    double sse[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double   sse[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t err     = 0;
     TMC2_HIP( hipMemcpyAsync( sse, d_sums.p, sizeof( sse ), hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipMemcpyAsync( &err, d_error.p, 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    TMC2_HIP( hipGetLastError() );
+    if ( err ) {
+      *overflow = true;
+      return TMC2_OK;
+    }
     qualityFromSums( sse, double( dS.n ), withNormals, resolution, out );
     qualityFromSums( sse + 5, double( dR.n ), withNormals, resolution, out + 8 );
   }
@@ -496,14 +606,123 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
     const bool isPsnr = ( i == 1 || i == 3 || i == 7 );
     out[16 + i]       = isPsnr ? std::min( out[i], out[8 + i] ) : std::max( out[i], out[8 + i] );
   }
-  uint32_t err = 0;
-  TMC2_HIP( hipMemcpyAsync( &err, d_error.p, 4, hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
-  TMC2_HIP( hipGetLastError() );
-  if ( err ) {
-    setError( "metrics_compute: a query has 16 or more equidistant nearest neighbours (the reference extends its search "
-              "to 30; not reproduced)" );
-    return TMC2_E_UNSUPPORTED;
+  return TMC2_OK;
+}
+
+// K = 16, and once more with K = 32 (the reference's 30) where a minimum-distance group filled all 16 slots
+int metricsBothWidths( tmc2_ctx* ctx, const CloudView& src, const CloudView& rec, const double* d_srcNormals, double resolution,
+                       double* out, int64_t* counts ) {
+  bool overflow = false;
+  // (test hook TMC2_METRICS_K=32: the wide search straight away)
+  const char* kEnv = getenv( "TMC2_METRICS_K" );
+  if ( !( kEnv && atoi( kEnv ) == 32 ) ) {
+    TMC2_TRY( metricsDevice( ctx, src, rec, d_srcNormals, resolution, 16, out, counts, &overflow ) );
+    if ( !overflow ) return TMC2_OK;
+  }
+  ctx->stageAddHostMs( "metrics_wide_search", 1.0 );  // (a count: how often the 30-neighbour search was needed)
+  return metricsDevice( ctx, src, rec, d_srcNormals, resolution, 32, out, counts, &overflow );
+}
+
+}  // namespace
+}  // namespace tmc2
+
+namespace tmc2 {
+namespace {
+// the source cloud (and its normals) as the caller holds them on the host, to the device
+struct UploadedSource {
+  DevBuf<int16_t> xyz;
+  DevBuf<uint8_t> rgb;
+  DevBuf<double>  nrm;
+  int put( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n, const double* srcNormals, CloudView& view ) {
+    hipStream_t s = ctx->stream;
+    StageScope  up{ctx, ctx->stageBegin( "metrics_upload" )};
+    TMC2_TRY( xyz.alloc( 3 * size_t( n ) ) );
+    TMC2_TRY( rgb.alloc( 3 * size_t( n ) ) );
+    TMC2_HIP( hipMemcpyAsync( xyz.p, srcXyz, 6 * size_t( n ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( rgb.p, srcRgb, 3 * size_t( n ), hipMemcpyHostToDevice, s ) );
+    if ( srcNormals ) {
+      TMC2_TRY( nrm.alloc( 3 * size_t( n ) ) );
+      TMC2_HIP( hipMemcpyAsync( nrm.p, srcNormals, 3 * size_t( n ) * sizeof( double ), hipMemcpyHostToDevice, s ) );
+    }
+    view = CloudView{xyz.p, rgb.p, uint32_t( n ), 3, 3};
+    return TMC2_OK;
+  }
+};
+// the reconstruction a frame holds: which 0: of the attribute-image step, 1: the finished cloud of the post-reconstruction tail
+int residentReconstruction( tmc2_frame* f, int which, CloudView& rec ) {
+  if ( !f->haveReconstruction || f->reconCount == 0 || f->reconCount > 0x7FFFFFFFull ) {
+    setError( "metrics: the frame holds no reconstruction" );
+    return TMC2_E_STATE;
+  }
+  rec = CloudView{reinterpret_cast<const int16_t*>( f->d_recon.p ), f->d_reconRgb.p, uint32_t( f->reconCount ), 4, 4};
+  if ( which == 0 ) {
+    if ( !f->haveAttributeImages ) {
+      setError( "metrics: the reconstruction has no colours yet (tmc2_encoder_generate_attribute_images)" );
+      return TMC2_E_STATE;
+    }
+  } else if ( which == 1 ) {
+    if ( !f->haveRgbPost ) {
+      setError( "metrics: the post-reconstruction tail has not run (tmc2_codec_convert_yuv16_to_rgb8 is its last step)" );
+      return TMC2_E_STATE;
+    }
+    if ( f->haveSmoothed ) rec.xyz = reinterpret_cast<const int16_t*>( f->d_reconSmoothed.p );
+    rec.rgb = f->d_rgbPost.p;
+  } else {
+    setError( "metrics: which = %d (0: the reconstruction of the attribute-image step, 1: the finished cloud)", which );
+    return TMC2_E_INVALID;
   }
   return TMC2_OK;
+}
+}  // namespace
+}  // namespace tmc2
+
+extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n,
+                                     const int16_t* recXyz, const uint8_t* recRgb, uint64_t m, const double* srcNormals,
+                                     double resolution, double* out, int64_t* counts ) {
+  using namespace tmc2;
+  if ( !ctx || !srcXyz || !srcRgb || !recXyz || !recRgb || !out || n == 0 || m == 0 || n > 0x7FFFFFFFull || m > 0x7FFFFFFFull ) {
+    setError( "metrics_compute: invalid argument (null pointer, empty cloud or more than 2^31 - 1 points)" );
+    return TMC2_E_INVALID;
+  }
+  ApiScope       scope( ctx );
+  UploadedSource src, rec;  // (9 bytes per point each way; fp64 normals: 24 per source point)
+  CloudView      vs{}, vr{};
+  TMC2_TRY( src.put( ctx, srcXyz, srcRgb, n, srcNormals, vs ) );
+  TMC2_TRY( rec.put( ctx, recXyz, recRgb, m, nullptr, vr ) );
+  return metricsBothWidths( ctx, vs, vr, srcNormals ? src.nrm.p : nullptr, resolution, out, counts );
+}
+
+extern "C" int tmc2_metrics_compute_frame( tmc2_frame* f, int which, int useNormals, double resolution, double* out, int64_t* counts ) {
+  using namespace tmc2;
+  if ( !f || !out ) {
+    setError( "metrics_compute_frame: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  ApiScope scope( f->ctx );
+  if ( f->n == 0 || f->d_rgb.count == 0 || f->n > 0x7FFFFFFFull ) {
+    setError( "metrics_compute_frame: the frame has no source cloud with colours (a decoder-side frame: tmc2_metrics_compute_frame_source)" );
+    return TMC2_E_STATE;
+  }
+  if ( useNormals && !f->haveNormals ) {
+    setError( "metrics_compute_frame: no normals on the frame (tmc2_normals_compute / tmc2_frame_set_normals)" );
+    return TMC2_E_STATE;
+  }
+  CloudView src{reinterpret_cast<const int16_t*>( f->d_pts.p ), f->d_rgb.p, uint32_t( f->n ), 4, 4}, rec{};
+  TMC2_TRY( residentReconstruction( f, which, rec ) );
+  return metricsBothWidths( f->ctx, src, rec, useNormals ? f->d_normals.p : nullptr, resolution, out, counts );
+}
+
+extern "C" int tmc2_metrics_compute_frame_source( tmc2_frame* f, int which, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n,
+                                                  const double* srcNormals, double resolution, double* out, int64_t* counts ) {
+  using namespace tmc2;
+  if ( !f || !out || !srcXyz || !srcRgb || n == 0 || n > 0x7FFFFFFFull ) {
+    setError( "metrics_compute_frame_source: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  ApiScope       scope( f->ctx );
+  CloudView      rec{}, vs{};
+  UploadedSource src;
+  TMC2_TRY( residentReconstruction( f, which, rec ) );
+  TMC2_TRY( src.put( f->ctx, srcXyz, srcRgb, n, srcNormals, vs ) );
+  return metricsBothWidths( f->ctx, vs, rec, srcNormals ? src.nrm.p : nullptr, resolution, out, counts );
 }

@@ -229,6 +229,26 @@ class Frame:
     def reset(self):
         _check(self.L.tmc2_frame_reset(self.h))
 
+    def metrics_compute(self, which=0, use_normals=True, resolution=1023.0):
+        """S23 on the frame's resident clouds (nothing is uploaded): source = the frame, reconstruction = which 0: the cloud of
+        the attribute-image step, 1: the finished cloud of the post-reconstruction tail.  Returns (q[3][8], counts[2])."""
+        out = np.zeros((3, 8), np.float64)
+        counts = np.zeros(2, np.int64)
+        _check(self.L.tmc2_metrics_compute_frame(self.h, C.c_int(which), C.c_int(1 if use_normals else 0), C.c_double(resolution),
+                                                 _ptr(out), _ptr(counts)))
+        return out, counts
+
+    def metrics_compute_source(self, src_xyz, src_rgb, normals=None, which=1, resolution=1023.0):
+        """S23 of a source cloud held on the host against this frame's resident reconstruction (the decoder side)."""
+        a = np.ascontiguousarray(src_xyz, np.int16)
+        b = np.ascontiguousarray(src_rgb, np.uint8)
+        nm = None if normals is None else np.ascontiguousarray(normals, np.float64)
+        out = np.zeros((3, 8), np.float64)
+        counts = np.zeros(2, np.int64)
+        _check(self.L.tmc2_metrics_compute_frame_source(self.h, C.c_int(which), _ptr(a), _ptr(b), C.c_uint64(len(a)),
+                                                        None if nm is None else _ptr(nm), C.c_double(resolution), _ptr(out), _ptr(counts)))
+        return out, counts
+
     def kdtree_build(self):
         _check(self.L.tmc2_kdtree_build(self.h))
 

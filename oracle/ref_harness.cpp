@@ -1144,6 +1144,35 @@ int ref_gof_dropin_check( int device ) {
     bad |= 512;
   return bad;
 }
+
+// needs an MI355X, after ref_gof_phase_a / _b / (ref_gof_set_decoded_attribute) / _c: tmc2hip::DecoderDropIn::reconstructFrame --
+// the per-frame finish of PCCDecoder::decode -- from the context's own containers (patch list, decoded occupancy / geometry /
+// attribute frames) against the clouds the reference's members finished for the same GOF: positions, 16-bit colours, 8-bit
+// colours, boundary point types.  Bit mask per kind of difference (1, 2, 4, 8); negative: the drop-in failed.
+int ref_gof_decoder_dropin_check( int device ) {
+  Gof&                   G = *g_gof;
+  tmc2hip::DecoderDropIn D( device );
+  GeneratePointCloudParameters pp;
+  G.encoder.setPostProcessingSeiParameters( pp, G.context );
+  int bad = 0;
+  for ( size_t f = 0; f < G.context.size(); ++f ) {
+    PCCPointSet3 got;
+    const int    rc = D.reconstructFrame( G.context, f, G.encoder.params_.occupancyPrecision_, pp.gridSize_, pp.thresholdSmoothing_, got );
+    if ( rc != 0 ) {
+      fprintf( stderr, "ref_gof_decoder_dropin_check: frame %zu: status %d: %s\n", f, rc, D.lastError() );
+      return rc < 0 ? rc : -rc;
+    }
+    const PCCPointSet3& want = G.reconstructs[f];
+    if ( got.getPointCount() != want.getPointCount() ) return 1 << 20;
+    for ( size_t i = 0; i < want.getPointCount(); ++i ) {
+      if ( got[i] != want[i] ) bad |= 1;
+      if ( got.getColor16bit( i ) != want.getColor16bit( i ) ) bad |= 2;
+      if ( got.getColor( i ) != want.getColor( i ) ) bad |= 4;
+      if ( got.getBoundaryPointType( i ) != want.getBoundaryPointType( i ) ) bad |= 8;
+    }
+  }
+  return bad;
+}
 #endif
 
 // integration/tmc2hip_convert.cpp, applyPacking: the records the product's packers return for a frame (by index, with

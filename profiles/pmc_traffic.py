@@ -5,10 +5,24 @@ FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled.  WRITE_SIZE 
 usage: python profiles/pmc_traffic.py <fetch_dir> <write_dir> <workload> > profiles/r02_pmc_traffic.json"""
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+
+def source_stamp(root):
+    """sha1 over the kernel sources: bench.py recomputes it and drops `roofline.traffic` when the counters are of other code"""
+    h = hashlib.sha1()
+    csrc = os.path.join(root, "mpeg-pcc-tmc2_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
 
 STAGE_OF = {"knnKernel<16, true, true>": "knn_self", "knnKernel<8, false, true>": "knn8_recon_in_source",
             "knnKernel<1, false, true>": "knn1_source_in_recon", "normalsKernel<16>": "normals",
@@ -33,7 +47,8 @@ def per_kernel(directory, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 unit = 1024.0   # rocprofv3 reports both in KiB
-out = {"workload": sys.argv[3], "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), one frame in flight",
+out = {"workload": sys.argv[3], "source_sha1": source_stamp(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")),
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), one frame in flight",
        "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-byte requests as 64 bytes); WRITE_SIZE as reported",
        "stages": {}, "kernels": {}}
 for k in sorted(set(fetch) | set(write)):

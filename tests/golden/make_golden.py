@@ -266,7 +266,41 @@ def full_size(only=None):
               "%.0f s" % (time.time() - t), flush=True)
 
 
+FULL_SIZE_METRIC_CASES = ("longdress_vox10_ai_r3", "loot_vox10_ai_r3", "redandblack_vox10_ai_r3", "soldier_vox10_ai_r3",
+                          "basketball_player_vox11_ra_r5", "longdress_vox10_ra_r3_gof3")
+
+
+def full_size_metrics(only=None):
+    """S23 at BASELINE size: PCCMetrics::compute of the unmodified reference (duplicate removal, normal copy / scaling,
+    QualityMetrics::compute both ways) on frame 0 of every single-GOF case -- source cloud + the reference's own normals
+    against the reconstruction of its attribute-image step -- as raw doubles (3 x 8) and the two point counts."""
+    import time
+    ref = ob.Reference()
+    path = os.path.join(HERE, "full_size.npz")
+    out = dict(np.load(path))
+    for name in FULL_SIZE_METRIC_CASES:
+        if only and name not in only:
+            continue
+        c = FULL_SIZE_CASES[name]
+        t = time.time()
+        frames = [synth_cloud(c["workload"], f) for f in range(c["frames"])]
+        a = ref.phase_a(frames, c["iterations"], c["bits3d"], c["precision"], c["min_w"], c["min_h"], c["pack"], c["vox_dim"])
+        b = ref.phase_b(frames, a, c["precision"])
+        assert digest(b[0]["recon_xyz"]) == str(out[name + "/f0_recon_xyz_md5"])
+        nrm = ref.normals(frames[0][0], 16, True)
+        q, counts = ref.metrics(frames[0][0], frames[0][1], b[0]["recon_xyz"], b[0]["recon_rgb"], nrm, float((1 << (c["bits3d"] - 1)) - 1))
+        q0, counts0 = ref.metrics(frames[0][0], frames[0][1], b[0]["recon_xyz"], b[0]["recon_rgb"], None, float((1 << (c["bits3d"] - 1)) - 1))
+        out[name + "/f0_metrics"], out[name + "/f0_metric_counts"] = q, counts
+        out[name + "/f0_metrics_no_normals"] = q0
+        out[name + "/f0_normals_md5"] = np.array(digest(nrm))
+        np.savez_compressed(path, **out)
+        print(name, "counts", counts.tolist(), "D1 psnr %.4f D2 psnr %.4f Y psnr %.4f" % (q[2, 1], q[2, 3], q[2, 7]), "%.0f s" % (time.time() - t), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "full_size_metrics":
+        full_size_metrics(sys.argv[2:])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full_size":
         full_size(sys.argv[2:])
         sys.exit(0)

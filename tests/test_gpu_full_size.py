@@ -67,8 +67,62 @@ def test_gpu_full_size_matches_golden(name):
             patches = fr.get_patches()[0][fr.get_patch_order()]
             per.append((patches, fr.get_geometry_images(), fr.get_reconstruction(), fr.get_attribute_images()))
         check_against_fixture(g, W, H, per)
+        if "f0_metrics" in g:
+            # S23 at BASELINE size on the RESIDENT clouds (tmc2_metrics_compute_frame): the 48-bit-key de-duplication, the
+            # 16-NN batches, normal copy / scaling and the ordered fp64 sums against PCCMetrics::compute of the unmodified
+            # reference, raw doubles.  (The frame's normals are the reference's: checked first.)
+            fr, res = frs[0], float((1 << (c["bits3d"] - 1)) - 1)
+            assert digest(fr.get_normals()) == str(g["f0_normals_md5"]), "normals of frame 0"
+            got, counts = enc.per_frame(frs[:1], lambda fr, i: fr.metrics_compute(0, True, res))[0]
+            assert counts.tolist() == g["f0_metric_counts"].tolist()
+            assert np.array_equal(got.view(np.uint64), g["f0_metrics"].view(np.uint64)), (got, g["f0_metrics"])
+            got, _ = enc.per_frame(frs[:1], lambda fr, i: fr.metrics_compute(0, False, res))[0]
+            assert np.array_equal(got.view(np.uint64), g["f0_metrics_no_normals"].view(np.uint64)), (got, g["f0_metrics_no_normals"])
     finally:
         enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_decoder_side(gpu_ctx):
+    """Config 5 at BASELINE size: a decoder-side frame (decoded patch records, occupancy video, geometry maps of a 0.84 M-point
+    longdress frame: no source cloud) -> generatePointCloud -> decoded attribute frames -> post-reconstruction tail -> D1 / D2 /
+    colour metric against the uncompressed frame.  The reconstruction equals the reference's (MD5 fixture); the finished cloud
+    and the metric equal what the encoder-side frame it was cut from gives (whose metric the fixture pins)."""
+    name = "longdress_vox10_ai_r3"
+    c, g = CASES[name], fixture(name)
+    xyz, rgb = synth_cloud(c["workload"], 0)
+    enc = gpu_ctx.frame(xyz, rgb)
+    enc.segmenter_compute(T.ctc_params(c["iterations"], c["bits3d"], enc.weight_normal(c["bits3d"], 0.6), c["vox_dim"]))
+    h = enc.encoder_pack_flexible(c["min_w"], 2, 1.0)
+    W, H = T.encoder_canvas_size([h], c["min_w"], c["min_w"], c["min_h"])
+    enc.encoder_generate_geometry_images(W, H, c["precision"])
+    enc.encoder_generate_attribute_images()
+    img = enc.get_geometry_images()
+    i420 = enc.encoder_attribute_to_yuv420(4)
+    patches = enc.get_patches()[0][enc.get_patch_order()]
+    sent = np.zeros(len(patches), patches.dtype)                     # only what the bitstream carries
+    for k in ("u0", "v0", "sizeU0", "sizeV0", "patchOrientation", "u1", "v1", "d1", "normalAxis", "tangentAxis", "bitangentAxis",
+              "projectionMode"):
+        sent[k] = patches[k]
+    sent["sizeU"], sent["sizeV"] = sent["sizeU0"] * 16, sent["sizeV0"] * 16
+    dec = gpu_ctx.decoder_frame(sent, W, H, c["precision"], img["occ_video"], np.stack([img["geo0"], img["geo1"]]))
+    dec.codec_generate_point_cloud()
+    rx, _, rp = dec.get_reconstruction(colors=False)
+    assert digest(rx) == str(g["f0_recon_xyz_md5"]) and digest(rp) == str(g["f0_point_to_pixel_md5"])
+    for fr in (dec, enc):
+        fr.codec_set_decoded_attribute_yuv420(i420, 0)
+        fr.codec_post_reconstruct(None)
+    a, b = dec.get_post_reconstruction(), enc.get_post_reconstruction()
+    for k in ("xyz", "colors16", "rgb", "boundary"):
+        assert np.array_equal(a[k], b[k]), k
+    assert int((a["boundary"] == 3).sum()) > 0                       # (the geometry smoothing moved points)
+    nrm, res = enc.get_normals(), float((1 << (c["bits3d"] - 1)) - 1)
+    for normals in (None, nrm):
+        got, gc = dec.metrics_compute_source(xyz, rgb, normals, 1, res)
+        exp, ec = enc.metrics_compute(1, normals is not None, res)
+        assert np.array_equal(gc, ec) and np.array_equal(got.view(np.uint64), exp.view(np.uint64)), (got, exp)
+        via_host, _ = gpu_ctx.metrics_compute(xyz, rgb, a["xyz"], a["rgb"], normals, res)
+        assert np.array_equal(got.view(np.uint64), via_host.view(np.uint64))
 
 
 def test_oracle_full_size_matches_golden(oracle):

@@ -51,3 +51,81 @@ def test_gpu_metrics_identity(gpu_ctx):
     got, counts = gpu_ctx.metrics_compute(xyz, rgb, xyz, rgb, None)
     assert counts[0] == counts[1] == len(xyz)
     assert got[2, 0] == 0.0 and np.isinf(got[2, 1]) and got[2, 4] == 0.0
+
+
+def shell_clouds(seed=3):
+    """Clouds whose nearest-neighbour groups are WIDE: around every centre of the source the reconstruction holds a whole shell
+    of lattice points at one squared distance -- 24 at d2 = 5, 30 at d2 = 9 (exactly the reference's last attempt) and 48 at
+    d2 = 14 (more than it ever asks for: the first 30 in k-d tree visiting order count).  The 16-neighbour search cannot
+    hold these groups; the reference extends its search 5, 10, .. 30 (PCCMetrics.cpp:91-96)."""
+    import itertools
+    rng = np.random.default_rng(seed)
+
+    def shell(d2):
+        r = range(-4, 5)
+        return np.array([p for p in itertools.product(r, r, r) if p[0] ** 2 + p[1] ** 2 + p[2] ** 2 == d2], np.int16)
+    centres, rec = [], []
+    for k, d2 in enumerate([5, 9, 14, 5, 9, 14, 14, 9]):
+        c = np.array([60 + 50 * (k % 4), 60 + 50 * (k // 4), 70], np.int16)
+        centres.append(c)
+        rec.append(shell(d2) + c)
+    filler = rng.integers(300, 900, (200, 3)).astype(np.int16)                  # ordinary neighbourhoods around both clouds
+    src = np.unique(np.concatenate([np.array(centres, np.int16), filler]), axis=0)
+    rec = np.unique(np.concatenate(rec + [filler + np.array([1, 0, 0], np.int16)]), axis=0)
+    src, rec = src[rng.permutation(len(src))], rec[rng.permutation(len(rec))]
+    nrm = rng.normal(size=(len(src), 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return src, rng.integers(0, 256, (len(src), 3)).astype(np.uint8), rec, rng.integers(0, 256, (len(rec), 3)).astype(np.uint8), nrm
+
+
+def test_gpu_metrics_wide_groups(gpu_ctx, oracle):
+    """16 or more equidistant nearest neighbours: the second attempt with 32 results (30 count) gives the reference's numbers,
+    in both directions and through scaleNormals (a centre votes for every member of its shell)."""
+    src, sc, rec, rc, nrm = shell_clouds()
+    for normals in (None, nrm):
+        gpu_ctx.stage_reset()
+        got, gc = gpu_ctx.metrics_compute(src, sc, rec, rc, normals)
+        assert gpu_ctx.stage_ms().get("metrics_wide_search", 0) == 1.0          # (the wide search really ran)
+        exp, ec = oracle.metrics(src, sc, rec, rc, normals)
+        assert np.array_equal(gc, ec) and np.array_equal(bits(got), bits(exp)), (got, exp)
+
+
+def test_gpu_metrics_wide_search_on_ordinary_clouds(gpu_ctx, oracle, monkeypatch):
+    """The 32-wide search on clouds that do not need it: a search for k results is a prefix of the search for more."""
+    monkeypatch.setenv("TMC2_METRICS_K", "32")
+    xyz, rgb = synth_cloud("small")
+    rec, col = _recon(oracle, xyz, rgb)
+    nrm = oracle.normals(xyz)
+    got, gc = gpu_ctx.metrics_compute(xyz, rgb, rec, col, nrm)
+    exp, ec = oracle.metrics(xyz, rgb, rec, col, nrm)
+    assert np.array_equal(gc, ec) and np.array_equal(bits(got), bits(exp)), (got, exp)
+
+
+def test_gpu_metrics_on_the_resident_frame(gpu_ctx, oracle):
+    """tmc2_metrics_compute_frame: the frame's own points / colours / normals against its resident reconstruction (nothing
+    uploaded) = tmc2_metrics_compute on the same clouds fetched to the host = the oracle; then the finished cloud of the
+    post-reconstruction tail."""
+    import tmc2_amd as T
+    xyz, rgb = synth_cloud("small")
+    fr = gpu_ctx.frame(xyz, rgb)
+    w = fr.weight_normal(11, 0.6)
+    fr.segmenter_compute(T.ctc_params(10, 11, w))
+    h = fr.encoder_pack_flexible(1280, 2, 1.0)
+    W, H = T.encoder_canvas_size([h], 1280, 1280, 1280)
+    fr.encoder_generate_geometry_images(W, H, 4)
+    fr.encoder_generate_attribute_images()
+    rx, rc, _ = fr.get_reconstruction()
+    nrm = fr.get_normals()
+    for use_normals in (False, True):
+        got, gc = fr.metrics_compute(0, use_normals)
+        exp, ec = oracle.metrics(xyz, rgb, rx, rc, nrm if use_normals else None)
+        assert np.array_equal(gc, ec) and np.array_equal(bits(got), bits(exp)), (got, exp)
+    with pytest.raises(T.Tmc2Error):
+        fr.metrics_compute(1, True)                                              # the tail has not run yet
+    i420 = fr.encoder_attribute_to_yuv420(4)
+    fr.codec_set_decoded_attribute_yuv420(i420, 0)
+    fr.codec_post_reconstruct(None)
+    post = fr.get_post_reconstruction()
+    got, gc = fr.metrics_compute(1, True)
+    exp, ec = oracle.metrics(xyz, rgb, post["xyz"], post["rgb"], nrm)
+    assert np.array_equal(gc, ec) and np.array_equal(bits(got), bits(exp)), (got, exp)

@@ -153,3 +153,65 @@ def test_adaptor_apply_packed_list_rebuilds_the_reference_lists_under_random_acc
         lst, pool, match = np.ascontiguousarray(lst, dtype=T.lib.PATCH_DTYPE), np.ascontiguousarray(pool, np.uint8), np.ascontiguousarray(match, np.int32)
         tracked += int((match >= 0).sum())
         assert reference.L.ref_adaptor_check_packed_list(f, _p(rec), len(rec), _p(lst), _p(match), _p(pool), len(lst)) == 0, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_adaptor_metrics_object_is_a_drop_in(adaptor, oracle, with_normals):
+    """On an MI355X: tmc2hip::MetricsDropIn in the place of the PCCMetrics object of PccAppEncoder / PccAppDecoder /
+    PccAppMetrics -- setParameters, compute( sources, reconstructs, normals ), display() -- against the reference's own
+    object on a 2-frame group: every number as raw doubles and the text display() prints."""
+    frames = [synth_cloud("small", f) for f in range(2)]
+    a = oracle.phase_a(frames, 10)
+    b = oracle.phase_b(frames, a)
+    sx = np.ascontiguousarray(np.concatenate([f[0] for f in frames]), np.int16)
+    sc = np.ascontiguousarray(np.concatenate([f[1] for f in frames]), np.uint8)
+    rx = np.ascontiguousarray(np.concatenate([x["recon_xyz"] for x in b]), np.int16)
+    rc = np.ascontiguousarray(np.concatenate([x["recon_rgb"] for x in b]), np.uint8)
+    n = np.array([len(f[0]) for f in frames], np.int64)
+    m = np.array([len(x["recon_xyz"]) for x in b], np.int64)
+    nrm = np.ascontiguousarray(np.concatenate([oracle.normals(f[0]) for f in frames]), np.float64) if with_normals else None
+    bad = adaptor.adaptor_check_metrics(0, len(frames), _p(sx), _p(sc), _p(n), _p(rx), _p(rc), _p(m), None if nrm is None else _p(nrm),
+                                        C.c_double(1023.0))
+    assert bad == 0, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 8, 16])
+def test_adaptor_kdtree_is_a_drop_in(adaptor, k):
+    """On an MI355X: tmc2hip::KdTreeDropIn (tree resident in HBM, a batch of queries per call) against PCCKdTree::search on the
+    same cloud: indices -- including the order among equidistant neighbours -- and squared distances, for the cloud's own
+    points and for points off the cloud."""
+    xyz, _ = synth_cloud("small", 0)
+    rng = np.random.default_rng(5)
+    q = np.concatenate([xyz[rng.permutation(len(xyz))[:3000]], rng.integers(0, 1024, (1000, 3)).astype(np.int16)])
+    x, q = np.ascontiguousarray(xyz, np.int16), np.ascontiguousarray(q, np.int16)
+    assert adaptor.adaptor_check_kdtree(0, _p(x), C.c_size_t(len(x)), _p(q), C.c_size_t(len(q)), k) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nframes,prec", [("small", 2, 4), ("tiny", 3, 2)])
+def test_adaptor_decoder_finish_is_a_drop_in(adaptor, oracle, name, nframes, prec):
+    """On an MI355X: tmc2hip::DecoderDropIn::reconstructFrame -- the per-frame finish of PCCDecoder::decode (occupancy map and
+    blockToPatch from the decoded occupancy video, generatePointCloud, colorPointCloud, grid smoothing, transferColors16bitBP,
+    convertYUV16ToRGB8) from the reference's own PCCContext -- against the clouds the reference's members finish for the
+    same GOF: positions, 16-bit and 8-bit colours, boundary point types."""
+    L = adaptor
+    frames = [synth_cloud(name, f) for f in range(nframes)]
+    assert L.ref_gof_begin2(len(frames), 10, 10, prec, 1280, 1280, 0) == 0
+    keep = []
+    for i, (xyz, rgb) in enumerate(frames):
+        x, c = np.ascontiguousarray(xyz, np.int16), np.ascontiguousarray(rgb, np.uint8)
+        keep.append((x, c))
+        L.ref_gof_set_frame(i, _p(x), _p(c), C.c_size_t(len(x)))
+    assert L.ref_gof_phase_a() == 0 and L.ref_gof_phase_b() == 0
+    w, h = C.c_int(), C.c_int()
+    L.ref_gof_frame_size(C.byref(w), C.byref(h))
+    for i in range(nframes):                                   # the attribute video through the colour conversion and back
+        att = np.zeros((2, 3, h.value, w.value), np.uint8)
+        assert L.ref_gof_get_attribute_images(i, _p(att)) == 0
+        dec = np.ascontiguousarray(np.stack([oracle.convert_yuv420_to_yuv444(*oracle.convert_rgb444_to_yuv420(att[m])) for m in range(2)]),
+                                   np.uint16)
+        assert L.ref_gof_set_decoded_attribute(i, _p(dec)) == 0
+    assert L.ref_gof_phase_c() == 0
+    assert L.ref_gof_decoder_dropin_check(0) == 0

@@ -536,3 +536,15 @@ def test_oracle_whole_path_matches_reference_on_degenerate_gofs(oracle, referenc
     for x, y in zip(reference.phase_c(rb, dec), oracle.phase_c(oa, ob_, dec, prec)):
         for k in x:
             assert np.array_equal(x[k], y[k]), k
+
+
+def test_oracle_metrics_wide_groups_match_reference(oracle, reference):
+    """Nearest-neighbour groups of 24, 30 and 48 equidistant points: the search extension 5, 10, .. 30 of
+    QualityMetrics::compute / scaleNormals (PCCMetrics.cpp:91-96, PCCPointSet.cpp:2340-2368), restatement against the compiled
+    reference -- the clouds the GPU tier's wide-search test uses (tests/test_gpu_metrics.py::shell_clouds)."""
+    from test_gpu_metrics import shell_clouds
+    src, sc, rec, rc, nrm = shell_clouds()
+    for normals in (None, nrm):
+        qa, ca = oracle.metrics(src, sc, rec, rc, normals)
+        qb, cb = reference.metrics(src, sc, rec, rc, normals)
+        assert np.array_equal(ca, cb) and np.array_equal(bits(qa), bits(qb)), (qa, qb)
