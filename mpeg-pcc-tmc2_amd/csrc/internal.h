@@ -359,13 +359,34 @@ void resolveSeedSigns( size_t n, const OrientContraction& g, int kNN, const std:
                        const uint32_t* component, const std::function<const uint32_t*( size_t )>& rowOf,
                        const std::function<const double*( size_t, int )>& normalOf, const int16_t* xyz0,
                        int8_t* clusterSign );
-int gatherSeedTables( tmc2_frame* f, const std::vector<uint32_t>& seeds, std::vector<uint32_t>& rows, std::vector<double>& normals );
+// the contracted graph in compact form (device contraction, orient_contract.hip): clusters numbered by first member, per
+// ordered pair of clusters the one light cross edge that can be accepted + the strong one-way edges
+struct OrientCompactEdge {
+  uint32_t u, v, c2, pad;  // start / end vertex (original indices: the tie order of the reference's queue), cluster of v
+  double   d;              // n_u . n_v on the original normals, negated if the parities of u and v differ
+};
+struct OrientClusterRec {
+  uint32_t off;        // edges of cluster c: edges[rec[c].off .. rec[c + 1].off)
+  uint32_t seedPoint;  // first member (smallest index) of the cluster
+  uint32_t seedParity; // its parity
+};
+struct OrientCompact {
+  uint32_t                 clusters;
+  const OrientClusterRec*  rec;  // [clusters + 1]
+  const OrientCompactEdge* edges;
+};
+bool orientCompactSigns( const OrientCompact& g, double tau, int8_t* clusterSign, uint32_t* component, std::vector<uint32_t>& seeds,
+                         std::vector<uint32_t>& seedClusters );
+void resolveSeedSignsCompact( const OrientCompact& g, int kNN, const std::vector<uint32_t>& seeds, const std::vector<uint32_t>& seedClusters,
+                              const uint32_t* component, const uint32_t* who, const double* normals, const int16_t* xyz0, int8_t* clusterSign );
+int gatherSeedTables( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const std::vector<uint32_t>& seeds,
+                      std::vector<uint32_t>& who, std::vector<double>& normals );
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
                              const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction );
 double orientFirstTau();
-int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_root,
-                               DevBuf<uint8_t>& d_parity, OrientContraction& g, bool& ok );
-int launchClusterSigns( tmc2_frame* f, const uint32_t* d_root, const uint8_t* d_parity, const int8_t* d_clusterSign,
+int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_cid,
+                               DevBuf<uint8_t>& d_parity, OrientCompact& g, bool& ok );
+int launchClusterSigns( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const int8_t* d_clusterSign,
                         int8_t* d_sign );
 int launchInitialSegmentation( tmc2_frame* f, const double weight[3] );
 int weightNormal( tmc2_frame* f, int bits, double minWeightEPP, double w[3] );

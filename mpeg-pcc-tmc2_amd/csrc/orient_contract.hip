@@ -29,41 +29,35 @@ __device__ __forceinline__ uint32_t ballot16( bool pred, int lane ) {  // the 16
   return uint32_t( __ballot( pred ) >> ( lane & 48 ) ) & 0xFFFFu;
 }
 
-// bit j: knn[u][j] is a mutual strong neighbour of u (mutual bits: ensureMutualMask, shared with S7)
-template <int K>
-__global__ __launch_bounds__( 256 ) void strongMutualMaskKernel( const uint16_t* __restrict__ mutual, const double* __restrict__ edgeDot,
-                                                                  uint32_t n, double tau, uint16_t* __restrict__ mask ) {
-  static_assert( K == 16, "16 lanes per point" );
-  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
-  const bool     in = u < n;
-  const bool     strong = in && ( ( mutual[u] >> j ) & 1u ) && fabs( edgeDot[size_t( u ) * K + j] ) >= tau;
-  const uint32_t out    = ballot16( strong, lane );
-  if ( in && j == 0 ) mask[u] = uint16_t( out );
-}
-
 // Initial forest without a single atomic: every point hooks itself under the mutual strong neighbour of smallest hashed
 // priority, if that is smaller than its own (priorities strictly decrease along parent links: no cycles; the word
 // states a true relation).  Most of the union work is done before the first compare-and-swap, and the paths the
 // union pass walks end at local priority minima a few steps away.
 template <int K>
 __global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                           const uint16_t* __restrict__ mask, uint32_t n,
-                                                           uint32_t* __restrict__ word, uint32_t* __restrict__ count ) {
+                                                           const uint16_t* __restrict__ mutual, double tau, uint32_t n,
+                                                           uint16_t* __restrict__ mask, uint32_t* __restrict__ word,
+                                                           uint32_t* __restrict__ count ) {
   static_assert( K == 16, "16 lanes per point" );
   const uint32_t i = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15;
+  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
   if ( i > n ) return;  // (uniform over the 16 lanes of a point)
   if ( i == n ) {
     if ( j == 0 ) count[n] = 0;
     return;
   }
+  // bit j of mask[i]: neighbour j is a mutual strong one (mutual bits: ensureMutualMask, shared with S7)
+  const double dj   = edgeDot[size_t( i ) * K + j];
+  const bool   cand = ( ( mutual[i] >> j ) & 1u ) && fabs( dj ) >= tau;
+  {
+    const uint32_t bits = ballot16( cand, lane );
+    if ( j == 0 ) mask[i] = uint16_t( bits );
+  }
   // candidate of this lane: neighbour j if it is a mutual strong one, else the point itself (first minimum wins below, as
   // the sequential scan over the set bits in ascending j did: strict "<" kept the earliest)
-  const bool     cand = ( mask[i] >> j ) & 1u;
   const uint32_t v    = cand ? knn[size_t( i ) * K + j] : i;
   uint32_t       prio = cand ? ufPriority( v ) : 0xFFFFFFFFu;
-  uint32_t       best = v, parity = cand && edgeDot[size_t( i ) * K + j] < 0.0 ? 1u : 0u;
+  uint32_t       best = v, parity = cand && dj < 0.0 ? 1u : 0u;
   uint32_t       slot = uint32_t( j );
 #pragma unroll
   for ( int off = 8; off > 0; off >>= 1 ) {  // minimum of (priority, j) over the 16 lanes
@@ -188,84 +182,173 @@ __global__ __launch_bounds__( 256 ) void parityCheckKernel( const uint32_t* __re
 }
 
 __global__ __launch_bounds__( 256 ) void flattenKernel( uint32_t n, uint32_t* __restrict__ word, uint32_t* __restrict__ root,
-                                                         uint8_t* __restrict__ parity, bool agent ) {
+                                                         uint8_t* __restrict__ parity, uint32_t* __restrict__ minIdx, bool agent ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if ( u >= n ) return;
   uint32_t       p;
   const uint32_t r = parityFind( word, u, p, agent );
   root[u]          = r;
   parity[u]        = uint8_t( p );
+  // first member of the cluster (the running minimum only falls: look before the atomic -- the early points of a big cluster
+  // settle it, the other hundred thousand skip)
+  if ( minIdx && u < loadStaleOk( &minIdx[r] ) ) atomicMin( &minIdx[r], u );
 }
 
-// every mutual strong edge against the settled parities; cross edges counted per source cluster
+// ---- compact form of the contracted graph ---------------------------------------------------------------------------------
+// What the host walk needs is small: the clusters (~ 18 K at longdress size), numbered in the order of their first member (the
+// order the walk opens components in), and per ordered pair of clusters (c, c2) ONE light cross edge -- the best one in the
+// reference's edge order (|n_u . n_v|, start, end): a cluster's cross edges are all offered the moment it is absorbed, and of
+// the offers into one target cluster only the best can ever be accepted (edges that tie in |n_u . n_v| all go: the walk's heap
+// orders them by start and end) -- plus one strong (one-way) cross edge per implied relative sign (they absorb the target at once; a pair that carries both signs is what the walk reports as inconsistent).
+// 540 K cross edges become ~ 130 K, and every per-point array of the walk (3.3 MB each, randomly accessed) a per-cluster
+// one that stays in the host's L1 / L2.  Pairs are found in an open-addressing hash table in HBM (key = the two cluster
+// ids; a probe sequence that runs too long raises the overflow flag and the frame takes the edge list as it is).
+struct PairTable {
+  unsigned long long *key, *bestW;  // key: (c + 1) << 32 | c2; bestW: the largest |d| (as bits) among the pair's light edges
+  uint32_t*           strongSeen;   // bit s: a strong edge of implied relative sign s has been kept
+  uint32_t            mask;         // capacity - 1 (a power of two)
+};
+constexpr int kPairProbes = 128;
+
+__device__ __forceinline__ uint32_t pairHash( uint32_t c, uint32_t c2 ) {
+  unsigned long long h = ( (unsigned long long)c << 32 | c2 ) * 0x9E3779B97F4A7C15ull;
+  return uint32_t( h >> 29 );
+}
+// slot of the pair (c, c2), claimed if new; 0xFFFFFFFF: the table is too full here
+__device__ __forceinline__ uint32_t pairSlot( const PairTable& t, uint32_t c, uint32_t c2, bool insert ) {
+  const unsigned long long key = ( (unsigned long long)( c + 1u ) << 32 ) | c2;
+  uint32_t                 s   = pairHash( c, c2 ) & t.mask;
+  for ( int probe = 0; probe < kPairProbes; ++probe ) {
+    unsigned long long k = __hip_atomic_load( &t.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( k == 0 && insert ) {
+      const unsigned long long prev = atomicCAS( &t.key[s], 0ull, key );
+      k                             = prev == 0 ? key : prev;
+    }
+    if ( k == key ) return s;
+    if ( k == 0 ) return 0xFFFFFFFFu;  // (lookup of a pair that was never inserted: cannot happen after a clean insert pass)
+    s = ( s + 1 ) & t.mask;
+  }
+  return 0xFFFFFFFFu;
+}
+
+// first member of every cluster (flattenKernel took the minima): the clusters are numbered in that order
+__global__ __launch_bounds__( 256 ) void clusterFlagKernel( const uint32_t* __restrict__ root, const uint32_t* __restrict__ minIdx, uint32_t n,
+                                                             uint32_t* __restrict__ flag ) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( u < n ) flag[u] = minIdx[root[u]] == u ? 1u : 0u;
+}
+// pass 1 over the edges (16 lanes per point, lane j = edge j): the cluster ids (rank of the cluster's first member), the
+// mutual strong edges against the settled parities, the cross edges into the pair table -- light ones raise the pair's best |d|
 template <int K>
-__global__ __launch_bounds__( 256 ) void verifyCountKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                             const uint16_t* __restrict__ mask, const uint32_t* __restrict__ root,
-                                                             const uint8_t* __restrict__ parity, uint32_t n,
-                                                             uint32_t* __restrict__ count, uint16_t* __restrict__ crossMask,
-                                                             uint32_t* __restrict__ bad ) {
+__global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
+                                                            const uint16_t* __restrict__ mask, const uint32_t* __restrict__ root,
+                                                            const uint32_t* __restrict__ minIdx, const uint32_t* __restrict__ rank,
+                                                            const uint8_t* __restrict__ parity, uint32_t n, double tau, PairTable t,
+                                                            uint32_t* __restrict__ cid, uint16_t* __restrict__ crossMask,
+                                                            uint32_t* __restrict__ flags /* [0] bad, [2] overflow */ ) {
   static_assert( K == 16, "16 lanes per point" );
   const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
   const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
   const bool     in = u < n;
-  bool           isCross = false, wrong = false;
-  uint32_t       ru = 0;
+  bool           isCross = false, wrong = false, full = false;
   if ( in ) {
-    ru                 = root[u];
-    const uint32_t v   = knn[size_t( u ) * K + j];
-    isCross            = root[v] != ru;
-    if ( ( mask[u] >> j ) & 1u ) {
-      const uint32_t s = edgeDot[size_t( u ) * K + j] < 0.0 ? 1u : 0u;
-      wrong            = ( uint32_t( parity[u] ) ^ parity[v] ) != s;
+    const uint32_t cu = rank[minIdx[root[u]]], v = knn[size_t( u ) * K + j], cv = rank[minIdx[root[v]]];
+    const double   d  = edgeDot[size_t( u ) * K + j];
+    if ( j == 0 ) cid[u] = cu;
+    isCross = cv != cu;
+    if ( ( mask[u] >> j ) & 1u ) wrong = ( uint32_t( parity[u] ) ^ parity[v] ) != ( d < 0.0 ? 1u : 0u );
+    if ( isCross ) {
+      const uint32_t s = pairSlot( t, cu, cv, true );
+      if ( s == 0xFFFFFFFFu )
+        full = true;
+      else if ( fabs( d ) < tau ) {
+        const unsigned long long w = (unsigned long long)__double_as_longlong( fabs( d ) );
+        if ( w > __hip_atomic_load( &t.bestW[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &t.bestW[s], w );
+      }
     }
   }
-  const uint32_t cross = ballot16( isCross, lane );  // bit j: edge j leaves the cluster (kept for the scatter pass)
-  if ( __ballot( wrong ) && lane == 0 ) *bad = 1u;
+  const uint32_t cross = ballot16( isCross, lane );
+  if ( __ballot( wrong ) && lane == 0 ) flags[0] = 1u;
+  if ( __ballot( full ) && lane == 0 ) flags[2] = 1u;
   if ( in && j == 0 ) crossMask[u] = uint16_t( cross );
-  // A smooth body part is ONE cluster of 100 K points: tens of thousands of reports on one counter, ~ 10 ns each, were most of
-  // this kernel.  The 16 points of a workgroup are neighbours in index order and mostly share their cluster: the first of
-  // them with a given root reports for all.
-  __shared__ uint32_t sRoot[16], sCross[16];
-  const int p = threadIdx.x >> 4;
-  if ( j == 0 ) sRoot[p] = in ? ru : 0xFFFFFFFFu, sCross[p] = in ? uint32_t( __popc( cross ) ) : 0u;
+}
+// pass 2: the edges the walk gets -- bit j of keepMask[u] -- and their number per source cluster (one report per workgroup and
+// cluster, as verifyCountKernel).  dedupe = false: every cross edge (the table overflowed).
+template <int K>
+__global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
+                                                            const uint16_t* __restrict__ crossMask, const uint32_t* __restrict__ cid,
+                                                            const uint8_t* __restrict__ parity, uint32_t n, double tau, PairTable t,
+                                                            int dedupe, uint16_t* __restrict__ keepMask, uint32_t* __restrict__ count ) {
+  static_assert( K == 16, "16 lanes per point" );
+  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
+  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const bool     in = u < n;
+  bool           keep = false;
+  uint32_t       cu = 0xFFFFFFFFu;
+  if ( in ) {
+    cu   = cid[u];
+    keep = ( crossMask[u] >> j ) & 1u;
+    if ( keep && dedupe ) {
+      const uint32_t v = knn[size_t( u ) * K + j];
+      const double   d = edgeDot[size_t( u ) * K + j];
+      const uint32_t s = pairSlot( t, cu, cid[v], false );
+      if ( s == 0xFFFFFFFFu ) {
+        keep = true;  // (unreachable after a clean insert pass; harmless: an extra edge)
+      } else if ( fabs( d ) >= tau ) {
+        const uint32_t bit = 1u << ( ( d < 0.0 ? 1u : 0u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) );
+        keep               = !( atomicOr( &t.strongSeen[s], bit ) & bit );
+      } else {
+        keep = (unsigned long long)__double_as_longlong( fabs( d ) ) == t.bestW[s];
+      }
+    }
+  }
+  const uint32_t kept = ballot16( keep, lane );
+  if ( in && j == 0 ) keepMask[u] = uint16_t( kept );
+  __shared__ uint32_t sCid[16], sKept[16];
+  const int           p = threadIdx.x >> 4;
+  if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( kept ) );
   __syncthreads();
   if ( in && j == 0 ) {
     bool     first = true;
     uint32_t total = 0;
     for ( int q = 0; q < 16; ++q ) {
-      if ( sRoot[q] != ru ) continue;
+      if ( sCid[q] != cu ) continue;
       if ( q < p ) first = false;
-      total += sCross[q];
+      total += sKept[q];
     }
-    if ( first && total ) atomicAdd( &count[ru], total );
+    if ( first && total ) atomicAdd( &count[cu], total );
   }
 }
-
+// the kept edges, per source cluster, with the target cluster and the two ends' parities folded into the dot product
 template <int K>
-__global__ __launch_bounds__( 256 ) void scatterCrossKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                              const uint32_t* __restrict__ root, const uint32_t* __restrict__ off,
-                                                              const uint16_t* __restrict__ crossMask, uint32_t n,
-                                                              uint32_t* __restrict__ cursor, OrientCrossEdge* __restrict__ edges ) {
+__global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
+                                                                const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
+                                                                const uint32_t* __restrict__ off, const uint16_t* __restrict__ keepMask,
+                                                                const uint32_t* __restrict__ root, const uint32_t* __restrict__ minIdx,
+                                                                uint32_t n, uint32_t clusters, uint32_t* __restrict__ cursor,
+                                                                OrientCompactEdge* __restrict__ edges, OrientClusterRec* __restrict__ rec ) {
   static_assert( K == 16, "16 lanes per point" );
   const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
   const int      j = threadIdx.x & 15, p = threadIdx.x >> 4;
   const bool     in = u < n;
-  const uint32_t m  = in ? crossMask[u] : 0u;
-  // one reservation per (workgroup, cluster), as the counts were reported (verifyCountKernel): the first point of the
-  // workgroup with a given root reserves for all, the others take their share in index order
-  __shared__ uint32_t sRoot[16], sCross[16], sBase[16];
-  const uint32_t ru = in ? root[u] : 0xFFFFFFFFu;
-  if ( j == 0 ) sRoot[p] = ru, sCross[p] = uint32_t( __popc( m ) );
+  const uint32_t m  = in ? keepMask[u] : 0u;
+  __shared__ uint32_t sCid[16], sKept[16], sBase[16];
+  const uint32_t cu = in ? cid[u] : 0xFFFFFFFFu;
+  if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( m ) );
+  // the cluster's record, written by its first member: where its edges start, the seed point and its parity (one copy to the
+  // host instead of three); the sentinel record by the last point
+  if ( in && j == 0 && minIdx[root[u]] == u ) rec[cu] = OrientClusterRec{off[cu], u, parity[u]};
+  if ( in && j == 0 && u == n - 1 ) rec[clusters] = OrientClusterRec{off[clusters], 0u, 0u};
   __syncthreads();
   if ( j == 0 && m ) {
     bool     first = true;
     uint32_t total = 0;
     for ( int q = 0; q < 16; ++q ) {
-      if ( sRoot[q] != ru || !sCross[q] ) continue;
+      if ( sCid[q] != cu || !sKept[q] ) continue;
       if ( q < p ) first = false;
-      total += sCross[q];
+      total += sKept[q];
     }
-    if ( first ) sBase[p] = off[ru] + atomicAdd( &cursor[ru], total );
+    if ( first ) sBase[p] = off[cu] + atomicAdd( &cursor[cu], total );
   }
   __syncthreads();
   if ( !m ) return;  // (uniform over the 16 lanes of a point)
@@ -273,137 +356,167 @@ __global__ __launch_bounds__( 256 ) void scatterCrossKernel( const uint32_t* __r
   if ( j == 0 ) {
     int lead = p;
     for ( int q = 0; q < p; ++q ) {
-      if ( sRoot[q] != ru || !sCross[q] ) continue;
-      if ( lead == p ) lead = q;  // the first point of this root that has cross edges made the reservation
-      at += sCross[q];
+      if ( sCid[q] != cu || !sKept[q] ) continue;
+      if ( lead == p ) lead = q;
+      at += sKept[q];
     }
     at += sBase[lead];
   }
   at = __shfl( at, ( threadIdx.x & 63 ) & 48, 64 );
-  if ( ( m >> j ) & 1u )  // (edges of a point in ascending j, as the sequential scan over the set bits wrote them)
-    edges[at + __popc( m & ( ( 1u << j ) - 1u ) )] = OrientCrossEdge{u, knn[size_t( u ) * K + j], edgeDot[size_t( u ) * K + j]};
+  if ( ( m >> j ) & 1u ) {
+    const uint32_t v = knn[size_t( u ) * K + j];
+    const double   d = edgeDot[size_t( u ) * K + j];
+    edges[at + __popc( m & ( ( 1u << j ) - 1u ) )] = OrientCompactEdge{u, v, cid[v], 0u, ( ( parity[u] ^ parity[v] ) & 1 ) ? -d : d};
+  }
 }
 
-__global__ __launch_bounds__( 256 ) void clusterSignsKernel( const uint32_t* __restrict__ root, const uint8_t* __restrict__ parity,
-                                                              const int8_t* __restrict__ clusterSign, uint32_t n,
-                                                              int8_t* __restrict__ sign ) {
+__global__ __launch_bounds__( 256 ) void compactSignsKernel( const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
+                                                              const int8_t* __restrict__ clusterSign, uint32_t n, int8_t* __restrict__ sign ) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u < n ) sign[u] = int8_t( parity[u] ? -clusterSign[root[u]] : clusterSign[root[u]] );
+  if ( u < n ) sign[u] = int8_t( parity[u] ? -clusterSign[cid[u]] : clusterSign[cid[u]] );
 }
 
-// inputs of the reference's seed rule for the listed seeds: their k-NN rows and the normals of (0) the seed, (1) the
-// point before it in index order, (2 + t) its t-th neighbour
+// inputs of the reference's seed rule for the listed seeds, compact form: their k-NN rows' cluster ids and parities
+// ([count][K + 1]: entry 0 = the point before the seed in index order, 1 + t = neighbour t) and the normals of (0) the seed,
+// (1) the point before it, (2 + t) its t-th neighbour
 template <int K>
-__global__ __launch_bounds__( 256 ) void seedTableKernel( const uint32_t* __restrict__ seeds, uint32_t count,
-                                                           const uint32_t* __restrict__ knn, const double* __restrict__ normals,
-                                                           uint32_t* __restrict__ rows, double* __restrict__ out ) {
+__global__ __launch_bounds__( 256 ) void seedCompactKernel( const uint32_t* __restrict__ seeds, uint32_t count,
+                                                             const uint32_t* __restrict__ knn, const double* __restrict__ normals,
+                                                             const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
+                                                             uint32_t* __restrict__ who /* [count][K + 1][3]: point, cluster, parity */,
+                                                             double* __restrict__ out ) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if ( t >= count * ( K + 2 ) ) return;
   const uint32_t s = t / ( K + 2 ), j = t % ( K + 2 );
   const uint32_t i = seeds[s];
   const uint32_t v = j == 0 ? i : ( j == 1 ? ( i ? i - 1 : 0 ) : knn[size_t( i ) * K + ( j - 2 )] );
-  if ( j >= 2 ) rows[size_t( s ) * K + ( j - 2 )] = v;
+  if ( j >= 1 ) {
+    uint32_t* w = who + ( size_t( s ) * ( K + 1 ) + ( j - 1 ) ) * 3;
+    w[0] = v, w[1] = cid[v], w[2] = parity[v];
+  }
   for ( int c = 0; c < 3; ++c ) out[3 * size_t( t ) + c] = normals[3 * size_t( v ) + c];
 }
 
 }  // namespace
 
-// rows: [count][16], normals: [count][18][3] (host vectors), for the seeds the walk has listed
-int gatherSeedTables( tmc2_frame* f, const std::vector<uint32_t>& seeds, std::vector<uint32_t>& rows, std::vector<double>& normals ) {
+// who: [count][17][3] (point, cluster, parity of: the point before the seed, then its 16 neighbours), normals: [count][18][3]
+// (host vectors), for the seeds the walk has listed
+int gatherSeedTables( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const std::vector<uint32_t>& seeds,
+                      std::vector<uint32_t>& who, std::vector<double>& normals ) {
   const uint32_t count = uint32_t( seeds.size() );
-  rows.assign( size_t( count ) * 16, 0 );
+  who.assign( size_t( count ) * 17 * 3, 0 );
   normals.assign( size_t( count ) * 18 * 3, 0.0 );
   if ( !count ) return TMC2_OK;
   hipStream_t      s = f->ctx->stream;
-  DevBuf<uint32_t> d_seeds, d_rows;
+  DevBuf<uint32_t> d_seeds, d_who;
   DevBuf<double>   d_out;
   TMC2_TRY( d_seeds.alloc( count ) );
-  TMC2_TRY( d_rows.alloc( size_t( count ) * 16 ) );
-  TMC2_TRY( d_out.alloc( size_t( count ) * 18 * 3 ) );
+  TMC2_TRY( d_who.alloc( who.size() ) );
+  TMC2_TRY( d_out.alloc( normals.size() ) );
   TMC2_HIP( hipMemcpyAsync( d_seeds.p, seeds.data(), size_t( count ) * 4, hipMemcpyHostToDevice, s ) );
-  hipLaunchKernelGGL( seedTableKernel<16>, dim3( ( count * 18 + 255 ) / 256 ), dim3( 256 ), 0, s, d_seeds.p, count, f->d_knn.p,
-                      f->d_normals.p, d_rows.p, d_out.p );
-  TMC2_HIP( hipMemcpyAsync( rows.data(), d_rows.p, rows.size() * 4, hipMemcpyDeviceToHost, s ) );
+  hipLaunchKernelGGL( seedCompactKernel<16>, dim3( ( count * 18 + 255 ) / 256 ), dim3( 256 ), 0, s, d_seeds.p, count, f->d_knn.p,
+                      f->d_normals.p, d_cid, d_parity, d_who.p, d_out.p );
+  TMC2_HIP( hipMemcpyAsync( who.data(), d_who.p, who.size() * 4, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipMemcpyAsync( normals.data(), d_out.p, normals.size() * 8, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   return TMC2_OK;
 }
 
-// Contracts the orientation graph of frame f on the device (k = 16) and brings it to the host (page-locked staging of the
-// context).  ok = false: some cluster's strong edges disagree.  d_root / d_parity stay valid for launchClusterSigns.
-int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_root,
-                               DevBuf<uint8_t>& d_parity, OrientContraction& g, bool& ok ) {
+// Contracts the orientation graph of frame f on the device (k = 16) and brings its COMPACT form to the host (page-locked
+// staging of the context): clusters numbered by first member, one light cross edge per ordered pair of clusters (+ the strong
+// one-way ones).  ok = false: some cluster's strong edges disagree.  d_cid / d_parity stay valid for launchClusterSigns.
+int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_cid, DevBuf<uint8_t>& d_parity,
+                               OrientCompact& g, bool& ok ) {
   tmc2_ctx*      ctx = f->ctx;
   hipStream_t    s   = ctx->stream;
   const uint32_t n   = uint32_t( f->n );
   ok                 = false;
   if ( f->k != 16 ) return TMC2_OK;  // not instantiated: the caller walks the points
-  DevBuf<uint32_t> d_word, d_count, d_off, d_cursor, d_small;
-  DevBuf<uint16_t> d_mask;
+  DevBuf<uint32_t> d_word, d_count, d_off, d_cursor, d_small, d_root, d_minIdx, d_flag, d_rank, d_strongSeen;
+  DevBuf<uint16_t> d_mask, d_crossMask, d_keepMask;
+  DevBuf<unsigned long long> d_pairs;
   TMC2_TRY( d_word.alloc( n ) );
-  TMC2_TRY( d_count.alloc( size_t( n ) + 1 ) );
-  TMC2_TRY( d_off.alloc( size_t( n ) + 1 ) );
-  TMC2_TRY( d_cursor.alloc( n ) );
-  TMC2_TRY( d_small.alloc( 4 ) );  // [0] bad flag, [1] total cross edges
+  TMC2_TRY( d_small.alloc( 8 ) );  // [0] bad flag, [1] kept cross edges, [2] pair table overflow, [3] clusters; [4], [5]: debug check
   TMC2_TRY( d_mask.alloc( n ) );
   TMC2_TRY( d_root.alloc( n ) );
+  TMC2_TRY( d_minIdx.alloc( n ) );
+  TMC2_TRY( d_flag.alloc( n ) );
+  TMC2_TRY( d_rank.alloc( n ) );
+  TMC2_TRY( d_cid.alloc( n ) );
   TMC2_TRY( d_parity.alloc( n ) );
+  TMC2_TRY( d_crossMask.alloc( n ) );
+  TMC2_TRY( d_keepMask.alloc( n ) );
+  // (test hook TMC2_ORIENT_PAIRS: log2 of the pair table's capacity; small values force the overflow path)
+  const char*    pairsEnv = getenv( "TMC2_ORIENT_PAIRS" );
+  const uint32_t pairCap  = 1u << ( pairsEnv ? std::min( 24, std::max( 4, atoi( pairsEnv ) ) ) : 20 );
+  TMC2_TRY( d_pairs.alloc( 2 * size_t( pairCap ) ) );
+  TMC2_TRY( d_strongSeen.alloc( pairCap ) );
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
-  TMC2_TRY( fillRegions( ctx, {{d_small.p, 16, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
+  TMC2_TRY( fillRegions( ctx, {{d_small.p, 32, 0},
+                               {d_minIdx.p, size_t( n ) * 4, 0xFF},
+                               {d_pairs.p, 2 * size_t( pairCap ) * 8, 0},
+                               {d_strongSeen.p, size_t( pairCap ) * 4, 0}} ) );
   TMC2_TRY( ensureMutualMask( f ) );
-  const dim3 grdN16( ( n + 15 ) / 16 ), grdN16p( ( n + 16 ) / 16 );  // 16 lanes per point (... and one more "point" for count[n])
-  hipLaunchKernelGGL( strongMutualMaskKernel<16>, grdN16, blk, 0, s, f->d_mutual.p, d_edgeDot, n, tau, d_mask.p );
-  hipLaunchKernelGGL( initWordsKernel<16>, grdN16p, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, d_count.p );
+  const dim3 grdN16( ( n + 15 ) / 16 );  // 16 lanes per point
+  TMC2_TRY( d_count.alloc( size_t( n ) + 1 ) );  // (initWordsKernel zeroes it; later: kept edges per cluster, C + 1 used)
+  hipLaunchKernelGGL( initWordsKernel<16>, dim3( ( n + 16 ) / 16 ), blk, 0, s, f->d_knn.p, d_edgeDot, f->d_mutual.p, tau, n, d_mask.p,
+                      d_word.p, d_count.p );
   hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, unionPrecheck(), unionAgentScope() );
   if ( unionCheck() ) {  // debug invariants (soak tests): costs a round trip
     uint32_t bad[2] = {0, 0};
-    hipLaunchKernelGGL( parityCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mask.p, n, d_word.p, d_small.p + 2 );
-    TMC2_HIP( hipMemcpyAsync( bad, d_small.p + 2, 8, hipMemcpyDeviceToHost, s ) );
+    hipLaunchKernelGGL( parityCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mask.p, n, d_word.p, d_small.p + 4 );
+    TMC2_HIP( hipMemcpyAsync( bad, d_small.p + 4, 8, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
     if ( bad[0] | bad[1] ) {
       setError( "orientNormals: union-find invariant broken (%u bad links, %u split edges)", bad[0], bad[1] );
       return TMC2_E_HIP;
     }
   }
-  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p, unionAgentScope() );
-  DevBuf<uint16_t> d_crossMask;
-  TMC2_TRY( d_crossMask.alloc( n ) );
-  hipLaunchKernelGGL( verifyCountKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_parity.p, n,
-                      d_count.p, d_crossMask.p, d_small.p );
-  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
-  uint32_t head[2] = {0, 0};
-  TMC2_HIP( hipMemcpyAsync( head, d_small.p, 8, hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipStreamSynchronize( s ) );
-  if ( head[0] ) return TMC2_OK;  // inconsistent cluster
-  const uint32_t   E = head[1];
-  DevBuf<OrientCrossEdge> d_edges;
+  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p, d_minIdx.p, unionAgentScope() );
+  hipLaunchKernelGGL( clusterFlagKernel, grdN, blk, 0, s, d_root.p, d_minIdx.p, n, d_flag.p );
+  TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 3 ) );
+  TMC2_TRY( d_off.alloc( size_t( n ) + 1 ) );  // (per-cluster arrays sized for the worst case, n clusters: the used part is known
+  TMC2_TRY( d_cursor.alloc( n ) );            //  only after the round trip below)
+  PairTable t{d_pairs.p, d_pairs.p + pairCap, d_strongSeen.p, pairCap - 1};
+  hipLaunchKernelGGL( pairInsertKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_minIdx.p, d_rank.p, d_parity.p, n,
+                      tau, t, d_cid.p, d_crossMask.p, d_small.p );
+  uint32_t head[4] = {0, 0, 0, 0};
+  for ( int dedupe = 1; dedupe >= 0; --dedupe ) {
+    TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
+    hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, dedupe,
+                        d_keepMask.p, d_count.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
+    TMC2_HIP( hipMemcpyAsync( head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    if ( head[0] ) return TMC2_OK;  // inconsistent cluster
+    if ( !head[2] || !dedupe ) break;
+    ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
+  }
+  const uint32_t E = head[1], C = head[3];
+  DevBuf<OrientCompactEdge> d_edges;
+  DevBuf<OrientClusterRec>  d_rec;
   TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
-  hipLaunchKernelGGL( scatterCrossKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_root.p, d_off.p, d_crossMask.p, n,
-                      d_cursor.p, d_edges.p );
-  uint32_t*        h_root   = ctx->hostA.get<uint32_t>( 2 * size_t( n ) + 2 );  // root | off
-  uint8_t*         h_parity = ctx->hostC.get<uint8_t>( 2 * size_t( n ) );       // parity | (cluster signs, see the caller)
-  OrientCrossEdge* h_edges  = ctx->hostE.get<OrientCrossEdge>( std::max<uint32_t>( E, 1u ) );
-  if ( !h_root || !h_parity || !h_edges ) {
+  TMC2_TRY( d_rec.alloc( size_t( C ) + 1 ) );
+  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+                      d_minIdx.p, n, C, d_cursor.p, d_edges.p, d_rec.p );
+  OrientClusterRec*  h_rec   = ctx->hostA.get<OrientClusterRec>( size_t( C ) + 1 );
+  OrientCompactEdge* h_edges = ctx->hostE.get<OrientCompactEdge>( std::max<uint32_t>( E, 1u ) );
+  if ( !h_rec || !h_edges ) {
     setError( "orientNormals: hipHostMalloc failed" );
     return TMC2_E_HIP;
   }
-  uint32_t* h_off = h_root + n;
-  TMC2_HIP( hipMemcpyAsync( h_root, d_root.p, size_t( n ) * 4, hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipMemcpyAsync( h_off, d_off.p, ( size_t( n ) + 1 ) * 4, hipMemcpyDeviceToHost, s ) );
-  TMC2_HIP( hipMemcpyAsync( h_parity, d_parity.p, n, hipMemcpyDeviceToHost, s ) );
-  if ( E ) TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( E ) * sizeof( OrientCrossEdge ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( h_rec, d_rec.p, ( size_t( C ) + 1 ) * sizeof( OrientClusterRec ), hipMemcpyDeviceToHost, s ) );
+  if ( E ) TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( E ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
-  g.root = h_root, g.off = h_off, g.parity = h_parity, g.edges = h_edges;
-  ok     = true;
+  g.clusters = C, g.rec = h_rec, g.edges = h_edges;
+  ok         = true;
   return TMC2_OK;
 }
 
-// sign[v] = clusterSign[root[v]] * (-1)^parity[v]
-int launchClusterSigns( tmc2_frame* f, const uint32_t* d_root, const uint8_t* d_parity, const int8_t* d_clusterSign,
-                        int8_t* d_sign ) {
+// sign[v] = clusterSign[cluster of v] * (-1)^parity[v]
+int launchClusterSigns( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const int8_t* d_clusterSign, int8_t* d_sign ) {
   const uint32_t n = uint32_t( f->n );
-  hipLaunchKernelGGL( clusterSignsKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, f->ctx->stream, d_root, d_parity,
-                      d_clusterSign, n, d_sign );
+  hipLaunchKernelGGL( compactSignsKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, f->ctx->stream, d_cid, d_parity, d_clusterSign, n, d_sign );
   TMC2_HIP( hipGetLastError() );
   return TMC2_OK;
 }

@@ -395,6 +395,202 @@ void resolveSeedSigns( size_t n, const OrientContraction& g, int kNN, const std:
     if ( g.root[i] == i && compSign[component[i]] < 0 ) clusterSign[i] = int8_t( -clusterSign[i] );
 }
 
+// ---- the walk on the COMPACT contracted graph (device contraction) -----------------------------------------------------------
+// orientContractedSigns() with clusters as the only vertices: every array is per cluster (18 K entries instead of 0.84 M: the
+// whole working set sits in the host's L1 / L2), a cluster's edge list holds one light edge per target cluster (the only one of
+// its offers into that cluster that can be accepted) and the strong one-way edges, with the target cluster and the ends'
+// parities already folded in.  Clusters are numbered by first member, so "the smallest point not oriented yet" -- the next seed
+// -- is the first member of the first cluster not visited yet.
+namespace {
+struct ClusterHeap {  // indexed 4-ary max-heap, one pending entry per cluster; key = the reference's (|d|, start, end)
+  struct Entry {
+    double   d;
+    uint32_t v, s, c, pad;
+  };
+  std::vector<Entry>   heap;
+  std::vector<int32_t> st;  // slot of the cluster's entry, kAbsent, kVisited
+  explicit ClusterHeap( size_t clusters ) : st( clusters, kAbsent ) { heap.reserve( clusters / 2 + 16 ); }
+  static unsigned __int128 key( const Entry& e ) {
+    uint64_t w[2];
+    memcpy( w, &e, 16 );
+    return ( static_cast<unsigned __int128>( w[0] & 0x7FFFFFFFFFFFFFFFull ) << 64 ) | w[1];
+  }
+  void place( size_t i, const Entry& e ) {
+    heap[i]   = e;
+    st[e.c]   = int32_t( i );
+  }
+  void siftUp( size_t i ) {
+    const Entry e = heap[i];
+    while ( i > 0 ) {
+      const size_t p = ( i - 1 ) >> 2;
+      if ( !( key( heap[p] ) < key( e ) ) ) break;
+      place( i, heap[p] );
+      i = p;
+    }
+    place( i, e );
+  }
+  void siftDown( size_t i ) {
+    const size_t n = heap.size();
+    const Entry  e = heap[i];
+    for ( ;; ) {
+      const size_t c0 = 4 * i + 1;
+      if ( c0 >= n ) break;
+      size_t c = c0;
+      for ( size_t t = c0 + 1; t < std::min( c0 + 4, n ); ++t )
+        if ( key( heap[c] ) < key( heap[t] ) ) c = t;
+      if ( !( key( e ) < key( heap[c] ) ) ) break;
+      place( i, heap[c] );
+      i = c;
+    }
+    place( i, e );
+  }
+  void offer( uint32_t c, double d, uint32_t v, uint32_t start ) {
+    const Entry   cand{d, v, start, c, 0};
+    const int32_t pos = st[c];
+    if ( pos == kAbsent ) {
+      heap.push_back( cand );
+      siftUp( heap.size() - 1 );
+    } else if ( key( heap[size_t( pos )] ) < key( cand ) ) {
+      heap[size_t( pos )] = cand;
+      siftUp( size_t( pos ) );
+    }
+  }
+  void remove( size_t i ) {
+    const Entry last = heap.back();
+    heap.pop_back();
+    if ( i == heap.size() ) return;
+    const bool up = key( heap[i] ) < key( last );
+    heap[i]       = last;
+    st[last.c]    = int32_t( i );
+    if ( up )
+      siftUp( i );
+    else
+      siftDown( i );
+  }
+  Entry popMax() {
+    const Entry top  = heap[0];
+    const Entry last = heap.back();
+    heap.pop_back();
+    if ( !heap.empty() ) {
+      heap[0] = last;
+      siftDown( 0 );
+    }
+    st[top.c] = kVisited;
+    return top;
+  }
+};
+}  // namespace
+
+// clusterSign[c]: the sign of cluster c's root-relative frame (as orientContractedSigns); component[c]: the component it
+// belongs to; seeds / seedClusters: the first point and the cluster of every component, in the order they were opened
+bool orientCompactSigns( const OrientCompact& g, double tau, int8_t* clusterSign, uint32_t* component, std::vector<uint32_t>& seeds,
+                         std::vector<uint32_t>& seedClusters ) {
+  const uint32_t        C = g.clusters;
+  ClusterHeap           heap( C );
+  std::vector<uint32_t> phase( C, 0 ), queue;
+  for ( uint32_t c = 0; c < C; ++c ) clusterSign[c] = 1;
+  queue.reserve( 1 << 10 );
+  uint32_t epoch  = 0;
+  auto     absorb = [&]( uint32_t c0 ) -> bool {
+    ++epoch;
+    phase[c0] = epoch;
+    queue.clear();
+    queue.push_back( c0 );
+    for ( size_t head = 0; head < queue.size(); ++head ) {
+      const uint32_t c  = queue[head];
+      const double   sc = double( clusterSign[c] );
+      for ( uint32_t e = g.rec[c].off; e < g.rec[c + 1].off; ++e ) {
+        const OrientCompactEdge& x      = g.edges[e];
+        const uint32_t           c2     = x.c2;
+        const double             d      = sc * x.d;  // = sign[u] n_u.n_v (-1)^parity[v]
+        const bool               strong = std::fabs( x.d ) >= tau;
+        const int32_t            pv     = heap.st[c2];
+        if ( pv == kVisited ) {
+          if ( strong && phase[c2] == epoch && ( d < 0.0 ) != ( clusterSign[c2] < 0 ) ) return false;
+        } else if ( strong ) {
+          if ( pv >= 0 ) heap.remove( size_t( pv ) );
+          heap.st[c2]     = kVisited;
+          clusterSign[c2] = d < 0.0 ? -1 : 1;
+          phase[c2]       = epoch;
+          queue.push_back( c2 );
+        } else {
+          heap.offer( c2, d, x.v, x.u );
+        }
+      }
+    }
+    return true;
+  };
+  seeds.clear();
+  seedClusters.clear();
+  std::vector<uint32_t> firstEpoch;
+  for ( uint32_t c = 0; c < C; ++c ) {  // (clusters in the order of their first members)
+    if ( heap.st[c] == kVisited ) continue;
+    seeds.push_back( g.rec[c].seedPoint );
+    seedClusters.push_back( c );
+    heap.st[c]     = kVisited;
+    clusterSign[c] = int8_t( ( g.rec[c].seedParity & 1 ) ? -1 : 1 );  // the seed itself: +1 for now
+    firstEpoch.push_back( epoch + 1 );
+    if ( !absorb( c ) ) return false;
+    while ( !heap.heap.empty() ) {
+      const ClusterHeap::Entry e = heap.popMax();
+      clusterSign[e.c]           = e.d < 0.0 ? -1 : 1;
+      if ( !absorb( e.c ) ) return false;
+    }
+  }
+  for ( uint32_t c = 0; c < C; ++c )
+    component[c] = uint32_t( std::upper_bound( firstEpoch.begin(), firstEpoch.end(), phase[c] ) - firstEpoch.begin() ) - 1u;
+  return true;
+}
+
+// Seed rule after the compact walk.  who: [seeds][kNN + 1][3] = (point, cluster, parity) of the point before the seed in index
+// order and of its kNN neighbours; normals: [seeds][kNN + 2][3] = seed, point before, neighbours (gatherSeedTables).
+void resolveSeedSignsCompact( const OrientCompact& g, int kNN, const std::vector<uint32_t>& seeds, const std::vector<uint32_t>& seedClusters,
+                              const uint32_t* component, const uint32_t* who, const double* normals, const int16_t* xyz0, int8_t* clusterSign ) {
+  std::vector<int8_t> compSign( seeds.size(), 1 );
+  for ( size_t k = 0; k < seeds.size(); ++k ) {
+    const uint32_t  i   = seeds[k];
+    const uint32_t* w   = who + k * size_t( kNN + 1 ) * 3;
+    const double*   nrm = normals + k * size_t( kNN + 2 ) * 3;
+    // sign of entry t of `who` as it stood when seed k was picked: 0 if that point had not been oriented yet
+    const auto signThen = [&]( int t ) -> int {
+      const uint32_t c = w[3 * t + 1];
+      if ( component[c] >= k ) return 0;
+      const int sc = int( clusterSign[c] ) * int( compSign[component[c]] );
+      return ( w[3 * t + 2] & 1 ) ? -sc : sc;
+    };
+    double acc[3]   = {0.0, 0.0, 0.0};
+    size_t accCount = 0;
+    for ( int j = 0; j < kNN; ++j ) {
+      const uint32_t v  = w[3 * ( 1 + j )];
+      const int      sv = v != i ? signThen( 1 + j ) : 0;
+      if ( sv != 0 ) {
+        const double* nv = nrm + 3 * ( 2 + j );
+        acc[0] += double( sv ) * nv[0];
+        acc[1] += double( sv ) * nv[1];
+        acc[2] += double( sv ) * nv[2];
+        ++accCount;
+      }
+    }
+    if ( accCount == 0 ) {
+      if ( i != 0 ) {
+        const int     sp = signThen( 0 );  // i is the smallest index not oriented yet: i - 1 has been
+        const double* np = nrm + 3;
+        acc[0] = double( sp == 0 ? 1 : sp ) * np[0];
+        acc[1] = double( sp == 0 ? 1 : sp ) * np[1];
+        acc[2] = double( sp == 0 ? 1 : sp ) * np[2];
+      } else {
+        acc[0] = 0.0 - xyz0[0];
+        acc[1] = 0.0 - xyz0[1];
+        acc[2] = 0.0 - xyz0[2];
+      }
+    }
+    compSign[k] = dot( nrm, acc ) < 0.0 ? -1 : 1;
+  }
+  (void)seedClusters;
+  for ( uint32_t c = 0; c < g.clusters; ++c )
+    if ( compSign[component[c]] < 0 ) clusterSign[c] = int8_t( -clusterSign[c] );
+}
+
 // host-side contraction (the device path does the same in orient_contract.hip): union-find with parity over the
 // mutual strong edges, consistency check, cross edges grouped by source cluster.  false = some cluster's strong edges
 // disagree (the caller then grows the plain way / with a tighter threshold).
@@ -577,39 +773,31 @@ int orientNormalsHost( tmc2_frame* f ) {
   // ---- fast path: contract on the device, walk the clusters on the host --------------------------------------------
   bool contracted = false;
   if ( tau <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) ) {
-    OrientContraction g{};
-    const int         sid = ctx->stageBegin( "orient_contract" );
-    TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );
+    OrientCompact g{};
+    const int     sid = ctx->stageBegin( "orient_contract" );
+    TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );  // (d_root: cluster ids here)
     ctx->stageEnd( sid );
     if ( contracted ) {
       if ( f->beforeHostWalk ) TMC2_TRY( f->beforeHostWalk() );  // device work that overlaps the walk
-      int8_t*               clusterSign = ctx->hostC.get<int8_t>( 2 * n ) + n;  // second half: the first holds the parities (g.parity)
-      std::vector<uint32_t> seeds;
-      uint32_t*             component = reinterpret_cast<uint32_t*>( ctx->hostB.get<uint32_t>( n ) );
-      if ( !component ) {
-        setError( "orientNormals: hipHostMalloc failed" );
-        return TMC2_E_HIP;
-      }
-      bool ok;
+      const uint32_t        C           = g.clusters;
+      int8_t*               clusterSign = ctx->hostC.get<int8_t>( size_t( C ) + 1 );
+      std::vector<uint32_t> seeds, seedClusters, component( C );
+      bool                  ok;
       {
         HostGate   gate;
         const auto t0 = std::chrono::steady_clock::now();
-        ok            = orientContractedSigns( n, g, tau, clusterSign, component, seeds, ctx->orientScratch.data() );
+        ok            = orientCompactSigns( g, tau, clusterSign, component.data(), seeds, seedClusters );
         const auto t1 = std::chrono::steady_clock::now();
         ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );
       }
       if ( ok ) {
         // the seed rule's inputs, gathered on the device for exactly the seeds the walk has listed (a few KB)
-        std::vector<uint32_t> rows;
+        std::vector<uint32_t> who;
         std::vector<double>   seedNormals;
-        TMC2_TRY( gatherSeedTables( f, seeds, rows, seedNormals ) );
-        const auto rowOf    = [&]( size_t k ) { return rows.data() + 16 * k; };
-        const auto normalOf = [&]( size_t k, int j ) { return seedNormals.data() + 3 * ( 18 * k + size_t( j ) ); };
-        resolveSeedSigns( n, g, f->k, seeds, component, rowOf, normalOf, f->h_xyz.data(), clusterSign );
-      }
-      if ( ok ) {
-        TMC2_TRY( d_clusterSign.alloc( n ) );
-        TMC2_HIP( hipMemcpyAsync( d_clusterSign.p, clusterSign, n, hipMemcpyHostToDevice, s ) );
+        TMC2_TRY( gatherSeedTables( f, d_root.p, d_parity.p, seeds, who, seedNormals ) );
+        resolveSeedSignsCompact( g, f->k, seeds, seedClusters, component.data(), who.data(), seedNormals.data(), f->h_xyz.data(), clusterSign );
+        TMC2_TRY( d_clusterSign.alloc( std::max<uint32_t>( C, 1u ) ) );
+        TMC2_HIP( hipMemcpyAsync( d_clusterSign.p, clusterSign, C, hipMemcpyHostToDevice, s ) );
         TMC2_TRY( launchClusterSigns( f, d_root.p, d_parity.p, d_clusterSign.p, d_sign.p ) );
         TMC2_TRY( launchApplyOrientation( f, d_sign.p, d_negCount.p ) );
         TMC2_HIP( hipStreamSynchronize( s ) );

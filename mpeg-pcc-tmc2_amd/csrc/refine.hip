@@ -162,8 +162,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t      v    = blockIdx.x * WAVES + wave;
   uint32_t*           keys = keysAll[wave];
-  if ( v >= V ) {  // whole wave exits together (v is wave-uniform); the barriers below count the waves still running
-    if ( lane == 0 ) keys[CAP - 2] = 0;
+  if ( v >= V ) {  // a wave of the last workgroup without a voxel: it reserves nothing, but stays for the two barriers of the
+    if ( lane == 0 ) keys[CAP - 2] = 0;  // row reservation below (leaving before them is undefined, whatever the hardware does)
+    __syncthreads();
+    __syncthreads();
     return;
   }
   const uint32_t idMask  = ( 1u << idBits ) - 1u;

@@ -139,8 +139,16 @@ int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size
   }
   hipLaunchKernelGGL( scanLookBackKernel, dim3( tiles ), dim3( 256 ), 0, ctx->stream, d_in, d_out, uint32_t( n ),
                       ctx->scanState.p, ctx->scanEpoch, ctx->scanTickets, tiles, d_total );
+  // (one scan state per context: every scan of a context is queued on ctx->stream, in order)
+  const hipError_t launched = hipGetLastError();
+  if ( launched != hipSuccess ) {
+    // the launch was refused: the device ticket counter did not move.  Start the next scan from a clean state instead of
+    // letting the host-side ticket base run ahead of it (tiles would index out of range, or wait for predecessors forever).
+    ctx->scanState.release();
+    setError( "exclusiveScanU32: %s", hipGetErrorString( launched ) );
+    return TMC2_E_HIP;
+  }
   ctx->scanTickets += tiles;
-  TMC2_HIP( hipGetLastError() );
   return TMC2_OK;
 }
 

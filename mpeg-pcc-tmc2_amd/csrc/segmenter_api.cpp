@@ -68,9 +68,13 @@ int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
   // TMC2_REFINE_OVERLAP=1: the refine step's geometry (voxels, neighbourhood rows: points only) is queued right before the
   // orientation's host walk and built while the host walks.  Measured: one frame alone 33.3 -> 32.0 ms, but 16 frames in flight
   // 96.8 -> 94.5 frames/s (the rows of one frame then compete with the orientation kernels of the others) -- off by default.
-  struct HookGuard {
-    tmc2_frame* f;
-    ~HookGuard() { f->beforeHostWalk = nullptr; }
+  struct HookGuard {  // on every way out: no hook left behind, and no half-used refine job (it holds the context's dense voxel table
+    tmc2_frame* f;    // filled: another frame's refinement on this context would look its cells up in a dirty table)
+    bool        done = false;
+    ~HookGuard() {
+      f->beforeHostWalk = nullptr;
+      if ( !done ) f->refineJob.reset();
+    }
   } guard{f};
   if ( p->gridBasedRefineSegmentation && getenv( "TMC2_REFINE_OVERLAP" ) )
     f->beforeHostWalk = [f, p]() {
@@ -84,6 +88,7 @@ int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
   TMC2_TRY( tmc2_segmenter_refine_grid_based( f, p->maxNNCountRefineSegmentation, p->lambdaRefineSegmentation,
                                               p->iterationCountRefineSegmentation, p->voxelDimensionRefineSegmentation,
                                               p->searchRadiusRefineSegmentation ) );
+  guard.done = true;  // (the refinement consumed its job)
   return segmentPatches( f, p );
 }
 

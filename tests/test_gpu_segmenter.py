@@ -324,6 +324,14 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch
     fr.normals_compute(16, 1)
     assert np.array_equal(fr.get_normals().view(np.uint64), exp.view(np.uint64))
     assert gpu_ctx.stage_calls().get("orient_contract", 0) == 1 and gpu_ctx.stage_calls().get("orient_normals_regrowth", 0) == 0
+    # the pair table too small for the frame: the walk gets every cross edge instead of one per pair of clusters
+    monkeypatch.setenv("TMC2_ORIENT_PAIRS", "6")
+    fr3 = gpu_ctx.frame(xyz, rgb)
+    gpu_ctx.stage_reset()
+    fr3.normals_compute(16, 1)
+    assert np.array_equal(fr3.get_normals().view(np.uint64), exp.view(np.uint64))
+    assert gpu_ctx.stage_calls().get("orient_pair_table_overflow", 0) == 1
+    monkeypatch.delenv("TMC2_ORIENT_PAIRS")
     monkeypatch.setenv("TMC2_ORIENT_NO_CONTRACTION", "1")
     fr2 = gpu_ctx.frame(xyz, rgb)
     fr2.normals_compute(16, 1)
