@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -408,6 +409,12 @@ int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iteration
 // the point-only half of it ahead of time (voxels, neighbourhood rows): queued, not waited for; refineGridBased picks it up
 int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
+// Grid of a kernel that walks its items with a stride loop: at most eight 256-thread workgroups per CU -- one full set of
+// resident waves.  A kernel of 50 K trivial workgroups is bound by workgroup dispatch (~ 500 per microsecond chip-wide), and
+// sixteen frames in flight queue their dispatches behind each other.
+inline uint32_t cappedBlocks( const tmc2_ctx* ctx, size_t wanted ) {
+  return uint32_t( std::max<size_t>( 1, std::min<size_t>( wanted, size_t( 8 ) * size_t( ctx->cuCount ) ) ) );
+}
 int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
 // union passes (S3 contraction, S7 components): answer "same set already?" from the CU's possibly stale view before any
 // find / compare-and-swap (TMC2_UF_PRECHECK=0 switches it off); TMC2_UF_CHECK=1: debug invariants after every union pass

@@ -222,12 +222,15 @@ int launchNormals( tmc2_frame* f ) {
 //   majorityFlipKernel : negate everything if that count exceeds half -- decided on the device, no round trip.
 __global__ __launch_bounds__( 256 ) void edgeDotKernel( const double* __restrict__ normals, const uint32_t* __restrict__ knn,
                                                          uint32_t n, int k, double* __restrict__ edgeDot ) {
-  const size_t e = size_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-  if ( e >= size_t( n ) * k ) return;
-  const size_t  u = e / k, v = knn[e];
-  const double* a = normals + 3 * u;
-  const double* b = normals + 3 * v;
-  edgeDot[e]      = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  // (a capped grid with a stride loop: 13 M edges as 52 K workgroups made the launch itself -- workgroup dispatch -- the cost,
+  // sixteen frames' worth of them at once all the more)
+  const size_t total = size_t( n ) * k, stride = size_t( gridDim.x ) * blockDim.x;
+  for ( size_t e = size_t( blockIdx.x ) * blockDim.x + threadIdx.x; e < total; e += stride ) {
+    const size_t  u = e / k, v = knn[e];
+    const double* a = normals + 3 * u;
+    const double* b = normals + 3 * v;
+    edgeDot[e]      = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  }
 }
 
 __global__ __launch_bounds__( 256 ) void applySignsKernel( const Pt* __restrict__ pts, const int8_t* __restrict__ sign,
@@ -258,7 +261,7 @@ __global__ __launch_bounds__( 256 ) void majorityFlipKernel( const uint32_t* __r
 
 int launchEdgeDots( tmc2_frame* f, double* d_edgeDot ) {
   const size_t edges = f->n * size_t( f->k );
-  hipLaunchKernelGGL( edgeDotKernel, dim3( uint32_t( ( edges + 255 ) / 256 ) ), dim3( 256 ), 0, f->ctx->stream, f->d_normals.p,
+  hipLaunchKernelGGL( edgeDotKernel, dim3( cappedBlocks( f->ctx, ( edges + 255 ) / 256 ) ), dim3( 256 ), 0, f->ctx->stream, f->d_normals.p,
                       f->d_knn.p, uint32_t( f->n ), f->k, d_edgeDot );
   TMC2_HIP( hipGetLastError() );
   return TMC2_OK;

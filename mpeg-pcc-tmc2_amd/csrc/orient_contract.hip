@@ -39,12 +39,11 @@ __global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __rest
                                                            uint16_t* __restrict__ mask, uint32_t* __restrict__ word,
                                                            uint32_t* __restrict__ count ) {
   static_assert( K == 16, "16 lanes per point" );
-  const uint32_t i = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
-  if ( i > n ) return;  // (uniform over the 16 lanes of a point)
+  const int j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  for ( uint32_t i = blockIdx.x * 16 + ( threadIdx.x >> 4 ); i <= n; i += gridDim.x * 16 ) {  // (uniform over the 16 lanes of a point)
   if ( i == n ) {
     if ( j == 0 ) count[n] = 0;
-    return;
+    continue;
   }
   // bit j of mask[i]: neighbour j is a mutual strong one (mutual bits: ensureMutualMask, shared with S7)
   const double dj   = edgeDot[size_t( i ) * K + j];
@@ -69,6 +68,7 @@ __global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __rest
     count[i] = 0;
     if ( prio >= ufPriority( i ) ) best = i;  // (no mutual strong neighbour of smaller priority: its own root)
     word[i] = ( best << 1 ) | ( best == i ? 0u : parity );
+  }
   }
 }
 
@@ -247,8 +247,9 @@ __global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __res
                                                             uint32_t* __restrict__ cid, uint16_t* __restrict__ crossMask,
                                                             uint32_t* __restrict__ flags /* [0] bad, [2] overflow */ ) {
   static_assert( K == 16, "16 lanes per point" );
-  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const int j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  for ( uint32_t g0 = blockIdx.x * 16; g0 < n; g0 += gridDim.x * 16 ) {
+  const uint32_t u = g0 + ( threadIdx.x >> 4 );
   const bool     in = u < n;
   bool           isCross = false, wrong = false, full = false;
   if ( in ) {
@@ -271,6 +272,7 @@ __global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __res
   if ( __ballot( wrong ) && lane == 0 ) flags[0] = 1u;
   if ( __ballot( full ) && lane == 0 ) flags[2] = 1u;
   if ( in && j == 0 ) crossMask[u] = uint16_t( cross );
+  }
 }
 // pass 2: the edges the walk gets -- bit j of keepMask[u] -- and their number per source cluster (one report per workgroup and
 // cluster, as verifyCountKernel).  dedupe = false: every cross edge (the table overflowed).
@@ -280,8 +282,10 @@ __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __res
                                                             const uint8_t* __restrict__ parity, uint32_t n, double tau, PairTable t,
                                                             int dedupe, uint16_t* __restrict__ keepMask, uint32_t* __restrict__ count ) {
   static_assert( K == 16, "16 lanes per point" );
-  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const int           j = threadIdx.x & 15, lane = threadIdx.x & 63;
+  __shared__ uint32_t sCid[16], sKept[16];
+  for ( uint32_t g0 = blockIdx.x * 16; g0 < n; g0 += gridDim.x * 16 ) {  // (uniform over the workgroup: barriers inside)
+  const uint32_t u = g0 + ( threadIdx.x >> 4 );
   const bool     in = u < n;
   bool           keep = false;
   uint32_t       cu = 0xFFFFFFFFu;
@@ -304,8 +308,7 @@ __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __res
   }
   const uint32_t kept = ballot16( keep, lane );
   if ( in && j == 0 ) keepMask[u] = uint16_t( kept );
-  __shared__ uint32_t sCid[16], sKept[16];
-  const int           p = threadIdx.x >> 4;
+  const int p = threadIdx.x >> 4;
   if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( kept ) );
   __syncthreads();
   if ( in && j == 0 ) {
@@ -318,6 +321,8 @@ __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __res
     }
     if ( first && total ) atomicAdd( &count[cu], total );
   }
+  __syncthreads();  // (the shared records are rewritten by the next group of points)
+  }
 }
 // the kept edges, per source cluster, with the target cluster and the two ends' parities folded into the dot product
 template <int K>
@@ -325,20 +330,25 @@ __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* _
                                                                 const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
                                                                 const uint32_t* __restrict__ off, const uint16_t* __restrict__ keepMask,
                                                                 const uint32_t* __restrict__ root, const uint32_t* __restrict__ minIdx,
-                                                                uint32_t n, uint32_t clusters, uint32_t* __restrict__ cursor,
+                                                                uint32_t n, const uint32_t* __restrict__ clustersPtr, uint32_t edgeCap,
+                                                                uint32_t recCap, uint32_t* __restrict__ cursor,
                                                                 OrientCompactEdge* __restrict__ edges, OrientClusterRec* __restrict__ rec ) {
   static_assert( K == 16, "16 lanes per point" );
-  const uint32_t u = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      j = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int           j = threadIdx.x & 15, p = threadIdx.x >> 4;
+  __shared__ uint32_t sCid[16], sKept[16], sBase[16];
+  for ( uint32_t g0 = blockIdx.x * 16; g0 < n; g0 += gridDim.x * 16 ) {  // (uniform over the workgroup: barriers inside)
+  const uint32_t u = g0 + ( threadIdx.x >> 4 );
   const bool     in = u < n;
   const uint32_t m  = in ? keepMask[u] : 0u;
-  __shared__ uint32_t sCid[16], sKept[16], sBase[16];
   const uint32_t cu = in ? cid[u] : 0xFFFFFFFFu;
   if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( m ) );
   // the cluster's record, written by its first member: where its edges start, the seed point and its parity (one copy to the
   // host instead of three); the sentinel record by the last point
-  if ( in && j == 0 && minIdx[root[u]] == u ) rec[cu] = OrientClusterRec{off[cu], u, parity[u]};
-  if ( in && j == 0 && u == n - 1 ) rec[clusters] = OrientClusterRec{off[clusters], 0u, 0u};
+  // (queued before the host knows the number of clusters / kept edges: both come from the device, writes stay inside the
+  // buffers -- a frame that needs more is repeated with exact sizes)
+  const uint32_t clusters = *clustersPtr;
+  if ( in && j == 0 && minIdx[root[u]] == u && cu < recCap ) rec[cu] = OrientClusterRec{off[cu], u, parity[u]};
+  if ( in && j == 0 && u == n - 1 && clusters < recCap ) rec[clusters] = OrientClusterRec{off[clusters], 0u, 0u};
   __syncthreads();
   if ( j == 0 && m ) {
     bool     first = true;
@@ -351,7 +361,7 @@ __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* _
     if ( first ) sBase[p] = off[cu] + atomicAdd( &cursor[cu], total );
   }
   __syncthreads();
-  if ( !m ) return;  // (uniform over the 16 lanes of a point)
+  if ( m ) {  // (uniform over the 16 lanes of a point)
   uint32_t at = 0;
   if ( j == 0 ) {
     int lead = p;
@@ -366,7 +376,11 @@ __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* _
   if ( ( m >> j ) & 1u ) {
     const uint32_t v = knn[size_t( u ) * K + j];
     const double   d = edgeDot[size_t( u ) * K + j];
-    edges[at + __popc( m & ( ( 1u << j ) - 1u ) )] = OrientCompactEdge{u, v, cid[v], 0u, ( ( parity[u] ^ parity[v] ) & 1 ) ? -d : d};
+    const uint32_t pos = at + __popc( m & ( ( 1u << j ) - 1u ) );
+    if ( pos < edgeCap ) edges[pos] = OrientCompactEdge{u, v, cid[v], 0u, ( ( parity[u] ^ parity[v] ) & 1 ) ? -d : d};
+  }
+  }
+  __syncthreads();  // (the shared records are rewritten by the next group of points)
   }
 }
 
@@ -457,9 +471,9 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
                                {d_pairs.p, 2 * size_t( pairCap ) * 8, 0},
                                {d_strongSeen.p, size_t( pairCap ) * 4, 0}} ) );
   TMC2_TRY( ensureMutualMask( f ) );
-  const dim3 grdN16( ( n + 15 ) / 16 );  // 16 lanes per point
+  const dim3 grdN16( cappedBlocks( ctx, ( size_t( n ) + 15 ) / 16 ) );  // 16 lanes per point, groups of 16 points in a stride loop
   TMC2_TRY( d_count.alloc( size_t( n ) + 1 ) );  // (initWordsKernel zeroes it; later: kept edges per cluster, C + 1 used)
-  hipLaunchKernelGGL( initWordsKernel<16>, dim3( ( n + 16 ) / 16 ), blk, 0, s, f->d_knn.p, d_edgeDot, f->d_mutual.p, tau, n, d_mask.p,
+  hipLaunchKernelGGL( initWordsKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, f->d_mutual.p, tau, n, d_mask.p,
                       d_word.p, d_count.p );
   hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, unionPrecheck(), unionAgentScope() );
   if ( unionCheck() ) {  // debug invariants (soak tests): costs a round trip
@@ -480,34 +494,75 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   PairTable t{d_pairs.p, d_pairs.p + pairCap, d_strongSeen.p, pairCap - 1};
   hipLaunchKernelGGL( pairInsertKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_minIdx.p, d_rank.p, d_parity.p, n,
                       tau, t, d_cid.p, d_crossMask.p, d_small.p );
-  uint32_t head[4] = {0, 0, 0, 0};
-  for ( int dedupe = 1; dedupe >= 0; --dedupe ) {
-    TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
-    hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, dedupe,
-                        d_keepMask.p, d_count.p );
-    TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
-    TMC2_HIP( hipMemcpyAsync( head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
-    TMC2_HIP( hipStreamSynchronize( s ) );
-    if ( head[0] ) return TMC2_OK;  // inconsistent cluster
-    if ( !head[2] || !dedupe ) break;
-    ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
-  }
-  const uint32_t E = head[1], C = head[3];
+  // First attempt without knowing the sizes: room for kSpecEdges kept edges and kSpecClusters clusters (three times what a
+  // longdress frame needs), everything queued back to back and ONE round trip -- counters, cluster records and edges come
+  // back together.  A frame that needs more room (or whose pair table overflowed) is repeated with exact sizes, two round trips.
+  constexpr uint32_t kSpecEdges = 384 * 1024, kSpecClusters = 64 * 1024;
   DevBuf<OrientCompactEdge> d_edges;
   DevBuf<OrientClusterRec>  d_rec;
-  TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
-  TMC2_TRY( d_rec.alloc( size_t( C ) + 1 ) );
-  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
-                      d_minIdx.p, n, C, d_cursor.p, d_edges.p, d_rec.p );
-  OrientClusterRec*  h_rec   = ctx->hostA.get<OrientClusterRec>( size_t( C ) + 1 );
-  OrientCompactEdge* h_edges = ctx->hostE.get<OrientCompactEdge>( std::max<uint32_t>( E, 1u ) );
-  if ( !h_rec || !h_edges ) {
+  TMC2_TRY( d_edges.alloc( kSpecEdges ) );
+  TMC2_TRY( d_rec.alloc( kSpecClusters ) );
+  uint32_t*          h_head  = ctx->hostC.get<uint32_t>( 4 + ( size_t( n ) + 4 ) / 4 + 4 );  // counters | (cluster signs, see the caller)
+  OrientClusterRec*  h_rec   = ctx->hostA.get<OrientClusterRec>( kSpecClusters );
+  OrientCompactEdge* h_edges = ctx->hostE.get<OrientCompactEdge>( kSpecEdges );
+  if ( !h_head || !h_rec || !h_edges ) {
     setError( "orientNormals: hipHostMalloc failed" );
     return TMC2_E_HIP;
   }
-  TMC2_HIP( hipMemcpyAsync( h_rec, d_rec.p, ( size_t( C ) + 1 ) * sizeof( OrientClusterRec ), hipMemcpyDeviceToHost, s ) );
-  if ( E ) TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( E ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
+  TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
+  hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, 1,
+                      d_keepMask.p, d_count.p );
+  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
+  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+                      d_minIdx.p, n, d_small.p + 3, kSpecEdges, kSpecClusters, d_cursor.p, d_edges.p, d_rec.p );
+  TMC2_HIP( hipMemcpyAsync( h_head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
+  // (what a frame typically needs, plus a margin, comes along right away; the rest -- if any -- after the counters are known)
+  constexpr uint32_t kFirstEdges = 192 * 1024, kFirstClusters = 32 * 1024;
+  TMC2_HIP( hipMemcpyAsync( h_rec, d_rec.p, size_t( kFirstClusters ) * sizeof( OrientClusterRec ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( kFirstEdges ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
+  uint32_t head[4] = {h_head[0], h_head[1], h_head[2], h_head[3]};
+  if ( head[0] ) return TMC2_OK;  // inconsistent cluster
+  uint32_t E = head[1], C = head[3];
+  if ( !head[2] && E <= kSpecEdges && C + 1 <= kSpecClusters ) {
+    bool more = false;
+    if ( C + 1 > kFirstClusters ) {
+      TMC2_HIP( hipMemcpyAsync( h_rec + kFirstClusters, d_rec.p + kFirstClusters, size_t( C + 1 - kFirstClusters ) * sizeof( OrientClusterRec ),
+                                hipMemcpyDeviceToHost, s ) );
+      more = true;
+    }
+    if ( E > kFirstEdges ) {
+      TMC2_HIP( hipMemcpyAsync( h_edges + kFirstEdges, d_edges.p + kFirstEdges, size_t( E - kFirstEdges ) * sizeof( OrientCompactEdge ),
+                                hipMemcpyDeviceToHost, s ) );
+      more = true;
+    }
+    if ( more ) TMC2_HIP( hipStreamSynchronize( s ) );
+  } else {
+    for ( int dedupe = head[2] ? 0 : 1;; ) {
+      if ( !dedupe ) ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
+      TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
+      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, dedupe,
+                          d_keepMask.p, d_count.p );
+      TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
+      TMC2_HIP( hipMemcpyAsync( head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+      break;
+    }
+    E = head[1], C = head[3];
+    TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
+    TMC2_TRY( d_rec.alloc( size_t( C ) + 1 ) );
+    hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+                        d_minIdx.p, n, d_small.p + 3, std::max<uint32_t>( E, 1u ), C + 1, d_cursor.p, d_edges.p, d_rec.p );
+    h_rec   = ctx->hostA.get<OrientClusterRec>( size_t( C ) + 1 );
+    h_edges = ctx->hostE.get<OrientCompactEdge>( std::max<uint32_t>( E, 1u ) );
+    if ( !h_rec || !h_edges ) {
+      setError( "orientNormals: hipHostMalloc failed" );
+      return TMC2_E_HIP;
+    }
+    TMC2_HIP( hipMemcpyAsync( h_rec, d_rec.p, ( size_t( C ) + 1 ) * sizeof( OrientClusterRec ), hipMemcpyDeviceToHost, s ) );
+    if ( E ) TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( E ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+  }
   g.clusters = C, g.rec = h_rec, g.edges = h_edges;
   ok         = true;
   return TMC2_OK;

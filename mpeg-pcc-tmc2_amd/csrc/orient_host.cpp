@@ -780,7 +780,7 @@ int orientNormalsHost( tmc2_frame* f ) {
     if ( contracted ) {
       if ( f->beforeHostWalk ) TMC2_TRY( f->beforeHostWalk() );  // device work that overlaps the walk
       const uint32_t        C           = g.clusters;
-      int8_t*               clusterSign = ctx->hostC.get<int8_t>( size_t( C ) + 1 );
+      int8_t*               clusterSign = reinterpret_cast<int8_t*>( ctx->hostC.get<uint32_t>( 4 + ( n + 4 ) / 4 + 4 ) + 4 );  // (behind the counters)
       std::vector<uint32_t> seeds, seedClusters, component( C );
       bool                  ok;
       {
