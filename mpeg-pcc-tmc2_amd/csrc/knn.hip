@@ -71,8 +71,18 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
                                                      uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist,
-                                                     int /*unused*/ ) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+                                                     int xcdAware ) {
+  // Which 256 queries this workgroup takes.  Workgroups are handed to the eight XCDs round-robin (block b runs on XCD b % 8:
+  // observed, not promised -- only speed depends on it), so consecutive blocks -- neighbours in tree order, walking the same
+  // part of the tree -- land on eight different L2s, and every L2 ends up streaming the whole tree (9.4 MB at longdress size
+  // against 4 MB of L2: 9.5 x the algorithmic bytes reached HBM).  With the mapping below XCD x works through the x-th eighth
+  // of the queries: its L2 holds an eighth of the tree.  (The grid is a multiple of 8 blocks; blocks past the end leave.)
+  uint32_t block = blockIdx.x;
+  if ( xcdAware ) {
+    const uint32_t perXcd = gridDim.x >> 3;
+    block                 = ( blockIdx.x & 7u ) * perXcd + ( blockIdx.x >> 3 );
+  }
+  const uint32_t j = block * blockDim.x + threadIdx.x;
   if ( j >= nq ) return;
   const Pt  qp = SELF ? ptsTree[j] : queries[j];
   const int qx = qp.x, qy = qp.y, qz = qp.z;
@@ -205,19 +215,21 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
     rb.hi[d] = t.hi[d];
   }
   const dim3 block( 256 );
-  const dim3 grid( uint32_t( ( nq + 255 ) / 256 ) );
+  // (test hook TMC2_KNN_XCD=0: blocks in launch order)
+  const char* xcdEnv   = getenv( "TMC2_KNN_XCD" );
+  const int   xcdAware = xcdEnv && xcdEnv[0] == '0' ? 0 : 1;
+  const dim3  grid( xcdAware ? uint32_t( ( ( nq + 255 ) / 256 + 7 ) & ~uint64_t( 7 ) ) : uint32_t( ( nq + 255 ) / 256 ) );
   // the packed LDS stack needs: every offset < 2^14 (tree box and queries inside a 16383-wide window -- the caller
   // vouches for the queries with t.queriesBounded), node ids < 2^22, and at most kLdsLevels pending far children
   bool lds = t.queriesBounded && t.depth <= kLdsLevels && t.n <= ( uint64_t( 1 ) << 21 );
   for ( int d = 0; d < 3; ++d ) lds = lds && t.lo[d] >= 0 && t.hi[d] <= 8191;
-  const int ldsBase = std::max( 0, t.depth - kLdsTop );  // at most depth - 1 far children are ever pending
 #define TMC2_LAUNCH_K( KK )                                                                                          \
   if ( lds ) {                                                                                                       \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,          \
-                        uint32_t( nq ), idx, dist, ldsBase );                                                        \
+                        uint32_t( nq ), idx, dist, xcdAware );                                                       \
   } else {                                                                                                           \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, false> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,         \
-                        uint32_t( nq ), idx, dist, 0 );                                                              \
+                        uint32_t( nq ), idx, dist, xcdAware );                                                       \
   }
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
