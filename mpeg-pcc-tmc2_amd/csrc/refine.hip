@@ -771,10 +771,10 @@ __global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __
                                                                 const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t V,
                                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ gAct,
                                                                 uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
-  const uint32_t u = blockIdx.x * 8 + ( threadIdx.x >> 5 );
-  if ( u >= V ) return;
-  prepareVoxel( u, threadIdx.x & 31, ( threadIdx.x >> 5 ) & 1, edge, ppi, recCur, recNxt, dev, devLen, stride, out, gAct, gFr,
-                       gMk );
+  // (a capped grid with a stride loop: 8 860 workgroups of eight voxels each made workgroup dispatch the cost of this kernel
+  // when sixteen frames issue it at the same time)
+  for ( uint32_t u = blockIdx.x * 8 + ( threadIdx.x >> 5 ); u < V; u += gridDim.x * 8 )
+    prepareVoxel( u, threadIdx.x & 31, ( threadIdx.x >> 5 ) & 1, edge, ppi, recCur, recNxt, dev, devLen, stride, out, gAct, gFr, gMk );
 }
 
 // Wave-level compaction of a bitmap into a voxel list (whole 64-word chunks; a chunk that does not fit stays for the next
@@ -1238,7 +1238,8 @@ int RefineJob::finish() {
                       d_hist.p );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
                       d_edge, d_ppi, d_active );
-  const dim3 grdV32( ( V + 7 ) / 8 );
+  const char* prepEnv = getenv( "TMC2_REFINE_PREPARE_BLOCKS" );  // (test hook: the grid of closurePrepareKernel)
+  const dim3  grdV32( std::min<uint32_t>( ( V + 7 ) / 8, prepEnv ? uint32_t( std::max( 1, atoi( prepEnv ) ) ) : cappedBlocks( ctx, ( V + 7 ) / 8 ) ) );
   if ( eventDriven ) {
     // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
     DevBuf<uint32_t> d_roff, d_radj, d_work, d_out;
@@ -1335,7 +1336,7 @@ int RefineJob::finish() {
     else
       hipLaunchKernelGGL( smoothKernel<true>, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
                           d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
-    hipLaunchKernelGGL( closureRoundZeroKernel, grdV32, blk, 0, s, d_edge, d_ppi, d_arg, d_dev.p, V, d_active, d_marked,
+    hipLaunchKernelGGL( closureRoundZeroKernel, dim3( ( V + 7 ) / 8 ), blk, 0, s, d_edge, d_ppi, d_arg, d_dev.p, V, d_active, d_marked,
                         d_out.p, d_activeBits, d_frontierBits, d_flags.p, iter );
     if ( tailInLds )
       hipLaunchKernelGGL( closureTailKernel, dim3( 1 ), dim3( 1024 ), tailLds, s, d_out.p, W, d_active, d_marked,
