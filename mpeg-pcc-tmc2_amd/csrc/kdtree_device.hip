@@ -47,7 +47,7 @@ constexpr int      kScanTile  = kBlock * 8;
 constexpr int      kLeafMax   = 10;
 constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kernels
 #ifndef TMC2_KD_RETIRE
-#define TMC2_KD_RETIRE 1024
+#define TMC2_KD_RETIRE 512
 #endif
 #ifndef TMC2_KD_LANEMAX
 #define TMC2_KD_LANEMAX 32
