@@ -654,6 +654,69 @@ static bool contractOnHost( size_t n, const uint32_t* knn, int k, const double* 
   return true;
 }
 
+// The contraction above in the compact form the device produces (orient_contract.hip: clusters numbered by first member, per
+// ordered pair of clusters the light edges that carry the pair's largest |n_u . n_v| and one strong edge per implied relative
+// sign): the host-only path walks the same structure as the device path -- and the CPU tier pins that walk and the reduction of
+// the edge list to the reference's growth.
+struct HostCompact {
+  std::vector<OrientClusterRec>  rec;
+  std::vector<OrientCompactEdge> edges;
+  std::vector<uint32_t>          cid;
+  OrientCompact view() const { return OrientCompact{uint32_t( rec.size() - 1 ), rec.data(), edges.data()}; }
+};
+static void compactOnHost( size_t n, const std::vector<uint32_t>& root, const std::vector<uint8_t>& parity, const std::vector<uint32_t>& off,
+                           const std::vector<OrientCrossEdge>& edges, double tau, HostCompact& out ) {
+  out.cid.assign( n, 0 );
+  std::vector<uint32_t> idOfRoot( n, 0xFFFFFFFFu );
+  uint32_t              C = 0;
+  for ( size_t i = 0; i < n; ++i ) {  // clusters in the order of their first members
+    uint32_t& id = idOfRoot[root[i]];
+    if ( id == 0xFFFFFFFFu ) {
+      id = C++;
+      out.rec.push_back( OrientClusterRec{0u, uint32_t( i ), parity[i]} );
+    }
+    out.cid[i] = id;
+  }
+  out.rec.push_back( OrientClusterRec{0u, 0u, 0u} );
+  std::vector<std::vector<OrientCompactEdge>> per( C );
+  for ( size_t r = 0; r < n; ++r ) {
+    if ( root[r] != r || off[r] == off[r + 1] ) continue;
+    // per target cluster: best |d| among the light edges; the strong edges' sign classes seen
+    std::vector<OrientCompactEdge> all;
+    for ( uint32_t e = off[r]; e < off[r + 1]; ++e ) {
+      const OrientCrossEdge& x = edges[e];
+      all.push_back( OrientCompactEdge{x.u, x.v, out.cid[x.v], 0u, ( ( parity[x.u] ^ parity[x.v] ) & 1 ) ? -x.d : x.d} );
+    }
+    std::stable_sort( all.begin(), all.end(), []( const OrientCompactEdge& a, const OrientCompactEdge& b ) { return a.c2 < b.c2; } );
+    std::vector<OrientCompactEdge>& keep = per[out.cid[r]];
+    for ( size_t i = 0; i < all.size(); ) {
+      size_t j    = i;
+      double best = -1.0;
+      while ( j < all.size() && all[j].c2 == all[i].c2 ) {
+        if ( std::fabs( all[j].d ) < tau ) best = std::max( best, std::fabs( all[j].d ) );
+        ++j;
+      }
+      bool strongSeen[2] = {false, false};
+      for ( size_t t = i; t < j; ++t ) {
+        const double w = std::fabs( all[t].d );
+        if ( w >= tau ) {
+          const int cls = all[t].d < 0.0 ? 1 : 0;
+          if ( !strongSeen[cls] ) keep.push_back( all[t] );
+          strongSeen[cls] = true;
+        } else if ( w == best ) {
+          keep.push_back( all[t] );
+        }
+      }
+      i = j;
+    }
+  }
+  for ( uint32_t c = 0; c < C; ++c ) {
+    out.rec[c].off = uint32_t( out.edges.size() );
+    out.edges.insert( out.edges.end(), per[c].begin(), per[c].end() );
+  }
+  out.rec[C].off = uint32_t( out.edges.size() );
+}
+
 // first strong-edge threshold: ~11 degrees (nearly every edge on a smooth surface is strong)
 double orientFirstTau() {
   static const double first = [] {
@@ -693,26 +756,57 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
                std::chrono::duration<double, std::milli>( tc1 - tc0 ).count(), int( okc ), clusters, edges.size(), n * size_t( k ) );
     }
     if ( okc ) {
-      const OrientContraction g{root.data(), parity.data(), off.data(), edges.data()};
-      std::vector<int8_t>   clusterSign( n );
-      std::vector<uint32_t> component( n ), seeds;
-      const auto tw0 = std::chrono::steady_clock::now();
-      const bool okw = orientContractedSigns( n, g, first, clusterSign.data(), component.data(), seeds, scratch );
-      if ( okw ) {
-        const auto rowOf    = [&]( size_t s ) { return knn + size_t( seeds[s] ) * k; };
-        const auto normalOf = [&]( size_t s, int j ) {
-          const uint32_t i = seeds[s];
-          const uint32_t v = j == 0 ? i : ( j == 1 ? ( i ? i - 1 : 0 ) : knn[size_t( i ) * k + ( j - 2 )] );
-          return normals + 3 * size_t( v );
-        };
-        resolveSeedSigns( n, g, k, seeds, component.data(), rowOf, normalOf, xyz, clusterSign.data() );
+      // (TMC2_ORIENT_HOST_WALK=points: the per-point-array walk over the full cross-edge list, kept as the cross-check)
+      const char* walkEnv = getenv( "TMC2_ORIENT_HOST_WALK" );
+      const auto  tw0     = std::chrono::steady_clock::now();
+      bool        okw;
+      size_t      seedCount = 0;
+      if ( walkEnv && walkEnv[0] == 'p' ) {
+        const OrientContraction g{root.data(), parity.data(), off.data(), edges.data()};
+        std::vector<int8_t>     clusterSign( n );
+        std::vector<uint32_t>   component( n ), seeds;
+        okw       = orientContractedSigns( n, g, first, clusterSign.data(), component.data(), seeds, scratch );
+        seedCount = seeds.size();
+        if ( okw ) {
+          const auto rowOf    = [&]( size_t s ) { return knn + size_t( seeds[s] ) * k; };
+          const auto normalOf = [&]( size_t s, int j ) {
+            const uint32_t i = seeds[s];
+            const uint32_t v = j == 0 ? i : ( j == 1 ? ( i ? i - 1 : 0 ) : knn[size_t( i ) * k + ( j - 2 )] );
+            return normals + 3 * size_t( v );
+          };
+          resolveSeedSigns( n, g, k, seeds, component.data(), rowOf, normalOf, xyz, clusterSign.data() );
+          for ( size_t i = 0; i < n; ++i ) sign[i] = int8_t( ( parity[i] & 1 ) ? -clusterSign[root[i]] : clusterSign[root[i]] );
+        }
+      } else {
+        HostCompact hc;
+        compactOnHost( n, root, parity, off, edges, first, hc );
+        const OrientCompact   g = hc.view();
+        std::vector<int8_t>   clusterSign( g.clusters + 1 );
+        std::vector<uint32_t> component( g.clusters + 1 ), seeds, seedClusters;
+        okw       = orientCompactSigns( g, first, clusterSign.data(), component.data(), seeds, seedClusters );
+        seedCount = seeds.size();
+        if ( okw ) {
+          // the seed rule's tables: (point, cluster, parity) of the point before the seed and of its neighbours; their normals
+          std::vector<uint32_t> who( seeds.size() * size_t( k + 1 ) * 3 );
+          std::vector<double>   nrm( seeds.size() * size_t( k + 2 ) * 3 );
+          for ( size_t sd = 0; sd < seeds.size(); ++sd ) {
+            const uint32_t i = seeds[sd];
+            for ( int j = 0; j < k + 2; ++j ) {
+              const uint32_t v = j == 0 ? i : ( j == 1 ? ( i ? i - 1 : 0 ) : knn[size_t( i ) * k + ( j - 2 )] );
+              if ( j >= 1 ) {
+                uint32_t* w = who.data() + ( sd * size_t( k + 1 ) + size_t( j - 1 ) ) * 3;
+                w[0] = v, w[1] = hc.cid[v], w[2] = parity[v];
+              }
+              for ( int c = 0; c < 3; ++c ) nrm[( sd * size_t( k + 2 ) + size_t( j ) ) * 3 + c] = normals[3 * size_t( v ) + c];
+            }
+          }
+          resolveSeedSignsCompact( g, k, seeds, seedClusters, component.data(), who.data(), nrm.data(), xyz, clusterSign.data() );
+          for ( size_t i = 0; i < n; ++i ) sign[i] = int8_t( ( parity[i] & 1 ) ? -clusterSign[hc.cid[i]] : clusterSign[hc.cid[i]] );
+        }
       }
       if ( getenv( "TMC2_ORIENT_TIMING" ) )
-        fprintf( stderr, "contracted walk %.1f ms ok=%d seeds %zu\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tw0 ).count(), int( okw ), seeds.size() );
-      if ( okw ) {
-        for ( size_t i = 0; i < n; ++i ) sign[i] = int8_t( ( parity[i] & 1 ) ? -clusterSign[root[i]] : clusterSign[root[i]] );
-        return growths;
-      }
+        fprintf( stderr, "contracted walk %.1f ms ok=%d seeds %zu\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tw0 ).count(), int( okw ), seedCount );
+      if ( okw ) return growths;
     }
   }
   for ( double tau : {first, 0.998} ) {

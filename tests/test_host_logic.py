@@ -83,6 +83,20 @@ def test_host_orientation_disconnected_components(oracle):
     assert np.array_equal(bits(T.host_orient_normals(two, knn, raw)), bits(oracle.orient_normals(two, knn, raw)))
 
 
+def test_host_orientation_compact_and_per_point_walks_agree(oracle, monkeypatch):
+    """The walk over the compact contracted graph (clusters numbered by first member, per pair of clusters the light edges of
+    largest |n_u . n_v| + one strong edge per sign: what the device hands to the host) and the walk over the full cross-edge
+    list with per-point arrays give the reference's normals on a 180 K-point cloud with several components."""
+    xyz, _ = synth_cloud("medium")
+    two = np.unique(np.concatenate([xyz, (xyz[::3] // 2 + np.array([700, 20, 40])).astype(np.int16)]), axis=0)
+    knn = oracle.knn_self(two, 16)
+    raw = oracle.compute_normals(two, knn)
+    exp = oracle.orient_normals(two, knn, raw)
+    assert np.array_equal(bits(T.host_orient_normals(two, knn, raw)), bits(exp))
+    monkeypatch.setenv("TMC2_ORIENT_HOST_WALK", "points")
+    assert np.array_equal(bits(T.host_orient_normals(two, knn, raw)), bits(exp))
+
+
 @pytest.mark.parametrize("tau", ["0.0", "0.5", "0.9", "0.98", "0.9999", "4"])
 def test_host_orientation_strong_edge_thresholds(oracle, tau, tmp_path):
     """The strong-edge shortcut of the orientation (breadth-first absorption of >= tau edges, verified for sign
