@@ -655,13 +655,10 @@ __global__ __launch_bounds__( 256 ) void rescoreVoxelsKernel( const uint8_t* __r
 //     copy of rec[cur] -- nobody reads a record that is being pushed into.
 //   * re-scoring a voxel is a pure function of S[v] (normals and weight are static): a voxel whose S has not changed
 //     since it was last re-scored keeps its labels, so only its edge class / ppi are refreshed (epochs, below).
-//   * the INDIRECT-edge closure (the one sequential coupling of a sweep): everything about it that is not sequential is
-//     done chip-wide first (closurePrepareKernel: every voxel's list of DEV neighbours it would mark, the marks of the
-//     voxels active at sweep start); the dependent rest runs in ONE workgroup with the active / frontier / marked
-//     bitmaps in LDS (closureLevelsKernel): a level of the chain costs one 16-byte load per frontier voxel, one voxel per
-//     thread, and the kernel hands the last one a compact work list (active + marked voxels).
-// Three launches per sweep: closurePrepareKernel (chip-wide), closureLevelsKernel (1 workgroup), sweepKernel (chip-wide
-// over the work list).
+//   * the INDIRECT-edge closure (the one sequential coupling of a sweep) is a monotone fixed point, so it needs no
+//     level-by-level order: closureKernel walks it chip-wide, depth first from the voxels active at sweep start, and lists
+//     every voxel the sweep has to touch (active + marked) exactly once.
+// Two launches per sweep: closureKernel, sweepKernel (both chip-wide; the second over the work list).
 //
 // rec[v] = { s0, s1, s2 : S[v] as packed u16 pairs (like hist), lastChange : id of the first S-state that holds the
 // current value }.  S-state t + 1 is what sweep t reads.  lastRescore[v] = id of the S-state v's labels were computed
@@ -729,185 +726,232 @@ __device__ __forceinline__ int argOfPacked( uint32_t s0, uint32_t s1, uint32_t s
   return a;
 }
 
-// Chip-wide first step of a sweep, 32 lanes per voxel u (its DEV row, padded to `stride` entries: 32 or 128):
-//   out[u] = { count, the DEV neighbours u marks if it is active: NO_EDGE voxels whose ppi differs from arg(S[u]) };
-//   rec[nxt][u] = rec[cur][u]  (the copy this sweep's pushes go into);
-//   u active at sweep start: its bit in the active bitmap, its marks, and the larger-index voxels it activates (frontier).
-__device__ __forceinline__ void prepareVoxel( uint32_t u, uint32_t lane, int half, const uint8_t* __restrict__ edge,
-                                              const uint8_t* __restrict__ ppi, const uint4* __restrict__ recCur,
-                                              uint4* __restrict__ recNxt, const uint32_t* __restrict__ dev,
-                                              const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t* __restrict__ out,
-                                              uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
-  const uint4    r      = recCur[u];
-  const uint8_t  a      = uint8_t( argOfPacked( r.x, r.y, r.z ) );
-  const bool     active = edge[u] != NO_EDGE;
-  const uint32_t len    = devLen[u];
-  uint32_t       nOut   = 0;
-  if ( lane == 0 ) {
-    recNxt[u] = r;
-    if ( active ) atomicOr( &gAct[u >> 5], 1u << ( u & 31 ) );
+// The INDIRECT-edge closure of a sweep: ONE chip-wide kernel, no levels.  edge / ppi / S are frozen until sweepKernel, so
+// "u marks v" (v a NO_EDGE voxel of u's DEV row whose ppi differs from arg S[u]) is a static relation, and the voxels a sweep
+// activates are the least fixed point of
+//      activated( v )  <=  some u < v marks v, u active at sweep start or activated
+// (the reference's in-order loop reaches v after u and finds it INDIRECT: PCCPatchSegmenter.cpp:1510-1560).  A union of
+// monotone bit sets: the order in which the marks are found is irrelevant, so nothing has to wait for a level to be
+// complete.  A workgroup takes a run of voxels and puts the ones active at sweep start into a ring in LDS; its 32-lane
+// groups take voxels from the ring, one hop each: read the voxel's DEV row one entry per lane (padded to `stride` entries:
+// 32 or 128), mark, and hand the voxels the hop is the FIRST to activate back to the ring -- except one, which the group
+// keeps and hops on from at once (a chain costs no ring traffic, a fan-out spreads over the workgroup's groups).
+//   state[v >> 4]: two bits per voxel (marked | activated).  One returning atomicOr per candidate answers both "first to
+//                  mark" (-> v is appended to the work list, exactly once) and "first to activate" (-> v is walked, once).
+//   work list:     kSubLists sub-lists with their counters 128 bytes apart (a reservation on ONE word costs 11 ns and they
+//                  queue up: tools/gpu/atomic_rate.hip; spread over cache lines they are free).  The voxels active at
+//                  sweep start carry kWorkActive; for the others sweepKernel reads the activated bit.
+//   LDS ring:      head / tail only grow; a slot holds kNoVoxel while it is empty, so a taker that won the slot waits for the
+//                  giver's store, and `freed` counts the slots handed back (a giver reserves only what `freed` covers).
+//                  `pending` = voxels given and not yet hopped on: a group retires when it finds nothing and pending == 0.
+//   spill ring:    what does not fit the LDS ring goes to a ring in global memory (same protocol); a workgroup that spilled
+//                  looks there whenever its own ring is empty and does not retire before it has seen the global ring empty
+//                  -- whatever it put there is claimed by somebody then, so the LDS ring's size bounds nothing.
+//   Nobody waits inside a divergent branch for anything a sibling half-wave has yet to do: taking is one attempt per loop
+//   iteration, and a giver stores right after its reservation.
+//   state and the counters are double-buffered by sweep parity: this kernel zeroes the pair the next sweep uses.
+// Also rec[nxt][u] = rec[cur][u] for every voxel (the copy this sweep's pushes go into).
+constexpr int      kSubLists = 32;
+constexpr uint32_t kNoVoxel  = 0xFFFFFFFFu;
+struct Closure {
+  const uint8_t*  edge;
+  const uint8_t*  ppi;
+  const uint4*    rec;
+  const uint32_t* dev;
+  const uint32_t* devLen;
+  uint32_t        stride;
+  uint32_t*       state;
+  uint32_t*       list;   // this workgroup's sub-list
+  uint32_t*       count;  // ... and its counter
+  uint32_t*       spill;  // global ring of spillCap voxels, kNoVoxel where empty
+  uint32_t        spillCap;
+  uint32_t*       ctl;  // [0] global ring head, [32] tail (both only ever grow)
+  volatile uint32_t* ring;  // LDS ring of ringCap voxels
+  uint32_t           ringCap;
+  uint32_t*          wg;  // LDS: [0] head, [1] tail, [2] freed, [3] pending, [4] spilled
+};
+enum { kHead = 0, kTail = 1, kFreed = 2, kPending = 3, kSpilled = 4 };
+
+// (one lane) next voxel of the global ring, kNoVoxel when everything handed to it so far has been claimed
+__device__ __forceinline__ uint32_t spillPop( const Closure& c ) {
+  while ( true ) {
+    const uint32_t h = __hip_atomic_load( &c.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    const uint32_t t = __hip_atomic_load( &c.ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( int32_t( t - h ) <= 0 ) return kNoVoxel;
+    if ( atomicCAS( &c.ctl[0], h, h + 1u ) != h ) continue;
+    uint32_t* slot = &c.spill[h % c.spillCap];  // reserved by a giver that stores right after its reservation
+    uint32_t  x;
+    do { x = __hip_atomic_load( slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); } while ( x == kNoVoxel );
+    __hip_atomic_store( slot, kNoVoxel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    return x;
   }
-  for ( uint32_t base = 0; base < len; base += 32 ) {  // (uniform over the 32 lanes of the voxel)
-    const uint32_t v    = base + lane < len ? dev[size_t( u ) * stride + base + lane] : kDevPad;
-    const bool     pred = v != kDevPad && edge[v] == NO_EDGE && ppi[v] != a;
-    const uint32_t m    = uint32_t( __ballot( pred ) >> ( 32 * half ) );
-    if ( pred ) {
-      out[size_t( u ) * stride + 1 + nOut + __popc( m & ( ( 1u << lane ) - 1u ) )] = v;
-      if ( active ) {
-        atomicOr( &gMk[v >> 5], 1u << ( v & 31 ) );
-        if ( v > u ) {  // (v is a NO_EDGE voxel: only marks activate it, so "activated" and "frontier" coincide here)
-          atomicOr( &gAct[v >> 5], 1u << ( v & 31 ) );
-          atomicOr( &gFr[v >> 5], 1u << ( v & 31 ) );
-        }
-      }
-    }
-    nOut += uint32_t( __popc( m ) );
-  }
-  if ( lane == 0 ) out[size_t( u ) * stride] = nOut;
-}
-__global__ __launch_bounds__( 256 ) void closurePrepareKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                                const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
-                                                                const uint32_t* __restrict__ dev,
-                                                                const uint32_t* __restrict__ devLen, uint32_t stride, uint32_t V,
-                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ gAct,
-                                                                uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk ) {
-  // (a capped grid with a stride loop: 8 860 workgroups of eight voxels each made workgroup dispatch the cost of this kernel
-  // when sixteen frames issue it at the same time)
-  for ( uint32_t u = blockIdx.x * 8 + ( threadIdx.x >> 5 ); u < V; u += gridDim.x * 8 )
-    prepareVoxel( u, threadIdx.x & 31, ( threadIdx.x >> 5 ) & 1, edge, ppi, recCur, recNxt, dev, devLen, stride, out, gAct, gFr, gMk );
 }
 
-// Wave-level compaction of a bitmap into a voxel list (whole 64-word chunks; a chunk that does not fit stays for the next
-// round and records where the complete part of the list ends: offsets are handed out in order, so everything below the
-// first failure is complete).  The caller zeroes *count, sets *valid = ~0 and synchronises before; returns the length.
-__device__ __forceinline__ uint32_t compactBitmap( uint32_t* __restrict__ bm, uint32_t W, uint32_t* __restrict__ list,
-                                                   uint32_t cap, uint32_t* count, uint32_t* valid ) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  for ( uint32_t chunk = wave; chunk * 64 < W; chunk += waves ) {
-    const uint32_t w    = chunk * 64 + lane;
-    uint32_t       bits = w < W ? bm[w] : 0u;
-    if ( !__ballot( bits != 0 ) ) continue;  // (most chunks of a late level are empty)
-    const uint32_t cnt = uint32_t( __popc( bits ) );
-    uint32_t       inc = cnt;
-#pragma unroll
-    for ( int off = 1; off < 64; off <<= 1 ) {
-      const uint32_t t = __shfl_up( inc, off, 64 );
-      if ( lane >= off ) inc += t;
+// (one lane) one attempt to take a voxel: the workgroup's ring, else -- if the workgroup spilled -- the global one
+__device__ __forceinline__ uint32_t closureTake( const Closure& c ) {
+  volatile uint32_t* wg = c.wg;
+  const uint32_t     h = wg[kHead], t = wg[kTail];
+  if ( h != t ) {
+    if ( atomicCAS( &c.wg[kHead], h, h + 1u ) != h ) return kNoVoxel;  // (somebody else took it: pending != 0, we come back)
+    volatile uint32_t* slot = &c.ring[h % c.ringCap];
+    uint32_t           x;
+    do { x = *slot; } while ( x == kNoVoxel );
+    *slot = kNoVoxel;
+    __builtin_amdgcn_fence( __ATOMIC_RELEASE, "workgroup" );
+    atomicAdd( &c.wg[kFreed], 1u );
+    return x;
+  }
+  if ( !wg[kSpilled] ) return kNoVoxel;
+  const uint32_t x = spillPop( c );
+  if ( x != kNoVoxel ) atomicAdd( &c.wg[kPending], 1u );
+  return x;
+}
+
+// One hop of the 32-lane group on voxel x; returns the activated voxel the group keeps (kNoVoxel: none).
+__device__ __forceinline__ uint32_t closureHop( const Closure& c, uint32_t x, uint32_t lane, int half ) {
+  const uint32_t below = ( 1u << lane ) - 1u;
+  const uint4    r     = c.rec[x];
+  const uint8_t  a     = uint8_t( argOfPacked( r.x, r.y, r.z ) );
+  // (rows are padded with kDevPad to `stride` entries; a row of 32 is one load that waits for nothing, a row of 128 is
+  // walked as far as its length says)
+  const uint32_t len  = c.stride == 32 ? 32u : c.devLen[x];
+  uint32_t       keep = kNoVoxel;
+  for ( uint32_t base = 0; base < len; base += 32 ) {
+    const uint32_t v     = c.dev[size_t( x ) * c.stride + base + lane];
+    bool           first = false, fresh = false;
+    if ( v != kDevPad && c.edge[v] == NO_EDGE && c.ppi[v] != a ) {
+      const uint32_t sh  = ( v & 15u ) * 2u;
+      const uint32_t old = atomicOr( &c.state[v >> 4], ( v > x ? 3u : 1u ) << sh ) >> sh;
+      first              = !( old & 1u );
+      fresh              = v > x && !( old & 2u );  // (v is a NO_EDGE voxel: only a mark activates it)
     }
-    const uint32_t total = __shfl( inc, 63, 64 );
-    uint32_t       base  = 0;
-    if ( lane == 0 ) base = atomicAdd( count, total );
-    base = __shfl( base, 0, 64 );
-    if ( base + total <= cap ) {
-      if ( bits ) {
-        bm[w]        = 0;
-        uint32_t off = base + inc - cnt;
-        while ( bits ) {
-          list[off++] = 32 * w + uint32_t( __ffs( int( bits ) ) - 1 );
-          bits &= bits - 1;
+    const uint32_t mFirst = uint32_t( __ballot( first ) >> ( 32 * half ) );
+    uint32_t       mFresh = uint32_t( __ballot( fresh ) >> ( 32 * half ) );
+    if ( mFirst ) {
+      const int leader = __ffs( int( mFirst ) ) - 1;
+      uint32_t  at     = 0;
+      if ( int( lane ) == leader ) at = atomicAdd( c.count, uint32_t( __popc( mFirst ) ) );
+      at = __shfl( at, leader, 32 );
+      if ( first ) c.list[at + __popc( mFirst & below )] = v;
+    }
+    if ( !mFresh ) continue;
+    const int leader = __ffs( int( mFresh ) ) - 1;
+    if ( keep == kNoVoxel ) {  // the first one stays with the group (it is pending like the others)
+      keep = __shfl( v, leader, 32 );
+      if ( int( lane ) == leader ) atomicAdd( &c.wg[kPending], 1u );
+      mFresh &= mFresh - 1u;
+      if ( int( lane ) == leader ) fresh = false;
+      if ( !mFresh ) continue;
+    }
+    const uint32_t k  = uint32_t( __popc( mFresh ) );
+    uint32_t       at = kNoVoxel;  // where the k voxels go in the workgroup's ring (kNoVoxel: no room, the global ring)
+    if ( int( lane ) == __ffs( int( mFresh ) ) - 1 ) {
+      volatile uint32_t* wg = c.wg;
+      atomicAdd( &c.wg[kPending], k );
+      while ( true ) {
+        const uint32_t t = wg[kTail];
+        if ( t + k - wg[kFreed] > c.ringCap ) break;
+        if ( atomicCAS( &c.wg[kTail], t, t + k ) == t ) {
+          at = t;
+          break;
         }
       }
-    } else if ( lane == 0 ) {
-      atomicMin( valid, base );
+      if ( at == kNoVoxel ) {
+        atomicSub( &c.wg[kPending], k );
+        wg[kSpilled] = 1u;
+      }
+    }
+    at = __shfl( at, __ffs( int( mFresh ) ) - 1, 32 );
+    if ( fresh ) {
+      if ( at != kNoVoxel ) {
+        c.ring[( at + __popc( mFresh & below ) ) % c.ringCap] = v;
+      } else {
+        const uint32_t idx = atomicAdd( &c.ctl[32], 1u );
+        __hip_atomic_store( &c.spill[idx % c.spillCap], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      }
+    }
+  }
+  return keep;
+}
+
+__global__ __launch_bounds__( 1024 ) void closureKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
+                                                          const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
+                                                          const uint32_t* __restrict__ dev, const uint32_t* __restrict__ devLen,
+                                                          uint32_t stride, uint32_t V, uint32_t run, uint32_t* __restrict__ state,
+                                                          uint32_t* __restrict__ stateNext, uint32_t stateWords,
+                                                          uint32_t* __restrict__ lists, uint32_t listCap,
+                                                          uint32_t* __restrict__ counts, uint32_t* __restrict__ countsNext,
+                                                          uint32_t* __restrict__ spill, uint32_t* __restrict__ ctl,
+                                                          uint32_t ringCap, unsigned long long* __restrict__ timing ) {
+  const unsigned long long   tStart = timing ? wall_clock64() : 0ull;
+  extern __shared__ uint32_t lds[];  // [0, run): the run's voxels active at sweep start; then the ring
+  __shared__ uint32_t        wg[8], listBase;
+  uint32_t*                  ring = lds + run;
+  for ( uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < stateWords; w += gridDim.x * blockDim.x ) stateNext[w] = 0;
+  if ( blockIdx.x == 0 && threadIdx.x < kSubLists ) countsNext[threadIdx.x * 32] = 0;
+  if ( threadIdx.x < 8 ) wg[threadIdx.x] = 0;
+  for ( uint32_t i = threadIdx.x; i < ringCap; i += blockDim.x ) ring[i] = kNoVoxel;
+  __syncthreads();
+  const uint32_t u0 = blockIdx.x * run, u1 = min( V, u0 + run );
+  for ( uint32_t u = u0 + threadIdx.x; u < u1; u += blockDim.x ) {
+    recNxt[u] = recCur[u];
+    if ( edge[u] != NO_EDGE ) {
+      const uint32_t i = atomicAdd( &wg[kTail], 1u );
+      lds[i] = u, ring[i] = u;  // (ringCap >= run)
     }
   }
   __syncthreads();
-  return min( *count, *valid );
+  const uint32_t n   = wg[kTail];
+  const uint32_t sub = blockIdx.x % kSubLists;
+  uint32_t       at  = 0;
+  if ( threadIdx.x == 0 ) {
+    wg[kPending] = n;
+    if ( n ) at = atomicAdd( &counts[sub * 32], n );  // (the answer is not needed before the walk is done)
+  }
+  __syncthreads();
+  Closure c;
+  c.edge = edge, c.ppi = ppi, c.rec = recCur, c.dev = dev, c.devLen = devLen, c.stride = stride, c.state = state;
+  c.list = lists + size_t( sub ) * listCap, c.count = &counts[sub * 32], c.spill = spill, c.spillCap = listCap, c.ctl = ctl;
+  c.ring = ring, c.ringCap = ringCap, c.wg = wg;
+  const uint32_t lane = threadIdx.x & 31;
+  const int      half = int( ( threadIdx.x >> 5 ) & 1 );
+  // (test hook: timing[0] = max ticks from kernel start to the walk, [1] = max ticks in the walk, [2] = most hops of a
+  //  group, [3] += hops, [4] += workgroups that spilled)
+  const unsigned long long t0   = timing ? wall_clock64() : 0ull;
+  uint32_t                 hops = 0, x = kNoVoxel;
+  while ( true ) {
+    if ( x == kNoVoxel ) {
+      const uint32_t pending = reinterpret_cast<volatile uint32_t*>( wg )[kPending];  // (read BEFORE the attempt)
+      if ( lane == 0 ) x = closureTake( c );
+      x = __shfl( x, 0, 32 );
+      if ( x == kNoVoxel ) {
+        if ( pending == 0 ) break;  // nothing in the ring, nobody hopping: nothing can turn up any more
+        __builtin_amdgcn_s_sleep( 2 );
+        continue;
+      }
+    }
+    const uint32_t next = closureHop( c, x, lane, half );
+    ++hops;
+    if ( lane == 0 ) atomicSub( &wg[kPending], 1u );
+    x = next;
+  }
+  if ( timing && lane == 0 ) {
+    atomicMax( &timing[0], t0 - tStart );
+    atomicMax( &timing[1], wall_clock64() - t0 );
+    atomicMax( &timing[2], (unsigned long long)hops );
+    atomicAdd( &timing[3], (unsigned long long)hops );
+    if ( threadIdx.x == 0 && wg[kSpilled] ) atomicAdd( &timing[4], 1ull );
+  }
+  if ( threadIdx.x == 0 ) listBase = at;
+  __syncthreads();
+  for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) c.list[listBase + i] = lds[i] | kWorkActive;
 }
 
-// The dependent rest of the closure, one workgroup.  LDS: active | frontier | marked | scratch bitmaps (V bits each), list.
-// Hands the global bitmaps back empty, writes the work list of sweepKernel: every active voxel, then the voxels that were
-// only marked.
-__device__ __forceinline__ void walkLevels( const uint32_t* __restrict__ out, uint32_t stride, uint32_t V, uint32_t listCap,
-                                            uint32_t* __restrict__ gAct, uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk,
-                                            uint32_t* __restrict__ work, uint32_t* __restrict__ workCount,
-                                            unsigned long long* __restrict__ timing ) {
-  extern __shared__ uint32_t lds[];
-  // (test hook: timing[0..3] += ticks of load / compaction / voxel processing / list emission, [4] += rounds, [5] += voxels)
-  unsigned long long tick = timing ? wall_clock64() : 0ull, tLoad = 0, tCompact = 0, tProcess = 0, tEmit = 0, rounds = 0;
-#define TMC2_LAP( acc )                              \
-  if ( timing && threadIdx.x == 0 ) {                \
-    const unsigned long long now_ = wall_clock64();  \
-    acc += now_ - tick;                              \
-    tick = now_;                                     \
-  }
-  __shared__ uint32_t nList, nValid;
-  const uint32_t      W   = ( V + 31 ) / 32;
-  uint32_t *          act = lds, *fr = act + W, *mk = fr + W, *tmp = mk + W, *list = tmp + W;
-  for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
-    const uint32_t a = gAct[w], f = gFr[w], m = gMk[w];
-    act[w] = a, fr[w] = f, mk[w] = m, tmp[w] = a & ~f;
-    if ( a ) gAct[w] = 0;
-    if ( f ) gFr[w] = 0;
-    if ( m ) gMk[w] = 0;
-  }
-  uint32_t nWork = 0;  // (uniform: every thread keeps the same count)
-  // phase 0: list the voxels active at sweep start (their marks are made already);  phase 1: the closure, level by level,
-  // listing the voxels of each level (the first one: what the voxels of phase 0 activated);  phase 2: the voxels that
-  // were only marked.  Every voxel is listed once, whatever the number of rounds a full list splits a level into.
-  for ( int phase = 0; phase < 3; ++phase ) {
-    bool first = true;
-    while ( true ) {
-      if ( threadIdx.x == 0 ) {
-        nList  = 0;
-        nValid = 0xFFFFFFFFu;
-      }
-      __syncthreads();
-      if ( phase == 0 && first ) { TMC2_LAP( tLoad ) }
-      const uint32_t n     = compactBitmap( phase == 0 ? tmp : ( phase == 1 ? fr : mk ), W, list, listCap, &nList, &nValid );
-      const bool     empty = nList == 0;
-      __syncthreads();  // (nList is reset at the top of the next round)
-      if ( phase == 1 ) { TMC2_LAP( tCompact ) } else { TMC2_LAP( tEmit ) }
-      if ( empty ) break;
-      for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) work[nWork + i] = list[i] | ( phase == 2 ? 0u : kWorkActive );
-      nWork += n;
-      first = false;
-      if ( phase != 1 ) continue;
-      ++rounds;
-      for ( uint32_t i = threadIdx.x; i < n; i += blockDim.x ) {  // one voxel per thread: one 16-byte load per hop
-        const uint32_t  u    = list[i];
-        const uint32_t* row  = out + size_t( u ) * stride;
-        const uint4 head = reinterpret_cast<const uint4*>( row )[0];  // count + the first seven targets: one round
-        const uint4 more = reinterpret_cast<const uint4*>( row )[1];  // trip for all but the rarest voxels
-        for ( uint32_t k = 0; k < head.x; ++k ) {
-          const uint32_t v   = k == 0   ? head.y
-                               : k == 1 ? head.z
-                               : k == 2 ? head.w
-                               : k == 3 ? more.x
-                               : k == 4 ? more.y
-                               : k == 5 ? more.z
-                               : k == 6 ? more.w
-                                        : row[1 + k];
-          const uint32_t bit = 1u << ( v & 31 );
-          atomicOr( &mk[v >> 5], bit );
-          if ( v > u && !( atomicOr( &act[v >> 5], bit ) & bit ) ) atomicOr( &fr[v >> 5], bit );
-        }
-      }
-      __syncthreads();
-      TMC2_LAP( tProcess )
-    }
-    if ( phase == 1 ) {  // what is left to list: marked, but never active
-      for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) mk[w] &= ~act[w];
-    }
-  }
-  if ( threadIdx.x == 0 ) *workCount = nWork;
-  TMC2_LAP( tEmit )
-  if ( timing && threadIdx.x == 0 ) {
-    timing[0] += tLoad, timing[1] += tCompact, timing[2] += tProcess, timing[3] += tEmit, timing[4] += rounds, timing[5] += nWork;
-  }
-#undef TMC2_LAP
-}
-__global__ __launch_bounds__( 1024 ) void closureLevelsKernel( const uint32_t* __restrict__ out, uint32_t stride, uint32_t V,
-                                                                uint32_t listCap, uint32_t* __restrict__ gAct,
-                                                                uint32_t* __restrict__ gFr, uint32_t* __restrict__ gMk,
-                                                                uint32_t* __restrict__ work, uint32_t* __restrict__ workCount,
-                                                                unsigned long long* __restrict__ timing ) {
-  walkLevels( out, stride, V, listCap, gAct, gFr, gMk, work, workCount, timing );
-}
 
 // The rest of a sweep for the voxels of the work list, 16 lanes each: decide, re-score if S changed since the labels were
 // computed, push the histogram difference to the reverse row, refresh edge class / ppi.
-__global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict__ work, const uint32_t* __restrict__ workCount,
+__global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict__ lists, uint32_t listCap,
+                                                       const uint32_t* __restrict__ counts, const uint32_t* __restrict__ state,
                                                        const uint4* __restrict__ recCur, uint4* __restrict__ recNxt,
                                                        uint32_t* __restrict__ lastRescore, const double* __restrict__ weight,
                                                        const uint32_t* __restrict__ pointStart,
@@ -916,10 +960,29 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
                                                        const uint32_t* __restrict__ radj, uint8_t* __restrict__ edge,
                                                        uint8_t* __restrict__ ppi, uint4* __restrict__ hist,
                                                        uint8_t* __restrict__ partition, uint32_t* __restrict__ flags, int iter ) {
+  // the sub-lists as one index space: pre[s] = entries of the sub-lists before s
+  __shared__ uint32_t pre[kSubLists + 1];
+  if ( threadIdx.x < 64 ) {
+    uint32_t inc = threadIdx.x < kSubLists ? counts[threadIdx.x * 32] : 0u;
+#pragma unroll
+    for ( int off = 1; off < kSubLists; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( int( threadIdx.x ) >= off ) inc += t;
+    }
+    if ( threadIdx.x < kSubLists ) pre[threadIdx.x + 1] = inc;
+    if ( threadIdx.x == 0 ) pre[0] = 0;
+  }
+  __syncthreads();
   const int      sub    = threadIdx.x & 15;
-  const uint32_t groups = gridDim.x * 16, count = *workCount;
+  const uint32_t groups = gridDim.x * 16, count = pre[kSubLists];
   for ( uint32_t idx = blockIdx.x * 16 + ( threadIdx.x >> 4 ); idx < count; idx += groups ) {  // (uniform over the 16 lanes)
-    const uint32_t entry = work[idx], v = entry & ~kWorkActive;
+    uint32_t sl = 0;  // the last sub-list that starts at or before idx
+#pragma unroll
+    for ( int step = kSubLists / 2; step > 0; step >>= 1 )
+      if ( pre[sl + step] <= idx ) sl += step;
+    const uint32_t raw = lists[size_t( sl ) * listCap + ( idx - pre[sl] )], v = raw & ~kWorkActive;
+    // active at sweep start (flagged by closureKernel), or activated by the closure
+    const uint32_t entry = v | ( ( raw & kWorkActive ) || ( ( state[v >> 4] >> ( ( v & 15u ) * 2u + 1u ) ) & 1u ) ? kWorkActive : 0u );
     const uint8_t  e0 = edge[v];
     bool           p  = false;
     uint32_t       b[6];
@@ -1028,7 +1091,7 @@ struct RefineJob {
   std::vector<int> offsets;
   uint32_t*        table = nullptr;
   bool             tableFilled = false, eventDriven = false;
-  size_t           Vp = 0, ldsRoom = 0, ldsFixed = 0, ball = 0, perVoxel = 0;
+  size_t           Vp = 0, W2 = 0, ball = 0, perVoxel = 0;
   uint64_t         capacity = 0;
   uint32_t         res[2] = {0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag
   DevBuf<uint32_t> d_key, d_flag, d_vid, d_small, d_count, d_rowLen, d_devLen, d_adjOff, d_hist, d_activeBuf, d_pointStart,
@@ -1142,13 +1205,13 @@ int RefineJob::geometry( tmc2_frame* f ) {
   TMC2_TRY( d_S.alloc( V ) );
   // every buffer of this stage that starts from zeros, in one launch (the event-driven loop's among them)
   W = ( V + 31 ) / 32;
-  // Which sweep loop: the event-driven one needs the closure's four bitmaps and a voxel list in the LDS of one workgroup
-  // (160 KB: up to ~ 290 K voxels; a vox11 frame has ~ 240 K).  Larger grids take the sweep-everything loop.
-  // (test hook TMC2_REFINE_SWEEPS=full forces that one)
+  // Which sweep loop: the event-driven one, unless the test hook TMC2_REFINE_SWEEPS=full asks for the sweep-everything loop
   const char* sweepsEnv = getenv( "TMC2_REFINE_SWEEPS" );
-  ldsRoom     = 160 * 1024 - 64;  // gfx950: 160 KB of LDS per workgroup (opt-in above 64 KB); static part: 8 bytes
-  ldsFixed    = 16 * size_t( W );
-  eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' ) && ldsFixed + 4 * 2048 <= ldsRoom;
+  eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' );
+  W2          = ( size_t( V ) + 15 ) / 16;  // closure state: two bits per voxel
+  // closure scratch: state bitmaps of the two sweep parities | list counters of the two parities (one per 128 bytes) | ring
+  // head, tail (64 words) | the spill ring (V voxels)
+  const size_t closureZeroWords = 2 * W2 + 2 * size_t( kSubLists ) * 32 + 64;
   TMC2_TRY( d_pointStart.alloc( size_t( V ) + 1 ) );
   TMC2_TRY( d_pointList.alloc( n ) );
   TMC2_TRY( d_cursor.alloc( V ) );
@@ -1157,7 +1220,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
     TMC2_TRY( d_rcount.alloc( size_t( V ) + 1 ) );
     TMC2_TRY( d_rcursor.alloc( size_t( V ) + 1 ) );
     TMC2_TRY( d_lastRescore.alloc( V ) );
-    TMC2_TRY( d_gbits.alloc( 3 * size_t( W ) ) );
+    TMC2_TRY( d_gbits.alloc( closureZeroWords + V ) );
   }
   TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( V ) + 1 ) * 4, 0},
                                {d_hist.p, size_t( V ) * 16, 0},
@@ -1168,7 +1231,8 @@ int RefineJob::geometry( tmc2_frame* f ) {
                                {d_rcount.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
                                {d_rcursor.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
                                {d_lastRescore.p, eventDriven ? size_t( V ) * 4 : 0, 0},
-                               {d_gbits.p, eventDriven ? 3 * size_t( W ) * 4 : 0, 0}} ) );
+                               {d_gbits.p, eventDriven ? closureZeroWords * 4 : 0, 0},
+                               {d_gbits.p + closureZeroWords, eventDriven ? size_t( V ) * 4 : 0, 0xFF}} ) );  // kNoVoxel
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
@@ -1238,17 +1302,14 @@ int RefineJob::finish() {
                       d_hist.p );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
                       d_edge, d_ppi, d_active );
-  const char* prepEnv = getenv( "TMC2_REFINE_PREPARE_BLOCKS" );  // (test hook: the grid of closurePrepareKernel)
-  const dim3  grdV32( std::min<uint32_t>( ( V + 7 ) / 8, prepEnv ? uint32_t( std::max( 1, atoi( prepEnv ) ) ) : cappedBlocks( ctx, ( V + 7 ) / 8 ) ) );
   if ( eventDriven ) {
     // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
-    DevBuf<uint32_t> d_roff, d_radj, d_work, d_out;
+    DevBuf<uint32_t> d_roff, d_radj, d_lists;
     DevBuf<uint4>    d_rec;
     TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
     TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
-    TMC2_TRY( d_work.alloc( size_t( V ) + 1 ) );  // [V]: the list's length
+    TMC2_TRY( d_lists.alloc( size_t( kSubLists ) * V ) );  // (a voxel is listed once per sweep: any sub-list can hold them all)
     TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
-    TMC2_TRY( d_out.alloc( size_t( V ) * devStride ) );
     hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcount.p );
     TMC2_TRY( exclusiveScanU32( ctx, d_rcount.p, d_roff.p, size_t( V ) + 1, nullptr ) );
     hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
@@ -1257,33 +1318,45 @@ int RefineJob::finish() {
                         d_rowLen.p, d_adj.p, V, d_rec.p );
     ctx->stageEnd( sidSetup );
     TMC2_HIP( hipGetLastError() );
-    const int      sidSweep = ctx->stageBegin( "refine_sweeps" );
-    // (test hook TMC2_REFINE_LISTCAP: a short voxel list, so that small frames split their levels over several rounds too)
-    const char*    listEnv  = getenv( "TMC2_REFINE_LISTCAP" );
-    const uint32_t listCap  = uint32_t( std::min<size_t>( listEnv ? std::max( 2048, atoi( listEnv ) ) : 8192, ( ldsRoom - ldsFixed ) / 4 ) );
-    const size_t   ldsBytes = ldsFixed + 4 * size_t( listCap );
-    if ( ldsBytes > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureLevelsKernel ), ldsBytes, ctx->device ) );
+    const int sidSweep = ctx->stageBegin( "refine_sweeps" );
+    // closureKernel: a run of voxels per workgroup; LDS = the run's active voxels + the ring
+    // (test hooks: TMC2_REFINE_CLOSURE_BLOCKS = its grid, TMC2_REFINE_CLOSURE_THREADS = its workgroup; TMC2_REFINE_RING = room
+    // of the LDS ring beyond the run -- 1 sends nearly every fan-out through the spill ring)
+    const char*    gridEnv    = getenv( "TMC2_REFINE_CLOSURE_BLOCKS" );
+    const char*    threadsEnv = getenv( "TMC2_REFINE_CLOSURE_THREADS" );
+    const char*    ringEnv    = getenv( "TMC2_REFINE_RING" );
+    const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 256;
+    const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
+    const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
+                                        : cappedBlocks( ctx, ( V + perGroup * ( closureThreads / 32 ) - 1 ) / ( perGroup * ( closureThreads / 32 ) ) );
+    const uint32_t run        = std::min<uint32_t>( 8192u, std::max<uint32_t>( 1u, ( V + wantGrid - 1 ) / wantGrid ) );
+    const dim3     grdClosure( ( V + run - 1 ) / run );
+    const uint32_t ringCap    = run + ( ringEnv ? uint32_t( std::min( 8192, std::max( 1, atoi( ringEnv ) ) ) ) : 1024u );
+    const size_t   closureLds = 4 * ( size_t( run ) + ringCap );
+    if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
     const dim3 grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, size_t( 2 ) * ctx->cuCount ) ) );
-    DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure's tail spends its time
+    const bool wantTrace = getenv( "TMC2_REFINE_TRACE" ) != nullptr;
+    DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
     const bool                 wantTiming = getenv( "TMC2_REFINE_TIMING" ) != nullptr;
-    const bool                 wantTrace  = getenv( "TMC2_REFINE_TRACE" ) != nullptr;
     if ( wantTiming ) {
-      TMC2_TRY( d_timing.alloc( 8 ) );
-      TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64, s ) );
+      TMC2_TRY( d_timing.alloc( 8 * size_t( iterationCount ) ) );
+      TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64 * size_t( iterationCount ), s ) );
     }
-    uint32_t *gAct = d_gbits.p, *gFr = d_gbits.p + W, *gMk = d_gbits.p + 2 * size_t( W );
-    // (test hook TMC2_REFINE_WALK_THREADS: the size of the level walk's one workgroup)
-    const char* walkEnv     = getenv( "TMC2_REFINE_WALK_THREADS" );
-    const int   walkThreads = walkEnv ? std::min( 1024, std::max( 64, atoi( walkEnv ) & ~63 ) ) : 1024;
+    // d_gbits: state bitmaps of the two sweep parities | list counters of the two parities (one per 128 bytes) | ring head,
+    // tail | the spill ring
+    uint32_t*  state[2]  = {d_gbits.p, d_gbits.p + W2};
+    uint32_t*  counts[2] = {d_gbits.p + 2 * size_t( W2 ), d_gbits.p + 2 * size_t( W2 ) + kSubLists * 32};
+    uint32_t*  ctl       = d_gbits.p + 2 * size_t( W2 ) + 2 * kSubLists * 32;
+    uint32_t*  spill     = ctl + 64;
     for ( int iter = 0; iter < iterationCount; ++iter ) {
-      uint4 *recCur = d_rec.p + size_t( iter & 1 ) * V, *recNxt = d_rec.p + size_t( ( iter + 1 ) & 1 ) * V;
-      hipLaunchKernelGGL( closurePrepareKernel, grdV32, blk, 0, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p, devStride,
-                          V, d_out.p, gAct, gFr, gMk );
-      hipLaunchKernelGGL( closureLevelsKernel, dim3( 1 ), dim3( walkThreads ), ldsBytes, s, d_out.p, devStride, V, listCap, gAct, gFr,
-                          gMk, d_work.p, d_work.p + V, wantTiming ? d_timing.p : nullptr );
-      hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_work.p, d_work.p + V, recCur, recNxt, d_lastRescore.p,
-                          d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge, d_ppi,
-                          reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
+      const int cur    = iter & 1, nxt = cur ^ 1;
+      uint4 *   recCur = d_rec.p + size_t( cur ) * V, *recNxt = d_rec.p + size_t( nxt ) * V;
+      hipLaunchKernelGGL( closureKernel, grdClosure, dim3( closureThreads ), closureLds, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p,
+                          devStride, V, run, state[cur], state[nxt], uint32_t( W2 ), d_lists.p, V, counts[cur], counts[nxt], spill,
+                          ctl, ringCap, wantTiming ? d_timing.p + 8 * size_t( iter ) : nullptr );
+      hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
+                          d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge,
+                          d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
     }
     ctx->stageEnd( sidSweep );
     TMC2_HIP( hipGetLastError() );
@@ -1291,12 +1364,12 @@ int RefineJob::finish() {
     ctx->stageAddHostMs( "refine_voxels", double( V ) );                        //  roofline of a sweep is quoted on,
     ctx->stageAddHostMs( "refine_row_entries", double( totalLen ) );            //  V and L = entries / V)
     if ( wantTiming ) {
-      unsigned long long t[8];
-      TMC2_HIP( hipMemcpyAsync( t, d_timing.p, 64, hipMemcpyDeviceToHost, s ) );
+      std::vector<unsigned long long> t( 8 * size_t( iterationCount ) );
+      TMC2_HIP( hipMemcpyAsync( t.data(), d_timing.p, t.size() * 8, hipMemcpyDeviceToHost, s ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
-      const double us = 0.01 / iterationCount;  // wall_clock64 ticks at 100 MHz
-      fprintf( stderr, "refine closure tail, per sweep: load %.1f us, compaction %.1f us, voxels %.1f us, lists %.1f us; %.1f levels, %.0f listed voxels (V = %u)\n",
-               t[0] * us, t[1] * us, t[2] * us, t[3] * us, double( t[4] ) / iterationCount, double( t[5] ) / iterationCount, V );
+      fprintf( stderr, "refine closure (V = %u, %u workgroups, runs of %u), per sweep: us to the walk | us walking | most hops of a group | hops | spilling workgroups\n", V, grdClosure.x, run );
+      for ( int m = 0; m < iterationCount; ++m )  // wall_clock64 ticks at 100 MHz
+        fprintf( stderr, "  %2d: %5.1f %5.1f %4llu %6llu %3llu\n", m, t[8 * m] * 0.01, t[8 * m + 1] * 0.01, t[8 * m + 2], t[8 * m + 3], t[8 * m + 4] );
     }
     if ( wantTrace ) {  // test hook: points moved per sweep
       std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );

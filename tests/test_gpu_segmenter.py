@@ -138,8 +138,8 @@ def test_gpu_full_size_properties(gpu_ctx):
 @pytest.mark.parametrize("sweeps", ["event-driven", "full"])
 @pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 50), ("medium", 20)])
 def test_gpu_refine_matches_oracle(gpu_ctx, oracle, monkeypatch, name, iters, sweeps):
-    """Both sweep loops of S5: the event-driven one (default: incremental S, re-scoring only where S changed, closure
-    levels in one workgroup) and the sweep-everything one that grids beyond the LDS take (TMC2_REFINE_SWEEPS=full)."""
+    """Both sweep loops of S5: the event-driven one (default: incremental S, re-scoring only where S changed, the closure
+    walked chip-wide without levels) and the sweep-everything one kept as a cross-check (TMC2_REFINE_SWEEPS=full)."""
     if sweeps == "full":
         monkeypatch.setenv("TMC2_REFINE_SWEEPS", "full")
     xyz, rgb = synth_cloud(name)
@@ -183,12 +183,17 @@ def test_gpu_refine_row_capacity_retry(gpu_ctx, oracle, monkeypatch, vox_dim):
     assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10, vox_dim=vox_dim))
 
 
+@pytest.mark.parametrize("stack,blocks", [("1", None), ("2", "3"), (None, "1")])
 @pytest.mark.parametrize("vox_dim", [4, 2])
-def test_gpu_refine_levels_split_over_rounds(gpu_ctx, oracle, monkeypatch, vox_dim):
-    """The closure's level walk keeps its frontier in a voxel list of bounded length; a level (or the set of voxels active at
-    sweep start) that does not fit is split over several rounds.  A short list makes a medium frame do what a full-size
-    frame does with the real one: every voxel must still be listed -- and processed -- exactly once."""
-    monkeypatch.setenv("TMC2_REFINE_LISTCAP", "2048")
+def test_gpu_refine_closure_spill_ring(gpu_ctx, oracle, monkeypatch, vox_dim, stack, blocks):
+    """The closure walks depth first with a ring in LDS per workgroup; what does not fit goes through a ring in global
+    memory that the spilling group drains before it retires.  A ring with room for one or two voxels beyond the run sends nearly every activated voxel
+    through the ring; a grid of 1 / 3 workgroups makes the runs of voxels long.  Every voxel must still be listed -- and
+    processed -- exactly once."""
+    if stack:
+        monkeypatch.setenv("TMC2_REFINE_RING", stack)
+    if blocks:
+        monkeypatch.setenv("TMC2_REFINE_CLOSURE_BLOCKS", blocks)
     xyz, rgb = synth_cloud("medium")
     nrm = oracle.normals(xyz)
     p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))

@@ -9,7 +9,7 @@ python - "$DB" > $OUT/${1:-r03}_sweep_kernels.txt <<'PY'
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name,start,end from kernels order by start").fetchall()
-want = ("sweepDirtyKernel", "sweepClosureKernel", "sweepProcessKernel", "closurePrepareKernel", "closureLevelsKernel", "sweepKernel")
+want = ("closureKernel", "sweepDirtyKernel", "sweepClosureKernel", "sweepProcessKernel", "closurePrepareKernel", "closureLevelsKernel", "sweepKernel")
 per = {}
 for n, s, e in rows:
     m = re.search(r"(\w+Kernel)", n)
