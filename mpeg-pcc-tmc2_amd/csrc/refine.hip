@@ -849,8 +849,8 @@ __device__ __forceinline__ uint32_t closureHop( const Closure& c, uint32_t x, ui
       volatile uint32_t* wg = c.wg;
       atomicAdd( &c.wg[kPending], k );
       while ( true ) {
-        const uint32_t t = wg[kTail];
-        if ( t + k - wg[kFreed] > c.ringCap ) break;
+        const uint32_t f = wg[kFreed], t = wg[kTail];  // (in this order: tail, read later, is not behind freed)
+        if ( t + k - f > c.ringCap ) break;
         if ( atomicCAS( &c.wg[kTail], t, t + k ) == t ) {
           at = t;
           break;
@@ -1325,7 +1325,7 @@ int RefineJob::finish() {
     const char*    gridEnv    = getenv( "TMC2_REFINE_CLOSURE_BLOCKS" );
     const char*    threadsEnv = getenv( "TMC2_REFINE_CLOSURE_THREADS" );
     const char*    ringEnv    = getenv( "TMC2_REFINE_RING" );
-    const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 256;
+    const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 512;
     const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
     const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
                                         : cappedBlocks( ctx, ( V + perGroup * ( closureThreads / 32 ) - 1 ) / ( perGroup * ( closureThreads / 32 ) ) );
