@@ -71,7 +71,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
                                                      uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist,
-                                                     int xcdAware ) {
+                                                     int xcdAware, uint32_t nTree ) {
   // Which 256 queries this workgroup takes.  Workgroups are handed to the eight XCDs round-robin (block b runs on XCD b % 8:
   // observed, not promised -- only speed depends on it), so consecutive blocks -- neighbours in tree order, walking the same
   // part of the tree -- land on eight different L2s, and every L2 ends up streaming the whole tree (9.4 MB at longdress size
@@ -103,6 +103,34 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   if ( qz < root.lo[2] ) o2 = root.lo[2] - qz;
   if ( qz > root.hi[2] ) o2 = qz - root.hi[2];
 
+  // An upper bound of the K-th distance BEFORE the traversal: K real points next to the query in tree order (the query's own
+  // neighbours for SELF; the points around the leaf a stack-less descent ends in otherwise) -- their largest distance bounds
+  // the K-th smallest distance of the whole cloud from above.  The traversal prunes with min( worst of the list, cap ): a
+  // subtree farther than cap holds nothing that can end up in the list, and skipping it leaves the order in which the others
+  // are visited as it was, so the list is the reference's, ties included.  What it buys: nanoflann's first descent runs with
+  // an unbounded list and leaves one pending far child per tree level (~ 25 stack entries per query, most of them spilled to
+  // private memory: ~ 90 MB written and read back per launch at longdress size, 6 x the algorithmic bytes); with the cap the
+  // stack holds the handful of far children that are really near.
+  uint32_t cap = 0;
+  {
+    uint32_t centre = j;
+    if ( !SELF ) {
+      uint32_t at = 0;
+      KdNode   nd = nodes[0];
+      while ( nd.dim >= 0 ) {
+        const int v = nd.dim == 0 ? qx : ( nd.dim == 1 ? qy : qz );
+        at          = ( ( v - nd.divlow ) + ( v - nd.divhigh ) ) < 0 ? uint32_t( nd.a ) : uint32_t( nd.b );
+        nd          = nodes[at];
+      }
+      centre = uint32_t( nd.a + nd.b ) >> 1;
+    }
+    const uint32_t first = min( centre > uint32_t( K / 2 ) ? centre - uint32_t( K / 2 ) : 0u, nTree - uint32_t( K ) );
+    for ( int i = 0; i < K; ++i ) {
+      const Pt  c  = ptsTree[first + i];
+      const int ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
+      cap          = max( cap, uint32_t( ex * ex + ey * ey + ez * ez ) );
+    }
+  }
   __shared__ unsigned long long ldsStack[LDS ? kLdsTop * 256 : 1];  // [slot][thread], slots < kLdsTop
   unsigned long long            lowStack[LDS ? kLdsLevels : 1];       // slots >= kLdsTop (private memory)
   uint4                         scratchStack[LDS ? 1 : kMaxStack];
@@ -121,7 +149,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       const uint32_t nearC = leftNear ? uint32_t( nd.a ) : uint32_t( nd.b );
       const uint32_t farC  = leftNear ? uint32_t( nd.b ) : uint32_t( nd.a );
       const uint32_t farMin = uint32_t( o0 * o0 + o1 * o1 + o2 * o2 + ofar * ofar - ocur * ocur );
-      if ( farMin <= bd[K - 1] && sp < ( LDS ? kLdsLevels : kMaxStack ) ) {
+      if ( farMin <= min( bd[K - 1], cap ) && sp < ( LDS ? kLdsLevels : kMaxStack ) ) {
         const uint32_t f0 = uint32_t( nd.dim == 0 ? ofar : o0 ), f1 = uint32_t( nd.dim == 1 ? ofar : o1 ),
                        f2 = uint32_t( nd.dim == 2 ? ofar : o2 );
         if ( LDS ) {
@@ -139,11 +167,28 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       node = nearC;
       nd   = nodes[node];
     }
-    for ( int p = nd.a; p < nd.b; ++p ) {
-      const Pt       c    = ptsTree[p];
-      const int      ex = qx - c.x, ey = qy - c.y, ez = qz - c.z;
-      const uint32_t dist = uint32_t( ex * ex + ey * ey + ez * ez );
-      if ( dist < bd[K - 1] ) knnInsert<K>( bd, bi, dist, perm[p] );
+    // The leaf's points, two per 16-byte load (a pair starts at an even tree position; what lies outside [a, b) is skipped).
+    // The list keeps TREE POSITIONS: the original indices are looked up once at the end, all lanes in step, instead of one
+    // scattered 4-byte load per insertion.  (A candidate beyond cap cannot stay in the list and is never the reason another
+    // one is rejected: it is skipped.)
+    for ( int p = nd.a & ~1; p < nd.b; p += 2 ) {
+      uint4 two;
+      if ( uint32_t( p ) + 1u < nTree ) {
+        two = *reinterpret_cast<const uint4*>( ptsTree + p );
+      } else {
+        const uint2 one = *reinterpret_cast<const uint2*>( ptsTree + p );
+        two             = make_uint4( one.x, one.y, 0u, 0u );
+      }
+      if ( p >= nd.a ) {
+        const int      ex = qx - int( int16_t( two.x & 0xFFFFu ) ), ey = qy - int( int16_t( two.x >> 16 ) ), ez = qz - int( int16_t( two.y & 0xFFFFu ) );
+        const uint32_t dist = uint32_t( ex * ex + ey * ey + ez * ez );
+        if ( dist < bd[K - 1] && dist <= cap ) knnInsert<K>( bd, bi, dist, uint32_t( p ) );
+      }
+      if ( p + 1 < nd.b ) {
+        const int      ex = qx - int( int16_t( two.z & 0xFFFFu ) ), ey = qy - int( int16_t( two.z >> 16 ) ), ez = qz - int( int16_t( two.w & 0xFFFFu ) );
+        const uint32_t dist = uint32_t( ex * ex + ey * ey + ez * ez );
+        if ( dist < bd[K - 1] && dist <= cap ) knnInsert<K>( bd, bi, dist, uint32_t( p + 1 ) );
+      }
     }
     // The first descent runs with an unbounded list and therefore leaves one pending far child per tree level.  As soon as
     // the list is full, nearly all of them (the far side of the coarse splits) fail the bound, and the bound only
@@ -156,7 +201,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       for ( int i = 0; i < sp; ++i ) {
         const unsigned long long e = i < kLdsTop ? ldsStack[i * 256 + threadIdx.x] : lowStack[i - kLdsTop];
         const uint32_t e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
-        if ( e0 * e0 + e1 * e1 + e2 * e2 <= bd[K - 1] ) {
+        if ( e0 * e0 + e1 * e1 + e2 * e2 <= min( bd[K - 1], cap ) ) {
           if ( w < kLdsTop )
             ldsStack[w * 256 + threadIdx.x] = e;
           else
@@ -177,7 +222,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
         const uint4 e = scratchStack[sp];
         en = e.x, e0 = e.y, e1 = e.z, e2 = e.w;
       }
-      if ( e0 * e0 + e1 * e1 + e2 * e2 <= bd[K - 1] ) {
+      if ( e0 * e0 + e1 * e1 + e2 * e2 <= min( bd[K - 1], cap ) ) {
         node  = en;
         o0    = int( e0 );
         o1    = int( e1 );
@@ -191,7 +236,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   const size_t row = SELF ? size_t( perm[j] ) : size_t( j );
   uint32_t*    oi  = outIdx + row * K;
 #pragma unroll
-  for ( int i = 0; i < K; ++i ) oi[i] = bi[i];
+  for ( int i = 0; i < K; ++i ) oi[i] = perm[bi[i]];  // (the list is full: k <= n, and everything within cap was visited)
   if ( outDist ) {
     uint32_t* od = outDist + row * K;
 #pragma unroll
@@ -226,10 +271,10 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
 #define TMC2_LAUNCH_K( KK )                                                                                          \
   if ( lds ) {                                                                                                       \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,          \
-                        uint32_t( nq ), idx, dist, xcdAware );                                                       \
+                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ) );                                                       \
   } else {                                                                                                           \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, false> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,         \
-                        uint32_t( nq ), idx, dist, xcdAware );                                                       \
+                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ) );                                                       \
   }
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
