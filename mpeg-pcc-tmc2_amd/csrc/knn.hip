@@ -51,16 +51,19 @@ struct RootBox {
 
 template <int K>
 __device__ __forceinline__ void knnInsert( uint32_t ( &bd )[K], uint32_t ( &bi )[K], uint32_t dist, uint32_t index ) {
-  // precondition: dist < bd[K-1].  New entry goes after every entry with bd <= dist.
+  // precondition: dist < bd[K-1].  New entry goes after every entry with bd <= dist.  Branch-free, top slot first (a slot
+  // reads the OLD value of the one below it): with the list sorted, the new bd[j] is the median of ( bd[j-1], dist, bd[j] ) --
+  // bd[j] where it stays, dist where the entry lands, bd[j-1] above that -- and the index follows the same two comparisons.
+  bool keep = bd[K - 1] <= dist;  // (false)
 #pragma unroll
-  for ( int j = K - 1; j >= 0; --j ) {
-    const bool keep  = bd[j] <= dist;
-    const bool place = ( j == 0 ) || ( bd[j > 0 ? j - 1 : 0] <= dist );
-    if ( !keep ) {
-      bd[j] = place ? dist : bd[j > 0 ? j - 1 : 0];
-      bi[j] = place ? index : bi[j > 0 ? j - 1 : 0];
-    }
+  for ( int j = K - 1; j > 0; --j ) {
+    const bool keepBelow = bd[j - 1] <= dist;
+    bi[j]                = keep ? bi[j] : ( keepBelow ? index : bi[j - 1] );
+    bd[j]                = min( max( bd[j - 1], dist ), bd[j] );
+    keep                 = keepBelow;
   }
+  bi[0] = keep ? bi[0] : index;
+  bd[0] = min( bd[0], dist );
 }
 
 // SELF = true : queries are the tree-order points themselves, row j is written to out[perm[j]]
