@@ -29,7 +29,7 @@ STAGE_OF = {"knnKernel<16, true, true>": "knn_self", "knnKernel<8, false, true>"
             "ccUnionKernel<16>": "k:ccUnion", "ccRelaxKernel<16>": "k:ccRelax", "ccMutualMaskKernel<16>": "k:ccMutualMask",
             "initialSegmentationKernel": "initial_segmentation"}
 # stages that are several kernels per run: bytes per run = sum over the kernels of (bytes per launch x launches per run)
-COMPOSITE = {"refine_sweep": {"closurePrepareKernel": 1, "closureLevelsKernel": 1, "sweepKernel": 1}}
+COMPOSITE = {"refine_sweep": {"closureKernel": 1, "sweepKernel": 1}}
 
 
 def per_kernel(directory, counter):
