@@ -85,6 +85,14 @@ struct RetiredSeg {
   int32_t  root;  // 1: the root of the whole tree (its loose box is its tight range)
 };
 
+// a segment handed to hugeSegmentsKernel: the same, with the tight ranges the level pass measured
+struct HugeSeg {
+  uint32_t begin, end, node, level;
+  int16_t  lo[3], hi[3];
+  int32_t  root;
+  int32_t  mn[3], mx[3];
+};
+
 struct BuildArgs {
   const Pt* pts;
   uint32_t  n, tiles;
@@ -101,6 +109,9 @@ struct BuildArgs {
   uint32_t*   retiredCount;
   RetiredSeg* big;      // segments of more than kRetire and at most kSplitMax points (splitSegmentsKernel)
   uint32_t*   bigCount;
+  HugeSeg*    huge;     // segments of more than kSplitMax and at most hugeMax points (hugeSegmentsKernel)
+  uint32_t*   hugeCount;
+  uint32_t    hugeMax;  // (>= kSplitMax; == kSplitMax: no such segments)
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
   uint32_t*   ticket;       // "last block done" counter of the prefix sums
 };
@@ -391,6 +402,13 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
       for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
       a.big[atomicAdd( a.bigCount, 1u )] = r;
       q->split = 0;
+    } else if ( cnt > uint32_t( kSplitMax ) && cnt <= a.hugeMax ) {  // ... by one workgroup in global memory
+      HugeSeg r;
+      r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
+      r.root  = q->parent == kNone ? 1 : 0;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d], r.mn[d] = q->mn[d], r.mx[d] = q->mx[d];
+      a.huge[atomicAdd( a.hugeCount, 1u )] = r;
+      q->split = 0;
     } else if ( splitRule( q, cutDim, cut ) ) {
       q->split = 1, q->cutDim = uint8_t( cutDim ), q->cut = cut;
     } else {
@@ -413,7 +431,7 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
           int     cutDim;
           int32_t cut;
           const BuildSeg* q = cur + s;
-          if ( q->end - q->begin > uint32_t( kSplitMax ) && splitRule( q, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
+          if ( q->end - q->begin > a.hugeMax && splitRule( q, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
         }
       }
       v[k] = f;
@@ -1049,6 +1067,227 @@ __global__ __launch_bounds__( 64 * kSplitWaves ) void splitSegmentsKernel( Build
   }
 }
 
+
+// ---- segments of kSplitMax .. hugeMax points: one workgroup each, points where they are (global memory, L2-resident), the
+// WHOLE workgroup on one node after the other, depth by depth, until the pieces fit splitSegmentsKernel.
+// Why: a level pass is five launches over ALL n points, and from the level on where the segments are a few tens of thousands of
+// points the chip streams the arrays five times per level to move a few elements inside each segment.  Sixteen frames in
+// flight pay for chip time, not for latency: ~ 20 workgroups busy for the time of those levels leave the rest of the chip to
+// the other frames.  Same closed-form sweeps as everywhere (the i-th misplaced element from the left swaps with the i-th from
+// the right), in three passes over a node instead of nine:
+//   * one pass lists the positions of the ">= c" elements and of the "< c" elements (both ascending, in the node's slices of
+//     loc1 / loc2, which the level passes no longer use) -- the number of "< c" elements IS the sweep's edge nL, the misplaced
+//     elements on the left are the head of the first list (positions < nL), their partners the tail of the second, read
+//     backwards;
+//   * the same on [nL, count) with c + 1 for the second sweep;
+//   * one pass gives the tight ranges of both children (divlow / divhigh are two of the twelve numbers), so the children start
+//     with their ranges known.
+// Four elements per thread and pass iteration (independent loads: the passes are bound by load latency, not by bandwidth).
+constexpr int      kHugeWaves = 16;
+constexpr uint32_t kHugeLimit = 131072;                                 // largest hugeMax
+constexpr int      kHugeNodes = 2 * int( kHugeLimit / kSplitMax ) + 4;  // nodes of more than kSplitMax points at one depth
+struct HugeNode {
+  uint32_t begin, end;  // range inside the segment
+  uint32_t node;
+  int16_t  lo[3], hi[3];  // loose box
+  int16_t  mn[3], mx[3];  // tight ranges
+  uint16_t depth;
+};
+
+// Lists the positions of pts[0..count) with coordinate >= c (listGE) and < c (listLT), both ascending; returns the number of
+// ">= c" elements.  waveCnt: LDS [2][kHugeWaves].
+__device__ __forceinline__ uint32_t blockClassLists( const Pt* pts, uint32_t count, int dim, int32_t c, uint32_t* listGE,
+                                                     uint32_t* listLT, uint32_t* waveCnt ) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t  mGE = 0, mIn = 0;
+  int       buf = 0;
+  for ( uint32_t base = 0; base < count; base += 4u * blockDim.x, buf ^= 1 ) {
+    const uint32_t i0 = base + 4u * threadIdx.x;
+    bool           ge[4];
+    uint32_t       cGE = 0, cIn = 0;
+#pragma unroll
+    for ( int j = 0; j < 4; ++j ) {
+      const bool    in = i0 + j < count;
+      const int32_t x  = coordOf( pts[in ? i0 + j : 0u], dim );
+      ge[j]            = in && x >= c;
+      cGE += uint32_t( ge[j] ), cIn += uint32_t( in );
+    }
+    uint32_t inc = cGE | ( cIn << 16 );  // (a wave holds at most 256 elements: both counts fit 16 bits)
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += t;
+    }
+    if ( lane == 63 ) waveCnt[buf * kHugeWaves + wave] = inc;
+    __syncthreads();  // (the other buffer is written next: whoever still reads this one has passed this barrier by then)
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for ( int w = 0; w < kHugeWaves; ++w ) {
+      const uint32_t cw = waveCnt[buf * kHugeWaves + w];
+      total += cw;
+      before += w < wave ? cw : 0u;
+    }
+    before += inc - ( cGE | ( cIn << 16 ) );
+    uint32_t atGE = mGE + ( before & 0xFFFFu ) + 0u, atIn = mIn + ( before >> 16 );
+    // (before / total: sums of packed pairs; the low halves cannot carry -- at most 4 096 elements per iteration)
+#pragma unroll
+    for ( int j = 0; j < 4; ++j ) {
+      if ( i0 + j < count ) {
+        if ( ge[j] )
+          listGE[atGE] = i0 + j;
+        else
+          listLT[atIn - atGE] = i0 + j;
+        atGE += uint32_t( ge[j] ), ++atIn;
+      }
+    }
+    mGE += total & 0xFFFFu, mIn += total >> 16;
+  }
+  return mGE;
+}
+
+// One sweep by the workgroup on pts[0..count): left class "value < c".  Returns nL, the number of elements of the left class.
+__device__ __forceinline__ uint32_t blockSweep( Pt* pts, uint32_t* id, uint32_t count, int dim, int32_t c, uint32_t* listGE,
+                                                uint32_t* listLT, uint32_t* waveCnt ) {
+  const uint32_t nGE = blockClassLists( pts, count, dim, c, listGE, listLT, waveCnt ), nL = count - nGE;
+  __syncthreads();
+  for ( uint32_t t = threadIdx.x; t < min( nGE, nL ); t += blockDim.x ) {
+    const uint32_t x = listGE[t];
+    if ( x >= nL ) break;  // (ascending: nothing misplaced from here on)
+    const uint32_t y  = listLT[nL - 1u - t];
+    const Pt       px = pts[x], py = pts[y];
+    const uint32_t ix = id[x], iy = id[y];
+    pts[x] = py, pts[y] = px, id[x] = iy, id[y] = ix;
+  }
+  __syncthreads();
+  return nL;
+}
+
+__global__ __launch_bounds__( 64 * kHugeWaves ) void hugeSegmentsKernel( BuildArgs a ) {
+  __shared__ HugeNode sNode[2][kHugeNodes];
+  __shared__ uint32_t sCount[2], waveCnt[2 * kHugeWaves];
+  __shared__ int32_t  red[kHugeWaves][12];
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t total = *a.hugeCount;
+  for ( uint32_t s = blockIdx.x; s < total; s += gridDim.x ) {
+    const HugeSeg seg = a.huge[s];
+    if ( threadIdx.x == 0 ) {
+      HugeNode r;
+      r.begin = 0, r.end = seg.end - seg.begin, r.node = seg.node, r.depth = 0;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = seg.lo[d], r.hi[d] = seg.hi[d], r.mn[d] = int16_t( seg.mn[d] ), r.mx[d] = int16_t( seg.mx[d] );
+      sNode[0][0] = r;
+      sCount[0] = 1, sCount[1] = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for ( uint32_t depth = 0;; ++depth ) {
+      const uint32_t nCur = sCount[cur];
+      if ( nCur == 0 ) break;
+      for ( uint32_t t = 0; t < nCur; ++t ) {  // (uniform over the workgroup)
+        const HugeNode q     = sNode[cur][t];
+        const uint32_t count = q.end - q.begin;
+        if ( uint32_t( q.depth ) + seg.level >= uint32_t( kMaxLevels ) - 2u ) {  // deeper than the k-NN traversal stack: refused
+          if ( threadIdx.x == 0 ) atomicMax( a.finishDepth, 0x10000u );
+          continue;
+        }
+        Pt*       pts = a.P + seg.begin + q.begin;
+        uint32_t* id  = a.perm + seg.begin + q.begin;
+        int32_t   mn[3], mx[3];
+        const bool isRoot = seg.root != 0 && depth == 0;  // the tree's root: its loose box is its tight range
+        int16_t    lo[3], hi[3];
+        for ( int d = 0; d < 3; ++d ) mn[d] = q.mn[d], mx[d] = q.mx[d], lo[d] = isRoot ? q.mn[d] : q.lo[d], hi[d] = isRoot ? q.mx[d] : q.hi[d];
+        const SplitRule rule  = splitOf( lo, hi, mn, mx );
+        uint32_t*       listA = a.loc1 + seg.begin + q.begin;
+        uint32_t*       listB = a.loc2 + seg.begin + q.begin;
+        const uint32_t  lt    = blockSweep( pts, id, count, rule.dim, rule.cut, listA, listB, waveCnt );
+        const uint32_t  le    = lt + blockSweep( pts + lt, id + lt, count - lt, rule.dim, rule.cut + 1, listA, listB, waveCnt );
+        const uint32_t  half  = count / 2;
+        const uint32_t  idx   = lt > half ? lt : ( le < half ? le : half );
+        // tight ranges of the two children
+        int32_t r[12];
+#pragma unroll
+        for ( int k = 0; k < 12; ++k ) r[k] = ( k % 6 ) < 3 ? 0x7FFFFFFF : int32_t( 0x80000000 );
+        for ( uint32_t base = 0; base < count; base += 4u * blockDim.x ) {
+          Pt p[4];
+#pragma unroll
+          for ( int j = 0; j < 4; ++j ) {
+            const uint32_t i = base + j * blockDim.x + threadIdx.x;
+            p[j]             = pts[i < count ? i : 0u];
+          }
+#pragma unroll
+          for ( int j = 0; j < 4; ++j ) {
+            const uint32_t i = base + j * blockDim.x + threadIdx.x;
+            if ( i < count ) {
+              const int o = i < idx ? 0 : 6;
+              if ( o == 0 ) {
+                r[0] = min( r[0], int32_t( p[j].x ) ), r[1] = min( r[1], int32_t( p[j].y ) ), r[2] = min( r[2], int32_t( p[j].z ) );
+                r[3] = max( r[3], int32_t( p[j].x ) ), r[4] = max( r[4], int32_t( p[j].y ) ), r[5] = max( r[5], int32_t( p[j].z ) );
+              } else {
+                r[6] = min( r[6], int32_t( p[j].x ) ), r[7] = min( r[7], int32_t( p[j].y ) ), r[8] = min( r[8], int32_t( p[j].z ) );
+                r[9] = max( r[9], int32_t( p[j].x ) ), r[10] = max( r[10], int32_t( p[j].y ) ), r[11] = max( r[11], int32_t( p[j].z ) );
+              }
+            }
+          }
+        }
+#pragma unroll
+        for ( int off = 32; off > 0; off >>= 1 )
+#pragma unroll
+          for ( int k = 0; k < 12; ++k ) {
+            const int32_t o = __shfl_xor( r[k], off, 64 );
+            r[k]            = ( k % 6 ) < 3 ? min( r[k], o ) : max( r[k], o );
+          }
+        if ( lane == 0 )
+          for ( int k = 0; k < 12; ++k ) red[wave][k] = r[k];
+        __syncthreads();
+        if ( threadIdx.x == 0 ) {
+          for ( int w = 0; w < kHugeWaves; ++w )
+            for ( int k = 0; k < 12; ++k ) r[k] = ( k % 6 ) < 3 ? min( r[k], red[w][k] ) : max( r[k], red[w][k] );
+          const uint32_t id0 = atomicAdd( a.nodeCount, 2u );
+          KdNode         nd;
+          nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( r[3 + rule.dim] ), nd.divhigh = int16_t( r[6 + rule.dim] ),
+          nd.dim = rule.dim;
+          a.nodes[q.node] = nd;
+          HugeNode child[2];
+          child[0].begin = q.begin, child[0].end = q.begin + idx, child[0].node = id0;
+          child[1].begin = q.begin + idx, child[1].end = q.end, child[1].node = id0 + 1;
+          for ( int c = 0; c < 2; ++c ) {
+            child[c].depth = uint16_t( q.depth + 1 );
+            for ( int d = 0; d < 3; ++d )
+              child[c].lo[d] = lo[d], child[c].hi[d] = hi[d], child[c].mn[d] = int16_t( r[6 * c + d] ), child[c].mx[d] = int16_t( r[6 * c + 3 + d] );
+          }
+          const int16_t cut = int16_t( rule.cut );
+          if ( rule.dim == 0 ) child[0].hi[0] = cut, child[1].lo[0] = cut;
+          if ( rule.dim == 1 ) child[0].hi[1] = cut, child[1].lo[1] = cut;
+          if ( rule.dim == 2 ) child[0].hi[2] = cut, child[1].lo[2] = cut;
+          for ( int c = 0; c < 2; ++c ) {
+            const uint32_t cc = child[c].end - child[c].begin, level = seg.level + child[c].depth;
+            if ( cc <= uint32_t( kLeafMax ) ) {
+              KdNode leaf;
+              leaf.a = int32_t( seg.begin + child[c].begin ), leaf.b = int32_t( seg.begin + child[c].end ), leaf.divlow = leaf.divhigh = 0,
+              leaf.dim = -1;
+              a.nodes[child[c].node] = leaf;
+              atomicMax( a.finishDepth, level + 1u );
+            } else if ( cc <= uint32_t( kSplitMax ) ) {  // to the wavefront finisher, or to the workgroup that splits in LDS first
+              RetiredSeg rs;
+              rs.begin = seg.begin + child[c].begin, rs.end = seg.begin + child[c].end, rs.node = child[c].node, rs.level = level, rs.root = 0;
+              for ( int d = 0; d < 3; ++d ) rs.lo[d] = child[c].lo[d], rs.hi[d] = child[c].hi[d];
+              if ( cc <= uint32_t( kRetire ) )
+                a.retired[atomicAdd( a.retiredCount, 1u )] = rs;
+              else
+                a.big[atomicAdd( a.bigCount, 1u )] = rs;
+            } else {
+              sNode[cur ^ 1][sCount[cur ^ 1]++] = child[c];
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if ( threadIdx.x == 0 ) sCount[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 // Builds the tree of d_pts[0..n) on the context's stream.  Outputs: points and permutation in tree order, node records
@@ -1075,6 +1314,11 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   const size_t       maxRetired = size_t( n ) / ( kLeafMax + 1 ) + 2;  // (retired segments are disjoint and hold > kLeafMax points)
   TMC2_TRY( d_retired.alloc( maxRetired ) );
   TMC2_TRY( d_big.alloc( size_t( n ) / ( kRetire + 1 ) + 2 ) );  // (disjoint segments of more than kRetire points)
+  DevBuf<HugeSeg> d_huge;
+  TMC2_TRY( d_huge.alloc( size_t( n ) / ( kSplitMax + 1 ) + 2 ) );  // (disjoint segments of more than kSplitMax points)
+  // (test hook TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes; <= kSplitMax: that tier is off)
+  const char*    hugeEnv = getenv( "TMC2_KD_HUGEMAX" );
+  const uint32_t hugeMax = std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kSplitMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 32768u ) );
   TMC2_TRY( d_work.alloc( 3 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
@@ -1094,6 +1338,9 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.ticket       = d_small.p + kMaxLevels + 5;
   a.big          = d_big.p;
   a.bigCount     = d_small.p + kMaxLevels + 6;
+  a.huge         = d_huge.p;
+  a.hugeCount    = d_small.p + kMaxLevels + 7;
+  a.hugeMax      = hugeMax;
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
   hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
@@ -1108,7 +1355,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
     if ( level == 0 && hint > 0 ) {
       chunkEnd = uint32_t( std::min( hint, kMaxLevels ) );
     } else {
-      while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( kSplitMax ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
+      while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( hugeMax ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
       if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 2, kMaxLevels );
     }
     for ( ; level < chunkEnd; ++level ) {
@@ -1135,7 +1382,11 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   hint  = std::max( found, 1 );
   const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
-  const uint32_t big = out[kMaxLevels + 6];
+  const uint32_t huge = out[kMaxLevels + 7];
+  if ( huge )  // segments of up to hugeMax points: one workgroup each, their pieces join the two lists below
+    hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( huge, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );
+  // (what the level passes handed over, plus what hugeSegmentsKernel may add: both kernels below stride over the device-side counts)
+  const uint32_t big = out[kMaxLevels + 6] + huge * ( 2u * hugeMax / uint32_t( kSplitMax ) );
   if ( big ) {  // segments between the two thresholds: one workgroup each, their pieces join the retired list
     const size_t lds = size_t( kSplitMax ) * ( sizeof( Pt ) + 4 + 4 );
     if ( lds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( splitSegmentsKernel ), lds, ctx->device,

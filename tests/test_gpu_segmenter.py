@@ -80,11 +80,15 @@ def test_gpu_knn_edge_cases(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("case", ["tiny", "small", "medium", "longdress_vox10", "line", "plane", "duplicates", "eleven",
-                                  "root3000", "root8192", "n8193", "dense20000"])
-def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, case):
+                                  "root3000", "root8192", "n8193", "dense20000", "root30000", "n40000", "dense60000",
+                                  "huge131072:root100000", "huge131072:dense120000", "huge8192:root30000"])
+def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, monkeypatch, case):
     """The level-parallel device build must leave exactly the permutation of nanoflann's recursive build (the oracle's
     restatement for the small clouds, the library's host builder -- itself pinned to the oracle on CPU -- for all)."""
     rng = np.random.default_rng(5)
+    if case.startswith("huge"):                      # TMC2_KD_HUGEMAX: the largest segment one workgroup splits in global memory
+        hook, case = case.split(":")                 # (default 32 768; 8 192 = that tier is off; 131 072 = its limit)
+        monkeypatch.setenv("TMC2_KD_HUGEMAX", hook[4:])
     if case == "line":                               # every split degenerates to one dimension, long equal runs
         xyz = np.zeros((5000, 3), np.int16); xyz[:, 1] = rng.integers(0, 40, 5000)
     elif case == "plane":
@@ -97,8 +101,12 @@ def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, case):
         xyz = rng.integers(0, 1024, (int(case[4:]), 3)).astype(np.int16)
     elif case == "n8193":                            # one level pass, then two such segments
         xyz = rng.integers(0, 512, (8193, 3)).astype(np.int16)
-    elif case == "dense20000":                       # many equal coordinates: unbalanced pieces, tiny children next to big ones
-        xyz = rng.integers(0, 12, (20000, 3)).astype(np.int16)
+    elif case.startswith("dense"):                   # many equal coordinates: unbalanced pieces, tiny children next to big ones
+        xyz = rng.integers(0, 12 if case == "dense20000" else 24, (int(case[5:]), 3)).astype(np.int16)
+    elif case in ("root30000", "root100000"):        # the whole tree is one segment for the workgroup-per-segment kernel
+        xyz = rng.integers(0, 1024, (int(case[4:]), 3)).astype(np.int16)
+    elif case == "n40000":                           # one level pass, then two such segments
+        xyz = rng.integers(0, 1024, (40000, 3)).astype(np.int16)
     else:
         xyz, _ = synth_cloud(case)
     fr = gpu_ctx.frame(xyz)
