@@ -49,10 +49,12 @@ def parse():
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
-    ap.add_argument("--rendezvous", default="phases", choices=["one", "phases"],
-                    help="all-intra: phases = the frames of the GOF meet after segmentation + packing, after phase A and after "
-                         "phase B (default: frames in the same phase share the chip better -- measured 90 against 79 frames/s); "
-                         "one = every frame runs its whole chain on its worker, the GOF meets once (GofEncoder.encode_all_intra)")
+    ap.add_argument("--rendezvous", default="phases", choices=["one", "phases", "four"],
+                    help="all-intra: phases = the frames of the GOF meet once, after segmentation + packing (the common canvas "
+                         "size), and go on independently from there (default); four = they also meet after phase A, after phase "
+                         "B and after the copies (round 2); one = every frame runs its whole chain on a guessed canvas size, "
+                         "the GOF meets at the end (GofEncoder.encode_all_intra: frames in different phases share the chip "
+                         "worse -- measured 132 against 152 frames/s)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--packing", default="all-intra", choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition: every frame on its own (the metric's configuration), the spatial-consistency chain, "
@@ -457,15 +459,24 @@ def main():
             if world > 1:
                 gather_canvases(enc, frames, sharder, gather_cache)
             return W, H
-        W, H = enc.phase_a(frames, sharder, constrained_pack={"all-intra": False, "low-delay": True, "random-access": 2}[a.packing],
-                           frame_count=a.frames)
         # identity video codec between the phases (HM/VTM on the host is outside the metric): phase B runs on the
         # resident canvases.  Finished canvases -> rank 0 -> host memory, where the video encoder reads them.
-        enc.phase_b(frames)
-        if world == 1:
-            bufs = host_out(W, H)
-            enc.per_frame(frames, lambda fr, i: (fr.get_geometry_images(bufs[i][0]), fr.get_attribute_images(bufs[i][1])))
-        else:
+        # Once the GOF's canvas size is settled the frames are independent: a frame's worker goes on with its phase B and the
+        # copy of its canvases in the same pass (one rendezvous per GOF instead of four: each one waits for its slowest frame).
+        def rest(fr, i, W_, H_):
+            fr.encoder_generate_attribute_images()
+            if world == 1:
+                bufs = host_out(W_, H_)
+                fr.get_geometry_images(bufs[i][0])
+                fr.get_attribute_images(bufs[i][1])
+        W, H = enc.phase_a(frames, sharder, constrained_pack={"all-intra": False, "low-delay": True, "random-access": 2}[a.packing],
+                           frame_count=a.frames, then=None if a.rendezvous == "four" else rest)
+        if a.rendezvous == "four":                              # (the round-2 schedule: a rendezvous after every phase)
+            enc.phase_b(frames)
+            if world == 1:
+                bufs = host_out(W, H)
+                enc.per_frame(frames, lambda fr, i: (fr.get_geometry_images(bufs[i][0]), fr.get_attribute_images(bufs[i][1])))
+        if world > 1:
             gather_canvases(enc, frames, sharder, gather_cache)
         return W, H
 
@@ -638,10 +649,12 @@ def main():
             def rank_step():
                 for fr in sub:
                     fr.reset()
-                w_, h_ = enc.phase_a(sub, sharder=T.Sharder())
-                enc.phase_b(sub)
-                b4 = host_out(w_, h_)
-                enc.per_frame(sub, lambda fr, i: (fr.get_geometry_images(b4[i][0]), fr.get_attribute_images(b4[i][1])))
+                def rest4(fr, i, w_, h_):
+                    fr.encoder_generate_attribute_images()
+                    b4 = host_out(w_, h_)
+                    fr.get_geometry_images(b4[i][0])
+                    fr.get_attribute_images(b4[i][1])
+                enc.phase_a(sub, sharder=T.Sharder(), then=rest4)
             rank_step()
             torch.cuda.synchronize()
             t0 = time.time()

@@ -222,15 +222,22 @@ class GofEncoder:
         """fn(frame, index) on the frame's own worker thread (e.g. the copies of finished canvases to host memory)."""
         return self._dispatch([(i % self.workers, (lambda fr=fr, i=i: fn(fr, i))) for i, fr in enumerate(frames)])
 
-    def phase_a(self, frames, sharder=None, weight=None, constrained_pack=False, frame_count=None, records_chain=False):
+    def phase_a(self, frames, sharder=None, weight=None, constrained_pack=False, frame_count=None, records_chain=False,
+                then=None):
         """constrained_pack: True = the low-delay condition -- frames after the first are packed against their predecessor
         (S10', a sequential chain over the GOF, microseconds per frame on the host); 2 = the random-access condition -- the same chain followed by the global patch allocation over the
         GOF (tracked patches share one place in all frames of a sub-context).  With several ranks (frame f on rank
         f mod world; frame_count = frames of the whole GOF) the chain runs on rank 0 over the gathered patch records and the
-        packed lists come back (records_chain=True forces that route in a single process)."""
+        packed lists come back (records_chain=True forces that route in a single process).
+        then(frame, index, W, H): what a frame goes on with once the canvas size is settled and its geometry images exist (phase B,
+        the copy of its canvases to the host, ...), on the frame's worker in the same pass -- the frames are independent from
+        there on, and every rendezvous of the GOF costs the wait for its slowest frame."""
         sharder = sharder or Sharder()
         if constrained_pack and (sharder.world > 1 or records_chain):
-            return self._phase_a_sharded_chain(frames, sharder, weight, int(constrained_pack), frame_count)
+            size = self._phase_a_sharded_chain(frames, sharder, weight, int(constrained_pack), frame_count)
+            if then is not None:
+                self.per_frame(frames, lambda fr, i: then(fr, i, size[0], size[1]))
+            return size
         if weight is None:
             w = frames[0].weight_normal(self.bits3d, 0.6) if sharder.rank == 0 else np.zeros(3)
             weight = sharder.broadcast_weight(w)
@@ -250,7 +257,8 @@ class GofEncoder:
                 widths, heights = lib.encoder_global_patch_allocation(frames, self.min_w, self.min_h)
                 W, H = lib.encoder_canvas_size([max(int(max(heights)), self.min_h)], max(int(max(widths)), self.min_w),
                                                self.min_w, self.min_h)
-                self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
+                self.per_frame(frames, lambda fr, i: (fr.encoder_generate_geometry_images(W, H, self.occ_precision),
+                                                      then(fr, i, W, H) if then is not None else None))
                 return W, H
         else:
             heights = self._per_worker(frames, segment_and_pack)
@@ -258,7 +266,8 @@ class GofEncoder:
         # the chained packer writes the width of its canvas back into the tile (a patch wider than the preset width widens it)
         tile_w = max([self.min_w] + [fr.get_packed_size()[0] for fr in frames]) if constrained_pack else self.min_w
         W, H = lib.encoder_canvas_size([gof_h], tile_w, self.min_w, self.min_h)
-        self._per_worker(frames, lambda fr: fr.encoder_generate_geometry_images(W, H, self.occ_precision))
+        self.per_frame(frames, lambda fr, i: (fr.encoder_generate_geometry_images(W, H, self.occ_precision),
+                                              then(fr, i, W, H) if then is not None else None))
         return W, H
 
     def encode_all_intra(self, frames, sharder=None, weight=None, finish=None):
