@@ -342,6 +342,7 @@ int launchNormals( tmc2_frame* f );
 int orientNormalsHost( tmc2_frame* f );
 int ensureMutualMask( tmc2_frame* f );  // k = 16 only
 int launchEdgeDots( tmc2_frame* f, double* d_edgeDot );
+constexpr size_t kOrientNegCountWords = 64 * 32;  // d_negCount: 64 counters, one per 128 bytes
 int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount );
 // contracted orientation graph (orient_host.cpp): clusters of mutual strong edges, their cross edges grouped by source
 struct OrientCrossEdge {

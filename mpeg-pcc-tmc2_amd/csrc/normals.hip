@@ -233,6 +233,7 @@ __global__ __launch_bounds__( 256 ) void edgeDotKernel( const double* __restrict
   }
 }
 
+constexpr uint32_t kNegCounters = 64;
 __global__ __launch_bounds__( 256 ) void applySignsKernel( const Pt* __restrict__ pts, const int8_t* __restrict__ sign,
                                                             uint32_t n, double* __restrict__ normals,
                                                             uint32_t* __restrict__ negCount ) {
@@ -248,13 +249,18 @@ __global__ __launch_bounds__( 256 ) void applySignsKernel( const Pt* __restrict_
     const double tx = 0.0 - double( p.x ), ty = 0.0 - double( p.y ), tz = 0.0 - double( p.z );
     neg             = nx * tx + ny * ty + nz * tz < 0.0;
   }
+  // (64 counters, 128 bytes apart: 13 K wavefronts adding to ONE word queue up for 11 ns each -- that was the kernel's 142 us)
   const unsigned long long m = __ballot( neg );
-  if ( ( threadIdx.x & 63 ) == 0 && m ) atomicAdd( negCount, uint32_t( __popcll( m ) ) );
+  if ( ( threadIdx.x & 63 ) == 0 && m )
+    atomicAdd( &negCount[( ( blockIdx.x * blockDim.x + threadIdx.x ) >> 6 ) % kNegCounters * 32], uint32_t( __popcll( m ) ) );
 }
 
 __global__ __launch_bounds__( 256 ) void majorityFlipKernel( const uint32_t* __restrict__ negCount, uint32_t n,
                                                               double* __restrict__ normals ) {
-  if ( *negCount <= ( n + 1 ) / 2 ) return;
+  uint32_t neg = negCount[( threadIdx.x & 63 ) * 32];  // (kNegCounters = a wavefront's lanes)
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) neg += __shfl_xor( neg, off, 64 );
+  if ( neg <= ( n + 1 ) / 2 ) return;
   const size_t i = size_t( blockIdx.x ) * blockDim.x + threadIdx.x;
   if ( i < 3 * size_t( n ) ) normals[i] = -normals[i];
 }
@@ -270,7 +276,7 @@ int launchEdgeDots( tmc2_frame* f, double* d_edgeDot ) {
 int launchApplyOrientation( tmc2_frame* f, const int8_t* d_sign, uint32_t* d_negCount ) {
   hipStream_t    s = f->ctx->stream;
   const uint32_t n = uint32_t( f->n );
-  TMC2_HIP( hipMemsetAsync( d_negCount, 0, 4, s ) );
+  TMC2_HIP( hipMemsetAsync( d_negCount, 0, kOrientNegCountWords * 4, s ) );
   hipLaunchKernelGGL( applySignsKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, s, f->d_pts.p, d_sign, n, f->d_normals.p,
                       d_negCount );
   hipLaunchKernelGGL( majorityFlipKernel, dim3( uint32_t( ( 3 * size_t( n ) + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_negCount, n,

@@ -859,7 +859,7 @@ int orientNormalsHost( tmc2_frame* f ) {
   DevBuf<uint8_t>  d_parity;
   TMC2_TRY( d_edgeDot.alloc( edges ) );
   TMC2_TRY( d_sign.alloc( n ) );
-  TMC2_TRY( d_negCount.alloc( 1 ) );
+  TMC2_TRY( d_negCount.alloc( kOrientNegCountWords ) );
   TMC2_TRY( launchEdgeDots( f, d_edgeDot.p ) );
   if ( ctx->orientScratch.size() < 2 * n ) ctx->orientScratch.resize( 2 * n );
   const double tau = orientFirstTau();
