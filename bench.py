@@ -29,7 +29,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "mpeg-pcc-tmc2_amd"))
+sys.path.insert(0, os.environ.get("TMC2_PACKAGE_DIR") or os.path.join(ROOT, "mpeg-pcc-tmc2_amd"))  # (TMC2_PACKAGE_DIR: tools/asan_gpu.sh)
 
 
 def parse():
@@ -395,6 +395,10 @@ def gather_canvases(enc, frames, sharder, cache, pin=True):
 
 def main():
     a = parse()
+    if a.cpu_child == "baseline":                              # the whole CPU baseline leg, in a process of its own
+        from tmc2_amd.synth import synth_cloud
+        print(json.dumps(cpu_baseline(a.workload, a.iterations, [synth_cloud(a.workload, i) for i in range(min(a.frames, 16))])))
+        return
     if a.cpu_child:
         return cpu_child(a.cpu_child, a.workload, a.iterations)
     rank = int(os.environ.get("RANK", "0"))
@@ -707,7 +711,17 @@ def main():
         except Exception as e:
             out["ingest"] = {"error": repr(e)}
     if a.cpu_baseline and world == 1:                          # rank 0 at N = 1 only (the contract of the bench line)
-        out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations, clouds)
+        # In a process of its own: the leg loads the reference's libraries (two builds of the same C++ code, one with TBB and
+        # 128 threads) -- foreign code that must not be able to take the metric line with it (a full run died once with glibc's
+        # "corrupted double-linked list" seconds into this leg; the path itself ran clean under MALLOC_CHECK_=3).
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "baseline", "--workload", a.workload,
+                                "--iterations", str(a.iterations), "--frames", str(a.frames)],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1800)
+            out["cpu_baseline"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        except Exception as e:
+            out["cpu_baseline"] = {"error": "the CPU baseline process failed: %r" % (e,)}
         for key in ("all_cores_value", "frame_processes_value"):
             if out["cpu_baseline"].get(key):
                 out["cpu_baseline"]["gpu_over_" + key[:-6]] = round(out["value"] / out["cpu_baseline"][key], 2)
