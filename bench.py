@@ -37,16 +37,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GOF (BASELINE: 32)")
-    ap.add_argument("--workload", default="longdress_vox10")
+    ap.add_argument("--config", default="longdress", help="BASELINE configuration: a short name (%s) or a case of "
+                    "tmc2_amd/configs.py FULL_SIZE_CASES -- workload, frames, refine iterations / voxel size, bit depth, occupancy "
+                    "precision, minimum canvas and packing condition come from the CTC table there, and the timed step is checked "
+                    "against that case's digests of the unmodified reference" % ", ".join(sorted(_bench_configs())))
+    ap.add_argument("--frames", type=int, default=None, help="frames per GOF (default: the configuration's)")
+    ap.add_argument("--workload", default=None, help="synthetic sequence (default: the configuration's)")
     ap.add_argument("--workers", type=int, default=0, help="concurrent frames per GPU (0 = auto)")
     ap.add_argument("--host-steps", type=int, default=16, help="max concurrent host-resident steps (tree build, orientation)")
     ap.add_argument("--kdtree", default="auto", choices=["auto", "device", "host", "adaptive"],
                     help="where the k-d trees are built (auto = device)")
-    ap.add_argument("--iterations", type=int, default=50, help="iterationCountRefineSegmentation (longdress cfg: 50)")
+    ap.add_argument("--iterations", type=int, default=None, help="iterationCountRefineSegmentation (default: the configuration's)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--ingest", type=int, default=1, help="0 skips the (untimed) PLY ingest measurement")
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
+    ap.add_argument("--decoder", type=int, default=1, help="0 skips the decoder-side GOF leg (BASELINE config 5: reconstruct + "
+                    "tail + D1/D2 metric for every frame, outside the headline metric)")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for synthetic data generation (1 = in-process; "
                     "use 1 under rocprofv3, whose signal handler deadlocks multiprocessing pools)")
     ap.add_argument("--rendezvous", default="phases", choices=["one", "phases", "four"],
@@ -56,10 +62,28 @@ def parse():
                          "the GOF meets at the end (GofEncoder.encode_all_intra: frames in different phases share the chip "
                          "worse -- measured 132 against 152 frames/s)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
-    ap.add_argument("--packing", default="all-intra", choices=["all-intra", "low-delay", "random-access"],
-                    help="S10 condition: every frame on its own (the metric's configuration), the spatial-consistency chain, "
+    ap.add_argument("--packing", default=None, choices=["all-intra", "low-delay", "random-access"],
+                    help="S10 condition (default: the configuration's): every frame on its own, the spatial-consistency chain, "
                          "or the chain + global patch allocation (with several ranks the chain runs on rank 0 over the patch records)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    from tmc2_amd import configs
+    a.case_name = configs.BENCH_CONFIGS.get(a.config, a.config)
+    if a.case_name not in configs.FULL_SIZE_CASES:
+        ap.error("unknown --config %s (known: %s)" % (a.config, ", ".join(sorted(configs.BENCH_CONFIGS) + sorted(configs.FULL_SIZE_CASES))))
+    a.case = dict(configs.FULL_SIZE_CASES[a.case_name], name=a.case_name)
+    # explicit flags override the table (such a run has no reference fixture: "verified" is null)
+    a.workload = a.workload or a.case["workload"]
+    a.frames = a.frames or a.case["frames"]
+    a.iterations = a.iterations or a.case["iterations"]
+    a.packing = a.packing or configs.PACKING_NAME[a.case["pack"]]
+    a.is_case = (a.workload, a.frames, a.iterations, a.packing) == (a.case["workload"], a.case["frames"], a.case["iterations"],
+                                                                    configs.PACKING_NAME[a.case["pack"]])
+    return a
+
+
+def _bench_configs():
+    from tmc2_amd import configs
+    return configs.BENCH_CONFIGS
 
 
 def _gen(arg):
@@ -141,7 +165,7 @@ def physical_cores():
         return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(workload, iterations, gof):
+def cpu_baseline(workload, iterations, gof, case):
     """The same workload through the CPU checker (test infrastructure, used here only as the reported baseline): the
     unmodified reference if oracle/_ref travelled with the repo, else our restatement.  One frame on one thread; then a GOF
     through the reference's own TBB path on all physical cores (its ENABLE_TBB build with the vendored TBB)."""
@@ -152,9 +176,10 @@ def cpu_baseline(workload, iterations, gof):
         eng, kind = ob.Reference(), "reference"
     else:
         eng, kind = ob.Oracle(), "port"
+    args = (iterations, case["bits3d"], case["precision"], case["min_w"], case["min_h"], case["pack"], case["vox_dim"])
     t = time.time()
-    a = eng.phase_a(frames, iterations)
-    eng.phase_b(frames, a)
+    a = eng.phase_a(frames, *args)
+    eng.phase_b(frames, a, case["precision"])
     dt = time.time() - t
     res = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": 1, "kind": kind,
            "sample": "1 frame of %s (%d points), stages S0-S22 (patch generation + occupancy/geometry/attribute images), "
@@ -166,12 +191,13 @@ def cpu_baseline(workload, iterations, gof):
         avail_gb = 8.0
         with open("/proc/meminfo") as f:
             avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
-        nfr = int(max(1, min(len(gof), 16, avail_gb * 0.5 / 1.2)))          # bounded sample; ~1.2 GB per frame inside the reference's containers
+        scale = max(1.0, len(gof[0][0]) / 0.84e6)                              # (memory per frame follows the point count)
+        nfr = int(max(1, min(len(gof), 16, avail_gb * 0.5 / (1.2 * scale))))          # bounded sample; ~1.2 GB per frame inside the reference's containers
         gof = gof[:nfr]                                                      # (the frames of the timed GOF, generated already)
         eng = ob.Reference(tbb=True, nb_thread=cores)
         t = time.time()
-        a = eng.phase_a(gof, iterations)
-        eng.phase_b(gof, a)
+        a = eng.phase_a(gof, *args)
+        eng.phase_b(gof, a, case["precision"])
         wall = time.time() - t
         res["all_cores_value"] = round(nfr / wall, 5)
         res["all_cores"] = cores
@@ -185,7 +211,7 @@ def cpu_baseline(workload, iterations, gof):
     except Exception as e:
         res["cli"] = {"error": repr(e)}
     try:
-        fp = cpu_baseline_frame_processes(workload, iterations, dt)
+        fp = cpu_baseline_frame_processes(workload, iterations, dt, case)
         res["frame_processes_value"], res["frame_processes"], res["frame_processes_sample"] = fp["value"], fp["cores"], fp["sample"]
     except Exception as e:
         res["frame_processes_error"] = repr(e)
@@ -235,7 +261,7 @@ def cpu_baseline_cli(frame, iterations, stage_seconds):
                     "video codec: end-to-end wall time; path_stages_s = the same frame through the path's stages alone"}
 
 
-def cpu_baseline_frame_processes(workload, iterations, one_frame_seconds):
+def cpu_baseline_frame_processes(workload, iterations, one_frame_seconds, case):
     """An upper bound on what frame-level parallelism alone can give the reference on this host (its own TBB path also runs
     the frames of a GOF side by side, PCCEncoder.cpp:4729-4750, but serialises parts of the path): the serial build, one
     PROCESS per frame, P different frames at once, frames/s = P / wall time from a common start."""
@@ -248,12 +274,12 @@ def cpu_baseline_frame_processes(workload, iterations, one_frame_seconds):
             avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
     except Exception:
         pass
-    procs = int(max(1, min(32, cores, avail_gb * 0.25 / 0.6)))      # a child peaks at ~0.45 GB on the longdress-like frame
+    procs = int(max(1, min(32, cores, avail_gb * 0.25 / (0.6 * (4.0 if case["bits3d"] > 11 else 1.0)))))      # a child peaks at ~0.45 GB on the longdress-like frame
     if procs < 2:
         return {"value": round(1.0 / one_frame_seconds, 5), "cores": 1, "sample": "single core host"}
     with tempfile.TemporaryDirectory() as d:
         kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-child", "%d,%s" % (i, d), "--workload", workload,
-                                  "--iterations", str(iterations)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(procs)]
+                                  "--iterations", str(iterations), "--config", case["name"]], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(procs)]
         limit = time.time() + 120 + 20 * one_frame_seconds
         try:
             while sum(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(procs)) < procs:
@@ -276,7 +302,7 @@ def cpu_baseline_frame_processes(workload, iterations, one_frame_seconds):
                       "%.1f s wall on %d usable hardware threads" % (procs, wall, cores)}
 
 
-def cpu_child(spec, workload, iterations):
+def cpu_child(spec, workload, iterations, case):
     index, d = spec.split(",", 1)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
@@ -286,13 +312,8 @@ def cpu_child(spec, workload, iterations):
     open(os.path.join(d, "ready" + index), "w").close()
     while not os.path.exists(os.path.join(d, "go")):
         time.sleep(0.01)
-    a = eng.phase_a(frames, iterations)
-    eng.phase_b(frames, a)
-
-
-
-
-VERIFY_CASE = "longdress_vox10_ai_r3_gof32"   # tests/golden/full_size.npz (make_golden.py full_size): MD5s from the unmodified reference
+    a = eng.phase_a(frames, iterations, case["bits3d"], case["precision"], case["min_w"], case["min_h"], case["pack"], case["vox_dim"])
+    eng.phase_b(frames, a, case["precision"])
 
 
 def verify_frames(a, frames, indices, W, H, host_bufs):
@@ -303,16 +324,11 @@ def verify_frames(a, frames, indices, W, H, host_bufs):
     or None when the run is not the fixture's configuration (other workload / frame count / iterations / packing)."""
     import hashlib
     import numpy as np
-    if not (a.workload == "longdress_vox10" and a.frames == 32 and a.iterations == 50 and a.packing == "all-intra"):
-        return None, "no reference fixture for this configuration"
-    path = os.path.join(ROOT, "tests", "golden", "full_size.npz")
-    try:
-        g = np.load(path)
-        g = {k[len(VERIFY_CASE) + 1:]: g[k] for k in g.files if k.startswith(VERIFY_CASE + "/")}
-    except OSError:
-        g = {}
+    if not a.is_case:
+        return None, "no reference fixture for this configuration (flags override the case %s)" % a.case_name
+    g = case_fixture(a.case_name)
     if not g:
-        return None, "fixture %s missing" % VERIFY_CASE
+        return None, "fixture %s missing" % a.case_name
 
     def md5(x):
         return hashlib.md5(np.ascontiguousarray(x).tobytes()).hexdigest()
@@ -334,6 +350,16 @@ def verify_frames(a, frames, indices, W, H, host_bufs):
         got.update({k: img[k] for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1")})
         bad += ["frame %d: %s" % (i, k) for k, v in got.items() if md5(v) != str(g["f%d_%s_md5" % (i, k)])]
     return (not bad), ("%d frames x 10 digests equal the reference's" % len(frames) if not bad else "; ".join(bad[:8]))
+
+
+def case_fixture(name):
+    """tests/golden/full_size.npz (make_golden.py full_size): digests of the unmodified reference for one case, {} if absent."""
+    import numpy as np
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "full_size.npz"))
+        return {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "/")}
+    except OSError:
+        return {}
 
 
 def host_slots(host_steps, world, frames_per_rank):
@@ -374,6 +400,86 @@ def ingest_leg(T, torch, ctx, cloud):
     return res
 
 
+def decoder_leg(a, T, torch, enc, frames, clouds, indices, W, H, reps=3):
+    """BASELINE config 5 as a GOF: every frame as the DECODER sees it -- the patch records a bitstream carries, the decoded
+    occupancy video, geometry maps and I420 attribute frames (identity video codec) in page-locked host memory, no source cloud
+    on the device -- through generatePointCloud, the inverse colour conversion, the post-reconstruction tail (boundary points,
+    colorPointCloud, grid smoothing, transferColors16bitBP, YUV -> RGB) and the D1 / D2 / colour metric against the uncompressed
+    source frame (host arrays, uploaded inside the timing: PccAppDecoder / PccAppMetrics read them from files).  All frames of the
+    GOF, as many in flight as the encoder run.  Outside the headline metric; checked frame by frame against the reference's
+    digests and PCCMetrics doubles (tests/golden/full_size.npz, make_golden.py full_size_decoder_side)."""
+    import hashlib
+    import numpy as np
+    c, P = a.case, a.case["precision"]
+    res = float((1 << (c["bits3d"] - 1)) - 1)
+
+    def pinned(x):
+        t = torch.empty(x.nbytes, dtype=torch.uint8, pin_memory=True)
+        out = t.numpy().view(x.dtype).reshape(x.shape)
+        out[...] = x
+        return out
+
+    def cut(fr, i):
+        patches = fr.get_patches()[0][fr.get_patch_order()]
+        sent = np.zeros(len(patches), patches.dtype)
+        for k in ("u0", "v0", "sizeU0", "sizeV0", "patchOrientation", "u1", "v1", "d1", "normalAxis", "tangentAxis", "bitangentAxis",
+                  "projectionMode"):
+            sent[k] = patches[k]
+        sent["sizeU"], sent["sizeV"] = sent["sizeU0"] * 16, sent["sizeV0"] * 16
+        img = fr.get_geometry_images()
+        return (sent, pinned(img["occ_video"]), pinned(np.stack([img["geo0"], img["geo1"]])), pinned(fr.encoder_attribute_to_yuv420(4)),
+                fr.get_normals())
+    cuts = enc.per_frame(frames, cut)
+    dec = enc.per_frame(frames, lambda fr, i: fr.ctx.decoder_frame(cuts[i][0], W, H, P, cuts[i][1], cuts[i][2]))
+
+    def chain(fr, i):
+        fr.set_decoded_geometry(cuts[i][1], cuts[i][2])            # the decoded video of this frame arrives (H2D)
+        fr.codec_generate_point_cloud()
+        fr.codec_set_decoded_attribute_yuv420(cuts[i][3], 0)
+        fr.codec_post_reconstruct(None)
+        return fr.metrics_compute_source(clouds[i][0], clouds[i][1], cuts[i][4], 1, res)
+    enc.per_frame(dec, chain)                                      # warm-up (allocations, trees' level counts)
+    enc.stage_reset()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(reps):
+        got = enc.per_frame(dec, chain)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / reps
+    ms, calls = enc.stage_ms(), enc.stage_calls()
+    out = {"what": "decoder side of the GOF: decoded occupancy / geometry / I420 attribute frames (page-locked host memory) -> "
+                   "generatePointCloud -> YUV420ToYUV444_8_0 -> boundary points, colorPointCloud, grid smoothing, "
+                   "transferColors16bitBP, YUV16 -> RGB8 -> PCCMetrics::compute (D1, D2, colour; both directions) against the "
+                   "uncompressed source frame (host arrays); %d frames, %d in flight, %d repetitions" % (len(dec), enc.workers, reps),
+           "frames_per_s": round(len(dec) / dt, 2), "ms_per_gof": round(1e3 * dt, 2),
+           "frame0": {"d1_psnr": round(float(got[0][0][2, 1]), 4), "d2_psnr": round(float(got[0][0][2, 3]), 4),
+                      "y_psnr": round(float(got[0][0][2, 7]), 4)},
+           "stage_ms_per_frame": {k: round(v / (reps * len(dec)), 3) for k, v in sorted(ms.items()) if v > 0 and calls.get(k)}}
+    # parity of what was just timed, against the unmodified reference
+    g = case_fixture(a.case_name) if a.is_case else {}
+    if "f0_post_xyz_md5" not in g:
+        out["verified"], out["verified_detail"] = None, "no decoder-side reference digests for this configuration"
+    else:
+        md5 = lambda x: hashlib.md5(np.ascontiguousarray(x).tobytes()).hexdigest()
+        posts = enc.per_frame(dec, lambda fr, i: fr.get_post_reconstruction())
+        bad = []
+        for slot, i in enumerate(indices):
+            if md5(cuts[slot][3]) != str(g["f%d_i420_md5" % i]):
+                bad.append("frame %d: i420" % i)
+            if md5(cuts[slot][4]) != str(g["f%d_src_normals_md5" % i]):
+                bad.append("frame %d: source normals" % i)
+            bad += ["frame %d: post %s" % (i, k) for k in ("xyz", "colors16", "rgb", "boundary")
+                    if md5(posts[slot][k]) != str(g["f%d_post_%s_md5" % (i, k)])]
+            if not np.array_equal(got[slot][0].view(np.uint64), g["f%d_post_metrics" % i].view(np.uint64)):
+                bad.append("frame %d: metric doubles" % i)
+        out["verified"] = not bad
+        out["verified_detail"] = ("%d frames x (I420 frames, source normals, 4 post-reconstruction digests, 24 metric doubles) equal the "
+                                  "reference's" % len(dec)) if not bad else "; ".join(bad[:8])
+    for fr in dec:
+        fr.close()
+    return out
+
+
 def gather_canvases(enc, frames, sharder, cache, pin=True):
     """The N > 1 tail of a step: the finished canvases of every frame slot go to rank 0 (one gather per canvas kind and
     slot: every rank holds the same number of frames), which moves what arrives into (page-locked) host memory with
@@ -397,10 +503,10 @@ def main():
     a = parse()
     if a.cpu_child == "baseline":                              # the whole CPU baseline leg, in a process of its own
         from tmc2_amd.synth import synth_cloud
-        print(json.dumps(cpu_baseline(a.workload, a.iterations, [synth_cloud(a.workload, i) for i in range(min(a.frames, 16))])))
+        print(json.dumps(cpu_baseline(a.workload, a.iterations, [synth_cloud(a.workload, i) for i in range(min(a.frames, 16))], a.case)))
         return
     if a.cpu_child:
-        return cpu_child(a.cpu_child, a.workload, a.iterations)
+        return cpu_child(a.cpu_child, a.workload, a.iterations, a.case)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -427,7 +533,10 @@ def main():
     #  16 frames in flight, measured: device 85, host 75 frames/s -- and the host cores stay free)
     kd_mode = {"device": 0, "host": 1, "adaptive": 2}.get(a.kdtree, 0)
     T.load_library().tmc2_set_kdtree_placement(kd_mode)
-    enc = T.GofEncoder(local, workers, a.iterations, 11, 4, 1280, 1280, timing=True, first_domain=rank * workers)
+    c = a.case
+    P = c["precision"]
+    enc = T.GofEncoder(local, workers, a.iterations, c["bits3d"], P, c["min_w"], c["min_h"], timing=True, first_domain=rank * workers,
+                       vox_dim=c["vox_dim"])
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
 
@@ -443,7 +552,7 @@ def main():
             return t.numpy().view(dtype).reshape(shape)
         with host_lock:                                         # (called from the worker threads)
           if (W, H) not in host_cache:
-            host_cache[(W, H)] = [(dict(occupancy=pinned((H, W), np.uint8), occ_video=pinned((H // 4, W // 4), np.uint8),
+            host_cache[(W, H)] = [(dict(occupancy=pinned((H, W), np.uint8), occ_video=pinned((H // P, W // P), np.uint8),
                                         block_to_patch=pinned((H // 16, W // 16), np.uint32),
                                         geo0=pinned((H, W), np.uint16), geo1=pinned((H, W), np.uint16)),
                                    pinned((2, 3, H, W), np.uint8)) for _ in frames]
@@ -536,7 +645,7 @@ def main():
         """(in-flight ms per launch, alone ms per launch, launches in the timed region, algorithmic bytes per launch)"""
         if name == "refine_sweep":                         # one of the I sweeps of the refine_sweeps stage
             fl, al, n_l = ms.get("refine_sweeps", 0.0), solo_ms.get("refine_sweeps", 0.0), calls.get("refine_sweeps", 0) * I
-            return fl / max(1, n_l), al / max(1, solo_calls.get("refine_sweeps", 1) * I), n_l, algorithmic_bytes(name, N, M, V, L, A)
+            return fl / max(1, n_l), al / max(1, solo_calls.get("refine_sweeps", 1) * I), n_l, algorithmic_bytes(name, N, M, V, L, A, P)
         if name == "patches":                              # S7-S9: connected components + per-patch build, all rounds
             fl = ms.get("patches_cc", 0.0) + ms.get("patches_build", 0.0)
             al = solo_ms.get("patches_cc", 0.0) + solo_ms.get("patches_build", 0.0)
@@ -544,7 +653,7 @@ def main():
             return fl / max(1, n_l), al / max(1, solo_calls.get("patches_build", 1)), n_l, 102.0 * N
         n_l = calls.get(name, 0)
         return (ms.get(name, 0.0) / max(1, n_l), solo_ms.get(name, 0.0) / max(1, solo_calls.get(name, 1)), n_l,
-                algorithmic_bytes(name, N, M, V, L, A))
+                algorithmic_bytes(name, N, M, V, L, A, P))
 
     names = ["knn_self", "normals", "initial_segmentation", "refine_setup", "refine_sweep", "patches", "k:ccMutualMask",
              "k:ccUnion", "k:ccRelax", "geometry_images", "reconstruct", "knn8_recon_in_source", "knn1_source_in_recon",
@@ -564,7 +673,7 @@ def main():
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     s_ach = dom_bytes / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
     fps = a.frames * a.steps / dt
-    b_alg = path_bytes(N, M, V, L, I, A, 4)
+    b_alg = path_bytes(N, M, V, L, I, A, P)
     # HBM bytes per launch from the PMC passes of profiles/collect.sh (FETCH_SIZE / WRITE_SIZE need their own runs under
     # rocprofv3, so they cannot be taken here): used only if they were collected from THESE kernel sources -- the file carries
     # a sha1 over mpeg-pcc-tmc2_amd/csrc, recomputed here; counters of other code are dropped, not quoted
@@ -594,14 +703,16 @@ def main():
     except (OSError, ValueError, KeyError, IndexError):
         pass
     out = {
-        "metric": "encoder patch+image-gen frames/sec, longdress_vox10 32-frame GOF",
+        "metric": "encoder patch+image-gen frames/sec, %s %d-frame GOF" % (a.workload, a.frames),
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int32/f64", "data": "synthetic",
         "verified": verdict, "verified_detail": detail,
-        "config": {"workload": "%s-like synthetic, %d frames, %d points/frame avg, ctc-common + %s + r3 "
-                               "(refine iterations %d, occupancyPrecision 4), canvas %dx%d" %
-                               (a.workload, a.frames, n_points // max(1, len(frames)), a.packing, a.iterations, W, H),
+        "config": {"workload": "%s-like synthetic, %d frames, %d points/frame avg, ctc-common + %s "
+                               "(refine iterations %d on voxels of %d, %d-bit geometry, occupancyPrecision %d), canvas %dx%d" %
+                               (a.workload, a.frames, n_points // max(1, len(frames)), a.packing, a.iterations, c["vox_dim"],
+                                c["bits3d"] - 1, P, W, H),
+                   "case": a.case_name if a.is_case else None,
                    "stages": "S0-S22: k-d tree, kNN, normals, orientation, segmentation, refinement, patches, packing, "
                              "occupancy + geometry images, dilation, reconstruction, colour transfer, attribute images, "
                              "push-pull padding (identity video codec between the phases); the D1/D2 metric (S23) is "
@@ -628,19 +739,22 @@ def main():
         out["roofline"]["stream_copy"] = {"error": repr(e)}
     # S23 is reported separately: one frame, D1 + D2 + colour, both directions
     # (tmc2_metrics_compute_frame: source, normals and reconstruction are the frame's resident arrays -- nothing is uploaded)
-    enc.per_frame(frames[:1], lambda fr, i: fr.metrics_compute(0, True))             # warm (allocations)
+    resolution = float((1 << (c["bits3d"] - 1)) - 1)
+    enc.per_frame(frames[:1], lambda fr, i: fr.metrics_compute(0, True, resolution))             # warm (allocations)
     enc.ctxs[0].stage_reset()
     t0 = time.time()
-    q, qc = enc.per_frame(frames[:1], lambda fr, i: fr.metrics_compute(0, True))[0]
+    q, qc = enc.per_frame(frames[:1], lambda fr, i: fr.metrics_compute(0, True, resolution))[0]
     out["metric_ms_per_frame"] = round(1000.0 * (time.time() - t0), 1)
     out["metric_stage_ms"] = {k: round(v, 3) for k, v in sorted(enc.ctxs[0].stage_ms().items()) if v > 0}
     out["metric_frame0"] = {"d1_psnr": round(float(q[2, 1]), 4), "d2_psnr": round(float(q[2, 3]), 4), "y_psnr": round(float(q[2, 7]), 4),
                             "points": [int(qc[0]), int(qc[1])]}
     try:                                                       # ... and against the reference's doubles where the fixture has them
-        g = np.load(os.path.join(ROOT, "tests", "golden", "full_size.npz"))
-        key = "longdress_vox10_ai_r3/f0_metrics"
-        if a.workload == "longdress_vox10" and a.iterations == 50 and key in g.files:
-            out["metric_frame0"]["equals_reference"] = bool(np.array_equal(q.view(np.uint64), g[key].view(np.uint64)))
+        # (the single-frame case of the same sequence holds PCCMetrics::compute's doubles for frame 0; an all-intra frame's
+        #  reconstruction does not depend on the other frames of its GOF)
+        import re
+        g1 = case_fixture(re.sub(r"_gof\d+$", "", a.case_name))
+        if a.is_case and c["pack"] == 0 and "f0_metrics" in g1:
+            out["metric_frame0"]["equals_reference"] = bool(np.array_equal(q.view(np.uint64), g1["f0_metrics"].view(np.uint64)))
     except OSError:
         pass
     # What ONE rank of the 8-GPU run does (the driver's SCALE run is the only real measurement; this is its single-GPU proxy):
@@ -703,6 +817,12 @@ def main():
                            "stage_ms_alone": {k: round(v, 3) for k, v in sorted(tail_ms.items()) if v > 0}}
         except Exception as e:                                 # never lose the metric line over the side measurement
             out["tail"] = {"error": repr(e)}
+    if world == 1 and a.decoder:
+        try:
+            W, H = step()                                     # (every frame as a full step leaves it)
+            out["decoder"] = decoder_leg(a, T, torch, enc, frames, clouds, my_indices, W, H)
+        except Exception as e:
+            out["decoder"] = {"error": repr(e)}
     # PLY ingest, outside the metric too: one frame written as the reference writes it (ASCII,
     # as the 8i / Owlii content ships, and binary), read straight into page-locked buffers, uploaded and bound to a frame
     if world == 1 and a.ingest:
@@ -717,7 +837,7 @@ def main():
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "baseline", "--workload", a.workload,
-                                "--iterations", str(a.iterations), "--frames", str(a.frames)],
+                                "--iterations", str(a.iterations), "--frames", str(a.frames), "--config", a.case_name],
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1800)
             out["cpu_baseline"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
         except Exception as e:

@@ -136,11 +136,13 @@ struct KdTreeHost {
 #if defined( __HIP_DEVICE_COMPILE__ ) && !defined( __gfx950__ ) && !defined( __gfx942__ )
 #error "loadStaleOk: the stale-view argument is written for the gfx942 / gfx950 cache hierarchy"
 #endif
+#if defined( __HIPCC__ )  // (device helper; the host-only translation units also build with a plain host compiler: tools/asan_host_gcc.sh)
 template <typename T>
 __device__ __forceinline__ T loadStaleOk( const T* p, bool agent = false ) {
   return agent ? __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT )
                : __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
+#endif
 
 // pointToPixel of a reconstructed point in one word: canvas x, y (15 bits each: canvases up to kMaxCanvasDim pixels a side,
 // enforced where a canvas size enters -- generateGeometryImages, the decoder frame), map layer, "a D1 point follows"

@@ -1170,6 +1170,7 @@ __global__ __launch_bounds__( 64 * kHugeWaves ) void hugeSegmentsKernel( BuildAr
   const uint32_t total = *a.hugeCount;
   for ( uint32_t s = blockIdx.x; s < total; s += gridDim.x ) {
     const HugeSeg seg = a.huge[s];
+    __syncthreads();  // (a slower wavefront may still be reading the previous segment's last sCount)
     if ( threadIdx.x == 0 ) {
       HugeNode r;
       r.begin = 0, r.end = seg.end - seg.begin, r.node = seg.node, r.depth = 0;

@@ -115,7 +115,9 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   // private memory: ~ 90 MB written and read back per launch at longdress size, 6 x the algorithmic bytes); with the cap the
   // stack holds the handful of far children that are really near.
   uint32_t cap = 0;
-  {
+  if ( nTree < uint32_t( K ) ) {
+    cap = 0xFFFFFFFFu;  // fewer than K points in the tree: nothing to bound with, the list keeps its unfilled slots
+  } else {
     uint32_t centre = j;
     if ( !SELF ) {
       uint32_t at = 0;

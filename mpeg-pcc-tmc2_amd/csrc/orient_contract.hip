@@ -205,7 +205,7 @@ __global__ __launch_bounds__( 256 ) void flattenKernel( uint32_t n, uint32_t* __
 // ids; a probe sequence that runs too long raises the overflow flag and the frame takes the edge list as it is).
 struct PairTable {
   unsigned long long *key, *bestW;  // key: (c + 1) << 32 | c2; bestW: the largest |d| (as bits) among the pair's light edges
-  uint32_t*           strongSeen;   // bit s: a strong edge of implied relative sign s has been kept
+  uint32_t*           strongFirst;  // [2 * slot + s]: the first strong edge (u * 16 + j) of implied relative sign s -- the one that is kept
   uint32_t            mask;         // capacity - 1 (a power of two)
 };
 constexpr int kPairProbes = 128;
@@ -265,6 +265,12 @@ __global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __res
       else if ( fabs( d ) < tau ) {
         const unsigned long long w = (unsigned long long)__double_as_longlong( fabs( d ) );
         if ( w > __hip_atomic_load( &t.bestW[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &t.bestW[s], w );
+      } else {
+        // a strong one-way edge: one per implied relative sign is enough, and it is the FIRST in (start, slot) order -- the one
+        // the host-only reduction keeps (compactOnHost), whatever the scheduling
+        uint32_t* first = &t.strongFirst[2 * size_t( s ) + ( ( d < 0.0 ? 1u : 0u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )];
+        const uint32_t id = u * 16u + uint32_t( j );
+        if ( id < __hip_atomic_load( first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( first, id );
       }
     }
   }
@@ -299,8 +305,7 @@ __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __res
       if ( s == 0xFFFFFFFFu ) {
         keep = true;  // (unreachable after a clean insert pass; harmless: an extra edge)
       } else if ( fabs( d ) >= tau ) {
-        const uint32_t bit = 1u << ( ( d < 0.0 ? 1u : 0u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) );
-        keep               = !( atomicOr( &t.strongSeen[s], bit ) & bit );
+        keep = t.strongFirst[2 * size_t( s ) + ( ( d < 0.0 ? 1u : 0u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )] == u * 16u + uint32_t( j );
       } else {
         keep = (unsigned long long)__double_as_longlong( fabs( d ) ) == t.bestW[s];
       }
@@ -446,7 +451,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   const uint32_t n   = uint32_t( f->n );
   ok                 = false;
   if ( f->k != 16 ) return TMC2_OK;  // not instantiated: the caller walks the points
-  DevBuf<uint32_t> d_word, d_count, d_off, d_cursor, d_small, d_root, d_minIdx, d_flag, d_rank, d_strongSeen;
+  DevBuf<uint32_t> d_word, d_count, d_off, d_cursor, d_small, d_root, d_minIdx, d_flag, d_rank, d_strongFirst;
   DevBuf<uint16_t> d_mask, d_crossMask, d_keepMask;
   DevBuf<unsigned long long> d_pairs;
   TMC2_TRY( d_word.alloc( n ) );
@@ -464,12 +469,13 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   const char*    pairsEnv = getenv( "TMC2_ORIENT_PAIRS" );
   const uint32_t pairCap  = 1u << ( pairsEnv ? std::min( 24, std::max( 4, atoi( pairsEnv ) ) ) : 20 );
   TMC2_TRY( d_pairs.alloc( 2 * size_t( pairCap ) ) );
-  TMC2_TRY( d_strongSeen.alloc( pairCap ) );
+  TMC2_TRY( d_strongFirst.alloc( 2 * size_t( pairCap ) ) );
+  if ( n >= ( 1u << 28 ) ) return TMC2_OK;  // (edge ids are u * 16 + j in 32 bits; the caller walks the points)
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
   TMC2_TRY( fillRegions( ctx, {{d_small.p, 32, 0},
                                {d_minIdx.p, size_t( n ) * 4, 0xFF},
                                {d_pairs.p, 2 * size_t( pairCap ) * 8, 0},
-                               {d_strongSeen.p, size_t( pairCap ) * 4, 0}} ) );
+                               {d_strongFirst.p, 2 * size_t( pairCap ) * 4, 0xFF}} ) );
   TMC2_TRY( ensureMutualMask( f ) );
   const dim3 grdN16( cappedBlocks( ctx, ( size_t( n ) + 15 ) / 16 ) );  // 16 lanes per point, groups of 16 points in a stride loop
   TMC2_TRY( d_count.alloc( size_t( n ) + 1 ) );  // (initWordsKernel zeroes it; later: kept edges per cluster, C + 1 used)
@@ -491,13 +497,18 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 3 ) );
   TMC2_TRY( d_off.alloc( size_t( n ) + 1 ) );  // (per-cluster arrays sized for the worst case, n clusters: the used part is known
   TMC2_TRY( d_cursor.alloc( n ) );            //  only after the round trip below)
-  PairTable t{d_pairs.p, d_pairs.p + pairCap, d_strongSeen.p, pairCap - 1};
+  PairTable t{d_pairs.p, d_pairs.p + pairCap, d_strongFirst.p, pairCap - 1};
   hipLaunchKernelGGL( pairInsertKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_minIdx.p, d_rank.p, d_parity.p, n,
                       tau, t, d_cid.p, d_crossMask.p, d_small.p );
   // First attempt without knowing the sizes: room for kSpecEdges kept edges and kSpecClusters clusters (three times what a
   // longdress frame needs), everything queued back to back and ONE round trip -- counters, cluster records and edges come
   // back together.  A frame that needs more room (or whose pair table overflowed) is repeated with exact sizes, two round trips.
-  constexpr uint32_t kSpecEdges = 384 * 1024, kSpecClusters = 64 * 1024;
+  // (test hook TMC2_ORIENT_SPEC = "<edges>,<clusters>": shrinks the speculative room so that small clouds take the repeat)
+  uint32_t kSpecEdges = 384 * 1024, kSpecClusters = 64 * 1024;
+  if ( const char* spec = getenv( "TMC2_ORIENT_SPEC" ) ) {
+    unsigned e = 0, c = 0;
+    if ( sscanf( spec, "%u,%u", &e, &c ) == 2 ) kSpecEdges = std::max( 1u, std::min( kSpecEdges, e ) ), kSpecClusters = std::max( 2u, std::min( kSpecClusters, c ) );
+  }
   DevBuf<OrientCompactEdge> d_edges;
   DevBuf<OrientClusterRec>  d_rec;
   TMC2_TRY( d_edges.alloc( kSpecEdges ) );
@@ -517,7 +528,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
                       d_minIdx.p, n, d_small.p + 3, kSpecEdges, kSpecClusters, d_cursor.p, d_edges.p, d_rec.p );
   TMC2_HIP( hipMemcpyAsync( h_head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
   // (what a frame typically needs, plus a margin, comes along right away; the rest -- if any -- after the counters are known)
-  constexpr uint32_t kFirstEdges = 192 * 1024, kFirstClusters = 32 * 1024;
+  const uint32_t kFirstEdges = std::min( 192u * 1024, kSpecEdges ), kFirstClusters = std::min( 32u * 1024, kSpecClusters );
   TMC2_HIP( hipMemcpyAsync( h_rec, d_rec.p, size_t( kFirstClusters ) * sizeof( OrientClusterRec ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( kFirstEdges ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
@@ -538,17 +549,22 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
     }
     if ( more ) TMC2_HIP( hipStreamSynchronize( s ) );
   } else {
-    for ( int dedupe = head[2] ? 0 : 1;; ) {
-      if ( !dedupe ) ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
+    if ( head[2] ) {
+      // the pair table overflowed: every cross edge goes (selection and counts again, without the table)
+      ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
       TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
-      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, dedupe,
+      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, 0,
                           d_keepMask.p, d_count.p );
       TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
       TMC2_HIP( hipMemcpyAsync( head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
-      break;
+      E = head[1], C = head[3];
+    } else {
+      // only the room was short: the selection, its counts and offsets stand as they are (they never depended on the room);
+      // the cursors start again and the scatter runs with exact sizes
+      ctx->stageAddHostMs( "orient_exact_size_repeat", 0.0 );
+      TMC2_TRY( fillRegions( ctx, {{d_cursor.p, size_t( n ) * 4, 0}} ) );
     }
-    E = head[1], C = head[3];
     TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
     TMC2_TRY( d_rec.alloc( size_t( C ) + 1 ) );
     hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
@@ -563,6 +579,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
     if ( E ) TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( E ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
   }
+  if ( getenv( "TMC2_ORIENT_SPEC" ) ) ctx->stageAddHostMs( "orient_compact_edges", double( E ) );  // (test hook: the size of the compact graph)
   g.clusters = C, g.rec = h_rec, g.edges = h_edges;
   ok         = true;
   return TMC2_OK;

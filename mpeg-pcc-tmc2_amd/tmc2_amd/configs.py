@@ -1,0 +1,76 @@
+"""The BASELINE.json configurations with their real common-test-condition settings -- ONE table for bench.py (--config), the
+GPU tests (tests/test_gpu_full_size.py, tests/test_gpu_gof_soak.py) and the fixture generator (tests/golden/make_golden.py).
+
+Each entry is what the reference's configuration stack resolves to for that sequence / condition / rate
+(cfg/common/ctc-common.cfg + cfg/sequence/<name>.cfg + cfg/condition/ctc-{all-intra,random-access}.cfg + cfg/rate/ctc-r{3,5}.cfg):
+    workload    the synthetic stand-in of the sequence (tmc2_amd.synth: the MPEG content is not redistributable)
+    frames      frames of the GOF
+    iterations  iterationCountRefineSegmentation           vox_dim   voxelDimensionRefineSegmentation
+    bits3d      geometry3dCoordinatesBitdepth + 1          precision occupancyPrecision
+    min_w/min_h minimumImageWidth / minimumImageHeight     pack      0 all-intra (packFlexible per frame), 1 low-delay
+                                                                      (spatial consistency), 2 random-access (+ global patch allocation)
+A case name is `<sequence>_<ai|ra>_r<rate>[_gof<frames>]`; tests/golden/full_size.npz holds the unmodified reference's digests
+under the same name."""
+
+_SEQ = {
+    # sequence: (iterations, vox_dim, bits3d, min_h)      (cfg/sequence/*.cfg)
+    "longdress_vox10": (50, 4, 11, 1280),
+    "loot_vox10": (10, 2, 11, 1280),
+    "redandblack_vox10": (10, 2, 11, 1344),
+    "soldier_vox10": (10, 2, 11, 1280),
+}
+
+
+def _ai(seq, frames):
+    it, vd, b, mh = _SEQ[seq]
+    return dict(workload=seq, frames=frames, iterations=it, vox_dim=vd, bits3d=b, precision=4, min_w=1280, min_h=mh, pack=0)
+
+
+def _basketball(frames):      # cfg/sequence/basketball_player_vox11.cfg + ctc-random-access + r5
+    return dict(workload="basketball_player_vox11", frames=frames, iterations=20, vox_dim=4, bits3d=12, precision=2,
+                min_w=2560, min_h=1280, pack=2)
+
+
+FULL_SIZE_CASES = {
+    # config 2: longdress_vox10, ctc-all-intra, r3
+    "longdress_vox10_ai_r3": _ai("longdress_vox10", 1),
+    # config 3: the other 8i sequences, ctc-all-intra, r3 (voxels of 2 for the refinement; redandblack's taller minimum canvas)
+    "loot_vox10_ai_r3": _ai("loot_vox10", 1),
+    "redandblack_vox10_ai_r3": _ai("redandblack_vox10", 1),
+    "soldier_vox10_ai_r3": _ai("soldier_vox10", 1),
+    # config 4: basketball_player_vox11, ctc-random-access, r5
+    "basketball_player_vox11_ra_r5": _basketball(1),
+    # config 2 as the bench runs it: the whole 32-frame GOF (the condition bench.py times, 16 frames in flight on the GPU)
+    "longdress_vox10_ai_r3_gof32": _ai("longdress_vox10", 32),
+    # config 4 with a real GOF: the global patch allocation (performDataAdaptiveGPAMethod, PCCEncoder.cpp:6821-6971) on the
+    # 2560-wide, occupancyPrecision-2 canvas BASELINE names (one frame alone leaves it degenerate)
+    "basketball_player_vox11_ra_r5_gof4": _basketball(4),
+    # the random-access packing chain (spatial consistency + global patch allocation) on the real 1280 canvas
+    "longdress_vox10_ra_r3_gof3": dict(_ai("longdress_vox10", 3), pack=2),
+    # configs 3 and 4 with several frames: the frames-in-flight gates and the per-config bench lines (round 4)
+    "loot_vox10_ai_r3_gof8": _ai("loot_vox10", 8),
+    "redandblack_vox10_ai_r3_gof8": _ai("redandblack_vox10", 8),
+    "soldier_vox10_ai_r3_gof8": _ai("soldier_vox10", 8),
+    "basketball_player_vox11_ra_r5_gof8": _basketball(8),
+    # ... and at BASELINE's GOF length (what `bench.py --config <sequence>` times)
+    "loot_vox10_ai_r3_gof32": _ai("loot_vox10", 32),
+    "redandblack_vox10_ai_r3_gof32": _ai("redandblack_vox10", 32),
+    "soldier_vox10_ai_r3_gof32": _ai("soldier_vox10", 32),
+    "basketball_player_vox11_ra_r5_gof32": _basketball(32),
+}
+
+# what `bench.py --config <short name>` runs (the fixture case whose digests the timed step is checked against)
+BENCH_CONFIGS = {
+    "longdress": "longdress_vox10_ai_r3_gof32",
+    "loot": "loot_vox10_ai_r3_gof8",
+    "redandblack": "redandblack_vox10_ai_r3_gof8",
+    "soldier": "soldier_vox10_ai_r3_gof8",
+    "basketball": "basketball_player_vox11_ra_r5_gof8",
+}
+
+PACKING_NAME = {0: "all-intra", 1: "low-delay", 2: "random-access"}
+
+
+def constrained_pack(case):
+    """GofEncoder.phase_a's constrained_pack argument for a case."""
+    return {0: False, 1: True, 2: 2}[case["pack"]]

@@ -9,6 +9,7 @@ import os as _os
 # set before the HIP runtime initialises; an explicit setting of the user wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import os
+import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -79,8 +80,45 @@ def ctc_params(iterations=10, bits3d=11, weight=(1.0, 1.0, 1.0), vox_dim=4):
     return p
 
 
+# TMC2_GUARD=1 (tests, bench.py --guard): every array handed to the C-ABI travels in a copy with a red zone of _GUARD bytes on
+# both sides, filled with a pattern; after the call (_check) the zones are verified -- the library wrote outside a buffer of the
+# caller's iff they changed -- and the payload is copied back.  Calls are synchronous on host buffers (the getters end with a
+# stream synchronisation), so the copy-back sees the final bytes.  Costs a copy per argument: a debugging aid, not a mode to time.
+_GUARD = 4096
+_guard_on = os.environ.get("TMC2_GUARD", "0") == "1"
+_guard_tls = threading.local()
+
+
+def set_guard(on):
+    global _guard_on
+    _guard_on = bool(on)
+
+
 def _ptr(a):
-    return a.ctypes.data_as(C.c_void_p)
+    if not _guard_on or a.nbytes == 0:
+        return a.ctypes.data_as(C.c_void_p)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise Tmc2Error("guard mode: array handed to the C-ABI is not contiguous")
+    g = np.full(a.nbytes + 2 * _GUARD, 0xA5, np.uint8)
+    g[_GUARD:_GUARD + a.nbytes] = a.reshape(-1).view(np.uint8)
+    if not hasattr(_guard_tls, "pending"):
+        _guard_tls.pending = []
+    _guard_tls.pending.append((a, g))
+    return C.c_void_p(g.ctypes.data + _GUARD)
+
+
+def _guard_finish():
+    pending, _guard_tls.pending = getattr(_guard_tls, "pending", []), []
+    for a, g in pending:
+        n = a.nbytes
+        lo, hi = g[:_GUARD], g[_GUARD + n:]
+        if (lo != 0xA5).any() or (hi != 0xA5).any():
+            before, after = int((lo != 0xA5).sum()), int((hi != 0xA5).sum())
+            first = int(np.argmax(hi != 0xA5)) if after else -1
+            raise Tmc2Error("guard mode: the library wrote outside a caller's buffer (%s %s, %d bytes): %d bytes changed before it, "
+                            "%d after it (first at +%d)" % (a.dtype, a.shape, n, before, after, first))
+        if a.flags["WRITEABLE"]:
+            a.reshape(-1).view(np.uint8)[:] = g[_GUARD:_GUARD + n]
 
 
 def load_library():
@@ -103,6 +141,8 @@ def load_library():
 
 
 def _check(rc):
+    if _guard_on:
+        _guard_finish()
     if rc != 0:
         raise Tmc2Error("tmc2hip error %d: %s" % (rc, load_library().tmc2_last_error().decode()))
 

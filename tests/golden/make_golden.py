@@ -196,34 +196,8 @@ def io_golden():
     print("io_golden", {k: (v.shape if getattr(v, "shape", ()) else str(v)) for k, v in out.items()})
 
 
-# BASELINE.json configurations at their real sizes and settings (cfg/common/ctc-common.cfg + cfg/sequence/<name>.cfg +
-# cfg/condition + cfg/rate): (iterationCountRefineSegmentation, voxelDimensionRefineSegmentation, geometry3dCoordinatesBitdepth
-# + 1, occupancyPrecision, minimumImageWidth, minimumImageHeight, constrainedPack / globalPatchAllocation)
-FULL_SIZE_CASES = {
-    # config 2: longdress_vox10, ctc-all-intra, r3
-    "longdress_vox10_ai_r3": dict(workload="longdress_vox10", frames=1, iterations=50, vox_dim=4, bits3d=11, precision=4,
-                                  min_w=1280, min_h=1280, pack=0),
-    # config 3: the other 8i sequences, ctc-all-intra, r3 (voxels of 2 for the refinement; redandblack's taller minimum canvas)
-    "loot_vox10_ai_r3": dict(workload="loot_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4,
-                             min_w=1280, min_h=1280, pack=0),
-    "redandblack_vox10_ai_r3": dict(workload="redandblack_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4,
-                                    min_w=1280, min_h=1344, pack=0),
-    "soldier_vox10_ai_r3": dict(workload="soldier_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4,
-                                min_w=1280, min_h=1280, pack=0),
-    # config 4: basketball_player_vox11, ctc-random-access, r5
-    "basketball_player_vox11_ra_r5": dict(workload="basketball_player_vox11", frames=1, iterations=20, vox_dim=4, bits3d=12,
-                                          precision=2, min_w=2560, min_h=1280, pack=2),
-    # config 2 as the bench runs it: the whole 32-frame GOF (the condition bench.py times, 16 frames in flight on the GPU)
-    "longdress_vox10_ai_r3_gof32": dict(workload="longdress_vox10", frames=32, iterations=50, vox_dim=4, bits3d=11, precision=4,
-                                        min_w=1280, min_h=1280, pack=0),
-    # config 4 with a real GOF: the global patch allocation (performDataAdaptiveGPAMethod, PCCEncoder.cpp:6821-6971) on the
-    # 2560-wide, occupancyPrecision-2 canvas BASELINE names (one frame alone leaves it degenerate)
-    "basketball_player_vox11_ra_r5_gof4": dict(workload="basketball_player_vox11", frames=4, iterations=20, vox_dim=4, bits3d=12,
-                                               precision=2, min_w=2560, min_h=1280, pack=2),
-    # the random-access packing chain (spatial consistency + global patch allocation) on the real 1280 canvas
-    "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4,
-                                       min_w=1280, min_h=1280, pack=2),
-}
+# BASELINE.json configurations at their real sizes and CTC settings: ONE table for the generator, the GPU tests and bench.py
+from tmc2_amd.configs import FULL_SIZE_CASES  # noqa: E402
 FULL_SIZE_PHASE_A = ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1")
 FULL_SIZE_PHASE_B = ("recon_xyz", "recon_rgb", "point_to_pixel", "attribute")
 
@@ -243,12 +217,44 @@ def full_size_digests(a, b):
     return out
 
 
-def full_size(only=None):
-    """MD5 fixtures at BASELINE size from the unmodified reference: minutes of CPU time, kilobytes of fixture."""
+FULL_SIZE_PHASE_C = ("xyz", "colors16", "rgb", "boundary")
+
+
+def full_size_decoder_side(ref, frames, a, b, resolution, metric_frames):
+    """Config 5 (the decoder's frame finish = the encoder's post-reconstruction tail) at BASELINE size, from the unmodified
+    reference: the attribute canvases through "RGB444ToYUV420_8_4" (the I420 frames the video encoder reads) and back through
+    "YUV420ToYUV444_8_0" (PCCInternalColorConverter.cpp:355-482: what an identity video codec hands the reconstruction),
+    colorPointCloud, smoothPointCloudPostprocess (PCCCodec.cpp:54, 1067-1106), transferColors16bitBP (PCCPointSet.cpp:1126),
+    convertYUV16ToRGB8 -- MD5s per frame -- and PCCMetrics::compute (PCCMetrics.cpp:324-375) of the source frame against the
+    finished cloud, raw doubles, for the frames in metric_frames."""
+    out, decoded = {}, []
+    for i, pb in enumerate(b):
+        planes = [ref.convert_rgb444_to_yuv420(pb["attribute"][m]) for m in range(2)]
+        i420 = np.stack([np.concatenate([p.ravel() for p in planes[m]]) for m in range(2)])
+        d444 = np.stack([ref.convert_yuv420_to_yuv444(*planes[m]) for m in range(2)])
+        out["f%d_i420_md5" % i], out["f%d_dec444_md5" % i] = np.array(digest(i420)), np.array(digest(d444))
+        decoded.append(d444)
+    post = ref.phase_c(b, decoded)
+    for i, pc in enumerate(post):
+        for k in FULL_SIZE_PHASE_C:
+            out["f%d_post_%s_md5" % (i, k)] = np.array(digest(pc[k]))
+        out["f%d_post_moved" % i] = np.array(int((pc["boundary"] == 3).sum()))
+        if i in metric_frames:
+            q, counts = ref.metrics(frames[i][0], frames[i][1], pc["xyz"], pc["rgb"], None, resolution)
+            out["f%d_post_metrics_no_normals" % i], out["f%d_post_metric_counts" % i] = q, counts
+            nrm = ref.normals(frames[i][0], 16, True)                  # (the source's normals: D2 needs them)
+            out["f%d_post_metrics" % i], _ = ref.metrics(frames[i][0], frames[i][1], pc["xyz"], pc["rgb"], nrm, resolution)
+            out["f%d_src_normals_md5" % i] = np.array(digest(nrm))
+    return out
+
+
+def full_size(only=None, part_dir=None):
+    """MD5 fixtures at BASELINE size from the unmodified reference: minutes of CPU time, kilobytes of fixture.  part_dir: write
+    each case to its own <part_dir>/<name>.npz (several cases at once, one process each; `full_size_merge` folds them in)."""
     import time
     ref = ob.Reference()
     path = os.path.join(HERE, "full_size.npz")
-    out = dict(np.load(path)) if os.path.exists(path) else {}
+    out = dict(np.load(path)) if os.path.exists(path) and not part_dir else {}
     for name, c in FULL_SIZE_CASES.items():
         if only and name not in only:
             continue
@@ -258,12 +264,33 @@ def full_size(only=None):
         b = ref.phase_b(frames, a, c["precision"])
         d = full_size_digests(a, b)
         d["input_md5"] = np.array("".join(digest(x) + digest(col) for x, col in frames))
-        for k in [k for k in out if k.startswith(name + "/")]:
+        t1 = time.time()
+        d.update(full_size_decoder_side(ref, frames, a, b, float((1 << (c["bits3d"] - 1)) - 1), range(c["frames"])))
+        for k in [k for k in out if k.startswith(name + "/") and not k.split("/")[1].startswith(("f0_metric", "f0_normals"))]:
             del out[k]
         out.update({name + "/" + k: v for k, v in d.items()})
-        np.savez_compressed(path, **out)
+        if part_dir:
+            os.makedirs(part_dir, exist_ok=True)
+            np.savez_compressed(os.path.join(part_dir, name + ".npz"), **{k: v for k, v in out.items() if k.startswith(name + "/")})
+        else:
+            np.savez_compressed(path, **out)
         print(name, [len(f[0]) for f in frames], "canvas", d["canvas"], "counts", [d["f%d_counts" % i].tolist() for i in range(c["frames"])],
-              "%.0f s" % (time.time() - t), flush=True)
+              "moved", [int(d["f%d_post_moved" % i]) for i in range(c["frames"])],
+              "%.0f s (decoder side %.0f s)" % (time.time() - t, time.time() - t1), flush=True)
+
+
+def full_size_merge(part_dir):
+    """Fold per-case part files into full_size.npz (a case's encoder-side metric doubles, made by full_size_metrics, stay)."""
+    path = os.path.join(HERE, "full_size.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for fn in sorted(os.listdir(part_dir)):
+        name = fn[:-4]
+        new = dict(np.load(os.path.join(part_dir, fn)))
+        for k in [k for k in out if k.startswith(name + "/") and not k.split("/")[1].startswith(("f0_metric", "f0_normals"))]:
+            del out[k]
+        out.update(new)
+        print("merged", name, len(new), "entries")
+    np.savez_compressed(path, **out)
 
 
 FULL_SIZE_METRIC_CASES = ("longdress_vox10_ai_r3", "loot_vox10_ai_r3", "redandblack_vox10_ai_r3", "soldier_vox10_ai_r3",
@@ -303,6 +330,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full_size":
         full_size(sys.argv[2:])
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "full_size_part":           # full_size_part <dir> <case> ...
+        full_size(sys.argv[3:], part_dir=sys.argv[2])
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "full_size_merge":
+        full_size_merge(sys.argv[2])
         sys.exit(0)
     main()
     gof()

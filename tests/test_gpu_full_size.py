@@ -14,16 +14,12 @@ from tmc2_amd.synth import synth_cloud
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURE = os.path.join(HERE, "golden", "full_size.npz")
 
-# (kept in step with tests/golden/make_golden.py FULL_SIZE_CASES; the fixture's input_md5 pins the synthetic input)
-CASES = {
-    "longdress_vox10_ai_r3": dict(workload="longdress_vox10", frames=1, iterations=50, vox_dim=4, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
-    "loot_vox10_ai_r3": dict(workload="loot_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
-    "redandblack_vox10_ai_r3": dict(workload="redandblack_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1344, pack=0),
-    "soldier_vox10_ai_r3": dict(workload="soldier_vox10", frames=1, iterations=10, vox_dim=2, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=0),
-    "basketball_player_vox11_ra_r5": dict(workload="basketball_player_vox11", frames=1, iterations=20, vox_dim=4, bits3d=12, precision=2, min_w=2560, min_h=1280, pack=2),
-    "basketball_player_vox11_ra_r5_gof4": dict(workload="basketball_player_vox11", frames=4, iterations=20, vox_dim=4, bits3d=12, precision=2, min_w=2560, min_h=1280, pack=2),
-    "longdress_vox10_ra_r3_gof3": dict(workload="longdress_vox10", frames=3, iterations=50, vox_dim=4, bits3d=11, precision=4, min_w=1280, min_h=1280, pack=2),
-}
+# one table for the fixture generator (tests/golden/make_golden.py), these tests and bench.py; the fixture's input_md5 pins the
+# synthetic input.  The several-frame cases of configs 2-4 run with many frames in flight in tests/test_gpu_gof_soak.py.
+from tmc2_amd.configs import FULL_SIZE_CASES as ALL_CASES, constrained_pack
+
+CASES = {k: ALL_CASES[k] for k in ("longdress_vox10_ai_r3", "loot_vox10_ai_r3", "redandblack_vox10_ai_r3", "soldier_vox10_ai_r3",
+                                   "basketball_player_vox11_ra_r5", "basketball_player_vox11_ra_r5_gof4", "longdress_vox10_ra_r3_gof3")}
 
 
 def digest(a):
@@ -60,7 +56,7 @@ def test_gpu_full_size_matches_golden(name):
                        min_w=c["min_w"], min_h=c["min_h"], vox_dim=c["vox_dim"])
     try:
         frs = enc.upload(frames)
-        W, H = enc.phase_a(frs, constrained_pack={0: False, 1: True, 2: 2}[c["pack"]])
+        W, H = enc.phase_a(frs, constrained_pack=constrained_pack(c))
         enc.phase_b(frs)
         per = []
         for fr in frs:
@@ -82,47 +78,75 @@ def test_gpu_full_size_matches_golden(name):
         enc.close()
 
 
+def decoder_side_cut(fr):
+    """What the bitstream carries of an encoder-side frame: the patch records a decoder parses (no depth pools, no 3-D boxes
+    beyond u1 / v1 / d1), the occupancy video and the two geometry maps (identity video codec), the two I420 attribute frames."""
+    patches = fr.get_patches()[0][fr.get_patch_order()]
+    sent = np.zeros(len(patches), patches.dtype)
+    for k in ("u0", "v0", "sizeU0", "sizeV0", "patchOrientation", "u1", "v1", "d1", "normalAxis", "tangentAxis", "bitangentAxis",
+              "projectionMode"):
+        sent[k] = patches[k]
+    sent["sizeU"], sent["sizeV"] = sent["sizeU0"] * 16, sent["sizeV0"] * 16
+    img = fr.get_geometry_images()
+    return sent, img["occ_video"], np.stack([img["geo0"], img["geo1"]]), fr.encoder_attribute_to_yuv420(4)
+
+
+def check_decoder_side(g, i, i420, dec444, post, metrics=None, metrics_no_normals=None, counts=None):
+    """Frame i of a case against the reference's digests of the decoder-side chain (make_golden.py full_size_decoder_side)."""
+    assert digest(i420) == str(g["f%d_i420_md5" % i]), "I420 attribute frames of frame %d" % i
+    if dec444 is not None:
+        assert digest(dec444) == str(g["f%d_dec444_md5" % i]), "decoded 4:4:4 attribute frames of frame %d" % i
+    for k in ("xyz", "colors16", "rgb", "boundary"):
+        assert digest(post[k]) == str(g["f%d_post_%s_md5" % (i, k)]), "post-reconstruction %s of frame %d" % (k, i)
+    assert int((post["boundary"] == 3).sum()) == int(g["f%d_post_moved" % i]) > 0     # (the geometry smoothing moved points)
+    for got, key in ((metrics, "f%d_post_metrics"), (metrics_no_normals, "f%d_post_metrics_no_normals")):
+        if got is not None:
+            exp = g[key % i]
+            assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), (key % i, got, exp)
+    if counts is not None:
+        assert np.asarray(counts).tolist() == g["f%d_post_metric_counts" % i].tolist()
+
+
 @pytest.mark.gpu
-def test_gpu_full_size_decoder_side(gpu_ctx):
-    """Config 5 at BASELINE size: a decoder-side frame (decoded patch records, occupancy video, geometry maps of a 0.84 M-point
-    longdress frame: no source cloud) -> generatePointCloud -> decoded attribute frames -> post-reconstruction tail -> D1 / D2 /
-    colour metric against the uncompressed frame.  The reconstruction equals the reference's (MD5 fixture); the finished cloud
-    and the metric equal what the encoder-side frame it was cut from gives (whose metric the fixture pins)."""
-    name = "longdress_vox10_ai_r3"
+@pytest.mark.parametrize("name", ["longdress_vox10_ai_r3", "loot_vox10_ai_r3", "basketball_player_vox11_ra_r5"])
+def test_gpu_full_size_decoder_side(gpu_ctx, name):
+    """Config 5 at BASELINE size against the UNMODIFIED REFERENCE: a decoder-side frame (decoded patch records, occupancy video,
+    geometry maps: no source cloud) -> generatePointCloud -> decoded attribute frames (I420 -> 16-bit 4:4:4,
+    PCCInternalColorConverter.cpp:355-482) -> post-reconstruction tail (smoothPointCloudPostprocess PCCCodec.cpp:54,1067-1106,
+    transferColors16bitBP PCCPointSet.cpp:1126) -> D1 / D2 / colour metric against the uncompressed frame (PCCMetrics.cpp:324-375).
+    Every intermediate is compared with the reference's digest / doubles (voxels of 4 and of 2; 10- and 11-bit geometry,
+    occupancyPrecision 4 and 2); the encoder-side frame it was cut from must give the same bytes."""
     c, g = CASES[name], fixture(name)
+    if "f0_post_xyz_md5" not in g:
+        pytest.fail("decoder-side digests of %s missing from tests/golden/full_size.npz" % name)
     xyz, rgb = synth_cloud(c["workload"], 0)
     enc = gpu_ctx.frame(xyz, rgb)
     enc.segmenter_compute(T.ctc_params(c["iterations"], c["bits3d"], enc.weight_normal(c["bits3d"], 0.6), c["vox_dim"]))
     h = enc.encoder_pack_flexible(c["min_w"], 2, 1.0)
     W, H = T.encoder_canvas_size([h], c["min_w"], c["min_w"], c["min_h"])
+    assert (W, H) == tuple(int(x) for x in g["canvas"])
     enc.encoder_generate_geometry_images(W, H, c["precision"])
     enc.encoder_generate_attribute_images()
-    img = enc.get_geometry_images()
-    i420 = enc.encoder_attribute_to_yuv420(4)
-    patches = enc.get_patches()[0][enc.get_patch_order()]
-    sent = np.zeros(len(patches), patches.dtype)                     # only what the bitstream carries
-    for k in ("u0", "v0", "sizeU0", "sizeV0", "patchOrientation", "u1", "v1", "d1", "normalAxis", "tangentAxis", "bitangentAxis",
-              "projectionMode"):
-        sent[k] = patches[k]
-    sent["sizeU"], sent["sizeV"] = sent["sizeU0"] * 16, sent["sizeV0"] * 16
-    dec = gpu_ctx.decoder_frame(sent, W, H, c["precision"], img["occ_video"], np.stack([img["geo0"], img["geo1"]]))
+    sent, occ_video, geometry, i420 = decoder_side_cut(enc)
+    dec = gpu_ctx.decoder_frame(sent, W, H, c["precision"], occ_video, geometry)
     dec.codec_generate_point_cloud()
     rx, _, rp = dec.get_reconstruction(colors=False)
     assert digest(rx) == str(g["f0_recon_xyz_md5"]) and digest(rp) == str(g["f0_point_to_pixel_md5"])
+    nrm, res = enc.get_normals(), float((1 << (c["bits3d"] - 1)) - 1)
+    assert digest(nrm) == str(g["f0_src_normals_md5"])
     for fr in (dec, enc):
         fr.codec_set_decoded_attribute_yuv420(i420, 0)
         fr.codec_post_reconstruct(None)
-    a, b = dec.get_post_reconstruction(), enc.get_post_reconstruction()
-    for k in ("xyz", "colors16", "rgb", "boundary"):
-        assert np.array_equal(a[k], b[k]), k
-    assert int((a["boundary"] == 3).sum()) > 0                       # (the geometry smoothing moved points)
-    nrm, res = enc.get_normals(), float((1 << (c["bits3d"] - 1)) - 1)
-    for normals in (None, nrm):
-        got, gc = dec.metrics_compute_source(xyz, rgb, normals, 1, res)
-        exp, ec = enc.metrics_compute(1, normals is not None, res)
-        assert np.array_equal(gc, ec) and np.array_equal(got.view(np.uint64), exp.view(np.uint64)), (got, exp)
-        via_host, _ = gpu_ctx.metrics_compute(xyz, rgb, a["xyz"], a["rgb"], normals, res)
-        assert np.array_equal(got.view(np.uint64), via_host.view(np.uint64))
+        post = fr.get_post_reconstruction()
+        if fr is dec:
+            m1, counts = fr.metrics_compute_source(xyz, rgb, nrm, 1, res)
+            m0, _ = fr.metrics_compute_source(xyz, rgb, None, 1, res)
+        else:
+            m1, counts = fr.metrics_compute(1, True, res)
+            m0, _ = fr.metrics_compute(1, False, res)
+        check_decoder_side(g, 0, i420, fr.get_decoded_attribute(), post, m1, m0, counts)
+    via_host, _ = gpu_ctx.metrics_compute(xyz, rgb, post["xyz"], post["rgb"], nrm, res)
+    assert np.array_equal(via_host.view(np.uint64), g["f0_post_metrics"].view(np.uint64))
 
 
 def test_oracle_full_size_matches_golden(oracle):

@@ -345,6 +345,21 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch
     assert np.array_equal(fr3.get_normals().view(np.uint64), exp.view(np.uint64))
     assert gpu_ctx.stage_calls().get("orient_pair_table_overflow", 0) == 1
     monkeypatch.delenv("TMC2_ORIENT_PAIRS")
+    # the speculative room of the first attempt too small (what a vox11-size or noisy frame meets: > 64 K clusters or > 384 K
+    # kept edges): the scatter is repeated with exact sizes on the SAME selection -- same compact graph (the strong one-way
+    # edges included: the first of every implied sign, whatever the scheduling), same bits
+    edges = []
+    for spec, repeats in (("1000000,1000000", 0), ("64,16", 1), ("1000000,16", 1), ("64,1000000", 1)):
+        monkeypatch.setenv("TMC2_ORIENT_SPEC", spec)
+        fr4 = gpu_ctx.frame(xyz, rgb)
+        gpu_ctx.stage_reset()
+        fr4.normals_compute(16, 1)
+        assert np.array_equal(fr4.get_normals().view(np.uint64), exp.view(np.uint64)), spec
+        assert gpu_ctx.stage_calls().get("orient_exact_size_repeat", 0) == repeats, spec
+        assert gpu_ctx.stage_calls().get("orient_normals_regrowth", 0) == 0
+        edges.append(gpu_ctx.stage_ms()["orient_compact_edges"])
+    assert edges[0] > 64 and len(set(edges)) == 1, edges
+    monkeypatch.delenv("TMC2_ORIENT_SPEC")
     monkeypatch.setenv("TMC2_ORIENT_NO_CONTRACTION", "1")
     fr2 = gpu_ctx.frame(xyz, rgb)
     fr2.normals_compute(16, 1)

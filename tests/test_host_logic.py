@@ -576,7 +576,9 @@ def test_bench_cpu_baseline_leg_reports_one_core_and_all_cores():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     from tmc2_amd.synth import synth_cloud
-    res = bench.cpu_baseline("tiny", 2, [synth_cloud("tiny", f) for f in range(4)])
+    from tmc2_amd.configs import FULL_SIZE_CASES
+    case = dict(FULL_SIZE_CASES["longdress_vox10_ai_r3_gof32"], name="longdress_vox10_ai_r3_gof32")
+    res = bench.cpu_baseline("tiny", 2, [synth_cloud("tiny", f) for f in range(4)], case)
     assert res["unit"] == "frames/s" and res["cores"] == 1 and res["value"] > 0 and res["kind"] in ("reference", "port")
     if os.path.exists(ob.REF_TBB_PATH):
         assert "all_cores_error" not in res, res

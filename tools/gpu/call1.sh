@@ -3,9 +3,9 @@
 mkdir -p gpurun_out
 
 
-timeout -k 10 900 python -m pytest tests/test_gpu_gof32.py -m gpu -x -q > gpurun_out/r03_gof32.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_gof_soak.py -m gpu -x -q > gpurun_out/r03_gof32.log 2>&1
 echo "gof32 rc=$?" >> gpurun_out/r03_gof32.log
-timeout -k 10 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_gof32.py > gpurun_out/r03_gpu_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_gof_soak.py > gpurun_out/r03_gpu_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/r03_gpu_tests.log
 timeout -k 10 600 python bench.py --steps 10 --warmup 3 --cpu-baseline 0 --tail 0 --ingest 0 > gpurun_out/r03_bench_pre1.json 2> gpurun_out/r03_bench_pre1.err
 TMC2_UF_PRECHECK=0 timeout -k 10 600 python bench.py --steps 10 --warmup 3 --cpu-baseline 0 --tail 0 --ingest 0 > gpurun_out/r03_bench_pre0.json 2> gpurun_out/r03_bench_pre0.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # patch-stage change check: parity tests through the patch kernels, then their durations in one frame
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "patch or segmenter or full_size or degenerate or whole_path" --deselect tests/test_gpu_gof32.py > gpurun_out/patch_tests.log 2>&1; echo "rc=$?" >> gpurun_out/patch_tests.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "patch or segmenter or full_size or degenerate or whole_path" --deselect tests/test_gpu_gof_soak.py > gpurun_out/patch_tests.log 2>&1; echo "rc=$?" >> gpurun_out/patch_tests.log
 tail -n 4 gpurun_out/patch_tests.log
 REPO=$(pwd); OUT=$REPO/gpurun_out; export TMPDIR=/tmp
 SOLO="python $REPO/bench.py --steps 1 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 --ingest 0"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick check: a pytest selection ($1), then the durations of the kernels matching $2 in one frame
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "$1" --deselect tests/test_gpu_gof32.py > gpurun_out/quick_tests.log 2>&1; echo "rc=$?" >> gpurun_out/quick_tests.log
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "$1" --deselect tests/test_gpu_gof_soak.py > gpurun_out/quick_tests.log 2>&1; echo "rc=$?" >> gpurun_out/quick_tests.log
 tail -n 3 gpurun_out/quick_tests.log
 REPO=$(pwd); OUT=$REPO/gpurun_out; export TMPDIR=/tmp
 SOLO="python $REPO/bench.py --steps 1 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 --ingest 0"

@@ -1,10 +1,10 @@
 #!/bin/bash
 # the whole GPU tier (the 16-in-flight soak last), then a bench line
 mkdir -p gpurun_out
-timeout -k 10 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_gof32.py > gpurun_out/tier_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/tier_tests.log
+timeout -k 10 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_gof_soak.py > gpurun_out/tier_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/tier_tests.log
 tail -n 5 gpurun_out/tier_tests.log
 if [ "$1" = "soak" ]; then
-  timeout -k 10 900 python -m pytest tests/test_gpu_gof32.py -m gpu -x -q > gpurun_out/tier_gof32.log 2>&1; echo "gof32 rc=$?" >> gpurun_out/tier_gof32.log
+  timeout -k 10 900 python -m pytest tests/test_gpu_gof_soak.py -m gpu -x -q > gpurun_out/tier_gof32.log 2>&1; echo "gof32 rc=$?" >> gpurun_out/tier_gof32.log
   tail -n 4 gpurun_out/tier_gof32.log
 fi
 timeout -k 10 600 python bench.py --steps 10 --warmup 3 > gpurun_out/tier_bench.json 2> gpurun_out/tier_bench.err
