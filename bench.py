@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--kdtree", default="auto", choices=["auto", "device", "host", "adaptive"],
                     help="where the k-d trees are built (auto = device)")
     ap.add_argument("--iterations", type=int, default=None, help="iterationCountRefineSegmentation (default: the configuration's)")
-    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg; 2 runs it inside this process "
+                    "(the round-3 form: two builds of the reference loaded next to the product library)")
     ap.add_argument("--ingest", type=int, default=1, help="0 skips the (untimed) PLY ingest measurement")
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--decoder", type=int, default=1, help="0 skips the decoder-side GOF leg (BASELINE config 5: reconstruct + "
@@ -830,7 +831,9 @@ def main():
             out["ingest"] = ingest_leg(T, torch, enc.ctxs[0], clouds[0])
         except Exception as e:
             out["ingest"] = {"error": repr(e)}
-    if a.cpu_baseline and world == 1:                          # rank 0 at N = 1 only (the contract of the bench line)
+    if a.cpu_baseline == 2 and world == 1:                     # the round-3 form, kept for reproducing its heap corruption: in-process
+        out["cpu_baseline"] = cpu_baseline(a.workload, a.iterations, clouds[:min(a.frames, 16)], a.case)
+    elif a.cpu_baseline and world == 1:                        # rank 0 at N = 1 only (the contract of the bench line)
         # In a process of its own: the leg loads the reference's libraries (two builds of the same C++ code, one with TBB and
         # 128 threads) -- foreign code that must not be able to take the metric line with it (a full run died once with glibc's
         # "corrupted double-linked list" seconds into this leg; the path itself ran clean under MALLOC_CHECK_=3).
@@ -849,10 +852,12 @@ def main():
     sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
-    # The line is out: leave without the interpreter's teardown (sixteen worker threads with their contexts, the pinned pools
-    # of two runtimes) -- nothing that happens while a benchmark process is torn down should turn a measured run into a failed one.
-    sys.stderr.flush()
-    os._exit(0)
+    # Orderly teardown (round 3 left through os._exit after an unexplained heap corruption in a bench process; DESIGN.md section 9
+    # has what round 4 found): frames before their contexts, each worker thread ended and joined, contexts closed, then the
+    # interpreter's own exit.
+    for fr in frames:
+        fr.close()
+    enc.close(join=True)
 
 
 if __name__ == "__main__":

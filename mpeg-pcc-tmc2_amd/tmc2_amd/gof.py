@@ -180,9 +180,16 @@ class GofEncoder:
         self.threads = [_Worker(w, device, cpus[w], timing) for w in range(workers)]
         self.ctxs = [t.ctx for t in self.threads]
 
-    def close(self):
+    def close(self, join=False):
+        """Ends the worker threads; join=True also waits for them and closes their contexts (every frame of this encoder must
+        have been closed before: a frame's device buffers go back to its context's pool)."""
         for t in self.threads:
             t.jobs.put(None)
+        if join:
+            for t in self.threads:
+                t.join()
+            for c in self.ctxs:
+                c.close()
 
     def upload(self, clouds):
         """Untimed: copy the GOF's point arrays to HBM (frame i lives on worker i % workers)."""

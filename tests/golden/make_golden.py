@@ -283,7 +283,7 @@ def full_size_merge(part_dir):
     """Fold per-case part files into full_size.npz (a case's encoder-side metric doubles, made by full_size_metrics, stay)."""
     path = os.path.join(HERE, "full_size.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
-    for fn in sorted(os.listdir(part_dir)):
+    for fn in sorted(f for f in os.listdir(part_dir) if f.endswith(".npz")):
         name = fn[:-4]
         new = dict(np.load(os.path.join(part_dir, fn)))
         for k in [k for k in out if k.startswith(name + "/") and not k.split("/")[1].startswith(("f0_metric", "f0_normals"))]:
