@@ -120,13 +120,13 @@ def test_gpu_full_size_decoder_side(gpu_ctx, name):
     if "f0_post_xyz_md5" not in g:
         pytest.fail("decoder-side digests of %s missing from tests/golden/full_size.npz" % name)
     xyz, rgb = synth_cloud(c["workload"], 0)
-    enc = gpu_ctx.frame(xyz, rgb)
-    enc.segmenter_compute(T.ctc_params(c["iterations"], c["bits3d"], enc.weight_normal(c["bits3d"], 0.6), c["vox_dim"]))
-    h = enc.encoder_pack_flexible(c["min_w"], 2, 1.0)
-    W, H = T.encoder_canvas_size([h], c["min_w"], c["min_w"], c["min_h"])
+    gof = T.GofEncoder(0, workers=1, iterations=c["iterations"], bits3d=c["bits3d"], occ_precision=c["precision"], min_w=c["min_w"],
+                       min_h=c["min_h"], vox_dim=c["vox_dim"])
+    gpu_ctx = gof.ctxs[0]                                            # (the packing condition of the case: through the GOF encoder)
+    enc = gof.upload([(xyz, rgb)])[0]
+    W, H = gof.phase_a([enc], constrained_pack=constrained_pack(c))
     assert (W, H) == tuple(int(x) for x in g["canvas"])
-    enc.encoder_generate_geometry_images(W, H, c["precision"])
-    enc.encoder_generate_attribute_images()
+    gof.phase_b([enc])
     sent, occ_video, geometry, i420 = decoder_side_cut(enc)
     dec = gpu_ctx.decoder_frame(sent, W, H, c["precision"], occ_video, geometry)
     dec.codec_generate_point_cloud()
@@ -147,6 +147,8 @@ def test_gpu_full_size_decoder_side(gpu_ctx, name):
         check_decoder_side(g, 0, i420, fr.get_decoded_attribute(), post, m1, m0, counts)
     via_host, _ = gpu_ctx.metrics_compute(xyz, rgb, post["xyz"], post["rgb"], nrm, res)
     assert np.array_equal(via_host.view(np.uint64), g["f0_post_metrics"].view(np.uint64))
+    dec.close(), enc.close()
+    gof.close()
 
 
 def test_oracle_full_size_matches_golden(oracle):

@@ -14,7 +14,7 @@ if [ "$1" = "run" ]; then
   shift
   export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0
   cd "$ROOT"
-  LD_PRELOAD=$RT TMC2_PACKAGE_DIR="$OUT/pkg" "$@"
+  LD_PRELOAD="$RT $(gcc -print-file-name=libstdc++.so)" TMC2_PACKAGE_DIR="$OUT/pkg" "$@"   # (libstdc++ up front: the runtime resolves __cxa_throw when it starts)
   exit $?
 fi
 mkdir -p "$OUT/build" "$OUT/pkg"
