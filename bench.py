@@ -62,6 +62,8 @@ def parse():
                          "B and after the copies (round 2); one = every frame runs its whole chain on a guessed canvas size, "
                          "the GOF meets at the end (GofEncoder.encode_all_intra: frames in different phases share the chip "
                          "worse -- measured 132 against 152 frames/s)")
+    ap.add_argument("--pin", type=int, default=1, help="0: plain host buffers instead of page-locked ones for the canvases (for runs "
+                    "under a sanitizer runtime, where torch's pinned allocator does not come up; slower copies)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--packing", default=None, choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition (default: the configuration's): every frame on its own, the spatial-consistency chain, "
@@ -415,6 +417,8 @@ def decoder_leg(a, T, torch, enc, frames, clouds, indices, W, H, reps=3):
     res = float((1 << (c["bits3d"] - 1)) - 1)
 
     def pinned(x):
+        if not a.pin:
+            return np.array(x, copy=True)
         t = torch.empty(x.nbytes, dtype=torch.uint8, pin_memory=True)
         out = t.numpy().view(x.dtype).reshape(x.shape)
         out[...] = x
@@ -549,6 +553,8 @@ def main():
         """Host-side destination of the finished canvases (what the video encoder reads), allocated once: page-locked
         host memory, so that the copies are plain DMA instead of being staged through the runtime's bounce buffers."""
         def pinned(shape, dtype):
+            if not a.pin:
+                return np.empty(shape, dtype)
             t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8, pin_memory=True)
             return t.numpy().view(dtype).reshape(shape)
         with host_lock:                                         # (called from the worker threads)
@@ -803,7 +809,7 @@ def main():
             tail_ms = enc.stage_ms()
             post = frames[0].get_post_reconstruction(xyz=False, colors16=False, rgb=False)
             W, H = step()                                     # (the one-frame run above left frame 0 on its own canvas)
-            i420 = [torch.empty(2 * (W * H * 3 // 2), dtype=torch.uint8, pin_memory=True).numpy().reshape(2, -1) for _ in frames]
+            i420 = [torch.empty(2 * (W * H * 3 // 2), dtype=torch.uint8, pin_memory=bool(a.pin)).numpy().reshape(2, -1) for _ in frames]
             enc.phase_c(frames, i420_out=i420)
             torch.cuda.synchronize()
             t0 = time.time()
@@ -826,7 +832,7 @@ def main():
             out["decoder"] = {"error": repr(e)}
     # PLY ingest, outside the metric too: one frame written as the reference writes it (ASCII,
     # as the 8i / Owlii content ships, and binary), read straight into page-locked buffers, uploaded and bound to a frame
-    if world == 1 and a.ingest:
+    if world == 1 and a.ingest and a.pin:
         try:
             out["ingest"] = ingest_leg(T, torch, enc.ctxs[0], clouds[0])
         except Exception as e:

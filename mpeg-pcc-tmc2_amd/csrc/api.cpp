@@ -211,6 +211,7 @@ void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   {
     ApiScope scope( ctx );
     ctx->gridTable.release();
+    ctx->gridBits.release();
     ctx->scanState.release();
     ctx->voxelBitmap.release();
   }

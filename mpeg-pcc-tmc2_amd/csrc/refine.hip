@@ -40,8 +40,11 @@ __device__ __forceinline__ uint32_t cellKey( int x0, int y0, int z0, int s ) {
 }
 
 // ---- voxelisation ---------------------------------------------------------------------------------
+// (bits: one bit per key -- the occupancy of the key table, which the neighbourhood passes probe 64 cells of a ball row at a
+//  time; look before the atomic: a voxel's points set the same bit)
 __global__ __launch_bounds__( 256 ) void voxelKeyKernel( const Pt* __restrict__ pts, uint32_t n, Grid g,
-                                                          uint32_t* __restrict__ key, uint32_t* __restrict__ table ) {
+                                                          uint32_t* __restrict__ key, uint32_t* __restrict__ table,
+                                                          uint32_t* __restrict__ bits ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
   const Pt       p = pts[i];
@@ -49,6 +52,8 @@ __global__ __launch_bounds__( 256 ) void voxelKeyKernel( const Pt* __restrict__ 
                               ( int( p.z ) + g.half ) >> g.voxShift, g.gridShift );
   key[i]           = k;
   atomicMin( &table[k], i );
+  const uint32_t bit = 1u << ( k & 31 );
+  if ( !( loadStaleOk( &bits[k >> 5] ) & bit ) ) atomicOr( &bits[k >> 5], bit );
 }
 
 __global__ __launch_bounds__( 256 ) void firstFlagKernel( const uint32_t* __restrict__ key,
@@ -87,9 +92,11 @@ __global__ __launch_bounds__( 256 ) void tableToVoxelKernel( const uint32_t* __r
 }
 
 __global__ __launch_bounds__( 256 ) void tableCleanKernel( const uint32_t* __restrict__ key, uint32_t n,
-                                                            uint32_t* __restrict__ table ) {
+                                                            uint32_t* __restrict__ table, uint32_t* __restrict__ bits ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i < n ) table[key[i]] = 0xFFFFFFFFu;
+  if ( i >= n ) return;
+  table[key[i]]    = 0xFFFFFFFFu;
+  bits[key[i] >> 5] = 0u;  // (whole words: every key of the word belongs to this frame)
 }
 
 // ---- histograms -----------------------------------------------------------------------------------
@@ -142,6 +149,111 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
   active[v] = e != NO_EDGE;
 }
 
+// ---- neighbourhoods, row-wise (round 4) ----------------------------------------------------------------------------------
+// The ball as ROWS: for every (dy, dz) with dy^2 + dz^2 < r2 the cells dx = -xr .. xr (xr the largest with dx^2 + dy^2 + dz^2
+// < r2).  Keys are linear in x, so the <= 2 xr + 1 <= 25 cells of a row are consecutive BITS of the occupancy bitmap: one lane
+// probes a whole row with two 4-byte loads instead of one load per cell (voxels of 2: 301 rows against 3 911 cells, of which
+// 8 % are occupied).  Only the occupied cells go on to the key table (the voxel id) and to the voxel's centre (aliased keys:
+// accept only the voxel whose centre really sits there).  Leaves the hits in keys[] as ( d2 << idBits ) | id, unsorted.
+//   rows[i] = ( dy + 128 ) | ( dz + 128 ) << 8 | xr << 16
+// phase 1: the occupied cells of the ball as packed offsets ( dx + 16 ) | ( dy + 16 ) << 5 | ( dz + 16 ) << 10 | d2 << 15
+// phase 2: id + centre of each, in place (a chunk of candidates is read whole before anything lands at or below it)
+template <int CAP>
+__device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ centre, const uint32_t* __restrict__ table,
+                                            const uint32_t* __restrict__ bits, const Grid g, const int* __restrict__ rows, int nRows,
+                                            int idBits, uint32_t* keys, int lane, uint32_t* __restrict__ overflow ) {
+  const int gridMax = 1 << g.gridShift;  // cell coordinates run 0 .. gridMax inclusive
+  int       cand    = 0;
+  constexpr int kRowBatch = 5;  // (5 x 64 rows: the whole ball of the CTC settings in one round of loads)
+  for ( int base = 0; base < nRows; base += 64 * kRowBatch ) {
+    uint32_t lo[kRowBatch], hi[kRowBatch];
+    int      sh[kRowBatch], len[kRowBatch], x0[kRowBatch], dyz[kRowBatch];
+#pragma unroll
+    for ( int k = 0; k < kRowBatch; ++k ) {
+      const int r = base + 64 * k + lane;
+      lo[k] = hi[k] = 0u;
+      sh[k] = len[k] = x0[k] = dyz[k] = 0;
+      if ( r < nRows ) {
+        const int packed = rows[r];
+        const int dy = ( packed & 0xFF ) - 128, dz = ( ( packed >> 8 ) & 0xFF ) - 128, xr = packed >> 16;
+        const int y = c.y + dy, z = c.z + dz;
+        const int xlo = max( 0, int( c.x ) - xr ), xhi = min( gridMax, int( c.x ) + xr );
+        if ( y >= 0 && z >= 0 && y <= gridMax && z <= gridMax && xlo <= xhi ) {
+          const uint32_t key0 = cellKey( xlo, y, z, g.gridShift );
+          lo[k]  = bits[key0 >> 5];
+          hi[k]  = bits[( key0 >> 5 ) + 1];  // (the bitmap carries a spare word behind its last key)
+          sh[k]  = int( key0 & 31 );
+          len[k] = xhi - xlo + 1;
+          x0[k]  = xlo - int( c.x );
+          dyz[k] = ( ( dy + 16 ) << 5 ) | ( ( dz + 16 ) << 10 ) | ( ( dy * dy + dz * dz ) << 15 );
+        }
+      }
+    }
+#pragma unroll
+    for ( int k = 0; k < kRowBatch; ++k ) {
+      uint32_t w = uint32_t( ( ( (unsigned long long)hi[k] << 32 ) | lo[k] ) >> sh[k] ) & ( len[k] >= 32 ? 0xFFFFFFFFu : ( ( 1u << len[k] ) - 1u ) );
+      const int mine = __popc( w );
+      int       inc  = mine;
+#pragma unroll
+      for ( int off = 1; off < 64; off <<= 1 ) {
+        const int t = __shfl_up( inc, off, 64 );
+        if ( lane >= off ) inc += t;
+      }
+      const int total = __shfl( inc, 63, 64 );
+      int       at    = cand + inc - mine;
+      while ( w ) {
+        const int b = __ffs( int( w ) ) - 1;
+        w &= w - 1u;
+        const int dx = x0[k] + b;
+        if ( at < CAP - 160 ) keys[at] = uint32_t( dx + 16 ) | uint32_t( dyz[k] + ( ( dx * dx ) << 15 ) );
+        ++at;
+      }
+      cand += total;
+    }
+  }
+  if ( cand > CAP - 160 ) {  // more occupied cells than this instantiation has room for: the host repeats with a larger one
+    if ( lane == 0 ) *overflow = 3u;
+    cand = CAP - 160;
+  }
+  __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  int hits = 0;
+  constexpr int kBatch = 4;
+  for ( int base = 0; base < cand; base += 64 * kBatch ) {
+    uint32_t u[kBatch], d2[kBatch], cell[kBatch];
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k ) {
+      const int i = base + 64 * k + lane;
+      u[k]        = 0xFFFFFFFFu;
+      d2[k] = cell[k] = 0;
+      if ( i < cand ) {
+        const uint32_t packed = keys[i];
+        const int x = c.x + int( packed & 31u ) - 16, y = c.y + int( ( packed >> 5 ) & 31u ) - 16, z = c.z + int( ( packed >> 10 ) & 31u ) - 16;
+        u[k]    = table[cellKey( x, y, z, g.gridShift )];
+        d2[k]   = packed >> 15;
+        cell[k] = uint32_t( x ) | ( uint32_t( y ) << 10 ) | ( uint32_t( z ) << 20 );  // (cell coordinates are at most 512)
+      }
+    }
+    uint32_t key[kBatch];
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k ) {
+      key[k] = 0xFFFFFFFFu;
+      if ( u[k] != 0xFFFFFFFFu ) {
+        const Pt cu = centre[u[k]];  // aliased keys: accept only the voxel whose centre really sits here
+        if ( ( uint32_t( cu.x ) | ( uint32_t( cu.y ) << 10 ) | ( uint32_t( cu.z ) << 20 ) ) == cell[k] ) key[k] = ( d2[k] << idBits ) | u[k];
+      }
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );  // (every lane has read its candidates of this batch)
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k ) {
+      const unsigned long long m = __ballot( key[k] != 0xFFFFFFFFu );
+      if ( key[k] != 0xFFFFFFFFu ) keys[hits + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = key[k];
+      hits += __popcll( m );
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  }
+  return hits;
+}
+
 // ---- neighbourhoods ---------------------------------------------------------------------------------
 // One wavefront per voxel.  offsets[] = all integer (dx,dy,dz) with d2 < radius2, packed, any order.
 // Collect hits (d2 << idBits | voxel id) in LDS, bitonic-sort, cut after the cumulative member count reaches maxNN; write
@@ -157,7 +269,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
     const int* __restrict__ offsets, int nOffsets, int maxNN, double lambda, int idBits, int devRange, uint32_t devStride,
     uint32_t rowCapacity, uint32_t* __restrict__ rowLen, uint32_t* __restrict__ devLen, double* __restrict__ weight,
     uint32_t* __restrict__ adjOff, uint32_t* __restrict__ adj, uint32_t* __restrict__ dev, uint32_t* __restrict__ rowCursor,
-    uint32_t* __restrict__ overflow ) {
+    uint32_t* __restrict__ overflow, const uint32_t* __restrict__ bits /* non-null: offsets = the ball's ROWS (collectBall) */,
+    uint32_t* __restrict__ lastKey /* the last key each row keeps: what the gathered reverse rows test against */ ) {
   __shared__ uint32_t keysAll[WAVES][CAP];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t      v    = blockIdx.x * WAVES + wave;
@@ -176,7 +289,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // all centre look-ups of its hits (two dependent round trips per batch instead of two per 64 cells: the kernel is bound by
   // exactly this latency).  The order of the hits does not matter: they are sorted below.
   constexpr int kBatch = 8;
-  for ( int base = 0; base < nOffsets; base += 64 * kBatch ) {
+  if ( bits ) hits = collectBall<CAP>( c, centre, table, bits, g, offsets, nOffsets, idBits, keys, lane, overflow );
+  for ( int base = 0; !bits && base < nOffsets; base += 64 * kBatch ) {
     uint32_t u[kBatch], d2[kBatch], cell[kBatch];
 #pragma unroll
     for ( int k = 0; k < kBatch; ++k ) {
@@ -314,9 +428,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   const bool fit = uint64_t( rowBase ) + uint32_t( used ) <= rowCapacity;
   if ( lane == 0 ) {
     rowLen[v] = uint32_t( used );
+    if ( lastKey ) lastKey[v] = used > 0 ? keys[used - 1] : 0u;
     adjOff[v] = fit ? rowBase : 0u;
     weight[v] = __ddiv_rn( lambda, double( nn ) );
-    if ( !fit ) *overflow = 1u;  // the host repeats the pass with room for whole balls
+    if ( !fit ) atomicMax( overflow, 1u );  // the host repeats the pass with room for whole balls
   }
   if ( fit )
     for ( int i = lane; i < used; i += 64 ) adj[size_t( rowBase ) + i] = keys[i] & idMask;
@@ -349,6 +464,62 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   }
   for ( uint32_t i = nDev + lane; i < devStride; i += 64 ) drow[i] = kDevPad;
   if ( lane == 0 ) devLen[v] = nDev;
+}
+
+
+// The REVERSE rows by gathering (round 4; rounds 1-3 scattered the forward rows: one returning atomic and one 4-byte store to
+// a random line per entry -- 13 x the contract bytes in HBM traffic).  u is listed by v iff u sits in v's ball and survives
+// v's truncation, i.e. iff ( d2( u, v ) << idBits | u ) <= the last key v kept (rows are sorted by exactly that key); the ball
+// is symmetric, so the candidates are u's own ball.  One wavefront per voxel u: collect the ball as above, keep the v with
+// key( u seen from v ) <= lastKey[v], write them back to back (one reservation per workgroup).  The order inside a reverse
+// row is immaterial (the sweeps push integer differences over it).
+template <int CAP, int WAVES>
+__global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint32_t* __restrict__ table,
+                                                                     const uint32_t* __restrict__ bits, Grid g, uint32_t V,
+                                                                     const int* __restrict__ rows, int nRows, int idBits,
+                                                                     const uint32_t* __restrict__ lastKey, uint32_t rowCapacity,
+                                                                     uint32_t* __restrict__ rOff, uint32_t* __restrict__ rLen,
+                                                                     uint32_t* __restrict__ radj, uint32_t* __restrict__ rowCursor,
+                                                                     uint32_t* __restrict__ overflow ) {
+  __shared__ uint32_t keysAll[WAVES][CAP];
+  const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t      u    = blockIdx.x * WAVES + wave;
+  uint32_t*           keys = keysAll[wave];
+  int                 kept = 0;
+  if ( u < V ) {
+    const uint32_t idMask = ( 1u << idBits ) - 1u;
+    const int      hits   = collectBall<CAP>( centre[u], centre, table, bits, g, rows, nRows, idBits, keys, lane, overflow );
+    for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
+      const int      i   = base + lane;
+      const uint32_t key = i < hits ? keys[i] : 0u;
+      const uint32_t v   = key & idMask;
+      const bool     in  = i < hits && ( ( key & ~idMask ) | u ) <= lastKey[v];
+      const unsigned long long m = __ballot( in );
+      __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+      if ( in ) keys[kept + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = v;
+      kept += __popcll( m );
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  }
+  if ( lane == 0 ) keys[CAP - 2] = uint32_t( kept );
+  __syncthreads();
+  if ( threadIdx.x == 0 ) {
+    uint32_t total = 0;
+    for ( int w = 0; w < WAVES; ++w ) total += keysAll[w][CAP - 2];
+    keysAll[0][CAP - 1] = atomicAdd( rowCursor, total );
+  }
+  __syncthreads();
+  if ( u >= V ) return;
+  uint32_t rowBase = keysAll[0][CAP - 1];
+  for ( int w = 0; w < wave; ++w ) rowBase += keysAll[w][CAP - 2];
+  const bool fit = uint64_t( rowBase ) + uint32_t( kept ) <= rowCapacity;
+  if ( lane == 0 ) {
+    rLen[u] = fit ? uint32_t( kept ) : 0u;
+    rOff[u] = fit ? rowBase : 0u;
+    if ( !fit ) atomicMax( overflow, 1u );  // (cannot happen when the forward rows fitted: the reverse rows hold the same entries)
+  }
+  if ( fit )
+    for ( int i = lane; i < kept; i += 64 ) radj[size_t( rowBase ) + i] = keys[i];
 }
 
 // ---- sweep kernels ----------------------------------------------------------------------------------
@@ -957,6 +1128,7 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
                                                        const uint32_t* __restrict__ pointStart,
                                                        const uint32_t* __restrict__ pointList,
                                                        const double* __restrict__ normals, const uint32_t* __restrict__ roff,
+                                                       const uint32_t* __restrict__ rlen /* null: roff is a CSR of V + 1 offsets */,
                                                        const uint32_t* __restrict__ radj, uint8_t* __restrict__ edge,
                                                        uint8_t* __restrict__ ppi, uint4* __restrict__ hist,
                                                        uint8_t* __restrict__ partition, uint32_t* __restrict__ flags, int iter ) {
@@ -1044,7 +1216,7 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
         // borrows between the halves cancel in the final sums whatever the order of the adds
         const uint32_t d0 = h0 - h.x, d1 = h1 - h.y, d2 = h2 - h.z;
         if ( d0 | d1 | d2 ) {
-          const uint32_t rb = roff[v], re = roff[v + 1];
+          const uint32_t rb = roff[v], re = rlen ? rb + rlen[v] : roff[v + 1];
           for ( uint32_t t = rb + sub; t < re; t += 16 ) {
             uint32_t* tr = reinterpret_cast<uint32_t*>( recNxt + radj[t] );
             if ( d0 ) atomicAdd( tr, d0 );
@@ -1088,14 +1260,16 @@ struct RefineJob {
   uint32_t         n = 0, V = 0, W = 0, devStride = 32, totalLen = 0;
   int              devRange = 1, idBits = 26;
   Grid             g{};
-  std::vector<int> offsets;
+  std::vector<int> offsets;  // the ball: its ROWS (byRows) or its cells
   uint32_t*        table = nullptr;
-  bool             tableFilled = false, eventDriven = false;
+  uint32_t*        bits  = nullptr;  // occupancy bitmap of the key table (kept all-zero between frames)
+  bool             tableFilled = false, eventDriven = false, byRows = true;
+  int              capTier = 2;  // which instantiation of the neighbourhood kernels (launchNeighbourhood)
   size_t           Vp = 0, W2 = 0, ball = 0, perVoxel = 0;
   uint64_t         capacity = 0;
   uint32_t         res[2] = {0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag
   DevBuf<uint32_t> d_key, d_flag, d_vid, d_small, d_count, d_rowLen, d_devLen, d_adjOff, d_hist, d_activeBuf, d_pointStart,
-      d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev;
+      d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev, d_lastKey, d_roffG, d_rlenG, d_radjG;
   DevBuf<Pt>      d_centre;
   DevBuf<double>  d_weight;
   DevBuf<uint8_t> d_state;  // edge | ppi | arg | marked | proc, V bytes each
@@ -1113,21 +1287,34 @@ struct RefineJob {
 RefineJob::~RefineJob() {
   if ( tableFilled && table && d_key.p ) {  // dropped between the halves: hand the context's table back empty
     ApiScope scope( ctx );
-    hipLaunchKernelGGL( tableCleanKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, s, d_key.p, n, table );
+    hipLaunchKernelGGL( tableCleanKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, s, d_key.p, n, table, bits );
     (void)hipStreamSynchronize( s );  // (the buffers go back to the pool when the members are destroyed)
   }
 }
 
+// forward rows and -- on the row-wise path -- the reverse rows behind them (d_small: [1] row cursor, [2] overflow, [3] reverse
+// row cursor)
 void RefineJob::launchNeighbourhood() {
+  const int nBall = int( offsets.size() );  // rows or cells
 #define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
   hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
-                      d_count.p, table, g, V, d_offsets.p, int( ball ), maxNNCount, lambda, idBits, devRange, devStride,       \
+                      d_count.p, table, g, V, d_offsets.p, nBall, maxNNCount, lambda, idBits, devRange, devStride,             \
                       uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
-                      d_small.p + 2 )
-  if ( ball <= 2048 - 160 )
+                      d_small.p + 2, byRows ? bits : (const uint32_t*)nullptr, byRows ? d_lastKey.p : (uint32_t*)nullptr );     \
+  if ( byRows )                                                                                                                \
+  hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, table, \
+                      bits, g, V, d_offsets.p, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
+                      d_small.p + 3, d_small.p + 2 )
+  // LDS per wavefront = room for the ball's OCCUPIED cells (row-wise form; a surface fills 5-10 % of a ball) or for all its
+  // cells; the smaller the room, the more wavefronts a CU holds (1024: 8 per SIMD, 4096: 2.5) -- a frame whose balls need more
+  // raises the overflow word to 3 and is repeated one tier up (the tier that worked is remembered per context)
+  if ( capTier == 0 ) {
+    TMC2_NEIGHBOURHOOD( 1024, 8 );
+  } else if ( capTier == 1 ) {
     TMC2_NEIGHBOURHOOD( 2048, 4 );
-  else
+  } else {
     TMC2_NEIGHBOURHOOD( 4096, 2 );
+  }
 #undef TMC2_NEIGHBOURHOOD
 }
 
@@ -1156,16 +1343,27 @@ int RefineJob::geometry( tmc2_frame* f ) {
     return TMC2_E_UNSUPPORTED;
   }
   const int r2 = searchRadius >> g.voxShift;
+  // (test hook TMC2_REFINE_NEIGHBOURHOOD=cells: the rounds 1-3 form -- one table look-up per cell of the ball, reverse rows by
+  //  scattering the forward rows -- kept as the cross-check of the row-wise form)
+  const char* nbEnv = getenv( "TMC2_REFINE_NEIGHBOURHOOD" );
+  byRows            = !( nbEnv && nbEnv[0] == 'c' );
   {
     int R = 0;
     while ( R * R < r2 ) ++R;
+    ball = 0;
     for ( int dz = -R; dz <= R; ++dz )
-      for ( int dy = -R; dy <= R; ++dy )
+      for ( int dy = -R; dy <= R; ++dy ) {
+        int xr = -1;
         for ( int dx = -R; dx <= R; ++dx )
-          if ( dx * dx + dy * dy + dz * dz < r2 )
-            offsets.push_back( ( dx + 128 ) | ( ( dy + 128 ) << 8 ) | ( ( dz + 128 ) << 16 ) );
+          if ( dx * dx + dy * dy + dz * dz < r2 ) {
+            ++ball;
+            xr = std::max( xr, dx );
+            if ( !byRows ) offsets.push_back( ( dx + 128 ) | ( ( dy + 128 ) << 8 ) | ( ( dz + 128 ) << 16 ) );
+          }
+        if ( byRows && xr >= 0 ) offsets.push_back( ( dy + 128 ) | ( ( dz + 128 ) << 8 ) | ( xr << 16 ) );
+      }
   }
-  if ( offsets.size() > 4096 - 160 || r2 > 128 ) {  // (the neighbourhood kernel keeps 160 words of its 2048 / 4096 for its own use)  // (search radius 192: r2 = 48 with voxels of 4, 96 with voxels of 2 -> 3 911 cells)
+  if ( ball > 4096 - 160 || r2 > 128 ) {  // (the neighbourhood kernel keeps 160 words of its 2048 / 4096 for its own use)  // (search radius 192: r2 = 48 with voxels of 4, 96 with voxels of 2 -> 3 911 cells)
     setError( "refineSegmentationGridBased: search radius %d too large for the LDS neighbourhood tile", searchRadius );
     return TMC2_E_UNSUPPORTED;
   }
@@ -1178,13 +1376,21 @@ int RefineJob::geometry( tmc2_frame* f ) {
     TMC2_HIP( hipMemsetAsync( ctx->gridTable.p, 0xFF, size_t( g.tableSize ) * 4, s ) );
   }
   table = ctx->gridTable.p;
+  {
+    const size_t bitWords = size_t( g.tableSize ) / 32 + 2;  // (+ spare words: a row's second word may lie behind the last key)
+    if ( ctx->gridBits.count < bitWords ) {
+      TMC2_TRY( ctx->gridBits.alloc( bitWords ) );
+      TMC2_HIP( hipMemsetAsync( ctx->gridBits.p, 0, bitWords * 4, s ) );
+    }
+    bits = ctx->gridBits.p;
+  }
   TMC2_TRY( d_key.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
   TMC2_TRY( d_vid.alloc( n ) );
   TMC2_TRY( d_small.alloc( 16 ) );  // [0] voxel count, [1] adjacency size, [2] closure flag
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
   tableFilled = true;
-  hipLaunchKernelGGL( voxelKeyKernel, grdN, blk, 0, s, f->d_pts.p, n, g, d_key.p, table );
+  hipLaunchKernelGGL( voxelKeyKernel, grdN, blk, 0, s, f->d_pts.p, n, g, d_key.p, table, bits );
   hipLaunchKernelGGL( firstFlagKernel, grdN, blk, 0, s, d_key.p, table, n, d_flag.p );
   DevBuf<uint32_t> d_rank;
   TMC2_TRY( d_rank.alloc( n ) );
@@ -1226,7 +1432,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
                                {d_hist.p, size_t( V ) * 16, 0},
                                {d_state.p, Vp * 6, 0},
                                {d_cursor.p, size_t( V ) * 4, 0},
-                               {d_small.p + 1, 8, 0},  // [1] row cursor, [2] overflow
+                               {d_small.p + 1, 12, 0},  // [1] row cursor, [2] overflow, [3] reverse row cursor
                                {d_flags.p, ( 2 * size_t( iterationCount ) + 2 ) * 4, 0},
                                {d_rcount.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
                                {d_rcursor.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
@@ -1247,7 +1453,6 @@ int RefineJob::geometry( tmc2_frame* f ) {
     return TMC2_E_UNSUPPORTED;
   }
   TMC2_TRY( d_dev.alloc( size_t( V ) * devStride ) );
-  ball                = offsets.size();
   const char* capEnv  = getenv( "TMC2_REFINE_ROWCAP" );
   perVoxel            = std::min<size_t>( ball, 2 * size_t( maxNNCount > 0 ? maxNNCount : 1 ) * V / std::max<uint32_t>( n, 1u ) + 32 );
   if ( capEnv && capEnv[0] == 't' ) perVoxel = 1;
@@ -1256,7 +1461,16 @@ int RefineJob::geometry( tmc2_frame* f ) {
     setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
     return TMC2_E_UNSUPPORTED;
   }
+  capTier = ball <= 2048 - 160 ? 1 : 2;
+  if ( byRows ) capTier = std::min( capTier, std::max( 0, ctx->refineCapTier ) );  // (test hook TMC2_REFINE_CAPTIER: start there)
+  if ( const char* tierEnv = getenv( "TMC2_REFINE_CAPTIER" ) ) capTier = std::min( 2, std::max( byRows ? 0 : capTier, atoi( tierEnv ) ) );
   TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
+  if ( byRows ) {  // the reverse rows hold the same entries as the forward rows: same room
+    TMC2_TRY( d_lastKey.alloc( V ) );
+    TMC2_TRY( d_roffG.alloc( V ) );
+    TMC2_TRY( d_rlenG.alloc( V ) );
+    TMC2_TRY( d_radjG.alloc( size_t( capacity ) ) );
+  }
   launchNeighbourhood();
   TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );  // (read in finish(), after a synchronisation)
   ctx->stageEnd( sidSetup );
@@ -1281,22 +1495,29 @@ int RefineJob::finish() {
     TMC2_HIP( hipGetLastError() );
     totalLen = res[0];
     if ( res[1] == 0 ) break;
-    if ( res[1] != 1 || attempt > 0 ) {
+    if ( ( res[1] != 1 && res[1] != 3 ) || attempt > 3 || ( res[1] == 3 && capTier >= 2 ) ) {
       setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
       return TMC2_E_HIP;
     }
-    perVoxel = ball;  // room for whole balls
+    if ( res[1] == 3 ) {  // balls with more occupied cells than the instantiation holds: one tier up, for this context's next frames too
+      ++capTier;
+      ctx->refineCapTier = capTier;
+      ctx->stageAddHostMs( "refine_cap_tier_repeat", 0.0 );
+    } else {
+      perVoxel = ball;  // room for whole balls
+    }
     capacity = uint64_t( V ) * perVoxel;
     if ( capacity > 0xFFFFFFFFull ) {
       setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
       return TMC2_E_UNSUPPORTED;
     }
     TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
-    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 8, s ) );  // [1] row cursor, [2] overflow
+    if ( byRows ) TMC2_TRY( d_radjG.alloc( size_t( capacity ) ) );
+    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 12, s ) );  // [1] row cursor, [2] overflow, [3] reverse row cursor
     launchNeighbourhood();
     TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );
   }
-  hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table );
+  hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table, bits );
   tableFilled = false;
   hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,
                       d_hist.p );
@@ -1306,14 +1527,18 @@ int RefineJob::finish() {
     // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
     DevBuf<uint32_t> d_roff, d_radj, d_lists;
     DevBuf<uint4>    d_rec;
-    TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
-    TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
     TMC2_TRY( d_lists.alloc( size_t( kSubLists ) * V ) );  // (a voxel is listed once per sweep: any sub-list can hold them all)
     TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
-    hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcount.p );
-    TMC2_TRY( exclusiveScanU32( ctx, d_rcount.p, d_roff.p, size_t( V ) + 1, nullptr ) );
-    hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
-                        d_radj.p );
+    const uint32_t *revOff = d_roffG.p, *revLen = d_rlenG.p, *revAdj = d_radjG.p;  // gathered behind the forward rows
+    if ( !byRows ) {  // the rounds 1-3 form: count, prefix sum, scatter
+      TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
+      TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
+      hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcount.p );
+      TMC2_TRY( exclusiveScanU32( ctx, d_rcount.p, d_roff.p, size_t( V ) + 1, nullptr ) );
+      hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
+                          d_radj.p );
+      revOff = d_roff.p, revLen = nullptr, revAdj = d_radj.p;
+    }
     hipLaunchKernelGGL( smoothInitKernel, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
                         d_rowLen.p, d_adj.p, V, d_rec.p );
     ctx->stageEnd( sidSetup );
@@ -1358,7 +1583,7 @@ int RefineJob::finish() {
                           devStride, V, run, state[cur], state[nxt], uint32_t( W2 ), d_lists.p, V, counts[cur], counts[nxt], spill,
                           ctl, ringCap, wantTiming ? d_timing.p + 8 * size_t( iter ) : nullptr );
       hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
-                          d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, d_roff.p, d_radj.p, d_edge,
+                          d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, revOff, revLen, revAdj, d_edge,
                           d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
     }
     ctx->stageEnd( sidSweep );

@@ -226,6 +226,56 @@ def test_gpu_refine_key_aliasing(gpu_ctx, oracle):
     assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=10))
 
 
+@pytest.mark.parametrize("vox_dim", [4, 2])
+@pytest.mark.parametrize("form", ["cells", "rows-tier1", "rows-tier2"])
+def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, monkeypatch, vox_dim, form):
+    """S5's neighbourhood rows two ways -- row-wise through the occupancy bitmap with gathered reverse rows (round 4, default)
+    and cell by cell with scattered reverse rows (rounds 1-3, TMC2_REFINE_NEIGHBOURHOOD=cells) -- and in every LDS tier of the
+    row-wise kernels: same bits as the reference's refinement.  A cloud with coordinates at the top of the range, so that
+    voxel keys alias in both."""
+    if form == "cells":
+        monkeypatch.setenv("TMC2_REFINE_NEIGHBOURHOOD", "cells")
+    else:
+        monkeypatch.setenv("TMC2_REFINE_CAPTIER", form[-1])
+    for shift_to_top in (False, True):
+        xyz, _ = synth_cloud("small")
+        if shift_to_top:
+            xyz = (xyz + (1023 - xyz.max(0))).astype(np.int16)
+        nrm = oracle.normals(xyz)
+        p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+        fr = gpu_ctx.frame(xyz)
+        fr.set_normals(nrm)
+        fr.set_partition(p0)
+        fr.segmenter_refine_grid_based(1024, 3.0, 8, vox_dim, 192)
+        assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=8, vox_dim=vox_dim)), (form, shift_to_top)
+
+
+@pytest.mark.parametrize("vox_dim", [4, 2])
+def test_gpu_refine_solid_cloud_takes_the_larger_tier(oracle, vox_dim):
+    """A SOLID block fills its balls (1 357 / 3 911 occupied cells a voxel): more than the smallest instantiation of the row-wise
+    neighbourhood kernels holds in LDS -- the frame is repeated one tier up (twice for voxels of 2), the context remembers, and
+    the result is the reference's."""
+    ctx = T.Context(0)                                                # (its own context: the tier is remembered per context)
+    side = 60 if vox_dim == 4 else 40
+    g = np.arange(side, dtype=np.int16)
+    xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + np.int16(200)
+    rng = np.random.default_rng(5)
+    nrm = rng.normal(size=(len(xyz), 3))
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    p0 = oracle.initial_segmentation(nrm, np.ones(3))
+    exp = oracle.refine_grid(xyz, nrm, p0, iterations=3, vox_dim=vox_dim)
+    for attempt in range(2):
+        fr = ctx.frame(xyz)
+        fr.set_normals(nrm)
+        fr.set_partition(p0)
+        ctx.stage_reset()
+        fr.segmenter_refine_grid_based(1024, 3.0, 3, vox_dim, 192)
+        assert np.array_equal(fr.get_partition(), exp), attempt
+        repeats = ctx.stage_calls().get("refine_cap_tier_repeat", 0)
+        assert repeats == ((1 if vox_dim == 4 else 2) if attempt == 0 else 0), (attempt, repeats)
+    ctx.close()
+
+
 def _to_oracle_params(p):
     import oracle_binding as ob
     return ob.seg_params(p.iterationCountRefineSegmentation, p.geometryBitDepth3D, list(p.weightNormal))

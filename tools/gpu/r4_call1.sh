@@ -5,7 +5,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out
 timeout -k 10 1500 python -m pytest tests -m gpu -x -q --durations=15 > $O/r04_gpu_tests.log 2>&1; echo "rc=$?" >> $O/r04_gpu_tests.log
 tail -n 25 $O/r04_gpu_tests.log
-timeout -k 10 900 bash tools/asan_host_gcc.sh run python bench.py --steps 3 --warmup 1 --cpu-baseline 0 > $O/r04_asan_bench.json 2> $O/r04_asan_bench.err; echo "asan rc=$?" | tee -a $O/r04_asan_bench.err
+timeout -k 10 900 bash tools/asan_host_gcc.sh run python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --pin 0 > $O/r04_asan_bench.json 2> $O/r04_asan_bench.err; echo "asan rc=$?" | tee -a $O/r04_asan_bench.err
 tail -n 5 $O/r04_asan_bench.err
 TMC2_GUARD=1 timeout -k 10 600 python bench.py --steps 2 --warmup 1 --cpu-baseline 0 > $O/r04_guard_bench.json 2> $O/r04_guard_bench.err; echo "guard rc=$?" | tee -a $O/r04_guard_bench.err
 for c in longdress loot redandblack soldier basketball; do

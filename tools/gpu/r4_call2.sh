@@ -4,7 +4,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 REPO=$(pwd); O=$REPO/gpurun_out
 timeout -k 10 1500 python -m pytest tests -m gpu -q --durations=12 > $O/r04_gpu_tests.log 2>&1; echo "rc=$?" >> $O/r04_gpu_tests.log
 tail -n 22 $O/r04_gpu_tests.log
-timeout -k 10 900 bash tools/asan_host_gcc.sh run python bench.py --steps 3 --warmup 1 --cpu-baseline 0 > $O/r04_asan_bench.json 2> $O/r04_asan_bench.err; echo "asan rc=$?" | tee -a $O/r04_asan_bench.err
+timeout -k 10 900 bash tools/asan_host_gcc.sh run python bench.py --steps 3 --warmup 1 --cpu-baseline 0 --pin 0 > $O/r04_asan_bench.json 2> $O/r04_asan_bench.err; echo "asan rc=$?" | tee -a $O/r04_asan_bench.err
 tail -n 3 $O/r04_asan_bench.err
 cd /tmp
 db() { find "$1" -name "*_results.db" | head -1; }
