@@ -64,6 +64,14 @@ def parse():
                          "worse -- measured 132 against 152 frames/s)")
     ap.add_argument("--pin", type=int, default=1, help="0: plain host buffers instead of page-locked ones for the canvases (for runs "
                     "under a sanitizer runtime, where torch's pinned allocator does not come up; slower copies)")
+    ap.add_argument("--gather", default="host", choices=["host", "rccl"],
+                    help="N > 1, where the finished canvases of a rank's frames go: host = straight into page-locked host memory of "
+                         "the node from the GPU that made them (a shared-memory segment per rank, mapped by rank 0: 8 PCIe links "
+                         "side by side, nothing crosses xGMI but the per-frame patch records, gathered to rank 0 over RCCL); rccl = "
+                         "gathered to rank 0's HBM first and copied out from there (round 3: ~ 550 MB per GOF through one GPU and one link)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: nccl = RCCL, one GPU per rank; gloo = control plane on the CPU and rank r on GPU r mod the visible "
+                         "ones (several ranks share a GPU: for trying the N > 1 path on a one-GPU box)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--packing", default=None, choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition (default: the configuration's): every frame on its own, the spatial-consistency chain, "
@@ -380,8 +388,7 @@ def ingest_leg(T, torch, ctx, cloud):
     n = len(xyz)
     res = {"points": int(n), "what": "PCCPointSet3::read replacement: file (page cache) -> page-locked buffers -> frame in HBM; "
                                      "ms per frame, one frame at a time; threads = parser threads"}
-    hx = torch.empty((n, 3), dtype=torch.int16, pin_memory=True).numpy()
-    hc = torch.empty((n, 3), dtype=torch.uint8, pin_memory=True).numpy()
+    hx, hc = T.host_array((n, 3), np.int16), T.host_array((n, 3), np.uint8)
     with tempfile.TemporaryDirectory() as d:
         for name, ascii_ in (("ascii", True), ("binary", False)):
             path = os.path.join(d, name + ".ply")
@@ -417,10 +424,7 @@ def decoder_leg(a, T, torch, enc, frames, clouds, indices, W, H, reps=3):
     res = float((1 << (c["bits3d"] - 1)) - 1)
 
     def pinned(x):
-        if not a.pin:
-            return np.array(x, copy=True)
-        t = torch.empty(x.nbytes, dtype=torch.uint8, pin_memory=True)
-        out = t.numpy().view(x.dtype).reshape(x.shape)
+        out = T.host_array(x.shape, x.dtype) if a.pin else np.empty(x.shape, x.dtype)
         out[...] = x
         return out
 
@@ -485,6 +489,30 @@ def decoder_leg(a, T, torch, enc, frames, clouds, indices, W, H, reps=3):
     return out
 
 
+RECORD_SLOTS = 1024      # patch records per frame the side-information gather has room for (a CTC frame has 100 - 200)
+
+
+def gather_records(enc, frames, sharder, cache):
+    """The N > 1 tail of a step when every rank lands its own canvases in host memory (--gather host): what is left to
+    gather is the per-frame side information of the bitstream -- the packed patch records (atlas data: ~ 100 bytes a patch) --
+    one RCCL gather per step to rank 0.  Returns rank 0's list of [frames per rank][RECORD_SLOTS] record arrays per rank."""
+    import numpy as np
+    import torch
+    import tmc2_amd as T
+    recs = enc.per_frame(frames, lambda fr, i: fr.get_patches()[0][fr.get_patch_order()])
+    size = recs[0].dtype.itemsize if recs else np.dtype(T.lib.PATCH_DTYPE).itemsize
+    buf = np.zeros((max(1, len(frames)), 8 + RECORD_SLOTS * size), np.uint8)
+    for i, r in enumerate(recs):
+        if len(r) > RECORD_SLOTS:
+            raise RuntimeError("frame with %d patches: more than the side-information gather holds" % len(r))
+        buf[i, :8] = np.frombuffer(np.int64(len(r)).tobytes(), np.uint8)
+        buf[i, 8:8 + len(r) * size] = np.frombuffer(np.ascontiguousarray(r).tobytes(), np.uint8)
+    got = sharder.gather(torch.from_numpy(buf).to(sharder.device))
+    if sharder.rank == 0:
+        cache["records"] = [g.cpu().numpy() for g in got]
+    return cache
+
+
 def gather_canvases(enc, frames, sharder, cache, pin=True):
     """The N > 1 tail of a step: the finished canvases of every frame slot go to rank 0 (one gather per canvas kind and
     slot: every rank holds the same number of frames), which moves what arrives into (page-locked) host memory with
@@ -525,9 +553,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    sharder = T.Sharder(rank, world, dist, "cuda:%d" % local)
+        if a.dist_backend == "gloo":
+            local = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sharder = T.Sharder(rank, world, dist, "cpu" if (world > 1 and a.dist_backend == "gloo") else "cuda:%d" % local)
+    to_host_here = world == 1 or a.gather == "host"     # every rank lands its own frames' canvases in host memory
     # one hardware queue per in-flight frame (GPU_MAX_HW_QUEUES = 16, tmc2_amd/lib.py): streams that share a queue serialise
     # behind each other, and 16 frames in flight keep the chip busy (measured: 12 -> 62, 16 -> 73, 20 -> 68, 24 -> 55, 32 -> 64 frames/s)
     workers = a.workers or max(1, min(len(clouds), 16, (os.cpu_count() or 8) // world))
@@ -549,16 +583,33 @@ def main():
     host_cache, host_lock = {}, threading.Lock()
     gather_cache = {}
 
+    shared = {}                                             # (W, H) -> this rank's shared-memory segment (N > 1)
+
     def host_out(W, H):
         """Host-side destination of the finished canvases (what the video encoder reads), allocated once: page-locked
-        host memory, so that the copies are plain DMA instead of being staged through the runtime's bounce buffers."""
+        host memory, so that the copies are plain DMA instead of being staged through the runtime's bounce buffers.
+        N > 1: a shared-memory segment per rank (page-locked by the rank that writes it, mapped by rank 0 afterwards): one
+        node, one address space -- the process that runs the video encoder reads every rank's canvases where they landed."""
+        per_frame = W * H * (1 + 2 + 2 + 6) + (W // P) * (H // P) + (W // 16) * (H // 16) * 4 + 64
+        seg = [None]
+
         def pinned(shape, dtype):
-            if not a.pin:
-                return np.empty(shape, dtype)
-            t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8, pin_memory=True)
-            return t.numpy().view(dtype).reshape(shape)
+            if seg[0] is not None:                              # carve the next 64-byte aligned piece out of the segment
+                n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                at = seg[1]
+                seg[1] = (at + n + 63) & ~63
+                return seg[0].array[at:at + n].view(dtype).reshape(shape)
+            return T.host_array(shape, dtype) if a.pin else np.empty(shape, dtype)   # (tmc2_host_alloc: page-locked, portable)
         with host_lock:                                         # (called from the worker threads)
           if (W, H) not in host_cache:
+            if world > 1 and a.pin:
+                try:
+                    name = "tmc2_bench_%s_%dx%d_r%d" % (os.environ.get("MASTER_PORT", "0"), W, H, rank)
+                    shared[(W, H)] = T.SharedHostArray(name, (per_frame + 64 * 8) * len(frames), create=True)
+                    seg[:] = [shared[(W, H)], 0]
+                except (OSError, T.Tmc2Error) as e:             # /dev/shm too small or not there: private page-locked memory
+                    shared[(W, H)] = "unavailable (%r): private page-locked buffers per rank" % (e,)
+                    seg[:] = [None]
             host_cache[(W, H)] = [(dict(occupancy=pinned((H, W), np.uint8), occ_video=pinned((H // P, W // P), np.uint8),
                                         block_to_patch=pinned((H // 16, W // 16), np.uint32),
                                         geo0=pinned((H, W), np.uint16), geo1=pinned((H, W), np.uint16)),
@@ -575,9 +626,9 @@ def main():
                 bufs = host_out(size[0], size[1])
                 fr.get_geometry_images(bufs[i][0])
                 fr.get_attribute_images(bufs[i][1])
-            W, H = enc.encode_all_intra(frames, sharder, finish=to_host if world == 1 else None)
+            W, H = enc.encode_all_intra(frames, sharder, finish=to_host if to_host_here else None)
             if world > 1:
-                gather_canvases(enc, frames, sharder, gather_cache)
+                (gather_records if a.gather == "host" else gather_canvases)(enc, frames, sharder, gather_cache)
             return W, H
         # identity video codec between the phases (HM/VTM on the host is outside the metric): phase B runs on the
         # resident canvases.  Finished canvases -> rank 0 -> host memory, where the video encoder reads them.
@@ -585,7 +636,7 @@ def main():
         # copy of its canvases in the same pass (one rendezvous per GOF instead of four: each one waits for its slowest frame).
         def rest(fr, i, W_, H_):
             fr.encoder_generate_attribute_images()
-            if world == 1:
+            if to_host_here:
                 bufs = host_out(W_, H_)
                 fr.get_geometry_images(bufs[i][0])
                 fr.get_attribute_images(bufs[i][1])
@@ -593,11 +644,11 @@ def main():
                            frame_count=a.frames, then=None if a.rendezvous == "four" else rest)
         if a.rendezvous == "four":                              # (the round-2 schedule: a rendezvous after every phase)
             enc.phase_b(frames)
-            if world == 1:
+            if to_host_here:
                 bufs = host_out(W, H)
                 enc.per_frame(frames, lambda fr, i: (fr.get_geometry_images(bufs[i][0]), fr.get_attribute_images(bufs[i][1])))
         if world > 1:
-            gather_canvases(enc, frames, sharder, gather_cache)
+            (gather_records if a.gather == "host" else gather_canvases)(enc, frames, sharder, gather_cache)
         return W, H
 
     def sync():
@@ -614,23 +665,29 @@ def main():
     sync()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
+        t = torch.tensor([dt], dtype=torch.float64, device=sharder.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms, calls = enc.stage_ms(), enc.stage_calls()
     # parity of what was just timed (outside the timing): every frame of every rank against the reference's MD5s
     try:
-        verdict, detail = verify_frames(a, frames, my_indices, W, H, host_out(W, H) if world == 1 else None)
+        verdict, detail = verify_frames(a, frames, my_indices, W, H, host_out(W, H) if to_host_here else None)
     except Exception as e:
         verdict, detail = False, "verification failed to run: %r" % (e,)
     if world > 1:
-        t = torch.tensor([-1 if verdict is None else int(bool(verdict))], dtype=torch.int32, device="cuda:%d" % local)
+        t = torch.tensor([-1 if verdict is None else int(bool(verdict))], dtype=torch.int32, device=sharder.device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if verdict is not None or int(t.item()) >= 0:
             verdict = bool(int(t.item()) > 0) and verdict is not False
+    def drop_shared():
+        for v in shared.values():
+            if hasattr(v, "close"):
+                v.close()
     if rank != 0:
         if world > 1:
+            dist.barrier()                                  # (rank 0 may still be reading this rank's segment)
             dist.destroy_process_group()
+        drop_shared()
         return
     # The timed region runs 32 frames at once: their launches share the chip and queue behind each other, so a kernel's
     # event-bracketed time in the region says how long it was in flight, not how much of the GPU it needs.  The kernel the
@@ -724,6 +781,10 @@ def main():
                              "occupancy + geometry images, dilation, reconstruction, colour transfer, attribute images, "
                              "push-pull padding (identity video codec between the phases); the D1/D2 metric (S23) is "
                              "reported separately (metric_ms_per_frame)",
+                   "canvases": ("each rank -> page-locked shared host memory (%s); patch records -> rank 0 over %s" %
+                                ("; ".join(sorted(set("a /dev/shm segment per rank" if hasattr(v, "close") else str(v) for v in shared.values()))) or "private buffers",
+                                 "RCCL" if a.dist_backend == "nccl" else "gloo")) if (world > 1 and a.gather == "host")
+                               else ("gathered to rank 0 over RCCL, copied out from there" if world > 1 else "page-locked host memory"),
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "host_step_slots_per_gpu": slots, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": round(avg_ms, 4),
@@ -809,7 +870,7 @@ def main():
             tail_ms = enc.stage_ms()
             post = frames[0].get_post_reconstruction(xyz=False, colors16=False, rgb=False)
             W, H = step()                                     # (the one-frame run above left frame 0 on its own canvas)
-            i420 = [torch.empty(2 * (W * H * 3 // 2), dtype=torch.uint8, pin_memory=bool(a.pin)).numpy().reshape(2, -1) for _ in frames]
+            i420 = [(T.host_array if a.pin else np.empty)((2, W * H * 3 // 2), np.uint8) for _ in frames]
             enc.phase_c(frames, i420_out=i420)
             torch.cuda.synchronize()
             t0 = time.time()
@@ -857,7 +918,9 @@ def main():
     print(json.dumps(out))
     sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    drop_shared()
     # Orderly teardown (round 3 left through os._exit after an unexplained heap corruption in a bench process; DESIGN.md section 9
     # has what round 4 found): frames before their contexts, each worker thread ended and joined, contexts closed, then the
     # interpreter's own exit.

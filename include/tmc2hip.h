@@ -87,6 +87,15 @@ int         tmc2_ctx_create( int device, tmc2_ctx** out );
 void        tmc2_ctx_destroy( tmc2_ctx* ctx );
 const char* tmc2_last_error( void );
 int         tmc2_ctx_synchronize( tmc2_ctx* ctx );
+/* Page-locked host memory that every device of the node can DMA into (hipHostMalloc, portable): where a native front end lands
+ * the finished canvases -- what the reference keeps in PCCVideo<T> frames for the video encoder (PCCVideo.h) -- so that the
+ * copies out of HBM are plain DMA from each GPU over its own PCIe link (integration/tmc2_encode_gof.cpp).          */
+int         tmc2_host_alloc( size_t bytes, void** out );
+void        tmc2_host_free( void* p );
+/* ... and the same for memory the caller already has (a shared-memory segment that several processes of the node map: every
+ * rank of a one-process-per-GPU run lands its frames' canvases where the process that runs the video encoder reads them) */
+int         tmc2_host_register( void* p, size_t bytes );
+int         tmc2_host_unregister( void* p );
 /* process-wide limit on concurrently running host-resident steps (k-d tree builds, normal orientation); 0 = none.
  * Frames of a GOF run on separate host threads; this keeps the cache-hungry host steps at the core-complex count
  * while the GPU phases of the other frames proceed.                                                          */

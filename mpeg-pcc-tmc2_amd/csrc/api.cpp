@@ -221,6 +221,37 @@ void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   delete ctx;
 }
 
+int tmc2_host_alloc( size_t bytes, void** out ) {
+  if ( !out || bytes == 0 ) return TMC2_E_INVALID;
+  *out = nullptr;
+  if ( hipHostMalloc( out, bytes, hipHostMallocPortable ) != hipSuccess ) {
+    (void)hipGetLastError();
+    setError( "host_alloc: %zu bytes of page-locked memory refused", bytes );
+    return TMC2_E_HIP;
+  }
+  return TMC2_OK;
+}
+void tmc2_host_free( void* p ) {
+  if ( p ) (void)hipHostFree( p );
+}
+int tmc2_host_register( void* p, size_t bytes ) {
+  if ( !p || bytes == 0 ) return TMC2_E_INVALID;
+  if ( hipHostRegister( p, bytes, hipHostRegisterPortable ) != hipSuccess ) {
+    (void)hipGetLastError();
+    setError( "host_register: %zu bytes at %p could not be page-locked", bytes, p );
+    return TMC2_E_HIP;
+  }
+  return TMC2_OK;
+}
+int tmc2_host_unregister( void* p ) {
+  if ( !p ) return TMC2_E_INVALID;
+  if ( hipHostUnregister( p ) != hipSuccess ) {
+    (void)hipGetLastError();
+    return TMC2_E_HIP;
+  }
+  return TMC2_OK;
+}
+
 void tmc2_set_host_parallelism( int maxConcurrentHostSteps ) { tmc2::setHostParallelism( maxConcurrentHostSteps ); }
 
 int tmc2_ctx_synchronize( tmc2_ctx* ctx ) {

@@ -1035,7 +1035,16 @@ __device__ __forceinline__ uint32_t closureHop( const Closure& c, uint32_t x, ui
     at = __shfl( at, __ffs( int( mFresh ) ) - 1, 32 );
     if ( fresh ) {
       if ( at != kNoVoxel ) {
-        c.ring[( at + __popc( mFresh & below ) ) % c.ringCap] = v;
+        // The reservation test counts the slots handed back, not WHICH ones: once the ring has wrapped, a slot this
+        // reservation covers may belong to a taker that has claimed it ( its position < head ) and not yet read it.  The giver
+        // waits for that taker's sentinel.  Nobody it waits for can be waiting for it: the taker reads and clears in one stretch
+        // ( closureTake ), waiting at most for the EARLIER giver of its position -- a chain that runs backwards through the
+        // positions and ends in the first lap -- and a sibling half-wave is never inside a take while this half is inside a
+        // hop.  ( Round 3 relied on the ring never getting within the group's k of full; a SOLID cloud, where one seed's
+        // activations cascade through a single workgroup, wraps it: tests/test_gpu_segmenter.py, solid cloud. )
+        volatile uint32_t* slot = &c.ring[( at + __popc( mFresh & below ) ) % c.ringCap];
+        while ( *slot != kNoVoxel ) __builtin_amdgcn_s_sleep( 1 );
+        *slot = v;
       } else {
         const uint32_t idx = atomicAdd( &c.ctl[32], 1u );
         __hip_atomic_store( &c.spill[idx % c.spillCap], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );

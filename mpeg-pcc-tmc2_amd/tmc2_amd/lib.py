@@ -545,6 +545,62 @@ class Frame:
         _check(self.L.tmc2_frame_set_decoded_geometry(self.h, None if ov is None else _ptr(ov), None if g is None else _ptr(g)))
 
 
+class _Pinned:
+    """tmc2_host_alloc / tmc2_host_free: page-locked host memory every device of the node can DMA into."""
+
+    def __init__(self, nbytes):
+        self.L, self.p, self.nbytes = load_library(), C.c_void_p(), int(nbytes)
+        _check(self.L.tmc2_host_alloc(C.c_size_t(self.nbytes), C.byref(self.p)))
+        self.__array_interface__ = dict(shape=(self.nbytes,), typestr="|u1", data=(self.p.value, False), version=3)
+
+    def __del__(self):
+        try:
+            if self.p:
+                self.L.tmc2_host_free(self.p)
+                self.p = C.c_void_p()
+        except Exception:
+            pass
+
+
+class SharedHostArray:
+    """A named shared-memory segment (/dev/shm) mapped by several processes of the node, page-locked in the process that writes
+    it from a GPU (tmc2_host_register).  create=True makes (and on close removes) the segment; every opener gets a numpy view."""
+
+    def __init__(self, name, nbytes, create, register=True):
+        import mmap
+        self.path, self.nbytes, self.created, self.registered = os.path.join("/dev/shm", name), int(nbytes), bool(create), False
+        fd = os.open(self.path, (os.O_CREAT | os.O_RDWR) if create else os.O_RDWR, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, self.nbytes)
+            self.map = mmap.mmap(fd, self.nbytes)
+        finally:
+            os.close(fd)
+        self.array = np.frombuffer(self.map, dtype=np.uint8)
+        if register:
+            _check(load_library().tmc2_host_register(_ptr(self.array), C.c_size_t(self.nbytes)))
+            self.registered = True
+
+    def close(self):
+        if self.registered:
+            load_library().tmc2_host_unregister(_ptr(self.array))
+            self.registered = False
+        if self.created:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            self.created = False
+
+
+def host_array(shape, dtype=np.uint8):
+    """A numpy array in page-locked host memory (the array keeps the allocation alive): destination of the canvas getters,
+    so that the copies out of HBM are plain DMA."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    return np.asarray(_Pinned(max(n, 1)))[:n].view(dtype).reshape(shape)
+
+
 def encoder_canvas_size(heights, tile_width=1280, min_w=1280, min_h=1280):
     """resizeTileGeometryVideo + resizeGeometryVideo: common canvas of a GOF."""
     L = load_library()

@@ -62,3 +62,31 @@ def test_gpu_ply_file_to_frame_to_ply_file(gpu_ctx, tmp_path, ascii_):
     assert np.array_equal(bx, rx) and np.array_equal(bc, rc)
     for reorder in (False, True):
         assert T.point_set_checksum(rx, rc, reorder) == port_io.checksum(rx, rc, reorder)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("condition", ["ai", "ld", "ra"])
+def test_gpu_native_front_end_sharded_over_device_shards(tmp_path, condition):
+    """integration/tmc2_encode_gof.cpp --devices: the GOF's frames sharded over several device shards from ONE native process
+    (frame f on shard f mod D; here the same GPU twice and three times, so that the sharded path -- contexts per shard, the
+    packing chain over frames that live on different shards, canvases into page-locked host memory -- runs on a one-GPU box)
+    must write the same bytes as the single-shard run: occupancy / geometry / attribute videos, reconstructed clouds,
+    checksums."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "integration")], check=True, capture_output=True)
+    exe = os.path.join(root, "integration", "tmc2_encode_gof")
+    frames = 5
+    for f in range(frames):
+        xyz, rgb = synth_cloud("tiny", f)
+        T.ply_write(str(tmp_path / ("fr_%04d.ply" % f)), xyz, rgb)
+    outs = {}
+    for tag, devices, workers in (("one", "0", "2"), ("two", "0,0", "2"), ("three", "0-0,0,0", "1")):
+        r = subprocess.run([exe, "--in", str(tmp_path / "fr_%04d.ply"), "--frames", str(frames), "--out", str(tmp_path / tag),
+                            "--condition", condition, "--devices", devices, "--workers", workers, "--min-width", "256",
+                            "--min-height", "256", "--repeat", "2"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert '"frames_per_s"' in r.stdout and ("%d device shard(s)" % len(devices.replace("-0", "").split(","))) in r.stdout, r.stdout
+        outs[tag] = {p.name[len(tag):]: p.read_bytes() for p in tmp_path.glob(tag + "*")}
+        assert len(outs[tag]) == 5 + frames, sorted(outs[tag])
+    assert outs["one"] == outs["two"] == outs["three"]

@@ -253,3 +253,86 @@ def test_bench_host_slot_budget_per_rank():
     assert bench.host_slots(16, 8, 4) == 4          # 16 // 8 = 2 would serialise four frames behind two slots
     assert bench.host_slots(16, 8, 1) == 2
     assert bench.host_slots(0, 8, 4) == 4
+
+
+class _FakeRecordFrame:
+    """What bench.gather_records needs of a frame: its packed patch list."""
+
+    def __init__(self, gof_index):
+        from tmc2_amd.lib import PATCH_DTYPE
+        self.gof_index = gof_index
+        self.records = np.zeros(3 + gof_index % 5, PATCH_DTYPE)
+        self.records["u0"] = gof_index
+        self.records["v0"] = np.arange(len(self.records))
+
+    def get_patches(self):
+        return (self.records, None, None, None)
+
+    def get_patch_order(self):
+        return np.arange(len(self.records))
+
+
+class _FakeRecordEncoder:
+    def per_frame(self, frames, fn):
+        return [fn(fr, i) for i, fr in enumerate(frames)]
+
+
+def _bench_records_worker(rank, world, port, frame_count, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bench = _load_bench()
+    sh = Sharder(rank, world, dist, "cpu")
+    frames = [_FakeRecordFrame(f) for f in sh.frames_of(frame_count)]
+    # every rank lands its "canvases" in its own shared host segment (no GPU here: not page-locked), rank 0 maps them all
+    from tmc2_amd.lib import SharedHostArray
+    seg = SharedHostArray("tmc2_test_%d_r%d" % (port, rank), 64 * len(frames), create=True, register=False)
+    for i, fr in enumerate(frames):
+        seg.array[64 * i:64 * (i + 1)] = fr.gof_index
+    cache = {}
+    for _ in range(2):
+        bench.gather_records(_FakeRecordEncoder(), frames, sh, cache)
+    sh.barrier()
+    if rank == 0:
+        seen = []
+        for r in range(world):
+            other = SharedHostArray("tmc2_test_%d_r%d" % (port, r), 64 * len(frames), create=False, register=False)
+            seen.append(other.array.reshape(len(frames), 64)[:, 0].copy())
+            other.close()
+        q.put(([x.copy() for x in cache["records"]], seen))
+    sh.barrier()
+    seg.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_records_gather_and_shared_host_canvases_world_2_and_8_gloo(world):
+    """bench.py --gather host (the default for N > 1): every rank copies its frames' canvases into its own shared host segment
+    (tmc2_amd.lib.SharedHostArray; page-locked on a GPU box) that rank 0 maps, and the only collective of the tail is ONE gather
+    of the per-frame patch records (bench.gather_records).  32 frames over 2 and 8 ranks: rank 0 sees every frame's records in
+    the slot its (rank, index) names, and every rank's segment."""
+    from tmc2_amd.lib import PATCH_DTYPE
+    frames = 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_records_worker, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    records, seen = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bench = _load_bench()
+    size = PATCH_DTYPE.itemsize
+    for r in range(world):
+        assert seen[r].tolist() == [r + slot * world for slot in range(frames // world)]
+        for slot in range(frames // world):
+            f = r + slot * world
+            row = records[r][slot]
+            count = int(np.frombuffer(row[:8].tobytes(), np.int64)[0])
+            assert count == 3 + f % 5
+            recs = np.frombuffer(row[8:8 + count * size].tobytes(), PATCH_DTYPE)
+            assert (recs["u0"] == f).all() and recs["v0"].tolist() == list(range(count))
+    assert not [n for n in os.listdir("/dev/shm") if n.startswith("tmc2_test_%d_" % port)]
+    assert bench.RECORD_SLOTS >= 512
