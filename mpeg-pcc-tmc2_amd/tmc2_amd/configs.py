@@ -62,8 +62,8 @@ FULL_SIZE_CASES = {
 # what `bench.py --config <short name>` runs (the fixture case whose digests the timed step is checked against)
 BENCH_CONFIGS = {
     "longdress": "longdress_vox10_ai_r3_gof32",
-    "loot": "loot_vox10_ai_r3_gof8",
-    "redandblack": "redandblack_vox10_ai_r3_gof8",
+    "loot": "loot_vox10_ai_r3_gof32",
+    "redandblack": "redandblack_vox10_ai_r3_gof32",
     "soldier": "soldier_vox10_ai_r3_gof8",
     "basketball": "basketball_player_vox11_ra_r5_gof8",
 }
