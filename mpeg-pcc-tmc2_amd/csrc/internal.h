@@ -225,7 +225,7 @@ struct tmc2_ctx {
   tmc2::PinnedBuf               hostA, hostB, hostC, hostD, hostE;  // staging for the host-side steps
   std::vector<int32_t>          orientScratch;                      // per-vertex state of the orientation walk
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
-  tmc2::DevBuf<uint32_t>        gridBits;        // its occupancy, one bit per key (kept all-zero between uses): S5 probes ball rows in it
+  tmc2::DevBuf<uint2>           gridBits;        // its occupancy, .x: one bit per key (kept all-zero between uses: S5 probes ball rows in it), .y: occupied keys below the word
   int                           refineCapTier = 0;  // the smallest neighbourhood-kernel instantiation that held this context's last frames
   tmc2::DevBuf<unsigned long long> scanState;    // look-back state of exclusiveScanU32: [0] tile tickets, [1 + t] tile t (epoch-tagged)
   uint32_t                      scanEpoch = 0, scanTickets = 0;

@@ -44,34 +44,108 @@ __device__ __forceinline__ uint32_t cellKey( int x0, int y0, int z0, int s ) {
 //  time; look before the atomic: a voxel's points set the same bit)
 __global__ __launch_bounds__( 256 ) void voxelKeyKernel( const Pt* __restrict__ pts, uint32_t n, Grid g,
                                                           uint32_t* __restrict__ key, uint32_t* __restrict__ table,
-                                                          uint32_t* __restrict__ bits ) {
+                                                          uint2* __restrict__ bits /* .x: 32 keys' occupancy, .y: see below */ ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
   const Pt       p = pts[i];
   const uint32_t k = cellKey( ( int( p.x ) + g.half ) >> g.voxShift, ( int( p.y ) + g.half ) >> g.voxShift,
                               ( int( p.z ) + g.half ) >> g.voxShift, g.gridShift );
   key[i]           = k;
-  atomicMin( &table[k], i );
+  if ( table ) atomicMin( &table[k], i );  // (the cell-by-cell form only: the row-wise form numbers the voxels through the ranks)
   const uint32_t bit = 1u << ( k & 31 );
-  if ( !( loadStaleOk( &bits[k >> 5] ) & bit ) ) atomicOr( &bits[k >> 5], bit );
+  if ( !( loadStaleOk( &bits[k >> 5].x ) & bit ) ) atomicOr( &bits[k >> 5].x, bit );
+}
+
+// The occupancy words carry the number of occupied keys BELOW them (bits[w].y = exclusive prefix sum of the popcounts): the rank
+// of a key among the occupied keys is then one 8-byte load and a popcount, and voxelOfRank[rank] is the voxel that owns the key
+// -- a look-up chain through a few dense megabytes that neighbouring voxels share (L2), instead of one random 4-byte read of the
+// gigabyte-sized key table per occupied cell (what bounded the neighbourhood pass of voxels of 2: 236 M reads, 64 bytes of HBM
+// each).  Three launches per frame over the words: totals of 2 048-word blocks, their prefix sum, the words' prefix sums.
+constexpr int kBitsPerThread = 8, kBitsBlock = 256 * kBitsPerThread;
+__global__ __launch_bounds__( 256 ) void bitsBlockCountKernel( const uint2* __restrict__ bits, uint32_t words, uint32_t* __restrict__ blockTotal ) {
+  const uint32_t base = blockIdx.x * kBitsBlock + threadIdx.x * kBitsPerThread;
+  uint32_t       sum  = 0;
+#pragma unroll
+  for ( int j = 0; j < kBitsPerThread; ++j )
+    if ( base + j < words ) sum += __popc( bits[base + j].x );
+  __shared__ uint32_t waveSum[4];
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) sum += __shfl_xor( sum, off, 64 );
+  if ( ( threadIdx.x & 63 ) == 0 ) waveSum[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if ( threadIdx.x == 0 ) blockTotal[blockIdx.x] = waveSum[0] + waveSum[1] + waveSum[2] + waveSum[3];
+}
+__global__ __launch_bounds__( 256 ) void bitsPrefixKernel( uint2* __restrict__ bits, uint32_t words, const uint32_t* __restrict__ blockBase ) {
+  const uint32_t base = blockIdx.x * kBitsBlock + threadIdx.x * kBitsPerThread;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t       cnt[kBitsPerThread], sum = 0;
+#pragma unroll
+  for ( int j = 0; j < kBitsPerThread; ++j ) {
+    cnt[j] = base + j < words ? uint32_t( __popc( bits[base + j].x ) ) : 0u;
+    sum += cnt[j];
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for ( int off = 1; off < 64; off <<= 1 ) {
+    const uint32_t t = __shfl_up( inc, off, 64 );
+    if ( lane >= off ) inc += t;
+  }
+  __shared__ uint32_t waveSum[4];
+  if ( lane == 63 ) waveSum[wave] = inc;
+  __syncthreads();
+  uint32_t at = blockBase[blockIdx.x] + inc - sum;
+  for ( int w = 0; w < wave; ++w ) at += waveSum[w];
+#pragma unroll
+  for ( int j = 0; j < kBitsPerThread; ++j ) {
+    if ( base + j < words ) bits[base + j].y = at;
+    at += cnt[j];
+  }
+}
+__device__ __forceinline__ uint32_t rankOfKey( const uint2* __restrict__ bits, uint32_t k ) {
+  const uint2 e = bits[k >> 5];
+  return e.y + uint32_t( __popc( e.x & ( ( 1u << ( k & 31 ) ) - 1u ) ) );
+}
+// voxelOfRank[rank of the voxel's key] = voxel id (written by the voxel's first point)
+__global__ __launch_bounds__( 256 ) void rankToVoxelKernel( const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag,
+                                                             const uint32_t* __restrict__ vid, uint32_t n,
+                                                             const uint2* __restrict__ bits, uint32_t* __restrict__ voxelOfRank ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i < n && flag[i] ) voxelOfRank[rankOfKey( bits, key[i] )] = vid[i];
+}
+
+// The first point of every voxel WITHOUT the dense key table (row-wise form: rounds 1-3 kept 2^(3s+1) words per context for this,
+// 1 GiB with voxels of 2 or 11-bit geometry): firstPoint[rank of the point's key] takes the minimum over the voxel's points.
+__global__ __launch_bounds__( 256 ) void firstPointKernel( const uint32_t* __restrict__ key, uint32_t n, const uint2* __restrict__ bits,
+                                                            uint32_t* __restrict__ firstPoint ) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n ) return;
+  uint32_t* slot = &firstPoint[rankOfKey( bits, key[i] )];
+  if ( i < loadStaleOk( slot ) ) atomicMin( slot, i );
+}
+// the first point of the voxel point i belongs to: through the key table, or through the ranks
+__device__ __forceinline__ uint32_t firstPointOf( uint32_t k, const uint32_t* __restrict__ table, const uint2* __restrict__ bits,
+                                                  const uint32_t* __restrict__ firstPoint ) {
+  return table ? table[k] : firstPoint[rankOfKey( bits, k )];
 }
 
 __global__ __launch_bounds__( 256 ) void firstFlagKernel( const uint32_t* __restrict__ key,
-                                                           const uint32_t* __restrict__ table, uint32_t n,
+                                                           const uint32_t* __restrict__ table, const uint2* __restrict__ bits,
+                                                           const uint32_t* __restrict__ firstPoint, uint32_t n,
                                                            uint32_t* __restrict__ flag ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i < n ) flag[i] = ( table[key[i]] == i ) ? 1u : 0u;
+  if ( i < n ) flag[i] = ( firstPointOf( key[i], table, bits, firstPoint ) == i ) ? 1u : 0u;
 }
 
 // vid[i] = rank of the voxel's first point; member counts; centre of each voxel
 __global__ __launch_bounds__( 256 ) void assignVoxelKernel( const Pt* __restrict__ pts, const uint32_t* __restrict__ key,
-                                                             const uint32_t* __restrict__ table,
+                                                             const uint32_t* __restrict__ table, const uint2* __restrict__ bits,
+                                                             const uint32_t* __restrict__ firstPoint,
                                                              const uint32_t* __restrict__ rank, uint32_t n, Grid g,
                                                              uint32_t* __restrict__ vid, uint32_t* __restrict__ count,
                                                              Pt* __restrict__ centre ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  const uint32_t first = table[key[i]];
+  const uint32_t first = firstPointOf( key[i], table, bits, firstPoint );
   const uint32_t v     = rank[first];
   vid[i]               = v;
   atomicAdd( &count[v], 1u );
@@ -92,11 +166,11 @@ __global__ __launch_bounds__( 256 ) void tableToVoxelKernel( const uint32_t* __r
 }
 
 __global__ __launch_bounds__( 256 ) void tableCleanKernel( const uint32_t* __restrict__ key, uint32_t n,
-                                                            uint32_t* __restrict__ table, uint32_t* __restrict__ bits ) {
+                                                            uint32_t* __restrict__ table, uint2* __restrict__ bits ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i >= n ) return;
-  table[key[i]]    = 0xFFFFFFFFu;
-  bits[key[i] >> 5] = 0u;  // (whole words: every key of the word belongs to this frame)
+  if ( table ) table[key[i]] = 0xFFFFFFFFu;
+  bits[key[i] >> 5].x = 0u;  // (whole words: every key of the word belongs to this frame; the prefix sums are rebuilt per frame)
 }
 
 // ---- histograms -----------------------------------------------------------------------------------
@@ -159,8 +233,8 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
 // phase 1: the occupied cells of the ball as packed offsets ( dx + 16 ) | ( dy + 16 ) << 5 | ( dz + 16 ) << 10 | d2 << 15
 // phase 2: id + centre of each, in place (a chunk of candidates is read whole before anything lands at or below it)
 template <int CAP>
-__device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ centre, const uint32_t* __restrict__ table,
-                                            const uint32_t* __restrict__ bits, const Grid g, const int* __restrict__ rows, int nRows,
+__device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ centre, const uint32_t* __restrict__ voxelOfRank,
+                                            const uint2* __restrict__ bits, const Grid g, const int* __restrict__ rows, int nRows,
                                             int idBits, uint32_t* keys, int lane, uint32_t* __restrict__ overflow ) {
   const int gridMax = 1 << g.gridShift;  // cell coordinates run 0 .. gridMax inclusive
   int       cand    = 0;
@@ -180,8 +254,8 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
         const int xlo = max( 0, int( c.x ) - xr ), xhi = min( gridMax, int( c.x ) + xr );
         if ( y >= 0 && z >= 0 && y <= gridMax && z <= gridMax && xlo <= xhi ) {
           const uint32_t key0 = cellKey( xlo, y, z, g.gridShift );
-          lo[k]  = bits[key0 >> 5];
-          hi[k]  = bits[( key0 >> 5 ) + 1];  // (the bitmap carries a spare word behind its last key)
+          lo[k]  = bits[key0 >> 5].x;
+          hi[k]  = bits[( key0 >> 5 ) + 1].x;  // (the bitmap carries a spare word behind its last key)
           sh[k]  = int( key0 & 31 );
           len[k] = xhi - xlo + 1;
           x0[k]  = xlo - int( c.x );
@@ -228,11 +302,14 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
       if ( i < cand ) {
         const uint32_t packed = keys[i];
         const int x = c.x + int( packed & 31u ) - 16, y = c.y + int( ( packed >> 5 ) & 31u ) - 16, z = c.z + int( ( packed >> 10 ) & 31u ) - 16;
-        u[k]    = table[cellKey( x, y, z, g.gridShift )];
+        u[k]    = rankOfKey( bits, cellKey( x, y, z, g.gridShift ) );  // (the words phase 1 has just read: L1 / L2)
         d2[k]   = packed >> 15;
         cell[k] = uint32_t( x ) | ( uint32_t( y ) << 10 ) | ( uint32_t( z ) << 20 );  // (cell coordinates are at most 512)
       }
     }
+#pragma unroll
+    for ( int k = 0; k < kBatch; ++k )
+      if ( u[k] != 0xFFFFFFFFu ) u[k] = voxelOfRank[u[k]];
     uint32_t key[kBatch];
 #pragma unroll
     for ( int k = 0; k < kBatch; ++k ) {
@@ -269,7 +346,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
     const int* __restrict__ offsets, int nOffsets, int maxNN, double lambda, int idBits, int devRange, uint32_t devStride,
     uint32_t rowCapacity, uint32_t* __restrict__ rowLen, uint32_t* __restrict__ devLen, double* __restrict__ weight,
     uint32_t* __restrict__ adjOff, uint32_t* __restrict__ adj, uint32_t* __restrict__ dev, uint32_t* __restrict__ rowCursor,
-    uint32_t* __restrict__ overflow, const uint32_t* __restrict__ bits /* non-null: offsets = the ball's ROWS (collectBall) */,
+    uint32_t* __restrict__ overflow, const uint2* __restrict__ bits /* non-null: offsets = the ball's ROWS (collectBall) */,
+    const uint32_t* __restrict__ voxelOfRank /* voxel of the rank-th occupied key */,
     uint32_t* __restrict__ lastKey /* the last key each row keeps: what the gathered reverse rows test against */ ) {
   __shared__ uint32_t keysAll[WAVES][CAP];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,7 +367,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // all centre look-ups of its hits (two dependent round trips per batch instead of two per 64 cells: the kernel is bound by
   // exactly this latency).  The order of the hits does not matter: they are sorted below.
   constexpr int kBatch = 8;
-  if ( bits ) hits = collectBall<CAP>( c, centre, table, bits, g, offsets, nOffsets, idBits, keys, lane, overflow );
+  if ( bits ) hits = collectBall<CAP>( c, centre, voxelOfRank, bits, g, offsets, nOffsets, idBits, keys, lane, overflow );
   for ( int base = 0; !bits && base < nOffsets; base += 64 * kBatch ) {
     uint32_t u[kBatch], d2[kBatch], cell[kBatch];
 #pragma unroll
@@ -474,8 +552,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
 // key( u seen from v ) <= lastKey[v], write them back to back (one reservation per workgroup).  The order inside a reverse
 // row is immaterial (the sweeps push integer differences over it).
 template <int CAP, int WAVES>
-__global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint32_t* __restrict__ table,
-                                                                     const uint32_t* __restrict__ bits, Grid g, uint32_t V,
+__global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint32_t* __restrict__ voxelOfRank,
+                                                                     const uint2* __restrict__ bits, Grid g, uint32_t V,
                                                                      const int* __restrict__ rows, int nRows, int idBits,
                                                                      const uint32_t* __restrict__ lastKey, uint32_t rowCapacity,
                                                                      uint32_t* __restrict__ rOff, uint32_t* __restrict__ rLen,
@@ -488,7 +566,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __r
   int                 kept = 0;
   if ( u < V ) {
     const uint32_t idMask = ( 1u << idBits ) - 1u;
-    const int      hits   = collectBall<CAP>( centre[u], centre, table, bits, g, rows, nRows, idBits, keys, lane, overflow );
+    const int      hits   = collectBall<CAP>( centre[u], centre, voxelOfRank, bits, g, rows, nRows, idBits, keys, lane, overflow );
     for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
       const int      i   = base + lane;
       const uint32_t key = i < hits ? keys[i] : 0u;
@@ -1271,14 +1349,15 @@ struct RefineJob {
   Grid             g{};
   std::vector<int> offsets;  // the ball: its ROWS (byRows) or its cells
   uint32_t*        table = nullptr;
-  uint32_t*        bits  = nullptr;  // occupancy bitmap of the key table (kept all-zero between frames)
+  uint2*           bits  = nullptr;  // occupancy bitmap of the key table (.x; kept all-zero between frames) + ranks (.y)
   bool             tableFilled = false, eventDriven = false, byRows = true;
   int              capTier = 2;  // which instantiation of the neighbourhood kernels (launchNeighbourhood)
   size_t           Vp = 0, W2 = 0, ball = 0, perVoxel = 0;
   uint64_t         capacity = 0;
   uint32_t         res[2] = {0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag
   DevBuf<uint32_t> d_key, d_flag, d_vid, d_small, d_count, d_rowLen, d_devLen, d_adjOff, d_hist, d_activeBuf, d_pointStart,
-      d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev, d_lastKey, d_roffG, d_rlenG, d_radjG;
+      d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev, d_lastKey, d_roffG, d_rlenG, d_radjG,
+      d_voxelOfRank;
   DevBuf<Pt>      d_centre;
   DevBuf<double>  d_weight;
   DevBuf<uint8_t> d_state;  // edge | ppi | arg | marked | proc, V bytes each
@@ -1294,7 +1373,7 @@ struct RefineJob {
 };
 
 RefineJob::~RefineJob() {
-  if ( tableFilled && table && d_key.p ) {  // dropped between the halves: hand the context's table back empty
+  if ( tableFilled && bits && d_key.p ) {  // dropped between the halves: hand the context's bitmap (and table) back empty
     ApiScope scope( ctx );
     hipLaunchKernelGGL( tableCleanKernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, s, d_key.p, n, table, bits );
     (void)hipStreamSynchronize( s );  // (the buffers go back to the pool when the members are destroyed)
@@ -1309,9 +1388,10 @@ void RefineJob::launchNeighbourhood() {
   hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
                       d_count.p, table, g, V, d_offsets.p, nBall, maxNNCount, lambda, idBits, devRange, devStride,             \
                       uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
-                      d_small.p + 2, byRows ? bits : (const uint32_t*)nullptr, byRows ? d_lastKey.p : (uint32_t*)nullptr );     \
+                      d_small.p + 2, byRows ? bits : (const uint2*)nullptr, d_voxelOfRank.p,                                  \
+                      byRows ? d_lastKey.p : (uint32_t*)nullptr );                                                              \
   if ( byRows )                                                                                                                \
-  hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, table, \
+  hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, d_voxelOfRank.p, \
                       bits, g, V, d_offsets.p, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
                       d_small.p + 3, d_small.p + 2 )
   // LDS per wavefront = room for the ball's OCCUPIED cells (row-wise form; a surface fills 5-10 % of a ball) or for all its
@@ -1380,16 +1460,19 @@ int RefineJob::geometry( tmc2_frame* f ) {
   devStride = devRange == 1 ? 32u : 128u;
   idBits    = r2 <= 64 ? 26 : 25;   // neighbourhood sort key: d2 above, voxel id below
   const int sidSetup = ctx->stageBegin( "refine_setup" );
-  if ( ctx->gridTable.count < g.tableSize ) {
-    TMC2_TRY( ctx->gridTable.alloc( g.tableSize ) );
-    TMC2_HIP( hipMemsetAsync( ctx->gridTable.p, 0xFF, size_t( g.tableSize ) * 4, s ) );
+  table = nullptr;
+  if ( !byRows ) {  // the dense key table (2^(3s+1) words: 1 GiB with voxels of 2 or 11-bit geometry) only for the cell-by-cell form
+    if ( ctx->gridTable.count < g.tableSize ) {
+      TMC2_TRY( ctx->gridTable.alloc( g.tableSize ) );
+      TMC2_HIP( hipMemsetAsync( ctx->gridTable.p, 0xFF, size_t( g.tableSize ) * 4, s ) );
+    }
+    table = ctx->gridTable.p;
   }
-  table = ctx->gridTable.p;
   {
     const size_t bitWords = size_t( g.tableSize ) / 32 + 2;  // (+ spare words: a row's second word may lie behind the last key)
     if ( ctx->gridBits.count < bitWords ) {
       TMC2_TRY( ctx->gridBits.alloc( bitWords ) );
-      TMC2_HIP( hipMemsetAsync( ctx->gridBits.p, 0, bitWords * 4, s ) );
+      TMC2_HIP( hipMemsetAsync( ctx->gridBits.p, 0, bitWords * sizeof( uint2 ), s ) );
     }
     bits = ctx->gridBits.p;
   }
@@ -1400,7 +1483,23 @@ int RefineJob::geometry( tmc2_frame* f ) {
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
   tableFilled = true;
   hipLaunchKernelGGL( voxelKeyKernel, grdN, blk, 0, s, f->d_pts.p, n, g, d_key.p, table, bits );
-  hipLaunchKernelGGL( firstFlagKernel, grdN, blk, 0, s, d_key.p, table, n, d_flag.p );
+  DevBuf<uint32_t> d_firstPoint;
+  if ( byRows ) {
+    // ranks of the occupied keys (the words' prefix sums), then the first point of every rank: the voxels are numbered through
+    // them -- and the row-wise neighbourhood passes look voxels up by them
+    const uint32_t   words  = g.tableSize / 32 + 2;
+    const uint32_t   blocks = ( words + kBitsBlock - 1 ) / kBitsBlock;
+    DevBuf<uint32_t> d_blockTotal, d_blockBase;
+    TMC2_TRY( d_blockTotal.alloc( blocks ) );
+    TMC2_TRY( d_blockBase.alloc( blocks ) );
+    TMC2_TRY( d_firstPoint.alloc( n ) );  // (one per occupied key: at most one per point)
+    TMC2_HIP( hipMemsetAsync( d_firstPoint.p, 0xFF, size_t( n ) * 4, s ) );
+    hipLaunchKernelGGL( bitsBlockCountKernel, dim3( blocks ), blk, 0, s, bits, words, d_blockTotal.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_blockTotal.p, d_blockBase.p, blocks, nullptr ) );
+    hipLaunchKernelGGL( bitsPrefixKernel, dim3( blocks ), blk, 0, s, bits, words, d_blockBase.p );
+    hipLaunchKernelGGL( firstPointKernel, grdN, blk, 0, s, d_key.p, n, bits, d_firstPoint.p );
+  }
+  hipLaunchKernelGGL( firstFlagKernel, grdN, blk, 0, s, d_key.p, table, bits, d_firstPoint.p, n, d_flag.p );
   DevBuf<uint32_t> d_rank;
   TMC2_TRY( d_rank.alloc( n ) );
   TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p ) );
@@ -1449,9 +1548,14 @@ int RefineJob::geometry( tmc2_frame* f ) {
                                {d_gbits.p, eventDriven ? closureZeroWords * 4 : 0, 0},
                                {d_gbits.p + closureZeroWords, eventDriven ? size_t( V ) * 4 : 0, 0xFF}} ) );  // kNoVoxel
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
-  hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, d_rank.p, n, g, d_vid.p,
+  hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, bits, d_firstPoint.p, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
-  hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
+  if ( byRows ) {
+    TMC2_TRY( d_voxelOfRank.alloc( V ) );
+    hipLaunchKernelGGL( rankToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, bits, d_voxelOfRank.p );
+  } else {
+    hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
+  }
   // points grouped by voxel, for the re-scoring pass
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_pointStart.p, size_t( V ) + 1, nullptr ) );
   hipLaunchKernelGGL( voxelPointListKernel, grdN, blk, 0, s, d_vid.p, d_pointStart.p, n, d_cursor.p, d_pointList.p );
@@ -1503,6 +1607,7 @@ int RefineJob::finish() {
     TMC2_HIP( hipStreamSynchronize( s ) );  // (usually long done: the orientation walk ran in between)
     TMC2_HIP( hipGetLastError() );
     totalLen = res[0];
+    if ( getenv( "TMC2_REFINE_DEBUG" ) ) fprintf( stderr, "refine: neighbourhood attempt %d tier %d: %u row entries, overflow word %u (V = %u)\n", attempt, capTier, res[0], res[1], V );
     if ( res[1] == 0 ) break;
     if ( ( res[1] != 1 && res[1] != 3 ) || attempt > 3 || ( res[1] == 3 && capTier >= 2 ) ) {
       setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
@@ -1591,9 +1696,17 @@ int RefineJob::finish() {
       hipLaunchKernelGGL( closureKernel, grdClosure, dim3( closureThreads ), closureLds, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p,
                           devStride, V, run, state[cur], state[nxt], uint32_t( W2 ), d_lists.p, V, counts[cur], counts[nxt], spill,
                           ctl, ringCap, wantTiming ? d_timing.p + 8 * size_t( iter ) : nullptr );
+      if ( getenv( "TMC2_REFINE_DEBUG" ) ) {
+        const hipError_t e = hipStreamSynchronize( s );
+        fprintf( stderr, "refine: sweep %d closure done (%d), %u workgroups of %d, run %u, ring %u\n", iter, int( e ), grdClosure.x, closureThreads, run, ringCap );
+      }
       hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
                           d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, revOff, revLen, revAdj, d_edge,
                           d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
+      if ( getenv( "TMC2_REFINE_DEBUG" ) ) {
+        const hipError_t e = hipStreamSynchronize( s );
+        fprintf( stderr, "refine: sweep %d sweep done (%d)\n", iter, int( e ) );
+      }
     }
     ctx->stageEnd( sidSweep );
     TMC2_HIP( hipGetLastError() );

@@ -12,7 +12,7 @@ OUT=$ROOT/asan_build
 RT=$(gcc -print-file-name=libasan.so)
 if [ "$1" = "run" ]; then
   shift
-  export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0
+  export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0:use_sigaltstack=0
   cd "$ROOT"
   LD_PRELOAD="$RT $(gcc -print-file-name=libstdc++.so)" TMC2_PACKAGE_DIR="$OUT/pkg" "$@"   # (libstdc++ up front: the runtime resolves __cxa_throw when it starts)
   exit $?
