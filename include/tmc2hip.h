@@ -121,6 +121,11 @@ int  tmc2_kdtree_build( tmc2_frame* f );
  * (tmc2_set_host_parallelism) is free at that moment, else on the device.  Both builders are exact; the choice
  * never changes a result.                                                                                   */
 void tmc2_set_kdtree_placement( int mode );
+/* process-wide: tmc2_segmenter_compute queues the geometry of the refinement (S5: voxels, neighbourhood rows -- it needs the
+ * points only) before the host-resident walk of the normal orientation (S3) and builds it while the host walks.  Shortens a
+ * frame's chain (few frames in flight: one rank of a many-GPU run); with the chip full of other frames it only competes with
+ * them -- off by default.  Never changes a result.                                                               */
+void tmc2_set_refine_overlap( int on );
 /* inspection: the permutation nanoflann's build leaves in vind (tree order -> point index), uint32[n], and the
  * number of tree levels; the search order under distance ties is a function of exactly this permutation */
 int  tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth );

@@ -176,6 +176,7 @@ int main( int argc, char** argv ) {
   std::vector<tmc2_ctx*> ctx( size_t( slots ), nullptr );
   for ( int s = 0; s < slots; ++s ) CHECK( tmc2_ctx_create( o.devices[size_t( s / workers )], &ctx[size_t( s )] ) );
   tmc2_set_host_parallelism( 16 );
+  tmc2_set_refine_overlap( workers <= 4 ? 1 : 0 );  // few frames in flight per device: shorten a frame's chain (include/tmc2hip.h)
   tmc2_set_kdtree_placement( 0 );  // device trees (round 2: the device build beats the host build at every number of frames in flight)
 
   std::vector<Frame> gof( size_t( o.frames ) );

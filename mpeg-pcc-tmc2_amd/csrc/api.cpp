@@ -205,6 +205,14 @@ int tmc2_ctx_create( int device, tmc2_ctx** out ) {
 
 void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   if ( !ctx ) return;
+  ctx->destroyRequested.store( true );
+  if ( ctx->liveFrames.load() > 0 ) return;  // frames of this context are alive: the last of them destroys it (FrameTicket)
+  if ( ctx->destroyClaimed.exchange( true ) ) return;
+  tmc2::destroyContextNow( ctx );
+}
+}  // extern "C"
+
+void tmc2::destroyContextNow( tmc2_ctx* ctx ) {
   (void)hipSetDevice( ctx->device );
   for ( auto& s : ctx->stages ) ctx->foldStage( s );
   for ( auto e : ctx->freeEvents ) (void)hipEventDestroy( e );
@@ -220,6 +228,8 @@ void tmc2_ctx_destroy( tmc2_ctx* ctx ) {
   if ( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
   delete ctx;
 }
+
+extern "C" {
 
 int tmc2_host_alloc( size_t bytes, void** out ) {
   if ( !out || bytes == 0 ) return TMC2_E_INVALID;
@@ -293,6 +303,7 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
   *out = nullptr;
   ApiScope                    scope( ctx );
   std::unique_ptr<tmc2_frame> f( new tmc2_frame() );
+  f->ticket.bind( ctx );
   f->ctx = ctx;
   f->n   = n;
   f->h_xyz.assign( xyz, xyz + 3 * n );
@@ -325,6 +336,15 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
 }  // extern "C"
 
 namespace tmc2 {
+// whether tmc2_segmenter_compute queues the refine step's geometry ahead of the orientation's host walk
+// (tmc2_set_refine_overlap; unset: the environment variable TMC2_REFINE_OVERLAP decides, off without it)
+std::atomic<int> g_refineOverlap{-1};
+bool refineOverlap() {
+  const int v = g_refineOverlap.load( std::memory_order_relaxed );
+  if ( v >= 0 ) return v != 0;
+  const char* e = getenv( "TMC2_REFINE_OVERLAP" );
+  return e && e[0] == '1';
+}
 // where the k-d trees are built (tmc2_set_kdtree_placement; TMC2_KDTREE_HOST=1 presets "host")
 static std::atomic<int> g_kdtreeOnHost{-1};
 int kdtreePlacement() {
@@ -410,6 +430,7 @@ int tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth )
 }
 
 void tmc2_set_kdtree_placement( int mode ) { tmc2::setKdtreePlacement( mode ); }
+void tmc2_set_refine_overlap( int on ) { tmc2::g_refineOverlap.store( on ? 1 : 0, std::memory_order_relaxed ); }
 
 void tmc2_frame_destroy( tmc2_frame* f ) {
   if ( !f ) return;

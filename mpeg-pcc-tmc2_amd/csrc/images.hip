@@ -252,6 +252,7 @@ int createDecoderFrame( tmc2_ctx* ctx, const tmc2_patch* patches, int count, int
     return TMC2_E_UNSUPPORTED;
   }
   std::unique_ptr<tmc2_frame> f( new tmc2_frame() );
+  f->ticket.bind( ctx );
   f->ctx = ctx;
   f->n   = 0;
   f->patches.assign( patches, patches + count );

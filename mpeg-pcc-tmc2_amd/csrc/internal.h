@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -220,6 +221,10 @@ struct PinnedBuf {
 }  // namespace tmc2
 
 struct tmc2_ctx {
+  // A context outlives its frames: tmc2_ctx_destroy on a context that still has frames only asks for the destruction, which the
+  // last frame to go carries out (a frame's device buffers return to the context's pool when the frame is destroyed).
+  std::atomic<int>              liveFrames{0};
+  std::atomic<bool>             destroyRequested{false}, destroyClaimed{false};
   int                           device = 0;
   tmc2::DevicePool              pool;
   tmc2::PinnedBuf               hostA, hostB, hostC, hostD, hostE;  // staging for the host-side steps
@@ -242,7 +247,25 @@ struct tmc2_ctx {
   void stageAddHostMs( const char* name, double ms );
 };
 
+namespace tmc2 {
+void destroyContextNow( tmc2_ctx* ctx );
+// first member of a frame, so destroyed last: counts the frame in its context and, when it was the last one of a context whose
+// destruction has been asked for, destroys the context
+struct FrameTicket {
+  tmc2_ctx* ctx = nullptr;
+  void      bind( tmc2_ctx* c ) {
+    ctx = c;
+    c->liveFrames.fetch_add( 1 );
+  }
+  ~FrameTicket() {
+    if ( ctx && ctx->liveFrames.fetch_sub( 1 ) == 1 && ctx->destroyRequested.load() && !ctx->destroyClaimed.exchange( true ) )
+      destroyContextNow( ctx );
+  }
+};
+}  // namespace tmc2
+
 struct tmc2_frame {
+  tmc2::FrameTicket ticket;
   tmc2_ctx* ctx = nullptr;
   uint64_t  n   = 0;
   int       k   = 0;  // k of the resident adjacency
@@ -412,6 +435,8 @@ int rgb444ToYuv420Device( tmc2_ctx* ctx, const uint8_t* d_rgb, int W, int H, int
 int yuv420ToYuv444Device( tmc2_ctx* ctx, const uint8_t* d_yuv, int W, int H, int filter, uint16_t* d_out );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // the point-only half of it ahead of time (voxels, neighbourhood rows): queued, not waited for; refineGridBased picks it up
+extern std::atomic<int> g_refineOverlap;
+bool refineOverlap();  // tmc2_set_refine_overlap / TMC2_REFINE_OVERLAP
 int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 // Grid of a kernel that walks its items with a stride loop: at most eight 256-thread workgroups per CU -- one full set of

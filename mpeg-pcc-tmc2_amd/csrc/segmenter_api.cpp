@@ -65,9 +65,11 @@ int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
   if ( !f || !p ) return TMC2_E_INVALID;
   tmc2::ApiScope scope( f->ctx );
   TMC2_TRY( tmc2_segmenter_params_check( p ) );
-  // TMC2_REFINE_OVERLAP=1: the refine step's geometry (voxels, neighbourhood rows: points only) is queued right before the
-  // orientation's host walk and built while the host walks.  Measured: one frame alone 33.3 -> 32.0 ms, but 16 frames in flight
-  // 96.8 -> 94.5 frames/s (the rows of one frame then compete with the orientation kernels of the others) -- off by default.
+  // tmc2_set_refine_overlap( 1 ) / TMC2_REFINE_OVERLAP=1: the refine step's geometry (voxels, neighbourhood rows forward and reverse:
+  // points only) is queued right before the orientation's host walk and built while the host walks.  It shortens a frame's
+  // chain and costs throughput when the chip is full: round 4, four frames in flight (one rank's share of an 8-GPU run):
+  // longdress 30.8 -> 30.4 ms, loot (voxels of 2: 5 ms of geometry) 57.8 -> 52.0 ms; sixteen in flight: 173.5 -> 174.0 and
+  // 91.5 -> 90.1 frames/s.  The GOF host (tmc2_amd/gof.py, integration/tmc2_encode_gof.cpp) turns it on for <= 4 frames in flight.
   struct HookGuard {  // on every way out: no hook left behind, and no half-used refine job (it holds the context's dense voxel table
     tmc2_frame* f;    // filled: another frame's refinement on this context would look its cells up in a dirty table)
     bool        done = false;
@@ -76,7 +78,7 @@ int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
       if ( !done ) f->refineJob.reset();
     }
   } guard{f};
-  if ( p->gridBasedRefineSegmentation && getenv( "TMC2_REFINE_OVERLAP" ) )
+  if ( p->gridBasedRefineSegmentation && tmc2::refineOverlap() )
     f->beforeHostWalk = [f, p]() {
       return tmc2::refinePrepareGeometry( f, p->maxNNCountRefineSegmentation, p->lambdaRefineSegmentation,
                                           p->iterationCountRefineSegmentation, p->voxelDimensionRefineSegmentation,

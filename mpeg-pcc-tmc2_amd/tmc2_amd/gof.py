@@ -177,6 +177,10 @@ class GofEncoder:
             for w in range(workers):
                 d = doms[(first_domain + w) % len(doms)]
                 cpus[w] = d[((first_domain + w) // len(doms)) % len(d)]
+        # few frames in flight (one rank's share of a many-GPU run): the refinement's geometry goes ahead of the orientation's host
+        # walk -- it shortens a frame's chain; with the chip full it would only compete (include/tmc2hip.h)
+        if os.environ.get("TMC2_REFINE_OVERLAP") is None:
+            lib.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
         self.threads = [_Worker(w, device, cpus[w], timing) for w in range(workers)]
         self.ctxs = [t.ctx for t in self.threads]
 

@@ -132,6 +132,7 @@ def load_library():
     L = C.CDLL(path)
     L.tmc2_last_error.restype = C.c_char_p
     L.tmc2_set_kdtree_placement.restype = None
+    L.tmc2_set_refine_overlap.restype = None
     L.tmc2_set_host_parallelism.restype = None
     L.tmc2_ctx_stage_name.restype = C.c_char_p
     L.tmc2_ctx_stage_ms.restype = C.c_double

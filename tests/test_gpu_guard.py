@@ -108,3 +108,25 @@ def test_gpu_guard_inter_frame_packers(guard, pack):
         enc.phase_a(frs, constrained_pack={1: True, 2: 2}[pack], records_chain=True)
     finally:
         enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_context_outlives_its_frames(oracle):
+    """tmc2_ctx_destroy on a context that still has frames must not pull the stream and the memory pool from under them (round 4:
+    a test that closed its context first hung in the frame's destructor): the destruction is carried out by the last frame to
+    go, and until then the frames keep working."""
+    xyz, rgb = synth_cloud("tiny")
+    ctx = T.Context(0)
+    a, b = ctx.frame(xyz, rgb), ctx.frame(xyz, rgb)
+    a.normals_compute(16, 1)
+    ctx.close()                                                       # asks for the destruction; two frames are alive
+    b.normals_compute(16, 1)                                          # ... and still have their context
+    assert np.array_equal(a.get_normals().view(np.uint64), b.get_normals().view(np.uint64))
+    assert np.array_equal(b.get_adjacency(16), oracle.knn_self(xyz, 16))
+    a.close()
+    b.close()                                                         # the last one out destroys the context
+    c2 = T.Context(0)                                                 # the device is fine
+    fr = c2.frame(xyz, rgb)
+    fr.normals_compute(16, 1)
+    fr.close()
+    c2.close()

@@ -273,6 +273,7 @@ def test_gpu_refine_solid_cloud_takes_the_larger_tier(oracle, vox_dim):
         assert np.array_equal(fr.get_partition(), exp), attempt
         repeats = ctx.stage_calls().get("refine_cap_tier_repeat", 0)
         assert repeats == ((1 if vox_dim == 4 else 2) if attempt == 0 else 0), (attempt, repeats)
+        fr.close()
     ctx.close()
 
 
