@@ -257,7 +257,10 @@ __global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __res
     const double   d  = edgeDot[size_t( u ) * K + j];
     if ( j == 0 ) cid[u] = cu;
     isCross = cv != cu;
-    if ( ( mask[u] >> j ) & 1u ) wrong = ( uint32_t( parity[u] ) ^ parity[v] ) != ( d < 0.0 ? 1u : 0u );
+    // every strong edge with both ends in one cluster -- the mutual ones the cluster was built from AND the one-way ones that
+    // happen to fall inside it -- must agree with the parities: the growth may take any of them first (orient_host.cpp,
+    // contractOnHost)
+    if ( !isCross && fabs( d ) >= tau ) wrong = ( uint32_t( parity[u] ) ^ parity[v] ) != ( d < 0.0 ? 1u : 0u );
     if ( isCross ) {
       const uint32_t s = pairSlot( t, cu, cv, true );
       if ( s == 0xFFFFFFFFu )

@@ -639,6 +639,17 @@ static bool contractOnHost( size_t n, const uint32_t* knn, int k, const double* 
   root.resize( n );
   parity.resize( n );
   for ( size_t i = 0; i < n; ++i ) root[i] = find( uint32_t( i ), parity[i] );
+  // A strong edge that is NOT mutual may still have both ends in one cluster (they are joined by other, mutual, strong edges).
+  // It is an edge of the strongly reachable set like any other: the growth may take it before the mutual ones (it does when it
+  // is the heavier way in), so it too must agree with the cluster's parities -- or the order of the growth matters and the
+  // caller has to grow the plain way.  (Round 4: frame 26 of the redandblack-like GOF has exactly one such edge in 12 M; the
+  // reference follows it and orients two points against their cluster.)
+  for ( size_t u = 0; u < n; ++u )
+    for ( int j = 0; j < k; ++j ) {
+      const uint32_t v = knn[u * k + j];
+      const double   d = edgeDot[u * k + j];
+      if ( std::fabs( d ) >= tau && root[v] == root[u] && ( uint8_t( parity[u] ^ parity[v] ) != ( d < 0.0 ? 1 : 0 ) ) ) return false;
+    }
   off.assign( n + 1, 0 );
   for ( size_t u = 0; u < n; ++u )
     for ( int j = 0; j < k; ++j )

@@ -64,7 +64,7 @@ BENCH_CONFIGS = {
     "longdress": "longdress_vox10_ai_r3_gof32",
     "loot": "loot_vox10_ai_r3_gof32",
     "redandblack": "redandblack_vox10_ai_r3_gof32",
-    "soldier": "soldier_vox10_ai_r3_gof8",
+    "soldier": "soldier_vox10_ai_r3_gof32",
     "basketball": "basketball_player_vox11_ra_r5_gof8",
 }
 

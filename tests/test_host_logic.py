@@ -431,6 +431,21 @@ def test_host_ply_write_is_byte_identical_to_the_reference(tmp_path, ascii_, wit
         assert mine.read_bytes() == theirs.read_bytes()
 
 
+def test_host_orientation_one_way_strong_edge_inside_a_cluster(oracle):
+    """Round 4, found by the 32-frame redandblack fixture: frame 26 of that GOF has ONE strong edge (|n_u . n_v| >= 0.98) that
+    is not mutual, lies inside a cluster of mutual strong edges and disagrees with the cluster's parities -- the reference's
+    growth happens to take it first and orients two points against their cluster.  The contraction must notice (every strong
+    edge inside a cluster is checked, not only the mutual ones) and grow with the tighter threshold; the result is the
+    reference's (its digest in tests/golden/full_size.npz)."""
+    import hashlib
+    xyz, _ = synth_cloud("redandblack_vox10", 26)
+    knn = oracle.knn_self(xyz, 16)
+    raw = oracle.compute_normals(xyz, knn)
+    got = T.host_orient_normals(xyz, knn, raw)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_size.npz"))
+    assert hashlib.md5(np.ascontiguousarray(got).tobytes()).hexdigest() == str(g["redandblack_vox10_ai_r3_gof32/f26_src_normals_md5"])
+
+
 def test_native_front_end_builds_and_fails_loudly_without_a_gpu(tmp_path):
     """integration/tmc2_encode_gof.cpp (a C++ host front end over the C-ABI, the whole GOF path) compiles against
     include/tmc2hip.h alone and, on a machine without an MI355X, stops with the library's "no device" error instead of
