@@ -108,9 +108,13 @@ __device__ __forceinline__ uint32_t rankOfKey( const uint2* __restrict__ bits, u
 // voxelOfRank[rank of the voxel's key] = voxel id (written by the voxel's first point)
 __global__ __launch_bounds__( 256 ) void rankToVoxelKernel( const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag,
                                                              const uint32_t* __restrict__ vid, uint32_t n,
-                                                             const uint2* __restrict__ bits, uint32_t* __restrict__ voxelOfRank ) {
+                                                             const uint2* __restrict__ bits, uint32_t* __restrict__ voxelOfRank,
+                                                             const uint32_t* __restrict__ count, Pt* __restrict__ centre ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( i < n && flag[i] ) voxelOfRank[rankOfKey( bits, key[i] )] = vid[i];
+  if ( i < n && flag[i] ) {
+    voxelOfRank[rankOfKey( bits, key[i] )] = vid[i];
+    centre[vid[i]].w = int16_t( count[vid[i]] & 0xFFu );  // (the neighbourhood pass reads a voxel's centre anyway: its member count rides along)
+  }
 }
 
 // The first point of every voxel WITHOUT the dense key table (row-wise form: rounds 1-3 kept 2^(3s+1) words per context for this,
@@ -235,7 +239,8 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
 template <int CAP>
 __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ centre, const uint32_t* __restrict__ voxelOfRank,
                                             const uint2* __restrict__ bits, const Grid g, const int* __restrict__ rows, int nRows,
-                                            int idBits, uint32_t* keys, int lane, uint32_t* __restrict__ overflow ) {
+                                            int idBits, uint32_t* keys, int lane, uint32_t* __restrict__ overflow,
+                                            uint32_t* bins /* LDS, zeroed, or null: members (low 20 bits) and hits (above) per squared distance */ ) {
   const int gridMax = 1 << g.gridShift;  // cell coordinates run 0 .. gridMax inclusive
   int       cand    = 0;
   constexpr int kRowBatch = 5;  // (5 x 64 rows: the whole ball of the CTC settings in one round of loads)
@@ -316,7 +321,10 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
       key[k] = 0xFFFFFFFFu;
       if ( u[k] != 0xFFFFFFFFu ) {
         const Pt cu = centre[u[k]];  // aliased keys: accept only the voxel whose centre really sits here
-        if ( ( uint32_t( cu.x ) | ( uint32_t( cu.y ) << 10 ) | ( uint32_t( cu.z ) << 20 ) ) == cell[k] ) key[k] = ( d2[k] << idBits ) | u[k];
+        if ( ( uint32_t( cu.x ) | ( uint32_t( cu.y ) << 10 ) | ( uint32_t( cu.z ) << 20 ) ) == cell[k] ) {
+          key[k] = ( d2[k] << idBits ) | u[k];
+          if ( bins ) atomicAdd( &bins[min( d2[k], 127u )], ( uint32_t( cu.w ) & 0xFFu ) | ( 1u << 20 ) );
+        }
       }
     }
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );  // (every lane has read its candidates of this batch)
@@ -367,7 +375,12 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // all centre look-ups of its hits (two dependent round trips per batch instead of two per 64 cells: the kernel is bound by
   // exactly this latency).  The order of the hits does not matter: they are sorted below.
   constexpr int kBatch = 8;
-  if ( bits ) hits = collectBall<CAP>( c, centre, voxelOfRank, bits, g, offsets, nOffsets, idBits, keys, lane, overflow );
+  uint32_t*     bins   = keys + CAP - 160;  // (the host checks that the ball leaves this room)
+  for ( int b = lane; b < 128; b += 64 ) bins[b] = 0;
+  __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  // (row-wise form: the bins -- members and hits per squared distance -- fill while the ball is collected: a voxel's member
+  //  count rides in its centre record, which the collection reads anyway)
+  if ( bits ) hits = collectBall<CAP>( c, centre, voxelOfRank, bits, g, offsets, nOffsets, idBits, keys, lane, overflow, bins );
   for ( int base = 0; !bits && base < nOffsets; base += 64 * kBatch ) {
     uint32_t u[kBatch], d2[kBatch], cell[kBatch];
 #pragma unroll
@@ -406,28 +419,33 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // distance takes few values, so the cut is found BEFORE sorting -- member totals per distance (LDS atomics into the unused
   // tail of the key array), a wave scan over them -- and the hits beyond the distance the cut falls in are dropped: the
   // sort below handles ~ 100-150 keys instead of the 300-400 voxels of the whole ball.
+  uint32_t membersBefore = 0, hitsBefore = 0;  // of the distance the cut falls in (row-wise form)
+  bool     cutFound      = false;
   {
-    uint32_t* bins = keys + CAP - 160;  // (the host checks that the ball leaves this room)
-    for ( int b = lane; b < 128; b += 64 ) bins[b] = 0;
+    if ( !bits )
+      for ( int i = lane; i < hits; i += 64 ) {
+        const uint32_t key = keys[i];
+        atomicAdd( &bins[min( key >> idBits, 127u )], ( count[key & idMask] & 0xFFu ) | ( 1u << 20 ) );
+      }
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
-    for ( int i = lane; i < hits; i += 64 ) {
-      const uint32_t key = keys[i];
-      atomicAdd( &bins[min( key >> idBits, 127u )], count[key & idMask] & 0xFFu );
-    }
-    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
-    const uint32_t b0 = bins[2 * lane], b1 = bins[2 * lane + 1];
-    uint32_t       inc = b0 + b1;
+    const uint32_t w0 = bins[2 * lane], w1 = bins[2 * lane + 1];
+    const uint32_t b0 = w0 & 0xFFFFFu, b1 = w1 & 0xFFFFFu, e0 = w0 >> 20, e1 = w1 >> 20;
+    uint32_t       inc = b0 + b1, einc = e0 + e1;
 #pragma unroll
     for ( int off = 1; off < 64; off <<= 1 ) {
-      const uint32_t t = __shfl_up( inc, off, 64 );
-      if ( lane >= off ) inc += t;
+      const uint32_t t = __shfl_up( inc, off, 64 ), te = __shfl_up( einc, off, 64 );
+      if ( lane >= off ) inc += t, einc += te;
     }
-    const uint32_t           before  = inc - ( b0 + b1 );
+    const uint32_t           before  = inc - ( b0 + b1 ), ebefore = einc - ( e0 + e1 );
     const unsigned long long reached = __ballot( inc >= uint32_t( maxNN ) );
     uint32_t                 cutoff  = 127;  // (fewer members than maxNN in the whole ball: everything stays)
     if ( reached ) {
-      const int first = __ffsll( (long long)reached ) - 1;
-      cutoff          = 2u * uint32_t( first ) + ( __shfl( before + b0, first, 64 ) >= uint32_t( maxNN ) ? 0u : 1u );
+      const int  first = __ffsll( (long long)reached ) - 1;
+      const bool even  = __shfl( before + b0, first, 64 ) >= uint32_t( maxNN );
+      cutoff           = 2u * uint32_t( first ) + ( even ? 0u : 1u );
+      membersBefore    = __shfl( even ? before : before + b0, first, 64 );
+      hitsBefore       = __shfl( even ? ebefore : ebefore + e0, first, 64 );
+      cutFound         = true;
     }
     int kept = 0;
     for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
@@ -465,12 +483,20 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
     }
   }
-  // truncation: first position where the running member count reaches maxNN (inclusive)
-  uint32_t running = 0;
+  // truncation: first position where the running member count reaches maxNN (inclusive).  The cut falls in the last distance
+  // kept (that is how it was chosen): everything before it counts whole -- members and hits are known from the bins -- and only
+  // the hits of that distance, sorted by voxel id, are walked.
+  uint32_t running = cutFound ? membersBefore : 0u;
   int      used    = hits;
   uint32_t nn      = 0;
   bool     done    = false;
-  for ( int base = 0; base < hits && !done; base += 64 ) {
+  if ( !cutFound ) {  // fewer members than maxNN in the whole ball: the row is the ball
+    for ( int b = lane; b < 128; b += 64 ) nn += bins[b] & 0xFFFFFu;
+#pragma unroll
+    for ( int off = 32; off > 0; off >>= 1 ) nn += __shfl_xor( nn, off, 64 );
+    done = true;
+  }
+  for ( int base = int( hitsBefore ); base < hits && !done; base += 64 ) {
     const int i   = base + lane;
     uint32_t  cnt = ( i < hits ) ? ( count[keys[i] & idMask] & 0xFFu ) : 0u;
     uint32_t  inc = cnt;
@@ -566,7 +592,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __r
   int                 kept = 0;
   if ( u < V ) {
     const uint32_t idMask = ( 1u << idBits ) - 1u;
-    const int      hits   = collectBall<CAP>( centre[u], centre, voxelOfRank, bits, g, rows, nRows, idBits, keys, lane, overflow );
+    const int      hits   = collectBall<CAP>( centre[u], centre, voxelOfRank, bits, g, rows, nRows, idBits, keys, lane, overflow, nullptr );
     for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
       const int      i   = base + lane;
       const uint32_t key = i < hits ? keys[i] : 0u;
@@ -1552,7 +1578,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
                       d_count.p, d_centre.p );
   if ( byRows ) {
     TMC2_TRY( d_voxelOfRank.alloc( V ) );
-    hipLaunchKernelGGL( rankToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, bits, d_voxelOfRank.p );
+    hipLaunchKernelGGL( rankToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, bits, d_voxelOfRank.p, d_count.p, d_centre.p );
   } else {
     hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
   }
