@@ -729,6 +729,19 @@ static void compactOnHost( size_t n, const std::vector<uint32_t>& root, const st
 }
 
 // first strong-edge threshold: ~11 degrees (nearly every edge on a smooth surface is strong)
+// The thresholds the CONTRACTED walk is tried with, in turn: any threshold at which every strong edge inside a cluster (and every
+// strong cross edge of a strongly reachable set) agrees with one sign assignment gives the reference's orientation, so a frame
+// whose graph is unbalanced at 0.98 -- one stray edge of weight 0.984 in 12 M is enough (round 4, redandblack-like frame 26) --
+// is tried again a little tighter (a contraction + a cluster walk: milliseconds) before it falls back to the growth point by
+// point (hundreds of milliseconds, and the GOF waits for it).
+std::vector<double> orientTauLadder() {
+  const double        first = orientFirstTau();
+  std::vector<double> l{first};
+  for ( double t : {0.99, 0.995, 0.998} )
+    if ( t > first && first <= 1.5 ) l.push_back( t );
+  return l;
+}
+
 double orientFirstTau() {
   static const double first = [] {
     const char* e = getenv( "TMC2_ORIENT_TAU" );  // test hook; >= 2 goes straight to the plain growth
@@ -749,9 +762,10 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
   }
   // thresholds tried in turn: the first (contracted, then point by point), then ~3.6 degrees, then none (the plain
   // growth, always exact by construction)
-  const double first = orientFirstTau();
+  const double first0 = orientFirstTau();
   int growths = 0;
-  if ( tryContraction && first <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) ) {  // (test hook: point-level walk only)
+  if ( tryContraction && first0 <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) )  // (test hook: point-level walk only)
+  for ( const double first : orientTauLadder() ) {
     // contracted walk: clusters of mutual strong edges first
     ++growths;
     std::vector<uint32_t>        root, off;
@@ -820,6 +834,7 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
       if ( okw ) return growths;
     }
   }
+  const double first = first0;
   for ( double tau : {first, 0.998} ) {
     if ( tau > 1.5 ) break;
     ++growths;
@@ -873,17 +888,21 @@ int orientNormalsHost( tmc2_frame* f ) {
   TMC2_TRY( d_negCount.alloc( kOrientNegCountWords ) );
   TMC2_TRY( launchEdgeDots( f, d_edgeDot.p ) );
   if ( ctx->orientScratch.size() < 2 * n ) ctx->orientScratch.resize( 2 * n );
-  const double tau = orientFirstTau();
-
-  // ---- fast path: contract on the device, walk the clusters on the host --------------------------------------------
+  // ---- fast path: contract on the device, walk the clusters on the host; a frame that is inconsistent at one threshold is
+  // tried with the next (orientTauLadder) --------------------------------------------------------------------------------
   bool contracted = false;
-  if ( tau <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) ) {
+  if ( orientFirstTau() <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) )
+  for ( const double tau : orientTauLadder() ) {
+    if ( tau != orientFirstTau() ) ctx->stageAddHostMs( "orient_tau_retry", 0.0 );  // (counts the repeats with a tighter threshold)
     OrientCompact g{};
     const int     sid = ctx->stageBegin( "orient_contract" );
     TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );  // (d_root: cluster ids here)
     ctx->stageEnd( sid );
     if ( contracted ) {
-      if ( f->beforeHostWalk ) TMC2_TRY( f->beforeHostWalk() );  // device work that overlaps the walk
+      if ( f->beforeHostWalk ) {  // device work that overlaps the walk (once, whatever the number of thresholds tried)
+        TMC2_TRY( f->beforeHostWalk() );
+        f->beforeHostWalk = nullptr;
+      }
       const uint32_t        C           = g.clusters;
       int8_t*               clusterSign = reinterpret_cast<int8_t*>( ctx->hostC.get<uint32_t>( 4 + ( n + 4 ) / 4 + 4 ) + 4 );  // (behind the counters)
       std::vector<uint32_t> seeds, seedClusters, component( C );
@@ -909,8 +928,9 @@ int orientNormalsHost( tmc2_frame* f ) {
         return TMC2_OK;
       }
     }
-    ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames that needed the point-level walk
   }
+  if ( orientFirstTau() <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) )
+    ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames that needed the point-level walk
 
   // ---- point-level walk: rows, dot products and normals to the host ----------------------------------------------------
   uint32_t* knn  = ctx->hostA.get<uint32_t>( edges );

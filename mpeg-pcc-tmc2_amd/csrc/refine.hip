@@ -419,8 +419,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // distance takes few values, so the cut is found BEFORE sorting -- member totals per distance (LDS atomics into the unused
   // tail of the key array), a wave scan over them -- and the hits beyond the distance the cut falls in are dropped: the
   // sort below handles ~ 100-150 keys instead of the 300-400 voxels of the whole ball.
-  uint32_t membersBefore = 0, hitsBefore = 0;  // of the distance the cut falls in (row-wise form)
+  uint32_t membersBefore = 0, hitsBefore = 0, hitsCut = 0;  // of the distance the cut falls in
   bool     cutFound      = false;
+  // Row-wise form: a row is a SET to everything that reads it (integer sums over it, marks through it, the reverse rows test
+  // membership by the last key), so only the hits of the distance the cut falls in have to be put in order -- by voxel id, to
+  // find where the row ends -- and not the whole row: ~ 100 keys to sort instead of 400-500 (the sort was two thirds of this
+  // kernel).  They go to the free room above the hits; the cell-by-cell form (and a ball too full for that room) sorts everything.
+  bool     partial       = false;
+  int      Pc            = 64;
+  uint32_t lastKeyValue  = 0;
   {
     if ( !bits )
       for ( int i = lane; i < hits; i += 64 ) {
@@ -445,10 +452,65 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       cutoff           = 2u * uint32_t( first ) + ( even ? 0u : 1u );
       membersBefore    = __shfl( even ? before : before + b0, first, 64 );
       hitsBefore       = __shfl( even ? ebefore : ebefore + e0, first, 64 );
+      hitsCut          = __shfl( even ? e0 : e1, first, 64 );
       cutFound         = true;
+      while ( Pc < int( hitsCut ) ) Pc <<= 1;
+      partial = bits != nullptr && hits + Pc <= CAP - 160;
+    }
+    if ( partial ) {
+      uint32_t* cut   = keys + ( CAP - 160 - Pc );  // (above every hit: nothing this loop still has to read)
+      int       front = 0, tail = 0;
+      for ( int base = 0; base < hits; base += 64 ) {  // the front in place: a chunk is read whole before anything lands at or below it
+        const int      i   = base + lane;
+        const uint32_t key = i < hits ? keys[i] : 0xFFFFFFFFu;
+        const bool     isFront = i < hits && ( key >> idBits ) < cutoff, isCut = i < hits && ( key >> idBits ) == cutoff;
+        const unsigned long long mF = __ballot( isFront ), mC = __ballot( isCut ), below = ( 1ull << lane ) - 1ull;
+        __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+        if ( isFront ) keys[front + __popcll( mF & below )] = key;
+        if ( isCut ) cut[tail + __popcll( mC & below )] = key;
+        front += __popcll( mF ), tail += __popcll( mC );
+      }
+      for ( int i = int( hitsCut ) + lane; i < Pc; i += 64 ) cut[i] = 0xFFFFFFFFu;
+      __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+      for ( int k = 2; k <= Pc; k <<= 1 )
+        for ( int j = k >> 1; j > 0; j >>= 1 ) {
+          for ( int i = lane; i < Pc; i += 64 ) {
+            const int partner = i ^ j;
+            if ( partner > i ) {
+              const uint32_t a = cut[i], b = cut[partner];
+              if ( ( a > b ) == ( ( i & k ) == 0 ) ) cut[i] = b, cut[partner] = a;
+            }
+          }
+          __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+        }
+      // where the row ends inside the cut distance
+      uint32_t running = membersBefore, m = hitsCut;
+      for ( int base = 0; base < int( hitsCut ); base += 64 ) {
+        const int i   = base + lane;
+        uint32_t  inc = i < int( hitsCut ) ? ( count[cut[i] & idMask] & 0xFFu ) : 0u;
+#pragma unroll
+        for ( int off = 1; off < 64; off <<= 1 ) {
+          const uint32_t t = __shfl_up( inc, off, 64 );
+          if ( lane >= off ) inc += t;
+        }
+        inc += running;
+        const unsigned long long reachedHere = __ballot( i < int( hitsCut ) && inc >= uint32_t( maxNN ) );
+        if ( reachedHere ) {
+          const int firstLane = __ffsll( (long long)reachedHere ) - 1;
+          m                   = uint32_t( base + firstLane + 1 );
+          running             = __shfl( inc, firstLane, 64 );
+          break;
+        }
+        running = __shfl( inc, 63, 64 );
+      }
+      membersBefore = running;  // = the row's member count
+      lastKeyValue  = cut[m - 1];
+      for ( int i = lane; i < int( m ); i += 64 ) keys[hitsBefore + i] = cut[i];  // (the front ends below the room the cut hits sat in)
+      hits = int( hitsBefore + m );
+      __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
     }
     int kept = 0;
-    for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
+    for ( int base = 0; !partial && base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
       const int      i    = base + lane;
       const uint32_t key  = i < hits ? keys[i] : 0xFFFFFFFFu;
       const bool     stay = i < hits && ( key >> idBits ) <= cutoff;
@@ -457,7 +519,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       if ( stay ) keys[kept + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = key;
       kept += __popcll( m );
     }
-    hits = kept;
+    if ( !partial ) hits = kept;
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
   }
   // pad to a power of two and sort ascending (wave-private LDS: no barrier needed beyond wave lockstep,
@@ -465,6 +527,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // use __builtin_amdgcn_wave_barrier to keep the order of LDS operations)
   int P = 64;
   while ( P < hits ) P <<= 1;
+  if ( partial ) P = 0;  // (nothing left to sort)
   for ( int i = hits + lane; i < P; i += 64 ) keys[i] = 0xFFFFFFFFu;
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
   for ( int k = 2; k <= P; k <<= 1 ) {
@@ -490,6 +553,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   int      used    = hits;
   uint32_t nn      = 0;
   bool     done    = false;
+  if ( partial ) nn = membersBefore, done = true;  // (found above: the row is keys[0 .. hits))
   if ( !cutFound ) {  // fewer members than maxNN in the whole ball: the row is the ball
     for ( int b = lane; b < 128; b += 64 ) nn += bins[b] & 0xFFFFFu;
 #pragma unroll
@@ -532,7 +596,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   const bool fit = uint64_t( rowBase ) + uint32_t( used ) <= rowCapacity;
   if ( lane == 0 ) {
     rowLen[v] = uint32_t( used );
-    if ( lastKey ) lastKey[v] = used > 0 ? keys[used - 1] : 0u;
+    if ( lastKey ) lastKey[v] = partial ? lastKeyValue : ( used > 0 ? keys[used - 1] : 0u );
     adjOff[v] = fit ? rowBase : 0u;
     weight[v] = __ddiv_rn( lambda, double( nn ) );
     if ( !fit ) atomicMax( overflow, 1u );  // the host repeats the pass with room for whole balls
@@ -560,7 +624,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       if ( pos < devStride ) drow[pos] = u;
     }
     nDev += uint32_t( __popcll( m ) );
-    if ( !__ballot( near ) ) break;
+    if ( !partial && !__ballot( near ) ) break;  // (a sorted row: nothing near can follow)
   }
   if ( nDev > devStride ) {  // (cannot happen: (2 R + 1)^3 <= devStride by construction)
     if ( lane == 0 ) *overflow = 2u;
