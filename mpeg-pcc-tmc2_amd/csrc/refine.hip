@@ -1080,8 +1080,8 @@ __device__ __forceinline__ int argOfPacked( uint32_t s0, uint32_t s1, uint32_t s
 //   work list:     kSubLists sub-lists with their counters 128 bytes apart (a reservation on ONE word costs 11 ns and they
 //                  queue up: tools/gpu/atomic_rate.hip; spread over cache lines they are free).  The voxels active at
 //                  sweep start carry kWorkActive; for the others sweepKernel reads the activated bit.
-//   LDS ring:      head / tail only grow; a slot holds kNoVoxel while it is empty, so a taker that won the slot waits for the
-//                  giver's store, and `freed` counts the slots handed back (a giver reserves only what `freed` covers).
+//   LDS ring:      head / tail only grow and never pass ringCap: a position is handed out once per sweep (what does not fit
+//                  spills); a slot holds kNoVoxel until its giver stores, so a taker that won the slot waits for that store.
 //                  `pending` = voxels given and not yet hopped on: a group retires when it finds nothing and pending == 0.
 //   spill ring:    what does not fit the LDS ring goes to a ring in global memory (same protocol); a workgroup that spilled
 //                  looks there whenever its own ring is empty and does not retire before it has seen the global ring empty
@@ -1132,12 +1132,9 @@ __device__ __forceinline__ uint32_t closureTake( const Closure& c ) {
   const uint32_t     h = wg[kHead], t = wg[kTail];
   if ( h != t ) {
     if ( atomicCAS( &c.wg[kHead], h, h + 1u ) != h ) return kNoVoxel;  // (somebody else took it: pending != 0, we come back)
-    volatile uint32_t* slot = &c.ring[h % c.ringCap];
+    volatile uint32_t* slot = &c.ring[h];  // (h < tail <= ringCap: positions are handed out once per sweep)
     uint32_t           x;
-    do { x = *slot; } while ( x == kNoVoxel );
-    *slot = kNoVoxel;
-    __builtin_amdgcn_fence( __ATOMIC_RELEASE, "workgroup" );
-    atomicAdd( &c.wg[kFreed], 1u );
+    do { x = *slot; } while ( x == kNoVoxel );  // (the giver stores right after its reservation)
     return x;
   }
   if ( !wg[kSpilled] ) return kNoVoxel;
@@ -1187,9 +1184,17 @@ __device__ __forceinline__ uint32_t closureHop( const Closure& c, uint32_t x, ui
     if ( int( lane ) == __ffs( int( mFresh ) ) - 1 ) {
       volatile uint32_t* wg = c.wg;
       atomicAdd( &c.wg[kPending], k );
+      // The LDS "ring" is used ONCE around per sweep: a position is never handed out twice, so a giver can never meet a slot
+      // whose previous taker has claimed it and not yet read it.  (Rounds 2-3 reused the slots the takers had handed back,
+      // counting them in `freed` -- but not WHICH ones; a SOLID cloud, where one seed's activations cascade through a single
+      // workgroup, wraps the ring and could lose a voxel or spin on its slot for ever.  Letting the giver wait for the slot's
+      // sentinel instead dead-locks: the two 32-lane groups of a wavefront leave a spin loop together, so a taker's clear can
+      // be held up by its sibling's wait for a store that is itself held up behind a sibling giver's wait -- seen as a GPU hang
+      // under 16 voxels-of-2 frames in flight.)  What does not fit goes through the ring in global memory, which holds every
+      // voxel of the grid and so cannot wrap within a sweep either.
       while ( true ) {
-        const uint32_t f = wg[kFreed], t = wg[kTail];  // (in this order: tail, read later, is not behind freed)
-        if ( t + k - f > c.ringCap ) break;
+        const uint32_t t = wg[kTail];
+        if ( t + k > c.ringCap ) break;
         if ( atomicCAS( &c.wg[kTail], t, t + k ) == t ) {
           at = t;
           break;
@@ -1203,16 +1208,7 @@ __device__ __forceinline__ uint32_t closureHop( const Closure& c, uint32_t x, ui
     at = __shfl( at, __ffs( int( mFresh ) ) - 1, 32 );
     if ( fresh ) {
       if ( at != kNoVoxel ) {
-        // The reservation test counts the slots handed back, not WHICH ones: once the ring has wrapped, a slot this
-        // reservation covers may belong to a taker that has claimed it ( its position < head ) and not yet read it.  The giver
-        // waits for that taker's sentinel.  Nobody it waits for can be waiting for it: the taker reads and clears in one stretch
-        // ( closureTake ), waiting at most for the EARLIER giver of its position -- a chain that runs backwards through the
-        // positions and ends in the first lap -- and a sibling half-wave is never inside a take while this half is inside a
-        // hop.  ( Round 3 relied on the ring never getting within the group's k of full; a SOLID cloud, where one seed's
-        // activations cascade through a single workgroup, wraps it: tests/test_gpu_segmenter.py, solid cloud. )
-        volatile uint32_t* slot = &c.ring[( at + __popc( mFresh & below ) ) % c.ringCap];
-        while ( *slot != kNoVoxel ) __builtin_amdgcn_s_sleep( 1 );
-        *slot = v;
+        c.ring[at + __popc( mFresh & below )] = v;  // (at + k <= ringCap: a slot nobody has used in this sweep)
       } else {
         const uint32_t idx = atomicAdd( &c.ctl[32], 1u );
         __hip_atomic_store( &c.spill[idx % c.spillCap], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
