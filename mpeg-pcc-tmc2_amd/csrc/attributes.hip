@@ -566,6 +566,7 @@ int generateAttributeImages( tmc2_frame* f ) {
   rt.depth = f->reconTree.depth;
   rt.n     = M;
   rt.queriesBounded = true;  // queried with the frame's own points; dispatch() checks both boxes
+  rt.queriesTight   = true;  // (non-negative and below 2^13, like the reconstruction the tree is built over)
   // ---- S18 ----------------------------------------------------------------------------------------------
   TMC2_TRY( f->d_reconRgb.alloc( size_t( M ) * 4 ) );
   const dim3 grdM( ( M + 255 ) / 256 );

@@ -176,6 +176,7 @@ struct TreeDev {
   int             depth = 0;
   uint64_t        n     = 0;
   bool            queriesBounded = false;  // the caller vouches: every query coordinate lies in [-4096, 12287]
+  bool            queriesTight   = false;  // ... and even in [0, 8191] (a frame's own points / reconstruction): larger trees keep the LDS stack
 };
 
 // GPU time per named stage / kernel: hipEvent pairs recorded on the context's stream, folded lazily when the

@@ -74,7 +74,13 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
                                                      uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist,
-                                                     int xcdAware, uint32_t nTree ) {
+                                                     int xcdAware, uint32_t nTree, int nodeBits ) {
+  // packed far-child entry (LDS form): node id in the low nodeBits, three offsets of ( 64 - nodeBits ) / 3 bits above it --
+  // 22 + 3 x 14 for trees of up to 2^21 points and queries within [-4096, 12287]; 25 + 3 x 13 for larger trees (the vox11
+  // frames: 3 M points) whose queries lie inside [0, 8191] like the tree's box (offsets < 2^13)
+  const int      offBits = ( 64 - nodeBits ) / 3, sh0 = nodeBits, sh1 = nodeBits + offBits, sh2 = nodeBits + 2 * offBits;
+  const uint32_t nodeMask = ( 1u << nodeBits ) - 1u, offMask = ( 1u << offBits ) - 1u;
+  (void)sh0, (void)sh1, (void)sh2, (void)nodeMask, (void)offMask;
   // Which 256 queries this workgroup takes.  Workgroups are handed to the eight XCDs round-robin (block b runs on XCD b % 8:
   // observed, not promised -- only speed depends on it), so consecutive blocks -- neighbours in tree order, walking the same
   // part of the tree -- land on eight different L2s, and every L2 ends up streaming the whole tree (9.4 MB at longdress size
@@ -158,8 +164,8 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
         const uint32_t f0 = uint32_t( nd.dim == 0 ? ofar : o0 ), f1 = uint32_t( nd.dim == 1 ? ofar : o1 ),
                        f2 = uint32_t( nd.dim == 2 ? ofar : o2 );
         if ( LDS ) {
-          const unsigned long long e = (unsigned long long)farC | ( (unsigned long long)f0 << 22 ) |
-                                       ( (unsigned long long)f1 << 36 ) | ( (unsigned long long)f2 << 50 );
+          const unsigned long long e = (unsigned long long)farC | ( (unsigned long long)f0 << sh0 ) |
+                                       ( (unsigned long long)f1 << sh1 ) | ( (unsigned long long)f2 << sh2 );
           if ( sp < kLdsTop )
             ldsStack[sp * 256 + threadIdx.x] = e;
           else
@@ -205,7 +211,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       int w = 0;
       for ( int i = 0; i < sp; ++i ) {
         const unsigned long long e = i < kLdsTop ? ldsStack[i * 256 + threadIdx.x] : lowStack[i - kLdsTop];
-        const uint32_t e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
+        const uint32_t e0 = uint32_t( e >> sh0 ) & offMask, e1 = uint32_t( e >> sh1 ) & offMask, e2 = uint32_t( e >> sh2 ) & offMask;
         if ( e0 * e0 + e1 * e1 + e2 * e2 <= min( bd[K - 1], cap ) ) {
           if ( w < kLdsTop )
             ldsStack[w * 256 + threadIdx.x] = e;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
       uint32_t en, e0, e1, e2;
       if ( LDS ) {
         const unsigned long long e = sp < kLdsTop ? ldsStack[sp * 256 + threadIdx.x] : lowStack[sp - kLdsTop];
-        en = uint32_t( e ) & 0x3FFFFFu, e0 = uint32_t( e >> 22 ) & 0x3FFFu, e1 = uint32_t( e >> 36 ) & 0x3FFFu, e2 = uint32_t( e >> 50 );
+        en = uint32_t( e ) & nodeMask, e0 = uint32_t( e >> sh0 ) & offMask, e1 = uint32_t( e >> sh1 ) & offMask, e2 = uint32_t( e >> sh2 ) & offMask;
       } else {
         const uint4 e = scratchStack[sp];
         en = e.x, e0 = e.y, e1 = e.z, e2 = e.w;
@@ -271,15 +277,16 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
   const dim3  grid( xcdAware ? uint32_t( ( ( nq + 255 ) / 256 + 7 ) & ~uint64_t( 7 ) ) : uint32_t( ( nq + 255 ) / 256 ) );
   // the packed LDS stack needs: every offset < 2^14 (tree box and queries inside a 16383-wide window -- the caller
   // vouches for the queries with t.queriesBounded), node ids < 2^22, and at most kLdsLevels pending far children
-  bool lds = t.queriesBounded && t.depth <= kLdsLevels && t.n <= ( uint64_t( 1 ) << 21 );
+  bool lds = t.depth <= kLdsLevels && ( ( t.queriesBounded && t.n <= ( uint64_t( 1 ) << 21 ) ) || ( ( SELF || t.queriesTight ) && t.n <= ( uint64_t( 1 ) << 23 ) ) );
   for ( int d = 0; d < 3; ++d ) lds = lds && t.lo[d] >= 0 && t.hi[d] <= 8191;
+  const int nodeBits = t.n <= ( uint64_t( 1 ) << 21 ) ? 22 : 25;  // (node ids stay below 2 n + the id chunks of the build)
 #define TMC2_LAUNCH_K( KK )                                                                                          \
   if ( lds ) {                                                                                                       \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,          \
-                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ) );                                                       \
+                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ), nodeBits );                                             \
   } else {                                                                                                           \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, false> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,         \
-                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ) );                                                       \
+                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ), nodeBits );                                             \
   }
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
@@ -309,6 +316,7 @@ TreeDev frameTree( const tmc2_frame* f ) {
   t.n     = f->n;
   // queries against a frame's tree are the frame's own points or its reconstruction (non-negative, < 2^13)
   t.queriesBounded = true;
+  t.queriesTight   = true;  // (... and below 2^13: inside [0, 8191])
   return t;
 }
 
@@ -329,6 +337,7 @@ int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, ui
                       bool queriesBounded ) {
   TreeDev t        = frameTree( f );
   t.queriesBounded = queriesBounded;
+  t.queriesTight   = false;  // (a caller's own queries: anywhere in the bounded window)
   return launchKnnTree( f->ctx, t, d_queries, nq, k, d_idx, d_dist, "knn_query" );
 }
 

@@ -414,29 +414,36 @@ __global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __res
   __shared__ unsigned long long d1Total[2];
   if ( threadIdx.x < 2 ) d1Total[threadIdx.x] = 0;
   const uint32_t     chunks = ( max( nA, nB ) + kSumChunk - 1 ) / kSumChunk;
-  double             acc    = 0.0;  // (lanes 0 .. 7: one ordered sum each)
+  double             acc    = 0.0;  // (lanes 0 .. 7 of the first wave: one ordered sum each)
   unsigned long long d1A = 0, d1B = 0;
-  auto               fetch = [&]( uint32_t c, int slot ) {
-    const uint32_t a   = c * kSumChunk + threadIdx.x;
-    double*        col = buf + size_t( slot ) * 8 * kSumStride + threadIdx.x;
-    if ( a < nA ) {
-      const double* t = termsA + 5 * size_t( a );
-      d1A += (unsigned long long)t[0];
+  // Round 4: the first wave only ADDS -- it never waits for global memory -- and the other fifteen only FETCH (element e of a
+  // chunk by producer thread e mod 960), one barrier per chunk instead of two: a chunk costs what its 1 024 dependent fp64 adds
+  // cost (rounds 2-3: the first wave fetched its share of the next chunk between the adds and a second barrier, and its
+  // exposed load latency was a third of the kernel).
+  const int  producer = int( threadIdx.x ) - 64;  // < 0: the adding wave
+  const auto fetch    = [&]( uint32_t c, int slot ) {
+    for ( int e = producer; e < kSumChunk; e += int( blockDim.x ) - 64 ) {
+      const uint32_t a   = c * kSumChunk + uint32_t( e );
+      double*        col = buf + size_t( slot ) * 8 * kSumStride + e;
+      if ( a < nA ) {
+        const double* t = termsA + 5 * size_t( a );
+        d1A += (unsigned long long)t[0];
 #pragma unroll
-      for ( int k = 0; k < 4; ++k ) col[k * kSumStride] = t[1 + k];
-    }
-    if ( a < nB ) {
-      const double* t = termsB + 5 * size_t( a );
-      d1B += (unsigned long long)t[0];
+        for ( int k = 0; k < 4; ++k ) col[k * kSumStride] = t[1 + k];
+      }
+      if ( a < nB ) {
+        const double* t = termsB + 5 * size_t( a );
+        d1B += (unsigned long long)t[0];
 #pragma unroll
-      for ( int k = 0; k < 4; ++k ) col[( 4 + k ) * kSumStride] = t[1 + k];
+        for ( int k = 0; k < 4; ++k ) col[( 4 + k ) * kSumStride] = t[1 + k];
+      }
     }
   };
-  if ( chunks ) fetch( 0, 0 );
+  if ( chunks && producer >= 0 ) fetch( 0, 0 );
   __syncthreads();
   for ( uint32_t c = 0; c < chunks; ++c ) {
     const int slot = int( c & 1 );
-    if ( threadIdx.x >= 64 ) {
+    if ( producer >= 0 ) {
       if ( c + 1 < chunks ) fetch( c + 1, slot ^ 1 );
     } else if ( threadIdx.x < 8 ) {
       const uint32_t n     = threadIdx.x < 4 ? nA : nB, first = c * kSumChunk;
@@ -444,15 +451,15 @@ __global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __res
       const double*  col   = buf + ( size_t( slot ) * 8 + threadIdx.x ) * kSumStride;
       const double2* pairs = reinterpret_cast<const double2*>( col );
       uint32_t       j     = 0;
-      for ( ; j + 8 <= cnt; j += 8 ) {  // the loads ahead of the (dependent) adds
+      for ( ; j + 16 <= cnt; j += 16 ) {  // the loads ahead of the (dependent) adds
         const double2 a = pairs[j / 2], b = pairs[j / 2 + 1], d = pairs[j / 2 + 2], e = pairs[j / 2 + 3];
+        const double2 f = pairs[j / 2 + 4], g = pairs[j / 2 + 5], h = pairs[j / 2 + 6], i2 = pairs[j / 2 + 7];
         acc += a.x, acc += a.y, acc += b.x, acc += b.y, acc += d.x, acc += d.y, acc += e.x, acc += e.y;
+        acc += f.x, acc += f.y, acc += g.x, acc += g.y, acc += h.x, acc += h.y, acc += i2.x, acc += i2.y;
       }
       for ( ; j < cnt; ++j ) acc += col[j];
     }
-    __syncthreads();
-    if ( threadIdx.x < 64 && c + 1 < chunks ) fetch( c + 1, slot ^ 1 );  // (the first wave's share of the next chunk)
-    __syncthreads();
+    __syncthreads();  // chunk c is summed, chunk c + 1 is in its slot
   }
   atomicAdd( &d1Total[0], d1A );
   atomicAdd( &d1Total[1], d1B );
