@@ -1762,7 +1762,13 @@ int RefineJob::finish() {
     const uint32_t ringCap    = run + ( ringEnv ? uint32_t( std::min( 8192, std::max( 1, atoi( ringEnv ) ) ) ) : 1024u );
     const size_t   closureLds = 4 * ( size_t( run ) + ringCap );
     if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
-    const dim3 grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, size_t( 2 ) * ctx->cuCount ) ) );
+    // (test hook TMC2_REFINE_SWEEP_BLOCKS: the sweep kernel's grid)
+    const char* sweepGridEnv = getenv( "TMC2_REFINE_SWEEP_BLOCKS" );
+    const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( 4 ) * ctx->cuCount ) ) );
+    // (round 4 sweep over the grids, 16 frames in flight / one sweep alone: sweep kernel 2 / 4 / 8 / 16 workgroups per CU ->
+    //  loot 109.0 / 108.1 / 107.1 / 106.6 frames/s, 338 / 327 / 305 / 289 us; longdress 174.1 / 174.9 frames/s, 54.8 / 51.9 us;
+    //  closure 1 / 2 / 4 / 8 per CU -> loot 109.3 / 109.0 / 107.8 / 107.1 frames/s, 434 / 338 / 308 / 291 us: all within
+    //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure)
     const bool wantTrace = getenv( "TMC2_REFINE_TRACE" ) != nullptr;
     DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
     const bool                 wantTiming = getenv( "TMC2_REFINE_TIMING" ) != nullptr;

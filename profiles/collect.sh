@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round's rocprofv3 artefacts on the GPU box (run from the repository root through gpurun); the summaries land in
 # gpurun_out/ and are copied into profiles/ by hand.   usage: bash profiles/collect.sh <tag>   (e.g. r02)
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp

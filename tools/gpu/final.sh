@@ -1,12 +1,38 @@
 #!/bin/bash
-# end-of-round artefacts: rocprof traces + PMC traffic (profiles/collect.sh), then the bench line that reads the fresh traffic file
-TAG=${1:-r03}
-mkdir -p gpurun_out
+# end-of-round artefacts: rocprof traces + PMC traffic of the headline configuration (profiles/collect.sh), one-frame traces of the
+# voxels-of-2 and vox11 configurations, where the GPU idles inside a frame, one bench line per BASELINE configuration (the headline
+# one with the CPU baseline, reading the fresh traffic file), two ranks on one GPU, the ASan run of the voxels-of-2 configuration
+TAG=${1:-r04}
+mkdir -p gpurun_out; export TMPDIR=/tmp
+REPO=$(pwd); O=$REPO/gpurun_out
 bash profiles/collect.sh $TAG
-cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # (bench.py reads profiles/; the copy travels back in gpurun_out/)
-timeout -k 10 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_final.json 2> gpurun_out/bench_${TAG}_final.err
+cp $O/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # (bench.py reads profiles/; the copy travels back in gpurun_out/)
+cd /tmp
+db() { find "$1" -name "*_results.db" | head -1; }
+for c in loot basketball; do
+  SOLO="python $REPO/bench.py --config $c --steps 2 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 --ingest 0 --decoder 0"
+  rm -rf $O/prof_solo; timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_solo -- $SOLO > $O/${TAG}_prof_$c.log 2>&1
+  python $REPO/profiles/summarise_rocpd.py "$(db $O/prof_solo)" "$SOLO  (one frame in flight)" > $O/${TAG}_kernel_stats_one_frame_$c.txt
+  rm -rf $O/prof_solo
+done
+cd $REPO
+bash tools/gpu/gaps.sh $TAG > /dev/null 2>&1
+timeout -k 10 1200 python bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_final.json 2> $O/bench_${TAG}_final.err; echo "longdress rc=$?"
+for c in loot redandblack soldier basketball; do
+  timeout -k 5 300 python bench.py --config $c --steps 10 --warmup 3 --cpu-baseline 0 --ingest 0 > $O/bench_${TAG}_$c.json 2> $O/bench_${TAG}_$c.err; echo "$c rc=$?"
+done
+timeout -k 5 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --dist-backend gloo --steps 5 --warmup 2 --cpu-baseline 0 > $O/bench_${TAG}_two_ranks_one_gpu.json 2> $O/bench_${TAG}_two_ranks_one_gpu.err; echo "two ranks rc=$?"
+timeout -k 5 300 bash tools/asan_host_gcc.sh run python tools/asan_gof.py --config loot --frames 8 --workers 8 --steps 2 > $O/${TAG}_asan_loot.log 2>&1; echo "asan loot rc=$?" >> $O/${TAG}_asan_loot.log
 python - <<PY
 import json
-d=json.loads(open("gpurun_out/bench_${TAG}_final.json").read().strip().splitlines()[-1])
-print(d["value"], d["verified"], d["roofline"]["kernel"], d["roofline"]["alone_avg_launch_ms"], d["roofline"]["alone_frac"], d["roofline"]["traffic"], d["roofline"].get("traffic_source"))
+for c in ("final", "loot", "redandblack", "soldier", "basketball", "two_ranks_one_gpu"):
+    try:
+        d = json.loads(open("gpurun_out/bench_${TAG}_%s.json" % c).read().strip().splitlines()[-1])
+        dec = d.get("decoder", {})
+        r = d["roofline"]
+        print(c, d["value"], "verified", d["verified"], "| roofline", r["kernel"], r["alone_avg_launch_ms"], r["alone_frac"], "traffic", r["traffic"], "| path", r["path"], "| proxy", d.get("per_rank_proxy", {}).get("ms"),
+              "| decoder", dec.get("frames_per_s"), dec.get("verified"), "| cpu", {k: v for k, v in d.get("cpu_baseline", {}).items() if k.endswith("value")})
+    except Exception as e:
+        print(c, "no line:", repr(e))
 PY
+tail -n 3 $O/${TAG}_asan_loot.log

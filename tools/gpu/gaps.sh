@@ -5,7 +5,7 @@ SOLO="python $REPO/bench.py --steps 1 --warmup 1 --frames 1 --workers 1 --gen-pr
 cd /tmp
 rm -rf $OUT/prof_solo; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_solo -- $SOLO > $OUT/gaps.log 2>&1
 DB=$(find $OUT/prof_solo -name "*_results.db" | head -1)
-python - "$DB" > $OUT/${1:-r03}_gaps_one_frame.txt <<'PY'
+python - "$DB" > $OUT/${1:-r04}_gaps_one_frame.txt <<'PY'
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name,start,end from kernels order by start").fetchall()
@@ -27,5 +27,5 @@ print("# gaps > 40 us: %d, total %.2f ms" % (len(gaps), sum(g for g, _ in gaps) 
 for g, i in gaps:
     print("%8.1f us  after %-34s before %s" % (g / 1e3, nm(rows[i - 1][0]), nm(rows[i][0])))
 PY
-cat $OUT/${1:-r03}_gaps_one_frame.txt
+cat $OUT/${1:-r04}_gaps_one_frame.txt
 rm -rf $OUT/prof_solo
