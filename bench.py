@@ -695,8 +695,10 @@ def main():
     # both durations are reported.
     enc.stage_reset()
     frames[0].reset()
-    enc.phase_a(frames[:1], sharder=T.Sharder())
+    T.load_library().tmc2_set_refine_overlap(1)             # one frame in flight: the library's few-frames-in-flight regime (what a
+    enc.phase_a(frames[:1], sharder=T.Sharder())            # GofEncoder of <= 4 workers sets; scheduling only, never a result)
     enc.phase_b(frames[:1])
+    T.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
     solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
     n_frames = max(1, len(frames))
     N = n_points / n_frames
@@ -791,7 +793,8 @@ def main():
                      "launches": launches, "alone_avg_launch_ms": round(s_avg, 4), "alone_achieved": round(s_ach, 2),
                      "alone_frac": round(s_ach / 8000.0, 5),
                      "algorithmic_MB_per_launch": round(dom_bytes / 1e6, 2),
-                     "what": "the dominant GPU step by time with the GPU to itself, over every timed stage with a contract byte "
+                     "what": "the dominant GPU step by time with the GPU to itself (one frame in flight: the library's "
+                             "few-frames-in-flight regime, tmc2_set_refine_overlap), over every timed stage with a contract byte "
                              "count (SURVEY.md 8d); refine_sweep = one of the %d sweeps of S5 = 4VL + 24V + 26N bytes" % I,
                      "N": int(N), "M": int(M), "V": int(V), "L": round(L, 1),
                      "path": {"B_alg_GB_per_frame": round(b_alg / 1e9, 3), "achieved": round(b_alg * fps / 1e9, 1),

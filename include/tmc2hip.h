@@ -124,7 +124,8 @@ void tmc2_set_kdtree_placement( int mode );
 /* process-wide: tmc2_segmenter_compute queues the geometry of the refinement (S5: voxels, neighbourhood rows -- it needs the
  * points only) before the host-resident walk of the normal orientation (S3) and builds it while the host walks.  Shortens a
  * frame's chain (few frames in flight: one rank of a many-GPU run); with the chip full of other frames it only competes with
- * them -- off by default.  Never changes a result.                                                               */
+ * them -- off by default.  The same setting makes the two kernels of a refinement sweep take the grids that are fastest with
+ * the GPU to themselves (twice the workgroups: idle waves are in nobody's way then).  Never changes a result.        */
 void tmc2_set_refine_overlap( int on );
 /* inspection: the permutation nanoflann's build leaves in vind (tree order -> point index), uint32[n], and the
  * number of tree levels; the search order under distance ties is a function of exactly this permutation */

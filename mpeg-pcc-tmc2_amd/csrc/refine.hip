@@ -1753,7 +1753,7 @@ int RefineJob::finish() {
     const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 512;
     const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
     const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
-                                        : std::min<uint32_t>( 2u * uint32_t( ctx->cuCount ),
+                                        : std::min<uint32_t>( ( refineOverlap() ? 4u : 2u ) * uint32_t( ctx->cuCount ),
                                                               ( V + perGroup * ( closureThreads / 32 ) - 1 ) / ( perGroup * ( closureThreads / 32 ) ) );
     // (two workgroups per CU: 8 % slower alone than four and 3 % more frames per second with sixteen frames in flight -- a
     // workgroup's groups idle through most of the walk, and idle waves are in the way of the other frames' kernels)
@@ -1764,7 +1764,9 @@ int RefineJob::finish() {
     if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
     // (test hook TMC2_REFINE_SWEEP_BLOCKS: the sweep kernel's grid)
     const char* sweepGridEnv = getenv( "TMC2_REFINE_SWEEP_BLOCKS" );
-    const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( 4 ) * ctx->cuCount ) ) );
+    const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap() ? 8 : 4 ) * ctx->cuCount ) ) );
+    // (tmc2_set_refine_overlap( 1 ) = "few frames in flight": the chip has room, so both kernels of a sweep take the grids that
+    //  are fastest with the GPU to themselves -- four closure workgroups and eight sweep workgroups per CU)
     // (round 4 sweep over the grids, 16 frames in flight / one sweep alone: sweep kernel 2 / 4 / 8 / 16 workgroups per CU ->
     //  loot 109.0 / 108.1 / 107.1 / 106.6 frames/s, 338 / 327 / 305 / 289 us; longdress 174.1 / 174.9 frames/s, 54.8 / 51.9 us;
     //  closure 1 / 2 / 4 / 8 per CU -> loot 109.3 / 109.0 / 107.8 / 107.1 frames/s, 434 / 338 / 308 / 291 us: all within

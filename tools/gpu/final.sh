@@ -5,6 +5,7 @@
 TAG=${1:-r04}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 REPO=$(pwd); O=$REPO/gpurun_out
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $O/${TAG}_smoke.log | cut -c1-200
 bash profiles/collect.sh $TAG
 cp $O/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # (bench.py reads profiles/; the copy travels back in gpurun_out/)
 cd /tmp
