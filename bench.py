@@ -693,11 +693,12 @@ def main():
     # event-bracketed time in the region says how long it was in flight, not how much of the GPU it needs.  The kernel the
     # roofline is reported for is therefore chosen by its time with the GPU to itself (one frame, outside the timing);
     # both durations are reported.
-    enc.stage_reset()
-    frames[0].reset()
     T.load_library().tmc2_set_refine_overlap(1)             # one frame in flight: the library's few-frames-in-flight regime (what a
-    enc.phase_a(frames[:1], sharder=T.Sharder())            # GofEncoder of <= 4 workers sets; scheduling only, never a result)
-    enc.phase_b(frames[:1])
+    for warm in (True, False):                              # GofEncoder of <= 4 workers sets; scheduling only, never a result);
+        enc.stage_reset()                                   # once untimed: the regime holds its buffers in another order, and the
+        frames[0].reset()                                   # context's pool has to have seen that (first-use hipMallocs otherwise)
+        enc.phase_a(frames[:1], sharder=T.Sharder())
+        enc.phase_b(frames[:1])
     T.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
     solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
     n_frames = max(1, len(frames))

@@ -14,7 +14,12 @@ oracle = ob.Oracle()
 ctx = T.Context(0)
 stats = collections.Counter()
 HOOKS = {"TMC2_REFINE_RING": [None, "1", "3", "40"], "TMC2_REFINE_CLOSURE_BLOCKS": [None, "1", "2", "7", "100"],
-         "TMC2_REFINE_CLOSURE_THREADS": [None, "64", "256", "1024"], "TMC2_KD_HUGEMAX": [None, "8192", "10000", "16384", "131072"]}
+         "TMC2_REFINE_CLOSURE_THREADS": [None, "64", "256", "1024"], "TMC2_KD_HUGEMAX": [None, "8192", "10000", "16384", "131072"],
+         # round 4: S5's neighbourhood forms (row-wise through the occupancy bitmap / cell by cell), the LDS tier the row-wise kernels
+         # start in, the sweep kernel's grid, the pair table of the orientation's contraction
+         "TMC2_REFINE_NEIGHBOURHOOD": [None, None, "cells"], "TMC2_REFINE_CAPTIER": [None, None, "1", "2"],
+         "TMC2_REFINE_SWEEP_BLOCKS": [None, "1", "64", "4096"], "TMC2_ORIENT_PAIRS": [None, None, "6", "10"],
+         "TMC2_ORIENT_SPEC": [None, None, "64,16"]}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(31000 + seed)
     kind = int(rng.integers(0, 4))
@@ -47,6 +52,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             why.append("knn%d" % k)
     if len(xyz) <= 60000:
         nrm = oracle.normals(xyz)
+        T.load_library().tmc2_set_refine_overlap(int(rng.integers(0, 2)))     # (few frames in flight: other grids, geometry ahead)
+        fr.normals_compute(16, 1)                     # S2 + S3 on the device: contraction (every strong edge inside a cluster checked),
+        if not np.array_equal(fr.get_normals().view(np.uint64), nrm.view(np.uint64)):   # threshold ladder, compact walk
+            why.append("normals")
         p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
         vox = int(rng.choice([4, 2])); it = int(rng.integers(2, 9))
         fr.set_normals(nrm); fr.set_partition(p0)
