@@ -65,7 +65,7 @@ BENCH_CONFIGS = {
     "loot": "loot_vox10_ai_r3_gof32",
     "redandblack": "redandblack_vox10_ai_r3_gof32",
     "soldier": "soldier_vox10_ai_r3_gof32",
-    "basketball": "basketball_player_vox11_ra_r5_gof8",
+    "basketball": "basketball_player_vox11_ra_r5_gof32",
 }
 
 PACKING_NAME = {0: "all-intra", 1: "low-delay", 2: "random-access"}
