@@ -63,6 +63,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             fr.segmenter_refine_grid_based(1024, 3.0, it, vox, 192)
         except T.Tmc2Error as e:                      # (a refusal -- e.g. a grid the dense voxel table does not take -- is not a mismatch)
             stats["refine_refused"] += 1
+            print("refused", seed, kind, len(xyz), vox, env, str(e)[:160], flush=True)
             fr.close()
             continue
         if not np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=it, vox_dim=vox)):
