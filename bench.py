@@ -4,12 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one GOF (default: 32 synthetic longdress_vox10-like frames,
-~0.84 M points each, CTC all-intra r3 flags: 50 refine iterations, occupancyPrecision 4, 1280x1280 minimum canvas).
+One "step" = one pass of the hot path over one GOF (default, --config longdress: 32 synthetic longdress_vox10-like frames,
+~0.84 M points each, CTC all-intra r3 flags: 50 refine iterations, occupancyPrecision 4, 1280x1280 minimum canvas; --config
+loot | redandblack | soldier | basketball: the other BASELINE configurations with their own CTC parameters, tmc2_amd/configs.py).
 Frames are sharded frame f -> rank f % N (strong scaling: the GOF is fixed); the only collectives are the
-24-byte axis-weight broadcast, the canvas-height all-reduce(max) and the final gather of the finished canvases to
-rank 0 (RCCL over xGMI).  The point arrays are resident in HBM before the timed region starts; everything from the
-k-d tree build to the finished, host-resident canvases on rank 0 is inside it.
+24-byte axis-weight broadcast, the canvas-height all-reduce(max) and one gather of the packed patch records to rank 0 (RCCL over
+xGMI); every rank copies its frames' finished canvases into page-locked shared host memory over its own PCIe link (--gather
+rccl: gathered to rank 0 first, round 3's route).  The point arrays are resident in HBM before the timed region starts;
+everything from the k-d tree build to the finished, host-resident canvases is inside it.  "verified": every frame of the last
+timed step against the unmodified reference's digests (tests/golden/full_size.npz); "decoder": the decoder side of the same
+GOF (reconstruct + post-reconstruction tail + D1/D2 metric per frame), timed and verified separately.
 
 Printed JSON (one line, rank 0): metric/value/unit as BASELINE.json, plus
   roofline     -- the dominant GPU step of the timed region, chosen over ALL timed stages by GPU time with the GPU to

@@ -446,6 +446,27 @@ def test_host_orientation_one_way_strong_edge_inside_a_cluster(oracle):
     assert hashlib.md5(np.ascontiguousarray(got).tobytes()).hexdigest() == str(g["redandblack_vox10_ai_r3_gof32/f26_src_normals_md5"])
 
 
+def test_every_bench_configuration_has_its_reference_fixture():
+    """`bench.py --config <name>` verifies what it timed against the digests of the unmodified reference: every configuration of
+    tmc2_amd/configs.py BENCH_CONFIGS (and every soak case) must be in tests/golden/full_size.npz with ALL its frames --
+    encoder side (10 digests a frame) and decoder side (I420, 4 post-reconstruction digests, source normals, metric doubles)."""
+    from tmc2_amd.configs import BENCH_CONFIGS, FULL_SIZE_CASES
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_size.npz"))
+    names = set(g.files)
+    for short, case in BENCH_CONFIGS.items():
+        c = FULL_SIZE_CASES[case]
+        assert c["frames"] == 32, (short, case)                      # BASELINE.json: 32-frame GOFs
+        for f in range(c["frames"]):
+            for k in ("counts", "patches_md5", "occupancy_md5", "occ_video_md5", "block_to_patch_md5", "geo0_md5", "geo1_md5",
+                      "recon_xyz_md5", "recon_rgb_md5", "point_to_pixel_md5", "attribute_md5", "i420_md5", "dec444_md5",
+                      "post_xyz_md5", "post_colors16_md5", "post_rgb_md5", "post_boundary_md5", "src_normals_md5"):
+                assert "%s/f%d_%s" % (case, f, k) in names, (case, f, k)
+            assert g["%s/f%d_post_metrics" % (case, f)].shape == (3, 8)
+    for case, c in FULL_SIZE_CASES.items():
+        assert case + "/canvas" in names and case + "/input_md5" in names, case
+        assert len(str(g[case + "/input_md5"])) == 64 * c["frames"]
+
+
 def test_native_front_end_builds_and_fails_loudly_without_a_gpu(tmp_path):
     """integration/tmc2_encode_gof.cpp (a C++ host front end over the C-ABI, the whole GOF path) compiles against
     include/tmc2hip.h alone and, on a machine without an MI355X, stops with the library's "no device" error instead of
