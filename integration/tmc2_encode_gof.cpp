@@ -32,6 +32,11 @@
 #include <thread>
 #include <vector>
 
+#include <fstream>
+#include <map>
+#include <pthread.h>
+#include <sched.h>
+
 #include "tmc2hip.h"
 
 namespace {
@@ -130,6 +135,41 @@ struct Frame {
   int32_t              height = 0;
 };
 
+// One core per slot, spread over the last-level caches (one entry per CCD on EPYC; SMT siblings dropped): the host-resident steps
+// of a frame (the orientation walk, the packers) are cache- and latency-bound, so sixteen of them should not share two L3s.
+// (What tmc2_amd/gof.py does for bench.py's workers.)  Empty when the topology cannot be read: the threads stay unpinned.
+std::vector<int> coresByCacheDomain() {
+  cpu_set_t allowed;
+  CPU_ZERO( &allowed );
+  if ( sched_getaffinity( 0, sizeof( allowed ), &allowed ) != 0 ) return {};
+  std::map<std::string, std::vector<int>> domains;
+  auto firstOf = []( const std::string& list ) { return std::atoi( list.c_str() ); };  // "0,128" / "0-7,128-135" -> 0
+  for ( int cpu = 0; cpu < CPU_SETSIZE; ++cpu ) {
+    if ( !CPU_ISSET( cpu, &allowed ) ) continue;
+    const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string( cpu ) + "/";
+    std::ifstream     sib( base + "topology/thread_siblings_list" ), l3( base + "cache/index3/shared_cpu_list" );
+    std::string       s, d;
+    if ( !std::getline( sib, s ) || !std::getline( l3, d ) ) return {};
+    if ( firstOf( s ) != cpu ) continue;  // the second hardware thread of a core already listed
+    domains[d].push_back( cpu );
+  }
+  std::vector<int> order;  // round-robin over the domains
+  for ( size_t k = 0;; ++k ) {
+    bool any = false;
+    for ( auto& kv : domains )
+      if ( k < kv.second.size() ) order.push_back( kv.second[k] ), any = true;
+    if ( !any ) break;
+  }
+  return order;
+}
+void pinThisThread( const std::vector<int>& cores, int slot ) {
+  if ( cores.empty() ) return;
+  cpu_set_t one;
+  CPU_ZERO( &one );
+  CPU_SET( cores[size_t( slot ) % cores.size()], &one );
+  (void)pthread_setaffinity_np( pthread_self(), sizeof( one ), &one );
+}
+
 // run fn( frameIndex ) for every frame on `workers` threads; worker w owns context w
 template <typename Fn>
 void forFrames( int frames, int workers, Fn fn ) {
@@ -174,7 +214,16 @@ int main( int argc, char** argv ) {
   const int slots   = D * workers;
   auto      slotOf  = [&]( int i ) { return ( i % D ) * workers + ( i / D ) % workers; };
   std::vector<tmc2_ctx*> ctx( size_t( slots ), nullptr );
-  for ( int s = 0; s < slots; ++s ) CHECK( tmc2_ctx_create( o.devices[size_t( s / workers )], &ctx[size_t( s )] ) );
+  {  // a slot's context is created by a thread pinned to the slot's core: its page-locked staging lands on that core's NUMA node
+    const std::vector<int>   cores = coresByCacheDomain();
+    std::vector<std::thread> makers;
+    for ( int s = 0; s < slots; ++s )
+      makers.emplace_back( [&, s] {
+        pinThisThread( cores, s );
+        CHECK( tmc2_ctx_create( o.devices[size_t( s / workers )], &ctx[size_t( s )] ) );
+      } );
+    for ( auto& t : makers ) t.join();
+  }
   tmc2_set_host_parallelism( 16 );
   tmc2_set_refine_overlap( workers <= 4 ? 1 : 0 );  // few frames in flight per device: shorten a frame's chain (include/tmc2hip.h)
   tmc2_set_kdtree_placement( 0 );  // device trees (round 2: the device build beats the host build at every number of frames in flight)
@@ -199,10 +248,12 @@ int main( int argc, char** argv ) {
                               &gof[size_t( i )].f ) );
 
   std::vector<std::thread> pool;
+  const std::vector<int>   cores = coresByCacheDomain();
   auto perFrame = [&]( auto fn ) {  // frames of one slot in order, slots in parallel
     pool.clear();
     for ( int sl = 0; sl < slots; ++sl )
       pool.emplace_back( [&, sl] {
+        pinThisThread( cores, sl );
         for ( int i = 0; i < o.frames; ++i )
           if ( slotOf( i ) == sl ) fn( gof[size_t( i )], i );
       } );
