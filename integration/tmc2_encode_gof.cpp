@@ -207,6 +207,9 @@ int main( int argc, char** argv ) {
     usage();
     return 1;
   }
+  // one hardware queue per in-flight frame: the HIP runtime multiplexes streams onto 4 hardware queues by default, and streams that
+  // share a queue serialise behind each other (must be set before the runtime initialises; a setting of the user wins)
+  setenv( "GPU_MAX_HW_QUEUES", "16", 0 );
   // slots: ( device shard d, worker w ) -> one host thread + one context (a HIP stream + allocator each); frame i lives on
   // shard i % D, worker ( i / D ) % workers of that shard, for its whole life
   const int D       = int( o.devices.size() );
