@@ -66,6 +66,10 @@ def parse():
                          "B and after the copies (round 2); one = every frame runs its whole chain on a guessed canvas size, "
                          "the GOF meets at the end (GofEncoder.encode_all_intra: frames in different phases share the chip "
                          "worse -- measured 132 against 152 frames/s)")
+    ap.add_argument("--host", default="auto", choices=["auto", "native", "python"],
+                    help="who drives the C-ABI inside the timed region: native = one tmc2_gof_encode call per GOF (libtmc2gof.so: C++ "
+                         "threads, include/tmc2gof.h), python = GofEncoder's worker threads.  auto: native on one GPU, python "
+                         "with several ranks (the collectives of the sharded GOF are torch.distributed's)")
     ap.add_argument("--pin", type=int, default=1, help="0: plain host buffers instead of page-locked ones for the canvases (for runs "
                     "under a sanitizer runtime, where torch's pinned allocator does not come up; slower copies)")
     ap.add_argument("--gather", default="host", choices=["host", "rccl"],
@@ -620,7 +624,27 @@ def main():
                                    pinned((2, 3, H, W), np.uint8)) for _ in frames]
         return host_cache[(W, H)]
 
+    native = a.host == "native" or (a.host == "auto" and world == 1)
+    if native and world > 1:
+        raise SystemExit("bench.py: --host native drives one process's frames; the sharded GOF (--gpus N) meets over torch.distributed")
+    if native:
+        from tmc2_amd import native_gof
+        native_gof.load_library()                           # (fails here, loudly, if it was not built)
+    capacity = [c["min_w"], c["min_h"]]
+
+    def native_step():
+        # reset, S0, S1-S9 + packing, the rendezvous, S12-S22 and the copies into page-locked host memory: one call into C++
+        while True:
+            try:
+                return native_gof.encode(frames, [i % workers for i in range(len(frames))], workers, a.iterations, c["vox_dim"],
+                                         c["bits3d"], P, c["min_w"], c["min_h"], a.packing, host_out(*capacity), capacity,
+                                         guess_canvas=a.rendezvous == "one")
+            except native_gof.CanvasTooSmall as e:          # (first pass of a GOF that outgrows the minimum canvas)
+                capacity[:] = [max(capacity[0], e.size[0]), max(capacity[1], e.size[1])]
+
     def step():
+        if native:
+            return native_step()
         for fr in frames:
             fr.reset()
         if a.packing == "all-intra" and a.rendezvous == "one":
@@ -792,6 +816,8 @@ def main():
                                 ("; ".join(sorted(set("a /dev/shm segment per rank" if hasattr(v, "close") else str(v) for v in shared.values()))) or "private buffers",
                                  "RCCL" if a.dist_backend == "nccl" else "gloo")) if (world > 1 and a.gather == "host")
                                else ("gathered to rank 0 over RCCL, copied out from there" if world > 1 else "page-locked host memory"),
+                   "host": ("native: one tmc2_gof_encode call per GOF (libtmc2gof.so, C++ threads over the C-ABI)" if native
+                            else "python: GofEncoder's worker threads over the C-ABI"),
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "host_step_slots_per_gpu": slots, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": round(avg_ms, 4),

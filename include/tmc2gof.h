@@ -1,0 +1,46 @@
+/* tmc2gof.h -- a native host for one GOF pass over the C-ABI of libtmc2hip.so (include/tmc2hip.h).
+ *
+ * Replaces, for the path S0-S22, the frame loop of PCCEncoder::encode (PccLibEncoder/source/PCCEncoder.cpp:85-172: generateSegments
+ * -- a tbb::parallel_for over the frames, :4729-4750 -- placeSegments, generateOccupancyMap .. generateGeometryVideo,
+ * generateAttributeVideo) as one call: host threads in C++, one per frame slot, pinned to cores of different last-level caches;
+ * the frames meet once per pass, for the common canvas size (resizeGeometryVideo, :5546-5591).  The frames live on contexts the
+ * caller made (one per slot, any device each: frame f of a sharded GOF on device f mod D); nothing here touches a GPU except
+ * through include/tmc2hip.h.  bench.py times the path through this entry (--host native); integration/tmc2_encode_gof.cpp is
+ * the same schedule as a program.  Built as mpeg-pcc-tmc2_amd/libtmc2gof.so (mpeg-pcc-tmc2_amd/host/Makefile).            */
+#ifndef TMC2GOF_H
+#define TMC2GOF_H
+#include "tmc2hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tmc2_gof_config {
+  int32_t iterationCountRefineSegmentation;  /* cfg/sequence/<name>.cfg: 50 longdress, 10 loot / redandblack / soldier, 20 basketball */
+  int32_t voxelDimensionRefineSegmentation;  /* 4 or 2 */
+  int32_t geometryBitDepth3D;                /* geometry3dCoordinatesBitdepth + 1: 11 (vox10), 12 (vox11) */
+  int32_t occupancyPrecision;                /* 4 (r3), 2 (r5) */
+  int32_t minimumImageWidth, minimumImageHeight;
+  int32_t packing;                           /* 0: all-intra (packFlexible per frame), 1: low-delay (spatial consistency chain),
+                                                2: random-access (the chain + global patch allocation) */
+  int32_t guessCanvas;                       /* all-intra only.  0: the frames meet once, after the packing, for the canvas size.
+                                                1: no frame waits -- each goes through S12-S22 on the canvas its OWN packed height
+                                                gives and only a frame whose guess was short rasterises again (same bytes) */
+} tmc2_gof_config;
+
+/* One pass over the GOF: every frame is reset (tmc2_frame_reset), S0 runs on frame 0, S1-S9 and the packing on `slots` host
+ * threads (frame i on slot slotOf[i] in [0, slots); the frames of one slot in index order), then -- the one rendezvous -- the
+ * canvas size (config->guessCanvas moves it to the end), then per frame the geometry images, the attribute images and the copies of its finished canvases into the
+ * caller's buffers (page-locked: tmc2_host_alloc; per-frame pointer arrays, any array or entry may be NULL):
+ * occupancy u8[W*H], occVideo u8[(W/p)*(H/p)], blockToPatch u32[(W/16)*(H/16)], geometryD0 / D1 u16[W*H], attribute u8[2*3*W*H].
+ * The canvas size is only known after the rendezvous: size the buffers for capacityWidth x capacityHeight; a GOF that needs a
+ * larger canvas fails with TMC2_E_INVALID after the rendezvous (nothing written), *width / *height say what it needs.
+ * Returns TMC2_OK or the first failing status; tmc2_gof_last_error() holds that call's message (of whichever thread failed). */
+int tmc2_gof_encode( tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots, const tmc2_gof_config* config,
+                     uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch, uint16_t** geometryD0, uint16_t** geometryD1,
+                     uint8_t** attribute, int32_t capacityWidth, int32_t capacityHeight, int32_t* width, int32_t* height );
+const char* tmc2_gof_last_error( void );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMC2GOF_H */

@@ -1,0 +1,208 @@
+// gof_runner.cpp -- libtmc2gof.so: the frame loop of a GOF pass as native host code over the C-ABI of libtmc2hip.so
+// (include/tmc2gof.h).  No device code and no HIP call here: threads, the call sequence of INTEGRATION.md section 4, one rendezvous.
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <pthread.h>
+#include <sched.h>
+
+#include "tmc2gof.h"
+
+namespace {
+std::mutex  g_errLock;
+std::string g_err;
+
+// One core per slot, round-robin over the last-level caches (SMT siblings dropped); empty if the topology cannot be read.
+std::vector<int> coresByCacheDomain() {
+  cpu_set_t allowed;
+  CPU_ZERO( &allowed );
+  if ( sched_getaffinity( 0, sizeof( allowed ), &allowed ) != 0 ) return {};
+  std::map<std::string, std::vector<int>> domains;
+  for ( int cpu = 0; cpu < CPU_SETSIZE; ++cpu ) {
+    if ( !CPU_ISSET( cpu, &allowed ) ) continue;
+    const std::string base = "/sys/devices/system/cpu/cpu" + std::to_string( cpu ) + "/";
+    std::ifstream     sib( base + "topology/thread_siblings_list" ), l3( base + "cache/index3/shared_cpu_list" );
+    std::string       s, d;
+    if ( !std::getline( sib, s ) || !std::getline( l3, d ) ) return {};
+    if ( std::atoi( s.c_str() ) != cpu ) continue;
+    domains[d].push_back( cpu );
+  }
+  std::vector<int> order;
+  for ( size_t k = 0;; ++k ) {
+    bool any = false;
+    for ( auto& kv : domains )
+      if ( k < kv.second.size() ) order.push_back( kv.second[k] ), any = true;
+    if ( !any ) break;
+  }
+  return order;
+}
+
+// the CTC lossy settings (cfg/common/ctc-common.cfg + the sequence's), as tmc2_amd.lib.ctc_params
+tmc2_segmenter_params ctcParams( const tmc2_gof_config& c, const double w[3] ) {
+  tmc2_segmenter_params p{};
+  p.nnNormalEstimation = 16, p.normalOrientation = 1, p.gridBasedRefineSegmentation = 1, p.maxNNCountRefineSegmentation = 1024;
+  p.iterationCountRefineSegmentation = c.iterationCountRefineSegmentation;
+  p.voxelDimensionRefineSegmentation = c.voxelDimensionRefineSegmentation, p.searchRadiusRefineSegmentation = 192;
+  p.occupancyResolution = 16, p.enablePatchSplitting = 1, p.maxPatchSize = 1024, p.quantizerSizeX = 16, p.quantizerSizeY = 16;
+  p.minPointCountPerCCPatchSegmentation = 16, p.maxNNCountPatchSegmentation = 16, p.surfaceThickness = 4, p.mapCountMinus1 = 1;
+  p.minLevel = 64, p.maxAllowedDepth = 255, p.geometryBitDepth2D = 8, p.geometryBitDepth3D = c.geometryBitDepth3D;
+  p.maxAllowedDist2RawPointsDetection = 9, p.maxAllowedDist2RawPointsSelection = 1, p.lambdaRefineSegmentation = 3;
+  for ( int k = 0; k < 3; ++k ) p.weightNormal[k] = w[k];
+  return p;
+}
+
+struct Pass {
+  std::atomic<int> status{TMC2_OK};
+  void             fail( int rc, const char* what ) {
+    int expected = TMC2_OK;
+    if ( status.compare_exchange_strong( expected, rc ) ) {
+      std::lock_guard<std::mutex> g( g_errLock );
+      g_err = std::string( what ) + ": " + tmc2_last_error();  // (the failing thread's own message)
+    }
+  }
+};
+#define GOF_TRY( call )                               \
+  do {                                                \
+    const int rc_ = ( call );                         \
+    if ( rc_ != TMC2_OK ) {                           \
+      pass.fail( rc_, #call );                        \
+      return;                                         \
+    }                                                 \
+  } while ( 0 )
+}  // namespace
+
+extern "C" const char* tmc2_gof_last_error( void ) {
+  std::lock_guard<std::mutex> g( g_errLock );
+  static thread_local std::string copy;
+  copy = g_err;
+  return copy.c_str();
+}
+
+extern "C" int tmc2_gof_encode( tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots, const tmc2_gof_config* config,
+                                uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch, uint16_t** geometryD0,
+                                uint16_t** geometryD1, uint8_t** attribute, int32_t capacityWidth, int32_t capacityHeight,
+                                int32_t* width, int32_t* height ) {
+  if ( !frames || !slotOf || !config || count <= 0 || slots <= 0 || !width || !height ) return TMC2_E_INVALID;
+  for ( int i = 0; i < count; ++i )
+    if ( !frames[i] || slotOf[i] < 0 || slotOf[i] >= slots ) return TMC2_E_INVALID;
+  const tmc2_gof_config& c = *config;
+  static const std::vector<int> cores = coresByCacheDomain();
+  Pass                          pass;
+  auto perSlot = [&]( auto fn ) {  // the frames of one slot in order, slots side by side
+    std::vector<std::thread> pool;
+    for ( int sl = 0; sl < slots; ++sl )
+      pool.emplace_back( [&, sl] {
+        if ( !cores.empty() ) {
+          cpu_set_t one;
+          CPU_ZERO( &one );
+          CPU_SET( cores[size_t( sl ) % cores.size()], &one );
+          (void)pthread_setaffinity_np( pthread_self(), sizeof( one ), &one );
+        }
+        for ( int i = 0; i < count; ++i )
+          if ( slotOf[i] == sl && pass.status.load() == TMC2_OK ) fn( i );
+      } );
+    for ( auto& t : pool ) t.join();
+  };
+  for ( int i = 0; i < count; ++i )
+    if ( tmc2_frame_reset( frames[i] ) != TMC2_OK ) return TMC2_E_INVALID;
+  double w[3];
+  {
+    const int rc = tmc2_weight_normal( frames[0], c.geometryBitDepth3D, 0.6, w );  // S0: frame 0 only
+    if ( rc != TMC2_OK ) {
+      pass.fail( rc, "tmc2_weight_normal" );
+      return rc;
+    }
+  }
+  const tmc2_segmenter_params params = ctcParams( c, w );
+  std::vector<int32_t>        heights( static_cast<size_t>( count ), 0 ), guessW( static_cast<size_t>( count ), 0 ),
+      guessH( static_cast<size_t>( count ), 0 );
+  const bool                  chained = c.packing != 0, guess = !chained && c.guessCanvas != 0;
+  const bool anyOut = occupancy || occVideo || blockToPatch || geometryD0 || geometryD1 || attribute;  // (none: nothing leaves the device)
+  if ( !anyOut ) capacityWidth = capacityHeight = INT32_MAX;
+  // what follows the packing of one frame, on a canvas of W x H: S12-S22 and the copies of its finished canvases
+  auto images = [&]( int i, int32_t W, int32_t H ) {
+    if ( W > capacityWidth || H > capacityHeight ) return;  // (refused after the rendezvous, with the size the GOF needs)
+    GOF_TRY( tmc2_encoder_generate_geometry_images( frames[i], W, H, c.occupancyPrecision ) );
+    GOF_TRY( tmc2_encoder_generate_attribute_images( frames[i] ) );
+    auto at = []( auto** arr, int k ) { return arr ? arr[k] : nullptr; };
+    if ( occupancy || occVideo || blockToPatch || geometryD0 || geometryD1 )
+      GOF_TRY( tmc2_frame_get_geometry_images( frames[i], at( occupancy, i ), at( occVideo, i ), at( blockToPatch, i ), at( geometryD0, i ),
+                                               at( geometryD1, i ) ) );
+    if ( attribute && attribute[i] ) GOF_TRY( tmc2_frame_get_attribute_images( frames[i], attribute[i] ) );
+  };
+  // All-intra with guessCanvas: a frame does not wait for the others.  It goes through its whole chain on the canvas ITS OWN packed height gives
+  // (with the CTC sequences: the minimum canvas, for every frame); the rendezvous then only compares, and a frame whose guess
+  // was short rasterises again on the common canvas (same bytes as the two-phase order: the images depend on the final size only).
+  perSlot( [&]( int i ) {
+    GOF_TRY( tmc2_segmenter_compute( frames[i], &params ) );
+    if ( chained ) return;
+    GOF_TRY( tmc2_encoder_pack_flexible( frames[i], c.minimumImageWidth, 2, 1.0, &heights[size_t( i )] ) );
+    if ( !guess ) return;
+    GOF_TRY( tmc2_encoder_canvas_size( &heights[size_t( i )], 1, c.minimumImageWidth, c.minimumImageWidth, c.minimumImageHeight,
+                                       &guessW[size_t( i )], &guessH[size_t( i )] ) );
+    images( i, guessW[size_t( i )], guessH[size_t( i )] );
+  } );
+  if ( pass.status.load() != TMC2_OK ) return pass.status.load();
+  // ---- the rendezvous: the packing chain (if any) and the common canvas size -------------------------------------------------
+  int32_t tileW = c.minimumImageWidth, gofH = 0;
+  if ( chained ) {
+    auto once = [&]( int rc, const char* what ) {
+      if ( rc != TMC2_OK ) pass.fail( rc, what );
+      return rc == TMC2_OK;
+    };
+    if ( !once( tmc2_encoder_pack_flexible( frames[0], c.minimumImageWidth, 2, 1.0, &heights[0] ), "tmc2_encoder_pack_flexible" ) )
+      return pass.status.load();
+    for ( int i = 1; i < count; ++i )
+      if ( !once( tmc2_encoder_pack_spatial_consistency( frames[i], frames[i - 1], c.minimumImageWidth, 2, 1.0, &heights[size_t( i )] ),
+                  "tmc2_encoder_pack_spatial_consistency" ) )
+        return pass.status.load();
+    if ( c.packing == 2 ) {
+      std::vector<int32_t> widths( static_cast<size_t>( count ), 0 );
+      if ( !once( tmc2_encoder_global_patch_allocation( frames, count, c.minimumImageWidth, c.minimumImageHeight, widths.data(), heights.data() ),
+                  "tmc2_encoder_global_patch_allocation" ) )
+        return pass.status.load();
+      for ( int i = 0; i < count; ++i ) {
+        tileW                = std::max( tileW, widths[size_t( i )] );
+        heights[size_t( i )] = std::max( heights[size_t( i )], c.minimumImageHeight );
+      }
+    } else {
+      for ( int i = 0; i < count; ++i ) {
+        int32_t pw = 0;
+        if ( !once( tmc2_frame_get_packed_size( frames[i], &pw, nullptr ), "tmc2_frame_get_packed_size" ) ) return pass.status.load();
+        tileW = std::max( tileW, pw );
+      }
+    }
+  }
+  for ( int i = 0; i < count; ++i ) gofH = std::max( gofH, heights[size_t( i )] );
+  int32_t W = 0, H = 0;
+  {
+    const int rc = tmc2_encoder_canvas_size( &gofH, 1, tileW, c.minimumImageWidth, c.minimumImageHeight, &W, &H );
+    if ( rc != TMC2_OK ) {
+      pass.fail( rc, "tmc2_encoder_canvas_size" );
+      return rc;
+    }
+  }
+  *width = W, *height = H;
+  if ( W > capacityWidth || H > capacityHeight ) {
+    std::lock_guard<std::mutex> g( g_errLock );
+    char                        msg[160];
+    std::snprintf( msg, sizeof( msg ), "tmc2_gof_encode: the GOF needs a %d x %d canvas, the buffers hold %d x %d", W, H, capacityWidth, capacityHeight );
+    g_err = msg;
+    return TMC2_E_INVALID;
+  }
+  // ---- from here the frames are independent: images, attribute images, copies, each on its slot -----------------------------
+  perSlot( [&]( int i ) {
+    if ( guess && guessW[size_t( i )] == W && guessH[size_t( i )] == H ) return;  // (already there)
+    images( i, W, H );
+  } );
+  return pass.status.load();
+}

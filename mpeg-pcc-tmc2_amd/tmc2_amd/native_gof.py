@@ -1,0 +1,81 @@
+"""The native host of a GOF pass: libtmc2gof.so (include/tmc2gof.h, mpeg-pcc-tmc2_amd/host/gof_runner.cpp) behind ctypes.
+
+GofEncoder (gof.py) drives the C-ABI from Python worker threads; this hands the same pass -- reset, S0, S1-S9 + packing per
+frame, one rendezvous for the canvas, S12-S22, the copies of the finished canvases -- to C++ threads in one call, which is what
+the reference's own host is (PCCEncoder::encode, PccLibEncoder/source/PCCEncoder.cpp:85-172, with its tbb::parallel_for over the
+frames at :4729-4750).  Same C-ABI calls in the same order per frame, so the same bytes; no interpreter between the launches.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import lib as _lib
+
+PACKING = {"all-intra": 0, "low-delay": 1, "random-access": 2}
+_GOF = None
+
+
+class GofConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("iterationCountRefineSegmentation", "voxelDimensionRefineSegmentation", "geometryBitDepth3D",
+                                         "occupancyPrecision", "minimumImageWidth", "minimumImageHeight", "packing", "guessCanvas")]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(_lib.library_path()), "libtmc2gof.so")
+
+
+def load_library():
+    """Load libtmc2gof.so (after libtmc2hip.so, which it links against); raises if it has not been built."""
+    global _GOF
+    if _GOF is None:
+        _lib.load_library()
+        path = library_path()
+        if not os.path.exists(path):
+            raise _lib.Tmc2Error("libtmc2gof.so not built: run `python __graft_entry__.py build` (make -C mpeg-pcc-tmc2_amd/host)")
+        G = C.CDLL(path)
+        G.tmc2_gof_last_error.restype = C.c_char_p
+        _GOF = G
+    return _GOF
+
+
+def _pointers(arrays, dtype):
+    if arrays is None:
+        return None
+    out = (C.c_void_p * len(arrays))()
+    for i, x in enumerate(arrays):
+        if x is not None:
+            assert x.dtype == dtype and x.flags["C_CONTIGUOUS"]
+            out[i] = x.ctypes.data
+    return out
+
+
+class CanvasTooSmall(_lib.Tmc2Error):
+    def __init__(self, W, H):
+        super().__init__("the GOF needs a %d x %d canvas" % (W, H))
+        self.size = (W, H)
+
+
+def encode(frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w, min_h, packing, out, capacity, guess_canvas=False):
+    """One pass over the GOF (tmc2_gof_encode).  frames: lib.Frame; slot_of[i]: the host thread of frame i (the frames of one
+    context on one slot); out: per frame (dict(occupancy, occ_video, block_to_patch, geo0, geo1), attribute) numpy buffers sized
+    for capacity = (W, H), or None (nothing leaves the device).  Returns (W, H); raises CanvasTooSmall with the size the GOF needs."""
+    G = load_library()
+    n = len(frames)
+    cfg = GofConfig(iterations, vox_dim, bits3d, precision, min_w, min_h, PACKING[packing] if isinstance(packing, str) else int(packing),
+                    int(bool(guess_canvas)))
+    handles = (C.c_void_p * n)(*[fr.h.value for fr in frames])
+    slot = (C.c_int32 * n)(*[int(s) for s in slot_of])
+    col = (lambda k, dt: _pointers([o[0][k] for o in out], dt)) if out is not None else (lambda k, dt: None)
+    W, H = C.c_int32(0), C.c_int32(0)
+    rc = G.tmc2_gof_encode(handles, slot, n, int(slots), C.byref(cfg), col("occupancy", np.uint8), col("occ_video", np.uint8),
+                           col("block_to_patch", np.uint32), col("geo0", np.uint16), col("geo1", np.uint16),
+                           _pointers([o[1] for o in out], np.uint8) if out is not None else None,
+                           int(capacity[0]), int(capacity[1]), C.byref(W), C.byref(H))
+    if rc != 0:
+        if W.value > capacity[0] or H.value > capacity[1]:
+            raise CanvasTooSmall(W.value, H.value)
+        raise _lib.Tmc2Error("tmc2gof error %d: %s" % (rc, G.tmc2_gof_last_error().decode()))
+    for fr in frames:                                         # (what Frame.encoder_generate_geometry_images notes for its getters)
+        fr._canvas = (W.value, H.value, int(precision))
+    return W.value, H.value

@@ -26,6 +26,29 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in tmc2hip.h but not exported: %s" % missing
 
 
+def test_native_gof_host_exports_its_header_and_refuses_bad_arguments():
+    """libtmc2gof.so (include/tmc2gof.h): every declared entry is exported; argument errors come back as TMC2_E_INVALID before
+    any device work (no GPU here)."""
+    import ctypes as C
+    from tmc2_amd import native_gof
+    hdr = open(os.path.join(ROOT, "include", "tmc2gof.h")).read()
+    names = sorted(set(re.findall(r"\b(tmc2_gof_[a-z0-9_]+)\s*\(", hdr)))
+    assert names == ["tmc2_gof_encode", "tmc2_gof_last_error"]
+    G = native_gof.load_library()
+    assert not [n for n in names if not hasattr(G, n)]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert not [n for n in names if n not in doc], "not in INTEGRATION.md"
+    cfg = native_gof.GofConfig(10, 4, 11, 4, 1280, 1280, 0, 0)
+    W, H = C.c_int32(0), C.c_int32(0)
+    invalid = int(re.search(r"#define TMC2_E_INVALID (-?\d+)", open(os.path.join(ROOT, "include", "tmc2hip.h")).read()).group(1))
+    none = None
+    assert G.tmc2_gof_encode(none, none, 0, 1, C.byref(cfg), none, none, none, none, none, none, 1280, 1280, C.byref(W), C.byref(H)) == invalid
+    handles, slot = (C.c_void_p * 1)(None), (C.c_int32 * 1)(0)
+    assert G.tmc2_gof_encode(handles, slot, 1, 1, C.byref(cfg), none, none, none, none, none, none, 1280, 1280, C.byref(W), C.byref(H)) == invalid
+    handles, slot = (C.c_void_p * 1)(1), (C.c_int32 * 1)(3)   # slot out of range: refused before the handle is touched
+    assert G.tmc2_gof_encode(handles, slot, 1, 2, C.byref(cfg), none, none, none, none, none, none, 1280, 1280, C.byref(W), C.byref(H)) == invalid
+
+
 def test_every_declared_symbol_is_bound_and_documented():
     """Each entry of include/tmc2hip.h has its ctypes binding (tmc2_amd/lib.py) and its reference counterpart in
     INTEGRATION.md -- the drop-in boundary stays in step with its documentation."""
