@@ -112,8 +112,13 @@ extern "C" int tmc2_gof_encode( tmc2_frame** frames, const int32_t* slotOf, int3
       } );
     for ( auto& t : pool ) t.join();
   };
-  for ( int i = 0; i < count; ++i )
-    if ( tmc2_frame_reset( frames[i] ) != TMC2_OK ) return TMC2_E_INVALID;
+  for ( int i = 0; i < count; ++i ) {
+    const int rc = tmc2_frame_reset( frames[i] );
+    if ( rc != TMC2_OK ) {
+      pass.fail( rc, "tmc2_frame_reset" );
+      return rc;
+    }
+  }
   double w[3];
   {
     const int rc = tmc2_weight_normal( frames[0], c.geometryBitDepth3D, 0.6, w );  // S0: frame 0 only

@@ -1,0 +1,104 @@
+// mock_tmc2hip.cpp -- test infrastructure: the entries of include/tmc2hip.h that libtmc2gof.so (mpeg-pcc-tmc2_amd/host/gof_runner.cpp)
+// calls, as a recorder without a device.  tests/test_native_gof_schedule.py builds the runner against this and checks the
+// schedule it drives: which calls, on which frame, in which order per slot, what happens on a failure.  Never shipped.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tmc2hip.h"
+
+struct tmc2_frame {
+  int32_t id, packedHeight, packedWidth, failAt;  // failAt: the call code that fails on this frame (0: none)
+  int32_t canvasW, canvasH;
+};
+
+namespace {
+enum Call { RESET = 1, WEIGHT, SEGMENT, PACK_FLEXIBLE, PACK_CHAIN, GPA, PACKED_SIZE, GEOMETRY, ATTRIBUTE, GET_GEOMETRY, GET_ATTRIBUTE };
+struct Event {
+  int32_t  call, frame, a, b;
+  uint64_t thread;
+};
+std::mutex                      g_lock;
+std::vector<Event>              g_log;
+static thread_local std::string g_err;
+
+int note( int call, tmc2_frame* f, int a = 0, int b = 0 ) {
+  {
+    std::lock_guard<std::mutex> g( g_lock );
+    g_log.push_back( {call, f ? f->id : -1, a, b, uint64_t( std::hash<std::thread::id>()( std::this_thread::get_id() ) )} );
+  }
+  if ( f && f->failAt == call ) {
+    char msg[96];
+    std::snprintf( msg, sizeof( msg ), "mock failure of call %d on frame %d", call, f->id );
+    g_err = msg;
+    return TMC2_E_HIP;
+  }
+  return TMC2_OK;
+}
+}  // namespace
+
+extern "C" {
+tmc2_frame* mock_frame( int32_t id, int32_t packedHeight, int32_t packedWidth, int32_t failAt ) {
+  return new tmc2_frame{id, packedHeight, packedWidth, failAt, 0, 0};
+}
+void    mock_frame_free( tmc2_frame* f ) { delete f; }
+void    mock_log_clear() { std::lock_guard<std::mutex> g( g_lock ); g_log.clear(); }
+int32_t mock_log_size() { std::lock_guard<std::mutex> g( g_lock ); return int32_t( g_log.size() ); }
+void    mock_log_get( int32_t i, int32_t* call, int32_t* frame, int32_t* a, int32_t* b, uint64_t* thread ) {
+  std::lock_guard<std::mutex> g( g_lock );
+  const Event&                e = g_log[size_t( i )];
+  *call = e.call, *frame = e.frame, *a = e.a, *b = e.b, *thread = e.thread;
+}
+
+const char* tmc2_last_error( void ) { return g_err.c_str(); }
+int         tmc2_frame_reset( tmc2_frame* f ) { return note( RESET, f ); }
+int         tmc2_weight_normal( tmc2_frame* f, int bits3d, double threshold, double* weights ) {
+  weights[0] = 1.0, weights[1] = 1.5, weights[2] = double( bits3d ) + threshold;
+  return note( WEIGHT, f, bits3d );
+}
+int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
+  // the parameters the runner derives: the iteration count and the weight it took from frame 0 travel in the log
+  return note( SEGMENT, f, p->iterationCountRefineSegmentation, int( p->weightNormal[2] * 10.0 + 0.5 ) );
+}
+int tmc2_encoder_pack_flexible( tmc2_frame* f, int, int, double, int32_t* height ) {
+  *height = f->packedHeight;
+  return note( PACK_FLEXIBLE, f );
+}
+int tmc2_encoder_pack_spatial_consistency( tmc2_frame* f, tmc2_frame* previous, int, int, double, int32_t* height ) {
+  *height = f->packedHeight;
+  return note( PACK_CHAIN, f, previous->id );
+}
+int tmc2_encoder_global_patch_allocation( tmc2_frame** frames, int count, int, int, int32_t* widths, int32_t* heights ) {
+  for ( int i = 0; i < count; ++i ) widths[i] = frames[i]->packedWidth, heights[i] = frames[i]->packedHeight + 16;  // (the GPA repacks)
+  return note( GPA, frames[0], count );
+}
+int tmc2_frame_get_packed_size( tmc2_frame* f, int32_t* width, int32_t* height ) {
+  if ( width ) *width = f->packedWidth;
+  if ( height ) *height = f->packedHeight;
+  return note( PACKED_SIZE, f );
+}
+int tmc2_encoder_canvas_size( const int32_t* heights, int frames, int tileWidth, int minW, int minH, int32_t* width, int32_t* height ) {
+  int32_t h = 0;
+  for ( int i = 0; i < frames; ++i ) h = std::max( h, heights[i] );
+  *width  = std::max( tileWidth, minW );
+  *height = std::max( ( h + 63 ) / 64 * 64, minH );
+  return TMC2_OK;
+}
+int tmc2_encoder_generate_geometry_images( tmc2_frame* f, int width, int height, int ) {
+  f->canvasW = width, f->canvasH = height;
+  return note( GEOMETRY, f, width, height );
+}
+int tmc2_encoder_generate_attribute_images( tmc2_frame* f ) { return note( ATTRIBUTE, f ); }
+int tmc2_frame_get_geometry_images( tmc2_frame* f, uint8_t* occupancy, uint8_t*, uint32_t*, uint16_t*, uint16_t* ) {
+  if ( occupancy ) memset( occupancy, 1 + f->id, size_t( f->canvasW ) * size_t( f->canvasH ) );  // (a buffer too small would show)
+  return note( GET_GEOMETRY, f, f->canvasW, f->canvasH );
+}
+int tmc2_frame_get_attribute_images( tmc2_frame* f, uint8_t* attribute ) {
+  if ( attribute ) attribute[0] = uint8_t( 100 + f->id );
+  return note( GET_ATTRIBUTE, f );
+}
+}
