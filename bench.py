@@ -554,6 +554,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.host == "native" and world > 1:
+        raise SystemExit("bench.py: --host native drives one process's frames; the sharded GOF (--gpus N) meets over torch.distributed")
     import numpy as np
     import tmc2_amd as T
     if a.frames % world:
@@ -628,8 +630,6 @@ def main():
         return host_cache[(W, H)]
 
     native = a.host == "native" or (a.host == "auto" and world == 1)
-    if native and world > 1:
-        raise SystemExit("bench.py: --host native drives one process's frames; the sharded GOF (--gpus N) meets over torch.distributed")
     if native:
         from tmc2_amd import native_gof
         native_gof.load_library()                           # (fails here, loudly, if it was not built)
