@@ -129,9 +129,11 @@ class _Worker(threading.Thread):
     def __init__(self, index, device, cpu, timing):
         super().__init__(daemon=True)
         self.index, self.device, self.cpu, self.timing = index, device, cpu, timing
-        self.jobs, self.ctx, self.ready = queue.Queue(), None, threading.Event()
+        self.jobs, self.ctx, self.ready, self.failed = queue.Queue(), None, threading.Event(), None
         self.start()
         self.ready.wait()
+        if self.failed is not None:                           # (no device, no memory ..: the caller hears it, nobody waits for ever)
+            raise self.failed
 
     def run(self):
         if self.cpu is not None:
@@ -139,9 +141,14 @@ class _Worker(threading.Thread):
                 os.sched_setaffinity(0, {self.cpu})          # applies to the calling thread
             except OSError:
                 pass
-        self.ctx = lib.Context(self.device)
-        self.ctx.set_timing(self.timing)
-        self.ready.set()
+        try:
+            self.ctx = lib.Context(self.device)
+            self.ctx.set_timing(self.timing)
+        except BaseException as e:
+            self.failed = e
+            return
+        finally:
+            self.ready.set()
         while True:
             job = self.jobs.get()
             if job is None:

@@ -667,3 +667,25 @@ def test_reference_tbb_build_gives_the_serial_results(reference):
         assert all(np.array_equal(x[k], y[k]) for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"))
     for x, y in zip(b1, b4):
         assert all(np.array_equal(x[k], y[k]) for k in ("recon_xyz", "recon_rgb", "point_to_pixel", "attribute"))
+
+
+def test_gof_encoder_without_a_device_fails_instead_of_waiting():
+    """A worker whose context cannot be created (here: no HIP device) hands the error to the constructor; before round 4's
+    end the thread died with it and `GofEncoder( .. )` -- and `python bench.py` on a box without a GPU -- waited for ever."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import threading
+    result = []
+
+    def make():
+        try:
+            T.GofEncoder(0, 2, 3, 11, 4, 256, 256)
+            result.append("made")
+        except T.Tmc2Error as e:
+            result.append(str(e))
+    w = threading.Thread(target=make, daemon=True)
+    w.start()
+    w.join(60)
+    assert not w.is_alive(), "GofEncoder() is still waiting for a worker that died"
+    assert result and "no HIP device" in result[0]
