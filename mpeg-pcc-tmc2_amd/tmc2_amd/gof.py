@@ -188,12 +188,14 @@ class GofEncoder:
         # walk -- it shortens a frame's chain; with the chip full it would only compete (include/tmc2hip.h)
         if os.environ.get("TMC2_REFINE_OVERLAP") is None:
             lib.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
+        self.closed = False
         self.threads = [_Worker(w, device, cpus[w], timing) for w in range(workers)]
         self.ctxs = [t.ctx for t in self.threads]
 
     def close(self, join=False):
         """Ends the worker threads; join=True also waits for them and closes their contexts (every frame of this encoder must
         have been closed before: a frame's device buffers go back to its context's pool)."""
+        self.closed = True
         for t in self.threads:
             t.jobs.put(None)
         if join:
@@ -225,6 +227,8 @@ class GofEncoder:
                 for j, fn in lst:
                     out[j] = fn()
             d = _Done()
+            if self.closed or not self.threads[w].is_alive():
+                raise lib.Tmc2Error("GofEncoder: worker %d has ended (close() was called): nobody would answer this call" % w)
             self.threads[w].jobs.put((run, d))
             waits.append(d)
         for d in waits:
