@@ -2,7 +2,9 @@
 """bench.py -- encoder patch-generation + image-generation throughput (frames/s) on a 32-frame GOF.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    (N > 1: under python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...,
+     or bare: without WORLD_SIZE in the environment bench.py starts that launcher itself; either way the ranks that came up must
+     be the N asked for, and the collectives of the sharded GOF run once as a pre-flight before the set-up)
 
 One "step" = one pass of the hot path over one GOF (default, --config longdress: 32 synthetic longdress_vox10-like frames,
 ~0.84 M points each, CTC all-intra r3 flags: 50 refine iterations, occupancyPrecision 4, 1280x1280 minimum canvas; --config
@@ -84,6 +86,9 @@ def parse():
                     help="N > 1: nccl = RCCL, one GPU per rank; gloo = control plane on the CPU and rank r on GPU r mod the visible "
                          "ones (several ranks share a GPU: for trying the N > 1 path on a one-GPU box)")
     ap.add_argument("--cpu-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--preflight-only", type=int, default=0, help="1: bring the process group of --gpus N ranks up, run the pre-flight "
+                    "collectives (broadcast, all-reduce, gather) and print {\"preflight\": \"ok\", \"n_gpus\": N}: no GPU work (with "
+                    "--dist-backend gloo it runs on a box without a GPU)")
     ap.add_argument("--packing", default=None, choices=["all-intra", "low-delay", "random-access"],
                     help="S10 condition (default: the configuration's): every frame on its own, the spatial-consistency chain, "
                          "or the chain + global patch allocation (with several ranks the chain runs on rank 0 over the patch records)")
@@ -138,14 +143,73 @@ def under_profiler():
 
 
 def make_frames(workload, indices, gen_procs=0):
+    return start_frames(workload, indices, gen_procs)()
+
+
+def start_frames(workload, indices, gen_procs=0):
+    """Starts the synthetic frames' generation in forked processes (BEFORE any GPU context exists: fork-safe) and returns the
+    callable that waits for them -- the rendezvous pre-flight of a sharded run goes in between."""
     import multiprocessing as mp
     if under_profiler():
         gen_procs = 1
     procs = gen_procs or max(1, min(len(indices), (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), 16))
     if procs == 1 or len(indices) < 2:
-        return [_gen((workload, i)) for i in indices]
-    with mp.get_context("fork").Pool(procs) as pool:
-        return pool.map(_gen, [(workload, i) for i in indices])
+        return lambda: [_gen((workload, i)) for i in indices]
+    pool = mp.get_context("fork").Pool(procs)
+    pending = pool.map_async(_gen, [(workload, i) for i in indices])
+
+    def finish():
+        try:
+            return pending.get()
+        finally:
+            pool.close()
+            pool.join()
+    return finish
+
+
+def relaunch_under_launcher(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`
+    -- one rank per GPU, the frame loop of PCCEncoder.cpp:4729-4750 sharded f -> rank f mod N.  Refuses, before anything is set up,
+    when the node has fewer GPUs than ranks (unless --dist-backend gloo, where ranks share the visible GPUs)."""
+    import socket
+    if a.dist_backend == "nccl" and not a.preflight_only:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible (RCCL needs one GPU per rank; --dist-backend gloo shares them)" % (a.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: %s\n" % (a.gpus, " ".join(cmd[1:9])))
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def preflight(a, torch, dist, sharder, rank, world):
+    """Before the set-up (tens of seconds of data generation, uploads and priming passes): the process group is up, and every
+    collective the sharded GOF uses -- the 24-byte weight broadcast, the height all-reduce(max), one gather of a dummy patch
+    record block to rank 0 -- has run once over the backend the timed region will use.  A RCCL / rendezvous problem surfaces
+    here, with the rank that saw it named."""
+    import numpy as np
+    t0 = time.time()
+    try:
+        w = sharder.broadcast_weight(np.array([1.0, 2.0, 3.0]) if rank == 0 else np.zeros(3))
+        assert w.tolist() == [1.0, 2.0, 3.0], w
+        assert sharder.max_height([100 + rank]) == 100 + world - 1
+        rec = torch.full((2, 8 + 64), rank, dtype=torch.uint8).to(sharder.device)
+        got = sharder.gather(rec)
+        if rank == 0:
+            assert [int(g[0, 0].item()) for g in got] == list(range(world))
+        sharder.barrier()
+    except Exception as e:
+        raise SystemExit("bench.py: pre-flight of the %s process group failed on rank %d of %d: %r" % (a.dist_backend, rank, world, e))
+    if rank == 0:
+        sys.stderr.write("bench.py: pre-flight ok: %d ranks over %s (%s), broadcast + all-reduce + gather in %.2f s\n" %
+                         (world, "RCCL" if a.dist_backend == "nccl" else "gloo", sharder.device, time.time() - t0))
+        sys.stderr.flush()
 
 
 # Algorithmic HBM bytes per frame of each timed stage (SURVEY.md section 8d; N points, M reconstructed points, V refinement
@@ -551,29 +615,48 @@ def main():
         return
     if a.cpu_child:
         return cpu_child(a.cpu_child, a.workload, a.iterations, a.case)
+    if a.host == "native" and max(a.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1:
+        raise SystemExit("bench.py: --host native drives one process's frames; the sharded GOF (--gpus N) meets over torch.distributed")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_launcher(a)                              # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.host == "native" and world > 1:
-        raise SystemExit("bench.py: --host native drives one process's frames; the sharded GOF (--gpus N) meets over torch.distributed")
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line's n_gpus would not be what "
+                         "was asked for" % (a.gpus, world))
     import numpy as np
     import tmc2_amd as T
     if a.frames % world:
         raise SystemExit("bench.py: --frames %d is not a multiple of the %d ranks (the canvas gather runs once per frame slot)" % (a.frames, world))
     my_indices = list(range(rank, a.frames, world))
-    clouds = make_frames(a.workload, my_indices, a.gen_procs)         # before any GPU context exists (fork-safe)
+    # generation starts in forked processes before any GPU context exists (fork-safe); the rendezvous comes up meanwhile
+    clouds_ready = (lambda: []) if a.preflight_only else start_frames(a.workload, my_indices, a.gen_procs)
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         if a.dist_backend == "gloo":
-            local = local % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local)
+            if not a.preflight_only:
+                local = local % max(1, torch.cuda.device_count())
+                torch.cuda.set_device(local)
             dist.init_process_group("gloo")
         else:
+            if torch.cuda.device_count() <= local:
+                raise SystemExit("bench.py: rank %d has no GPU %d (%d visible): RCCL needs one GPU per rank" % (rank, local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     sharder = T.Sharder(rank, world, dist, "cpu" if (world > 1 and a.dist_backend == "gloo") else "cuda:%d" % local)
+    if world > 1:
+        preflight(a, torch, dist, sharder, rank, world)
+    if a.preflight_only:
+        if rank == 0:
+            print(json.dumps({"preflight": "ok", "n_gpus": world, "backend": a.dist_backend}))
+            sys.stdout.flush()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    clouds = clouds_ready()
     to_host_here = world == 1 or a.gather == "host"     # every rank lands its own frames' canvases in host memory
     # one hardware queue per in-flight frame (GPU_MAX_HW_QUEUES = 16, tmc2_amd/lib.py): streams that share a queue serialise
     # behind each other, and 16 frames in flight keep the chip busy (measured: 12 -> 62, 16 -> 73, 20 -> 68, 24 -> 55, 32 -> 64 frames/s)

@@ -348,3 +348,35 @@ def test_bench_refuses_the_native_host_with_several_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--host", "native"],
                        capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "--host native drives one process's frames" in r.stderr, r.stderr[-400:]
+
+
+def test_bench_gpus_n_starts_its_own_launcher():
+    """`python bench.py --gpus 2` with no launcher around it (the way the N = 1 line is invoked) must not run one rank and print
+    n_gpus 1: it becomes `torch.distributed.run --nproc-per-node 2` itself, the ranks that come up are the ranks asked for, and the
+    collectives of the sharded GOF (24-byte broadcast, height all-reduce, record gather) run once as a pre-flight before any
+    set-up.  --preflight-only stops there, so the route is covered on a box without a GPU (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--preflight-only", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-600:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"preflight": "ok", "n_gpus": 2, "backend": "gloo"}
+    assert "pre-flight ok: 2 ranks over gloo" in r.stderr
+
+
+def test_bench_refuses_a_world_that_is_not_the_gpus_asked_for():
+    """A launcher that started another number of ranks than --gpus says: refused before anything is set up (the line's n_gpus
+    would not be what was asked for); and RCCL ranks without a GPU each are refused by the parent, before the launcher starts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 2 rank(s)" in r.stderr, r.stderr[-400:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "--gpus 8 but 0 GPU(s) visible" in r.stderr, r.stderr[-400:]
