@@ -1,0 +1,65 @@
+"""The BENCHMARKED condition of every BASELINE configuration inside `pytest -m gpu`: the whole 32-frame GOF, SIXTEEN frames in
+flight, repeated with the union-find invariants on -- the condition in which round 4's closure-ring dead-lock showed (16
+voxels-of-2 frames in flight) -- against the unmodified reference's per-frame digests (tests/golden/full_size.npz, `*_gof32`),
+and the DECODER side of the same GOFs (BASELINE config 5 as a GOF: reconstruct, inverse colour conversion, post-reconstruction
+tail, D1 / D2 / colour metric per frame, 16 in flight) against the reference's `f%d_post_*` digests and PCCMetrics doubles
+(PCCVideoEncoder.cpp:389-396, PCCEncoder.cpp:714-718, PCCMetrics.cpp:324-375).  The 8-frame soaks of test_gpu_gof_soak.py keep
+the conservative union-find forms; longdress' 32-frame encoder-side soak lives there too."""
+import argparse
+import importlib.util
+import os
+
+import pytest
+
+import tmc2_amd as T
+from tmc2_amd.configs import constrained_pack
+from test_gpu_gof_soak import gof_input, run_and_check
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# case -> (encoder-side repetitions with invariants on, without, decoder side too)
+GOF32 = {
+    "longdress_vox10_ai_r3_gof32": (1, 0, True),         # (encoder side soaked in test_gpu_gof_soak.py: 5 + 3 repetitions)
+    "loot_vox10_ai_r3_gof32": (2, 1, True),
+    "redandblack_vox10_ai_r3_gof32": (2, 1, False),
+    "soldier_vox10_ai_r3_gof32": (2, 1, False),
+    "basketball_player_vox11_ra_r5_gof32": (2, 1, True),
+}
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", list(GOF32))
+def test_gpu_gof32_sixteen_in_flight(name, monkeypatch):
+    c, g, frames = gof_input(name)
+    checked, plain, decoder = GOF32[name]
+    monkeypatch.setenv("TMC2_UF_CHECK", "1")
+    enc = T.GofEncoder(0, workers=16, iterations=c["iterations"], bits3d=c["bits3d"], occ_precision=c["precision"],
+                       min_w=c["min_w"], min_h=c["min_h"], vox_dim=c["vox_dim"])
+    try:
+        frs = enc.upload(frames)
+        for rep in range(checked):
+            run_and_check(enc, frs, c, g, "%s: repetition %d, 16 frames in flight, invariants on" % (name, rep))
+        monkeypatch.setenv("TMC2_UF_CHECK", "0")
+        for rep in range(plain):
+            run_and_check(enc, frs, c, g, "%s: repetition %d, 16 frames in flight" % (name, rep))
+        if decoder:
+            import torch
+            for fr in frs:
+                fr.reset()
+            W, H = enc.phase_a(frs, constrained_pack=constrained_pack(c))
+            enc.phase_b(frs)
+            a = argparse.Namespace(case=dict(c, name=name), case_name=name, is_case=True, pin=True)
+            out = _bench().decoder_leg(a, T, torch, enc, frs, frames, list(range(len(frames))), W, H, reps=2)
+            assert out["verified"] is True, "%s, decoder side, 16 in flight: %s" % (name, out["verified_detail"])
+    finally:
+        for fr in frs:
+            fr.close()
+        enc.close(join=True)
