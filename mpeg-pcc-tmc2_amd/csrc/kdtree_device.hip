@@ -34,6 +34,7 @@
 // write-back + invalidate per workgroup, ~45 us per pass, and the builds of concurrent frames serialise.  Separate
 // launches leave the gaps of one frame to the passes of the others.)
 #include <algorithm>
+#include <cstring>
 
 #include "internal.h"
 
@@ -111,7 +112,11 @@ struct BuildArgs {
   uint32_t*   bigCount;
   HugeSeg*    huge;     // segments of more than kSplitMax and at most hugeMax points (hugeSegmentsKernel)
   uint32_t*   hugeCount;
-  uint32_t    hugeMax;  // (>= kSplitMax; == kSplitMax: no such segments)
+  uint32_t    hugeMax;  // (>= splitMax; == splitMax: no such segments)
+  uint32_t    retireMax, splitMax;  // round 4's tiers: kRetire / kSplitMax; pieceKernel: kPieceMax for all three thresholds
+  struct LvSeg *lvA, *lvB;          // round 5's level passes: the segments of a level (by level parity)
+  uint16_t*   list;                 // [n rounded up to whole tiles] positions not of a sweep's class, compacted per tile
+  struct LvPartial* partial;        // [n / kBlock + 1] what a workgroup of the landing pass found for the two children of its segment
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
   uint32_t*   ticket;       // "last block done" counter of the prefix sums
 };
@@ -388,21 +393,21 @@ __global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint3
     int     cutDim;
     int32_t cut;
     const uint32_t cnt = q->end - q->begin;
-    if ( cnt > uint32_t( kLeafMax ) && cnt <= uint32_t( kRetire ) ) {  // the rest of this subtree is built in LDS
+    if ( cnt > uint32_t( kLeafMax ) && cnt <= a.retireMax ) {  // the rest of this subtree is built in LDS
       RetiredSeg r;
       r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
       r.root  = q->parent == kNone ? 1 : 0;
       for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
       a.retired[atomicAdd( a.retiredCount, 1u )] = r;
       q->split = 0;
-    } else if ( cnt > uint32_t( kRetire ) && cnt <= uint32_t( kSplitMax ) ) {  // split further by one workgroup in LDS
+    } else if ( cnt > a.retireMax && cnt <= a.splitMax ) {  // split further by one workgroup in LDS
       RetiredSeg r;
       r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
       r.root  = q->parent == kNone ? 1 : 0;
       for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
       a.big[atomicAdd( a.bigCount, 1u )] = r;
       q->split = 0;
-    } else if ( cnt > uint32_t( kSplitMax ) && cnt <= a.hugeMax ) {  // ... by one workgroup in global memory
+    } else if ( cnt > a.splitMax && cnt <= a.hugeMax ) {  // ... by one workgroup in global memory
       HugeSeg r;
       r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
       r.root  = q->parent == kNone ? 1 : 0;
@@ -1085,7 +1090,7 @@ __global__ __launch_bounds__( 64 * kSplitWaves ) void splitSegmentsKernel( Build
 // Four elements per thread and pass iteration (independent loads: the passes are bound by load latency, not by bandwidth).
 constexpr int      kHugeWaves = 16;
 constexpr uint32_t kHugeLimit = 131072;                                 // largest hugeMax
-constexpr int      kHugeNodes = 2 * int( kHugeLimit / kSplitMax ) + 4;  // nodes of more than kSplitMax points at one depth
+constexpr int      kHugeNodes = 2 * int( kHugeLimit / 4096 ) + 4;  // nodes of more than splitMax (>= 4096) points at one depth
 struct HugeNode {
   uint32_t begin, end;  // range inside the segment
   uint32_t node;
@@ -1267,11 +1272,11 @@ __global__ __launch_bounds__( 64 * kHugeWaves ) void hugeSegmentsKernel( BuildAr
               leaf.dim = -1;
               a.nodes[child[c].node] = leaf;
               atomicMax( a.finishDepth, level + 1u );
-            } else if ( cc <= uint32_t( kSplitMax ) ) {  // to the wavefront finisher, or to the workgroup that splits in LDS first
+            } else if ( cc <= a.splitMax ) {  // to the wavefront finisher / the piece kernel, or to the workgroup that splits in LDS first
               RetiredSeg rs;
               rs.begin = seg.begin + child[c].begin, rs.end = seg.begin + child[c].end, rs.node = child[c].node, rs.level = level, rs.root = 0;
               for ( int d = 0; d < 3; ++d ) rs.lo[d] = child[c].lo[d], rs.hi[d] = child[c].hi[d];
-              if ( cc <= uint32_t( kRetire ) )
+              if ( cc <= a.retireMax )
                 a.retired[atomicAdd( a.retiredCount, 1u )] = rs;
               else
                 a.big[atomicAdd( a.bigCount, 1u )] = rs;
@@ -1286,6 +1291,958 @@ __global__ __launch_bounds__( 64 * kHugeWaves ) void hugeSegmentsKernel( BuildAr
       cur ^= 1;
       __syncthreads();
     }
+  }
+}
+
+// ---- pieces of at most kPieceMax points: ONE workgroup each, points in LDS, ALL nodes of a depth at once (round 5) --------
+// The same level-parallel closed form as the chip-wide passes above, with workgroup barriers where those have kernel boundaries
+// and LDS where those have global memory: per depth, every record (= node of more than kLeafMax points) of the piece is
+// split at the same time -- class flags and ONE workgroup prefix sum per sweep, the misplaced right-hand elements publish
+// their position by rank (from the right) in the node's own slice of a list, the misplaced left-hand elements swap with the
+// entry of their rank (from the left); the children's tight ranges (and with them the parent's divlow / divhigh) come from one
+// segmented wavefront reduction keyed by (record, side) once the elements have landed.  A thread owns K consecutive
+// positions and keeps what it has read of them (record, its range and rule, the prefix sums) in registers from pass to pass.
+// Replaces hugeSegmentsKernel / splitSegmentsKernel / finishSubtreesKernel (a wavefront per node, depth by depth, single lanes
+// running nanoflann's recursion below 32 points: 0.3 + 0.2 + 0.25 ms per tree, most of it divergence and one wavefront on a
+// node of thousands of points); here nothing diverges and nothing is sequential but the depths themselves.
+// The barriers between the passes order LDS only (s_waitcnt lgkmcnt(0) + s_barrier): the node records a pass writes to global
+// memory and the one returning atomic per depth (node ids of the NEXT depth's children, asked for a few passes ahead) stay
+// in flight across them -- nobody in the workgroup reads those back.
+constexpr int      kPieceMax  = 4096;
+constexpr int      kPieceRecs = kPieceMax / ( kLeafMax + 1 ) + 2;  // records of one depth: disjoint, more than kLeafMax points each
+constexpr uint16_t kNoRec     = 0xFFFFu;
+constexpr uint32_t kNoKey     = 0xFFFFFFFFu;
+
+struct alignas( 8 ) PieceRec {
+  uint16_t begin, end;     // [0] what the flag passes read: range inside the piece, the split rule
+  int16_t  cut;
+  uint8_t  dim, unused0;
+  uint16_t edge1, rb1;     // [8] first sweep: end of the "< cut" class, prefix at begin
+  uint16_t edge2, rb2;     //     second sweep: end of the "<= cut" class, prefix at edge1
+  uint16_t mid;            // [16] first position of the right child
+  uint16_t child[2];       //      records of the children at the next depth (kNoRec: a leaf)
+  uint16_t unused1;
+  uint32_t node;           // own node id
+  int32_t  lmax, rmin;     // tight bounds of the two children on the cut dimension (divlow / divhigh)
+  int16_t  lo[3], hi[3];   // loose box
+  int32_t  mn[3], mx[3];   // tight range (LDS atomics)
+};
+static_assert( sizeof( PieceRec ) == 72, "PieceRec layout" );
+struct PieceHot0 {
+  uint32_t be, dc;  // begin | end << 16 ;  cut (16 bits) | dim << 16
+};
+struct PieceHot1 {
+  uint32_t e1rb1, e2rb2;
+};
+struct PieceHot2 {
+  uint32_t midc0, c1;
+};
+
+__device__ __forceinline__ void pieceBarrier() { asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" ); }
+
+typedef short pkShort2 __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ uint32_t pkMin( uint32_t a, uint32_t b ) {
+  return __builtin_bit_cast( uint32_t, __builtin_elementwise_min( __builtin_bit_cast( pkShort2, a ), __builtin_bit_cast( pkShort2, b ) ) );
+}
+__device__ __forceinline__ uint32_t pkMax( uint32_t a, uint32_t b ) {
+  return __builtin_bit_cast( uint32_t, __builtin_elementwise_max( __builtin_bit_cast( pkShort2, a ), __builtin_bit_cast( pkShort2, b ) ) );
+}
+__device__ __forceinline__ uint32_t pk2( int lo16, int hi16 ) { return ( uint32_t( lo16 ) & 0xFFFFu ) | ( uint32_t( hi16 ) << 16 ); }
+__device__ __forceinline__ int      pkLo( uint32_t v ) { return int( int16_t( v & 0xFFFFu ) ); }
+__device__ __forceinline__ int      pkHi( uint32_t v ) { return int( int16_t( v >> 16 ) ); }
+
+// exclusive prefix sum over the workgroup of one value per thread; waveTot: LDS [WAVES] -- the caller alternates between two
+// of them, so that the next scan may start while slow wavefronts still read this one's
+template <int WAVES>
+__device__ __forceinline__ uint32_t pieceScan( uint32_t v, uint32_t* waveTot ) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t  inc  = v;
+#pragma unroll
+  for ( int off = 1; off < 64; off <<= 1 ) {
+    const uint32_t t = __shfl_up( inc, off, 64 );
+    if ( lane >= off ) inc += t;
+  }
+  if ( lane == 63 ) waveTot[wave] = inc;
+  pieceBarrier();
+  uint32_t before = 0;
+#pragma unroll
+  for ( int w = 0; w < WAVES; w += 4 ) {
+    const uint4 t = *reinterpret_cast<const uint4*>( waveTot + w );
+    before += ( w + 0 < wave ? t.x : 0u ) + ( w + 1 < wave ? t.y : 0u ) + ( w + 2 < wave ? t.z : 0u ) + ( w + 3 < wave ? t.w : 0u );
+  }
+  return before + inc - v;
+}
+
+// Segmented min / max over a wavefront of (x, y, z) packed as A = (x, y) under min, B = (x, y) under max, C = (z, ~z) under min:
+// lanes with equal keys are contiguous; afterwards the first lane of every run holds the run's values.  Returns: this lane is
+// such a first lane (of a real key).
+__device__ __forceinline__ bool waveSegMinMaxPacked( uint32_t key, uint32_t& A, uint32_t& B, uint32_t& C, int lane ) {
+#pragma unroll
+  for ( int off = 1; off < 64; off <<= 1 ) {
+    const uint32_t ok = __shfl_down( key, off, 64 );
+    const uint32_t oa = __shfl_down( A, off, 64 ), ob = __shfl_down( B, off, 64 ), oc = __shfl_down( C, off, 64 );
+    if ( lane + off < 64 && ok == key ) A = pkMin( A, oa ), B = pkMax( B, ob ), C = pkMin( C, oc );
+  }
+  const uint32_t pk = __shfl_up( key, 1, 64 );
+  return key != kNoKey && ( lane == 0 || pk != key );
+}
+
+__device__ __forceinline__ void ldsMin( int32_t* slot, int32_t v ) {
+  if ( v < *reinterpret_cast<volatile int32_t*>( slot ) ) atomicMin( slot, v );
+}
+__device__ __forceinline__ void ldsMax( int32_t* slot, int32_t v ) {
+  if ( v > *reinterpret_cast<volatile int32_t*>( slot ) ) atomicMax( slot, v );
+}
+
+
+// ---- round 5's level passes -----------------------------------------------------------------------------------------------
+// The same five steps per level (ranges; flags + prefix sum; first swaps; second flags + prefix sum; second swaps + children),
+// re-cut so that every launch is a SHORT chain of dependent loads -- a level pass over 0.84 M points moves a few megabytes, what it
+// costs is the number of L2 round trips one thread makes in a row:
+//   * a misplaced element finds its partner through a LIST instead of a binary search over the prefix sums (20 dependent loads
+//     near the root): the flag passes compact the tile-local offsets of the elements that are NOT of the class per tile; the
+//     partner of left-rank r is the element of global rank U(end) - 1 - r among those, its tile found by a search of the tile
+//     totals in LDS, its offset by one load;
+//   * the split rule, the children's slots and node ids are decided once per segment by one small launch (lvDecideKernel:
+//     prefix sum over the segments that split) instead of being re-derived per point with fp64 / handed out by atomics;
+//   * the children's tight ranges are gathered by the pass that lands the elements (a segmented wavefront reduction keyed by the
+//     child; what a swap moves reports on its own), so the separate range pass and its re-labelling of every point are gone;
+//   * the first sweep's edge is stored by the thread that sits on the segment's first position, the children are written by
+//     that thread of the last pass.
+// Launches per level: flags, swaps, flags, swaps + landing, decide (tiny).  Swap for swap nanoflann's planeSplit
+// (nanoflann.hpp:1154-1181), as everything in this file.
+struct LvSeg {
+  uint32_t begin, end;     // range in tree order
+  uint32_t cutInfo;        // cut (16 bits) | cutDim << 16 | splits << 24
+  uint32_t edge1;          // first position not of the first sweep's left class (stored by the first swap pass)
+  uint32_t slot;           // the children's segments at the next level: slot, slot + 1
+  uint32_t childNode;      // ... and their node ids: childNode, childNode + 1
+  uint32_t node, parent;   // own node id; parent's node id (kNone for the root)
+  int16_t  lo[3], hi[3];   // loose box handed down by the parent (root: unused, its box is its range)
+  uint8_t  side, pdim;     // which child of the parent we are, and the parent's cut dimension
+  uint16_t unused;
+  int32_t  mn[3], mx[3];   // tight range of the points (atomics)
+};
+
+struct LvPartial {
+  uint32_t slot;  // left child's segment at the next level (kNone: this workgroup reported on its own / had nothing)
+  uint32_t v[6];  // packed (mn x|y, mx x|y, mn z | ~mx z) of the left and of the right child
+  uint32_t unused;
+};
+
+__device__ __forceinline__ void lvReport( LvSeg* child, int mnx, int mny, int mnz, int mxx, int mxy, int mxz ) {
+  if ( mnx < loadStaleOk( &child->mn[0] ) ) atomicMin( &child->mn[0], mnx );
+  if ( mny < loadStaleOk( &child->mn[1] ) ) atomicMin( &child->mn[1], mny );
+  if ( mnz < loadStaleOk( &child->mn[2] ) ) atomicMin( &child->mn[2], mnz );
+  if ( mxx > loadStaleOk( &child->mx[0] ) ) atomicMax( &child->mx[0], mxx );
+  if ( mxy > loadStaleOk( &child->mx[1] ) ) atomicMax( &child->mx[1], mxy );
+  if ( mxz > loadStaleOk( &child->mx[2] ) ) atomicMax( &child->mx[2], mxz );
+}
+
+__device__ __forceinline__ uint32_t lvPrefix( const uint32_t* __restrict__ loc, const uint32_t* sums, uint32_t tiles, uint32_t i, uint32_t n ) {
+  return i < n ? loc[i] + sums[i / kScanTile] : sums[tiles];
+}
+
+// The position of the element of global rank G among the elements that are NOT of the sweep's class, known to lie in
+// [from, to): U( T ) = T * kScanTile - sums[T] such elements precede tile T (sums in LDS), the tile's list holds their offsets.
+__device__ __forceinline__ uint32_t lvPartner( const uint16_t* __restrict__ list, const uint32_t* sums, uint32_t from, uint32_t to, uint32_t G ) {
+  uint32_t lo = from / kScanTile, hi = ( to - 1u ) / kScanTile;
+  while ( lo < hi ) {
+    const uint32_t mid = ( lo + hi + 1u ) / 2u;
+    if ( mid * kScanTile - sums[mid] <= G )
+      lo = mid;
+    else
+      hi = mid - 1u;
+  }
+  return lo * kScanTile + list[size_t( lo ) * kScanTile + ( G - ( lo * kScanTile - sums[lo] ) )];
+}
+
+// tree-order arrays start as the input order; the root's tight range on the way (one report per workgroup).  The root record
+// itself (lvA[0], counts[0], nodeCount) is set up by the memset + lvRootKernel queued before this launch.
+__global__ __launch_bounds__( kBlock ) void lvInitKernel( BuildArgs a ) {
+  __shared__ int blockRange[6 * kWaves];
+  const uint32_t n = a.n, gsize = gridDim.x * blockDim.x;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int mnx = 0x7FFFFFFF, mny = mnx, mnz = mnx, mxx = int( 0x80000000 ), mxy = mxx, mxz = mxx;
+  for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsize ) {
+    const Pt p = a.pts[i];
+    a.P[i]     = p;
+    a.perm[i]  = i;
+    a.seg[i]   = 0;
+    mnx = min( mnx, int( p.x ) ), mny = min( mny, int( p.y ) ), mnz = min( mnz, int( p.z ) );
+    mxx = max( mxx, int( p.x ) ), mxy = max( mxy, int( p.y ) ), mxz = max( mxz, int( p.z ) );
+  }
+#pragma unroll
+  for ( int off = 32; off > 0; off >>= 1 ) {
+    mnx = min( mnx, __shfl_xor( mnx, off, 64 ) ), mny = min( mny, __shfl_xor( mny, off, 64 ) ), mnz = min( mnz, __shfl_xor( mnz, off, 64 ) );
+    mxx = max( mxx, __shfl_xor( mxx, off, 64 ) ), mxy = max( mxy, __shfl_xor( mxy, off, 64 ) ), mxz = max( mxz, __shfl_xor( mxz, off, 64 ) );
+  }
+  if ( lane == 0 ) {
+    int* w = blockRange + 6 * wave;
+    w[0] = mnx, w[1] = mny, w[2] = mnz, w[3] = mxx, w[4] = mxy, w[5] = mxz;
+  }
+  __syncthreads();
+  if ( threadIdx.x < 6 ) {
+    int v = blockRange[threadIdx.x];
+    for ( int w = 1; w < kWaves; ++w ) v = threadIdx.x < 3 ? min( v, blockRange[6 * w + threadIdx.x] ) : max( v, blockRange[6 * w + threadIdx.x] );
+    int32_t* slot = threadIdx.x < 3 ? &a.lvA[0].mn[threadIdx.x] : &a.lvA[0].mx[threadIdx.x - 3];
+    if ( threadIdx.x < 3 ) {
+      if ( v < loadStaleOk( slot ) ) atomicMin( slot, v );
+    } else {
+      if ( v > loadStaleOk( slot ) ) atomicMax( slot, v );
+    }
+  }
+}
+__global__ void lvRootKernel( BuildArgs a ) {
+  LvSeg r{};
+  r.begin = 0, r.end = a.n, r.node = 0, r.parent = kNone;
+  for ( int d = 0; d < 3; ++d ) r.mn[d] = 0x7FFFFFFF, r.mx[d] = int32_t( 0x80000000 );
+  a.lvA[0]     = r;
+  a.counts[0]  = 1;
+  *a.nodeCount = 1;  // node 0 = the root
+}
+
+// Once per level, one workgroup: every segment of the level reports its tight range to its parent's node record (divlow /
+// divhigh), and is a leaf, a piece for pieceKernel, or splits -- then its rule, and (a prefix sum over the segments that split)
+// the slots and node ids of its children.
+constexpr int kDecideThreads = 1024;
+constexpr int kDecideRng     = 2000;  // segments of a level whose ranges are folded in LDS (48 KB)
+__global__ __launch_bounds__( kDecideThreads ) void lvDecideKernel( BuildArgs a, uint32_t level ) {
+  __shared__ uint32_t waveTot[kDecideThreads / 64];
+  __shared__ uint32_t sCarry;
+  __shared__ int32_t  sRng[kDecideRng][6];
+  LvSeg*         cur   = ( level & 1 ) ? a.lvB : a.lvA;
+  const uint32_t count = a.counts[level], nodeBase = *a.nodeCount;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ( threadIdx.x == 0 ) sCarry = 0;
+  // What the workgroups of the landing pass found for the children of the segment they sat in (one record per workgroup and
+  // round, in position order: records of one segment are neighbours) is folded HERE -- thousands of workgroups reporting to the
+  // same twelve words queue up for ~ 100 us near the root, and so do a few hundred atomics of this one workgroup (they are
+  // carried out past the L2, one after the other): segmented wavefront reductions, then LDS atomics into a table of the
+  // level's segments; only a level of more than kDecideRng segments goes through global memory.
+  const bool inLds = level > 0 && count <= uint32_t( kDecideRng );
+  if ( inLds ) {
+    for ( uint32_t t = threadIdx.x; t < count * 6u; t += kDecideThreads ) sRng[t / 6u][t % 6u] = ( t % 6u ) < 3u ? 0x7FFFFFFF : int32_t( 0x80000000 );
+    __syncthreads();
+  }
+  if ( level > 0 ) {
+    const uint32_t nPart = ( a.n + uint32_t( kBlock ) - 1u ) / uint32_t( kBlock );
+    for ( uint32_t base = 0; base < nPart; base += kDecideThreads ) {  // (uniform over the workgroup)
+      const uint32_t t = base + threadIdx.x;
+      LvPartial      pt;
+      pt.slot = kNone;
+      if ( t < nPart ) pt = a.partial[t];
+#pragma unroll
+      for ( int c = 0; c < 2; ++c ) {
+        uint32_t A = pt.v[3 * c], B = pt.v[3 * c + 1], C = pt.v[3 * c + 2];
+        if ( waveSegMinMaxPacked( pt.slot == kNone ? kNoKey : pt.slot, A, B, C, lane ) ) {
+          if ( inLds ) {
+            int32_t* r = sRng[pt.slot + c];
+            ldsMin( &r[0], pkLo( A ) ), ldsMin( &r[1], pkHi( A ) ), ldsMin( &r[2], pkLo( C ) );
+            ldsMax( &r[3], pkLo( B ) ), ldsMax( &r[4], pkHi( B ) ), ldsMax( &r[5], ~pkHi( C ) );
+          } else {
+            lvReport( cur + pt.slot + c, pkLo( A ), pkHi( A ), pkLo( C ), pkLo( B ), pkHi( B ), ~pkHi( C ) );
+          }
+        }
+      }
+    }
+    // (global atomics are carried out at agent scope, i.e. past this XCD's L2: once acknowledged, the agent-scope loads below
+    //  see them -- a release fence here would write the whole L2 back, tens of microseconds)
+    if ( !inLds ) asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+  }
+  __syncthreads();
+  for ( uint32_t base = 0; base < count; base += kDecideThreads ) {
+    const uint32_t s     = base + threadIdx.x;
+    uint32_t       split = 0;
+    LvSeg*         q     = cur + s;
+    if ( s < count ) {
+      const bool root = q->parent == kNone;
+      int32_t    mn[3], mx[3], lo[3], hi[3];
+#pragma unroll
+      for ( int d = 0; d < 3; ++d ) {
+        mn[d] = __hip_atomic_load( &q->mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );  // (what was reported directly)
+        mx[d] = __hip_atomic_load( &q->mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        if ( inLds ) mn[d] = min( mn[d], sRng[s][d] ), mx[d] = max( mx[d], sRng[s][3 + d] );
+        lo[d] = root ? mn[d] : int32_t( q->lo[d] );
+        hi[d] = root ? mx[d] : int32_t( q->hi[d] );
+      }
+      if ( root ) {
+        for ( int d = 0; d < 3; ++d ) a.rootBox[d] = mn[d], a.rootBox[3 + d] = mx[d];
+      } else {
+        const int pd = q->pdim;
+        if ( q->side == 0 )
+          a.nodes[q->parent].divlow = int16_t( pd == 0 ? mx[0] : ( pd == 1 ? mx[1] : mx[2] ) );
+        else
+          a.nodes[q->parent].divhigh = int16_t( pd == 0 ? mn[0] : ( pd == 1 ? mn[1] : mn[2] ) );
+      }
+      const uint32_t cnt = q->end - q->begin;
+      if ( cnt <= uint32_t( kLeafMax ) ) {
+        KdNode nd;
+        nd.a = int32_t( q->begin ), nd.b = int32_t( q->end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
+        a.nodes[q->node] = nd;
+      } else if ( cnt <= a.retireMax ) {  // the rest of this subtree is built in LDS
+        RetiredSeg r;
+        r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
+        r.root  = root ? 1 : 0;
+        for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
+        a.retired[atomicAdd( a.retiredCount, 1u )] = r;
+      } else if ( cnt <= a.hugeMax ) {  // one workgroup cuts it into pieces where it lies (hugeSegmentsKernel)
+        HugeSeg r;
+        r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
+        r.root  = root ? 1 : 0;
+        for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d], r.mn[d] = mn[d], r.mx[d] = mx[d];
+        a.huge[atomicAdd( a.hugeCount, 1u )] = r;
+      } else {
+        const int32_t maxSpan = max( hi[0] - lo[0], max( hi[1] - lo[1], hi[2] - lo[2] ) );
+        const double  limit   = ( 1.0 - 0.00001 ) * double( maxSpan );
+        int           dim     = 0;
+        int32_t       best    = -1;
+        if ( double( hi[0] - lo[0] ) > limit && mx[0] - mn[0] > best ) best = mx[0] - mn[0], dim = 0;
+        if ( double( hi[1] - lo[1] ) > limit && mx[1] - mn[1] > best ) best = mx[1] - mn[1], dim = 1;
+        if ( double( hi[2] - lo[2] ) > limit && mx[2] - mn[2] > best ) best = mx[2] - mn[2], dim = 2;
+        const int32_t l = dim == 0 ? lo[0] : ( dim == 1 ? lo[1] : lo[2] ), h = dim == 0 ? hi[0] : ( dim == 1 ? hi[1] : hi[2] );
+        const int32_t lowest = dim == 0 ? mn[0] : ( dim == 1 ? mn[1] : mn[2] ), highest = dim == 0 ? mx[0] : ( dim == 1 ? mx[1] : mx[2] );
+        const int32_t cut = min( max( ( l + h ) / 2, lowest ), highest );
+        q->cutInfo = ( uint32_t( cut ) & 0xFFFFu ) | ( uint32_t( dim ) << 16 ) | ( 1u << 24 );
+        if ( root )
+          for ( int d = 0; d < 3; ++d ) q->lo[d] = int16_t( mn[d] ), q->hi[d] = int16_t( mx[d] );  // (its children inherit the tight box)
+        split = 1;
+      }
+      if ( !split ) q->cutInfo = 0;
+    }
+    uint32_t inc = split;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t t = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += t;
+    }
+    if ( lane == 63 ) waveTot[wave] = inc;
+    __syncthreads();
+    uint32_t before = sCarry, all = 0;
+    for ( int w = 0; w < kDecideThreads / 64; ++w ) {
+      all += waveTot[w];
+      before += w < wave ? waveTot[w] : 0u;
+    }
+    const uint32_t rank = before + inc - split;
+    if ( split ) q->slot = 2u * rank, q->childNode = nodeBase + 2u * rank;
+    __syncthreads();
+    if ( threadIdx.x == 0 ) sCarry += all;
+    __syncthreads();
+  }
+  if ( threadIdx.x == 0 ) {
+    a.counts[level + 1] = 2u * sCarry;
+    *a.nodeCount        = nodeBase + 2u * sCarry;
+  }
+}
+
+// flags of a sweep (FIRST: ">= cut" over the whole segment; second: "> cut" from the first sweep's edge on), their prefix sums
+// (tile-local + tile totals scanned by the block that finishes last), and the tile's list of the positions NOT of the class
+template <bool FIRST>
+__global__ __launch_bounds__( kBlock ) void lvFlagKernel( BuildArgs a, uint32_t level ) {
+  __shared__ uint32_t waveSum[kWaves];
+  const uint32_t n = a.n, tiles = a.tiles;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LvSeg*         cur   = ( level & 1 ) ? a.lvB : a.lvA;
+  LvSeg*         next  = ( level & 1 ) ? a.lvA : a.lvB;
+  const uint32_t count = a.counts[level];
+  uint32_t*      loc   = FIRST ? a.loc1 : a.loc2;
+  uint32_t*      tile  = FIRST ? a.tile1 : a.tile2;
+  if ( !FIRST ) {  // the children's ranges start empty (the landing pass gathers them)
+    for ( uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < count; s += gridDim.x * blockDim.x ) {
+      const LvSeg* q = cur + s;
+      if ( !( q->cutInfo >> 24 ) ) continue;
+      for ( int c = 0; c < 2; ++c )
+        for ( int d = 0; d < 3; ++d ) next[q->slot + c].mn[d] = 0x7FFFFFFF, next[q->slot + c].mx[d] = int32_t( 0x80000000 );
+    }
+  }
+  for ( uint32_t t = blockIdx.x; t < tiles; t += gridDim.x ) {
+    const uint32_t base = t * kScanTile + threadIdx.x * 8;
+    uint32_t       v[8], run = 0;
+#pragma unroll
+    for ( int k = 0; k < 8; ++k ) {
+      const uint32_t i = base + k;
+      uint32_t       f = 0;
+      if ( i < n ) {
+        const uint32_t s = a.seg[i];
+        if ( s != kNone ) {
+          const LvSeg*   q  = cur + s;
+          const uint32_t ci = q->cutInfo;
+          if ( ci >> 24 ) {
+            const int32_t c = int32_t( int16_t( ci & 0xFFFFu ) ), x = coordOf( a.P[i], int( ( ci >> 16 ) & 0xFFu ) );
+            f               = FIRST ? uint32_t( x >= c ) : uint32_t( i >= q->edge1 && x > c );
+          }
+        }
+      }
+      v[k] = f;
+      run += f;
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t u = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += u;
+    }
+    if ( lane == 63 ) waveSum[wave] = inc;
+    __syncthreads();
+    uint32_t offset = inc - run;
+    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
+#pragma unroll
+    for ( int k = 0; k < 8; ++k ) {
+      if ( base + k < n ) {
+        loc[base + k] = offset;
+        if ( !v[k] ) a.list[size_t( t ) * kScanTile + ( threadIdx.x * 8 + k - offset )] = uint16_t( threadIdx.x * 8 + k );
+      }
+      offset += v[k];
+    }
+    if ( threadIdx.x == kBlock - 1 ) tile[t] = offset;  // (the RAW total: the swap passes scan the totals themselves, in LDS)
+    __syncthreads();
+  }
+}
+
+// The tile totals of a flag pass (raw, in global memory) -> their exclusive prefix sums in LDS, sums[tiles] = the grand total.
+// Every workgroup of a swap pass does this for itself: a few hundred words, one LDS scan -- instead of the flag pass ending in
+// a ticket, a hand-off to the workgroup that finishes last and ITS scan, with the whole chip waiting.
+__device__ __forceinline__ void lvLoadSums( uint32_t* sums, const uint32_t* __restrict__ raw, uint32_t tiles ) {
+  __shared__ uint32_t waveSum[kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t  carry = 0;
+  for ( uint32_t base = 0; base < tiles; base += kBlock ) {
+    const uint32_t i   = base + threadIdx.x;
+    const uint32_t v   = i < tiles ? raw[i] : 0u;
+    uint32_t       inc = v;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const uint32_t u = __shfl_up( inc, off, 64 );
+      if ( lane >= off ) inc += u;
+    }
+    if ( lane == 63 ) waveSum[wave] = inc;
+    __syncthreads();
+    uint32_t offset = carry + inc - v;
+    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
+    if ( i < tiles ) sums[i] = offset;
+    for ( int w = 0; w < kWaves; ++w ) carry += waveSum[w];
+    __syncthreads();
+  }
+  if ( threadIdx.x == 0 ) sums[tiles] = carry;
+  __syncthreads();
+}
+
+// first sweep: the misplaced left-hand elements (">= cut" before the edge) swap with the misplaced right-hand element of the
+// same rank counted from the segment's end
+__global__ __launch_bounds__( kBlock ) void lvSwapOneKernel( BuildArgs a, uint32_t level ) {
+  extern __shared__ uint32_t lvSums[];  // [tiles + 1]
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x;
+  LvSeg*         cur = ( level & 1 ) ? a.lvB : a.lvA;
+  lvLoadSums( lvSums, a.tile1, tiles );
+  for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsize ) {
+    const uint32_t s = a.seg[i];
+    if ( s == kNone ) continue;
+    LvSeg*         q  = cur + s;
+    const uint32_t ci = q->cutInfo;
+    if ( !( ci >> 24 ) ) continue;
+    const uint32_t b = q->begin, e = q->end;
+    const Pt       pi = a.P[i];
+    const uint32_t li = a.loc1[i];
+    const uint32_t rb = lvPrefix( a.loc1, lvSums, tiles, b, n ), re = lvPrefix( a.loc1, lvSums, tiles, e, n );
+    const uint32_t edge = b + ( ( e - b ) - ( re - rb ) );
+    if ( i == b ) q->edge1 = edge;
+    if ( i >= edge || coordOf( pi, int( ( ci >> 16 ) & 0xFFu ) ) < int32_t( int16_t( ci & 0xFFFFu ) ) ) continue;
+    const uint32_t r  = li + lvSums[i / kScanTile] - rb;
+    const uint32_t j  = lvPartner( a.list, lvSums, edge, e, ( e - re ) - 1u - r );
+    const Pt       pj = a.P[j];
+    a.P[i]            = pj;
+    a.P[j]            = pi;
+    const uint32_t u  = a.perm[i];
+    a.perm[i]         = a.perm[j];
+    a.perm[j]         = u;
+  }
+}
+
+// second sweep's swaps, and the landing: every position learns its child (its segment of the next level), the children's
+// tight ranges are gathered, the thread on a segment's first position writes the children and the node record
+__global__ __launch_bounds__( kBlock ) void lvSwapTwoKernel( BuildArgs a, uint32_t level ) {
+  extern __shared__ uint32_t lvSums[];  // [tiles + 1]
+  const uint32_t n = a.n, tiles = a.tiles;
+  const uint32_t gsize = gridDim.x * blockDim.x;
+  const int      lane  = threadIdx.x & 63;
+  LvSeg*         cur  = ( level & 1 ) ? a.lvB : a.lvA;
+  LvSeg*         next = ( level & 1 ) ? a.lvA : a.lvB;
+  lvLoadSums( lvSums, a.tile2, tiles );
+  const uint32_t nRound = ( n + uint32_t( kBlock ) - 1u ) & ~( uint32_t( kBlock ) - 1u );
+  __shared__ uint32_t blockSeg;
+  __shared__ uint32_t red[kWaves][6];
+  const int wave = threadIdx.x >> 6;
+  for ( uint32_t i0 = blockIdx.x * blockDim.x; i0 < nRound; i0 += gsize ) {  // (uniform per workgroup: it reduces together)
+    const uint32_t i   = i0 + threadIdx.x;
+    uint32_t       key = kNoKey;  // the child the element that ENDS at position i belongs to
+    uint32_t       A = pk2( 0x7FFF, 0x7FFF ), B = pk2( -0x8000, -0x8000 ), C = pk2( 0x7FFF, 0x7FFF );      // ... that element
+    uint32_t       A2 = A, B2 = B, C2 = C;  // the element a swap of this thread has moved away (always into the RIGHT child: mid <= edge2)
+    bool           moved = false;
+    uint32_t       s = kNone, slot = 0;
+    if ( i < n ) {
+      s           = a.seg[i];
+      uint32_t to = kNone;
+      if ( s != kNone ) {
+        LvSeg*         q  = cur + s;
+        const uint32_t ci = q->cutInfo;
+        if ( ci >> 24 ) {
+          const uint32_t b = q->begin, e = q->end, e1 = q->edge1;
+          slot               = q->slot;
+          const int      dim = int( ( ci >> 16 ) & 0xFFu );
+          const int32_t  cut = int32_t( int16_t( ci & 0xFFFFu ) );
+          Pt             pi  = a.P[i];
+          const uint32_t li  = a.loc2[i];
+          const uint32_t rb = lvPrefix( a.loc2, lvSums, tiles, e1, n ), re = lvPrefix( a.loc2, lvSums, tiles, e, n );
+          const uint32_t e2   = e1 + ( ( e - e1 ) - ( re - rb ) );
+          const uint32_t cnt  = e - b, half = cnt / 2, lim1 = e1 - b, lim2 = e2 - b;
+          const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
+          const uint32_t mid  = b + idx;
+          if ( i == b ) {  // the children (their ranges are being gathered by everybody: not touched here) and the node record
+            KdNode nd;
+            nd.a = int32_t( q->childNode ), nd.b = int32_t( q->childNode + 1u ), nd.divlow = nd.divhigh = 0, nd.dim = dim;
+            a.nodes[q->node] = nd;
+            for ( int c = 0; c < 2; ++c ) {
+              LvSeg* ch = next + slot + c;
+              ch->begin = c ? mid : b, ch->end = c ? e : mid, ch->cutInfo = 0, ch->edge1 = 0, ch->slot = 0, ch->childNode = 0;
+              ch->node = q->childNode + c, ch->parent = q->node, ch->side = uint8_t( c ), ch->pdim = uint8_t( dim ), ch->unused = 0;
+              for ( int d = 0; d < 3; ++d ) ch->lo[d] = q->lo[d], ch->hi[d] = q->hi[d];
+              if ( c == 0 ) {
+                if ( dim == 0 ) ch->hi[0] = int16_t( cut );
+                if ( dim == 1 ) ch->hi[1] = int16_t( cut );
+                if ( dim == 2 ) ch->hi[2] = int16_t( cut );
+              } else {
+                if ( dim == 0 ) ch->lo[0] = int16_t( cut );
+                if ( dim == 1 ) ch->lo[1] = int16_t( cut );
+                if ( dim == 2 ) ch->lo[2] = int16_t( cut );
+              }
+            }
+          }
+          const int32_t x = coordOf( pi, dim );
+          to              = slot + ( i >= mid ? 1u : 0u );
+          key             = to;
+          if ( i >= e1 && i < e2 && x > cut ) {  // misplaced on the left of the second sweep: swap; what moves away lands right of mid
+            const uint32_t r  = li + lvSums[i / kScanTile] - rb;
+            const uint32_t j  = lvPartner( a.list, lvSums, e2, e, ( e - re ) - 1u - r );
+            const Pt       pj = a.P[j];
+            a.P[i]            = pj;
+            a.P[j]            = pi;
+            const uint32_t u  = a.perm[i];
+            a.perm[i]         = a.perm[j];
+            a.perm[j]         = u;
+            moved             = true;
+            A2 = pk2( pi.x, pi.y ), B2 = A2, C2 = pk2( pi.z, ~int( pi.z ) );
+            pi = pj;
+          }
+          // (misplaced on the right of the second sweep: the partner swaps and reports what lands here -- this lane keeps the
+          //  run of its child together and adds nothing; if the swap has happened already it sees the element that landed)
+          if ( !( i >= e2 && x <= cut ) ) A = pk2( pi.x, pi.y ), B = A, C = pk2( pi.z, ~int( pi.z ) );
+        }
+        a.seg[i] = to;
+      }
+    }
+    // Near the root a whole workgroup sits inside one segment: then it reduces for the two children in registers / LDS and
+    // reports ONCE per child -- otherwise thousands of wavefronts queue up on the same six words of a handful of records.
+    if ( threadIdx.x == 0 ) blockSeg = s;
+    __syncthreads();
+    const bool uniform = __syncthreads_and( s == blockSeg ) != 0;
+    if ( uniform ) {
+      const bool anything = __syncthreads_or( key != kNoKey ) != 0;
+      if ( anything ) {  // (one segment, and it splits: slot is the same for every lane)
+        uint32_t v[6];
+        const bool right = key != kNoKey && key != slot;
+        v[0] = right || key == kNoKey ? pk2( 0x7FFF, 0x7FFF ) : A, v[1] = right || key == kNoKey ? pk2( -0x8000, -0x8000 ) : B,
+        v[2] = right || key == kNoKey ? pk2( 0x7FFF, 0x7FFF ) : C;
+        v[3] = pkMin( right ? A : pk2( 0x7FFF, 0x7FFF ), A2 ), v[4] = pkMax( right ? B : pk2( -0x8000, -0x8000 ), B2 ),
+        v[5] = pkMin( right ? C : pk2( 0x7FFF, 0x7FFF ), C2 );
+#pragma unroll
+        for ( int off = 32; off > 0; off >>= 1 ) {
+          v[0] = pkMin( v[0], __shfl_xor( v[0], off, 64 ) ), v[1] = pkMax( v[1], __shfl_xor( v[1], off, 64 ) ), v[2] = pkMin( v[2], __shfl_xor( v[2], off, 64 ) );
+          v[3] = pkMin( v[3], __shfl_xor( v[3], off, 64 ) ), v[4] = pkMax( v[4], __shfl_xor( v[4], off, 64 ) ), v[5] = pkMin( v[5], __shfl_xor( v[5], off, 64 ) );
+        }
+        if ( lane == 0 )
+          for ( int k = 0; k < 6; ++k ) red[wave][k] = v[k];
+        __syncthreads();
+        if ( threadIdx.x == 0 ) {  // one record per workgroup and round, in position order: lvDecideKernel folds them
+          LvPartial pt;
+          pt.slot = slot, pt.unused = 0;
+          for ( int k = 0; k < 6; ++k ) {
+            uint32_t x = red[0][k];
+            for ( int w = 1; w < kWaves; ++w ) x = ( k % 3 ) == 1 ? pkMax( x, red[w][k] ) : pkMin( x, red[w][k] );
+            pt.v[k] = x;
+          }
+          a.partial[i0 / kBlock] = pt;
+        }
+      } else if ( threadIdx.x == 0 ) {
+        a.partial[i0 / kBlock].slot = kNone;
+      }
+      __syncthreads();
+      continue;
+    }
+    if ( threadIdx.x == 0 ) a.partial[i0 / kBlock].slot = kNone;
+    if ( moved ) lvReport( next + slot + 1u, pkLo( A2 ), pkHi( A2 ), pkLo( C2 ), pkLo( A2 ), pkHi( A2 ), pkLo( C2 ) );
+    if ( waveSegMinMaxPacked( key, A, B, C, lane ) )
+      lvReport( next + key, pkLo( A ), pkHi( A ), pkLo( C ), pkLo( B ), pkHi( B ), ~pkHi( C ) );
+  }
+}
+
+constexpr size_t kPieceLdsBytes = size_t( kPieceMax ) * ( sizeof( Pt ) + 4 + 2 + 2 + 2 ) + 16 + 2 * size_t( kPieceRecs ) * sizeof( PieceRec );
+
+template <int K>  // positions per thread: kPieceMax / K threads
+__global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
+  constexpr int THREADS = kPieceMax / K, WAVES = THREADS / 64;
+  static_assert( K == 4 || K == 8, "pieceKernel: four or eight positions per thread" );
+  extern __shared__ __align__( 16 ) unsigned char pieceLds[];
+  Pt*       P     = reinterpret_cast<Pt*>( pieceLds );                       // [kPieceMax] the piece's points
+  uint32_t* perm  = reinterpret_cast<uint32_t*>( P + kPieceMax );            // [kPieceMax]
+  uint16_t* pre   = reinterpret_cast<uint16_t*>( perm + kPieceMax );         // [kPieceMax + 8] exclusive prefix of a sweep's class flag
+  uint16_t* lst   = pre + kPieceMax + 8;                                     // [kPieceMax] misplaced right-hand positions by rank
+  uint16_t* segOf = lst + kPieceMax;                                         // [kPieceMax] record of a position (kNoRec: settled)
+  PieceRec* recs  = reinterpret_cast<PieceRec*>( segOf + kPieceMax );        // [2][kPieceRecs]
+  __shared__ __align__( 16 ) uint32_t sWave[2][WAVES];
+  __shared__ uint32_t sCount[2], sNodeBase, sDepth;
+  const int      lane = threadIdx.x & 63, tid = threadIdx.x;
+  const uint32_t total = *a.retiredCount;
+  const uint32_t p0    = uint32_t( tid ) * K;
+  // (measured and dropped: largest pieces first -- every workgroup ranking the list for itself; 302 against 291 us: the launch is
+  //  bound by the sum of the pieces' work over the CUs, not by a late large piece)
+  for ( uint32_t s = blockIdx.x; s < total; s += gridDim.x ) {  // (uniform over the workgroup)
+    const RetiredSeg seg = a.retired[s];
+    const uint32_t   cnt = seg.end - seg.begin;
+    uint32_t idPending   = 0;  // thread 0: node ids of the children of the coming depth's records (a returning atomic in flight)
+    if ( tid == 0 ) idPending = atomicAdd( a.nodeCount, 2u );
+    pieceBarrier();  // (the previous piece's stores have read the arrays)
+    for ( uint32_t i = tid; i < uint32_t( kPieceMax ); i += THREADS ) {
+      if ( i < cnt ) {
+        P[i]     = a.P[seg.begin + i];
+        perm[i]  = a.perm[seg.begin + i];
+        segOf[i] = 0;
+      } else {
+        segOf[i] = kNoRec;
+      }
+    }
+    if ( tid == 0 ) {
+      PieceRec r{};
+      r.begin = 0, r.end = uint16_t( cnt ), r.node = seg.node;
+      for ( int d = 0; d < 3; ++d ) r.lo[d] = seg.lo[d], r.hi[d] = seg.hi[d], r.mn[d] = 0x7FFFFFFF, r.mx[d] = int32_t( 0x80000000 );
+      recs[0]   = r;
+      sCount[0] = 1, sCount[1] = 0, sDepth = 0;
+    }
+    pieceBarrier();
+    {  // tight range of the piece's root
+      uint32_t A = pk2( 0x7FFF, 0x7FFF ), B = pk2( -0x8000, -0x8000 ), C = pk2( 0x7FFF, 0x7FFF );
+      bool     any = false;
+#pragma unroll
+      for ( int k = 0; k < K; ++k ) {
+        const uint32_t p = p0 + k;
+        if ( p < cnt ) {
+          const Pt x = P[p];
+          A = pkMin( A, pk2( x.x, x.y ) ), B = pkMax( B, pk2( x.x, x.y ) ), C = pkMin( C, pk2( x.z, ~int( x.z ) ) );
+          any = true;
+        }
+      }
+      if ( waveSegMinMaxPacked( any ? 0u : kNoKey, A, B, C, lane ) ) {
+        ldsMin( &recs[0].mn[0], pkLo( A ) ), ldsMin( &recs[0].mn[1], pkHi( A ) ), ldsMin( &recs[0].mn[2], pkLo( C ) );
+        ldsMax( &recs[0].mx[0], pkLo( B ) ), ldsMax( &recs[0].mx[1], pkHi( B ) ), ldsMax( &recs[0].mx[2], ~pkHi( C ) );
+      }
+    }
+    pieceBarrier();
+    if ( seg.root != 0 && tid == 0 ) {  // the root of the whole tree: its loose box is its tight range
+      for ( int d = 0; d < 3; ++d ) {
+        recs[0].lo[d] = int16_t( recs[0].mn[d] ), recs[0].hi[d] = int16_t( recs[0].mx[d] );
+        a.rootBox[d] = recs[0].mn[d], a.rootBox[3 + d] = recs[0].mx[d];
+      }
+    }
+    uint32_t deepest  = 0;  // (level of the deepest leaf this thread has written) + 1
+    uint32_t prevBase = 0, prevCount = 0;
+    int      cur      = 0;
+    for ( uint32_t depth = 0;; ++depth ) {
+      pieceBarrier();  // (the records of this depth and their ranges are complete; so is sCount[cur])
+      const uint32_t nc = sCount[cur];
+      PieceRec*      R  = recs + cur * kPieceRecs;
+      PieceRec*      RN = recs + ( cur ^ 1 ) * kPieceRecs;
+      // ---- the node records of the previous depth (their divlow / divhigh are complete now)
+      for ( uint32_t r = tid; r < prevCount; r += THREADS ) {
+        const PieceRec* q = RN + r;
+        KdNode          nd;
+        nd.a = int32_t( prevBase + 2u * r ), nd.b = int32_t( prevBase + 2u * r + 1u ), nd.divlow = int16_t( q->lmax ), nd.divhigh = int16_t( q->rmin ),
+        nd.dim = q->dim;
+        a.nodes[q->node] = nd;
+      }
+      if ( nc == 0 ) break;
+      if ( seg.level + depth >= uint32_t( kMaxLevels ) - 2u ) {  // deeper than the k-NN traversal stack: refused
+        if ( tid == 0 ) atomicMax( a.finishDepth, 0x10000u );
+        break;
+      }
+      // ---- the split rule of every record; node ids of their children
+      if ( tid == 0 ) sNodeBase = idPending, sCount[cur ^ 1] = 0;
+      for ( uint32_t r = tid; r < nc; r += THREADS ) {
+        PieceRec*     q   = R + r;
+        const int32_t lo0 = q->lo[0], lo1 = q->lo[1], lo2 = q->lo[2], hi0 = q->hi[0], hi1 = q->hi[1], hi2 = q->hi[2];
+        const int32_t mn0 = q->mn[0], mn1 = q->mn[1], mn2 = q->mn[2], mx0 = q->mx[0], mx1 = q->mx[1], mx2 = q->mx[2];
+        const int32_t maxSpan = max( hi0 - lo0, max( hi1 - lo1, hi2 - lo2 ) );
+        const double  limit   = ( 1.0 - 0.00001 ) * double( maxSpan );
+        int           dim     = 0;
+        int32_t       best    = -1;
+        if ( double( hi0 - lo0 ) > limit && mx0 - mn0 > best ) best = mx0 - mn0, dim = 0;
+        if ( double( hi1 - lo1 ) > limit && mx1 - mn1 > best ) best = mx1 - mn1, dim = 1;
+        if ( double( hi2 - lo2 ) > limit && mx2 - mn2 > best ) best = mx2 - mn2, dim = 2;
+        const int32_t l = dim == 0 ? lo0 : ( dim == 1 ? lo1 : lo2 ), h = dim == 0 ? hi0 : ( dim == 1 ? hi1 : hi2 );
+        const int32_t lowest = dim == 0 ? mn0 : ( dim == 1 ? mn1 : mn2 ), highest = dim == 0 ? mx0 : ( dim == 1 ? mx1 : mx2 );
+        q->dim = uint8_t( dim ), q->unused0 = 0, q->cut = int16_t( min( max( ( l + h ) / 2, lowest ), highest ) );
+      }
+      pieceBarrier();
+      // ---- what this thread's positions belong to (kept in registers for the whole depth)
+      uint32_t rec[K], be[K], dc[K];
+      {
+        uint16_t raw[K];
+        if ( K == 4 )
+          *reinterpret_cast<uint2*>( raw ) = *reinterpret_cast<const uint2*>( segOf + p0 );
+        else
+          *reinterpret_cast<uint4*>( raw ) = *reinterpret_cast<const uint4*>( segOf + p0 );
+        bool same = true;
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) rec[k] = raw[k], same = same && raw[k] == raw[0];
+        if ( same ) {
+          PieceHot0 h{0, 0};
+          if ( rec[0] != kNoRec ) h = *reinterpret_cast<const PieceHot0*>( R + rec[0] );
+#pragma unroll
+          for ( int k = 0; k < K; ++k ) be[k] = h.be, dc[k] = h.dc;
+        } else {
+#pragma unroll
+          for ( int k = 0; k < K; ++k ) {
+            PieceHot0 h{0, 0};
+            if ( rec[k] != kNoRec ) h = *reinterpret_cast<const PieceHot0*>( R + rec[k] );
+            be[k] = h.be, dc[k] = h.dc;
+          }
+        }
+      }
+      // ---- first sweep: class ">= cut", prefix sum
+      uint32_t f1 = 0;  // bit k: position p0 + k is of the class
+      {
+        Pt x[K];
+#pragma unroll
+        for ( int k = 0; k < K; k += 2 ) *reinterpret_cast<uint4*>( &x[k] ) = *reinterpret_cast<const uint4*>( P + p0 + k );
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) {
+          const int d = int( ( dc[k] >> 16 ) & 0xFFu ), c = int( int16_t( dc[k] & 0xFFFFu ) );
+          const int v = int( int16_t( __builtin_bit_cast( uint64_t, x[k] ) >> ( 16 * d ) ) );  // (a shift, not a three-way select: that one became an indexed load from the stack)
+          if ( rec[k] != kNoRec && v >= c ) f1 |= 1u << k;
+        }
+      }
+      uint32_t preA[K + 1];  // prefix at p0 .. p0 + K
+      {
+        uint32_t at = pieceScan<WAVES>( uint32_t( __popc( f1 ) ), sWave[0] );
+        uint16_t out[K];
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) preA[k] = at, out[k] = uint16_t( at ), at += ( f1 >> k ) & 1u;
+        preA[K] = at;
+        if ( K == 4 )
+          *reinterpret_cast<uint2*>( pre + p0 ) = *reinterpret_cast<const uint2*>( out );
+        else
+          *reinterpret_cast<uint4*>( pre + p0 ) = *reinterpret_cast<const uint4*>( out );
+        if ( tid == THREADS - 1 ) pre[kPieceMax] = uint16_t( at );
+      }
+      pieceBarrier();
+      // ---- the misplaced right-hand elements ("< cut" beyond the edge) publish their position by rank from the right
+      uint32_t edge1[K], rb1[K];
+#pragma unroll
+      for ( int k = 0; k < K; ++k ) {
+        edge1[k] = rb1[k] = 0;
+        if ( rec[k] == kNoRec ) continue;
+        if ( k > 0 && rec[k] == rec[k - 1] ) {
+          edge1[k] = edge1[k - 1], rb1[k] = rb1[k - 1];
+        } else {
+          const uint32_t b = be[k] & 0xFFFFu, e = be[k] >> 16, rb = pre[b], re = pre[e];
+          edge1[k] = b + ( ( e - b ) - ( re - rb ) ), rb1[k] = rb | ( re << 16 );
+        }
+        const uint32_t p = p0 + k, b = be[k] & 0xFFFFu, e = be[k] >> 16;
+        if ( p >= edge1[k] && !( ( f1 >> k ) & 1u ) ) lst[b + ( ( e - p - 1u ) - ( ( rb1[k] >> 16 ) - preA[k + 1] ) )] = uint16_t( p );
+        if ( p == b ) *reinterpret_cast<uint32_t*>( &R[rec[k]].edge1 ) = edge1[k] | ( ( rb1[k] & 0xFFFFu ) << 16 );
+      }
+      pieceBarrier();
+      // ---- ... and the misplaced left-hand elements (">= cut" before the edge) swap with the entry of their rank from the left
+#pragma unroll
+      for ( int k = 0; k < K; ++k ) {
+        const uint32_t p = p0 + k;
+        if ( rec[k] != kNoRec && p < edge1[k] && ( ( f1 >> k ) & 1u ) ) {
+          const uint32_t j  = lst[( be[k] & 0xFFFFu ) + ( preA[k] - ( rb1[k] & 0xFFFFu ) )];
+          const Pt       px = P[p], pj = P[j];
+          const uint32_t ip = perm[p], ij = perm[j];
+          P[p] = pj, P[j] = px, perm[p] = ij, perm[j] = ip;
+        }
+      }
+      pieceBarrier();
+      // ---- second sweep on [edge1, end): class "> cut", prefix sum
+      uint32_t f2 = 0;
+      {
+        Pt x[K];
+#pragma unroll
+        for ( int k = 0; k < K; k += 2 ) *reinterpret_cast<uint4*>( &x[k] ) = *reinterpret_cast<const uint4*>( P + p0 + k );
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) {
+          const int d = int( ( dc[k] >> 16 ) & 0xFFu ), c = int( int16_t( dc[k] & 0xFFFFu ) );
+          const int v = int( int16_t( __builtin_bit_cast( uint64_t, x[k] ) >> ( 16 * d ) ) );  // (a shift, not a three-way select: that one became an indexed load from the stack)
+          if ( rec[k] != kNoRec && p0 + k >= edge1[k] && v > c ) f2 |= 1u << k;
+        }
+      }
+      {
+        uint32_t at = pieceScan<WAVES>( uint32_t( __popc( f2 ) ), sWave[1] );
+        uint16_t out[K];
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) preA[k] = at, out[k] = uint16_t( at ), at += ( f2 >> k ) & 1u;
+        preA[K] = at;
+        if ( K == 4 )
+          *reinterpret_cast<uint2*>( pre + p0 ) = *reinterpret_cast<const uint2*>( out );
+        else
+          *reinterpret_cast<uint4*>( pre + p0 ) = *reinterpret_cast<const uint4*>( out );
+        if ( tid == THREADS - 1 ) pre[kPieceMax] = uint16_t( at );
+      }
+      pieceBarrier();
+      // ---- per record: the second sweep's edge, the balance rule, the children (records of the next depth, or leaves);
+      //      per element: the misplaced right-hand elements of the second sweep ("<= cut" beyond its edge) publish
+      const uint32_t base = sNodeBase;
+      for ( uint32_t r = tid; r < nc; r += THREADS ) {
+        PieceRec*      q  = R + r;
+        const uint32_t b = q->begin, e = q->end, e1 = q->edge1, rb2 = pre[e1], re2 = pre[e];
+        const uint32_t e2   = e1 + ( ( e - e1 ) - ( re2 - rb2 ) );
+        const uint32_t n    = e - b, half = n / 2, lim1 = e1 - b, lim2 = e2 - b;
+        const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
+        const uint32_t mid  = b + idx;
+        const uint32_t id0  = base + 2u * r;
+        const int      dim  = q->dim;
+        const int16_t  cut  = q->cut;
+        q->edge2 = uint16_t( e2 ), q->rb2 = uint16_t( rb2 ), q->mid = uint16_t( mid );
+        q->lmax = int32_t( 0x80000000 ), q->rmin = 0x7FFFFFFF;
+#pragma unroll
+        for ( int c = 0; c < 2; ++c ) {
+          const uint32_t cb = c ? mid : b, ce = c ? e : mid;
+          if ( ce - cb <= uint32_t( kLeafMax ) ) {
+            KdNode leaf;
+            leaf.a = int32_t( seg.begin + cb ), leaf.b = int32_t( seg.begin + ce ), leaf.divlow = leaf.divhigh = 0, leaf.dim = -1;
+            a.nodes[id0 + c] = leaf;
+            q->child[c]      = kNoRec;
+            deepest          = max( deepest, seg.level + depth + 2u );
+          } else {
+            const uint32_t slot = atomicAdd( &sCount[cur ^ 1], 1u );
+            PieceRec*      ch   = RN + slot;
+            ch->begin = uint16_t( cb ), ch->end = uint16_t( ce ), ch->node = id0 + c;
+            int16_t l0 = q->lo[0], l1 = q->lo[1], l2 = q->lo[2], h0 = q->hi[0], h1 = q->hi[1], h2 = q->hi[2];
+            if ( c == 0 ) {
+              if ( dim == 0 ) h0 = cut;
+              if ( dim == 1 ) h1 = cut;
+              if ( dim == 2 ) h2 = cut;
+            } else {
+              if ( dim == 0 ) l0 = cut;
+              if ( dim == 1 ) l1 = cut;
+              if ( dim == 2 ) l2 = cut;
+            }
+            ch->lo[0] = l0, ch->lo[1] = l1, ch->lo[2] = l2, ch->hi[0] = h0, ch->hi[1] = h1, ch->hi[2] = h2;
+            ch->mn[0] = ch->mn[1] = ch->mn[2] = 0x7FFFFFFF, ch->mx[0] = ch->mx[1] = ch->mx[2] = int32_t( 0x80000000 );
+            q->child[c] = uint16_t( slot );
+          }
+        }
+      }
+      uint32_t edge2[K], rb2[K];
+#pragma unroll
+      for ( int k = 0; k < K; ++k ) {
+        edge2[k] = rb2[k] = 0;
+        if ( rec[k] == kNoRec ) continue;
+        const uint32_t e = be[k] >> 16, e1 = edge1[k];
+        if ( k > 0 && rec[k] == rec[k - 1] ) {
+          edge2[k] = edge2[k - 1], rb2[k] = rb2[k - 1];
+        } else {
+          const uint32_t rb = pre[e1], re = pre[e];
+          edge2[k] = e1 + ( ( e - e1 ) - ( re - rb ) ), rb2[k] = rb | ( re << 16 );
+        }
+        const uint32_t p = p0 + k;
+        if ( p >= edge2[k] && !( ( f2 >> k ) & 1u ) ) lst[e1 + ( ( e - p - 1u ) - ( ( rb2[k] >> 16 ) - preA[k + 1] ) )] = uint16_t( p );
+      }
+      pieceBarrier();
+      // (the records of the next depth are counted: their children's node ids, a few passes ahead of their use)
+      prevBase = base, prevCount = nc;
+      if ( tid == 0 && sCount[cur ^ 1] ) idPending = atomicAdd( a.nodeCount, 2u * sCount[cur ^ 1] );
+      // ---- second sweep: the misplaced left-hand elements ("> cut" in [edge1, edge2)) swap
+#pragma unroll
+      for ( int k = 0; k < K; ++k ) {
+        const uint32_t p = p0 + k;
+        if ( rec[k] != kNoRec && p >= edge1[k] && p < edge2[k] && ( ( f2 >> k ) & 1u ) ) {
+          const uint32_t j  = lst[edge1[k] + ( preA[k] - ( rb2[k] & 0xFFFFu ) )];
+          const Pt       px = P[p], pj = P[j];
+          const uint32_t ip = perm[p], ij = perm[j];
+          P[p] = pj, P[j] = px, perm[p] = ij, perm[j] = ip;
+        }
+      }
+      pieceBarrier();
+      // ---- the elements have landed: tight ranges of the children (one segmented reduction per wavefront where a thread's
+      //      positions share a child, LDS atomics where they do not), divlow / divhigh of the parent, record of a position
+      {
+        uint32_t key[K], mc[K], c1[K];
+        bool     same = true;
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) {
+          mc[k] = c1[k] = 0;
+          if ( rec[k] != kNoRec ) {
+            if ( k > 0 && rec[k] == rec[k - 1] ) {
+              mc[k] = mc[k - 1], c1[k] = c1[k - 1];
+            } else {
+              const PieceHot2 h = *reinterpret_cast<const PieceHot2*>( &R[rec[k]].mid );
+              mc[k] = h.midc0, c1[k] = h.c1 & 0xFFFFu;
+            }
+          }
+          key[k] = rec[k] == kNoRec ? kNoKey : 2u * rec[k] + ( p0 + k >= ( mc[k] & 0xFFFFu ) ? 1u : 0u );
+          same   = same && key[k] == key[0];
+        }
+        Pt x[K];
+#pragma unroll
+        for ( int k = 0; k < K; k += 2 ) *reinterpret_cast<uint4*>( &x[k] ) = *reinterpret_cast<const uint4*>( P + p0 + k );
+        uint32_t A = pk2( 0x7FFF, 0x7FFF ), B = pk2( -0x8000, -0x8000 ), C = pk2( 0x7FFF, 0x7FFF );
+        if ( same && key[0] != kNoKey ) {
+#pragma unroll
+          for ( int k = 0; k < K; ++k )
+            A = pkMin( A, pk2( x[k].x, x[k].y ) ), B = pkMax( B, pk2( x[k].x, x[k].y ) ), C = pkMin( C, pk2( x[k].z, ~int( x[k].z ) ) );
+        }
+        const bool head = waveSegMinMaxPacked( same ? key[0] : kNoKey, A, B, C, lane );
+        uint16_t out[K];
+#pragma unroll
+        for ( int k = 0; k < K; ++k ) {
+          out[k] = kNoRec;
+          if ( key[k] == kNoKey ) continue;
+          const uint32_t side = key[k] & 1u;
+          const uint32_t cr   = side ? c1[k] : ( mc[k] >> 16 );
+          out[k]              = uint16_t( cr );
+          if ( same ? ( k > 0 || !head ) : false ) continue;
+          int mnx, mny, mnz, mxx, mxy, mxz;
+          if ( same )
+            mnx = pkLo( A ), mny = pkHi( A ), mnz = pkLo( C ), mxx = pkLo( B ), mxy = pkHi( B ), mxz = ~pkHi( C );
+          else
+            mnx = mxx = x[k].x, mny = mxy = x[k].y, mnz = mxz = x[k].z;
+          PieceRec* q = R + rec[k];
+          const int d = int( ( dc[k] >> 16 ) & 0xFFu );
+          if ( side == 0 )
+            ldsMax( &q->lmax, d == 0 ? mxx : ( d == 1 ? mxy : mxz ) );
+          else
+            ldsMin( &q->rmin, d == 0 ? mnx : ( d == 1 ? mny : mnz ) );
+          if ( cr != kNoRec ) {
+            PieceRec* ch = RN + cr;
+            ldsMin( &ch->mn[0], mnx ), ldsMin( &ch->mn[1], mny ), ldsMin( &ch->mn[2], mnz );
+            ldsMax( &ch->mx[0], mxx ), ldsMax( &ch->mx[1], mxy ), ldsMax( &ch->mx[2], mxz );
+          }
+        }
+        if ( K == 4 )
+          *reinterpret_cast<uint2*>( segOf + p0 ) = *reinterpret_cast<const uint2*>( out );
+        else
+          *reinterpret_cast<uint4*>( segOf + p0 ) = *reinterpret_cast<const uint4*>( out );
+      }
+      cur ^= 1;
+    }
+    if ( deepest ) atomicMax( &sDepth, deepest );
+    pieceBarrier();
+    for ( uint32_t i = tid; i < cnt; i += THREADS ) {
+      a.P[seg.begin + i]    = P[i];
+      a.perm[seg.begin + i] = perm[i];
+    }
+    if ( tid == 0 && sDepth ) atomicMax( a.finishDepth, sDepth );
   }
 }
 
@@ -1316,10 +2273,17 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   TMC2_TRY( d_retired.alloc( maxRetired ) );
   TMC2_TRY( d_big.alloc( size_t( n ) / ( kRetire + 1 ) + 2 ) );  // (disjoint segments of more than kRetire points)
   DevBuf<HugeSeg> d_huge;
-  TMC2_TRY( d_huge.alloc( size_t( n ) / ( kSplitMax + 1 ) + 2 ) );  // (disjoint segments of more than kSplitMax points)
+  TMC2_TRY( d_huge.alloc( size_t( n ) / ( std::min( kSplitMax, kPieceMax ) + 1 ) + 2 ) );  // (disjoint segments of more than splitMax points)
   // (test hook TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes; <= kSplitMax: that tier is off)
+  // Form of the lower tiers: pieces of at most kPieceMax points, one workgroup each, all nodes of a depth at once (pieceKernel,
+  // the default), or round 4's three tiers (TMC2_KD_FORM=tiers: kept as the cross-check of the other).
+  const char*    formEnv = getenv( "TMC2_KD_FORM" );
+  const bool     pieces  = !( formEnv && !strcmp( formEnv, "tiers" ) );
   const char*    hugeEnv = getenv( "TMC2_KD_HUGEMAX" );
-  const uint32_t hugeMax = std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kSplitMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 32768u ) );
+  // (TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes from the level passes -- with the pieces it saves
+  //  the last few level passes, which move a few dozen segments of 4 097 .. hugeMax points with five chip-wide launches each)
+  const uint32_t hugeMax = pieces ? std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kPieceMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 16384u ) )
+                                  : std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kSplitMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 32768u ) );
   TMC2_TRY( d_work.alloc( 3 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
@@ -1342,15 +2306,37 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.huge         = d_huge.p;
   a.hugeCount    = d_small.p + kMaxLevels + 7;
   a.hugeMax      = hugeMax;
+  a.retireMax    = pieces ? uint32_t( kPieceMax ) : uint32_t( kRetire );
+  a.splitMax     = pieces ? uint32_t( kPieceMax ) : uint32_t( kSplitMax );
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
-  hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
+  // round 5's level passes go with the pieces (TMC2_KD_LEVELS=r4: round 4's five launches per level, the cross-check); their
+  // swap passes keep the tile totals in LDS
+  const char*  levelsEnv = getenv( "TMC2_KD_LEVELS" );
+  const size_t sumsLds   = ( size_t( tiles ) + 1 ) * 4;
+  const bool   newLevels = pieces && !( levelsEnv && !strcmp( levelsEnv, "r4" ) ) && sumsLds <= 48 * 1024;
+  DevBuf<LvSeg>    d_lv;
+  DevBuf<uint16_t> d_list;
+  DevBuf<LvPartial> d_partial;
+  const size_t     maxLv = 2 * ( size_t( n ) / ( size_t( kPieceMax ) + 1 ) + 2 );  // (segments that split are disjoint and hold > kPieceMax points)
+  if ( newLevels ) {
+    TMC2_TRY( d_lv.alloc( 2 * maxLv ) );
+    TMC2_TRY( d_list.alloc( size_t( tiles ) * kScanTile ) );
+    TMC2_TRY( d_partial.alloc( size_t( n ) / kBlock + 2 ) );
+    a.lvA = d_lv.p, a.lvB = d_lv.p + maxLv, a.list = d_list.p, a.partial = d_partial.p;
+    hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 1 ), 0, s, a );
+    hipLaunchKernelGGL( lvInitKernel, grdE, blk, 0, s, a );
+    hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, 0u );
+  } else {
+    a.lvA = a.lvB = nullptr, a.list = nullptr, a.partial = nullptr;
+    hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
+  }
   uint32_t out[kMaxLevels + 16];
   int      found = -1;
   // How many levels the passes run is only known on the device.  Frames of a sequence are alike: the count of the last tree
   // of about this size (kept in the context) is queued back to back and then checked; without it, the levels that cannot be
   // the last; afterwards two at a time per read-back (launches past the last level find nothing to do).
-  int& hint = ctx->kdLevelHint[n >> 15];
+  int& hint = ctx->kdLevelHint[( n >> 15 ) * 2u + ( pieces ? 1u : 0u )];
   for ( uint32_t level = 0; level < uint32_t( kMaxLevels ) && found < 0; ) {
     uint32_t chunkEnd = level + 1;
     if ( level == 0 && hint > 0 ) {
@@ -1360,11 +2346,19 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
       if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 2, kMaxLevels );
     }
     for ( ; level < chunkEnd; ++level ) {
-      hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
-      hipLaunchKernelGGL( decideFlagKernel, grdT, blk, 0, s, a, level );
-      hipLaunchKernelGGL( swapOneKernel, grdE, blk, 0, s, a, level );
-      hipLaunchKernelGGL( flagTwoKernel, grdT, blk, 0, s, a, level );
-      hipLaunchKernelGGL( swapTwoKernel, grdE, blk, 0, s, a, level );
+      if ( newLevels ) {
+        hipLaunchKernelGGL( lvFlagKernel<true>, grdT, blk, 0, s, a, level );
+        hipLaunchKernelGGL( lvSwapOneKernel, grdE, blk, sumsLds, s, a, level );
+        hipLaunchKernelGGL( lvFlagKernel<false>, grdT, blk, 0, s, a, level );
+        hipLaunchKernelGGL( lvSwapTwoKernel, grdE, blk, sumsLds, s, a, level );
+        hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, level + 1u );
+      } else {
+        hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
+        hipLaunchKernelGGL( decideFlagKernel, grdT, blk, 0, s, a, level );
+        hipLaunchKernelGGL( swapOneKernel, grdE, blk, 0, s, a, level );
+        hipLaunchKernelGGL( flagTwoKernel, grdT, blk, 0, s, a, level );
+        hipLaunchKernelGGL( swapTwoKernel, grdE, blk, 0, s, a, level );
+      }
     }
     TMC2_HIP( hipGetLastError() );
     TMC2_HIP( hipMemcpyAsync( out, d_small.p, sizeof( out ), hipMemcpyDeviceToHost, s ) );
@@ -1383,6 +2377,33 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   hint  = std::max( found, 1 );
   const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
+  if ( pieces ) {  // everything below the level passes: one workgroup per piece
+    const uint32_t hugeSegs = out[kMaxLevels + 7];
+    if ( hugeSegs )  // (segments of up to hugeMax points: one workgroup each cuts its segment into pieces, which join the list)
+      hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( hugeSegs, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );
+    const uint32_t retired = out[kMaxLevels + 3] + hugeSegs * ( 2u * hugeMax / uint32_t( kPieceMax ) );
+    if ( retired ) {
+      const char* perEnv = getenv( "TMC2_KD_PIECE_PER" );  // positions per thread: 4 (1 024 threads) or 8 (512)
+      const dim3  grid( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) );
+      if ( perEnv && atoi( perEnv ) == 8 ) {
+        TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<8> ), kPieceLdsBytes, ctx->device, 256 ) );
+        hipLaunchKernelGGL( pieceKernel<8>, grid, dim3( kPieceMax / 8 ), kPieceLdsBytes, s, a );
+      } else {
+        TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<4> ), kPieceLdsBytes, ctx->device, 256 ) );
+        hipLaunchKernelGGL( pieceKernel<4>, grid, dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
+      }
+      TMC2_HIP( hipGetLastError() );
+      uint32_t fin = 0;
+      TMC2_HIP( hipMemcpyAsync( &fin, a.finishDepth, 4, hipMemcpyDeviceToHost, s ) );
+      TMC2_HIP( hipStreamSynchronize( s ) );
+      if ( fin >= uint32_t( kMaxLevels ) ) {
+        setError( "kdtree: more than %d levels", kMaxLevels - 1 );
+        return TMC2_E_UNSUPPORTED;
+      }
+      depth = std::max( depth, int( fin ) );
+    }
+    return TMC2_OK;
+  }
   const uint32_t huge = out[kMaxLevels + 7];
   if ( huge )  // segments of up to hugeMax points: one workgroup each, their pieces join the two lists below
     hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( huge, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );

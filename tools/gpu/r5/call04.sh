@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, call 4: the re-cut level passes (lists instead of binary searches, decide per segment, ranges gathered by the landing pass)
+export TMPDIR=/tmp; mkdir -p gpurun_out; O=$(pwd)/gpurun_out
+(timeout -k 10 600 python -m pytest tests/test_gpu_segmenter.py tests/test_gpu_fuzz.py -m gpu -x -q -k "kdtree or fuzz" 2>&1 | tail -15) > $O/r05c4_kd_tests.log 2>&1
+tail -2 $O/r05c4_kd_tests.log
+REPO=$(pwd); SOLO="python $REPO/bench.py --steps 1 --warmup 1 --frames 1 --workers 1 --gen-procs 1 --cpu-baseline 0 --tail 0 --ingest 0 --decoder 0"
+cd /tmp
+for lv in r5 r4; do
+  rm -rf $O/prof_solo; TMC2_KD_LEVELS=$lv timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_solo -- $SOLO > $O/kd_prof.log 2>&1
+  DB=$(find $O/prof_solo -name "*_results.db" | head -1)
+  echo "TMC2_KD_LEVELS=$lv  $(grep -o '"kdtree_build": [0-9.]*' $O/kd_prof.log | head -1) $(grep -o '"verified": [a-z]*' $O/kd_prof.log | head -1)"; python $REPO/profiles/summarise_rocpd.py "$DB" "$SOLO" | grep -E "pieceKernel|lv[A-Z]|rangeKernel|decideFlag|swapOne|flagTwo|swapTwo"
+done
+rm -rf $O/prof_solo
+cd $REPO; (timeout -k 10 600 python -m pytest tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -3) > $O/r05c4_full.log 2>&1; tail -1 $O/r05c4_full.log
