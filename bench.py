@@ -43,9 +43,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--prime", type=int, default=3, help="untimed passes of set-up before the W warmup steps: the contexts' pools see "
-                    "every buffer size of the GOF once (a first-use hipMalloc synchronises the device; measured on one box: "
-                    "--steps 2 --warmup 1 without them 158-161 frames/s, settled 174-176)")
+    ap.add_argument("--prime", type=int, default=0, help="untimed passes of set-up before the W warmup steps (rounds 3-4 needed three: "
+                    "the contexts' pools sized their buffers by first use, and a first-use hipMalloc synchronises the device; round "
+                    "5 reserves the sequence's worst case at context creation, tmc2_ctx_reserve, and reports the first passes as "
+                    "first_gof_ms)")
+    ap.add_argument("--reserve", type=int, default=1, help="0: no tmc2_ctx_reserve (the pools grow by hipMalloc on first use)")
     ap.add_argument("--config", default="longdress", help="BASELINE configuration: a short name (%s) or a case of "
                     "tmc2_amd/configs.py FULL_SIZE_CASES -- workload, frames, refine iterations / voxel size, bit depth, occupancy "
                     "precision, minimum canvas and packing condition come from the CTC table there, and the timed step is checked "
@@ -58,7 +60,9 @@ def parse():
                     help="where the k-d trees are built (auto = device)")
     ap.add_argument("--iterations", type=int, default=None, help="iterationCountRefineSegmentation (default: the configuration's)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg; 2 runs it inside this process "
-                    "(the round-3 form: two builds of the reference loaded next to the product library)")
+                    "(the round-3 form: two builds of the reference loaded next to the product library); 3: the bounded form -- one "
+                    "frame on one thread and 8 frames through the reference's TBB path, no CLI run, no process-per-frame bound (what "
+                    "the per-configuration lines of tools/gpu/final.sh use)")
     ap.add_argument("--ingest", type=int, default=1, help="0 skips the (untimed) PLY ingest measurement")
     ap.add_argument("--tail", type=int, default=1, help="0 skips the (untimed) post-reconstruction tail measurement")
     ap.add_argument("--decoder", type=int, default=1, help="0 skips the decoder-side GOF leg (BASELINE config 5: reconstruct + "
@@ -73,8 +77,10 @@ def parse():
                          "worse -- measured 132 against 152 frames/s)")
     ap.add_argument("--host", default="auto", choices=["auto", "native", "python"],
                     help="who drives the C-ABI inside the timed region: native = one tmc2_gof_encode call per GOF (libtmc2gof.so: C++ "
-                         "threads, include/tmc2gof.h), python = GofEncoder's worker threads.  auto: native on one GPU, python "
-                         "with several ranks (the collectives of the sharded GOF are torch.distributed's)")
+                         "threads, include/tmc2gof.h; with several ranks tmc2_gof_encode_sharded: the all-intra GOF's collectives are "
+                         "RCCL calls from C++), python = GofEncoder's worker threads.  auto: native on one GPU, python with several "
+                         "ranks (the collectives of the sharded GOF are torch.distributed's there; the packing chains of the "
+                         "low-delay / random-access conditions need that route)")
     ap.add_argument("--pin", type=int, default=1, help="0: plain host buffers instead of page-locked ones for the canvases (for runs "
                     "under a sanitizer runtime, where torch's pinned allocator does not come up; slower copies)")
     ap.add_argument("--gather", default="host", choices=["host", "rccl"],
@@ -251,7 +257,7 @@ def physical_cores():
         return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(workload, iterations, gof, case):
+def cpu_baseline(workload, iterations, gof, case, bounded=False):
     """The same workload through the CPU checker (test infrastructure, used here only as the reported baseline): the
     unmodified reference if oracle/_ref travelled with the repo, else our restatement.  One frame on one thread; then a GOF
     through the reference's own TBB path on all physical cores (its ENABLE_TBB build with the vendored TBB)."""
@@ -278,7 +284,7 @@ def cpu_baseline(workload, iterations, gof, case):
         with open("/proc/meminfo") as f:
             avail_gb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1048576.0
         scale = max(1.0, len(gof[0][0]) / 0.84e6)                              # (memory per frame follows the point count)
-        nfr = int(max(1, min(len(gof), 16, avail_gb * 0.5 / (1.2 * scale))))          # bounded sample; ~1.2 GB per frame inside the reference's containers
+        nfr = int(max(1, min(len(gof), 8 if bounded else 16, avail_gb * 0.5 / (1.2 * scale))))   # bounded sample; ~1.2 GB per frame inside the reference's containers
         gof = gof[:nfr]                                                      # (the frames of the timed GOF, generated already)
         eng = ob.Reference(tbb=True, nb_thread=cores)
         t = time.time()
@@ -292,6 +298,8 @@ def cpu_baseline(workload, iterations, gof, case):
                                    "inside a frame), same stages, %.1f s wall" % (nfr, cores, wall))
     except Exception as e:
         res["all_cores_error"] = repr(e)
+    if bounded:                                                # (--cpu-baseline 3: one thread + the TBB path, nothing else)
+        return res
     try:                                                       # the CLI's wall time next to the stage sum
         res["cli"] = cpu_baseline_cli(frames[0], iterations, dt)
     except Exception as e:
@@ -609,14 +617,17 @@ def gather_canvases(enc, frames, sharder, cache, pin=True):
 
 def main():
     a = parse()
-    if a.cpu_child == "baseline":                              # the whole CPU baseline leg, in a process of its own
+    if a.cpu_child in ("baseline", "baseline-bounded"):        # the whole CPU baseline leg, in a process of its own
         from tmc2_amd.synth import synth_cloud
-        print(json.dumps(cpu_baseline(a.workload, a.iterations, [synth_cloud(a.workload, i) for i in range(min(a.frames, 16))], a.case)))
+        bounded = a.cpu_child == "baseline-bounded"
+        print(json.dumps(cpu_baseline(a.workload, a.iterations, [synth_cloud(a.workload, i) for i in range(min(a.frames, 8 if bounded else 16))],
+                                      a.case, bounded=bounded)))
         return
     if a.cpu_child:
         return cpu_child(a.cpu_child, a.workload, a.iterations, a.case)
-    if a.host == "native" and max(a.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1:
-        raise SystemExit("bench.py: --host native drives one process's frames; the sharded GOF (--gpus N) meets over torch.distributed")
+    if a.host == "native" and max(a.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 and a.packing != "all-intra":
+        raise SystemExit("bench.py: --host native with several ranks runs the all-intra GOF (tmc2_gof_encode_sharded: RCCL from C++); the "
+                         "%s packing chain runs over ALL frames in order -- that sharded GOF meets over torch.distributed (--host python)" % a.packing)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_launcher(a)                              # (does not return)
     rank = int(os.environ.get("RANK", "0"))
@@ -667,11 +678,13 @@ def main():
     # (round 1 preferred host builds above 8 frames in flight; with the subtree-finishing device build the device wins:
     #  16 frames in flight, measured: device 85, host 75 frames/s -- and the host cores stay free)
     kd_mode = {"device": 0, "host": 1, "adaptive": 2}.get(a.kdtree, 0)
-    T.load_library().tmc2_set_kdtree_placement(kd_mode)
     c = a.case
     P = c["precision"]
     enc = T.GofEncoder(local, workers, a.iterations, c["bits3d"], P, c["min_w"], c["min_h"], timing=True, first_domain=rank * workers,
                        vox_dim=c["vox_dim"])
+    enc.set_option("KDTREE_HOST", kd_mode)                # (options of this encoder's contexts: nothing process-wide)
+    if a.reserve:                                          # the sequence's largest frame, before the first one arrives
+        enc.reserve(max(len(c_[0]) for c_ in clouds), c["min_w"], max(c["min_h"], c["min_w"]))
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
 
@@ -713,19 +726,29 @@ def main():
         return host_cache[(W, H)]
 
     native = a.host == "native" or (a.host == "auto" and world == 1)
+    comm = None
     if native:
         from tmc2_amd import native_gof
         native_gof.load_library()                           # (fails here, loudly, if it was not built)
+        if world > 1:                                       # the ranks of the sharded GOF meet in C++: RCCL on this rank's stream
+            comm = native_gof.Comm(enc.ctxs[0], rank, world)
     capacity = [c["min_w"], c["min_h"]]
 
     def native_step():
         # reset, S0, S1-S9 + packing, the rendezvous, S12-S22 and the copies into page-locked host memory: one call into C++
         while True:
             try:
+                if comm is not None:                        # this rank's frames; weights, canvas height and records cross over RCCL
+                    W_, H_, recs = native_gof.encode_sharded(comm, frames, [i % workers for i in range(len(frames))], workers, a.iterations,
+                                                             c["vox_dim"], c["bits3d"], P, c["min_w"], c["min_h"], host_out(*capacity),
+                                                             capacity, record_slots=RECORD_SLOTS)
+                    if recs is not None:
+                        gather_cache["records"] = recs
+                    return W_, H_
                 return native_gof.encode(frames, [i % workers for i in range(len(frames))], workers, a.iterations, c["vox_dim"],
                                          c["bits3d"], P, c["min_w"], c["min_h"], a.packing, host_out(*capacity), capacity,
                                          guess_canvas=a.rendezvous == "one")
-            except native_gof.CanvasTooSmall as e:          # (first pass of a GOF that outgrows the minimum canvas)
+            except native_gof.CanvasTooSmall as e:          # (first pass of a GOF that outgrows the minimum canvas; the same on every rank)
                 capacity[:] = [max(capacity[0], e.size[0]), max(capacity[1], e.size[1])]
 
     def step():
@@ -769,8 +792,18 @@ def main():
         torch.cuda.synchronize()
         sharder.barrier()
 
-    for _ in range(max(0, a.prime) + a.warmup):
+    if to_host_here:
+        host_out(*capacity)                                 # the encoder's own output buffers (page-locked): set-up, not a pass
+    pass_ms = []                                            # the first passes of this process over the GOF, one by one
+    first_stage_ms = {}
+    for k_pass in range(max(0, a.prime) + a.warmup):
+        if k_pass == 0:
+            enc.stage_reset()
+        t_pass = time.time()
         step()
+        pass_ms.append(round(1e3 * (time.time() - t_pass), 2))
+        if k_pass == 0:
+            first_stage_ms = enc.stage_ms()                   # (event-bracketed: in flight from the first to the last launch of a stage)
     enc.stage_reset()
     sync()
     t0 = time.time()
@@ -802,18 +835,20 @@ def main():
             dist.barrier()                                  # (rank 0 may still be reading this rank's segment)
             dist.destroy_process_group()
         drop_shared()
+        if comm is not None:
+            comm.close()
         return
     # The timed region runs 32 frames at once: their launches share the chip and queue behind each other, so a kernel's
     # event-bracketed time in the region says how long it was in flight, not how much of the GPU it needs.  The kernel the
     # roofline is reported for is therefore chosen by its time with the GPU to itself (one frame, outside the timing);
     # both durations are reported.
-    T.load_library().tmc2_set_refine_overlap(1)             # one frame in flight: the library's few-frames-in-flight regime (what a
+    enc.set_option("REFINE_OVERLAP", 1)                     # one frame in flight: the library's few-frames-in-flight regime (what a
     for warm in (True, False):                              # GofEncoder of <= 4 workers sets; scheduling only, never a result);
         enc.stage_reset()                                   # once untimed: the regime holds its buffers in another order, and the
         frames[0].reset()                                   # context's pool has to have seen that (first-use hipMallocs otherwise)
         enc.phase_a(frames[:1], sharder=T.Sharder())
         enc.phase_b(frames[:1])
-    T.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
+    enc.set_option("REFINE_OVERLAP", 1 if workers <= 4 else 0)
     solo_ms, solo_calls = enc.stage_ms(), enc.stage_calls()
     n_frames = max(1, len(frames))
     N = n_points / n_frames
@@ -827,6 +862,12 @@ def main():
         if name == "refine_sweep":                         # one of the I sweeps of the refine_sweeps stage
             fl, al, n_l = ms.get("refine_sweeps", 0.0), solo_ms.get("refine_sweeps", 0.0), calls.get("refine_sweeps", 0) * I
             return fl / max(1, n_l), al / max(1, solo_calls.get("refine_sweeps", 1) * I), n_l, algorithmic_bytes(name, N, M, V, L, A, P)
+        if name == "tree_knn_normals":                     # SURVEY 8d's S1 + S2 + S6 row: source k-d tree build + 16-NN lists + normals = 94 N
+            parts = ("kdtree_build", "knn_self", "normals")
+            n_l = calls.get("knn_self", 0)
+            fl = sum(ms.get(k, 0.0) / max(1, calls.get(k, 1)) for k in parts)
+            al = sum(solo_ms.get(k, 0.0) / max(1, solo_calls.get(k, 1)) for k in parts)
+            return fl, al, n_l, 94.0 * N
         if name == "patches":                              # S7-S9: connected components + per-patch build, all rounds
             fl = ms.get("patches_cc", 0.0) + ms.get("patches_build", 0.0)
             al = solo_ms.get("patches_cc", 0.0) + solo_ms.get("patches_build", 0.0)
@@ -836,7 +877,7 @@ def main():
         return (ms.get(name, 0.0) / max(1, n_l), solo_ms.get(name, 0.0) / max(1, solo_calls.get(name, 1)), n_l,
                 algorithmic_bytes(name, N, M, V, L, A, P))
 
-    names = ["knn_self", "normals", "initial_segmentation", "refine_setup", "refine_sweep", "patches", "k:ccMutualMask",
+    names = ["tree_knn_normals", "knn_self", "normals", "initial_segmentation", "refine_setup", "refine_sweep", "patches", "k:ccMutualMask",
              "k:ccUnion", "k:ccRelax", "geometry_images", "reconstruct", "knn8_recon_in_source", "knn1_source_in_recon",
              "attribute_images"]
     per_stage, alone_total = {}, {}
@@ -887,6 +928,11 @@ def main():
         "metric": "encoder patch+image-gen frames/sec, %s %d-frame GOF" % (a.workload, a.frames),
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "priming_passes": max(0, a.prime), "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
+        "first_gof_ms": pass_ms[0] if pass_ms else None, "untimed_pass_ms": pass_ms, "pool": dict(enc.pool_stats(), reserved=bool(a.reserve)),
+        "first_gof_excess_ms_per_frame": dict(sorted(((k, round((first_stage_ms.get(k, 0.0) - v / a.steps) / max(1, len(frames)), 3))
+                                                      for k, v in ms.items() if first_stage_ms.get(k, 0.0) - v / a.steps > 0.2 * len(frames)
+                                                      and not k.startswith(("refine_row_entries", "refine_voxels", "refine_sweeps_executed"))),   # (counters, not times)
+                                                     key=lambda kv: -kv[1])[:8]),
         "scaling": "strong", "vs_baseline": None, "dtype": "int32/f64", "data": "synthetic",
         "verified": verdict, "verified_detail": detail,
         "config": {"workload": "%s-like synthetic, %d frames, %d points/frame avg, ctc-common + %s "
@@ -902,7 +948,9 @@ def main():
                                 ("; ".join(sorted(set("a /dev/shm segment per rank" if hasattr(v, "close") else str(v) for v in shared.values()))) or "private buffers",
                                  "RCCL" if a.dist_backend == "nccl" else "gloo")) if (world > 1 and a.gather == "host")
                                else ("gathered to rank 0 over RCCL, copied out from there" if world > 1 else "page-locked host memory"),
-                   "host": ("native: one tmc2_gof_encode call per GOF (libtmc2gof.so, C++ threads over the C-ABI)" if native
+                   "host": (("native: one tmc2_gof_encode_sharded call per GOF and rank (libtmc2gof.so: C++ threads over the C-ABI; weights, "
+                             "canvas height and patch records cross the node as RCCL collectives issued from C++)" if comm is not None else
+                             "native: one tmc2_gof_encode call per GOF (libtmc2gof.so, C++ threads over the C-ABI)") if native
                             else "python: GofEncoder's worker threads over the C-ABI"),
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "host_step_slots_per_gpu": slots, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
@@ -911,8 +959,9 @@ def main():
                      "alone_frac": round(s_ach / 8000.0, 5),
                      "algorithmic_MB_per_launch": round(dom_bytes / 1e6, 2),
                      "what": "the dominant GPU step by time with the GPU to itself (one frame in flight: the library's "
-                             "few-frames-in-flight regime, tmc2_set_refine_overlap), over every timed stage with a contract byte "
-                             "count (SURVEY.md 8d); refine_sweep = one of the %d sweeps of S5 = 4VL + 24V + 26N bytes" % I,
+                             "few-frames-in-flight regime, option REFINE_OVERLAP), over every timed stage with a contract byte "
+                             "count (SURVEY.md 8d; tree_knn_normals = its S1 + S2 + S6 row, the source tree build included: 94 N); "
+                             "refine_sweep = one of the %d sweeps of S5 = 4VL + 24V + 26N bytes" % I,
                      "N": int(N), "M": int(M), "V": int(V), "L": round(L, 1),
                      "path": {"B_alg_GB_per_frame": round(b_alg / 1e9, 3), "achieved": round(b_alg * fps / 1e9, 1),
                               "frac": round(b_alg * fps / 1e9 / 8000.0, 5)},
@@ -961,7 +1010,7 @@ def main():
                     fr.get_geometry_images(b4[i][0])
                     fr.get_attribute_images(b4[i][1])
                 enc.phase_a(sub, sharder=T.Sharder(), then=rest4)
-            T.load_library().tmc2_set_refine_overlap(1)         # (what a GofEncoder of <= 4 workers -- a rank of the 8-GPU run -- sets)
+            enc.set_option("REFINE_OVERLAP", 1)                 # (what a GofEncoder of <= 4 workers -- a rank of the 8-GPU run -- sets)
             rank_step()
             torch.cuda.synchronize()
             t0 = time.time()
@@ -970,7 +1019,7 @@ def main():
                 rank_step()
             torch.cuda.synchronize()
             ms4 = 1000.0 * (time.time() - t0) / reps
-            T.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
+            enc.set_option("REFINE_OVERLAP", 1 if workers <= 4 else 0)
             out["per_rank_proxy"] = {"frames": 4, "workers": 4, "ms": round(ms4, 2),
                                      "predicted_n8_frames_per_s": round(a.frames / (ms4 * 1e-3), 1),
                                      "predicted_n8_speedup": round(a.frames / (ms4 * 1e-3) / out["value"], 2),
@@ -1028,7 +1077,8 @@ def main():
         # "corrupted double-linked list" seconds into this leg; the path itself ran clean under MALLOC_CHECK_=3).
         import subprocess
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "baseline", "--workload", a.workload,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "baseline-bounded" if a.cpu_baseline == 3 else "baseline",
+                                "--workload", a.workload,
                                 "--iterations", str(a.iterations), "--frames", str(a.frames), "--config", a.case_name],
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1800)
             out["cpu_baseline"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
@@ -1046,6 +1096,8 @@ def main():
     # Orderly teardown (round 3 left through os._exit after an unexplained heap corruption in a bench process; DESIGN.md section 9
     # has what round 4 found): frames before their contexts, each worker thread ended and joined, contexts closed, then the
     # interpreter's own exit.
+    if comm is not None:
+        comm.close()
     for fr in frames:
         fr.close()
     enc.close(join=True)

@@ -33,12 +33,41 @@ typedef struct tmc2_gof_config {
  * caller's buffers (page-locked: tmc2_host_alloc; per-frame pointer arrays, any array or entry may be NULL):
  * occupancy u8[W*H], occVideo u8[(W/p)*(H/p)], blockToPatch u32[(W/16)*(H/16)], geometryD0 / D1 u16[W*H], attribute u8[2*3*W*H].
  * The canvas size is only known after the rendezvous: size the buffers for capacityWidth x capacityHeight; a GOF that needs a
- * larger canvas fails with TMC2_E_INVALID after the rendezvous (nothing written), *width / *height say what it needs.
- * Returns TMC2_OK or the first failing status; tmc2_gof_last_error() holds that call's message (of whichever thread failed). */
+ * larger canvas fails with TMC2_E_INVALID after the rendezvous, *width / *height say what it needs.  Nothing has been written to
+ * the buffers then -- EXCEPT with config->guessCanvas: there a frame whose own guess fitted has copied its canvases, laid out for
+ * the guessed size, before the GOF's size was known; after TMC2_E_INVALID the buffers' contents are undefined.
+ * Returns TMC2_OK or the first failing status; tmc2_gof_last_error() holds the message of the calling thread's last call (of
+ * whichever of its slot threads failed first).  No exception leaves the call (TMC2_E_STATE + message instead).        */
 int tmc2_gof_encode( tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots, const tmc2_gof_config* config,
                      uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch, uint16_t** geometryD0, uint16_t** geometryD1,
                      uint8_t** attribute, int32_t capacityWidth, int32_t capacityHeight, int32_t* width, int32_t* height );
 const char* tmc2_gof_last_error( void );
+
+/* ---- a GOF sharded over several processes, one per GPU (BASELINE configs 3-4: frame f of the GOF on rank f mod worldSize) -------
+ * The reference runs the frames of a GOF through one tbb::parallel_for in one address space (PCCEncoder.cpp:4729-4750) and takes
+ * the common canvas from all of them (:5546-5591).  Across processes the same three things cross the node, as RCCL collectives on
+ * the stream of the rank's context (librccl.so is loaded when a communicator is made; TMC2_E_UNSUPPORTED without it):
+ *   the axis weights of frame 0   24 bytes, ncclBroadcast from rank 0 (calculateWeightNormal looks at the first frame only);
+ *   the canvas height             ncclAllReduce( max ) of one int32;
+ *   the packed patch records      one grouped ncclSend / ncclRecv per pass to rank 0 (the bitstream's side information,
+ *                                 ~ 100 bytes a patch); the CANVASES do not cross xGMI: every rank copies its frames' canvases
+ *                                 into the (page-locked, shared) host buffers it was given, over its own PCIe link.
+ * tmc2_gof_comm_create: ctx = a context on this rank's device; rendezvous = the file rank 0 publishes the communicator's 128-byte
+ * id in and the other ranks read it from (NULL: /dev/shm/tmc2_gof_id_$MASTER_PORT -- one node); it ends with a checked
+ * all-reduce, so a rank that cannot reach the others fails here.  worldSize 1 is valid (the collectives still run).
+ * tmc2_gof_encode_sharded: tmc2_gof_encode over THIS rank's frames (every rank passes equally many), all-intra packing only --
+ * the low-delay / random-access chains need every frame's records on one rank, in frame order (TMC2_E_UNSUPPORTED; the caller
+ * gathers them, runs tmc2_host_place_segments and hands the lists back with tmc2_frame_set_packing).  Rank 0 receives the records:
+ * gathered[(r * count + i) * recordSlots + k] = patch k (list order) of frame i of rank r, gatheredCounts[r * count + i] their
+ * number (either may be NULL; ignored on the other ranks); a frame with more than recordSlots patches fails the call.       */
+typedef struct tmc2_gof_comm tmc2_gof_comm;
+int  tmc2_gof_comm_create( int rank, int worldSize, tmc2_ctx* ctx, const char* rendezvous, tmc2_gof_comm** out );
+void tmc2_gof_comm_destroy( tmc2_gof_comm* comm );
+int  tmc2_gof_encode_sharded( tmc2_gof_comm* comm, tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots,
+                              const tmc2_gof_config* config, uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch,
+                              uint16_t** geometryD0, uint16_t** geometryD1, uint8_t** attribute, int32_t capacityWidth,
+                              int32_t capacityHeight, int32_t* width, int32_t* height, int32_t recordSlots, tmc2_patch* gathered,
+                              int64_t* gatheredCounts );
 
 #ifdef __cplusplus
 }

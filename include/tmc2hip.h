@@ -100,6 +100,33 @@ int         tmc2_host_unregister( void* p );
  * Frames of a GOF run on separate host threads; this keeps the cache-hungry host steps at the core-complex count
  * while the GPU phases of the other frames proceed.                                                          */
 void        tmc2_set_host_parallelism( int maxConcurrentHostSteps );
+/* Per-context options: everything that tunes or cross-checks the path is a property of ONE context -- no process-global state, and
+ * the library does not look at the environment while it runs.  key = the knob's name (DESIGN.md section 5 lists them):
+ * "REFINE_OVERLAP" (0 / 1, below), "KDTREE_HOST" (0 / 1 / 2, below), "UF_PRECHECK" / "UF_SCOPE" / "UF_CHECK" (the union passes'
+ * conservative forms and debug invariants), "KD_FORM" / "KD_LEVELS" / "KD_HUGEMAX" (tiers of the device tree build),
+ * "REFINE_*" (forms and grids of the refinement), "METRICS_K", "ORIENT_*"; a "TMC2_" prefix is accepted and dropped.  When a
+ * context is created its options start as the TMC2_* variables of the process environment (read once, there); value NULL
+ * unsets an option.  None of them ever changes a result.                                                              */
+int         tmc2_ctx_set_option( tmc2_ctx* ctx, const char* key, const char* value );
+const char* tmc2_ctx_get_option( tmc2_ctx* ctx, const char* key );
+/* Reserve, at context creation time, the device memory the frames of a sequence will need (upper bounds of the sequence: points
+ * per frame, voxelDimensionRefineSegmentation, geometry3dCoordinatesBitdepth + 1, the largest canvas).  The reference sizes its
+ * containers per frame as it goes (std::vector growth inside PCCPatchSegmenter3::compute / PCCEncoder::generateGeometryVideo); here
+ * every temporary comes from the context's caching pool, whose FIRST use of a size is a hipMalloc -- a device-wide synchronisation
+ * under all frames in flight: the first GOFs of a process ran at half speed.  With the reservation the pool carves from memory it
+ * already holds.  Optional; a frame that needs more than was reserved still works (hipMalloc).                        */
+int         tmc2_ctx_reserve( tmc2_ctx* ctx, uint64_t maxPoints, int voxelDimRefine, int bits3d, int maxCanvasWidth, int maxCanvasHeight );
+int         tmc2_ctx_pool_stats( tmc2_ctx* ctx, uint64_t* bytesHeld, uint64_t* mallocCalls, double* mallocMs, uint64_t* carvedBlocks );
+/* Device staging for a host that exchanges small records between the ranks of a sharded GOF itself (libtmc2gof.so over RCCL,
+ * include/tmc2gof.h: the collectives need device buffers and the stream they become ready on): memory of the context's device,
+ * copies ordered on the context's stream (download waits for it), the stream (a hipStream_t) and the device ordinal.      */
+int         tmc2_ctx_device_alloc( tmc2_ctx* ctx, size_t bytes, void** out );
+int         tmc2_ctx_device_free( tmc2_ctx* ctx, void* p );
+int         tmc2_ctx_upload( tmc2_ctx* ctx, void* deviceDst, const void* hostSrc, size_t bytes );
+int         tmc2_ctx_download( tmc2_ctx* ctx, void* hostDst, const void* deviceSrc, size_t bytes );
+void*       tmc2_ctx_stream( tmc2_ctx* ctx );
+int         tmc2_ctx_device( tmc2_ctx* ctx );
+int         tmc2_ctx_make_current( tmc2_ctx* ctx );
 /* per-stage GPU time of the last frame operation, milliseconds (hipEvent); name list via index */
 int         tmc2_ctx_stage_count( tmc2_ctx* ctx );
 const char* tmc2_ctx_stage_name( tmc2_ctx* ctx, int i );
@@ -115,13 +142,15 @@ int  tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, u
 void tmc2_frame_destroy( tmc2_frame* f );
 /* the tree is built (host) and uploaded on first use; this forces it (PCCKdTree::init, PCCKdTree.cpp:56-59) */
 int  tmc2_kdtree_build( tmc2_frame* f );
-/* process-wide: where PCCKdTree::init runs.  0 (default): on the device, lowest latency for a frame on its own;
+/* where PCCKdTree::init runs: option "KDTREE_HOST" of the frame's context; this call presets what contexts WITHOUT the option do
+ * (rounds 1-4's process-wide switch).  0 (default): on the device, lowest latency for a frame on its own;
  * 1: on the host (same algorithm, same tree) -- with many frames in flight and idle host cores this leaves the
  * GPU to the stages only it can run; 2: adaptive -- on the host while one of the host slots
  * (tmc2_set_host_parallelism) is free at that moment, else on the device.  Both builders are exact; the choice
  * never changes a result.                                                                                   */
 void tmc2_set_kdtree_placement( int mode );
-/* process-wide: tmc2_segmenter_compute queues the geometry of the refinement (S5: voxels, neighbourhood rows -- it needs the
+/* option "REFINE_OVERLAP" of the frame's context (this call presets what contexts WITHOUT the option do):
+ * tmc2_segmenter_compute queues the geometry of the refinement (S5: voxels, neighbourhood rows -- it needs the
  * points only) before the host-resident walk of the normal orientation (S3) and builds it while the host walks.  Shortens a
  * frame's chain (few frames in flight: one rank of a many-GPU run); with the chip full of other frames it only competes with
  * them -- off by default.  The same setting makes the two kernels of a refinement sweep take the grids that are fastest with

@@ -228,8 +228,10 @@ int main( int argc, char** argv ) {
     for ( auto& t : makers ) t.join();
   }
   tmc2_set_host_parallelism( 16 );
-  tmc2_set_refine_overlap( workers <= 4 ? 1 : 0 );  // few frames in flight per device: shorten a frame's chain (include/tmc2hip.h)
-  tmc2_set_kdtree_placement( 0 );  // device trees (round 2: the device build beats the host build at every number of frames in flight)
+  for ( tmc2_ctx* c : ctx ) {  // options of THESE contexts (nothing process-wide: another encoder of the process keeps its own)
+    CHECK( tmc2_ctx_set_option( c, "REFINE_OVERLAP", workers <= 4 ? "1" : "0" ) );  // few frames in flight per device: shorten a frame's chain
+    CHECK( tmc2_ctx_set_option( c, "KDTREE_HOST", "0" ) );  // device trees (the device build beats the host build at every number of frames in flight)
+  }
 
   std::vector<Frame> gof( size_t( o.frames ) );
   // ingest + upload (all later calls on a frame are ordered on its slot's context)

@@ -1,5 +1,6 @@
 // api.cpp -- extern "C" surface of libtmc2hip.so (see include/tmc2hip.h for the reference seams).
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -9,6 +10,8 @@
 #include <mutex>
 
 #include "internal.h"
+
+extern char** environ;
 
 namespace tmc2 {
 // Opt-in to more than 48 KB of dynamic LDS, once per device and kernel: hipFuncSetAttribute mutates runtime-wide kernel
@@ -92,14 +95,39 @@ int DevicePool::acquire( size_t bytes, void** out, size_t* got ) {
       return TMC2_OK;
     }
   }
-  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> g( lock );
+    for ( Slab& sl : slabs ) {  // reserved memory first (256-byte aligned pieces; a piece goes back to the free lists like any block)
+      if ( sl.size - sl.used >= cls ) {
+        *out = sl.base + sl.used;
+        *got = cls;
+        sl.used += cls;
+        ++carved;
+        return TMC2_OK;
+      }
+    }
+  }
+  void*      p  = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   TMC2_HIP( hipMalloc( &p, cls ) );
+  const auto t1 = std::chrono::steady_clock::now();
   {
     std::lock_guard<std::mutex> g( lock );
     bytesHeld += cls;
+    ++mallocCalls;
+    mallocMs += std::chrono::duration<double, std::milli>( t1 - t0 ).count();
   }
   *out = p;
   *got = cls;
+  return TMC2_OK;
+}
+int DevicePool::reserve( size_t bytes ) {
+  bytes = ( bytes + 255 ) & ~size_t( 255 );
+  void* p = nullptr;
+  TMC2_HIP( hipMalloc( &p, bytes ) );
+  std::lock_guard<std::mutex> g( lock );
+  slabs.push_back( Slab{static_cast<char*>( p ), bytes, 0} );
+  bytesHeld += bytes;
   return TMC2_OK;
 }
 void DevicePool::recycle( void* p, size_t cls ) {
@@ -108,9 +136,17 @@ void DevicePool::recycle( void* p, size_t cls ) {
 }
 void DevicePool::drain() {
   std::lock_guard<std::mutex> g( lock );
+  const auto inSlab = [&]( const void* p ) {
+    for ( const Slab& sl : slabs )
+      if ( static_cast<const char*>( p ) >= sl.base && static_cast<const char*>( p ) < sl.base + sl.size ) return true;
+    return false;
+  };
   for ( auto& kv : freeBlocks )
-    for ( void* p : kv.second ) (void)hipFree( p );
+    for ( void* p : kv.second )
+      if ( !inSlab( p ) ) (void)hipFree( p );
   freeBlocks.clear();
+  for ( const Slab& sl : slabs ) (void)hipFree( sl.base );
+  slabs.clear();
 }
 
 void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* knn, int k, double* normals, void* scratch );
@@ -199,7 +235,105 @@ int tmc2_ctx_create( int device, tmc2_ctx** out ) {
     delete c;
     return TMC2_E_HIP;
   }
+  // the defaults of this context's options: every TMC2_* variable of the process environment, read here and never again
+  for ( char** e = environ; e && *e; ++e ) {
+    if ( strncmp( *e, "TMC2_", 5 ) != 0 ) continue;
+    const char* eq = strchr( *e, '=' );
+    if ( !eq ) continue;
+    c->options[std::string( *e + 5, size_t( eq - ( *e + 5 ) ) )] = std::string( eq + 1 );
+  }
   *out = c;
+  return TMC2_OK;
+}
+
+/* Per-context options: no process-global state, no environment look-ups at run time.  key: the knob's name without the
+   TMC2_ prefix ("REFINE_OVERLAP", "KDTREE_HOST", "UF_CHECK", "KD_FORM", ...: the names DESIGN.md lists); value NULL unsets it. */
+int tmc2_ctx_set_option( tmc2_ctx* ctx, const char* key, const char* value ) {
+  if ( !ctx || !key || !*key ) {
+    tmc2::setError( "tmc2_ctx_set_option: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  const std::string k = strncmp( key, "TMC2_", 5 ) == 0 ? key + 5 : key;
+  if ( value )
+    ctx->options[k] = value;
+  else
+    ctx->options.erase( k );
+  return TMC2_OK;
+}
+const char* tmc2_ctx_get_option( tmc2_ctx* ctx, const char* key ) {
+  if ( !ctx || !key ) return nullptr;
+  return tmc2::ctxOption( ctx, strncmp( key, "TMC2_", 5 ) == 0 ? key + 5 : key );
+}
+
+/* Device memory for the frames this context will see, allocated NOW: every buffer a stage asks the context's pool for is carved
+   from it, so that the first GOFs of a sequence make no hipMalloc (each one synchronises the device under all frames in flight).
+   The figure is an upper estimate of what ONE frame in flight holds at its peak (tmc2_ctx_pool_stats of the BASELINE
+   configurations, with the pool's power-of-two size classes): 2.1 KB per point with voxels of 4, 3.4 KB with voxels of 2, 64 bytes
+   per canvas pixel, the dense occupancy words of the refinement grid.  A frame that needs more falls back to hipMalloc. */
+int tmc2_ctx_reserve( tmc2_ctx* ctx, uint64_t maxPoints, int voxelDimRefine, int bits3d, int maxCanvasWidth, int maxCanvasHeight ) {
+  if ( !ctx || maxPoints == 0 || maxPoints > ( uint64_t( 1 ) << 32 ) || bits3d < 1 || bits3d > 16 || maxCanvasWidth < 0 || maxCanvasHeight < 0 ) {
+    tmc2::setError( "tmc2_ctx_reserve: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  tmc2::ApiScope scope( ctx );
+  const uint64_t perPoint = voxelDimRefine > 0 && voxelDimRefine <= 2 ? 3400 : 2100;
+  const int      gridShift = std::max( 1, bits3d - 1 - ( voxelDimRefine >= 4 ? 2 : ( voxelDimRefine >= 2 ? 1 : 0 ) ) );
+  const uint64_t dense     = ( uint64_t( 1 ) << std::min( 33, 3 * gridShift + 1 ) ) / 32 * 8;  // uint2 per 32 keys
+  const uint64_t bytes     = maxPoints * perPoint + uint64_t( maxCanvasWidth ) * uint64_t( maxCanvasHeight ) * 64 + dense + ( uint64_t( 64 ) << 20 );
+  // ... and the page-locked staging of the host-resident step of the default path (S3: cluster records, the reduced cross-edge
+  // list and the cluster signs): grown on first use otherwise -- hipHostMalloc / hipHostFree pairs in the middle of the first GOFs
+  if ( !ctx->hostC.get<uint32_t>( 4 + ( size_t( maxPoints ) + 4 ) / 4 + 4 ) || !ctx->hostA.get<tmc2::OrientClusterRec>( 64 * 1024 ) ||
+       !ctx->hostE.get<tmc2::OrientCompactEdge>( 384 * 1024 ) ) {
+    tmc2::setError( "tmc2_ctx_reserve: hipHostMalloc failed" );
+    return TMC2_E_HIP;
+  }
+  return ctx->pool.reserve( size_t( bytes ) );
+}
+/* what the context's pool holds (bytes of device memory, reserved slabs included), how many hipMalloc calls its misses have cost
+   so far and the host time spent in them, and how many blocks were carved from reserved memory instead */
+int tmc2_ctx_pool_stats( tmc2_ctx* ctx, uint64_t* bytesHeld, uint64_t* mallocCalls, double* mallocMs, uint64_t* carvedBlocks ) {
+  if ( !ctx ) return TMC2_E_INVALID;
+  std::lock_guard<std::mutex> g( ctx->pool.lock );
+  if ( bytesHeld ) *bytesHeld = ctx->pool.bytesHeld;
+  if ( mallocCalls ) *mallocCalls = ctx->pool.mallocCalls;
+  if ( mallocMs ) *mallocMs = ctx->pool.mallocMs;
+  if ( carvedBlocks ) *carvedBlocks = ctx->pool.carved;
+  return TMC2_OK;
+}
+
+/* Device staging for a host that moves small records between ranks itself (libtmc2gof.so: RCCL needs device buffers and the
+   stream they are ready on): plain device memory of the context's device, copies ordered on the context's stream. */
+int tmc2_ctx_device_alloc( tmc2_ctx* ctx, size_t bytes, void** out ) {
+  if ( !ctx || !out ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( ctx );
+  *out = nullptr;
+  TMC2_HIP( hipMalloc( out, std::max<size_t>( bytes, 1 ) ) );
+  return TMC2_OK;
+}
+int tmc2_ctx_device_free( tmc2_ctx* ctx, void* p ) {
+  if ( !ctx ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( ctx );
+  if ( p ) TMC2_HIP( hipFree( p ) );
+  return TMC2_OK;
+}
+int tmc2_ctx_upload( tmc2_ctx* ctx, void* deviceDst, const void* hostSrc, size_t bytes ) {
+  if ( !ctx || ( bytes && ( !deviceDst || !hostSrc ) ) ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( ctx );
+  if ( bytes ) TMC2_HIP( hipMemcpyAsync( deviceDst, hostSrc, bytes, hipMemcpyHostToDevice, ctx->stream ) );
+  return TMC2_OK;
+}
+int tmc2_ctx_download( tmc2_ctx* ctx, void* hostDst, const void* deviceSrc, size_t bytes ) {
+  if ( !ctx || ( bytes && ( !hostDst || !deviceSrc ) ) ) return TMC2_E_INVALID;
+  tmc2::ApiScope scope( ctx );
+  if ( bytes ) TMC2_HIP( hipMemcpyAsync( hostDst, deviceSrc, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  TMC2_HIP( hipStreamSynchronize( ctx->stream ) );
+  return TMC2_OK;
+}
+void* tmc2_ctx_stream( tmc2_ctx* ctx ) { return ctx ? static_cast<void*>( ctx->stream ) : nullptr; }
+int   tmc2_ctx_device( tmc2_ctx* ctx ) { return ctx ? ctx->device : -1; }
+int   tmc2_ctx_make_current( tmc2_ctx* ctx ) {  /* hipSetDevice( the context's device ) on the calling thread */
+  if ( !ctx ) return TMC2_E_INVALID;
+  TMC2_HIP( hipSetDevice( ctx->device ) );
   return TMC2_OK;
 }
 
@@ -338,42 +472,48 @@ int tmc2_frame_create( tmc2_ctx* ctx, const int16_t* xyz, const uint8_t* rgb, ui
 namespace tmc2 {
 // whether tmc2_segmenter_compute queues the refine step's geometry ahead of the orientation's host walk
 // (tmc2_set_refine_overlap; unset: the environment variable TMC2_REFINE_OVERLAP decides, off without it)
-std::atomic<int> g_refineOverlap{-1};
-bool refineOverlap() {
-  const int v = g_refineOverlap.load( std::memory_order_relaxed );
-  if ( v >= 0 ) return v != 0;
-  const char* e = getenv( "TMC2_REFINE_OVERLAP" );
-  return e && e[0] == '1';
+// Options are per context (tmc2_ctx_set_option; defaults = the TMC2_* environment at tmc2_ctx_create).  The two process-wide
+// setters of rounds 2-4 (tmc2_set_refine_overlap, tmc2_set_kdtree_placement) only preset what a context WITHOUT the option does.
+const char* ctxOption( const tmc2_ctx* ctx, const char* key ) {
+  if ( !ctx ) {
+    const std::string name = std::string( "TMC2_" ) + key;
+    return getenv( name.c_str() );
+  }
+  const auto it = ctx->options.find( key );
+  return it == ctx->options.end() ? nullptr : it->second.c_str();
+}
+static std::atomic<int> g_refineOverlap{-1};
+bool refineOverlap( const tmc2_ctx* ctx ) {
+  if ( const char* e = ctxOption( ctx, "REFINE_OVERLAP" ) ) return e[0] == '1';
+  return g_refineOverlap.load( std::memory_order_relaxed ) > 0;
 }
 // where the k-d trees are built (tmc2_set_kdtree_placement; TMC2_KDTREE_HOST=1 presets "host")
 static std::atomic<int> g_kdtreeOnHost{-1};
-int kdtreePlacement() {
-  int v = g_kdtreeOnHost.load( std::memory_order_relaxed );
-  if ( v < 0 ) {
-    const char* e = getenv( "TMC2_KDTREE_HOST" );
-    v             = ( e && e[0] >= '0' && e[0] <= '2' ) ? e[0] - '0' : 0;
-    g_kdtreeOnHost.store( v, std::memory_order_relaxed );
-  }
-  return v;
+int kdtreePlacement( const tmc2_ctx* ctx ) {
+  if ( const char* e = ctxOption( ctx, "KDTREE_HOST" ) )
+    if ( e[0] >= '0' && e[0] <= '2' ) return e[0] - '0';
+  const int v = g_kdtreeOnHost.load( std::memory_order_relaxed );
+  return v < 0 ? 0 : v;
 }
-int unionPrecheck() {
-  const char* e = getenv( "TMC2_UF_PRECHECK" );
+int unionPrecheck( const tmc2_ctx* ctx ) {
+  const char* e = ctxOption( ctx, "UF_PRECHECK" );
   return e ? ( e[0] != '0' ) : 1;
 }
-bool unionAgentScope() {
-  const char* e = getenv( "TMC2_UF_SCOPE" );
+bool unionAgentScope( const tmc2_ctx* ctx ) {
+  const char* e = ctxOption( ctx, "UF_SCOPE" );
   return e && e[0] == 'a';
 }
-bool unionCheck() {
-  const char* e = getenv( "TMC2_UF_CHECK" );
+bool unionCheck( const tmc2_ctx* ctx ) {
+  const char* e = ctxOption( ctx, "UF_CHECK" );
   return e && e[0] == '1';
 }
+void setRefineOverlapDefault( int on ) { g_refineOverlap.store( on ? 1 : 0, std::memory_order_relaxed ); }
 void setKdtreePlacement( int mode ) { g_kdtreeOnHost.store( mode < 0 || mode > 2 ? 0 : mode, std::memory_order_relaxed ); }
 }  // namespace tmc2
 
 int tmc2_frame::ensureTree() {
   if ( haveTree ) return TMC2_OK;
-  const int placement = tmc2::kdtreePlacement();
+  const int placement = tmc2::kdtreePlacement( ctx );
   // adaptive: take a host slot if one is free right now, otherwise the device builds it (same tree either way)
   tmc2::HostGate gate( placement == 1 );
   if ( placement == 0 || !gate.held ) {
@@ -430,7 +570,7 @@ int tmc2_frame_get_kdtree_order( tmc2_frame* f, uint32_t* perm, int32_t* depth )
 }
 
 void tmc2_set_kdtree_placement( int mode ) { tmc2::setKdtreePlacement( mode ); }
-void tmc2_set_refine_overlap( int on ) { tmc2::g_refineOverlap.store( on ? 1 : 0, std::memory_order_relaxed ); }
+void tmc2_set_refine_overlap( int on ) { tmc2::setRefineOverlapDefault( on ); }
 
 void tmc2_frame_destroy( tmc2_frame* f ) {
   if ( !f ) return;

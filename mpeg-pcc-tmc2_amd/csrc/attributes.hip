@@ -502,7 +502,7 @@ int reconstructPointCloud( tmc2_frame* f ) {
   ctx->stageEnd( sid );
   f->reconCount = M;
   // ---- tree over the reconstruction (like S1) --------------------------------------------------------------
-  const int placement = kdtreePlacement();
+  const int placement = kdtreePlacement( ctx );
   HostGate  treeGate( placement == 1 );
   if ( placement == 0 || !treeGate.held ) {
     const int kt = ctx->stageBegin( "kdtree_build_recon" );

@@ -43,6 +43,16 @@ struct DevicePool {
   std::mutex                                 lock;
   std::map<size_t, std::vector<void*>>       freeBlocks;  // size class -> blocks
   size_t                                     bytesHeld = 0;
+  // tmc2_ctx_reserve: slabs allocated up front; a miss of the free lists is carved from them (no hipMalloc -- which
+  // synchronises the device under every frame in flight -- while they last)
+  struct Slab {
+    char*  base;
+    size_t size, used;
+  };
+  std::vector<Slab>                          slabs;
+  size_t                                     mallocCalls = 0, carved = 0;  // hipMalloc calls on a miss; blocks carved from a slab
+  double                                     mallocMs = 0.0;               // host time spent in those hipMalloc calls
+  int  reserve( size_t bytes );
   static size_t sizeClass( size_t bytes ) {
     size_t c = 256;
     while ( c < bytes ) c <<= 1;
@@ -237,6 +247,10 @@ struct tmc2_ctx {
   uint32_t                      scanEpoch = 0, scanTickets = 0;
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
   std::map<uint32_t, int>       kdLevelHint;     // levels of level passes the last device k-d tree of ~ this size took (by n >> 15)
+  // Per-context options (tmc2_ctx_set_option): key = the name of the knob without its TMC2_ prefix.  Filled ONCE, when the
+  // context is created, from the process environment (every TMC2_* variable: the defaults); nothing in the library reads the
+  // environment after that, and nothing is process-wide: two encoders of one process can run with different settings.
+  std::map<std::string, std::string> options;
   hipStream_t                   stream = nullptr;
   std::vector<tmc2::StageTimer> stages;
   std::vector<hipEvent_t>       freeEvents;
@@ -412,8 +426,8 @@ void resolveSeedSignsCompact( const OrientCompact& g, int kNN, const std::vector
 int gatherSeedTables( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const std::vector<uint32_t>& seeds,
                       std::vector<uint32_t>& who, std::vector<double>& normals );
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
-                             const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction );
-double orientFirstTau();
+                             const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction, const tmc2_ctx* ctx );
+double orientFirstTau( const tmc2_ctx* ctx );
 int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_cid,
                                DevBuf<uint8_t>& d_parity, OrientCompact& g, bool& ok );
 int launchClusterSigns( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const int8_t* d_clusterSign,
@@ -436,8 +450,8 @@ int rgb444ToYuv420Device( tmc2_ctx* ctx, const uint8_t* d_rgb, int W, int H, int
 int yuv420ToYuv444Device( tmc2_ctx* ctx, const uint8_t* d_yuv, int W, int H, int filter, uint16_t* d_out );
 int refineGridBased( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // the point-only half of it ahead of time (voxels, neighbourhood rows): queued, not waited for; refineGridBased picks it up
-extern std::atomic<int> g_refineOverlap;
-bool refineOverlap();  // tmc2_set_refine_overlap / TMC2_REFINE_OVERLAP
+void setRefineOverlapDefault( int on );
+bool refineOverlap( const tmc2_ctx* ctx );  // option REFINE_OVERLAP; unset: the process default of tmc2_set_refine_overlap
 int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius );
 // exclusive prefix sum of n uint32 (in -> out, may alias); returns the total through *d_total (device) if non-null
 // Grid of a kernel that walks its items with a stride loop: at most eight 256-thread workgroups per CU -- one full set of
@@ -446,12 +460,15 @@ int refinePrepareGeometry( tmc2_frame* f, int maxNNCount, double lambda, int ite
 inline uint32_t cappedBlocks( const tmc2_ctx* ctx, size_t wanted ) {
   return uint32_t( std::max<size_t>( 1, std::min<size_t>( wanted, size_t( 8 ) * size_t( ctx->cuCount ) ) ) );
 }
-int  kdtreePlacement();  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
+// The value of a context's option (key without the TMC2_ prefix), nullptr if unset.  ctx == nullptr (the host-only entry points
+// have no context): the process environment.
+const char* ctxOption( const tmc2_ctx* ctx, const char* key );
+int  kdtreePlacement( const tmc2_ctx* ctx );  // 0 device, 1 host, 2 adaptive (host while a host slot is free, else device)
 // union passes (S3 contraction, S7 components): answer "same set already?" from the CU's possibly stale view before any
 // find / compare-and-swap (TMC2_UF_PRECHECK=0 switches it off); TMC2_UF_CHECK=1: debug invariants after every union pass
-int  unionPrecheck();
-bool unionCheck();
-bool unionAgentScope();  // TMC2_UF_SCOPE=agent: every load of the union passes at agent scope (the formally clean form)
+int  unionPrecheck( const tmc2_ctx* ctx );
+bool unionCheck( const tmc2_ctx* ctx );
+bool unionAgentScope( const tmc2_ctx* ctx );  // TMC2_UF_SCOPE=agent: every load of the union passes at agent scope (the formally clean form)
 int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d_ptsTree, DevBuf<uint32_t>& d_perm,
                        DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
 // opt-in to more than 48 KB of dynamic LDS for a kernel (once per device and kernel, serialised)

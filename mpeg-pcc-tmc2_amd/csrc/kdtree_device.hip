@@ -2277,9 +2277,9 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   // (test hook TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes; <= kSplitMax: that tier is off)
   // Form of the lower tiers: pieces of at most kPieceMax points, one workgroup each, all nodes of a depth at once (pieceKernel,
   // the default), or round 4's three tiers (TMC2_KD_FORM=tiers: kept as the cross-check of the other).
-  const char*    formEnv = getenv( "TMC2_KD_FORM" );
+  const char*    formEnv = ctxOption( ctx, "KD_FORM" );
   const bool     pieces  = !( formEnv && !strcmp( formEnv, "tiers" ) );
-  const char*    hugeEnv = getenv( "TMC2_KD_HUGEMAX" );
+  const char*    hugeEnv = ctxOption( ctx, "KD_HUGEMAX" );
   // (TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes from the level passes -- with the pieces it saves
   //  the last few level passes, which move a few dozen segments of 4 097 .. hugeMax points with five chip-wide launches each)
   const uint32_t hugeMax = pieces ? std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kPieceMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 16384u ) )
@@ -2312,7 +2312,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
   // round 5's level passes go with the pieces (TMC2_KD_LEVELS=r4: round 4's five launches per level, the cross-check); their
   // swap passes keep the tile totals in LDS
-  const char*  levelsEnv = getenv( "TMC2_KD_LEVELS" );
+  const char*  levelsEnv = ctxOption( ctx, "KD_LEVELS" );
   const size_t sumsLds   = ( size_t( tiles ) + 1 ) * 4;
   const bool   newLevels = pieces && !( levelsEnv && !strcmp( levelsEnv, "r4" ) ) && sumsLds <= 48 * 1024;
   DevBuf<LvSeg>    d_lv;
@@ -2383,7 +2383,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
       hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( hugeSegs, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );
     const uint32_t retired = out[kMaxLevels + 3] + hugeSegs * ( 2u * hugeMax / uint32_t( kPieceMax ) );
     if ( retired ) {
-      const char* perEnv = getenv( "TMC2_KD_PIECE_PER" );  // positions per thread: 4 (1 024 threads) or 8 (512)
+      const char* perEnv = ctxOption( ctx, "KD_PIECE_PER" );  // positions per thread: 4 (1 024 threads) or 8 (512)
       const dim3  grid( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) );
       if ( perEnv && atoi( perEnv ) == 8 ) {
         TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<8> ), kPieceLdsBytes, ctx->device, 256 ) );

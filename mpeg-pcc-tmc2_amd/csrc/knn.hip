@@ -256,7 +256,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
 }
 
 template <bool SELF>
-int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, uint32_t* idx, uint32_t* dist ) {
+int dispatch( const tmc2_ctx* ctx, hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, uint32_t* idx, uint32_t* dist ) {
   if ( t.depth > kMaxStack ) {
     setError( "k-d tree depth %d exceeds the traversal stack (%d)", t.depth, kMaxStack );
     return TMC2_E_UNSUPPORTED;
@@ -272,7 +272,7 @@ int dispatch( hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, 
   }
   const dim3 block( 256 );
   // (test hook TMC2_KNN_XCD=0: blocks in launch order)
-  const char* xcdEnv   = getenv( "TMC2_KNN_XCD" );
+  const char* xcdEnv   = ctxOption( ctx, "KNN_XCD" );
   const int   xcdAware = xcdEnv && xcdEnv[0] == '0' ? 0 : 1;
   const dim3  grid( xcdAware ? uint32_t( ( ( nq + 255 ) / 256 + 7 ) & ~uint64_t( 7 ) ) : uint32_t( ( nq + 255 ) / 256 ) );
   // the packed LDS stack needs: every offset < 2^14 (tree box and queries inside a 16383-wide window -- the caller
@@ -323,7 +323,7 @@ TreeDev frameTree( const tmc2_frame* f ) {
 int launchKnnSelf( tmc2_frame* f, int k ) {
   TMC2_TRY( f->d_knn.alloc( f->n * size_t( k ) ) );
   const int sid = f->ctx->stageBegin( "knn_self" );
-  const int r   = dispatch<true>( f->ctx->stream, frameTree( f ), nullptr, f->n, k, f->d_knn.p, nullptr );
+  const int r   = dispatch<true>( f->ctx, f->ctx->stream, frameTree( f ), nullptr, f->n, k, f->d_knn.p, nullptr );
   f->ctx->stageEnd( sid );
   if ( r == TMC2_OK ) {
     f->k       = k;
@@ -344,7 +344,7 @@ int launchKnnQueries( tmc2_frame* f, const Pt* d_queries, uint64_t nq, int k, ui
 int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_idx,
                    uint32_t* d_dist, const char* stage ) {
   const int sid = ctx->stageBegin( stage );
-  const int r   = dispatch<false>( ctx->stream, tree, d_queries, nq, k, d_idx, d_dist );
+  const int r   = dispatch<false>( ctx, ctx->stream, tree, d_queries, nq, k, d_idx, d_dist );
   ctx->stageEnd( sid );
   return r;
 }

@@ -621,7 +621,7 @@ int metricsBothWidths( tmc2_ctx* ctx, const CloudView& src, const CloudView& rec
                        double* out, int64_t* counts ) {
   bool overflow = false;
   // (test hook TMC2_METRICS_K=32: the wide search straight away)
-  const char* kEnv = getenv( "TMC2_METRICS_K" );
+  const char* kEnv = ctxOption( ctx, "METRICS_K" );
   if ( !( kEnv && atoi( kEnv ) == 32 ) ) {
     TMC2_TRY( metricsDevice( ctx, src, rec, d_srcNormals, resolution, 16, out, counts, &overflow ) );
     if ( !overflow ) return TMC2_OK;

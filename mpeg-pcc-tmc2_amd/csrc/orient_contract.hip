@@ -469,7 +469,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   TMC2_TRY( d_crossMask.alloc( n ) );
   TMC2_TRY( d_keepMask.alloc( n ) );
   // (test hook TMC2_ORIENT_PAIRS: log2 of the pair table's capacity; small values force the overflow path)
-  const char*    pairsEnv = getenv( "TMC2_ORIENT_PAIRS" );
+  const char*    pairsEnv = ctxOption( f->ctx, "ORIENT_PAIRS" );
   const uint32_t pairCap  = 1u << ( pairsEnv ? std::min( 24, std::max( 4, atoi( pairsEnv ) ) ) : 20 );
   TMC2_TRY( d_pairs.alloc( 2 * size_t( pairCap ) ) );
   TMC2_TRY( d_strongFirst.alloc( 2 * size_t( pairCap ) ) );
@@ -484,8 +484,8 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   TMC2_TRY( d_count.alloc( size_t( n ) + 1 ) );  // (initWordsKernel zeroes it; later: kept edges per cluster, C + 1 used)
   hipLaunchKernelGGL( initWordsKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, f->d_mutual.p, tau, n, d_mask.p,
                       d_word.p, d_count.p );
-  hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, unionPrecheck(), unionAgentScope() );
-  if ( unionCheck() ) {  // debug invariants (soak tests): costs a round trip
+  hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, unionPrecheck( f->ctx ), unionAgentScope( f->ctx ) );
+  if ( unionCheck( f->ctx ) ) {  // debug invariants (soak tests): costs a round trip
     uint32_t bad[2] = {0, 0};
     hipLaunchKernelGGL( parityCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mask.p, n, d_word.p, d_small.p + 4 );
     TMC2_HIP( hipMemcpyAsync( bad, d_small.p + 4, 8, hipMemcpyDeviceToHost, s ) );
@@ -495,7 +495,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
       return TMC2_E_HIP;
     }
   }
-  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p, d_minIdx.p, unionAgentScope() );
+  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p, d_minIdx.p, unionAgentScope( f->ctx ) );
   hipLaunchKernelGGL( clusterFlagKernel, grdN, blk, 0, s, d_root.p, d_minIdx.p, n, d_flag.p );
   TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 3 ) );
   TMC2_TRY( d_off.alloc( size_t( n ) + 1 ) );  // (per-cluster arrays sized for the worst case, n clusters: the used part is known
@@ -508,7 +508,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
   // back together.  A frame that needs more room (or whose pair table overflowed) is repeated with exact sizes, two round trips.
   // (test hook TMC2_ORIENT_SPEC = "<edges>,<clusters>": shrinks the speculative room so that small clouds take the repeat)
   uint32_t kSpecEdges = 384 * 1024, kSpecClusters = 64 * 1024;
-  if ( const char* spec = getenv( "TMC2_ORIENT_SPEC" ) ) {
+  if ( const char* spec = ctxOption( f->ctx, "ORIENT_SPEC" ) ) {
     unsigned e = 0, c = 0;
     if ( sscanf( spec, "%u,%u", &e, &c ) == 2 ) kSpecEdges = std::max( 1u, std::min( kSpecEdges, e ) ), kSpecClusters = std::max( 2u, std::min( kSpecClusters, c ) );
   }
@@ -582,7 +582,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
     if ( E ) TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( E ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
   }
-  if ( getenv( "TMC2_ORIENT_SPEC" ) ) ctx->stageAddHostMs( "orient_compact_edges", double( E ) );  // (test hook: the size of the compact graph)
+  if ( ctxOption( f->ctx, "ORIENT_SPEC" ) ) ctx->stageAddHostMs( "orient_compact_edges", double( E ) );  // (test hook: the size of the compact graph)
   g.clusters = C, g.rec = h_rec, g.edges = h_edges;
   ok         = true;
   return TMC2_OK;

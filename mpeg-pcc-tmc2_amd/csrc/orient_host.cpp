@@ -734,26 +734,23 @@ static void compactOnHost( size_t n, const std::vector<uint32_t>& root, const st
 // whose graph is unbalanced at 0.98 -- one stray edge of weight 0.984 in 12 M is enough (round 4, redandblack-like frame 26) --
 // is tried again a little tighter (a contraction + a cluster walk: milliseconds) before it falls back to the growth point by
 // point (hundreds of milliseconds, and the GOF waits for it).
-std::vector<double> orientTauLadder() {
-  const double        first = orientFirstTau();
+std::vector<double> orientTauLadder( const tmc2_ctx* ctx ) {
+  const double        first = orientFirstTau( ctx );
   std::vector<double> l{first};
   for ( double t : {0.99, 0.995, 0.998} )
     if ( t > first && first <= 1.5 ) l.push_back( t );
   return l;
 }
 
-double orientFirstTau() {
-  static const double first = [] {
-    const char* e = getenv( "TMC2_ORIENT_TAU" );  // test hook; >= 2 goes straight to the plain growth
-    return e ? atof( e ) : 0.98;
-  }();
-  return first;
+double orientFirstTau( const tmc2_ctx* ctx ) {
+  const char* e = ctxOption( ctx, "ORIENT_TAU" );  // test hook; >= 2 goes straight to the plain growth
+  return e ? atof( e ) : 0.98;
 }
 
 // returns the number of growths it took (1: the first attempt held; each disagreement costs one more).
 // tryContraction: contract on the host first (the device path has done that -- or failed at it -- on the device)
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
-                             const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction ) {
+                             const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction, const tmc2_ctx* ctx ) {
   if ( n == 0 ) return 0;
   std::vector<uint64_t> own;
   if ( !scratch ) {
@@ -762,10 +759,10 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
   }
   // thresholds tried in turn: the first (contracted, then point by point), then ~3.6 degrees, then none (the plain
   // growth, always exact by construction)
-  const double first0 = orientFirstTau();
+  const double first0 = orientFirstTau( ctx );
   int growths = 0;
-  if ( tryContraction && first0 <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) )  // (test hook: point-level walk only)
-  for ( const double first : orientTauLadder() ) {
+  if ( tryContraction && first0 <= 1.5 && !ctxOption( ctx, "ORIENT_NO_CONTRACTION" ) )  // (test hook: point-level walk only)
+  for ( const double first : orientTauLadder( ctx ) ) {
     // contracted walk: clusters of mutual strong edges first
     ++growths;
     std::vector<uint32_t>        root, off;
@@ -774,7 +771,7 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
     const auto tc0 = std::chrono::steady_clock::now();
     const bool okc = contractOnHost( n, knn, k, edgeDot, first, root, parity, off, edges );
     const auto tc1 = std::chrono::steady_clock::now();
-    if ( getenv( "TMC2_ORIENT_TIMING" ) ) {
+    if ( ctxOption( ctx, "ORIENT_TIMING" ) ) {
       size_t clusters = 0;
       for ( size_t i = 0; okc && i < n; ++i ) clusters += root[i] == i;
       fprintf( stderr, "contraction %.1f ms ok=%d clusters %zu cross edges %zu of %zu\n",
@@ -782,7 +779,7 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
     }
     if ( okc ) {
       // (TMC2_ORIENT_HOST_WALK=points: the per-point-array walk over the full cross-edge list, kept as the cross-check)
-      const char* walkEnv = getenv( "TMC2_ORIENT_HOST_WALK" );
+      const char* walkEnv = ctxOption( ctx, "ORIENT_HOST_WALK" );
       const auto  tw0     = std::chrono::steady_clock::now();
       bool        okw;
       size_t      seedCount = 0;
@@ -829,7 +826,7 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
           for ( size_t i = 0; i < n; ++i ) sign[i] = int8_t( ( parity[i] & 1 ) ? -clusterSign[hc.cid[i]] : clusterSign[hc.cid[i]] );
         }
       }
-      if ( getenv( "TMC2_ORIENT_TIMING" ) )
+      if ( ctxOption( ctx, "ORIENT_TIMING" ) )
         fprintf( stderr, "contracted walk %.1f ms ok=%d seeds %zu\n", std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tw0 ).count(), int( okw ), seedCount );
       if ( okw ) return growths;
     }
@@ -853,8 +850,8 @@ void orientNormalsSpanningTree( const int16_t* xyz, size_t n, const uint32_t* kn
     for ( int j = 0; j < k; ++j ) edgeDot[u * k + j] = dot( normals + 3 * u, normals + 3 * size_t( knn[u * k + j] ) );
   std::vector<int8_t> sign( n );
   const auto          tt0 = std::chrono::steady_clock::now();
-  const int growths = orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch, true );
-  if ( getenv( "TMC2_ORIENT_TIMING" ) )  // test hook: time of the growth alone
+  const int growths = orientSpanningTreeSigns( xyz, n, knn, k, normals, edgeDot, sign.data(), scratch, true, nullptr );
+  if ( ctxOption( nullptr, "ORIENT_TIMING" ) )  // test hook: time of the growth alone
     fprintf( stderr, "orient core %.1f ms (%d growth%s)\n",
              std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tt0 ).count(), growths, growths == 1 ? "" : "s" );
   size_t negCount = 0;
@@ -891,9 +888,9 @@ int orientNormalsHost( tmc2_frame* f ) {
   // ---- fast path: contract on the device, walk the clusters on the host; a frame that is inconsistent at one threshold is
   // tried with the next (orientTauLadder) --------------------------------------------------------------------------------
   bool contracted = false;
-  if ( orientFirstTau() <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) )
-  for ( const double tau : orientTauLadder() ) {
-    if ( tau != orientFirstTau() ) ctx->stageAddHostMs( "orient_tau_retry", 0.0 );  // (counts the repeats with a tighter threshold)
+  if ( orientFirstTau( ctx ) <= 1.5 && !ctxOption( ctx, "ORIENT_NO_CONTRACTION" ) )
+  for ( const double tau : orientTauLadder( ctx ) ) {
+    if ( tau != orientFirstTau( ctx ) ) ctx->stageAddHostMs( "orient_tau_retry", 0.0 );  // (counts the repeats with a tighter threshold)
     OrientCompact g{};
     const int     sid = ctx->stageBegin( "orient_contract" );
     TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );  // (d_root: cluster ids here)
@@ -929,7 +926,7 @@ int orientNormalsHost( tmc2_frame* f ) {
       }
     }
   }
-  if ( orientFirstTau() <= 1.5 && !getenv( "TMC2_ORIENT_NO_CONTRACTION" ) )
+  if ( orientFirstTau( ctx ) <= 1.5 && !ctxOption( ctx, "ORIENT_NO_CONTRACTION" ) )
     ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames that needed the point-level walk
 
   // ---- point-level walk: rows, dot products and normals to the host ----------------------------------------------------
@@ -949,7 +946,7 @@ int orientNormalsHost( tmc2_frame* f ) {
   {
     HostGate gate;
     t0 = std::chrono::steady_clock::now();
-    orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data(), false );
+    orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data(), false, ctx );
     t1 = std::chrono::steady_clock::now();
   }
   ctx->stageAddHostMs( "orient_normals_host", std::chrono::duration<double, std::milli>( t1 - t0 ).count() );

@@ -791,7 +791,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   int        rounds   = 0;
   TMC2_TRY( ensureMutualMask( f ) );  // usually there already: the orientation (S3) needs the same bits
   DevBuf<uint16_t>& d_mutual   = f->d_mutual;
-  const bool        agentScope = unionAgentScope();
+  const bool        agentScope = unionAgentScope( f->ctx );
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );
@@ -800,9 +800,9 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     {
       const int kt = ctx->stageBegin( "k:ccUnion" );
       hipLaunchKernelGGL( ccUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
-                          d_parent.p, unionPrecheck(), agentScope );
+                          d_parent.p, unionPrecheck( f->ctx ), agentScope );
       ctx->stageEnd( kt );
-      if ( unionCheck() ) {  // debug invariants (soak tests): costs a round trip
+      if ( unionCheck( f->ctx ) ) {  // debug invariants (soak tests): costs a round trip
         uint32_t bad[2] = {0, 0};
         TMC2_HIP( hipMemsetAsync( d_small.p + 8, 0, 8, s ) );
         hipLaunchKernelGGL( ccCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,

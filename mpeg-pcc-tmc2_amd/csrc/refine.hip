@@ -291,7 +291,7 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
     }
   }
   if ( cand > CAP - 160 ) {  // more occupied cells than this instantiation has room for: the host repeats with a larger one
-    if ( lane == 0 ) *overflow = 3u;
+    if ( lane == 0 ) atomicMax( overflow, 3u );  // (atomic like every other writer of this word; the fatal code is the largest)
     cand = CAP - 160;
   }
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
@@ -627,7 +627,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
     if ( !partial && !__ballot( near ) ) break;  // (a sorted row: nothing near can follow)
   }
   if ( nDev > devStride ) {  // (cannot happen: (2 R + 1)^3 <= devStride by construction)
-    if ( lane == 0 ) *overflow = 2u;
+    if ( lane == 0 ) atomicMax( overflow, 4u );  // fatal: above the two codes the host answers with a repeat, so that neither hides it
     nDev = devStride;
   }
   for ( uint32_t i = nDev + lane; i < devStride; i += 64 ) drow[i] = kDevPad;
@@ -1520,7 +1520,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
   const int r2 = searchRadius >> g.voxShift;
   // (test hook TMC2_REFINE_NEIGHBOURHOOD=cells: the rounds 1-3 form -- one table look-up per cell of the ball, reverse rows by
   //  scattering the forward rows -- kept as the cross-check of the row-wise form)
-  const char* nbEnv = getenv( "TMC2_REFINE_NEIGHBOURHOOD" );
+  const char* nbEnv = ctxOption( ctx, "REFINE_NEIGHBOURHOOD" );
   byRows            = !( nbEnv && nbEnv[0] == 'c' );
   {
     int R = 0;
@@ -1606,7 +1606,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
   // every buffer of this stage that starts from zeros, in one launch (the event-driven loop's among them)
   W = ( V + 31 ) / 32;
   // Which sweep loop: the event-driven one, unless the test hook TMC2_REFINE_SWEEPS=full asks for the sweep-everything loop
-  const char* sweepsEnv = getenv( "TMC2_REFINE_SWEEPS" );
+  const char* sweepsEnv = ctxOption( ctx, "REFINE_SWEEPS" );
   eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' );
   W2          = ( size_t( V ) + 15 ) / 16;  // closure state: two bits per voxel
   // closure scratch: state bitmaps of the two sweep parities | list counters of the two parities (one per 128 bytes) | ring
@@ -1652,7 +1652,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
     return TMC2_E_UNSUPPORTED;
   }
   TMC2_TRY( d_dev.alloc( size_t( V ) * devStride ) );
-  const char* capEnv  = getenv( "TMC2_REFINE_ROWCAP" );
+  const char* capEnv  = ctxOption( ctx, "REFINE_ROWCAP" );
   perVoxel            = std::min<size_t>( ball, 2 * size_t( maxNNCount > 0 ? maxNNCount : 1 ) * V / std::max<uint32_t>( n, 1u ) + 32 );
   if ( capEnv && capEnv[0] == 't' ) perVoxel = 1;
   capacity = uint64_t( V ) * perVoxel;
@@ -1662,7 +1662,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
   }
   capTier = ball <= 2048 - 160 ? 1 : 2;
   if ( byRows ) capTier = std::min( capTier, std::max( 0, ctx->refineCapTier ) );  // (test hook TMC2_REFINE_CAPTIER: start there)
-  if ( const char* tierEnv = getenv( "TMC2_REFINE_CAPTIER" ) ) capTier = std::min( 2, std::max( byRows ? 0 : capTier, atoi( tierEnv ) ) );
+  if ( const char* tierEnv = ctxOption( ctx, "REFINE_CAPTIER" ) ) capTier = std::min( 2, std::max( byRows ? 0 : capTier, atoi( tierEnv ) ) );
   TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
   if ( byRows ) {  // the reverse rows hold the same entries as the forward rows: same room
     TMC2_TRY( d_lastKey.alloc( V ) );
@@ -1693,7 +1693,7 @@ int RefineJob::finish() {
     TMC2_HIP( hipStreamSynchronize( s ) );  // (usually long done: the orientation walk ran in between)
     TMC2_HIP( hipGetLastError() );
     totalLen = res[0];
-    if ( getenv( "TMC2_REFINE_DEBUG" ) ) fprintf( stderr, "refine: neighbourhood attempt %d tier %d: %u row entries, overflow word %u (V = %u)\n", attempt, capTier, res[0], res[1], V );
+    if ( ctxOption( ctx, "REFINE_DEBUG" ) ) fprintf( stderr, "refine: neighbourhood attempt %d tier %d: %u row entries, overflow word %u (V = %u)\n", attempt, capTier, res[0], res[1], V );
     if ( res[1] == 0 ) break;
     if ( ( res[1] != 1 && res[1] != 3 ) || attempt > 3 || ( res[1] == 3 && capTier >= 2 ) ) {
       setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
@@ -1747,13 +1747,13 @@ int RefineJob::finish() {
     // closureKernel: a run of voxels per workgroup; LDS = the run's active voxels + the ring
     // (test hooks: TMC2_REFINE_CLOSURE_BLOCKS = its grid, TMC2_REFINE_CLOSURE_THREADS = its workgroup; TMC2_REFINE_RING = room
     // of the LDS ring beyond the run -- 1 sends nearly every fan-out through the spill ring)
-    const char*    gridEnv    = getenv( "TMC2_REFINE_CLOSURE_BLOCKS" );
-    const char*    threadsEnv = getenv( "TMC2_REFINE_CLOSURE_THREADS" );
-    const char*    ringEnv    = getenv( "TMC2_REFINE_RING" );
+    const char*    gridEnv    = ctxOption( ctx, "REFINE_CLOSURE_BLOCKS" );
+    const char*    threadsEnv = ctxOption( ctx, "REFINE_CLOSURE_THREADS" );
+    const char*    ringEnv    = ctxOption( ctx, "REFINE_RING" );
     const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 512;
     const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
     const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
-                                        : std::min<uint32_t>( ( refineOverlap() ? 4u : 2u ) * uint32_t( ctx->cuCount ),
+                                        : std::min<uint32_t>( ( refineOverlap( ctx ) ? 4u : 2u ) * uint32_t( ctx->cuCount ),
                                                               ( V + perGroup * ( closureThreads / 32 ) - 1 ) / ( perGroup * ( closureThreads / 32 ) ) );
     // (two workgroups per CU: 8 % slower alone than four and 3 % more frames per second with sixteen frames in flight -- a
     // workgroup's groups idle through most of the walk, and idle waves are in the way of the other frames' kernels)
@@ -1763,17 +1763,17 @@ int RefineJob::finish() {
     const size_t   closureLds = 4 * ( size_t( run ) + ringCap );
     if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
     // (test hook TMC2_REFINE_SWEEP_BLOCKS: the sweep kernel's grid)
-    const char* sweepGridEnv = getenv( "TMC2_REFINE_SWEEP_BLOCKS" );
-    const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap() ? 8 : 4 ) * ctx->cuCount ) ) );
+    const char* sweepGridEnv = ctxOption( ctx, "REFINE_SWEEP_BLOCKS" );
+    const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap( ctx ) ? 8 : 4 ) * ctx->cuCount ) ) );
     // (tmc2_set_refine_overlap( 1 ) = "few frames in flight": the chip has room, so both kernels of a sweep take the grids that
     //  are fastest with the GPU to themselves -- four closure workgroups and eight sweep workgroups per CU)
     // (round 4 sweep over the grids, 16 frames in flight / one sweep alone: sweep kernel 2 / 4 / 8 / 16 workgroups per CU ->
     //  loot 109.0 / 108.1 / 107.1 / 106.6 frames/s, 338 / 327 / 305 / 289 us; longdress 174.1 / 174.9 frames/s, 54.8 / 51.9 us;
     //  closure 1 / 2 / 4 / 8 per CU -> loot 109.3 / 109.0 / 107.8 / 107.1 frames/s, 434 / 338 / 308 / 291 us: all within
     //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure)
-    const bool wantTrace = getenv( "TMC2_REFINE_TRACE" ) != nullptr;
+    const bool wantTrace = ctxOption( ctx, "REFINE_TRACE" ) != nullptr;
     DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
-    const bool                 wantTiming = getenv( "TMC2_REFINE_TIMING" ) != nullptr;
+    const bool                 wantTiming = ctxOption( ctx, "REFINE_TIMING" ) != nullptr;
     if ( wantTiming ) {
       TMC2_TRY( d_timing.alloc( 8 * size_t( iterationCount ) ) );
       TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64 * size_t( iterationCount ), s ) );
@@ -1790,14 +1790,14 @@ int RefineJob::finish() {
       hipLaunchKernelGGL( closureKernel, grdClosure, dim3( closureThreads ), closureLds, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p,
                           devStride, V, run, state[cur], state[nxt], uint32_t( W2 ), d_lists.p, V, counts[cur], counts[nxt], spill,
                           ctl, ringCap, wantTiming ? d_timing.p + 8 * size_t( iter ) : nullptr );
-      if ( getenv( "TMC2_REFINE_DEBUG" ) ) {
+      if ( ctxOption( ctx, "REFINE_DEBUG" ) ) {
         const hipError_t e = hipStreamSynchronize( s );
         fprintf( stderr, "refine: sweep %d closure done (%d), %u workgroups of %d, run %u, ring %u\n", iter, int( e ), grdClosure.x, closureThreads, run, ringCap );
       }
       hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
                           d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, revOff, revLen, revAdj, d_edge,
                           d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
-      if ( getenv( "TMC2_REFINE_DEBUG" ) ) {
+      if ( ctxOption( ctx, "REFINE_DEBUG" ) ) {
         const hipError_t e = hipStreamSynchronize( s );
         fprintf( stderr, "refine: sweep %d sweep done (%d)\n", iter, int( e ) );
       }
@@ -1842,7 +1842,7 @@ int RefineJob::finish() {
   TMC2_HIP( hipMemsetAsync( d_bits.p, 0, 3 * size_t( W ) * 4, s ) );
   const size_t tailLds   = 3 * size_t( W ) * 4;
   // (test hook TMC2_REFINE_TAIL=global: take the global-memory tail regardless, the path of grids > 349 K voxels)
-  const char*  tailEnv   = getenv( "TMC2_REFINE_TAIL" );
+  const char*  tailEnv   = ctxOption( ctx, "REFINE_TAIL" );
   const bool   tailInLds = tailLds <= 128 * 1024 && !( tailEnv && tailEnv[0] == 'g' );
   if ( tailInLds && tailLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureTailKernel ), tailLds, ctx->device ) );
   // d_flags: [0] fixpoint reached; [2k + 1] sweep k moved a point; [2k + 2] sweep k changed a voxel state
@@ -1880,7 +1880,7 @@ int RefineJob::finish() {
           break;
         }
     ctx->stageAddHostMs( "refine_sweeps_executed", double( executed ) );  // (a count, not milliseconds)
-    if ( getenv( "TMC2_REFINE_TRACE" ) ) {  // test hook: points moved per sweep
+    if ( ctxOption( ctx, "REFINE_TRACE" ) ) {  // test hook: points moved per sweep
       fprintf( stderr, "refine: points moved per sweep:" );
       for ( int m = 0; m < iterationCount; ++m ) fprintf( stderr, " %u", h_flags[2 * m + 1] );
       fprintf( stderr, "\n" );

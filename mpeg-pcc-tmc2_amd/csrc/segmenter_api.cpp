@@ -78,7 +78,7 @@ int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
       if ( !done ) f->refineJob.reset();
     }
   } guard{f};
-  if ( p->gridBasedRefineSegmentation && tmc2::refineOverlap() )
+  if ( p->gridBasedRefineSegmentation && tmc2::refineOverlap( f->ctx ) )
     f->beforeHostWalk = [f, p]() {
       return tmc2::refinePrepareGeometry( f, p->maxNNCountRefineSegmentation, p->lambdaRefineSegmentation,
                                           p->iterationCountRefineSegmentation, p->voxelDimensionRefineSegmentation,

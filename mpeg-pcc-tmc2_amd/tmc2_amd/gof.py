@@ -186,11 +186,29 @@ class GofEncoder:
                 cpus[w] = d[((first_domain + w) // len(doms)) % len(d)]
         # few frames in flight (one rank's share of a many-GPU run): the refinement's geometry goes ahead of the orientation's host
         # walk -- it shortens a frame's chain; with the chip full it would only compete (include/tmc2hip.h)
-        if os.environ.get("TMC2_REFINE_OVERLAP") is None:
-            lib.load_library().tmc2_set_refine_overlap(1 if workers <= 4 else 0)
         self.closed = False
         self.threads = [_Worker(w, device, cpus[w], timing) for w in range(workers)]
         self.ctxs = [t.ctx for t in self.threads]
+        if os.environ.get("TMC2_REFINE_OVERLAP") is None:      # (an option of THIS encoder's contexts: nothing process-wide)
+            self.set_option("REFINE_OVERLAP", 1 if workers <= 4 else 0)
+
+    def set_option(self, key, value):
+        """tmc2_ctx_set_option on every context of this encoder (value None: unset)."""
+        for c in self.ctxs:
+            c.set_option(key, value)
+
+    def reserve(self, max_points, max_w=None, max_h=None):
+        """tmc2_ctx_reserve on every context (on its own worker thread): the sequence's largest frame, with this encoder's
+        refinement voxels / bit depth; canvas: the minimum one unless the caller knows better."""
+        w, h = max_w or self.min_w, max_h or max(self.min_h, self.min_w)
+        self._dispatch([(i, (lambda c=c: c.reserve(max_points, self.vox_dim, self.bits3d, w, h))) for i, c in enumerate(self.ctxs)])
+
+    def pool_stats(self):
+        tot = {}
+        for c in self.ctxs:
+            for k, v in c.pool_stats().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
 
     def close(self, join=False):
         """Ends the worker threads; join=True also waits for them and closes their contexts (every frame of this encoder must

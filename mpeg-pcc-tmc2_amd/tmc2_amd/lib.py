@@ -133,6 +133,18 @@ def load_library():
     L.tmc2_last_error.restype = C.c_char_p
     L.tmc2_set_kdtree_placement.restype = None
     L.tmc2_set_refine_overlap.restype = None
+    L.tmc2_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.tmc2_ctx_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.tmc2_ctx_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.tmc2_ctx_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.tmc2_ctx_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tmc2_ctx_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tmc2_ctx_stream.argtypes = [C.c_void_p]
+    L.tmc2_ctx_device.argtypes = [C.c_void_p]
+    L.tmc2_ctx_make_current.argtypes = [C.c_void_p]
+    L.tmc2_ctx_pool_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tmc2_ctx_get_option.argtypes = [C.c_void_p, C.c_char_p]
+    L.tmc2_ctx_get_option.restype = C.c_char_p
     L.tmc2_set_host_parallelism.restype = None
     L.tmc2_ctx_stage_name.restype = C.c_char_p
     L.tmc2_ctx_stage_ms.restype = C.c_double
@@ -167,6 +179,52 @@ class Context:
 
     def synchronize(self):
         _check(self.L.tmc2_ctx_synchronize(self.h))
+
+    def set_option(self, key, value):
+        """Per-context option (include/tmc2hip.h: tmc2_ctx_set_option); value None unsets it.  A context starts with the TMC2_*
+        variables of the environment it was created in."""
+        _check(self.L.tmc2_ctx_set_option(self.h, key.encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, key):
+        v = self.L.tmc2_ctx_get_option(self.h, key.encode())
+        return None if v is None else v.decode()
+
+    def reserve(self, max_points, vox_dim, bits3d, max_w, max_h):
+        """tmc2_ctx_reserve: the device memory of the sequence's largest frame, allocated now (no first-use hipMalloc later)."""
+        _check(self.L.tmc2_ctx_reserve(self.h, C.c_uint64(int(max_points)), int(vox_dim), int(bits3d), int(max_w), int(max_h)))
+
+    # device staging (what libtmc2gof.so's RCCL mode uses between its collectives): raw device memory of this context's device,
+    # copies ordered on its stream
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(self.L.tmc2_ctx_device_alloc(self.h, C.c_size_t(int(nbytes)), C.byref(p)))
+        return p
+
+    def device_free(self, p):
+        _check(self.L.tmc2_ctx_device_free(self.h, p))
+
+    def upload(self, device_ptr, array):
+        a = np.ascontiguousarray(array)
+        _check(self.L.tmc2_ctx_upload(self.h, device_ptr, _ptr(a), C.c_size_t(a.nbytes)))
+
+    def download(self, array, device_ptr):
+        _check(self.L.tmc2_ctx_download(self.h, _ptr(array), device_ptr, C.c_size_t(array.nbytes)))
+        return array
+
+    def stream(self):
+        self.L.tmc2_ctx_stream.restype = C.c_void_p
+        return self.L.tmc2_ctx_stream(self.h)
+
+    def device(self):
+        return int(self.L.tmc2_ctx_device(self.h))
+
+    def make_current(self):
+        _check(self.L.tmc2_ctx_make_current(self.h))
+
+    def pool_stats(self):
+        held, calls, carved, ms = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
+        _check(self.L.tmc2_ctx_pool_stats(self.h, C.byref(held), C.byref(calls), C.byref(ms), C.byref(carved)))
+        return {"bytes_held": held.value, "hipmalloc_calls": calls.value, "hipmalloc_ms": ms.value, "carved_blocks": carved.value}
 
     def stage_ms(self):
         return {self.L.tmc2_ctx_stage_name(self.h, i).decode(): self.L.tmc2_ctx_stage_ms(self.h, i)
@@ -579,13 +637,16 @@ class SharedHostArray:
             os.close(fd)
         self.array = np.frombuffer(self.map, dtype=np.uint8)
         if register:
-            _check(load_library().tmc2_host_register(_ptr(self.array), C.c_size_t(self.nbytes)))
+            # (the mapping's own address, never a red-zone copy of the guard mode: the call page-locks the memory, it moves no payload)
+            _check(load_library().tmc2_host_register(C.c_void_p(self.array.ctypes.data), C.c_size_t(self.nbytes)))
             self.registered = True
 
     def close(self):
         if self.registered:
-            load_library().tmc2_host_unregister(_ptr(self.array))
+            rc = load_library().tmc2_host_unregister(C.c_void_p(self.array.ctypes.data))
             self.registered = False
+            if rc != 0:
+                raise Tmc2Error("tmc2_host_unregister(%s) failed: %d" % (self.path, rc))
         if self.created:
             try:
                 os.unlink(self.path)

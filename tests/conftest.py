@@ -39,3 +39,34 @@ def reference():
 def gpu_ctx():
     import tmc2_amd as T
     return T.Context(0)
+
+
+class _CtxOptions:
+    """monkeypatch-shaped access to the per-context options of the session's context (tmc2_ctx_set_option: the library reads the
+    environment once, when a context is created -- a test that wants another form of a stage says so to ITS context)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.saved = ctx, {}
+
+    @staticmethod
+    def _key(name):
+        return name[5:] if name.startswith("TMC2_") else name
+
+    def setenv(self, name, value):
+        key = self._key(name)
+        self.saved.setdefault(key, self.ctx.get_option(key))
+        self.ctx.set_option(key, value)
+
+    def delenv(self, name):
+        self.setenv(name, None)
+
+    def undo(self):
+        for key, old in self.saved.items():
+            self.ctx.set_option(key, old)
+
+
+@pytest.fixture
+def ctx_options(gpu_ctx):
+    o = _CtxOptions(gpu_ctx)
+    yield o
+    o.undo()

@@ -102,3 +102,35 @@ int tmc2_frame_get_attribute_images( tmc2_frame* f, uint8_t* attribute ) {
   return note( GET_ATTRIBUTE, f );
 }
 }
+
+// ---- what the sharded mode of the runner (tmc2_gof_encode_sharded) needs on top: a "device" that is host memory, and the patch
+// list of a frame (frame id f: 3 + f % 5 patches; patch k of it: u0 = f, v0 = k -- in list order through an order that reverses)
+struct tmc2_ctx {
+  int device;
+};
+extern "C" {
+tmc2_ctx* mock_ctx( int device ) { return new tmc2_ctx{device}; }
+void      mock_ctx_free( tmc2_ctx* c ) { delete c; }
+int       tmc2_ctx_device_alloc( tmc2_ctx*, size_t bytes, void** out ) { *out = calloc( 1, bytes ? bytes : 1 ); return *out ? TMC2_OK : TMC2_E_HIP; }
+int       tmc2_ctx_device_free( tmc2_ctx*, void* p ) { free( p ); return TMC2_OK; }
+int       tmc2_ctx_upload( tmc2_ctx*, void* d, const void* s, size_t n ) { memcpy( d, s, n ); return TMC2_OK; }
+int       tmc2_ctx_download( tmc2_ctx*, void* d, const void* s, size_t n ) { memcpy( d, s, n ); return TMC2_OK; }
+int       tmc2_ctx_synchronize( tmc2_ctx* ) { return TMC2_OK; }
+void*     tmc2_ctx_stream( tmc2_ctx* c ) { return c; }
+int       tmc2_ctx_device( tmc2_ctx* c ) { return c->device; }
+int       tmc2_ctx_make_current( tmc2_ctx* ) { return TMC2_OK; }
+int       tmc2_frame_patch_count( tmc2_frame* f ) { return 3 + f->id % 5; }
+int       tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t*, int16_t*, uint8_t* ) {
+  const int n = 3 + f->id % 5;
+  for ( int k = 0; k < n; ++k ) {
+    memset( &patches[k], 0, sizeof( tmc2_patch ) );
+    patches[k].index = k, patches[k].u0 = f->id, patches[k].v0 = n - 1 - k;  // (stored in reverse of the list order)
+  }
+  return TMC2_OK;
+}
+int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order ) {
+  const int n = 3 + f->id % 5;
+  for ( int k = 0; k < n; ++k ) order[k] = n - 1 - k;
+  return TMC2_OK;
+}
+}

@@ -47,7 +47,7 @@ def test_gpu_gof32_sixteen_in_flight(name, monkeypatch):
         frs = enc.upload(frames)
         for rep in range(checked):
             run_and_check(enc, frs, c, g, "%s: repetition %d, 16 frames in flight, invariants on" % (name, rep))
-        monkeypatch.setenv("TMC2_UF_CHECK", "0")
+        enc.set_option("UF_CHECK", "0")
         for rep in range(plain):
             run_and_check(enc, frs, c, g, "%s: repetition %d, 16 frames in flight" % (name, rep))
         if decoder:

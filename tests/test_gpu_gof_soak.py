@@ -72,13 +72,13 @@ def test_gpu_gof_frames_in_flight_soak(name, monkeypatch):
         frs = enc.upload(frames)
         for rep in range(checked):
             run_and_check(enc, frs, c, g, "%s: repetition %d, %d frames in flight, invariants on" % (name, rep, workers))
-        monkeypatch.setenv("TMC2_UF_CHECK", "0")
+        enc.set_option("UF_CHECK", "0")
         for rep in range(plain):
             run_and_check(enc, frs, c, g, "%s: repetition %d, %d frames in flight" % (name, rep, workers))
         # the conservative forms must give the same bytes: no stale pre-check; every hop of every find at agent scope
-        monkeypatch.setenv("TMC2_UF_PRECHECK", "0")
+        enc.set_option("UF_PRECHECK", "0")
         run_and_check(enc, frs, c, g, name + ": pre-check off")
-        monkeypatch.setenv("TMC2_UF_SCOPE", "agent")
+        enc.set_option("UF_SCOPE", "agent")
         run_and_check(enc, frs, c, g, name + ": agent-scope finds")
     finally:
         enc.close()

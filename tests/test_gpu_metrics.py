@@ -90,9 +90,9 @@ def test_gpu_metrics_wide_groups(gpu_ctx, oracle):
         assert np.array_equal(gc, ec) and np.array_equal(bits(got), bits(exp)), (got, exp)
 
 
-def test_gpu_metrics_wide_search_on_ordinary_clouds(gpu_ctx, oracle, monkeypatch):
+def test_gpu_metrics_wide_search_on_ordinary_clouds(gpu_ctx, oracle, ctx_options):
     """The 32-wide search on clouds that do not need it: a search for k results is a prefix of the search for more."""
-    monkeypatch.setenv("TMC2_METRICS_K", "32")
+    ctx_options.setenv("TMC2_METRICS_K", "32")
     xyz, rgb = synth_cloud("small")
     rec, col = _recon(oracle, xyz, rgb)
     nrm = oracle.normals(xyz)

@@ -82,3 +82,68 @@ def test_gpu_native_gof_host_reports_the_failing_call():
         native_gof.encode([fr], [0], 1, 3, 4, 11, P, MIN_W, MIN_H, "all-intra", None, (MIN_W, MIN_H))
     fr.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_native_gof_sharded_runs_rccl_from_cpp():
+    """tmc2_gof_encode_sharded on this box's one GPU: a communicator of ONE rank is still librccl.so's ncclCommInitRank, and the pass
+    still runs the 24-byte ncclBroadcast, the ncclAllReduce( max ) of the canvas height and the grouped ncclSend / ncclRecv of the
+    packed patch records on the context's stream -- RCCL driven from the C++ host, for real.  Same canvases as the unsharded entry;
+    the gathered records are the frames' patch lists in list order.  (Several ranks: tests/test_native_gof_schedule.py, against a
+    recorder; the 8-GPU run: bench.py --host native --gpus 8.)"""
+    workers, n = 2, 4
+    clouds = [synth_cloud("tiny", i) for i in range(n)]
+    enc = T.GofEncoder(0, workers, 3, 11, P, MIN_W, MIN_H)
+    frames = enc.upload(clouds)
+    want_size, want = through_python(enc, frames, "all-intra")
+    comm = native_gof.Comm(enc.ctxs[0], rank=0, world=1)
+    try:
+        for rep in range(2):
+            bufs = buffers(n, *want_size)
+            W, H, records = native_gof.encode_sharded(comm, frames, [i % workers for i in range(n)], workers, 3, 4, 11, P, MIN_W, MIN_H,
+                                                      bufs, want_size)
+            assert (W, H) == tuple(want_size)
+            for i, (b, w, fr) in enumerate(zip(bufs, want, frames)):
+                for k, y in zip(("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"), w[0]):
+                    assert np.array_equal(b[0][k], y), (rep, i, k)
+                assert np.array_equal(b[1], w[1]), (rep, i)
+                assert records[0][i].tobytes() == fr.get_patches()[0][fr.get_patch_order()].tobytes(), (rep, i)
+    finally:
+        comm.close()
+        for fr in frames:
+            fr.close()
+        enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_two_contexts_two_sets_of_options():
+    """Options are per context (tmc2_ctx_set_option): two contexts of one process build the same tree through different tiers of
+    the device builder, and the environment is read once, when a context is created."""
+    import os
+    xyz, _ = synth_cloud("medium")
+    a = T.Context(0)
+    os.environ["TMC2_KD_FORM"] = "tiers"
+    try:
+        b = T.Context(0)
+    finally:
+        del os.environ["TMC2_KD_FORM"]
+    assert a.get_option("KD_FORM") is None and b.get_option("KD_FORM") == "tiers"
+    a.set_option("TMC2_KD_HUGEMAX", 4096)                      # (the prefix is accepted)
+    assert a.get_option("KD_HUGEMAX") == "4096"
+    fa, fb = a.frame(xyz), b.frame(xyz)
+    pa, pb = fa.kdtree_order(), fb.kdtree_order()
+    assert np.array_equal(pa[0], pb[0]) and pa[1] == pb[1]
+    assert np.array_equal(pa[0], T.host_kdtree_build(xyz)[0])
+    assert "kdtree_build" in a.stage_ms() and "kdtree_build" in b.stage_ms()
+    a.set_option("KD_HUGEMAX", None)
+    assert a.get_option("KD_HUGEMAX") is None
+    st = a.pool_stats()
+    assert st["bytes_held"] > 0 and st["hipmalloc_calls"] > 0 and st["carved_blocks"] == 0
+    c = T.Context(0)
+    c.reserve(len(xyz), 4, 11, 1280, 1280)
+    fc = c.frame(xyz)
+    assert np.array_equal(fc.kdtree_order()[0], pa[0])
+    st = c.pool_stats()
+    assert st["carved_blocks"] > 0 and st["hipmalloc_calls"] == 0, st
+    for f in (fa, fb, fc):
+        f.close()

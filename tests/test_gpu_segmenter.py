@@ -82,13 +82,13 @@ def test_gpu_knn_edge_cases(gpu_ctx, oracle):
 @pytest.mark.parametrize("case", ["tiny", "small", "medium", "longdress_vox10", "line", "plane", "duplicates", "eleven",
                                   "root3000", "root8192", "n8193", "dense20000", "root30000", "n40000", "dense60000",
                                   "huge131072:root100000", "huge131072:dense120000", "huge8192:root30000"])
-def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, monkeypatch, case):
+def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, ctx_options, case):
     """The level-parallel device build must leave exactly the permutation of nanoflann's recursive build (the oracle's
     restatement for the small clouds, the library's host builder -- itself pinned to the oracle on CPU -- for all)."""
     rng = np.random.default_rng(5)
     if case.startswith("huge"):                      # TMC2_KD_HUGEMAX: the largest segment one workgroup splits in global memory
         hook, case = case.split(":")                 # (default 32 768; 8 192 = that tier is off; 131 072 = its limit)
-        monkeypatch.setenv("TMC2_KD_HUGEMAX", hook[4:])
+        ctx_options.setenv("TMC2_KD_HUGEMAX", hook[4:])
     if case == "line":                               # every split degenerates to one dimension, long equal runs
         xyz = np.zeros((5000, 3), np.int16); xyz[:, 1] = rng.integers(0, 40, 5000)
     elif case == "plane":
@@ -145,11 +145,11 @@ def test_gpu_full_size_properties(gpu_ctx):
 
 @pytest.mark.parametrize("sweeps", ["event-driven", "full"])
 @pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 50), ("medium", 20)])
-def test_gpu_refine_matches_oracle(gpu_ctx, oracle, monkeypatch, name, iters, sweeps):
+def test_gpu_refine_matches_oracle(gpu_ctx, oracle, ctx_options, name, iters, sweeps):
     """Both sweep loops of S5: the event-driven one (default: incremental S, re-scoring only where S changed, the closure
     walked chip-wide without levels) and the sweep-everything one kept as a cross-check (TMC2_REFINE_SWEEPS=full)."""
     if sweeps == "full":
-        monkeypatch.setenv("TMC2_REFINE_SWEEPS", "full")
+        ctx_options.setenv("TMC2_REFINE_SWEEPS", "full")
     xyz, rgb = synth_cloud(name)
     nrm = oracle.normals(xyz)
     w = oracle.weight_normal(xyz)
@@ -177,10 +177,10 @@ def test_gpu_refine_voxels_of_two(gpu_ctx, oracle, name, iters):
 
 
 @pytest.mark.parametrize("vox_dim", [4, 2])
-def test_gpu_refine_row_capacity_retry(gpu_ctx, oracle, monkeypatch, vox_dim):
+def test_gpu_refine_row_capacity_retry(gpu_ctx, oracle, ctx_options, vox_dim):
     """The neighbourhood rows lie back to back in a table sized for twice the expected mean row; a frame that needs more
     repeats the pass with room for whole balls (forced here)."""
-    monkeypatch.setenv("TMC2_REFINE_ROWCAP", "tiny")
+    ctx_options.setenv("TMC2_REFINE_ROWCAP", "tiny")
     xyz, rgb = synth_cloud("small")
     nrm = oracle.normals(xyz)
     p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
@@ -193,15 +193,15 @@ def test_gpu_refine_row_capacity_retry(gpu_ctx, oracle, monkeypatch, vox_dim):
 
 @pytest.mark.parametrize("stack,blocks", [("1", None), ("2", "3"), (None, "1")])
 @pytest.mark.parametrize("vox_dim", [4, 2])
-def test_gpu_refine_closure_spill_ring(gpu_ctx, oracle, monkeypatch, vox_dim, stack, blocks):
+def test_gpu_refine_closure_spill_ring(gpu_ctx, oracle, ctx_options, vox_dim, stack, blocks):
     """The closure walks depth first with a ring in LDS per workgroup; what does not fit goes through a ring in global
     memory that the spilling group drains before it retires.  A ring with room for one or two voxels beyond the run sends nearly every activated voxel
     through the ring; a grid of 1 / 3 workgroups makes the runs of voxels long.  Every voxel must still be listed -- and
     processed -- exactly once."""
     if stack:
-        monkeypatch.setenv("TMC2_REFINE_RING", stack)
+        ctx_options.setenv("TMC2_REFINE_RING", stack)
     if blocks:
-        monkeypatch.setenv("TMC2_REFINE_CLOSURE_BLOCKS", blocks)
+        ctx_options.setenv("TMC2_REFINE_CLOSURE_BLOCKS", blocks)
     xyz, rgb = synth_cloud("medium")
     nrm = oracle.normals(xyz)
     p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
@@ -228,15 +228,15 @@ def test_gpu_refine_key_aliasing(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("vox_dim", [4, 2])
 @pytest.mark.parametrize("form", ["cells", "rows-tier1", "rows-tier2"])
-def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, monkeypatch, vox_dim, form):
+def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, ctx_options, vox_dim, form):
     """S5's neighbourhood rows two ways -- row-wise through the occupancy bitmap with gathered reverse rows (round 4, default)
     and cell by cell with scattered reverse rows (rounds 1-3, TMC2_REFINE_NEIGHBOURHOOD=cells) -- and in every LDS tier of the
     row-wise kernels: same bits as the reference's refinement.  A cloud with coordinates at the top of the range, so that
     voxel keys alias in both."""
     if form == "cells":
-        monkeypatch.setenv("TMC2_REFINE_NEIGHBOURHOOD", "cells")
+        ctx_options.setenv("TMC2_REFINE_NEIGHBOURHOOD", "cells")
     else:
-        monkeypatch.setenv("TMC2_REFINE_CAPTIER", form[-1])
+        ctx_options.setenv("TMC2_REFINE_CAPTIER", form[-1])
     for shift_to_top in (False, True):
         xyz, _ = synth_cloud("small")
         if shift_to_top:
@@ -308,12 +308,12 @@ def test_gpu_segment_patches_matches_oracle(gpu_ctx, oracle, name, iters):
 
 
 @pytest.mark.parametrize("rowcap", [None, "tiny"])
-def test_gpu_segmenter_compute_with_refine_geometry_ahead(gpu_ctx, oracle, monkeypatch, rowcap):
+def test_gpu_segmenter_compute_with_refine_geometry_ahead(gpu_ctx, oracle, ctx_options, rowcap):
     """TMC2_REFINE_OVERLAP=1: the refine step's point-only half (voxels, neighbourhood rows) is queued before the orientation's
     host walk and picked up afterwards -- also when the neighbourhood pass has to be repeated with more room."""
-    monkeypatch.setenv("TMC2_REFINE_OVERLAP", "1")
+    ctx_options.setenv("TMC2_REFINE_OVERLAP", "1")
     if rowcap:
-        monkeypatch.setenv("TMC2_REFINE_ROWCAP", rowcap)
+        ctx_options.setenv("TMC2_REFINE_ROWCAP", rowcap)
     xyz, rgb = synth_cloud("small", 2)
     fr = gpu_ctx.frame(xyz, rgb)
     p = T.ctc_params(10, 11, fr.weight_normal(11, 0.6))
@@ -378,7 +378,7 @@ def test_gpu_refine_many_sweeps(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("name", ["small", "medium"])
-def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch, name):
+def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, ctx_options, name):
     """S3 both ways: clusters contracted on the device + cluster walk on the host (default), and the point-level walk
     (what a frame falls back to when a cluster's strong edges disagree) -- same bits as the reference's growth."""
     xyz, rgb = synth_cloud(name)
@@ -389,19 +389,19 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch
     assert np.array_equal(fr.get_normals().view(np.uint64), exp.view(np.uint64))
     assert gpu_ctx.stage_calls().get("orient_contract", 0) == 1 and gpu_ctx.stage_calls().get("orient_normals_regrowth", 0) == 0
     # the pair table too small for the frame: the walk gets every cross edge instead of one per pair of clusters
-    monkeypatch.setenv("TMC2_ORIENT_PAIRS", "6")
+    ctx_options.setenv("TMC2_ORIENT_PAIRS", "6")
     fr3 = gpu_ctx.frame(xyz, rgb)
     gpu_ctx.stage_reset()
     fr3.normals_compute(16, 1)
     assert np.array_equal(fr3.get_normals().view(np.uint64), exp.view(np.uint64))
     assert gpu_ctx.stage_calls().get("orient_pair_table_overflow", 0) == 1
-    monkeypatch.delenv("TMC2_ORIENT_PAIRS")
+    ctx_options.delenv("TMC2_ORIENT_PAIRS")
     # the speculative room of the first attempt too small (what a vox11-size or noisy frame meets: > 64 K clusters or > 384 K
     # kept edges): the scatter is repeated with exact sizes on the SAME selection -- same compact graph (the strong one-way
     # edges included: the first of every implied sign, whatever the scheduling), same bits
     edges = []
     for spec, repeats in (("1000000,1000000", 0), ("64,16", 1), ("1000000,16", 1), ("64,1000000", 1)):
-        monkeypatch.setenv("TMC2_ORIENT_SPEC", spec)
+        ctx_options.setenv("TMC2_ORIENT_SPEC", spec)
         fr4 = gpu_ctx.frame(xyz, rgb)
         gpu_ctx.stage_reset()
         fr4.normals_compute(16, 1)
@@ -410,17 +410,17 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, monkeypatch
         assert gpu_ctx.stage_calls().get("orient_normals_regrowth", 0) == 0
         edges.append(gpu_ctx.stage_ms()["orient_compact_edges"])
     assert edges[0] > 64 and len(set(edges)) == 1, edges
-    monkeypatch.delenv("TMC2_ORIENT_SPEC")
-    monkeypatch.setenv("TMC2_ORIENT_NO_CONTRACTION", "1")
+    ctx_options.delenv("TMC2_ORIENT_SPEC")
+    ctx_options.setenv("TMC2_ORIENT_NO_CONTRACTION", "1")
     fr2 = gpu_ctx.frame(xyz, rgb)
     fr2.normals_compute(16, 1)
     assert np.array_equal(fr2.get_normals().view(np.uint64), exp.view(np.uint64))
 
 
-def test_gpu_refine_global_memory_tail(gpu_ctx, oracle, monkeypatch):
+def test_gpu_refine_global_memory_tail(gpu_ctx, oracle, ctx_options):
     """Sweep-everything loop, grids too large for the LDS bitmaps: the closure tail drains through global memory."""
-    monkeypatch.setenv("TMC2_REFINE_SWEEPS", "full")
-    monkeypatch.setenv("TMC2_REFINE_TAIL", "global")
+    ctx_options.setenv("TMC2_REFINE_SWEEPS", "full")
+    ctx_options.setenv("TMC2_REFINE_TAIL", "global")
     xyz, rgb = synth_cloud("small")
     nrm = oracle.normals(xyz)
     p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))

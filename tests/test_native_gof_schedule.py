@@ -151,3 +151,112 @@ def test_a_failing_call_ends_the_pass_with_its_status_and_message(runner, call, 
     assert not after
     if call in (SEGMENT, PACK_FLEXIBLE, PACK_CHAIN, GPA):
         assert not [e for e in log if e[0] >= GEOMETRY]
+
+
+# ---- the sharded mode: one process per rank, RCCL replaced by a recorder that moves the bytes through files -------------------------
+class _Patch(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("index", "viewId", "normalAxis", "tangentAxis", "bitangentAxis", "projectionMode", "u1", "v1", "d1",
+                                         "sizeU", "sizeV", "sizeD", "sizeDPixel", "sizeU0", "sizeV0", "size2DXInPixel", "size2DYInPixel",
+                                         "d0Count", "eomAndD1Count", "u0", "v0", "patchOrientation")] + [("depthOffset", C.c_int64), ("occOffset", C.c_int64)]
+
+
+def _sharded_rank(args):
+    """One rank of a sharded GOF pass against the recorders (runs in a process of its own)."""
+    d, rank, world, frames_per_rank, heights, packing = args
+    os.environ["TMC2_RCCL_LIBRARY"] = os.path.join(d, "libmockrccl.so")
+    os.environ["MOCK_RCCL_DIR"] = d
+    M = C.CDLL(os.path.join(d, "libtmc2hipmock.so"), mode=C.RTLD_GLOBAL)
+    G = C.CDLL(os.path.join(d, "libtmc2gofmock.so"))
+    M.mock_frame.restype = C.c_void_p
+    M.mock_ctx.restype = C.c_void_p
+    G.tmc2_gof_last_error.restype = C.c_char_p
+    ctx = C.c_void_p(M.mock_ctx(rank))
+    comm = C.c_void_p()
+    rc = G.tmc2_gof_comm_create(rank, world, ctx, os.path.join(d, "id").encode(), C.byref(comm))
+    if rc != 0:
+        return {"rc": rc, "err": G.tmc2_gof_last_error().decode()}
+    n = frames_per_rank
+    ids = [rank + i * world for i in range(n)]                       # frame f of the GOF on rank f mod world
+    frames = [M.mock_frame(f, int(heights[f]), MIN_W, 0) for f in ids]
+    handles = (C.c_void_p * n)(*frames)
+    slot_of = (C.c_int32 * n)(*[i % 2 for i in range(n)])
+    cfg = Config(7, 4, 11, 4, MIN_W, MIN_H, packing, 0)
+    W, H = C.c_int32(0), C.c_int32(0)
+    slots_rec = 16
+    gathered = (_Patch * (world * n * slots_rec))()
+    counts = (C.c_int64 * (world * n))()
+    M.mock_log_clear()
+    rc = G.tmc2_gof_encode_sharded(comm, handles, slot_of, n, 2, C.byref(cfg), None, None, None, None, None, None, 1 << 20, 1 << 20,
+                                   C.byref(W), C.byref(H), slots_rec, gathered, counts)
+    err = G.tmc2_gof_last_error().decode()
+    log = []
+    for i in range(M.mock_log_size()):
+        call, frame, a, b, th = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        M.mock_log_get(i, C.byref(call), C.byref(frame), C.byref(a), C.byref(b), C.byref(th))
+        log.append((call.value, frame.value, a.value, b.value))
+    G.tmc2_gof_comm_destroy(comm)
+    recs = [[(gathered[(s * slots_rec) + k].u0, gathered[(s * slots_rec) + k].v0) for k in range(int(counts[s]))] for s in range(world * n)]
+    with open(os.path.join(d, "log_%d" % rank)) as f:
+        rccl = f.read().split("\n")
+    return {"rc": rc, "err": err, "size": (W.value, H.value), "log": log, "counts": list(counts), "records": recs, "rccl": [x for x in rccl if x]}
+
+
+@pytest.fixture(scope="module")
+def sharded_libs(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("mock_gof_sharded"))
+    inc = os.path.join(ROOT, "include")
+    flags = ["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc]
+    subprocess.run(flags + [os.path.join(ROOT, "tests", "mock", "mock_tmc2hip.cpp"), "-o", os.path.join(d, "libtmc2hipmock.so"), "-pthread"], check=True)
+    subprocess.run(flags + [os.path.join(ROOT, "tests", "mock", "mock_rccl.cpp"), "-o", os.path.join(d, "libmockrccl.so")], check=True)
+    subprocess.run(flags + [os.path.join(ROOT, "mpeg-pcc-tmc2_amd", "host", "gof_runner.cpp"), "-o", os.path.join(d, "libtmc2gofmock.so"),
+                            "-L" + d, "-ltmc2hipmock", "-Wl,-rpath," + d, "-pthread", "-ldl"], check=True)
+    return d
+
+
+def _run_world(d, world, frames_per_rank, heights, packing=0):
+    import multiprocessing as mp
+    for name in os.listdir(d):                                         # (files of an earlier world)
+        if name.startswith(("log_", "p2p_", "ar_", "bcast_", "id")):
+            os.unlink(os.path.join(d, name))
+    with mp.get_context("spawn").Pool(world) as pool:
+        return pool.map(_sharded_rank, [(d, r, world, frames_per_rank, heights, packing) for r in range(world)])
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_sharded_gof_crosses_the_node_three_times(sharded_libs, world):
+    """tmc2_gof_encode_sharded (RCCL from C++: include/tmc2gof.h), one process per rank against recorders: S0 runs on rank 0 only
+    and its weights reach every rank's frames (24-byte broadcast); every rank rasterises on the canvas the TALLEST frame of the
+    GOF needs (all-reduce of one int32, max); the packed records of all frames end on rank 0, in list order (one grouped send /
+    receive) -- and nothing else crosses: per pass one broadcast, one all-reduce, one group.  World 1 runs the same collectives."""
+    n = 3
+    heights = [64 + 8 * f for f in range(world * n)]
+    heights[world * n - 1] = 400                                        # the tallest frame lives on the LAST rank
+    res = _run_world(sharded_libs, world, n, heights)
+    for r, x in enumerate(res):
+        assert x["rc"] == 0, (r, x["err"])
+        assert x["size"] == (MIN_W, 448), x["size"]                      # (the mock rounds the height up to a multiple of 64)
+        weights = [e for e in x["log"] if e[0] == WEIGHT]
+        assert (len(weights) == 1 and weights[0][1] == 0) if r == 0 else not weights
+        seg = [e for e in x["log"] if e[0] == SEGMENT]
+        assert sorted(e[1] for e in seg) == [r + i * world for i in range(n)] and all(e[2] == 7 and e[3] == 116 for e in seg), seg
+        assert all(e[2:] == (MIN_W, 448) for e in x["log"] if e[0] == GEOMETRY)
+        calls = [c.split()[0] for c in x["rccl"]]
+        per_pass = calls[calls.index("allreduce") + 1:-1]                # (after create's pre-flight all-reduce, before destroy)
+        assert per_pass.count("broadcast") == 1 and per_pass.count("allreduce") == 1 and per_pass.count("group") == 1, x["rccl"]
+        assert per_pass.count("send") == 1 and per_pass.count("recv") == (world if r == 0 else 0), x["rccl"]
+        assert "broadcast 24 root 0" in x["rccl"] and "allreduce 4 op 2" in x["rccl"]
+    got = res[0]
+    for r in range(world):
+        for i in range(n):
+            f = r + i * world
+            assert got["counts"][r * n + i] == 3 + f % 5
+            assert got["records"][r * n + i] == [(f, k) for k in range(3 + f % 5)], (f, got["records"][r * n + i])
+
+
+def test_sharded_gof_refuses_the_packing_chains(sharded_libs):
+    """The low-delay / random-access chains run over all frames of the GOF in order: with the frames on several ranks that is the
+    caller's job, and the sharded entry says so on every rank before anything is queued (nobody is left waiting in a collective)."""
+    res = _run_world(sharded_libs, 2, 2, [64, 64, 64, 64], packing=2)
+    for x in res:
+        assert x["rc"] != 0 and "packing chains" in x["err"], x
+        assert not [e for e in x["log"] if e[0] in (SEGMENT, WEIGHT)]
