@@ -967,6 +967,17 @@ def main():
                               "frac": round(b_alg * fps / 1e9 / 8000.0, 5)},
                      "stages": per_stage},
         "stage_ms_per_frame": {k: round(v / (a.steps * len(frames)), 3) for k, v in sorted(ms.items())},
+        # S3's cliff: a frame whose contracted graph is inconsistent at 0.98 walks the threshold ladder (a contraction + a cluster
+        # walk per step: milliseconds) and, past its last step, falls back to the growth point by point (hundreds of milliseconds,
+        # and the GOF's rendezvous waits for it).  Per GOF of the timed region:
+        "orientation": {"frames_per_gof": a.frames,
+                        "contracted_walks_per_gof": round(calls.get("orient_contract", 0) / a.steps, 2),
+                        "ladder_steps_per_gof": round(calls.get("orient_tau_retry", 0) / a.steps, 2),
+                        "point_level_fallbacks_per_gof": round(calls.get("orient_normals_regrowth", 0) / a.steps, 2),
+                        "pair_table_overflows_per_gof": round(calls.get("orient_pair_table_overflow", 0) / a.steps, 2),
+                        "exact_size_repeats_per_gof": round(calls.get("orient_exact_size_repeat", 0) / a.steps, 2),
+                        "what": "this rank's frames; SURVEY 8a S3 (PCCNormalsGenerator.cpp:198-242): the exact directed growth runs on the "
+                                "contracted graph; ladder = thresholds 0.99 / 0.995 / 0.998 tried after 0.98"},
     }
     # the measured ceiling next to the nominal 8 TB/s: a device-to-device copy of 1 GiB, bytes read +
     # bytes written per second, with the GPU to itself (outside the timed region)

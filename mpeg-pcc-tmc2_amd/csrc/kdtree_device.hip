@@ -1424,6 +1424,7 @@ struct LvSeg {
   int32_t  mn[3], mx[3];   // tight range of the points (atomics)
 };
 
+constexpr int kLandBlock = 256;  // the landing pass: one record of the children's ranges per workgroup (measured: 1 024-thread workgroups quarter the records the decide pass folds -- 14 -> 7 us -- and cost the landing pass itself 18 -> 32 us)
 struct LvPartial {
   uint32_t slot;  // left child's segment at the next level (kNone: this workgroup reported on its own / had nothing)
   uint32_t v[6];  // packed (mn x|y, mx x|y, mn z | ~mx z) of the left and of the right child
@@ -1493,7 +1494,10 @@ __global__ __launch_bounds__( kBlock ) void lvInitKernel( BuildArgs a ) {
     }
   }
 }
-__global__ void lvRootKernel( BuildArgs a ) {
+__global__ void lvRootKernel( BuildArgs a ) {  // (one workgroup of 128: it also clears the counters -- one launch instead of a memset + this)
+  if ( threadIdx.x < kMaxLevels + 16 ) a.counts[threadIdx.x] = 0;
+  __syncthreads();
+  if ( threadIdx.x != 0 ) return;
   LvSeg r{};
   r.begin = 0, r.end = a.n, r.node = 0, r.parent = kNone;
   for ( int d = 0; d < 3; ++d ) r.mn[d] = 0x7FFFFFFF, r.mx[d] = int32_t( 0x80000000 );
@@ -1526,7 +1530,7 @@ __global__ __launch_bounds__( kDecideThreads ) void lvDecideKernel( BuildArgs a,
     __syncthreads();
   }
   if ( level > 0 ) {
-    const uint32_t nPart = ( a.n + uint32_t( kBlock ) - 1u ) / uint32_t( kBlock );
+    const uint32_t nPart = ( a.n + uint32_t( kLandBlock ) - 1u ) / uint32_t( kLandBlock );
     for ( uint32_t base = 0; base < nPart; base += kDecideThreads ) {  // (uniform over the workgroup)
       const uint32_t t = base + threadIdx.x;
       LvPartial      pt;
@@ -1702,11 +1706,12 @@ __global__ __launch_bounds__( kBlock ) void lvFlagKernel( BuildArgs a, uint32_t 
 // The tile totals of a flag pass (raw, in global memory) -> their exclusive prefix sums in LDS, sums[tiles] = the grand total.
 // Every workgroup of a swap pass does this for itself: a few hundred words, one LDS scan -- instead of the flag pass ending in
 // a ticket, a hand-off to the workgroup that finishes last and ITS scan, with the whole chip waiting.
+template <int BLOCK>
 __device__ __forceinline__ void lvLoadSums( uint32_t* sums, const uint32_t* __restrict__ raw, uint32_t tiles ) {
-  __shared__ uint32_t waveSum[kWaves];
+  __shared__ uint32_t waveSum[BLOCK / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t  carry = 0;
-  for ( uint32_t base = 0; base < tiles; base += kBlock ) {
+  for ( uint32_t base = 0; base < tiles; base += BLOCK ) {
     const uint32_t i   = base + threadIdx.x;
     const uint32_t v   = i < tiles ? raw[i] : 0u;
     uint32_t       inc = v;
@@ -1720,7 +1725,7 @@ __device__ __forceinline__ void lvLoadSums( uint32_t* sums, const uint32_t* __re
     uint32_t offset = carry + inc - v;
     for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
     if ( i < tiles ) sums[i] = offset;
-    for ( int w = 0; w < kWaves; ++w ) carry += waveSum[w];
+    for ( int w = 0; w < BLOCK / 64; ++w ) carry += waveSum[w];
     __syncthreads();
   }
   if ( threadIdx.x == 0 ) sums[tiles] = carry;
@@ -1734,7 +1739,7 @@ __global__ __launch_bounds__( kBlock ) void lvSwapOneKernel( BuildArgs a, uint32
   const uint32_t n = a.n, tiles = a.tiles;
   const uint32_t gsize = gridDim.x * blockDim.x;
   LvSeg*         cur = ( level & 1 ) ? a.lvB : a.lvA;
-  lvLoadSums( lvSums, a.tile1, tiles );
+  lvLoadSums<kBlock>( lvSums, a.tile1, tiles );
   for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gsize ) {
     const uint32_t s = a.seg[i];
     if ( s == kNone ) continue;
@@ -1761,17 +1766,17 @@ __global__ __launch_bounds__( kBlock ) void lvSwapOneKernel( BuildArgs a, uint32
 
 // second sweep's swaps, and the landing: every position learns its child (its segment of the next level), the children's
 // tight ranges are gathered, the thread on a segment's first position writes the children and the node record
-__global__ __launch_bounds__( kBlock ) void lvSwapTwoKernel( BuildArgs a, uint32_t level ) {
+__global__ __launch_bounds__( kLandBlock ) void lvSwapTwoKernel( BuildArgs a, uint32_t level ) {
   extern __shared__ uint32_t lvSums[];  // [tiles + 1]
   const uint32_t n = a.n, tiles = a.tiles;
   const uint32_t gsize = gridDim.x * blockDim.x;
   const int      lane  = threadIdx.x & 63;
   LvSeg*         cur  = ( level & 1 ) ? a.lvB : a.lvA;
   LvSeg*         next = ( level & 1 ) ? a.lvA : a.lvB;
-  lvLoadSums( lvSums, a.tile2, tiles );
-  const uint32_t nRound = ( n + uint32_t( kBlock ) - 1u ) & ~( uint32_t( kBlock ) - 1u );
+  lvLoadSums<kLandBlock>( lvSums, a.tile2, tiles );
+  const uint32_t nRound = ( n + uint32_t( kLandBlock ) - 1u ) & ~( uint32_t( kLandBlock ) - 1u );
   __shared__ uint32_t blockSeg;
-  __shared__ uint32_t red[kWaves][6];
+  __shared__ uint32_t red[kLandBlock / 64][6];
   const int wave = threadIdx.x >> 6;
   for ( uint32_t i0 = blockIdx.x * blockDim.x; i0 < nRound; i0 += gsize ) {  // (uniform per workgroup: it reduces together)
     const uint32_t i   = i0 + threadIdx.x;
@@ -1868,18 +1873,18 @@ __global__ __launch_bounds__( kBlock ) void lvSwapTwoKernel( BuildArgs a, uint32
           pt.slot = slot, pt.unused = 0;
           for ( int k = 0; k < 6; ++k ) {
             uint32_t x = red[0][k];
-            for ( int w = 1; w < kWaves; ++w ) x = ( k % 3 ) == 1 ? pkMax( x, red[w][k] ) : pkMin( x, red[w][k] );
+            for ( int w = 1; w < kLandBlock / 64; ++w ) x = ( k % 3 ) == 1 ? pkMax( x, red[w][k] ) : pkMin( x, red[w][k] );
             pt.v[k] = x;
           }
-          a.partial[i0 / kBlock] = pt;
+          a.partial[i0 / kLandBlock] = pt;
         }
       } else if ( threadIdx.x == 0 ) {
-        a.partial[i0 / kBlock].slot = kNone;
+        a.partial[i0 / kLandBlock].slot = kNone;
       }
       __syncthreads();
       continue;
     }
-    if ( threadIdx.x == 0 ) a.partial[i0 / kBlock].slot = kNone;
+    if ( threadIdx.x == 0 ) a.partial[i0 / kLandBlock].slot = kNone;
     if ( moved ) lvReport( next + slot + 1u, pkLo( A2 ), pkHi( A2 ), pkLo( C2 ), pkLo( A2 ), pkHi( A2 ), pkLo( C2 ) );
     if ( waveSegMinMaxPacked( key, A, B, C, lane ) )
       lvReport( next + key, pkLo( A ), pkHi( A ), pkLo( C ), pkLo( B ), pkHi( B ), ~pkHi( C ) );
@@ -2287,7 +2292,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   TMC2_TRY( d_work.alloc( 3 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
-  TMC2_HIP( hipMemsetAsync( d_small.p, 0, ( kMaxLevels + 16 ) * 4, s ) );
+  static_assert( kMaxLevels + 16 <= 128, "lvRootKernel clears the counters with one workgroup of 128" );
   BuildArgs a;
   a.pts = d_pts, a.n = n, a.tiles = tiles, a.P = d_ptsTree.p, a.perm = d_perm.p;
   a.seg = d_work.p, a.loc1 = d_work.p + n, a.loc2 = d_work.p + 2 * size_t( n );
@@ -2310,6 +2315,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.splitMax     = pieces ? uint32_t( kPieceMax ) : uint32_t( kSplitMax );
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
+  const dim3 grdL( std::max<uint32_t>( 1u, ( n + kLandBlock - 1 ) / kLandBlock ) );
   // round 5's level passes go with the pieces (TMC2_KD_LEVELS=r4: round 4's five launches per level, the cross-check); their
   // swap passes keep the tile totals in LDS
   const char*  levelsEnv = ctxOption( ctx, "KD_LEVELS" );
@@ -2322,13 +2328,14 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   if ( newLevels ) {
     TMC2_TRY( d_lv.alloc( 2 * maxLv ) );
     TMC2_TRY( d_list.alloc( size_t( tiles ) * kScanTile ) );
-    TMC2_TRY( d_partial.alloc( size_t( n ) / kBlock + 2 ) );
+    TMC2_TRY( d_partial.alloc( size_t( n ) / kLandBlock + 2 ) );
     a.lvA = d_lv.p, a.lvB = d_lv.p + maxLv, a.list = d_list.p, a.partial = d_partial.p;
-    hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 1 ), 0, s, a );
-    hipLaunchKernelGGL( lvInitKernel, grdE, blk, 0, s, a );
+    hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 128 ), 0, s, a );
+    hipLaunchKernelGGL( lvInitKernel, dim3( std::min<uint32_t>( grdE.x, 1024u ) ), blk, 0, s, a );  // (each workgroup reports the root's range once)
     hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, 0u );
   } else {
     a.lvA = a.lvB = nullptr, a.list = nullptr, a.partial = nullptr;
+    TMC2_HIP( hipMemsetAsync( d_small.p, 0, ( kMaxLevels + 16 ) * 4, s ) );
     hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
   }
   uint32_t out[kMaxLevels + 16];
@@ -2350,7 +2357,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
         hipLaunchKernelGGL( lvFlagKernel<true>, grdT, blk, 0, s, a, level );
         hipLaunchKernelGGL( lvSwapOneKernel, grdE, blk, sumsLds, s, a, level );
         hipLaunchKernelGGL( lvFlagKernel<false>, grdT, blk, 0, s, a, level );
-        hipLaunchKernelGGL( lvSwapTwoKernel, grdE, blk, sumsLds, s, a, level );
+        hipLaunchKernelGGL( lvSwapTwoKernel, grdL, dim3( kLandBlock ), sumsLds, s, a, level );
         hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, level + 1u );
       } else {
         hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );

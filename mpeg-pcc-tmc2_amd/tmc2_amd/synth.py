@@ -52,6 +52,13 @@ def _sdf_capsule(p, a, b, r):
 
 
 def synth_cloud(name="small", frame=0, height=None, bits=None, seed=None):
+    """name + "_noisy": the same body with per-sample jitter along the surface normal on the scale of the voxel pitch (sigma = 0.8
+    voxels) -- a thick, rough shell, the way a reconstructed capture looks next to a smooth CAD-like surface: normals of
+    neighbouring points disagree, the orientation's strong-edge contraction (S3) meets inconsistent cycles and its threshold ladder
+    / point-level fallback get exercised (bench.py --workload longdress_vox10_noisy reports how often)."""
+    noisy = name.endswith("_noisy")
+    if noisy:
+        name = name[:-len("_noisy")]
     pb, ph, ps = _PRESETS[name] if name in _PRESETS else (10, 170, 11)
     bits = pb if bits is None else bits
     H = float(ph if height is None else height)
@@ -98,6 +105,8 @@ def synth_cloud(name="small", frame=0, height=None, bits=None, seed=None):
         surf = pc + r * nc
         bump = (0.008 * H) * np.sin(surf[:, 0] * (37.0 / H) + k) * np.sin(surf[:, 1] * (29.0 / H)) * np.sin(
             surf[:, 2] * (31.0 / H) + 0.1 * frame)
+        if noisy:
+            bump = bump + 0.8 * rng.normal(size=len(bump))
         surf = np.rint(surf + bump[:, None] * nc).astype(np.int64)
         surf = surf[np.all((surf >= 0) & (surf < size), axis=1)]
         kk = np.unique(surf[:, 0] | (surf[:, 1] << 12) | (surf[:, 2] << 24))

@@ -324,7 +324,7 @@ def test_gpu_segmenter_compute_with_refine_geometry_ahead(gpu_ctx, oracle, ctx_o
     _assert_patches_equal(fr.get_patches(), exp)
 
 
-@pytest.mark.parametrize("name,frame,iters", [("small", 1, 50), ("medium", 2, 10)])
+@pytest.mark.parametrize("name,frame,iters", [("small", 1, 50), ("medium", 2, 10), ("small_noisy", 0, 10)])
 def test_gpu_segmenter_compute_matches_oracle(gpu_ctx, oracle, name, frame, iters):
     """PCCPatchSegmenter3::compute end to end (S1..S9) through the C-ABI."""
     xyz, rgb = synth_cloud(name, frame)

@@ -68,6 +68,11 @@ def test_oracle_matches_reference_live(oracle, reference):
     # disconnected components exercise the orientation's re-seeding path
     two = np.concatenate([xyz[:3000], xyz[:3000] + np.array([300, 0, 0], np.int16)])
     assert np.array_equal(bits(oracle.normals(two, 16)), bits(reference.normals(two, 16)))
+    # a rough, thick shell (per-sample jitter of the voxel pitch along the normal): neighbouring normals disagree, the growth's
+    # order decides signs all over the cloud -- the restatement must follow the reference there too
+    rough, _ = synth_cloud("small_noisy", frame=1)
+    assert np.array_equal(oracle.knn_self(rough, 16), reference.knn_self(rough, 16))
+    assert np.array_equal(bits(oracle.normals(rough, 16, oriented=True)), bits(reference.normals(rough, 16, oriented=True)))
 
 
 def _gof_fixture():
