@@ -268,7 +268,8 @@ const char* tmc2_ctx_get_option( tmc2_ctx* ctx, const char* key ) {
 /* Device memory for the frames this context will see, allocated NOW: every buffer a stage asks the context's pool for is carved
    from it, so that the first GOFs of a sequence make no hipMalloc (each one synchronises the device under all frames in flight).
    The figure is an upper estimate of what ONE frame in flight holds at its peak (tmc2_ctx_pool_stats of the BASELINE
-   configurations, with the pool's power-of-two size classes): 2.1 KB per point with voxels of 4, 3.4 KB with voxels of 2, 64 bytes
+   configurations, with the pool's power-of-two size classes): 2.1 KB per point with voxels of 4, 4.6 KB with voxels of 2 (the
+   85 M-entry forward and reverse rows of the refinement land in 1 GiB classes), 64 bytes
    per canvas pixel, the dense occupancy words of the refinement grid.  A frame that needs more falls back to hipMalloc. */
 int tmc2_ctx_reserve( tmc2_ctx* ctx, uint64_t maxPoints, int voxelDimRefine, int bits3d, int maxCanvasWidth, int maxCanvasHeight ) {
   if ( !ctx || maxPoints == 0 || maxPoints > ( uint64_t( 1 ) << 32 ) || bits3d < 1 || bits3d > 16 || maxCanvasWidth < 0 || maxCanvasHeight < 0 ) {
@@ -276,7 +277,7 @@ int tmc2_ctx_reserve( tmc2_ctx* ctx, uint64_t maxPoints, int voxelDimRefine, int
     return TMC2_E_INVALID;
   }
   tmc2::ApiScope scope( ctx );
-  const uint64_t perPoint = voxelDimRefine > 0 && voxelDimRefine <= 2 ? 3400 : 2100;
+  const uint64_t perPoint = voxelDimRefine > 0 && voxelDimRefine <= 2 ? 4600 : 2100;
   const int      gridShift = std::max( 1, bits3d - 1 - ( voxelDimRefine >= 4 ? 2 : ( voxelDimRefine >= 2 ? 1 : 0 ) ) );
   const uint64_t dense     = ( uint64_t( 1 ) << std::min( 33, 3 * gridShift + 1 ) ) / 32 * 8;  // uint2 per 32 keys
   const uint64_t bytes     = maxPoints * perPoint + uint64_t( maxCanvasWidth ) * uint64_t( maxCanvasHeight ) * 64 + dense + ( uint64_t( 64 ) << 20 );
@@ -358,6 +359,8 @@ void tmc2::destroyContextNow( tmc2_ctx* ctx ) {
     ctx->voxelBitmap.release();
   }
   if ( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
+  if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
+  if ( ctx->sweepGraph ) (void)hipGraphDestroy( static_cast<hipGraph_t>( ctx->sweepGraph ) );
   ctx->pool.drain();
   if ( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
   delete ctx;
