@@ -683,8 +683,12 @@ def main():
     enc = T.GofEncoder(local, workers, a.iterations, c["bits3d"], P, c["min_w"], c["min_h"], timing=True, first_domain=rank * workers,
                        vox_dim=c["vox_dim"])
     enc.set_option("KDTREE_HOST", kd_mode)                # (options of this encoder's contexts: nothing process-wide)
+    reserve_note = None
     if a.reserve:                                          # the sequence's largest frame, before the first one arrives
-        enc.reserve(max(len(c_[0]) for c_ in clouds), c["min_w"], max(c["min_h"], c["min_w"]))
+        try:
+            enc.reserve(max(len(c_[0]) for c_ in clouds), c["min_w"], max(c["min_h"], c["min_w"]))
+        except T.Tmc2Error as e:                           # (not enough device memory for every context's worst case: grow on demand)
+            reserve_note = "tmc2_ctx_reserve failed (%s): the pools grow by hipMalloc" % (e,)
     frames = enc.upload(clouds)                          # inputs resident in HBM
     n_points = sum(len(c[0]) for c in clouds)
 
@@ -928,7 +932,7 @@ def main():
         "metric": "encoder patch+image-gen frames/sec, %s %d-frame GOF" % (a.workload, a.frames),
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "priming_passes": max(0, a.prime), "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
-        "first_gof_ms": pass_ms[0] if pass_ms else None, "untimed_pass_ms": pass_ms, "pool": dict(enc.pool_stats(), reserved=bool(a.reserve)),
+        "first_gof_ms": pass_ms[0] if pass_ms else None, "untimed_pass_ms": pass_ms, "pool": dict(enc.pool_stats(), reserved=bool(a.reserve) and reserve_note is None, note=reserve_note),
         "first_gof_excess_ms_per_frame": dict(sorted(((k, round((first_stage_ms.get(k, 0.0) - v / a.steps) / max(1, len(frames)), 3))
                                                       for k, v in ms.items() if first_stage_ms.get(k, 0.0) - v / a.steps > 0.2 * len(frames)
                                                       and not k.startswith(("refine_row_entries", "refine_voxels", "refine_sweeps_executed"))),   # (counters, not times)
