@@ -207,7 +207,7 @@ int commMaxHeight( tmc2_gof_comm* comm, int32_t* h ) {
 // The final gather: the packed patch records of every frame (the side information the bitstream carries: ~ 100 bytes a patch) to
 // rank 0 -- one grouped send / receive per pass.  Block of a frame: int64 count, then recordSlots records in list order.
 int commGatherRecords( tmc2_gof_comm* comm, tmc2_frame** frames, int32_t count, int32_t recordSlots, tmc2_patch* gathered,
-                       int64_t* gatheredCounts ) {
+                       int64_t* gatheredCounts, int failed ) {
   const size_t frameBytes = 8 + size_t( recordSlots ) * sizeof( tmc2_patch ), mine = frameBytes * size_t( count );
   const size_t need       = mine * ( comm->rank == 0 ? size_t( comm->world ) + 1 : 1 );
   if ( need > comm->blocksBytes ) {
@@ -219,19 +219,31 @@ int commGatherRecords( tmc2_gof_comm* comm, tmc2_frame** frames, int32_t count, 
   comm->hostBlocks.assign( need, 0 );
   std::vector<tmc2_patch> list;
   std::vector<int32_t>    order;
+  // (A rank that cannot fill its block -- its pass failed after the rendezvous, or a frame has more patches than the block holds --
+  //  STILL takes part in the exchange, with a negative count in the block: the other ranks must not be left waiting in a receive.)
+  int         localStatus = failed;
+  std::string localError  = failed != TMC2_OK ? t_err : std::string();
   for ( int i = 0; i < count; ++i ) {
-    const int n = tmc2_frame_patch_count( frames[i] );
-    if ( n < 0 || n > recordSlots ) {
-      t_err = "tmc2_gof_encode_sharded: a frame with " + std::to_string( n ) + " patches, the gather holds " + std::to_string( recordSlots );
-      return TMC2_E_INVALID;
+    uint8_t* at  = comm->hostBlocks.data() + frameBytes * size_t( i );
+    int64_t  n64 = -1;
+    if ( localStatus == TMC2_OK ) {
+      const int n = tmc2_frame_patch_count( frames[i] );
+      if ( n < 0 || n > recordSlots ) {
+        localStatus = TMC2_E_INVALID;
+        localError  = "tmc2_gof_encode_sharded: a frame with " + std::to_string( n ) + " patches, the gather holds " + std::to_string( recordSlots );
+      } else {
+        list.resize( size_t( n ) ), order.resize( size_t( n ) );
+        int rc = tmc2_frame_get_patches( frames[i], list.data(), nullptr, nullptr, nullptr );
+        if ( rc == TMC2_OK ) rc = tmc2_frame_get_patch_order( frames[i], order.data() );
+        if ( rc != TMC2_OK ) {
+          localStatus = rc, localError = std::string( "tmc2_frame_get_patches: " ) + tmc2_last_error();
+        } else {
+          n64 = n;
+          for ( int k = 0; k < n; ++k ) memcpy( at + 8 + size_t( k ) * sizeof( tmc2_patch ), &list[size_t( order[size_t( k )] )], sizeof( tmc2_patch ) );
+        }
+      }
     }
-    list.resize( size_t( n ) ), order.resize( size_t( n ) );
-    HIP_TRY( tmc2_frame_get_patches( frames[i], list.data(), nullptr, nullptr, nullptr ), "tmc2_frame_get_patches" );
-    HIP_TRY( tmc2_frame_get_patch_order( frames[i], order.data() ), "tmc2_frame_get_patch_order" );
-    uint8_t*      at = comm->hostBlocks.data() + frameBytes * size_t( i );
-    const int64_t n64 = n;
     memcpy( at, &n64, 8 );
-    for ( int k = 0; k < n; ++k ) memcpy( at + 8 + size_t( k ) * sizeof( tmc2_patch ), &list[size_t( order[size_t( k )] )], sizeof( tmc2_patch ) );
   }
   void*    st   = tmc2_ctx_stream( comm->ctx );
   uint8_t* dev  = static_cast<uint8_t*>( comm->dBlocks );
@@ -242,16 +254,25 @@ int commGatherRecords( tmc2_gof_comm* comm, tmc2_frame** frames, int32_t count, 
       COMM_TRY( comm->rccl.Recv( dev + mine * size_t( r + 1 ), mine, kNcclUint8, r, comm->comm, st ), "ncclRecv( records )" );
   COMM_TRY( comm->rccl.Send( dev, mine, kNcclUint8, 0, comm->comm, st ), "ncclSend( records )" );
   COMM_TRY( comm->rccl.GroupEnd(), "ncclGroupEnd" );
-  if ( comm->rank != 0 ) return tmc2_ctx_synchronize( comm->ctx );
+  if ( comm->rank != 0 ) {
+    const int rc = tmc2_ctx_synchronize( comm->ctx );
+    if ( localStatus != TMC2_OK ) t_err = localError;
+    return localStatus != TMC2_OK ? localStatus : rc;
+  }
   HIP_TRY( tmc2_ctx_download( comm->ctx, comm->hostBlocks.data() + mine, dev + mine, mine * size_t( comm->world ) ), "records: download" );
+  if ( localStatus != TMC2_OK ) {
+    t_err = localError;
+    return localStatus;
+  }
   for ( int r = 0; r < comm->world; ++r )
     for ( int i = 0; i < count; ++i ) {
       const uint8_t* at = comm->hostBlocks.data() + mine * size_t( r + 1 ) + frameBytes * size_t( i );
       int64_t        n  = 0;
       memcpy( &n, at, 8 );
       if ( n < 0 || n > recordSlots ) {
-        t_err = "tmc2_gof_encode_sharded: rank " + std::to_string( r ) + " sent a block with " + std::to_string( n ) + " records";
-        return TMC2_E_INVALID;
+        t_err = "tmc2_gof_encode_sharded: rank " + std::to_string( r ) + " could not deliver the records of its frame " + std::to_string( i ) +
+                " (its own call says why)";
+        return TMC2_E_STATE;
       }
       if ( gatheredCounts ) gatheredCounts[size_t( r ) * size_t( count ) + size_t( i )] = n;
       if ( gathered )
@@ -387,12 +408,18 @@ int encodeGof( tmc2_gof_comm* comm, tmc2_frame** frames, const int32_t* slotOf, 
     const int rc = tmc2_weight_normal( frames[0], c.geometryBitDepth3D, 0.6, w );  // S0: frame 0 of the GOF only (rank 0's first)
     if ( rc != TMC2_OK ) {
       pass.fail( rc, "tmc2_weight_normal" );
-      return pass.done();
+      if ( !comm ) return pass.done();
+      w[0] = w[1] = w[2] = -1.0;  // (no axis weight is negative: the other ranks learn from the broadcast that there is no pass)
     }
   }
   if ( comm ) {
     const int rc = commBroadcastWeights( comm, w );
     if ( rc != TMC2_OK ) return rc;
+    if ( pass.status.load() != TMC2_OK ) return pass.done();
+    if ( w[0] < 0.0 ) {
+      t_err = "tmc2_gof_encode_sharded: rank 0 could not compute the axis weights of frame 0 (its own call says why)";
+      return TMC2_E_STATE;
+    }
   }
   const tmc2_segmenter_params params = ctcParams( c, w );
   std::vector<int32_t>        heights( static_cast<size_t>( count ), 0 ), guessW( static_cast<size_t>( count ), 0 ),
@@ -423,7 +450,16 @@ int encodeGof( tmc2_gof_comm* comm, tmc2_frame** frames, const int32_t* slotOf, 
                                        &guessW[size_t( i )], &guessH[size_t( i )] ) );
     images( i, guessW[size_t( i )], guessH[size_t( i )] );
   } );
-  if ( pass.status.load() != TMC2_OK ) return pass.done();
+  // (several ranks: a rank whose frames failed still goes to the rendezvous -- with a height no canvas has -- so that every rank
+  //  leaves the pass at the same place instead of waiting in a collective for one that has returned)
+  constexpr int32_t kFailedHeight = 0x7FFFFFF0;
+  if ( pass.status.load() != TMC2_OK ) {
+    if ( comm ) {
+      int32_t h = kFailedHeight;
+      (void)commMaxHeight( comm, &h );
+    }
+    return pass.done();
+  }
   // ---- the rendezvous: the packing chain (if any) and the common canvas size -------------------------------------------------
   int32_t tileW = c.minimumImageWidth, gofH = 0;
   if ( chained ) {
@@ -458,6 +494,10 @@ int encodeGof( tmc2_gof_comm* comm, tmc2_frame** frames, const int32_t* slotOf, 
   if ( comm ) {  // the one number the ranks of an all-intra GOF share
     const int rc = commMaxHeight( comm, &gofH );
     if ( rc != TMC2_OK ) return rc;
+    if ( gofH == kFailedHeight ) {
+      t_err = "tmc2_gof_encode_sharded: another rank's frames failed before the rendezvous (its own call says why)";
+      return TMC2_E_STATE;
+    }
   }
   int32_t W = 0, H = 0;
   {
@@ -479,8 +519,9 @@ int encodeGof( tmc2_gof_comm* comm, tmc2_frame** frames, const int32_t* slotOf, 
     if ( guess && guessW[size_t( i )] == W && guessH[size_t( i )] == H ) return;  // (already there)
     images( i, W, H );
   } );
-  if ( pass.status.load() != TMC2_OK || !comm ) return pass.done();
-  return commGatherRecords( comm, frames, count, recordSlots, gathered, gatheredCounts );
+  if ( !comm ) return pass.done();
+  const int failed = pass.done();  // (a pass that failed after the rendezvous still takes part in the exchange: see commGatherRecords)
+  return commGatherRecords( comm, frames, count, recordSlots, gathered, gatheredCounts, failed );
 }
 }  // namespace
 

@@ -162,7 +162,7 @@ class _Patch(C.Structure):
 
 def _sharded_rank(args):
     """One rank of a sharded GOF pass against the recorders (runs in a process of its own)."""
-    d, rank, world, frames_per_rank, heights, packing = args
+    d, rank, world, frames_per_rank, heights, packing, fail = args
     os.environ["TMC2_RCCL_LIBRARY"] = os.path.join(d, "libmockrccl.so")
     os.environ["MOCK_RCCL_DIR"] = d
     M = C.CDLL(os.path.join(d, "libtmc2hipmock.so"), mode=C.RTLD_GLOBAL)
@@ -177,7 +177,7 @@ def _sharded_rank(args):
         return {"rc": rc, "err": G.tmc2_gof_last_error().decode()}
     n = frames_per_rank
     ids = [rank + i * world for i in range(n)]                       # frame f of the GOF on rank f mod world
-    frames = [M.mock_frame(f, int(heights[f]), MIN_W, 0) for f in ids]
+    frames = [M.mock_frame(f, int(heights[f]), MIN_W, int(fail[1]) if fail and fail[0] == f else 0) for f in ids]
     handles = (C.c_void_p * n)(*frames)
     slot_of = (C.c_int32 * n)(*[i % 2 for i in range(n)])
     cfg = Config(7, 4, 11, 4, MIN_W, MIN_H, packing, 0)
@@ -213,13 +213,13 @@ def sharded_libs(tmp_path_factory):
     return d
 
 
-def _run_world(d, world, frames_per_rank, heights, packing=0):
+def _run_world(d, world, frames_per_rank, heights, packing=0, fail=None):
     import multiprocessing as mp
     for name in os.listdir(d):                                         # (files of an earlier world)
         if name.startswith(("log_", "p2p_", "ar_", "bcast_", "id")):
             os.unlink(os.path.join(d, name))
     with mp.get_context("spawn").Pool(world) as pool:
-        return pool.map(_sharded_rank, [(d, r, world, frames_per_rank, heights, packing) for r in range(world)])
+        return pool.map(_sharded_rank, [(d, r, world, frames_per_rank, heights, packing, fail) for r in range(world)])
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])
@@ -260,3 +260,21 @@ def test_sharded_gof_refuses_the_packing_chains(sharded_libs):
     for x in res:
         assert x["rc"] != 0 and "packing chains" in x["err"], x
         assert not [e for e in x["log"] if e[0] in (SEGMENT, WEIGHT)]
+
+
+@pytest.mark.parametrize("frame,call", [(0, WEIGHT), (3, SEGMENT), (1, GEOMETRY), (2, ATTRIBUTE)])
+def test_sharded_gof_a_failing_rank_does_not_leave_the_others_waiting(sharded_libs, frame, call):
+    """A call that fails on ONE rank (S0 on rank 0; a frame's segmentation before the rendezvous; a frame's images after it): every
+    rank still goes through the same collectives -- the failed rank with a value that says so (negative weights, a height no canvas
+    has, a negative record count) -- and every rank returns with an error instead of waiting in a receive for a rank that has left.
+    The rank that failed reports the library's message, the others that another rank failed."""
+    world, n = 2, 2
+    res = _run_world(sharded_libs, world, n, [64] * (world * n), fail=(frame, call))      # (returns at all: nobody hangs)
+    owner = frame % world
+    assert res[owner]["rc"] != 0 and "mock failure of call %d on frame %d" % (call, frame) in res[owner]["err"], res[owner]
+    assert res[0]["rc"] != 0                                           # the rank that gathers always knows
+    other = res[1 - owner]
+    if call in (WEIGHT, SEGMENT) or owner != 0:                        # before the rendezvous everybody learns it; after it, rank 0 does
+        assert other["rc"] != 0 and "rank" in other["err"] and "its own call says why" in other["err"], other
+    else:                                                              # (rank 0 failed after the rendezvous: rank 1 delivered its records)
+        assert other["rc"] == 0, other
