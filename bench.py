@@ -1091,14 +1091,23 @@ def main():
         # 128 threads) -- foreign code that must not be able to take the metric line with it (a full run died once with glibc's
         # "corrupted double-linked list" seconds into this leg; the path itself ran clean under MALLOC_CHECK_=3).
         import subprocess
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", "baseline-bounded" if a.cpu_baseline == 3 else "baseline",
-                                "--workload", a.workload,
+
+        def baseline_child(kind):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", kind, "--workload", a.workload,
                                 "--iterations", str(a.iterations), "--frames", str(a.frames), "--config", a.case_name],
-                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1800)
-            out["cpu_baseline"] = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        except Exception as e:
-            out["cpu_baseline"] = {"error": "the CPU baseline process failed: %r" % (e,)}
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+            lines = r.stdout.decode(errors="replace").strip().splitlines()
+            if r.returncode != 0 or not lines:
+                raise RuntimeError("exit code %d, stderr tail: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:].replace("\n", " | ")))
+            return json.loads(lines[-1])
+        try:
+            out["cpu_baseline"] = baseline_child("baseline-bounded" if a.cpu_baseline == 3 else "baseline")
+        except Exception as e:                                  # foreign code (the reference's libraries, 128 TBB threads): once more, bounded
+            first_error = repr(e)
+            try:
+                out["cpu_baseline"] = dict(baseline_child("baseline-bounded"), first_attempt_failed=first_error)
+            except Exception as e2:
+                out["cpu_baseline"] = {"error": "the CPU baseline process failed twice: %s; %r" % (first_error, e2)}
         for key in ("all_cores_value", "frame_processes_value"):
             if out["cpu_baseline"].get(key):
                 out["cpu_baseline"]["gpu_over_" + key[:-6]] = round(out["value"] / out["cpu_baseline"][key], 2)

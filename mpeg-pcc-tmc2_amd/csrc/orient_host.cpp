@@ -805,7 +805,11 @@ int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, 
         const OrientCompact   g = hc.view();
         std::vector<int8_t>   clusterSign( g.clusters + 1 );
         std::vector<uint32_t> component( g.clusters + 1 ), seeds, seedClusters;
+        const auto tg0 = std::chrono::steady_clock::now();
         okw       = orientCompactSigns( g, first, clusterSign.data(), component.data(), seeds, seedClusters );
+        if ( ctxOption( ctx, "ORIENT_TIMING" ) )
+          fprintf( stderr, "  the growth over the compact graph alone: %.2f ms (%u clusters, %u edges)\n",
+                   std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - tg0 ).count(), g.clusters, g.rec[g.clusters].off );
         seedCount = seeds.size();
         if ( okw ) {
           // the seed rule's tables: (point, cluster, parity) of the point before the seed and of its neighbours; their normals
