@@ -1425,6 +1425,7 @@ struct LvSeg {
 };
 
 constexpr int kLandBlock = 256;  // the landing pass: one record of the children's ranges per workgroup (measured: 1 024-thread workgroups quarter the records the decide pass folds -- 14 -> 7 us -- and cost the landing pass itself 18 -> 32 us)
+constexpr int kLandRounds = 2;  // ... of consecutive rounds of kLandBlock positions: their records are merged where they name the same segment
 struct LvPartial {
   uint32_t slot;  // left child's segment at the next level (kNone: this workgroup reported on its own / had nothing)
   uint32_t v[6];  // packed (mn x|y, mx x|y, mn z | ~mx z) of the left and of the right child
@@ -1530,7 +1531,7 @@ __global__ __launch_bounds__( kDecideThreads ) void lvDecideKernel( BuildArgs a,
     __syncthreads();
   }
   if ( level > 0 ) {
-    const uint32_t nPart = ( a.n + uint32_t( kLandBlock ) - 1u ) / uint32_t( kLandBlock );
+    const uint32_t nPart = ( a.n + uint32_t( kLandBlock * kLandRounds ) - 1u ) / uint32_t( kLandBlock * kLandRounds );
     for ( uint32_t base = 0; base < nPart; base += kDecideThreads ) {  // (uniform over the workgroup)
       const uint32_t t = base + threadIdx.x;
       LvPartial      pt;
@@ -1769,7 +1770,6 @@ __global__ __launch_bounds__( kBlock ) void lvSwapOneKernel( BuildArgs a, uint32
 __global__ __launch_bounds__( kLandBlock ) void lvSwapTwoKernel( BuildArgs a, uint32_t level ) {
   extern __shared__ uint32_t lvSums[];  // [tiles + 1]
   const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x;
   const int      lane  = threadIdx.x & 63;
   LvSeg*         cur  = ( level & 1 ) ? a.lvB : a.lvA;
   LvSeg*         next = ( level & 1 ) ? a.lvA : a.lvB;
@@ -1777,8 +1777,12 @@ __global__ __launch_bounds__( kLandBlock ) void lvSwapTwoKernel( BuildArgs a, ui
   const uint32_t nRound = ( n + uint32_t( kLandBlock ) - 1u ) & ~( uint32_t( kLandBlock ) - 1u );
   __shared__ uint32_t blockSeg;
   __shared__ uint32_t red[kLandBlock / 64][6];
+  __shared__ uint32_t accV[6], accSlot;  // what the rounds of this pass have found so far for the children of ONE segment
   const int wave = threadIdx.x >> 6;
-  for ( uint32_t i0 = blockIdx.x * blockDim.x; i0 < nRound; i0 += gsize ) {  // (uniform per workgroup: it reduces together)
+  constexpr uint32_t kChunk = uint32_t( kLandBlock ) * kLandRounds;  // a workgroup lands kLandRounds consecutive rounds and leaves one record
+  for ( uint32_t c0 = blockIdx.x * kChunk; c0 < nRound; c0 += gridDim.x * kChunk ) {
+  if ( threadIdx.x == 0 ) accSlot = kNone;  // (ordered before its first use by the barriers of the round)
+  for ( uint32_t i0 = c0; i0 < min( c0 + kChunk, nRound ); i0 += kLandBlock ) {  // (uniform per workgroup: it reduces together)
     const uint32_t i   = i0 + threadIdx.x;
     uint32_t       key = kNoKey;  // the child the element that ENDS at position i belongs to
     uint32_t       A = pk2( 0x7FFF, 0x7FFF ), B = pk2( -0x8000, -0x8000 ), C = pk2( 0x7FFF, 0x7FFF );      // ... that element
@@ -1868,26 +1872,37 @@ __global__ __launch_bounds__( kLandBlock ) void lvSwapTwoKernel( BuildArgs a, ui
         if ( lane == 0 )
           for ( int k = 0; k < 6; ++k ) red[wave][k] = v[k];
         __syncthreads();
-        if ( threadIdx.x == 0 ) {  // one record per workgroup and round, in position order: lvDecideKernel folds them
-          LvPartial pt;
-          pt.slot = slot, pt.unused = 0;
+        if ( threadIdx.x == 0 ) {  // merged into the pass' record (in position order: lvDecideKernel folds the records of all passes)
+          uint32_t x[6];
           for ( int k = 0; k < 6; ++k ) {
-            uint32_t x = red[0][k];
-            for ( int w = 1; w < kLandBlock / 64; ++w ) x = ( k % 3 ) == 1 ? pkMax( x, red[w][k] ) : pkMin( x, red[w][k] );
-            pt.v[k] = x;
+            x[k] = red[0][k];
+            for ( int w = 1; w < kLandBlock / 64; ++w ) x[k] = ( k % 3 ) == 1 ? pkMax( x[k], red[w][k] ) : pkMin( x[k], red[w][k] );
           }
-          a.partial[i0 / kLandBlock] = pt;
+          if ( accSlot != kNone && accSlot != slot ) {  // the earlier rounds sat in another segment: that one reports for itself
+            for ( int c = 0; c < 2; ++c )
+              lvReport( next + accSlot + c, pkLo( accV[3 * c] ), pkHi( accV[3 * c] ), pkLo( accV[3 * c + 2] ), pkLo( accV[3 * c + 1] ), pkHi( accV[3 * c + 1] ),
+                        ~pkHi( accV[3 * c + 2] ) );
+            accSlot = kNone;
+          }
+          for ( int k = 0; k < 6; ++k ) accV[k] = accSlot == kNone ? x[k] : ( ( k % 3 ) == 1 ? pkMax( accV[k], x[k] ) : pkMin( accV[k], x[k] ) );
+          accSlot = slot;
         }
-      } else if ( threadIdx.x == 0 ) {
-        a.partial[i0 / kLandBlock].slot = kNone;
       }
       __syncthreads();
       continue;
     }
-    if ( threadIdx.x == 0 ) a.partial[i0 / kLandBlock].slot = kNone;
     if ( moved ) lvReport( next + slot + 1u, pkLo( A2 ), pkHi( A2 ), pkLo( C2 ), pkLo( A2 ), pkHi( A2 ), pkLo( C2 ) );
     if ( waveSegMinMaxPacked( key, A, B, C, lane ) )
       lvReport( next + key, pkLo( A ), pkHi( A ), pkLo( C ), pkLo( B ), pkHi( B ), ~pkHi( C ) );
+  }
+  __syncthreads();
+  if ( threadIdx.x == 0 ) {
+    LvPartial pt;
+    pt.slot = accSlot, pt.unused = 0;
+    for ( int k = 0; k < 6; ++k ) pt.v[k] = accV[k];
+    a.partial[c0 / kChunk] = pt;
+  }
+  __syncthreads();
   }
 }
 
@@ -2315,7 +2330,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.splitMax     = pieces ? uint32_t( kPieceMax ) : uint32_t( kSplitMax );
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
-  const dim3 grdL( std::max<uint32_t>( 1u, ( n + kLandBlock - 1 ) / kLandBlock ) );
+  const dim3 grdL( std::max<uint32_t>( 1u, ( n + kLandBlock * kLandRounds - 1 ) / ( kLandBlock * kLandRounds ) ) );
   // round 5's level passes go with the pieces (TMC2_KD_LEVELS=r4: round 4's five launches per level, the cross-check); their
   // swap passes keep the tile totals in LDS
   const char*  levelsEnv = ctxOption( ctx, "KD_LEVELS" );
@@ -2328,7 +2343,7 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   if ( newLevels ) {
     TMC2_TRY( d_lv.alloc( 2 * maxLv ) );
     TMC2_TRY( d_list.alloc( size_t( tiles ) * kScanTile ) );
-    TMC2_TRY( d_partial.alloc( size_t( n ) / kLandBlock + 2 ) );
+    TMC2_TRY( d_partial.alloc( size_t( n ) / ( kLandBlock * kLandRounds ) + 2 ) );
     a.lvA = d_lv.p, a.lvB = d_lv.p + maxLv, a.list = d_list.p, a.partial = d_partial.p;
     hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 128 ), 0, s, a );
     hipLaunchKernelGGL( lvInitKernel, dim3( std::min<uint32_t>( grdE.x, 1024u ) ), blk, 0, s, a );  // (each workgroup reports the root's range once)

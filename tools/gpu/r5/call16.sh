@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 16: landing pass in 1 024-thread workgroups (a quarter of the records for the decide pass), init from <= 1 024 workgroups
+# round 5, call 16 (run twice): landing pass in 1 024-thread workgroups (dropped); then two consecutive 256-position rounds per workgroup merged into one record
 export TMPDIR=/tmp; mkdir -p gpurun_out; O=$(pwd)/gpurun_out
 (timeout -k 10 600 python -m pytest tests/test_gpu_segmenter.py tests/test_gpu_fuzz.py -m gpu -x -q -k "kdtree or fuzz" 2>&1 | tail -15) > $O/r05c16_kd_tests.log 2>&1
 tail -2 $O/r05c16_kd_tests.log
