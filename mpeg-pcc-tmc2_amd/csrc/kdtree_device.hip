@@ -116,7 +116,8 @@ struct BuildArgs {
   uint32_t    retireMax, splitMax;  // round 4's tiers: kRetire / kSplitMax; pieceKernel: kPieceMax for all three thresholds
   struct LvSeg *lvA, *lvB;          // round 5's level passes: the segments of a level (by level parity)
   uint16_t*   list;                 // [n rounded up to whole tiles] positions not of a sweep's class, compacted per tile
-  struct LvPartial* partial;        // [n / kBlock + 1] what a workgroup of the landing pass found for the two children of its segment
+  struct LvPartial* partial;        // [n / (kLandBlock * kLandRounds) + 1] what a workgroup of the landing pass found for the two children of its segment
+  uint32_t    decideRng;            // segments of a level whose ranges the decide pass folds in LDS (kDecideRng; 0: option KD_DECIDE=global, the path of larger levels)
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
   uint32_t*   ticket;       // "last block done" counter of the prefix sums
 };
@@ -1525,7 +1526,7 @@ __global__ __launch_bounds__( kDecideThreads ) void lvDecideKernel( BuildArgs a,
   // same twelve words queue up for ~ 100 us near the root, and so do a few hundred atomics of this one workgroup (they are
   // carried out past the L2, one after the other): segmented wavefront reductions, then LDS atomics into a table of the
   // level's segments; only a level of more than kDecideRng segments goes through global memory.
-  const bool inLds = level > 0 && count <= uint32_t( kDecideRng );
+  const bool inLds = level > 0 && count <= a.decideRng;
   if ( inLds ) {
     for ( uint32_t t = threadIdx.x; t < count * 6u; t += kDecideThreads ) sRng[t / 6u][t % 6u] = ( t % 6u ) < 3u ? 0x7FFFFFFF : int32_t( 0x80000000 );
     __syncthreads();
@@ -2345,11 +2346,13 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
     TMC2_TRY( d_list.alloc( size_t( tiles ) * kScanTile ) );
     TMC2_TRY( d_partial.alloc( size_t( n ) / ( kLandBlock * kLandRounds ) + 2 ) );
     a.lvA = d_lv.p, a.lvB = d_lv.p + maxLv, a.list = d_list.p, a.partial = d_partial.p;
+    const char* decideOpt = ctxOption( ctx, "KD_DECIDE" );  // (test hook: "global" = the fold of a level of more than kDecideRng segments)
+    a.decideRng = decideOpt && decideOpt[0] == 'g' ? 0u : uint32_t( kDecideRng );
     hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 128 ), 0, s, a );
     hipLaunchKernelGGL( lvInitKernel, dim3( std::min<uint32_t>( grdE.x, 1024u ) ), blk, 0, s, a );  // (each workgroup reports the root's range once)
     hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, 0u );
   } else {
-    a.lvA = a.lvB = nullptr, a.list = nullptr, a.partial = nullptr;
+    a.lvA = a.lvB = nullptr, a.list = nullptr, a.partial = nullptr, a.decideRng = 0;
     TMC2_HIP( hipMemsetAsync( d_small.p, 0, ( kMaxLevels + 16 ) * 4, s ) );
     hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
   }

@@ -121,6 +121,24 @@ def test_gpu_kdtree_order_matches_reference_build(gpu_ctx, oracle, ctx_options, 
         assert np.array_equal(fr.kdtree_search(q, k), oracle.knn(xyz, q, k))
 
 
+@pytest.mark.parametrize("option,value,case", [("KD_FORM", "tiers", "dense60000"), ("KD_FORM", "tiers", "n40000"), ("KD_LEVELS", "r4", "n40000"),
+                                               ("KD_LEVELS", "r4", "dense60000"), ("KD_DECIDE", "global", "n40000"),
+                                               ("KD_DECIDE", "global", "dense120000"), ("KD_PIECE_PER", "8", "root30000"),
+                                               ("KD_HUGEMAX", "4096", "dense120000")])
+def test_gpu_kdtree_cross_check_forms(gpu_ctx, ctx_options, option, value, case):
+    """The forms of the device builder that are not the default -- round 4's lower tiers, round 4's level passes under the pieces,
+    the decide pass folding through global memory (what a level of more than 2 000 segments takes), eight positions per thread in
+    the piece kernel, no workgroup-per-segment tier -- leave the host builder's permutation too."""
+    rng = np.random.default_rng(11)
+    n = int("".join(ch for ch in case if ch.isdigit()))
+    xyz = rng.integers(0, 24 if case.startswith("dense") else 1024, (n, 3)).astype(np.int16)
+    ctx_options.setenv(option, value)
+    fr = gpu_ctx.frame(xyz)
+    perm, depth = fr.kdtree_order()
+    hperm, _, hdepth = T.host_kdtree_build(xyz)
+    assert np.array_equal(perm, hperm) and depth == hdepth
+
+
 def test_gpu_full_size_properties(gpu_ctx):
     """BASELINE-size frame (~0.8 M points): size-independent properties instead of the (slow) oracle."""
     xyz, rgb = synth_cloud("longdress_vox10")
