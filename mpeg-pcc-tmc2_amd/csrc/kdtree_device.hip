@@ -117,6 +117,7 @@ struct BuildArgs {
   struct LvSeg *lvA, *lvB;          // round 5's level passes: the segments of a level (by level parity)
   uint16_t*   list;                 // [n rounded up to whole tiles] positions not of a sweep's class, compacted per tile
   struct LvPartial* partial;        // [n / (kLandBlock * kLandRounds) + 1] what a workgroup of the landing pass found for the two children of its segment
+  unsigned long long* pieceProfile;  // option KD_PIECE_PROFILE: wall-clock ticks (10 ns) thread 0 of every workgroup spent between the barriers of a depth
   uint32_t    decideRng;            // segments of a level whose ranges the decide pass folds in LDS (kDecideRng; 0: option KD_DECIDE=global, the path of larger levels)
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
   uint32_t*   ticket;       // "last block done" counter of the prefix sums
@@ -1909,8 +1910,14 @@ __global__ __launch_bounds__( kLandBlock ) void lvSwapTwoKernel( BuildArgs a, ui
 
 constexpr size_t kPieceLdsBytes = size_t( kPieceMax ) * ( sizeof( Pt ) + 4 + 2 + 2 + 2 ) + 16 + 2 * size_t( kPieceRecs ) * sizeof( PieceRec );
 
-template <int K>  // positions per thread: kPieceMax / K threads
+template <int K, bool PROFILE = false>  // positions per thread: kPieceMax / K threads
 __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
+  unsigned long long profLast = 0, prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PIECE_MARK( k )                                        \
+  if ( PROFILE && threadIdx.x == 0 ) {                         \
+    const unsigned long long now_ = wall_clock64();            \
+    prof[k] += now_ - profLast, profLast = now_;               \
+  }
   constexpr int THREADS = kPieceMax / K, WAVES = THREADS / 64;
   static_assert( K == 4 || K == 8, "pieceKernel: four or eight positions per thread" );
   extern __shared__ __align__( 16 ) unsigned char pieceLds[];
@@ -1974,11 +1981,13 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         a.rootBox[d] = recs[0].mn[d], a.rootBox[3 + d] = recs[0].mx[d];
       }
     }
+    if ( PROFILE && threadIdx.x == 0 ) profLast = wall_clock64();
     uint32_t deepest  = 0;  // (level of the deepest leaf this thread has written) + 1
     uint32_t prevBase = 0, prevCount = 0;
     int      cur      = 0;
     for ( uint32_t depth = 0;; ++depth ) {
       pieceBarrier();  // (the records of this depth and their ranges are complete; so is sCount[cur])
+      PIECE_MARK( 0 )  // landing of the previous depth (or the piece's load)
       const uint32_t nc = sCount[cur];
       PieceRec*      R  = recs + cur * kPieceRecs;
       PieceRec*      RN = recs + ( cur ^ 1 ) * kPieceRecs;
@@ -2013,17 +2022,22 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         q->dim = uint8_t( dim ), q->unused0 = 0, q->cut = int16_t( min( max( ( l + h ) / 2, lowest ), highest ) );
       }
       pieceBarrier();
-      // ---- what this thread's positions belong to (kept in registers for the whole depth)
+      PIECE_MARK( 1 )  // node records of the previous depth + split rules
+      // ---- what this thread's positions belong to (kept in registers for the whole depth).  Settled subtrees are contiguous, so
+      //      from the middle depths on whole wavefronts hold nothing but settled positions: they keep the barriers and the two prefix
+      //      sums company and skip the rest (waveLive).
       uint32_t rec[K], be[K], dc[K];
+      bool     waveLive = true;
       {
         uint16_t raw[K];
         if ( K == 4 )
           *reinterpret_cast<uint2*>( raw ) = *reinterpret_cast<const uint2*>( segOf + p0 );
         else
           *reinterpret_cast<uint4*>( raw ) = *reinterpret_cast<const uint4*>( segOf + p0 );
-        bool same = true;
+        bool same = true, live = false;
 #pragma unroll
-        for ( int k = 0; k < K; ++k ) rec[k] = raw[k], same = same && raw[k] == raw[0];
+        for ( int k = 0; k < K; ++k ) rec[k] = raw[k], same = same && raw[k] == raw[0], live = live || raw[k] != kNoRec;
+        waveLive = __ballot( live ) != 0ull;
         if ( same ) {
           PieceHot0 h{0, 0};
           if ( rec[0] != kNoRec ) h = *reinterpret_cast<const PieceHot0*>( R + rec[0] );
@@ -2040,7 +2054,7 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
       }
       // ---- first sweep: class ">= cut", prefix sum
       uint32_t f1 = 0;  // bit k: position p0 + k is of the class
-      {
+      if ( waveLive ) {
         Pt x[K];
 #pragma unroll
         for ( int k = 0; k < K; k += 2 ) *reinterpret_cast<uint4*>( &x[k] ) = *reinterpret_cast<const uint4*>( P + p0 + k );
@@ -2065,12 +2079,13 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         if ( tid == THREADS - 1 ) pre[kPieceMax] = uint16_t( at );
       }
       pieceBarrier();
+      PIECE_MARK( 2)  // first flags + prefix sum
       // ---- the misplaced right-hand elements ("< cut" beyond the edge) publish their position by rank from the right
       uint32_t edge1[K], rb1[K];
 #pragma unroll
       for ( int k = 0; k < K; ++k ) {
         edge1[k] = rb1[k] = 0;
-        if ( rec[k] == kNoRec ) continue;
+        if ( !waveLive || rec[k] == kNoRec ) continue;
         if ( k > 0 && rec[k] == rec[k - 1] ) {
           edge1[k] = edge1[k - 1], rb1[k] = rb1[k - 1];
         } else {
@@ -2082,11 +2097,12 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         if ( p == b ) *reinterpret_cast<uint32_t*>( &R[rec[k]].edge1 ) = edge1[k] | ( ( rb1[k] & 0xFFFFu ) << 16 );
       }
       pieceBarrier();
+      PIECE_MARK( 3)  // first publish
       // ---- ... and the misplaced left-hand elements (">= cut" before the edge) swap with the entry of their rank from the left
 #pragma unroll
       for ( int k = 0; k < K; ++k ) {
         const uint32_t p = p0 + k;
-        if ( rec[k] != kNoRec && p < edge1[k] && ( ( f1 >> k ) & 1u ) ) {
+        if ( waveLive && rec[k] != kNoRec && p < edge1[k] && ( ( f1 >> k ) & 1u ) ) {
           const uint32_t j  = lst[( be[k] & 0xFFFFu ) + ( preA[k] - ( rb1[k] & 0xFFFFu ) )];
           const Pt       px = P[p], pj = P[j];
           const uint32_t ip = perm[p], ij = perm[j];
@@ -2094,9 +2110,10 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         }
       }
       pieceBarrier();
+      PIECE_MARK( 4)  // first swaps
       // ---- second sweep on [edge1, end): class "> cut", prefix sum
       uint32_t f2 = 0;
-      {
+      if ( waveLive ) {
         Pt x[K];
 #pragma unroll
         for ( int k = 0; k < K; k += 2 ) *reinterpret_cast<uint4*>( &x[k] ) = *reinterpret_cast<const uint4*>( P + p0 + k );
@@ -2120,6 +2137,7 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         if ( tid == THREADS - 1 ) pre[kPieceMax] = uint16_t( at );
       }
       pieceBarrier();
+      PIECE_MARK( 5)  // second flags + prefix sum
       // ---- per record: the second sweep's edge, the balance rule, the children (records of the next depth, or leaves);
       //      per element: the misplaced right-hand elements of the second sweep ("<= cut" beyond its edge) publish
       const uint32_t base = sNodeBase;
@@ -2168,7 +2186,7 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
 #pragma unroll
       for ( int k = 0; k < K; ++k ) {
         edge2[k] = rb2[k] = 0;
-        if ( rec[k] == kNoRec ) continue;
+        if ( !waveLive || rec[k] == kNoRec ) continue;
         const uint32_t e = be[k] >> 16, e1 = edge1[k];
         if ( k > 0 && rec[k] == rec[k - 1] ) {
           edge2[k] = edge2[k - 1], rb2[k] = rb2[k - 1];
@@ -2180,6 +2198,7 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         if ( p >= edge2[k] && !( ( f2 >> k ) & 1u ) ) lst[e1 + ( ( e - p - 1u ) - ( ( rb2[k] >> 16 ) - preA[k + 1] ) )] = uint16_t( p );
       }
       pieceBarrier();
+      PIECE_MARK( 6)  // children + second publish
       // (the records of the next depth are counted: their children's node ids, a few passes ahead of their use)
       prevBase = base, prevCount = nc;
       if ( tid == 0 && sCount[cur ^ 1] ) idPending = atomicAdd( a.nodeCount, 2u * sCount[cur ^ 1] );
@@ -2187,7 +2206,7 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
 #pragma unroll
       for ( int k = 0; k < K; ++k ) {
         const uint32_t p = p0 + k;
-        if ( rec[k] != kNoRec && p >= edge1[k] && p < edge2[k] && ( ( f2 >> k ) & 1u ) ) {
+        if ( waveLive && rec[k] != kNoRec && p >= edge1[k] && p < edge2[k] && ( ( f2 >> k ) & 1u ) ) {
           const uint32_t j  = lst[edge1[k] + ( preA[k] - ( rb2[k] & 0xFFFFu ) )];
           const Pt       px = P[p], pj = P[j];
           const uint32_t ip = perm[p], ij = perm[j];
@@ -2195,9 +2214,10 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
         }
       }
       pieceBarrier();
+      PIECE_MARK( 7)  // second swaps
       // ---- the elements have landed: tight ranges of the children (one segmented reduction per wavefront where a thread's
       //      positions share a child, LDS atomics where they do not), divlow / divhigh of the parent, record of a position
-      {
+      if ( waveLive ) {
         uint32_t key[K], mc[K], c1[K];
         bool     same = true;
 #pragma unroll
@@ -2258,6 +2278,10 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
       cur ^= 1;
     }
     if ( deepest ) atomicMax( &sDepth, deepest );
+    if ( PROFILE && threadIdx.x == 0 ) {
+      for ( int k = 0; k < 8; ++k ) atomicAdd( a.pieceProfile + k, prof[k] ), prof[k] = 0;
+      atomicAdd( a.pieceProfile + 8, 1ull );
+    }
     pieceBarrier();
     for ( uint32_t i = tid; i < cnt; i += THREADS ) {
       a.P[seg.begin + i]    = P[i];
@@ -2409,8 +2433,26 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
     const uint32_t retired = out[kMaxLevels + 3] + hugeSegs * ( 2u * hugeMax / uint32_t( kPieceMax ) );
     if ( retired ) {
       const char* perEnv = ctxOption( ctx, "KD_PIECE_PER" );  // positions per thread: 4 (1 024 threads) or 8 (512)
+      if ( ctxOption( ctx, "KD_PIECE_PROFILE" ) ) {  // diagnostic: where a depth's time goes (thread 0 of every workgroup, between barriers)
+        DevBuf<unsigned long long> d_prof;
+        TMC2_TRY( d_prof.alloc( 16 ) );
+        TMC2_HIP( hipMemsetAsync( d_prof.p, 0, 16 * 8, s ) );
+        a.pieceProfile = d_prof.p;
+        TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<4, true> ), kPieceLdsBytes, ctx->device, 256 ) );
+        hipLaunchKernelGGL( ( pieceKernel<4, true> ), dim3( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) ), dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
+        unsigned long long h[16];
+        TMC2_HIP( hipMemcpyAsync( h, d_prof.p, sizeof( h ), hipMemcpyDeviceToHost, s ) );
+        TMC2_HIP( hipStreamSynchronize( s ) );
+        static const char* what[8] = {"landing of the previous depth", "node records + split rules", "first flags + prefix sum", "first publish",
+                                      "first swaps", "second flags + prefix sum", "children + second publish", "second swaps"};
+        fprintf( stderr, "pieceKernel: %llu pieces, us per piece between the barriers of its depths (thread 0 of each workgroup):", h[8] );
+        for ( int k = 0; k < 8; ++k ) fprintf( stderr, " %s %.1f |", what[k], 0.01 * double( h[k] ) / double( std::max<unsigned long long>( h[8], 1 ) ) );
+        fprintf( stderr, "\n" );
+      }
       const dim3  grid( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) );
-      if ( perEnv && atoi( perEnv ) == 8 ) {
+      if ( ctxOption( ctx, "KD_PIECE_PROFILE" ) ) {
+        // (done above)
+      } else if ( perEnv && atoi( perEnv ) == 8 ) {
         TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<8> ), kPieceLdsBytes, ctx->device, 256 ) );
         hipLaunchKernelGGL( pieceKernel<8>, grid, dim3( kPieceMax / 8 ), kPieceLdsBytes, s, a );
       } else {
