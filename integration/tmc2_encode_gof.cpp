@@ -248,6 +248,14 @@ int main( int argc, char** argv ) {
     fr.xyz.resize( 3 * fr.n ), fr.rgb.resize( 3 * fr.n );
     CHECK( tmc2_ply_read( path, fr.xyz.data(), fr.rgb.data(), nullptr, fr.n, 4, &fr.n ) );
   } );
+  {  // the sequence's bounds are known now: every context reserves its worst case before the first frame arrives (no hipMalloc --
+     // a device-wide synchronisation under all frames in flight -- inside the GOFs; a context that cannot is left to grow on demand)
+    uint64_t most = 0;
+    for ( const Frame& fr : gof ) most = std::max<uint64_t>( most, fr.n );
+    for ( tmc2_ctx* c : ctx )
+      if ( tmc2_ctx_reserve( c, most, o.voxel, o.bits + 1, o.minW, std::max( o.minW, o.minH ) ) != TMC2_OK )
+        std::fprintf( stderr, "tmc2_encode_gof: no reservation (%s): the pool grows on demand\n", tmc2_last_error() );
+  }
   for ( int i = 0; i < o.frames; ++i )
     CHECK( tmc2_frame_create( ctx[size_t( slotOf( i ) )], gof[size_t( i )].xyz.data(), gof[size_t( i )].rgb.data(), gof[size_t( i )].n,
                               &gof[size_t( i )].f ) );

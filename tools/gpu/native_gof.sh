@@ -2,7 +2,7 @@
 # the native C++ front end (integration/tmc2_encode_gof) timing the path on the 32-frame longdress-like GOF: one device shard with
 # 16 workers, and two shards on the one GPU with 8 workers each
 mkdir -p gpurun_out; export TMPDIR=/tmp
-O=$(pwd)/gpurun_out/r04_native_front_end.txt; : > $O
+O=$(pwd)/gpurun_out/${1:-r05}_native_front_end.txt; : > $O
 make -C integration > /dev/null 2>&1
 D=/tmp/gof_ply; mkdir -p $D
 python - <<'PY'
