@@ -19,10 +19,15 @@ GOF (reconstruct + post-reconstruction tail + D1/D2 metric per frame), timed and
 
 Printed JSON (one line, rank 0): metric/value/unit as BASELINE.json, plus
   roofline     -- the dominant GPU step of the timed region, chosen over ALL timed stages by GPU time with the GPU to
-                  itself: algorithmic bytes per launch (SURVEY.md 8d formulas, with the V and L of this very run) / mean
-                  launch duration (HIP events on the launching stream, inside the timed region) against 8 TB/s HBM;
+                  itself (SURVEY.md 8d's S1 + S2 + S6 row -- the source tree build, the 16-NN lists and the normals, 94 N
+                  bytes -- is one of the candidates, "tree_knn_normals"): algorithmic bytes per launch (SURVEY.md 8d
+                  formulas, with the V and L of this very run) / mean launch duration (HIP events on the launching
+                  stream, inside the timed region) against 8 TB/s HBM;
                   "path" = the contract figure of the whole path, B_alg per frame x frames/s / peak; "stages" = achieved
                   GB/s of every stage whose algorithmic bytes are defined
+  first_gof_ms / untimed_pass_ms / pool / orientation -- the first pass of this process over the GOF as it is (no priming
+                  passes; the contexts reserve their worst case up front: pool.hipmalloc_calls), S3's ladder steps and
+                  fallbacks per GOF
   cpu_baseline -- the unmodified reference (oracle/_ref, kind "reference") or our restatement (kind "port") on the host
                   cores of this box: "value" = one frame, one thread (what MPEG's anchors use); "all_cores_value" = a GOF
                   through the reference's own TBB path (ENABLE_TBB build with its vendored TBB: frames in parallel, points
