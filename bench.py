@@ -83,9 +83,9 @@ def parse():
     ap.add_argument("--host", default="auto", choices=["auto", "native", "python"],
                     help="who drives the C-ABI inside the timed region: native = one tmc2_gof_encode call per GOF (libtmc2gof.so: C++ "
                          "threads, include/tmc2gof.h; with several ranks tmc2_gof_encode_sharded: the all-intra GOF's collectives are "
-                         "RCCL calls from C++), python = GofEncoder's worker threads.  auto: native on one GPU, python with several "
-                         "ranks (the collectives of the sharded GOF are torch.distributed's there; the packing chains of the "
-                         "low-delay / random-access conditions need that route)")
+                         "RCCL calls from C++), python = GofEncoder's worker threads.  auto: native wherever libtmc2gof.so loads -- one GPU or several ranks under RCCL, every packing condition (the "
+                         "low-delay / random-access chains run on rank 0 over the gathered records); python only under --dist-backend "
+                         "gloo (ranks sharing a GPU cannot form an RCCL world)")
     ap.add_argument("--pin", type=int, default=1, help="0: plain host buffers instead of page-locked ones for the canvases (for runs "
                     "under a sanitizer runtime, where torch's pinned allocator does not come up; slower copies)")
     ap.add_argument("--gather", default="host", choices=["host", "rccl"],
@@ -630,9 +630,6 @@ def main():
         return
     if a.cpu_child:
         return cpu_child(a.cpu_child, a.workload, a.iterations, a.case)
-    if a.host == "native" and max(a.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 and a.packing != "all-intra":
-        raise SystemExit("bench.py: --host native with several ranks runs the all-intra GOF (tmc2_gof_encode_sharded: RCCL from C++); the "
-                         "%s packing chain runs over ALL frames in order -- that sharded GOF meets over torch.distributed (--host python)" % a.packing)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_launcher(a)                              # (does not return)
     rank = int(os.environ.get("RANK", "0"))
@@ -734,31 +731,46 @@ def main():
                                    pinned((2, 3, H, W), np.uint8)) for _ in frames]
         return host_cache[(W, H)]
 
-    native = a.host == "native" or (a.host == "auto" and world == 1)
+    # auto: the C++ host (north_star: "host code stays C++ ... RCCL only for the final gather") whenever its libraries load -- one GPU
+    # or several; with several ranks under RCCL that needs librccl.so (tmc2_gof_comm_create says so), under --dist-backend gloo (ranks
+    # sharing a GPU: no RCCL world to make) the ranks meet over torch.distributed as before
+    native = a.host == "native" or (a.host == "auto" and (world == 1 or a.dist_backend == "nccl"))
     comm = None
     if native:
         from tmc2_amd import native_gof
         native_gof.load_library()                           # (fails here, loudly, if it was not built)
         if world > 1:                                       # the ranks of the sharded GOF meet in C++: RCCL on this rank's stream
-            comm = native_gof.Comm(enc.ctxs[0], rank, world)
+            # the communicator's id travels through a file only this job knows: a name with a nonce from rank 0, agreed over the
+            # launcher's process group (include/tmc2gof.h: the default name is per user and port, a caller with a launcher does better)
+            import uuid
+            box = ["/dev/shm/tmc2_gof_id_%d_%s" % (os.getuid(), uuid.uuid4().hex)]
+            dist.broadcast_object_list(box, src=0)
+            comm = native_gof.Comm(enc.ctxs[0], rank, world, rendezvous=box[0])
     capacity = [c["min_w"], c["min_h"]]
+    resumed_passes = [0]
 
     def native_step():
-        # reset, S0, S1-S9 + packing, the rendezvous, S12-S22 and the copies into page-locked host memory: one call into C++
+        # reset, S0, S1-S9 + packing, the rendezvous, S12-S22 and the copies into page-locked host memory: one call into C++.
+        # A GOF that outgrows the buffers (longdress: 1280 x 1344 on a 1280 x 1280 minimum canvas) is refused at the rendezvous with
+        # the size it needs; the pass is RESUMED there with larger buffers (tmc2_gof_encode_resume) -- rounds 4-5 called the whole
+        # pass again, which made the first pass of the process twice as long as the others (profiles/r06_first_pass.txt)
+        resume = False
         while True:
             try:
+                slot_of = [i % workers for i in range(len(frames))]
                 if comm is not None:                        # this rank's frames; weights, canvas height and records cross over RCCL
-                    W_, H_, recs = native_gof.encode_sharded(comm, frames, [i % workers for i in range(len(frames))], workers, a.iterations,
-                                                             c["vox_dim"], c["bits3d"], P, c["min_w"], c["min_h"], host_out(*capacity),
-                                                             capacity, record_slots=RECORD_SLOTS)
+                    W_, H_, recs = native_gof.encode_sharded(comm, frames, slot_of, workers, a.iterations, c["vox_dim"], c["bits3d"], P,
+                                                             c["min_w"], c["min_h"], host_out(*capacity), capacity,
+                                                             record_slots=RECORD_SLOTS, packing=a.packing, resume=resume)
                     if recs is not None:
                         gather_cache["records"] = recs
                     return W_, H_
-                return native_gof.encode(frames, [i % workers for i in range(len(frames))], workers, a.iterations, c["vox_dim"],
-                                         c["bits3d"], P, c["min_w"], c["min_h"], a.packing, host_out(*capacity), capacity,
-                                         guess_canvas=a.rendezvous == "one")
-            except native_gof.CanvasTooSmall as e:          # (first pass of a GOF that outgrows the minimum canvas; the same on every rank)
+                return native_gof.encode(frames, slot_of, workers, a.iterations, c["vox_dim"], c["bits3d"], P, c["min_w"], c["min_h"],
+                                         a.packing, host_out(*capacity), capacity, guess_canvas=a.rendezvous == "one", resume=resume)
+            except native_gof.CanvasTooSmall as e:          # (the same on every rank: the size is the GOF's)
                 capacity[:] = [max(capacity[0], e.size[0]), max(capacity[1], e.size[1])]
+                resume = a.rendezvous != "one"              # (a guessed canvas has no second half to resume: the whole pass again)
+                resumed_passes[0] += 1
 
     def step():
         if native:
@@ -937,7 +949,7 @@ def main():
         "metric": "encoder patch+image-gen frames/sec, %s %d-frame GOF" % (a.workload, a.frames),
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "priming_passes": max(0, a.prime), "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
-        "first_gof_ms": pass_ms[0] if pass_ms else None, "untimed_pass_ms": pass_ms, "pool": dict(enc.pool_stats(), reserved=bool(a.reserve) and reserve_note is None, note=reserve_note),
+        "first_gof_ms": pass_ms[0] if pass_ms else None, "untimed_pass_ms": pass_ms, "passes_resumed_with_larger_buffers": resumed_passes[0], "pool": dict(enc.pool_stats(), reserved=bool(a.reserve) and reserve_note is None, note=reserve_note),
         "first_gof_excess_ms_per_frame": dict(sorted(((k, round((first_stage_ms.get(k, 0.0) - v / a.steps) / max(1, len(frames)), 3))
                                                       for k, v in ms.items() if first_stage_ms.get(k, 0.0) - v / a.steps > 0.2 * len(frames)
                                                       and not k.startswith(("refine_row_entries", "refine_voxels", "refine_sweeps_executed"))),   # (counters, not times)

@@ -37,29 +37,60 @@ typedef struct tmc2_gof_config {
  * the buffers then -- EXCEPT with config->guessCanvas: there a frame whose own guess fitted has copied its canvases, laid out for
  * the guessed size, before the GOF's size was known; after TMC2_E_INVALID the buffers' contents are undefined.
  * Returns TMC2_OK or the first failing status; tmc2_gof_last_error() holds the message of the calling thread's last call (of
- * whichever of its slot threads failed first).  No exception leaves the call (TMC2_E_STATE + message instead).        */
+ * whichever of its slot threads failed first).  No exception leaves the call (TMC2_E_STATE + message instead).
+ * The slot threads are the library's (parked between passes, leased per pass: two passes of two caller threads never share one). */
 int tmc2_gof_encode( tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots, const tmc2_gof_config* config,
                      uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch, uint16_t** geometryD0, uint16_t** geometryD1,
                      uint8_t** attribute, int32_t capacityWidth, int32_t capacityHeight, int32_t* width, int32_t* height );
+/* After tmc2_gof_encode returned TMC2_E_INVALID with *width > capacityWidth or *height > capacityHeight (the reference learns
+ * the canvas of a GOF the same way, after the packing: resizeGeometryVideo, PCCEncoder.cpp:5546-5591): the SECOND HALF of that
+ * pass with the buffers the GOF needs -- the canvas size from the tiles the packers left in the frames, then S12-S22 and the
+ * copies.  S0-S10 are not repeated (round 6: repeating them was what made the first pass of a process over a GOF that
+ * outgrows the minimum canvas twice as long as the later ones).  TMC2_E_STATE if a frame is not packed (it was reset, or the
+ * pass before did not get that far).  Not for config->guessCanvas.                                                     */
+int tmc2_gof_encode_resume( tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots, const tmc2_gof_config* config,
+                            uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch, uint16_t** geometryD0,
+                            uint16_t** geometryD1, uint8_t** attribute, int32_t capacityWidth, int32_t capacityHeight, int32_t* width,
+                            int32_t* height );
 const char* tmc2_gof_last_error( void );
 
 /* ---- a GOF sharded over several processes, one per GPU (BASELINE configs 3-4: frame f of the GOF on rank f mod worldSize) -------
  * The reference runs the frames of a GOF through one tbb::parallel_for in one address space (PCCEncoder.cpp:4729-4750) and takes
- * the common canvas from all of them (:5546-5591).  Across processes the same three things cross the node, as RCCL collectives on
- * the stream of the rank's context (librccl.so is loaded when a communicator is made; TMC2_E_UNSUPPORTED without it):
+ * the common canvas from all of them (:5546-5591).  Across processes the same things cross the node, as RCCL collectives on the
+ * stream of the rank's context (librccl.so is loaded when a communicator is made; TMC2_E_UNSUPPORTED without it):
  *   the axis weights of frame 0   24 bytes, ncclBroadcast from rank 0 (calculateWeightNormal looks at the first frame only);
- *   the canvas height             ncclAllReduce( max ) of one int32;
- *   the packed patch records      one grouped ncclSend / ncclRecv per pass to rank 0 (the bitstream's side information,
- *                                 ~ 100 bytes a patch); the CANVASES do not cross xGMI: every rank copies its frames' canvases
- *                                 into the (page-locked, shared) host buffers it was given, over its own PCIe link.
+ *   all-intra (config->packing 0):
+ *     the canvas height           ncclAllReduce( max ) of one int32;
+ *     the packed patch records    one grouped ncclSend / ncclRecv per pass to rank 0 (the bitstream's side information,
+ *                                 ~ 100 bytes a patch);
+ *   low-delay / random access (config->packing 1 / 2: spatialConsistencyPackFlexible PCCEncoder.cpp:1183-1412,
+ *   performDataAdaptiveGPAMethod :6821-6971 -- chains over ALL frames of the GOF in frame order, on patch records):
+ *     the largest frame           ncclAllReduce( max ) of three int32 (sizes the blocks below);
+ *     records + occupancy pools   one grouped ncclSend / ncclRecv to rank 0, which runs PCCEncoder::placeSegments over the GOF's
+ *                                 records (tmc2_host_place_segments: host, microseconds per frame);
+ *     the canvas of the GOF       32 bytes, ncclBroadcast from rank 0;
+ *     the packed lists            one grouped ncclSend / ncclRecv from rank 0 to the ranks that hold the frames
+ *                                 (tmc2_frame_set_packing); rank 0 keeps every frame's records: no gather at the end, one
+ *                                 ncclAllReduce( max ) of the pass' status instead.
+ * The CANVASES never cross xGMI: every rank copies its frames' canvases into the (page-locked, shared) host buffers it was
+ * given, over its own PCIe link.
  * tmc2_gof_comm_create: ctx = a context on this rank's device; rendezvous = the file rank 0 publishes the communicator's 128-byte
- * id in and the other ranks read it from (NULL: /dev/shm/tmc2_gof_id_$MASTER_PORT -- one node); it ends with a checked
- * all-reduce, so a rank that cannot reach the others fails here.  worldSize 1 is valid (the collectives still run).
- * tmc2_gof_encode_sharded: tmc2_gof_encode over THIS rank's frames (every rank passes equally many), all-intra packing only --
- * the low-delay / random-access chains need every frame's records on one rank, in frame order (TMC2_E_UNSUPPORTED; the caller
- * gathers them, runs tmc2_host_place_segments and hands the lists back with tmc2_frame_set_packing).  Rank 0 receives the records:
- * gathered[(r * count + i) * recordSlots + k] = patch k (list order) of frame i of rank r, gatheredCounts[r * count + i] their
- * number (either may be NULL; ignored on the other ranks); a frame with more than recordSlots patches fails the call.       */
+ * id in and the other ranks read it from (one node).  NULL: /dev/shm/tmc2_gof_id_<uid>_$MASTER_PORT -- refused for several ranks
+ * when MASTER_PORT is not set (two jobs of a node would read each other's id).  Rank 0 removes what an earlier run left under the
+ * name and creates the file exclusively (O_EXCL | O_NOFOLLOW, 0600), renamed into place complete; a reader takes only a complete
+ * file of its own user that is not older than the reader's process -- a caller with a launcher at hand should still name a file
+ * of its own (a nonce in the name).  Creation ends with a checked all-reduce, so a rank that cannot reach the others fails here;
+ * every failure path releases the communicator.  worldSize 1 is valid (the collectives still run).
+ * tmc2_gof_encode_sharded: tmc2_gof_encode over THIS rank's frames (every rank passes equally many, and every rank calls the
+ * passes in the same order).  Rank 0 receives the records: gathered[(r * count + i) * recordSlots + k] = patch k (list order) of
+ * frame i of rank r, gatheredCounts[r * count + i] their number (either may be NULL; ignored on the other ranks); a frame with
+ * more than recordSlots patches fails the call -- on every rank.  tmc2_gof_encode_sharded_resume: as tmc2_gof_encode_resume, on
+ * every rank (the size a GOF needs is the same everywhere); the tiles meet in one ncclAllReduce, the records are gathered.
+ * FAILURES: a rank whose frames fail goes on through every collective of the pass with a value that says so (negative weights,
+ * a height no canvas has, a negative record count, a block of another pass), so every rank returns -- the failing one with the
+ * library's message, the others with "another rank ...".  A collective CALL that fails, or a wait behind one that is not over
+ * after TMC2_GOF_COLLECTIVE_TIMEOUT seconds (default 600; 0: wait for ever), ABORTS the communicator (ncclCommAbort) -- the
+ * other ranks' watchdogs end their waits the same way -- and every later call on it returns TMC2_E_STATE: make a new one.   */
 typedef struct tmc2_gof_comm tmc2_gof_comm;
 int  tmc2_gof_comm_create( int rank, int worldSize, tmc2_ctx* ctx, const char* rendezvous, tmc2_gof_comm** out );
 void tmc2_gof_comm_destroy( tmc2_gof_comm* comm );
@@ -68,6 +99,11 @@ int  tmc2_gof_encode_sharded( tmc2_gof_comm* comm, tmc2_frame** frames, const in
                               uint16_t** geometryD0, uint16_t** geometryD1, uint8_t** attribute, int32_t capacityWidth,
                               int32_t capacityHeight, int32_t* width, int32_t* height, int32_t recordSlots, tmc2_patch* gathered,
                               int64_t* gatheredCounts );
+int  tmc2_gof_encode_sharded_resume( tmc2_gof_comm* comm, tmc2_frame** frames, const int32_t* slotOf, int32_t count, int32_t slots,
+                                     const tmc2_gof_config* config, uint8_t** occupancy, uint8_t** occVideo, uint32_t** blockToPatch,
+                                     uint16_t** geometryD0, uint16_t** geometryD1, uint8_t** attribute, int32_t capacityWidth,
+                                     int32_t capacityHeight, int32_t* width, int32_t* height, int32_t recordSlots, tmc2_patch* gathered,
+                                     int64_t* gatheredCounts );
 
 #ifdef __cplusplus
 }

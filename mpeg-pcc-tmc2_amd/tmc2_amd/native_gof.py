@@ -79,10 +79,13 @@ class CanvasTooSmall(_lib.Tmc2Error):
         self.size = (W, H)
 
 
-def encode(frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w, min_h, packing, out, capacity, guess_canvas=False):
+def encode(frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w, min_h, packing, out, capacity, guess_canvas=False,
+           resume=False):
     """One pass over the GOF (tmc2_gof_encode).  frames: lib.Frame; slot_of[i]: the host thread of frame i (the frames of one
     context on one slot); out: per frame (dict(occupancy, occ_video, block_to_patch, geo0, geo1), attribute) numpy buffers sized
-    for capacity = (W, H), or None (nothing leaves the device).  Returns (W, H); raises CanvasTooSmall with the size the GOF needs."""
+    for capacity = (W, H), or None (nothing leaves the device).  Returns (W, H); raises CanvasTooSmall with the size the GOF needs --
+    the caller then calls again with resume=True and buffers of that size (tmc2_gof_encode_resume: the second half of the same
+    pass; S0-S10 are not repeated)."""
     G = load_library()
     n = len(frames)
     cfg = GofConfig(iterations, vox_dim, bits3d, precision, min_w, min_h, PACKING[packing] if isinstance(packing, str) else int(packing),
@@ -91,10 +94,11 @@ def encode(frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w
     slot = (C.c_int32 * n)(*[int(s) for s in slot_of])
     col = (lambda k, dt: _pointers([o[0][k] for o in out], dt)) if out is not None else (lambda k, dt: None)
     W, H = C.c_int32(0), C.c_int32(0)
-    rc = G.tmc2_gof_encode(handles, slot, n, int(slots), C.byref(cfg), col("occupancy", np.uint8), col("occ_video", np.uint8),
-                           col("block_to_patch", np.uint32), col("geo0", np.uint16), col("geo1", np.uint16),
-                           _pointers([o[1] for o in out], np.uint8) if out is not None else None,
-                           int(capacity[0]), int(capacity[1]), C.byref(W), C.byref(H))
+    fn = G.tmc2_gof_encode_resume if resume else G.tmc2_gof_encode
+    rc = fn(handles, slot, n, int(slots), C.byref(cfg), col("occupancy", np.uint8), col("occ_video", np.uint8),
+            col("block_to_patch", np.uint32), col("geo0", np.uint16), col("geo1", np.uint16),
+            _pointers([o[1] for o in out], np.uint8) if out is not None else None,
+            int(capacity[0]), int(capacity[1]), C.byref(W), C.byref(H))
     if rc != 0:
         if W.value > capacity[0] or H.value > capacity[1]:
             raise CanvasTooSmall(W.value, H.value)
@@ -104,13 +108,16 @@ def encode(frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w
     return W.value, H.value
 
 
-def encode_sharded(comm, frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w, min_h, out, capacity, record_slots=1024):
-    """One pass over THIS rank's frames of a sharded all-intra GOF (tmc2_gof_encode_sharded): weights from rank 0, canvas height
-    all-reduced, canvases into `out` (this rank's page-locked / shared buffers), the packed patch records of every frame gathered
-    to rank 0.  Returns (W, H, records): records = on rank 0 a list [rank][frame] of PATCH_DTYPE arrays in list order, else None."""
+def encode_sharded(comm, frames, slot_of, slots, iterations, vox_dim, bits3d, precision, min_w, min_h, out, capacity, record_slots=1024,
+                   packing="all-intra", resume=False):
+    """One pass over THIS rank's frames of a sharded GOF (tmc2_gof_encode_sharded): weights from rank 0, canvases into `out` (this
+    rank's page-locked / shared buffers).  all-intra: canvas height all-reduced, the packed patch records of every frame gathered
+    to rank 0; low-delay / random-access: records and pools to rank 0, the chain there (tmc2_host_place_segments), packed lists back.
+    resume: after CanvasTooSmall, the second half of the same pass (tmc2_gof_encode_sharded_resume) -- on every rank.
+    Returns (W, H, records): records = on rank 0 a list [rank][frame] of PATCH_DTYPE arrays in list order, else None."""
     G = load_library()
     n = len(frames)
-    cfg = GofConfig(iterations, vox_dim, bits3d, precision, min_w, min_h, 0, 0)
+    cfg = GofConfig(iterations, vox_dim, bits3d, precision, min_w, min_h, PACKING[packing] if isinstance(packing, str) else int(packing), 0)
     handles = (C.c_void_p * n)(*[fr.h.value for fr in frames])
     slot = (C.c_int32 * n)(*[int(s) for s in slot_of])
     col = (lambda k, dt: _pointers([o[0][k] for o in out], dt)) if out is not None else (lambda k, dt: None)
@@ -119,12 +126,13 @@ def encode_sharded(comm, frames, slot_of, slots, iterations, vox_dim, bits3d, pr
     if comm.rank == 0:
         gathered = np.zeros((comm.world, n, record_slots), _lib.PATCH_DTYPE)
         counts = np.zeros((comm.world, n), np.int64)
-    rc = G.tmc2_gof_encode_sharded(comm.h, handles, slot, n, int(slots), C.byref(cfg), col("occupancy", np.uint8), col("occ_video", np.uint8),
-                                   col("block_to_patch", np.uint32), col("geo0", np.uint16), col("geo1", np.uint16),
-                                   _pointers([o[1] for o in out], np.uint8) if out is not None else None,
-                                   int(capacity[0]), int(capacity[1]), C.byref(W), C.byref(H), int(record_slots),
-                                   None if gathered is None else C.c_void_p(gathered.ctypes.data),
-                                   None if counts is None else C.c_void_p(counts.ctypes.data))
+    fn = G.tmc2_gof_encode_sharded_resume if resume else G.tmc2_gof_encode_sharded
+    rc = fn(comm.h, handles, slot, n, int(slots), C.byref(cfg), col("occupancy", np.uint8), col("occ_video", np.uint8),
+            col("block_to_patch", np.uint32), col("geo0", np.uint16), col("geo1", np.uint16),
+            _pointers([o[1] for o in out], np.uint8) if out is not None else None,
+            int(capacity[0]), int(capacity[1]), C.byref(W), C.byref(H), int(record_slots),
+            None if gathered is None else C.c_void_p(gathered.ctypes.data),
+            None if counts is None else C.c_void_p(counts.ctypes.data))
     if rc != 0:
         if W.value > capacity[0] or H.value > capacity[1]:
             raise CanvasTooSmall(W.value, H.value)

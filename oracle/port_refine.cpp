@@ -51,8 +51,10 @@ void rescore( Voxel& v, const uint32_t* partition ) {
 }
 }  // namespace
 
-extern "C" int orc_refine_grid( const int16_t* xyz, const double* normals, size_t n, uint32_t* partition,
-                                int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
+// trace (optional): per iteration 4 words -- points whose plane differs from the state 1 and 2 iterations earlier, voxels whose
+// edge class does (the state the reference carries across iterations is exactly (partition, edge): tools/refine_recurrence.py)
+static int refineGrid( const int16_t* xyz, const double* normals, size_t n, uint32_t* partition, int maxNNCount, double lambda,
+                       int iterationCount, int voxDim, int searchRadius, uint32_t* trace ) {
   static const double O[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}};
   if ( n == 0 ) return 0;
   // grid geometry exactly as the reference derives it (note: the key packs with gridDimShift bits per
@@ -129,6 +131,14 @@ extern "C" int orc_refine_grid( const int16_t* xyz, const double* normals, size_
   uint16_t S[6];
   double   score[6];
   int      iter = 0;
+  std::vector<uint32_t> prevP[2];
+  std::vector<uint8_t>  prevE[2];
+  auto snapshot = [&]( int slotIdx ) {
+    prevP[slotIdx].assign( partition, partition + n );
+    prevE[slotIdx].resize( V );
+    for ( size_t i = 0; i < V; ++i ) prevE[slotIdx][i] = vox[i].edge;
+  };
+  if ( trace ) { snapshot( 0 ); snapshot( 1 ); }
   do {
     for ( size_t i = 0; i < V; ++i ) {
       Voxel&        v      = vox[i];
@@ -159,6 +169,29 @@ extern "C" int orc_refine_grid( const int16_t* xyz, const double* normals, size_
       v.updated = 1;
     }
     for ( auto& v : vox ) rescore( v, partition );
+    if ( trace ) {  // prev[(iter+1)&1] = state after iteration iter-1, prev[iter&1] = state after iteration iter-2
+      uint32_t* tr = trace + 4 * size_t( iter );
+      tr[0] = tr[1] = tr[2] = tr[3] = 0;
+      for ( size_t j = 0; j < n; ++j ) {
+        tr[0] += partition[j] != prevP[( iter + 1 ) & 1][j];
+        tr[1] += partition[j] != prevP[iter & 1][j];
+      }
+      for ( size_t i = 0; i < V; ++i ) {
+        tr[2] += vox[i].edge != prevE[( iter + 1 ) & 1][i];
+        tr[3] += vox[i].edge != prevE[iter & 1][i];
+      }
+      snapshot( iter & 1 );
+    }
   } while ( ++iter < iterationCount );
   return 0;
+}
+
+extern "C" int orc_refine_grid( const int16_t* xyz, const double* normals, size_t n, uint32_t* partition,
+                                int maxNNCount, double lambda, int iterationCount, int voxDim, int searchRadius ) {
+  return refineGrid( xyz, normals, n, partition, maxNNCount, lambda, iterationCount, voxDim, searchRadius, nullptr );
+}
+
+extern "C" int orc_refine_grid_trace( const int16_t* xyz, const double* normals, size_t n, uint32_t* partition, int maxNNCount,
+                                      double lambda, int iterationCount, int voxDim, int searchRadius, uint32_t* trace ) {
+  return refineGrid( xyz, normals, n, partition, maxNNCount, lambda, iterationCount, voxDim, searchRadius, trace );
 }

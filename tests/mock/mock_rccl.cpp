@@ -1,7 +1,8 @@
-// mock_rccl.cpp -- test infrastructure: the ten entries of librccl.so that libtmc2gof.so's sharded mode calls
+// mock_rccl.cpp -- test infrastructure: the eleven entries of librccl.so that libtmc2gof.so's sharded mode calls
 // (mpeg-pcc-tmc2_amd/host/gof_runner.cpp, loaded through TMC2_RCCL_LIBRARY), carried out between PROCESSES through files in
 // $MOCK_RCCL_DIR -- "device" buffers are host memory here (tests/mock/mock_tmc2hip.cpp) -- and logged per rank in
 // $MOCK_RCCL_DIR/log_<rank>: one line per call.  tests/test_native_gof_schedule.py checks what crosses and how often.  Never shipped.
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@ struct Comm {
   int rank, world;
   long seq = 0;
   bool grouped = false;
+  std::atomic<bool> aborted{false};  // (ncclCommAbort from the runner's watchdog thread: every pending wait gives up)
   struct P2p {
     bool        send;
     void*       buf;
@@ -41,9 +43,10 @@ void   put( const std::string& name, const void* p, size_t n ) {
   }
   rename( tmp.c_str(), path.c_str() );
 }
-bool get( const std::string& name, void* p, size_t n ) {
+bool get( const Comm* c, const std::string& name, void* p, size_t n ) {
   const auto limit = std::chrono::steady_clock::now() + std::chrono::seconds( 60 );
   for ( ;; ) {
+    if ( c->aborted.load() ) return false;
     std::ifstream f( dir() + "/" + name, std::ios::binary );
     if ( f && f.read( static_cast<char*>( p ), std::streamsize( n ) ) ) return true;
     if ( std::chrono::steady_clock::now() > limit ) return false;
@@ -55,7 +58,7 @@ int flush( Comm* c ) {  // sends first (they only write), then the receives
   for ( const auto& x : c->pending )
     if ( x.send ) put( "p2p_" + std::to_string( s ) + "_" + std::to_string( c->rank ) + "_" + std::to_string( x.peer ), x.buf, x.bytes );
   for ( const auto& x : c->pending )
-    if ( !x.send && !get( "p2p_" + std::to_string( s ) + "_" + std::to_string( x.peer ) + "_" + std::to_string( c->rank ), x.buf, x.bytes ) ) return 1;
+    if ( !x.send && !get( c, "p2p_" + std::to_string( s ) + "_" + std::to_string( x.peer ) + "_" + std::to_string( c->rank ), x.buf, x.bytes ) ) return 1;
   c->pending.clear();
   return 0;
 }
@@ -70,7 +73,8 @@ int ncclGetUniqueId( Id* id ) {
 }
 int ncclCommInitRank( void** comm, int world, Id id, int rank ) {
   if ( strcmp( id.internal, "mock-rccl-id" ) != 0 ) return 5;
-  Comm* c = new Comm{rank, world};
+  Comm* c = new Comm();
+  c->rank = rank, c->world = world;
   *comm   = c;
   g_last  = c;
   log( c, "init " + std::to_string( rank ) + " " + std::to_string( world ) );
@@ -92,23 +96,29 @@ int ncclBroadcast( const void* send, void* recv, size_t count, int type, int roo
     if ( recv != send ) memcpy( recv, send, n );
     return 0;
   }
-  return get( "bcast_" + std::to_string( s ), recv, n ) ? 0 : 1;
+  return get( c, "bcast_" + std::to_string( s ), recv, n ) ? 0 : 1;
 }
 int ncclAllReduce( const void* send, void* recv, size_t count, int type, int op, void* comm, void* ) {
   Comm*      c = static_cast<Comm*>( comm );
   const long s = c->seq++;
   log( c, "allreduce " + std::to_string( count * width( type ) ) + " op " + std::to_string( op ) );
-  if ( type != 2 || op != 2 || count != 1 ) return 4;  // (the runner reduces one int32 with max)
-  int32_t mine;
-  memcpy( &mine, send, 4 );
-  put( "ar_" + std::to_string( s ) + "_" + std::to_string( c->rank ), &mine, 4 );
-  int32_t best = mine;
+  if ( type != 2 || op != 2 || count < 1 || count > 16 ) return 4;  // (the runner reduces a few int32 with max)
+  int32_t mine[16], best[16];
+  memcpy( mine, send, 4 * count ), memcpy( best, send, 4 * count );
+  put( "ar_" + std::to_string( s ) + "_" + std::to_string( c->rank ), mine, 4 * count );
   for ( int r = 0; r < c->world; ++r ) {
-    int32_t v;
-    if ( !get( "ar_" + std::to_string( s ) + "_" + std::to_string( r ), &v, 4 ) ) return 1;
-    best = v > best ? v : best;
+    int32_t v[16];
+    if ( !get( c, "ar_" + std::to_string( s ) + "_" + std::to_string( r ), v, 4 * count ) ) return 1;
+    for ( size_t k = 0; k < count; ++k ) best[k] = v[k] > best[k] ? v[k] : best[k];
   }
-  memcpy( recv, &best, 4 );
+  memcpy( recv, best, 4 * count );
+  return 0;
+}
+int ncclCommAbort( void* comm ) {  // (from another thread than the one that waits: the object stays, a mock may leak)
+  Comm* c = static_cast<Comm*>( comm );
+  log( c, "abort" );
+  c->aborted.store( true );
+  if ( g_last == c ) g_last = nullptr;
   return 0;
 }
 int ncclGroupStart() {

@@ -3,6 +3,7 @@
 // schedule it drives: which calls, on which frame, in which order per slot, what happens on a failure.  Never shipped.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -17,7 +18,7 @@ struct tmc2_frame {
 };
 
 namespace {
-enum Call { RESET = 1, WEIGHT, SEGMENT, PACK_FLEXIBLE, PACK_CHAIN, GPA, PACKED_SIZE, GEOMETRY, ATTRIBUTE, GET_GEOMETRY, GET_ATTRIBUTE };
+enum Call { RESET = 1, WEIGHT, SEGMENT, PACK_FLEXIBLE, PACK_CHAIN, GPA, PACKED_SIZE, GEOMETRY, ATTRIBUTE, GET_GEOMETRY, GET_ATTRIBUTE, PLACE, SET_PACKING };
 struct Event {
   int32_t  call, frame, a, b;
   uint64_t thread;
@@ -120,17 +121,90 @@ void*     tmc2_ctx_stream( tmc2_ctx* c ) { return c; }
 int       tmc2_ctx_device( tmc2_ctx* c ) { return c->device; }
 int       tmc2_ctx_make_current( tmc2_ctx* ) { return TMC2_OK; }
 int       tmc2_frame_patch_count( tmc2_frame* f ) { return 3 + f->id % 5; }
-int       tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t*, int16_t*, uint8_t* ) {
+int       tmc2_frame_patch_pool_sizes( tmc2_frame* f, int64_t* depthCount, int64_t* occCount ) {
+  if ( depthCount ) *depthCount = 0;
+  if ( occCount ) *occCount = 6 * ( 3 + f->id % 5 );
+  return TMC2_OK;
+}
+// by index: patch k of frame f has u0 = f, v0 = n - 1 - k (the list order is the reverse), a block box with six pool bytes of value
+// f + 1, and -- so that the packers of the record route (tmc2_host_place_segments below) know the tile the mock frame was made
+// with -- sizeU / sizeV = the frame's packed width / height
+int tmc2_frame_get_patches( tmc2_frame* f, tmc2_patch* patches, int16_t*, int16_t*, uint8_t* occupancy ) {
   const int n = 3 + f->id % 5;
   for ( int k = 0; k < n; ++k ) {
     memset( &patches[k], 0, sizeof( tmc2_patch ) );
     patches[k].index = k, patches[k].u0 = f->id, patches[k].v0 = n - 1 - k;  // (stored in reverse of the list order)
+    patches[k].sizeU = f->packedWidth, patches[k].sizeV = f->packedHeight, patches[k].sizeU0 = 4, patches[k].sizeV0 = 3, patches[k].occOffset = 6 * k;
   }
+  if ( occupancy ) memset( occupancy, f->id + 1, size_t( 6 * n ) );
   return TMC2_OK;
 }
 int tmc2_frame_get_patch_order( tmc2_frame* f, int32_t* order ) {
   const int n = 3 + f->id % 5;
   for ( int k = 0; k < n; ++k ) order[k] = n - 1 - k;
   return TMC2_OK;
+}
+// PCCEncoder::placeSegments over records: the mock checks that the frames arrive in GOF order with their own pools (frame number
+// f of the call must carry u0 = f and pool bytes f + 1), reverses every list (v0 = list position), doubles the pools under the
+// random-access condition (a tracked patch grows) and leaves the tiles the mock frames were made with (+ 16 rows under random access).
+// MOCK_PLACE_FAIL=1 in the environment: fails.
+int tmc2_host_place_segments( int frames, const int32_t* counts, tmc2_patch* patches, const uint8_t* occupancy, const int64_t* occupancyBase,
+                              int mode, int, int, int, double, int32_t* matches, uint8_t* occupancyOut, int64_t occupancyOutCapacity,
+                              int64_t* occupancyOutBase, int32_t* widths, int32_t* heights ) {
+  note( PLACE, nullptr, frames, mode );
+  if ( getenv( "MOCK_PLACE_FAIL" ) ) {
+    g_err = "mock failure of the packing chain";
+    return TMC2_E_HIP;
+  }
+  const int grow = mode == 2 ? 2 : 1;
+  int64_t   out  = 0;
+  size_t    at   = 0;
+  for ( int f = 0; f < frames; ++f ) {
+    const int n = counts[f];
+    occupancyOutBase[f] = out;
+    if ( out + int64_t( 6 * n * grow ) > occupancyOutCapacity ) {
+      g_err = "mock: the packed pools do not fit";
+      return TMC2_E_INVALID;
+    }
+    std::vector<tmc2_patch> list( static_cast<size_t>( n ) );
+    for ( int k = 0; k < n; ++k ) {
+      const tmc2_patch& p = patches[at + size_t( k )];
+      if ( p.u0 != f || p.index != k || occupancy[occupancyBase[f] + p.occOffset] != uint8_t( f + 1 ) ) {
+        char msg[96];
+        std::snprintf( msg, sizeof( msg ), "mock: frame %d of the chain carries records of frame %d", f, p.u0 );
+        g_err = msg;
+        return TMC2_E_INVALID;
+      }
+      list[size_t( n - 1 - k )] = p;
+    }
+    for ( int j = 0; j < n; ++j ) {
+      list[size_t( j )].v0 = j, list[size_t( j )].occOffset = int64_t( 6 * j * grow );
+      patches[at + size_t( j )] = list[size_t( j )];
+      matches[at + size_t( j )] = j - 1;
+    }
+    memset( occupancyOut + out, f + 1, size_t( 6 * n * grow ) );
+    out += 6 * n * grow;
+    if ( widths ) widths[f] = n ? patches[at].sizeU : 0;
+    if ( heights ) heights[f] = ( n ? patches[at].sizeV : 0 ) + ( mode == 2 ? 16 : 0 );
+    at += size_t( n );
+  }
+  occupancyOutBase[frames] = out;
+  return TMC2_OK;
+}
+// the packed list of a frame, installed: must be THIS frame's (u0), in list order (v0), with its matches and its pool
+int tmc2_frame_set_packing( tmc2_frame* f, const tmc2_patch* list, int count, const int32_t* matches, const uint8_t* occupancy,
+                            int64_t occupancyBytes, int packedWidth, int packedHeight ) {
+  bool ok = count == 3 + f->id % 5 && ( occupancyBytes == 6 * count || occupancyBytes == 12 * count );
+  for ( int j = 0; ok && j < count; ++j ) ok = list[j].u0 == f->id && list[j].v0 == j && matches[j] == j - 1;
+  for ( int64_t b = 0; ok && b < occupancyBytes; ++b ) ok = occupancy[b] == uint8_t( f->id + 1 );
+  if ( !ok ) {
+    char msg[96];
+    std::snprintf( msg, sizeof( msg ), "mock: the packed list handed to frame %d is not its own", f->id );
+    g_err = msg;
+    (void)note( SET_PACKING, f, count, -1 );
+    return TMC2_E_INVALID;
+  }
+  f->packedWidth = packedWidth, f->packedHeight = packedHeight;
+  return note( SET_PACKING, f, count, packedHeight );
 }
 }

@@ -133,6 +133,17 @@ class Oracle:
                                int(iterations), int(vox_dim), int(radius))
         return part
 
+    def refine_grid_trace(self, xyz, normals, partition, max_nn=1024, lam=3.0, iterations=10, vox_dim=4, radius=192):
+        """refine_grid + per iteration [points that differ from 1 / 2 iterations earlier, voxel edge classes that do] -- the state
+        the reference carries across iterations is (partition, edge): a zero pair in a column means the state recurs."""
+        xyz = _i16(xyz)
+        nm = np.ascontiguousarray(normals, dtype=np.float64)
+        part = np.array(partition, dtype=np.uint32, order="C", copy=True)
+        trace = np.zeros((int(iterations), 4), np.uint32)
+        self.L.orc_refine_grid_trace(_p(xyz), _p(nm), C.c_size_t(len(xyz)), _p(part), int(max_nn), C.c_double(lam),
+                                     int(iterations), int(vox_dim), int(radius), _p(trace))
+        return part, trace
+
 
     # S7-S9 and the whole segmenter
     def _collect(self, r):

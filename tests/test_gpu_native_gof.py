@@ -31,13 +31,15 @@ def through_python(enc, frames, packing):
 
 
 def through_native(frames, workers, packing, guess):
+    """A GOF that outgrows the buffers is refused once, with the size it needs, and RESUMED there with larger buffers
+    (tmc2_gof_encode_resume: S0-S10 are not repeated; with a guessed canvas there is no second half: the whole pass again)."""
     capacity = [MIN_W, MIN_H]
     refused = 0
     while True:
         bufs = buffers(len(frames), *capacity)
         try:
             size = native_gof.encode(frames, [i % workers for i in range(len(frames))], workers, 3, 4, 11, P, MIN_W, MIN_H, packing,
-                                     bufs, capacity, guess_canvas=guess)
+                                     bufs, capacity, guess_canvas=guess, resume=refused > 0 and not guess)
             break
         except native_gof.CanvasTooSmall as e:
             refused += 1
@@ -85,34 +87,151 @@ def test_gpu_native_gof_host_reports_the_failing_call():
 
 
 @pytest.mark.gpu
-def test_gpu_native_gof_sharded_runs_rccl_from_cpp():
+def test_gpu_native_gof_resume_needs_packed_frames():
+    """tmc2_gof_encode_resume on frames that were reset: there is no tile to take the canvas from (TMC2_E_STATE, nothing rasterised)."""
+    enc = T.GofEncoder(0, 2, 3, 11, P, MIN_W, MIN_H)
+    frames = enc.upload([synth_cloud("tiny", i) for i in range(2)])
+    native_gof.encode(frames, [0, 1], 2, 3, 4, 11, P, MIN_W, MIN_H, "all-intra", None, (MIN_W, MIN_H))
+    for fr in frames:
+        fr.reset()
+    with pytest.raises(T.Tmc2Error, match="not packed"):
+        native_gof.encode(frames, [0, 1], 2, 3, 4, 11, P, MIN_W, MIN_H, "all-intra", None, (MIN_W, MIN_H), resume=True)
+    for fr in frames:
+        fr.close()
+    enc.close()
+
+
+def _sharded_pass(comm, frames, workers, packing, want_size=None):
+    """tmc2_gof_encode_sharded on this rank's frames, the way bench.py drives it: refused once if the GOF outgrows the minimum canvas,
+    resumed with the size it needs.  -> (size, buffers, records, times refused)"""
+    capacity, refused = [MIN_W, MIN_H], 0
+    while True:
+        bufs = buffers(len(frames), *capacity)
+        try:
+            W, H, records = native_gof.encode_sharded(comm, frames, [i % workers for i in range(len(frames))], workers, 3, 4, 11, P, MIN_W,
+                                                      MIN_H, bufs, capacity, packing=packing, resume=refused > 0)
+            return (W, H), bufs, records, refused
+        except native_gof.CanvasTooSmall as e:
+            refused += 1
+            assert refused == 1
+            capacity = list(e.size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packing", ["all-intra", "low-delay", "random-access"])
+def test_gpu_native_gof_sharded_runs_rccl_from_cpp(packing, monkeypatch):
     """tmc2_gof_encode_sharded on this box's one GPU: a communicator of ONE rank is still librccl.so's ncclCommInitRank, and the pass
-    still runs the 24-byte ncclBroadcast, the ncclAllReduce( max ) of the canvas height and the grouped ncclSend / ncclRecv of the
-    packed patch records on the context's stream -- RCCL driven from the C++ host, for real.  Same canvases as the unsharded entry;
-    the gathered records are the frames' patch lists in list order.  (Several ranks: tests/test_native_gof_schedule.py, against a
-    recorder; the 8-GPU run: bench.py --host native --gpus 8.)"""
+    still runs its collectives on the context's stream -- RCCL driven from the C++ host, for real.  all-intra: the 24-byte
+    ncclBroadcast, the ncclAllReduce( max ) of the canvas height, the grouped ncclSend / ncclRecv of the packed patch records.
+    low-delay / random-access (round 6; TMC2_GOF_RECORDS_CHAIN forces the route several ranks take): records and block-occupancy
+    pools through a grouped send / receive to "rank 0", PCCEncoder::placeSegments there over the records (tmc2_host_place_segments),
+    the packed lists back through a second one, tmc2_frame_set_packing.  Same canvases as the Python host's frame-based chain;
+    the records rank 0 is left with are the frames' patch lists in list order.  The GOF outgrows the minimum canvas: refused once,
+    resumed (tmc2_gof_encode_sharded_resume).  (Several ranks: tests/test_native_gof_schedule.py against a recorder, and
+    test_gpu_native_gof_sharded_over_the_gpus_of_this_box below wherever the box has them.)"""
+    monkeypatch.setenv("TMC2_GOF_RECORDS_CHAIN", "1")
     workers, n = 2, 4
-    clouds = [synth_cloud("tiny", i) for i in range(n)]
+    clouds = [synth_cloud("small" if i == 2 else "tiny", i) for i in range(n)]        # 'small' outgrows the 256 x 256 canvas
     enc = T.GofEncoder(0, workers, 3, 11, P, MIN_W, MIN_H)
     frames = enc.upload(clouds)
-    want_size, want = through_python(enc, frames, "all-intra")
+    want_size, want = through_python(enc, frames, packing)
+    assert tuple(want_size) != (MIN_W, MIN_H)
     comm = native_gof.Comm(enc.ctxs[0], rank=0, world=1)
     try:
         for rep in range(2):
-            bufs = buffers(n, *want_size)
-            W, H, records = native_gof.encode_sharded(comm, frames, [i % workers for i in range(n)], workers, 3, 4, 11, P, MIN_W, MIN_H,
-                                                      bufs, want_size)
-            assert (W, H) == tuple(want_size)
+            size, bufs, records, refused = _sharded_pass(comm, frames, workers, packing)
+            assert size == tuple(want_size) and refused == 1
             for i, (b, w, fr) in enumerate(zip(bufs, want, frames)):
                 for k, y in zip(("occupancy", "occ_video", "block_to_patch", "geo0", "geo1"), w[0]):
                     assert np.array_equal(b[0][k], y), (rep, i, k)
                 assert np.array_equal(b[1], w[1]), (rep, i)
-                assert records[0][i].tobytes() == fr.get_patches()[0][fr.get_patch_order()].tobytes(), (rep, i)
+                mine = fr.get_patches()[0][fr.get_patch_order()]
+                assert len(records[0][i]) == len(mine)
+                if packing == "all-intra":                         # (the gather moves the frame's own records: every byte)
+                    assert records[0][i].tobytes() == mine.tobytes(), (rep, i)
+                for field in ("u0", "v0", "patchOrientation", "sizeU0", "sizeV0", "u1", "v1", "d1", "index"):
+                    assert np.array_equal(records[0][i][field], mine[field]), (rep, i, field)
     finally:
         comm.close()
         for fr in frames:
             fr.close()
         enc.close()
+
+
+def _rank_of_a_real_world(args):
+    """One rank of a sharded GOF on its OWN GPU (a process of its own): RCCL between real devices, from the C++ host."""
+    rank, world, n, rendezvous, out_path = args
+    import hashlib
+    import pickle
+    clouds = [synth_cloud("small" if f == 2 else "tiny", f) for f in range(rank, n * world, world)]      # frame f on rank f mod world
+    enc = T.GofEncoder(rank, 2, 3, 11, P, MIN_W, MIN_H)
+    frames = enc.upload(clouds)
+    comm = native_gof.Comm(enc.ctxs[0], rank=rank, world=world, rendezvous=rendezvous)
+    res = {}
+    try:
+        for packing in ("all-intra", "low-delay", "random-access"):
+            size, bufs, records, refused = _sharded_pass(comm, frames, 2, packing)
+            res[packing] = dict(size=size, refused=refused,
+                                md5=[[hashlib.md5(np.ascontiguousarray(b[0][k]).tobytes()).hexdigest()
+                                      for k in ("occupancy", "occ_video", "block_to_patch", "geo0", "geo1")] +
+                                     [hashlib.md5(np.ascontiguousarray(b[1]).tobytes()).hexdigest()] for b in bufs],
+                                records=None if records is None else [[(r_["u0"].tolist(), r_["v0"].tolist()) for r_ in per] for per in records])
+    finally:
+        comm.close()
+        for fr in frames:
+            fr.close()
+        enc.close(join=True)
+    with open(out_path, "wb") as f:
+        pickle.dump(res, f)
+    return 0
+
+
+@pytest.mark.gpu
+def test_gpu_native_gof_sharded_over_the_gpus_of_this_box(tmp_path):
+    """ARMS ITSELF wherever the box shows two or more GPUs (skipped on the one-GPU box the builder has -- say so): one process per
+    GPU, tmc2_gof_comm_create for real (the id through a file with a nonce, ncclCommInitRank between devices) and
+    tmc2_gof_encode_sharded under all three packing conditions -- the weights broadcast, the height all-reduce, the grouped
+    send / receive of the records, the records route of the packing chains and the resume of a GOF that outgrows the minimum canvas
+    -- against the single-process Python host over the same frames on device 0."""
+    import hashlib
+    import multiprocessing as mp
+    import pickle
+    import uuid
+    import torch
+    have = torch.cuda.device_count()
+    if have < 2:
+        pytest.skip("this box shows %d GPU: a real world of several RCCL ranks needs one GPU per rank (the test arms itself on a "
+                    "multi-GPU box; worlds of 2 and 4 ranks run against a recorder in tests/test_native_gof_schedule.py)" % have)
+    world, n = min(have, 4), 2
+    rendezvous = "/dev/shm/tmc2_gof_test_id_%s" % uuid.uuid4().hex
+    outs = [str(tmp_path / ("rank%d.pkl" % r)) for r in range(world)]
+    with mp.get_context("spawn").Pool(world) as pool:
+        assert pool.map(_rank_of_a_real_world, [(r, world, n, rendezvous, outs[r]) for r in range(world)]) == [0] * world
+    res = []
+    for o in outs:
+        with open(o, "rb") as f:
+            res.append(pickle.load(f))
+    clouds = [synth_cloud("small" if f == 2 else "tiny", f) for f in range(n * world)]
+    enc = T.GofEncoder(0, 2, 3, 11, P, MIN_W, MIN_H)
+    frames = enc.upload(clouds)
+    md5 = lambda x: hashlib.md5(np.ascontiguousarray(x).tobytes()).hexdigest()
+    for packing in ("all-intra", "low-delay", "random-access"):
+        want_size, want = through_python(enc, frames, packing)
+        lists = [fr.get_patches()[0][fr.get_patch_order()] for fr in frames]
+        for r in range(world):
+            got = res[r][packing]
+            assert got["size"] == tuple(want_size) and got["refused"] == 1, (packing, r, got["size"])
+            for i in range(n):
+                f = r + i * world
+                assert got["md5"][i] == [md5(x) for x in want[f][0]] + [md5(want[f][1])], (packing, f)
+        for r in range(world):
+            for i in range(n):
+                f = r + i * world
+                assert res[0][packing]["records"][r][i] == (lists[f]["u0"].tolist(), lists[f]["v0"].tolist()), (packing, f)
+        assert all(res[r][packing]["records"] is None for r in range(1, world))
+    for fr in frames:
+        fr.close()
+    enc.close()
 
 
 @pytest.mark.gpu

@@ -33,7 +33,8 @@ def test_native_gof_host_exports_its_header_and_refuses_bad_arguments():
     from tmc2_amd import native_gof
     hdr = open(os.path.join(ROOT, "include", "tmc2gof.h")).read()
     names = sorted(set(re.findall(r"\b(tmc2_gof_[a-z0-9_]+)\s*\(", hdr)))
-    assert names == ["tmc2_gof_comm_create", "tmc2_gof_comm_destroy", "tmc2_gof_encode", "tmc2_gof_encode_sharded", "tmc2_gof_last_error"]
+    assert names == ["tmc2_gof_comm_create", "tmc2_gof_comm_destroy", "tmc2_gof_encode", "tmc2_gof_encode_resume", "tmc2_gof_encode_sharded",
+                     "tmc2_gof_encode_sharded_resume", "tmc2_gof_last_error"]
     G = native_gof.load_library()
     assert not [n for n in names if not hasattr(G, n)]
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()

@@ -338,20 +338,6 @@ def test_bench_records_gather_and_shared_host_canvases_world_2_and_8_gloo(world)
     assert bench.RECORD_SLOTS >= 512
 
 
-def test_bench_refuses_the_native_host_for_a_sharded_packing_chain():
-    """--host native with several ranks is tmc2_gof_encode_sharded -- the all-intra GOF, its collectives issued from C++ over RCCL.
-    The low-delay / random-access packing chains run over ALL frames in order; a sharded GOF under those conditions meets over
-    torch.distributed (--host python), and bench.py says so instead of timing something else.  No GPU and no rendezvous needed: the
-    refusal comes before either."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--host", "native", "--config", "basketball"],
-                       capture_output=True, text=True, env=env, timeout=120)
-    assert r.returncode != 0 and "random-access packing chain runs over ALL frames" in r.stderr, r.stderr[-400:]
-
-
 def test_bench_gpus_n_starts_its_own_launcher():
     """`python bench.py --gpus 2` with no launcher around it (the way the N = 1 line is invoked) must not run one rank and print
     n_gpus 1: it becomes `torch.distributed.run --nproc-per-node 2` itself, the ranks that come up are the ranks asked for, and the
