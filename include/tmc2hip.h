@@ -106,7 +106,9 @@ void        tmc2_set_host_parallelism( int maxConcurrentHostSteps );
  * conservative forms and debug invariants), "KD_FORM" / "KD_LEVELS" / "KD_HUGEMAX" (tiers of the device tree build),
  * "REFINE_*" (forms and grids of the refinement), "METRICS_K", "ORIENT_*"; a "TMC2_" prefix is accepted and dropped.  When a
  * context is created its options start as the TMC2_* variables of the process environment (read once, there); value NULL
- * unsets an option.  None of them ever changes a result.                                                              */
+ * unsets an option.  None of them ever changes a result.  Options may be set from any thread while frames of the context are
+ * in flight (a mutex guards the table; a stage reads an option when it starts).  tmc2_ctx_get_option returns a COPY that belongs
+ * to the calling thread and stays valid until that thread's eighth later look-up -- never a pointer into the table.      */
 int         tmc2_ctx_set_option( tmc2_ctx* ctx, const char* key, const char* value );
 const char* tmc2_ctx_get_option( tmc2_ctx* ctx, const char* key );
 /* Reserve, at context creation time, the device memory the frames of a sequence will need (upper bounds of the sequence: points

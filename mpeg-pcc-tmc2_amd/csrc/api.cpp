@@ -230,17 +230,20 @@ int tmc2_ctx_create( int device, tmc2_ctx** out ) {
   c->device   = device;
   hipDeviceProp_t prop;
   if ( hipGetDeviceProperties( &prop, device ) == hipSuccess ) c->cuCount = prop.multiProcessorCount;
-  if ( hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
-    setError( "hipStreamCreate failed" );
-    delete c;
-    return TMC2_E_HIP;
-  }
   // the defaults of this context's options: every TMC2_* variable of the process environment, read here and never again
   for ( char** e = environ; e && *e; ++e ) {
     if ( strncmp( *e, "TMC2_", 5 ) != 0 ) continue;
     const char* eq = strchr( *e, '=' );
     if ( !eq ) continue;
     c->options[std::string( *e + 5, size_t( eq - ( *e + 5 ) ) )] = std::string( eq + 1 );
+  }
+  // (Round 6 tried to confine a context's stream to some of the chip's eight XCDs with hipExtStreamCreateWithCUMask, so that a
+  //  frame's next kernel finds in "its" L2 what the previous one left: in this partition mode the workgroups of a masked stream
+  //  still land on all eight XCCs, whichever bits are set -- the mask thins the CUs inside every XCC.  profiles/r06_stream_cu_mask.txt.)
+  if ( hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking ) != hipSuccess ) {
+    setError( "hipStreamCreate failed" );
+    delete c;
+    return TMC2_E_HIP;
   }
   *out = c;
   return TMC2_OK;
@@ -254,6 +257,7 @@ int tmc2_ctx_set_option( tmc2_ctx* ctx, const char* key, const char* value ) {
     return TMC2_E_INVALID;
   }
   const std::string k = strncmp( key, "TMC2_", 5 ) == 0 ? key + 5 : key;
+  std::lock_guard<std::mutex> g( ctx->optionsLock );  // (the context's worker thread may be reading: stage code looks options up)
   if ( value )
     ctx->options[k] = value;
   else
@@ -482,8 +486,17 @@ const char* ctxOption( const tmc2_ctx* ctx, const char* key ) {
     const std::string name = std::string( "TMC2_" ) + key;
     return getenv( name.c_str() );
   }
-  const auto it = ctx->options.find( key );
-  return it == ctx->options.end() ? nullptr : it->second.c_str();
+  // a COPY of the value, in a slot of the calling thread (eight slots, used in turn): the map may change under a reader's feet --
+  // options are set from the caller's thread while stage code of the context's worker thread looks them up -- and what
+  // tmc2_ctx_get_option hands out must outlive the next set / unset of the key
+  static thread_local std::string slots[8];
+  static thread_local unsigned    turn = 0;
+  std::lock_guard<std::mutex>     g( ctx->optionsLock );
+  const auto                      it = ctx->options.find( key );
+  if ( it == ctx->options.end() ) return nullptr;
+  std::string& slot = slots[turn++ & 7u];
+  slot              = it->second;
+  return slot.c_str();
 }
 static std::atomic<int> g_refineOverlap{-1};
 bool refineOverlap( const tmc2_ctx* ctx ) {

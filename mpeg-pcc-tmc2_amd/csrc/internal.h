@@ -251,6 +251,7 @@ struct tmc2_ctx {
   // context is created, from the process environment (every TMC2_* variable: the defaults); nothing in the library reads the
   // environment after that, and nothing is process-wide: two encoders of one process can run with different settings.
   std::map<std::string, std::string> options;
+  mutable std::mutex                 optionsLock;
   void* sweepGraph = nullptr;      // option REFINE_GRAPH: the hipGraph_t / hipGraphExec_t of the last refinement's sweeps (kept until the next one)
   void* sweepGraphExec = nullptr;
   hipStream_t                   stream = nullptr;

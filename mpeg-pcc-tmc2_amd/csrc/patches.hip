@@ -79,11 +79,23 @@ __device__ __forceinline__ int waveMaxMasked( int v, bool mine ) {
 // The result is the unique fixpoint, so it does not depend on scheduling.
 
 // bit j of mutual[u] = knn[u][j] lists u in its own row.  Depends only on the adjacency: once per call.
+// Every row is read by the point itself and by its (up to) sixteen in-neighbours: 64 N bytes if each row reached HBM once, sixteen
+// times that if none stayed cached.  Rounds 1-5 walked the points in INPUT order with the blocks dealt round-robin over the eight
+// XCDs: every L2 saw every region of the cloud (counters: 325 MB for 55 MB of contract bytes).  Round 6: the points are taken in
+// TREE order (perm: tree position -> point; neighbours in space are neighbours in the tree) and XCD x works through the x-th
+// eighth of the tree (the mapping of knnKernel) -- the rows a workgroup needs are the rows its neighbours on the same L2 have just
+// fetched.  perm == nullptr: input order (a frame whose adjacency came from the caller has no tree).
 template <int K>
-__global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __restrict__ knn, uint32_t n,
+__global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __restrict__ knn, const uint32_t* __restrict__ perm, uint32_t n,
                                                               uint16_t* __restrict__ mutual ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( u >= n ) return;
+  uint32_t block = blockIdx.x;
+  if ( perm ) {  // (grid: a multiple of 8 blocks; block b runs on XCD b % 8 -- observed, not promised: only speed depends on it)
+    const uint32_t perXcd = gridDim.x >> 3;
+    block                 = ( blockIdx.x & 7u ) * perXcd + ( blockIdx.x >> 3 );
+  }
+  const uint32_t at = block * blockDim.x + threadIdx.x;
+  if ( at >= n ) return;
+  const uint32_t u = perm ? perm[at] : at;
   uint32_t     nb[K];
   const uint4* row = reinterpret_cast<const uint4*>( knn + size_t( u ) * K );
 #pragma unroll
@@ -702,8 +714,11 @@ int ensureMutualMask( tmc2_frame* f ) {
   const uint32_t n = uint32_t( f->n );
   TMC2_TRY( f->d_mutual.alloc( n ) );
   const int kt = f->ctx->stageBegin( "k:ccMutualMask" );
-  hipLaunchKernelGGL( ccMutualMaskKernel<16>, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, f->ctx->stream, f->d_knn.p, n,
-                      f->d_mutual.p );
+  const char*     order = ctxOption( f->ctx, "MUTUAL_ORDER" );  // (cross-check hook: "input" = rounds 1-5)
+  const uint32_t* perm  = f->haveTree && f->d_perm.p && f->d_perm.count >= n && !( order && order[0] == 'i' ) ? f->d_perm.p : nullptr;
+  const uint32_t  blocks = ( n + 255 ) / 256;
+  hipLaunchKernelGGL( ccMutualMaskKernel<16>, dim3( perm ? ( ( blocks + 7 ) & ~7u ) : blocks ), dim3( 256 ), 0, f->ctx->stream, f->d_knn.p,
+                      perm, n, f->d_mutual.p );
   f->ctx->stageEnd( kt );
   TMC2_HIP( hipGetLastError() );
   f->haveMutual = true;

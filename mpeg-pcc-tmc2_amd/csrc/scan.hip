@@ -176,3 +176,4 @@ int fillRegions( tmc2_ctx* ctx, std::initializer_list<FillRegion> regions ) {
 }
 
 }  // namespace tmc2
+

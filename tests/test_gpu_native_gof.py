@@ -131,7 +131,7 @@ def test_gpu_native_gof_sharded_runs_rccl_from_cpp(packing, monkeypatch):
     test_gpu_native_gof_sharded_over_the_gpus_of_this_box below wherever the box has them.)"""
     monkeypatch.setenv("TMC2_GOF_RECORDS_CHAIN", "1")
     workers, n = 2, 4
-    clouds = [synth_cloud("small" if i == 2 else "tiny", i) for i in range(n)]        # 'small' outgrows the 256 x 256 canvas
+    clouds = [synth_cloud("medium" if i == 2 else "tiny", i) for i in range(n)]       # 'medium' (180 K points) outgrows the 256 x 256 canvas
     enc = T.GofEncoder(0, workers, 3, 11, P, MIN_W, MIN_H)
     frames = enc.upload(clouds)
     want_size, want = through_python(enc, frames, packing)
@@ -163,7 +163,7 @@ def _rank_of_a_real_world(args):
     rank, world, n, rendezvous, out_path = args
     import hashlib
     import pickle
-    clouds = [synth_cloud("small" if f == 2 else "tiny", f) for f in range(rank, n * world, world)]      # frame f on rank f mod world
+    clouds = [synth_cloud("medium" if f == 2 else "tiny", f) for f in range(rank, n * world, world)]     # frame f on rank f mod world
     enc = T.GofEncoder(rank, 2, 3, 11, P, MIN_W, MIN_H)
     frames = enc.upload(clouds)
     comm = native_gof.Comm(enc.ctxs[0], rank=rank, world=world, rendezvous=rendezvous)
@@ -211,7 +211,7 @@ def test_gpu_native_gof_sharded_over_the_gpus_of_this_box(tmp_path):
     for o in outs:
         with open(o, "rb") as f:
             res.append(pickle.load(f))
-    clouds = [synth_cloud("small" if f == 2 else "tiny", f) for f in range(n * world)]
+    clouds = [synth_cloud("medium" if f == 2 else "tiny", f) for f in range(n * world)]
     enc = T.GofEncoder(0, 2, 3, 11, P, MIN_W, MIN_H)
     frames = enc.upload(clouds)
     md5 = lambda x: hashlib.md5(np.ascontiguousarray(x).tobytes()).hexdigest()

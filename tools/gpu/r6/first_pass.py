@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--warm-all", type=int, default=0)
     ap.add_argument("--marker", type=int, default=0)
     ap.add_argument("--gen-procs", type=int, default=0)
+    ap.add_argument("--capacity-h", type=int, default=0, help="rows the buffers hold from the start (0: the minimum canvas)")
+    ap.add_argument("--resume", type=int, default=1, help="0: rounds 4-5 -- the whole pass again after 'the GOF needs a larger canvas'")
     a = ap.parse_args()
     import bench
     from tmc2_amd import configs
@@ -54,7 +56,7 @@ def main():
         enc = T.GofEncoder(0, a.workers, case["iterations"], case["bits3d"], P, W0, H0, timing=True, first_domain=0, vox_dim=case["vox_dim"])
         enc.reserve(max(len(c[0]) for c in clouds), W0, max(H0, W0))
         frames = enc.upload(clouds)
-        cap = [W0, H0]
+        cap = [W0, max(H0, a.capacity_h)]
 
         def bufs(W, H):
             return [(dict(occupancy=T.host_array((H, W), np.uint8), occ_video=T.host_array((H // P, W // P), np.uint8),
@@ -84,17 +86,25 @@ def main():
                 torch.cuda.synchronize()
             enc.stage_reset()
             t0 = time.time()
+            resume = False
+            marks = []
             while True:
+                marks.append(round(1e3 * (time.time() - t0), 1))
                 try:
                     native_gof.encode(frames, [i % a.workers for i in range(len(frames))], a.workers, case["iterations"], case["vox_dim"],
-                                      case["bits3d"], P, W0, H0, packing, host, cap)
+                                      case["bits3d"], P, W0, H0, packing, host, cap, resume=resume)
                     break
                 except native_gof.CanvasTooSmall as e:
                     cap[:] = [max(cap[0], e.size[0]), max(cap[1], e.size[1])]
+                    t1 = time.time()
                     host = bufs(*cap)
                     rec["canvas_grew_in_pass"] = p
+                    rec["new_buffers_ms"] = round(1e3 * (time.time() - t1), 1)
+                    resume = bool(a.resume)
+            marks.append(round(1e3 * (time.time() - t0), 1))
             torch.cuda.synchronize()
             rec["pass_ms"].append(round(1e3 * (time.time() - t0), 1))
+            rec.setdefault("call_marks_ms", []).append(marks)
             st = {k: round(v / len(frames), 2) for k, v in enc.stage_ms().items() if not k.startswith(("refine_row", "refine_vox", "refine_sweeps_ex"))}
             if p == 0:
                 rec["stage_ms_first"] = st
