@@ -103,7 +103,7 @@ void        tmc2_set_host_parallelism( int maxConcurrentHostSteps );
 /* Per-context options: everything that tunes or cross-checks the path is a property of ONE context -- no process-global state, and
  * the library does not look at the environment while it runs.  key = the knob's name (DESIGN.md section 5 lists them):
  * "REFINE_OVERLAP" (0 / 1, below), "KDTREE_HOST" (0 / 1 / 2, below), "UF_PRECHECK" / "UF_SCOPE" / "UF_CHECK" (the union passes'
- * conservative forms and debug invariants), "KD_FORM" / "KD_LEVELS" / "KD_HUGEMAX" (tiers of the device tree build),
+ * conservative forms and debug invariants), "KD_HUGEMAX" / "KD_PIECE_PER" / "KD_DECIDE" (forms of the device tree build),
  * "REFINE_*" (forms and grids of the refinement), "METRICS_K", "ORIENT_*"; a "TMC2_" prefix is accepted and dropped.  When a
  * context is created its options start as the TMC2_* variables of the process environment (read once, there); value NULL
  * unsets an option.  None of them ever changes a result.  Options may be set from any thread while frames of the context are

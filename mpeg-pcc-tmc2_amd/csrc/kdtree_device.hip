@@ -19,17 +19,16 @@
 //   * children: node ids and next-level slots from atomic counters (ids are arbitrary: the traversal follows explicit
 //     child ids; only the ROOT must be node 0), loose boxes handed down, and each child reports its tight range to
 //     the parent's divlow / divhigh when it is measured at the next level.
-// A level is five short launches over <= n points (ranges; split rule + flags + prefix sum; first swaps; second flags +
-// prefix sum; children + second swaps -- the tile totals of a prefix sum are scanned by the block that finishes last, a
-// misplaced element finds its partner by binary search in the prefix sums).  Per-node quantities that cost a handful of loads (split rule, sweep limits) are re-derived per point rather
-// than materialised by extra per-node launches.  Termination needs the host only from the level on at which the tree
-// CAN end (10 * 2^level >= n), and then once per three levels (launches past the last level find nothing to do).
-// The level passes only carry the top of the tree: a segment of at most kRetire points is RETIRED at the level it appears
-// and finished later by one wavefront with its points in LDS (finishSubtreesKernel): nodes down to kLaneMax points by the
-// wave together (the same closed-form sweeps, ranks from ballots), smaller ones by single lanes running nanoflann's
-// recursion literally.  In between, a segment of at most kSplitMax points goes to ONE workgroup (splitSegmentsKernel: points in
-// LDS, a wavefront per node, depth by depth) that cuts it into retired pieces.  A 0.84 M-point frame takes ~ 10 levels of
-// passes instead of ~ 24, one splitting and one finishing launch.
+// A level is five short launches over <= n points (round 5: class flags + prefix sum, first swaps through partner lists, second
+// flags, second swaps + landing, decide -- see "round 5's level passes" below); how many levels the passes run is read back once
+// per tree (the count of the previous tree of this size is queued speculatively).
+// The level passes only carry the top of the tree: a segment of at most 16 384 points (option KD_HUGEMAX) leaves them for ONE
+// workgroup that cuts it into pieces in global memory (hugeSegmentsKernel), and a piece of at most kPieceMax = 4 096 points is
+// finished by one workgroup with its points in LDS, ALL nodes of a depth at once (pieceKernel).
+// Rounds 2-4 finished the subtrees with three other tiers (a workgroup per <= 8 192-point segment with a wavefront per node, a
+// wavefront per <= 512-point subtree, single lanes below 32 points) and round 4 ran its own five launches per level; round 5
+// kept both behind options (KD_FORM=tiers, KD_LEVELS=r4) as a third cross-check next to the host builder and the oracle; round 6
+// took them out of the library (~ 950 lines: git show 5d8d688:mpeg-pcc-tmc2_amd/csrc/kdtree_device.hip).
 // (A single persistent launch with grid-wide barriers was measured too: on this multi-XCD part every barrier is an L2
 // write-back + invalidate per workgroup, ~45 us per pass, and the builds of concurrent frames serialise.  Separate
 // launches leave the gaps of one frame to the passes of the others.)
@@ -47,25 +46,6 @@ constexpr int      kWaves     = kBlock / 64;
 constexpr int      kScanTile  = kBlock * 8;
 constexpr int      kLeafMax   = 10;
 constexpr int      kMaxLevels = 64;    // = the traversal stack of the k-NN kernels
-#ifndef TMC2_KD_RETIRE
-#define TMC2_KD_RETIRE 512
-#endif
-#ifndef TMC2_KD_LANEMAX
-#define TMC2_KD_LANEMAX 32
-#endif
-constexpr int      kRetire    = TMC2_KD_RETIRE;   // segments of at most this many points leave the level passes (one wavefront each)
-constexpr int      kLaneMax   = TMC2_KD_LANEMAX;  // ... and inside a wavefront's subtree, nodes of at most this many points go to single lanes
-constexpr int      kSmallMax  = 64;    // such nodes are handed to the lanes in batches of at most this many
-#ifndef TMC2_KD_SPLITMAX
-#define TMC2_KD_SPLITMAX 8192
-#endif
-// Between the two: a segment of more than kRetire and at most kSplitMax points also leaves the level passes -- one workgroup
-// splits it in LDS (a wavefront per node, level by level) until its pieces are at most kRetire points and joins them to the
-// retired list (splitSegmentsKernel).  Five launches per level are worth it while a level holds hundreds of thousands of points
-// in a few segments; the 0.84 M-point frame needs 15 levels to get every segment below 1 024 points, 10 to get below 8 192.
-constexpr int      kSplitMax  = TMC2_KD_SPLITMAX > TMC2_KD_RETIRE ? TMC2_KD_SPLITMAX : TMC2_KD_RETIRE;
-constexpr int      kSplitWaves = 8;
-constexpr int      kSplitNodes = 2 * ( kSplitMax / kRetire ) + 4;  // nodes of more than kRetire points at one depth of such a segment
 
 struct BuildSeg {
   uint32_t begin, end;    // range in tree order
@@ -106,14 +86,13 @@ struct BuildArgs {
   uint32_t* nodeCount;
   int32_t*  rootBox;    // [6]
   uint32_t* levels;     // out: number of levels
-  RetiredSeg* retired;  // [n / (kRetire / 2) + 2]: every retired segment has a parent of more than kRetire points
+  RetiredSeg* retired;  // the pieces: disjoint segments of more than kLeafMax and at most kPieceMax points
   uint32_t*   retiredCount;
-  RetiredSeg* big;      // segments of more than kRetire and at most kSplitMax points (splitSegmentsKernel)
   uint32_t*   bigCount;
-  HugeSeg*    huge;     // segments of more than kSplitMax and at most hugeMax points (hugeSegmentsKernel)
+  HugeSeg*    huge;     // segments of more than kPieceMax and at most hugeMax points (hugeSegmentsKernel)
   uint32_t*   hugeCount;
   uint32_t    hugeMax;  // (>= splitMax; == splitMax: no such segments)
-  uint32_t    retireMax, splitMax;  // round 4's tiers: kRetire / kSplitMax; pieceKernel: kPieceMax for all three thresholds
+  uint32_t    retireMax, splitMax;  // both kPieceMax (round 4's tiers had two thresholds)
   struct LvSeg *lvA, *lvB;          // round 5's level passes: the segments of a level (by level parity)
   uint16_t*   list;                 // [n rounded up to whole tiles] positions not of a sweep's class, compacted per tile
   struct LvPartial* partial;        // [n / (kLandBlock * kLandRounds) + 1] what a workgroup of the landing pass found for the two children of its segment
@@ -124,514 +103,6 @@ struct BuildArgs {
 };
 
 __device__ __forceinline__ int coordOf( const Pt p, int d ) { return d == 0 ? p.x : ( d == 1 ? p.y : p.z ); }
-
-// leaf or split rule of one segment (kdtree_build.cpp, state 0).  Returns false for a leaf.
-__device__ __forceinline__ bool splitRule( const BuildSeg* q, int& cutDim, int32_t& cut ) {
-  if ( q->end - q->begin <= uint32_t( kLeafMax ) ) return false;
-  const bool root = q->parent == kNone;
-  int32_t    lo[3], hi[3], mn[3], mx[3];
-#pragma unroll
-  for ( int d = 0; d < 3; ++d ) {
-    mn[d] = q->mn[d], mx[d] = q->mx[d];
-    lo[d] = root ? mn[d] : int32_t( q->lo[d] );
-    hi[d] = root ? mx[d] : int32_t( q->hi[d] );
-  }
-  const int32_t maxSpan = max( hi[0] - lo[0], max( hi[1] - lo[1], hi[2] - lo[2] ) );
-  cutDim                = 0;
-  int32_t bestSpread    = -1;
-#pragma unroll
-  for ( int d = 0; d < 3; ++d ) {
-    if ( double( hi[d] - lo[d] ) > ( 1.0 - 0.00001 ) * double( maxSpan ) ) {
-      const int32_t spread = mx[d] - mn[d];
-      if ( spread > bestSpread ) {
-        bestSpread = spread;
-        cutDim     = d;
-      }
-    }
-  }
-  const int32_t l = cutDim == 0 ? lo[0] : ( cutDim == 1 ? lo[1] : lo[2] ), h = cutDim == 0 ? hi[0] : ( cutDim == 1 ? hi[1] : hi[2] );
-  const int32_t a = cutDim == 0 ? mn[0] : ( cutDim == 1 ? mn[1] : mn[2] ), b = cutDim == 0 ? mx[0] : ( cutDim == 1 ? mx[1] : mx[2] );
-  cut             = min( max( ( l + h ) / 2, a ), b );
-  return true;
-}
-
-// exclusive prefix of the class flag at position i: tile-local part + scanned tile totals
-__device__ __forceinline__ uint32_t prefixAt( const uint32_t* __restrict__ loc, const uint32_t* sums, uint32_t tiles,
-                                              uint32_t i, uint32_t n ) {
-  return i < n ? loc[i] + sums[i / kScanTile] : sums[tiles];
-}
-
-// one block: exclusive scan of the tile totals in place, grand total to sums[tiles]
-__device__ __forceinline__ void scanTileTotals( uint32_t* __restrict__ sums, uint32_t tiles, uint32_t* waveSum ) {
-  const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t            carry = 0;
-  for ( uint32_t base = 0; base < tiles; base += kBlock ) {
-    const uint32_t i   = base + threadIdx.x;
-    const uint32_t v   = i < tiles ? __hip_atomic_load( &sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) : 0u;
-    uint32_t       inc = v;
-#pragma unroll
-    for ( int off = 1; off < 64; off <<= 1 ) {
-      const uint32_t t = __shfl_up( inc, off, 64 );
-      if ( lane >= off ) inc += t;
-    }
-    if ( lane == 63 ) waveSum[wave] = inc;
-    __syncthreads();
-    uint32_t offset = carry + inc - v;
-    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
-    if ( i < tiles ) sums[i] = offset;
-    for ( int w = 0; w < kWaves; ++w ) carry += waveSum[w];
-    __syncthreads();
-  }
-  if ( threadIdx.x == 0 ) sums[tiles] = carry;
-}
-
-// The block that finishes LAST scans the tile totals all blocks have written (saves a one-block launch per prefix sum).
-// Hand-off without cache maintenance: the totals are written through (agent-scope stores, drained before the block takes its
-// ticket) and the last block reads them past its L1 (agent-scope loads) -- 4 bytes per block, no L2 write-back.
-__device__ __forceinline__ void storeTileTotal( uint32_t* slot, uint32_t v ) {
-  __hip_atomic_store( slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-}
-__device__ __forceinline__ void lastBlockScansTotals( uint32_t* __restrict__ sums, uint32_t tiles, uint32_t* ticket,
-                                                      uint32_t* waveSum ) {
-  __shared__ uint32_t isLast;
-  __syncthreads();  // (the thread that stored the block's total has drained it)
-  if ( threadIdx.x == 0 ) isLast = atomicAdd( ticket, 1u ) == gridDim.x - 1u ? 1u : 0u;
-  __syncthreads();
-  if ( !isLast ) return;
-  if ( threadIdx.x == 0 ) *ticket = 0;  // (for the next prefix sum; ordered before it by the kernel boundary)
-  scanTileTotals( sums, tiles, waveSum );
-}
-
-// first sweep of a segment, from the first prefix sum: #L (= lim1), prefix at begin and at begin + lim1
-struct Sweep {
-  uint32_t b, edge, m, rb, rm;  // swept range start, end of its left class, #swaps, prefix at b and at edge
-};
-__device__ __forceinline__ Sweep sweepOne( const BuildSeg* q, const uint32_t* __restrict__ loc1, const uint32_t* sums1,
-                                           uint32_t tiles, uint32_t n ) {
-  Sweep s;
-  s.b  = q->begin;
-  s.rb = prefixAt( loc1, sums1, tiles, q->begin, n );
-  const uint32_t re = prefixAt( loc1, sums1, tiles, q->end, n );
-  s.edge            = s.b + ( ( q->end - q->begin ) - ( re - s.rb ) );
-  s.rm              = prefixAt( loc1, sums1, tiles, s.edge, n );
-  s.m               = s.rm - s.rb;
-  return s;
-}
-// second sweep ("<= cut" on [begin + lim1, end)), from the second prefix sum
-__device__ __forceinline__ Sweep sweepTwo( const BuildSeg* q, uint32_t lim1Pos, const uint32_t* __restrict__ loc2,
-                                           const uint32_t* sums2, uint32_t tiles, uint32_t n ) {
-  Sweep s;
-  s.b  = lim1Pos;
-  s.rb = prefixAt( loc2, sums2, tiles, lim1Pos, n );
-  const uint32_t re = prefixAt( loc2, sums2, tiles, q->end, n );
-  s.edge            = s.b + ( ( q->end - lim1Pos ) - ( re - s.rb ) );
-  s.rm              = prefixAt( loc2, sums2, tiles, s.edge, n );
-  s.m               = s.rm - s.rb;
-  return s;
-}
-
-// The partner of a misplaced left-hand element of a sweep: the misplaced right-hand element of the same rank counted from
-// the right end, i.e. the k-th (k = m - 1 - rank, from 0) element of [edge, end) that is NOT flagged.  With h(t) = number of
-// unflagged elements in [edge, t) (from the prefix sum of the flags), it sits at t - 1 for the smallest t with h(t) >= k + 1:
-// a binary search over the prefix sums instead of a published position list (one launch less per sweep).
-__device__ __forceinline__ uint32_t partnerOf( const uint32_t* __restrict__ loc, const uint32_t* sums, uint32_t tiles, uint32_t n,
-                                               uint32_t edge, uint32_t end, uint32_t rm, uint32_t k ) {
-  uint32_t lo = edge + 1, hi = end;
-  while ( lo < hi ) {
-    const uint32_t mid = lo + ( hi - lo ) / 2;
-    const uint32_t h   = ( mid - edge ) - ( prefixAt( loc, sums, tiles, mid, n ) - rm );
-    if ( h >= k + 1 )
-      hi = mid;
-    else
-      lo = mid + 1;
-  }
-  return lo - 1;
-}
-
-__global__ __launch_bounds__( kBlock ) void initKernel( BuildArgs a ) {
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  // ---- init ------------------------------------------------------------------------------------------------
-  for ( uint32_t i = gtid; i < n; i += gsize ) {
-    a.P[i]    = a.pts[i];
-    a.perm[i] = i;
-    a.seg[i]  = 0;
-  }
-  if ( gtid == 0 ) {
-    BuildSeg r{};
-    r.begin  = 0;
-    r.end    = n;
-    r.node   = 0;
-    r.parent = kNone;
-    for ( int d = 0; d < 3; ++d ) r.mn[d] = 0x7FFFFFFF, r.mx[d] = int32_t( 0x80000000 );
-    a.segA[0]    = r;
-    a.counts[0]  = 1;
-    *a.nodeCount = 1;  // node 0 = the root
-  }
-}
-
-__global__ __launch_bounds__( kBlock ) void rangeKernel( BuildArgs a, uint32_t level ) {
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  const uint32_t nRound = ( n + uint32_t( kBlock ) - 1u ) & ~( uint32_t( kBlock ) - 1u );
-  __shared__ uint32_t blockSeg;
-  __shared__ int      blockRange[6 * kWaves];
-  // ---- pass 1: move every point to its segment of this level, accumulate the tight ranges ------------------
-  for ( uint32_t base = blockIdx.x * blockDim.x; base < nRound; base += gsize ) {
-    const uint32_t i = base + threadIdx.x;
-    uint32_t       s = kNone;
-    if ( i < n ) {
-      if ( level == 0 ) {
-        s = 0;
-      } else {
-        const uint32_t so = a.seg[i];
-        if ( so != kNone ) {
-          const BuildSeg* p = other + so;
-          if ( p->split ) s = p->slot + ( i >= p->mid ? 1u : 0u );
-          a.seg[i] = s;
-        }
-      }
-    }
-    int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mnz = 0x7FFFFFFF, mxx = int( 0x80000000 ), mxy = mxx, mxz = mxx;
-    if ( s != kNone ) {
-      const Pt p = a.P[i];
-      mnx = mxx = p.x;
-      mny = mxy = p.y;
-      mnz = mxz = p.z;
-    }
-    // Near the root a whole block sits inside one segment (segments are contiguous): then the block reduces in
-    // registers / LDS and reports ONCE -- otherwise thousands of waves would queue up on the same six words.
-    if ( threadIdx.x == 0 ) blockSeg = s;
-    __syncthreads();
-    const bool uniform = __syncthreads_and( s == blockSeg ) != 0;
-    if ( uniform ) {
-      if ( blockSeg != kNone ) {
-#pragma unroll
-        for ( int off = 32; off > 0; off >>= 1 ) {
-          mnx = min( mnx, __shfl_xor( mnx, off, 64 ) ), mny = min( mny, __shfl_xor( mny, off, 64 ) ), mnz = min( mnz, __shfl_xor( mnz, off, 64 ) );
-          mxx = max( mxx, __shfl_xor( mxx, off, 64 ) ), mxy = max( mxy, __shfl_xor( mxy, off, 64 ) ), mxz = max( mxz, __shfl_xor( mxz, off, 64 ) );
-        }
-        if ( lane == 0 ) {
-          int* w = blockRange + 6 * wave;
-          w[0] = mnx, w[1] = mny, w[2] = mnz, w[3] = mxx, w[4] = mxy, w[5] = mxz;
-        }
-        __syncthreads();
-        if ( threadIdx.x < 6 ) {
-          int v = blockRange[threadIdx.x];
-          for ( int w = 1; w < kWaves; ++w ) v = threadIdx.x < 3 ? min( v, blockRange[6 * w + threadIdx.x] ) : max( v, blockRange[6 * w + threadIdx.x] );
-          BuildSeg* q = cur + blockSeg;
-          int32_t*  slot = threadIdx.x < 3 ? &q->mn[threadIdx.x] : &q->mx[threadIdx.x - 3];
-          if ( threadIdx.x < 3 ) {
-            if ( v < loadStaleOk( slot ) ) atomicMin( slot, v );
-          } else {
-            if ( v > loadStaleOk( slot ) ) atomicMax( slot, v );
-          }
-        }
-      }
-      __syncthreads();
-      continue;
-    }
-    // points of one segment are contiguous: a segmented shuffle reduction leaves each run's range in its first lane
-#pragma unroll
-    for ( int off = 1; off < 64; off <<= 1 ) {
-      const uint32_t os = __shfl_down( s, off, 64 );
-      const int      x0 = __shfl_down( mnx, off, 64 ), y0 = __shfl_down( mny, off, 64 ), z0 = __shfl_down( mnz, off, 64 );
-      const int      x1 = __shfl_down( mxx, off, 64 ), y1 = __shfl_down( mxy, off, 64 ), z1 = __shfl_down( mxz, off, 64 );
-      if ( lane + off < 64 && os == s ) {
-        mnx = min( mnx, x0 ), mny = min( mny, y0 ), mnz = min( mnz, z0 );
-        mxx = max( mxx, x1 ), mxy = max( mxy, y1 ), mxz = max( mxz, z1 );
-      }
-    }
-    const uint32_t ps = __shfl_up( s, 1, 64 );
-    if ( s != kNone && ( lane == 0 || ps != s ) ) {
-      // near the root thousands of waves report to the same record: look first, most have nothing to add
-      BuildSeg* q = cur + s;
-      if ( mnx < loadStaleOk( &q->mn[0] ) ) atomicMin( &q->mn[0], mnx );
-      if ( mny < loadStaleOk( &q->mn[1] ) ) atomicMin( &q->mn[1], mny );
-      if ( mnz < loadStaleOk( &q->mn[2] ) ) atomicMin( &q->mn[2], mnz );
-      if ( mxx > loadStaleOk( &q->mx[0] ) ) atomicMax( &q->mx[0], mxx );
-      if ( mxy > loadStaleOk( &q->mx[1] ) ) atomicMax( &q->mx[1], mxy );
-      if ( mxz > loadStaleOk( &q->mx[2] ) ) atomicMax( &q->mx[2], mxz );
-    }
-  }
-}
-
-__global__ __launch_bounds__( kBlock ) void decideFlagKernel( BuildArgs a, uint32_t level ) {
-  __shared__ uint32_t waveSum[kWaves];
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  // ---- pass 2: per segment: report the range to the parent, leaf record or split rule;
-  //              per point  : first-sweep class flag (the rule is cheap enough to be re-derived per point) -----
-  for ( uint32_t s = gtid; s < count; s += gsize ) {
-    BuildSeg* q = cur + s;
-    if ( q->parent == kNone ) {
-      for ( int d = 0; d < 3; ++d ) a.rootBox[d] = q->mn[d], a.rootBox[3 + d] = q->mx[d];
-    } else {
-      const int pd = q->pdim;
-      if ( q->side == 0 )
-        a.nodes[q->parent].divlow = int16_t( pd == 0 ? q->mx[0] : ( pd == 1 ? q->mx[1] : q->mx[2] ) );
-      else
-        a.nodes[q->parent].divhigh = int16_t( pd == 0 ? q->mn[0] : ( pd == 1 ? q->mn[1] : q->mn[2] ) );
-    }
-    int     cutDim;
-    int32_t cut;
-    const uint32_t cnt = q->end - q->begin;
-    if ( cnt > uint32_t( kLeafMax ) && cnt <= a.retireMax ) {  // the rest of this subtree is built in LDS
-      RetiredSeg r;
-      r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
-      r.root  = q->parent == kNone ? 1 : 0;
-      for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
-      a.retired[atomicAdd( a.retiredCount, 1u )] = r;
-      q->split = 0;
-    } else if ( cnt > a.retireMax && cnt <= a.splitMax ) {  // split further by one workgroup in LDS
-      RetiredSeg r;
-      r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
-      r.root  = q->parent == kNone ? 1 : 0;
-      for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d];
-      a.big[atomicAdd( a.bigCount, 1u )] = r;
-      q->split = 0;
-    } else if ( cnt > a.splitMax && cnt <= a.hugeMax ) {  // ... by one workgroup in global memory
-      HugeSeg r;
-      r.begin = q->begin, r.end = q->end, r.node = q->node, r.level = level;
-      r.root  = q->parent == kNone ? 1 : 0;
-      for ( int d = 0; d < 3; ++d ) r.lo[d] = q->lo[d], r.hi[d] = q->hi[d], r.mn[d] = q->mn[d], r.mx[d] = q->mx[d];
-      a.huge[atomicAdd( a.hugeCount, 1u )] = r;
-      q->split = 0;
-    } else if ( splitRule( q, cutDim, cut ) ) {
-      q->split = 1, q->cutDim = uint8_t( cutDim ), q->cut = cut;
-    } else {
-      KdNode nd;
-      nd.a = int32_t( q->begin ), nd.b = int32_t( q->end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
-      a.nodes[q->node] = nd;
-      q->split         = 0;
-    }
-  }
-  for ( uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x ) {
-    const uint32_t base = tile * kScanTile + threadIdx.x * 8;
-    uint32_t       v[8], run = 0;
-#pragma unroll
-    for ( int k = 0; k < 8; ++k ) {
-      const uint32_t i = base + k;
-      uint32_t       f = 0;
-      if ( i < n ) {
-        const uint32_t s = a.seg[i];
-        if ( s != kNone ) {
-          int     cutDim;
-          int32_t cut;
-          const BuildSeg* q = cur + s;
-          if ( q->end - q->begin > a.hugeMax && splitRule( q, cutDim, cut ) ) f = coordOf( a.P[i], cutDim ) >= cut;
-        }
-      }
-      v[k] = f;
-      run += f;
-    }
-    uint32_t inc = run;
-#pragma unroll
-    for ( int off = 1; off < 64; off <<= 1 ) {
-      const uint32_t t = __shfl_up( inc, off, 64 );
-      if ( lane >= off ) inc += t;
-    }
-    if ( lane == 63 ) waveSum[wave] = inc;
-    __syncthreads();
-    uint32_t offset = inc - run;
-    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
-#pragma unroll
-    for ( int k = 0; k < 8; ++k ) {
-      if ( base + k < n ) a.loc1[base + k] = offset;
-      offset += v[k];
-    }
-    if ( threadIdx.x == kBlock - 1 ) storeTileTotal( &a.tile1[tile], offset );
-    __syncthreads();
-  }
-  lastBlockScansTotals( a.tile1, tiles, a.ticket, waveSum );
-}
-
-__global__ __launch_bounds__( kBlock ) void swapOneKernel( BuildArgs a, uint32_t level ) {
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  // ---- pass 4: first sweep, misplaced left-hand elements swap with the published position of equal rank -----
-  for ( uint32_t i = gtid; i < n; i += gsize ) {
-    const uint32_t s = a.seg[i];
-    if ( s == kNone ) continue;
-    const BuildSeg* q = cur + s;
-    if ( !q->split ) continue;
-    const Sweep w = sweepOne( q, a.loc1, sums1, tiles, n );
-    if ( i >= w.edge ) continue;
-    const Pt pi = a.P[i];
-    if ( coordOf( pi, q->cutDim ) < q->cut ) continue;
-    const uint32_t r  = ( a.loc1[i] + sums1[i / kScanTile] ) - w.rb;
-    const uint32_t j  = partnerOf( a.loc1, sums1, tiles, n, w.edge, q->end, w.rm, w.m - 1u - r );
-    const Pt       pj = a.P[j];
-    a.P[i]            = pj;
-    a.P[j]            = pi;
-    const uint32_t t  = a.perm[i];
-    a.perm[i]         = a.perm[j];
-    a.perm[j]         = t;
-  }
-}
-
-__global__ __launch_bounds__( kBlock ) void flagTwoKernel( BuildArgs a, uint32_t level ) {
-  __shared__ uint32_t waveSum[kWaves];
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  // ---- pass 5: second-sweep class flag ("> cut" on [begin + lim1, end)) ---------------------------------------
-  for ( uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x ) {
-    const uint32_t base = tile * kScanTile + threadIdx.x * 8;
-    uint32_t       v[8], run = 0;
-#pragma unroll
-    for ( int k = 0; k < 8; ++k ) {
-      const uint32_t i = base + k;
-      uint32_t       f = 0;
-      if ( i < n ) {
-        const uint32_t s = a.seg[i];
-        if ( s != kNone ) {
-          const BuildSeg* q = cur + s;
-          if ( q->split && coordOf( a.P[i], q->cutDim ) > q->cut ) f = i >= sweepOne( q, a.loc1, sums1, tiles, n ).edge;
-        }
-      }
-      v[k] = f;
-      run += f;
-    }
-    uint32_t inc = run;
-#pragma unroll
-    for ( int off = 1; off < 64; off <<= 1 ) {
-      const uint32_t t = __shfl_up( inc, off, 64 );
-      if ( lane >= off ) inc += t;
-    }
-    if ( lane == 63 ) waveSum[wave] = inc;
-    __syncthreads();
-    uint32_t offset = inc - run;
-    for ( int w = 0; w < wave; ++w ) offset += waveSum[w];
-#pragma unroll
-    for ( int k = 0; k < 8; ++k ) {
-      if ( base + k < n ) a.loc2[base + k] = offset;
-      offset += v[k];
-    }
-    if ( threadIdx.x == kBlock - 1 ) storeTileTotal( &a.tile2[tile], offset );
-    __syncthreads();
-  }
-  lastBlockScansTotals( a.tile2, tiles, a.ticket, waveSum );
-}
-
-// per segment of a level: lim2, the balance rule, the node record and the two children (next level's segments)
-__device__ __forceinline__ void createChildren( const BuildArgs& a, uint32_t level, BuildSeg* cur, BuildSeg* other, uint32_t count,
-                                                const uint32_t* sums1, const uint32_t* sums2, uint32_t gtid, uint32_t gsize ) {
-  const uint32_t n = a.n, tiles = a.tiles;
-  for ( uint32_t s = gtid; s < count; s += gsize ) {
-    BuildSeg* q = cur + s;
-    if ( !q->split ) continue;
-    const Sweep    w1   = sweepOne( q, a.loc1, sums1, tiles, n );
-    const Sweep    w2   = sweepTwo( q, w1.edge, a.loc2, sums2, tiles, n );
-    const uint32_t cnt  = q->end - q->begin, half = cnt / 2, lim1 = w1.edge - q->begin, lim2 = w2.edge - q->begin;
-    const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
-    const uint32_t mid  = q->begin + idx;
-    const uint32_t id   = atomicAdd( a.nodeCount, 2u );
-    const uint32_t sl   = atomicAdd( &a.counts[level + 1], 2u );
-    q->mid              = mid;
-    q->slot             = sl;
-    KdNode nd;
-    nd.a = int32_t( id ), nd.b = int32_t( id + 1 ), nd.divlow = nd.divhigh = 0, nd.dim = q->cutDim;
-    a.nodes[q->node] = nd;
-    const bool root  = q->parent == kNone;
-    BuildSeg   c{};
-    c.parent = q->node;
-    c.pdim   = q->cutDim;
-    for ( int d = 0; d < 3; ++d ) {
-      c.mn[d] = 0x7FFFFFFF, c.mx[d] = int32_t( 0x80000000 );
-      c.lo[d] = root ? int16_t( q->mn[d] ) : q->lo[d];
-      c.hi[d] = root ? int16_t( q->mx[d] ) : q->hi[d];
-    }
-    BuildSeg l = c, r = c;
-    l.begin = q->begin, l.end = mid, l.node = id, l.side = 0;
-    r.begin = mid, r.end = q->end, r.node = id + 1, r.side = 1;
-    const int16_t cut = int16_t( q->cut );
-    if ( q->cutDim == 0 ) l.hi[0] = cut, r.lo[0] = cut;
-    if ( q->cutDim == 1 ) l.hi[1] = cut, r.lo[1] = cut;
-    if ( q->cutDim == 2 ) l.hi[2] = cut, r.lo[2] = cut;
-    other[sl]     = l;
-    other[sl + 1] = r;
-  }
-}
-
-__global__ __launch_bounds__( kBlock ) void swapTwoKernel( BuildArgs a, uint32_t level ) {
-  const uint32_t n = a.n, tiles = a.tiles;
-  const uint32_t gsize = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)tiles, (void)gsize, (void)gtid, (void)lane, (void)wave;
-  BuildSeg*       cur   = ( level & 1 ) ? a.segB : a.segA;
-  BuildSeg*       other = ( level & 1 ) ? a.segA : a.segB;  // previous level's segments, then the next level's
-  const uint32_t  count = a.counts[level];
-  const uint32_t* sums1 = a.tile1;
-  const uint32_t* sums2 = a.tile2;
-  (void)cur, (void)other, (void)count, (void)sums1, (void)sums2;
-  // ---- pass 6: the children of every split segment (independent of the swaps below: it reads the prefix sums only)
-  createChildren( a, level, cur, other, count, sums1, sums2, gtid, gsize );
-  // ---- pass 7: second sweep, swap --------------------------------------------------------------------------------
-  for ( uint32_t i = gtid; i < n; i += gsize ) {
-    const uint32_t s = a.seg[i];
-    if ( s == kNone ) continue;
-    const BuildSeg* q = cur + s;
-    if ( !q->split ) continue;
-    const uint32_t lim1Pos = sweepOne( q, a.loc1, sums1, tiles, n ).edge;
-    if ( i < lim1Pos ) continue;
-    const Sweep w = sweepTwo( q, lim1Pos, a.loc2, sums2, tiles, n );
-    if ( i >= w.edge ) continue;
-    const Pt pi = a.P[i];
-    if ( coordOf( pi, q->cutDim ) <= q->cut ) continue;
-    const uint32_t r  = ( a.loc2[i] + sums2[i / kScanTile] ) - w.rb;
-    const uint32_t j  = partnerOf( a.loc2, sums2, tiles, n, w.edge, q->end, w.rm, w.m - 1u - r );
-    const Pt       pj = a.P[j];
-    a.P[i]            = pj;
-    a.P[j]            = pi;
-    const uint32_t t  = a.perm[i];
-    a.perm[i]         = a.perm[j];
-    a.perm[j]         = t;
-  }
-}
-
-
-// ---- the retired subtrees, one wavefront each, points in LDS ----------------------------------------------------------------
-struct SubNode {  // a node of the subtree waiting to be processed (wave stack / small-node list / lane stack)
-  uint16_t begin, end;  // range inside the segment
-  uint32_t node;        // node id (allocated by the parent)
-  int16_t  lo[3], hi[3];
-  uint16_t depth;       // levels below the segment's root
-};
 
 struct SplitRule {
   int     dim;
@@ -659,421 +130,6 @@ __device__ __forceinline__ SplitRule splitOf( const int16_t ( &lo )[3], const in
   r.cut           = min( max( ( l + h ) / 2, a ), b );
   return r;
 }
-
-__device__ __forceinline__ void waveFence() { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); }
-
-// One sweep of the two-pass partition by a wavefront, on P[0..count) / perm[0..count) in LDS: left class = "value < c", nL of
-// them.  The i-th misplaced element from the left swaps with the i-th misplaced element from the right (ranks from ballots).
-__device__ __forceinline__ void waveSweep( Pt* P, uint32_t* perm, uint32_t count, uint32_t nL, int dim, int32_t c, uint16_t* lst,
-                                           int lane ) {
-  uint16_t* fromLeft  = lst;
-  uint16_t* fromRight = lst + nL + 1;
-  uint32_t  m         = 0;
-  for ( uint32_t i0 = 0; i0 < nL; i0 += 64 ) {
-    const uint32_t i = i0 + lane;
-    const bool     f = i < nL && coordOf( P[i], dim ) >= c;
-    const unsigned long long b = __ballot( f );
-    if ( f ) fromLeft[m + __popcll( b & ( ( 1ull << lane ) - 1ull ) )] = uint16_t( i );
-    m += uint32_t( __popcll( b ) );
-  }
-  uint32_t m2 = 0;
-  for ( uint32_t top = count; top > nL; ) {  // descending: lane 0 holds the highest position of the chunk
-    const uint32_t span = min( 64u, top - nL );
-    const bool     in   = uint32_t( lane ) < span;
-    const uint32_t j    = in ? top - 1u - uint32_t( lane ) : 0u;
-    const bool     f    = in && coordOf( P[j], dim ) < c;
-    const unsigned long long b = __ballot( f );
-    if ( f ) fromRight[m2 + __popcll( b & ( ( 1ull << lane ) - 1ull ) )] = uint16_t( j );
-    m2 += uint32_t( __popcll( b ) );
-    top -= span;
-  }
-  waveFence();
-  for ( uint32_t t = lane; t < m; t += 64 ) {  // (m == m2: every misplaced element on one side has its partner on the other)
-    const uint32_t x = fromLeft[t], y = fromRight[t];
-    const Pt       px = P[x], py = P[y];
-    const uint32_t ix = perm[x], iy = perm[y];
-    P[x] = py, P[y] = px, perm[x] = iy, perm[y] = ix;
-  }
-  waveFence();
-}
-
-// tight ranges of pts[0..count) on the three dimensions, by a wavefront
-__device__ __forceinline__ void waveTightRange( const Pt* pts, uint32_t count, int lane, int32_t ( &mn )[3], int32_t ( &mx )[3] ) {
-  int mn0 = 0x7FFFFFFF, mn1 = mn0, mn2 = mn0, mx0 = int( 0x80000000 ), mx1 = mx0, mx2 = mx0;
-  for ( uint32_t i = lane; i < count; i += 64 ) {
-    const Pt p = pts[i];
-    mn0 = min( mn0, int( p.x ) ), mx0 = max( mx0, int( p.x ) );
-    mn1 = min( mn1, int( p.y ) ), mx1 = max( mx1, int( p.y ) );
-    mn2 = min( mn2, int( p.z ) ), mx2 = max( mx2, int( p.z ) );
-  }
-#pragma unroll
-  for ( int off = 32; off > 0; off >>= 1 ) {
-    mn0 = min( mn0, __shfl_xor( mn0, off, 64 ) ), mn1 = min( mn1, __shfl_xor( mn1, off, 64 ) ), mn2 = min( mn2, __shfl_xor( mn2, off, 64 ) );
-    mx0 = max( mx0, __shfl_xor( mx0, off, 64 ) ), mx1 = max( mx1, __shfl_xor( mx1, off, 64 ) ), mx2 = max( mx2, __shfl_xor( mx2, off, 64 ) );
-  }
-  mn[0] = mn0, mn[1] = mn1, mn[2] = mn2, mx[0] = mx0, mx[1] = mx1, mx[2] = mx2;
-}
-
-// One node of more than kLeafMax points split by a wavefront on its slice of the LDS arrays: nanoflann's middleSplit_ +
-// planeSplit (both sweeps) + the balance rule; returns the rule, the size of the left child and the tight ranges of the two
-// children on the cut dimension (the parent's divlow / divhigh).
-struct NodeSplit {
-  SplitRule rule;
-  uint32_t  idx;
-  int       lmax, rmin;
-};
-__device__ __forceinline__ NodeSplit waveSplitNode( Pt* pts, uint32_t* id, uint32_t count, const int16_t ( &lo )[3],
-                                                    const int16_t ( &hi )[3], const int32_t ( &mn )[3], const int32_t ( &mx )[3],
-                                                    uint16_t* lst, int lane ) {
-  NodeSplit ns;
-  ns.rule           = splitOf( lo, hi, mn, mx );
-  const SplitRule r = ns.rule;
-  // class counts of both sweeps in one pass
-  uint32_t lt = 0, le = 0;
-  for ( uint32_t i = lane; i < count; i += 64 ) {
-    const int32_t x = coordOf( pts[i], r.dim );
-    lt += uint32_t( x < r.cut ), le += uint32_t( x <= r.cut );
-  }
-#pragma unroll
-  for ( int off = 32; off > 0; off >>= 1 ) lt += __shfl_xor( lt, off, 64 ), le += __shfl_xor( le, off, 64 );
-  waveSweep( pts, id, count, lt, r.dim, r.cut, lst, lane );
-  waveSweep( pts + lt, id + lt, count - lt, le - lt, r.dim, r.cut + 1, lst, lane );
-  const uint32_t half = count / 2;
-  ns.idx              = lt > half ? lt : ( le < half ? le : half );
-  int lmax = int( 0x80000000 ), rmin = 0x7FFFFFFF;
-  for ( uint32_t i = lane; i < count; i += 64 ) {
-    const int x = coordOf( pts[i], r.dim );
-    if ( i < ns.idx ) lmax = max( lmax, x ); else rmin = min( rmin, x );
-  }
-#pragma unroll
-  for ( int off = 32; off > 0; off >>= 1 ) lmax = max( lmax, __shfl_xor( lmax, off, 64 ) ), rmin = min( rmin, __shfl_xor( rmin, off, 64 ) );
-  ns.lmax = lmax, ns.rmin = rmin;
-  return ns;
-}
-
-// nanoflann's divideTree on P[b..e) by ONE lane (literal two-pass planeSplit with std::swap semantics), explicit stack.
-// Node ids come from the one global counter in chunks of kLaneIdChunk (an atomic per node on a single address, ~ 10 ns each,
-// ~ 130 K per tree, was most of the finishing kernel); what is left of the last chunk stays unused (host: maxNode).
-constexpr uint32_t kLaneIdChunk = 16;
-__device__ void laneSubtree( Pt* P, uint32_t* perm, const SubNode root, uint32_t globalBegin, KdNode* __restrict__ nodes,
-                             uint32_t* __restrict__ nodeCount, uint32_t& maxDepth, uint32_t* __restrict__ refuse ) {
-  uint32_t idNext = 0, idEnd = 0;
-  SubNode stack[kLaneMax + 8];  // a node of at most kLaneMax points is at most kLaneMax - kLeafMax levels deep
-  int     sp  = 0;
-  stack[sp++] = root;
-  while ( sp > 0 ) {
-    const SubNode  q     = stack[--sp];
-    const uint32_t count = uint32_t( q.end ) - q.begin;
-    maxDepth             = max( maxDepth, uint32_t( q.depth ) );
-    if ( count <= uint32_t( kLeafMax ) ) {
-      KdNode nd;
-      nd.a = int32_t( globalBegin + q.begin ), nd.b = int32_t( globalBegin + q.end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
-      nodes[q.node] = nd;
-      continue;
-    }
-    Pt*      pts = P + q.begin;
-    uint32_t* id = perm + q.begin;
-    int32_t  mn[3] = {pts[0].x, pts[0].y, pts[0].z}, mx[3] = {pts[0].x, pts[0].y, pts[0].z};
-    for ( uint32_t i = 1; i < count; ++i ) {
-      const Pt p = pts[i];
-      mn[0] = min( mn[0], int32_t( p.x ) ), mx[0] = max( mx[0], int32_t( p.x ) );
-      mn[1] = min( mn[1], int32_t( p.y ) ), mx[1] = max( mx[1], int32_t( p.y ) );
-      mn[2] = min( mn[2], int32_t( p.z ) ), mx[2] = max( mx[2], int32_t( p.z ) );
-    }
-    const SplitRule r = splitOf( q.lo, q.hi, mn, mx );
-    // planeSplit (nanoflann.hpp:1154-1181): two Hoare sweeps with swaps
-    uint32_t left = 0, right = count - 1;
-    for ( ;; ) {
-      while ( left <= right && coordOf( pts[left], r.dim ) < r.cut ) ++left;
-      while ( right && left <= right && coordOf( pts[right], r.dim ) >= r.cut ) --right;
-      if ( left > right || !right ) break;
-      const Pt       tp = pts[left];
-      const uint32_t ti = id[left];
-      pts[left] = pts[right], id[left] = id[right], pts[right] = tp, id[right] = ti;
-      ++left;
-      --right;
-    }
-    const uint32_t lim1 = left;
-    right               = count - 1;
-    for ( ;; ) {
-      while ( left <= right && coordOf( pts[left], r.dim ) <= r.cut ) ++left;
-      while ( right && left <= right && coordOf( pts[right], r.dim ) > r.cut ) --right;
-      if ( left > right || !right ) break;
-      const Pt       tp = pts[left];
-      const uint32_t ti = id[left];
-      pts[left] = pts[right], id[left] = id[right], pts[right] = tp, id[right] = ti;
-      ++left;
-      --right;
-    }
-    const uint32_t lim2 = left, half = count / 2;
-    const uint32_t idx  = lim1 > half ? lim1 : ( lim2 < half ? lim2 : half );
-    int32_t        lmax = int32_t( 0x80000000 ), rmin = 0x7FFFFFFF;  // tight ranges of the children on the cut dimension
-    for ( uint32_t i = 0; i < idx; ++i ) lmax = max( lmax, coordOf( pts[i], r.dim ) );
-    for ( uint32_t i = idx; i < count; ++i ) rmin = min( rmin, coordOf( pts[i], r.dim ) );
-    if ( idNext == idEnd ) {
-      idNext = atomicAdd( nodeCount, kLaneIdChunk );
-      idEnd  = idNext + kLaneIdChunk;
-    }
-    const uint32_t id0 = idNext;
-    idNext += 2;
-    KdNode         nd;
-    nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( lmax ), nd.divhigh = int16_t( rmin ), nd.dim = r.dim;
-    nodes[q.node] = nd;
-    SubNode l = q, rr = q;
-    l.end = uint16_t( q.begin + idx ), l.node = id0, l.depth = uint16_t( q.depth + 1 );
-    rr.begin = uint16_t( q.begin + idx ), rr.node = id0 + 1, rr.depth = uint16_t( q.depth + 1 );
-    const int16_t cut = int16_t( r.cut );
-    if ( r.dim == 0 ) l.hi[0] = cut, rr.lo[0] = cut;
-    if ( r.dim == 1 ) l.hi[1] = cut, rr.lo[1] = cut;
-    if ( r.dim == 2 ) l.hi[2] = cut, rr.lo[2] = cut;
-    if ( sp > kLaneMax + 5 ) {  // (cannot happen for kLaneMax points; never write past the stack)
-      atomicMax( refuse, 0x10000u );
-      return;
-    }
-    stack[sp++] = rr;
-    stack[sp++] = l;
-  }
-}
-
-constexpr int kFinishWaves = kRetire <= 512 ? 4 : 2;  // (< 64 KB of LDS per workgroup: several workgroups per CU)
-// (node ids of the nodes a wavefront splits together: in chunks as well)
-constexpr uint32_t kIdChunk      = 256;
-constexpr uint32_t kFinishBlocks = 1024;  // at most this many workgroups: what the chunks can waste is bounded (host: maxNode)
-struct IdRange {
-  uint32_t next, end;
-};
-__device__ __forceinline__ uint32_t reserveIds( IdRange& r, uint32_t k, uint32_t* __restrict__ nodeCount, int lane ) {  // (wave-uniform)
-  if ( r.next + k > r.end ) {
-    const uint32_t take = max( k, kIdChunk );
-    uint32_t       base = 0;
-    if ( lane == 0 ) base = atomicAdd( nodeCount, take );
-    base   = __shfl( base, 0, 64 );
-    r.next = base;
-    r.end  = base + take;
-  }
-  const uint32_t first = r.next;
-  r.next += k;
-  return first;
-}
-__global__ __launch_bounds__( 64 * kFinishWaves ) void finishSubtreesKernel( BuildArgs a ) {
-  __shared__ Pt       sP[kFinishWaves][kRetire];
-  __shared__ uint32_t sPerm[kFinishWaves][kRetire];
-  __shared__ uint16_t sList[kFinishWaves][kRetire + 4];
-  __shared__ SubNode  sStack[kFinishWaves][kMaxLevels + 2];
-  __shared__ SubNode  sSmall[kFinishWaves][kSmallMax];
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t total = *a.retiredCount;
-  Pt*            P     = sP[wave];
-  uint32_t*      perm  = sPerm[wave];
-  uint16_t*      lst   = sList[wave];
-  SubNode*       stack = sStack[wave];
-  SubNode*       small = sSmall[wave];
-  uint32_t       maxDepth = 0;
-  IdRange        ids{0, 0};
-  for ( uint32_t s = blockIdx.x * kFinishWaves + wave; s < total; s += gridDim.x * kFinishWaves ) {  // (uniform per wave)
-    const RetiredSeg seg = a.retired[s];
-    const uint32_t   cnt = seg.end - seg.begin;
-    for ( uint32_t i = lane; i < cnt; i += 64 ) {
-      P[i]    = a.P[seg.begin + i];
-      perm[i] = a.perm[seg.begin + i];
-    }
-    waveFence();
-    int sp = 0, nSmall = 0;
-    if ( lane == 0 ) {
-      SubNode r;
-      r.begin = 0, r.end = uint16_t( cnt ), r.node = seg.node, r.depth = 0;
-      for ( int d = 0; d < 3; ++d ) r.lo[d] = seg.lo[d], r.hi[d] = seg.hi[d];
-      stack[0] = r;
-    }
-    sp = 1;
-    bool isRoot = seg.root != 0;
-    waveFence();
-    while ( sp > 0 ) {
-      const SubNode  q     = stack[--sp];
-      const uint32_t count = uint32_t( q.end ) - q.begin;
-      if ( uint32_t( q.depth ) + seg.level >= uint32_t( kMaxLevels ) - 1u ) {  // deeper than the k-NN traversal stack: refused
-        if ( lane == 0 ) atomicMax( a.finishDepth, 0x10000u );
-        break;
-      }
-      if ( nSmall == kSmallMax ) {  // (a degenerate subtree can shed hundreds of tiny nodes: the lanes take them in batches)
-        waveFence();
-        uint32_t d = 0;
-        for ( int t = lane; t < nSmall; t += 64 ) laneSubtree( P, perm, small[t], seg.begin, a.nodes, a.nodeCount, d, a.finishDepth );
-#pragma unroll
-        for ( int off = 32; off > 0; off >>= 1 ) d = max( d, __shfl_xor( d, off, 64 ) );
-        maxDepth = max( maxDepth, d );
-        nSmall   = 0;
-        waveFence();
-      }
-      if ( count <= uint32_t( kLaneMax ) && !isRoot ) {  // (the tree's root needs its tight range as loose box: handled below)
-        if ( lane == 0 ) small[nSmall] = q;
-        ++nSmall;
-        continue;
-      }
-      Pt*       pts = P + q.begin;
-      uint32_t* id  = perm + q.begin;
-      int32_t mn[3], mx[3];
-      waveTightRange( pts, count, lane, mn, mx );
-      int16_t       lo[3], hi[3];
-      for ( int d = 0; d < 3; ++d ) lo[d] = isRoot ? int16_t( mn[d] ) : q.lo[d], hi[d] = isRoot ? int16_t( mx[d] ) : q.hi[d];
-      if ( isRoot && lane == 0 )
-        for ( int d = 0; d < 3; ++d ) a.rootBox[d] = mn[d], a.rootBox[3 + d] = mx[d];
-      isRoot = false;
-      if ( count <= uint32_t( kLeafMax ) ) {  // (only a root of at most kLeafMax points gets here)
-        if ( lane == 0 ) {
-          KdNode nd;
-          nd.a = int32_t( seg.begin + q.begin ), nd.b = int32_t( seg.begin + q.end ), nd.divlow = nd.divhigh = 0, nd.dim = -1;
-          a.nodes[q.node] = nd;
-        }
-        maxDepth = max( maxDepth, uint32_t( q.depth ) );
-        continue;
-      }
-      if ( count <= uint32_t( kLaneMax ) ) {  // a small root: to the lanes, with its loose box resolved
-        if ( lane == 0 ) {
-          SubNode t = q;
-          for ( int d = 0; d < 3; ++d ) t.lo[d] = lo[d], t.hi[d] = hi[d];
-          small[nSmall] = t;
-        }
-        ++nSmall;
-        continue;
-      }
-      const NodeSplit ns   = waveSplitNode( pts, id, count, lo, hi, mn, mx, lst, lane );
-      const SplitRule r    = ns.rule;
-      const uint32_t  idx  = ns.idx;
-      const int       lmax = ns.lmax, rmin = ns.rmin;
-      const uint32_t id0 = reserveIds( ids, 2u, a.nodeCount, lane );
-      if ( lane == 0 ) {
-        KdNode nd;
-        nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( lmax ), nd.divhigh = int16_t( rmin ), nd.dim = r.dim;
-        a.nodes[q.node] = nd;
-        SubNode l, rr;
-        l.begin = q.begin, l.end = uint16_t( q.begin + idx ), l.node = id0, l.depth = uint16_t( q.depth + 1 );
-        rr.begin = uint16_t( q.begin + idx ), rr.end = q.end, rr.node = id0 + 1, rr.depth = uint16_t( q.depth + 1 );
-        for ( int d = 0; d < 3; ++d ) l.lo[d] = rr.lo[d] = lo[d], l.hi[d] = rr.hi[d] = hi[d];
-        const int16_t cut = int16_t( r.cut );
-        if ( r.dim == 0 ) l.hi[0] = cut, rr.lo[0] = cut;
-        if ( r.dim == 1 ) l.hi[1] = cut, rr.lo[1] = cut;
-        if ( r.dim == 2 ) l.hi[2] = cut, rr.lo[2] = cut;
-        stack[sp]     = rr;
-        stack[sp + 1] = l;
-      }
-      sp += 2;
-      maxDepth = max( maxDepth, uint32_t( q.depth ) );
-      waveFence();
-    }
-    // the small nodes, one lane each
-    waveFence();
-    uint32_t laneDepth = 0;
-    for ( int t = lane; t < nSmall; t += 64 ) laneSubtree( P, perm, small[t], seg.begin, a.nodes, a.nodeCount, laneDepth, a.finishDepth );
-#pragma unroll
-    for ( int off = 32; off > 0; off >>= 1 ) laneDepth = max( laneDepth, __shfl_xor( laneDepth, off, 64 ) );
-    maxDepth = max( maxDepth, laneDepth );
-    waveFence();
-    for ( uint32_t i = lane; i < cnt; i += 64 ) {
-      a.P[seg.begin + i]    = P[i];
-      a.perm[seg.begin + i] = perm[i];
-    }
-    waveFence();
-    if ( lane == 0 ) atomicMax( a.finishDepth, seg.level + maxDepth + 1u );  // levels down to the deepest node of this subtree
-    maxDepth = 0;
-  }
-}
-
-// ---- segments of kRetire .. kSplitMax points: one workgroup each, points in LDS, one wavefront per node, depth by depth ----
-__global__ __launch_bounds__( 64 * kSplitWaves ) void splitSegmentsKernel( BuildArgs a ) {
-  extern __shared__ unsigned char splitLds[];
-  Pt*       P       = reinterpret_cast<Pt*>( splitLds );
-  uint32_t* perm    = reinterpret_cast<uint32_t*>( P + kSplitMax );
-  uint16_t* scratch = reinterpret_cast<uint16_t*>( perm + kSplitMax );  // [2 * kSplitMax]: a node's sweep lists at 2 * its begin
-  __shared__ SubNode  sNode[2][kSplitNodes];
-  __shared__ uint32_t sCount[2];
-  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t total = *a.bigCount;
-  for ( uint32_t s = blockIdx.x; s < total; s += gridDim.x ) {
-    const RetiredSeg seg = a.big[s];
-    const uint32_t   cnt = seg.end - seg.begin;
-    for ( uint32_t i = threadIdx.x; i < cnt; i += blockDim.x ) {
-      P[i]    = a.P[seg.begin + i];
-      perm[i] = a.perm[seg.begin + i];
-    }
-    if ( threadIdx.x == 0 ) {
-      SubNode r;
-      r.begin = 0, r.end = uint16_t( cnt ), r.node = seg.node, r.depth = 0;
-      for ( int d = 0; d < 3; ++d ) r.lo[d] = seg.lo[d], r.hi[d] = seg.hi[d];
-      sNode[0][0] = r;
-      sCount[0] = 1, sCount[1] = 0;
-    }
-    __syncthreads();
-    int cur = 0;
-    for ( uint32_t depth = 0;; ++depth ) {
-      const uint32_t nCur = sCount[cur];
-      if ( nCur == 0 ) break;
-      for ( uint32_t t = wave; t < nCur; t += kSplitWaves ) {  // (uniform per wave)
-        const SubNode  q     = sNode[cur][t];
-        const uint32_t count = uint32_t( q.end ) - q.begin;
-        if ( uint32_t( q.depth ) + seg.level >= uint32_t( kMaxLevels ) - 2u ) {  // deeper than the k-NN traversal stack: refused
-          if ( lane == 0 ) atomicMax( a.finishDepth, 0x10000u );
-          continue;
-        }
-        Pt*       pts = P + q.begin;
-        uint32_t* id  = perm + q.begin;
-        int32_t   mn[3], mx[3];
-        waveTightRange( pts, count, lane, mn, mx );
-        const bool isRoot = seg.root != 0 && depth == 0;  // the tree's root: its loose box is its tight range
-        int16_t    lo[3], hi[3];
-        for ( int d = 0; d < 3; ++d ) lo[d] = isRoot ? int16_t( mn[d] ) : q.lo[d], hi[d] = isRoot ? int16_t( mx[d] ) : q.hi[d];
-        if ( isRoot && lane == 0 )
-          for ( int d = 0; d < 3; ++d ) a.rootBox[d] = mn[d], a.rootBox[3 + d] = mx[d];
-        const NodeSplit ns = waveSplitNode( pts, id, count, lo, hi, mn, mx, scratch + 2 * size_t( q.begin ), lane );
-        if ( lane == 0 ) {
-          const uint32_t id0 = atomicAdd( a.nodeCount, 2u );
-          KdNode         nd;
-          nd.a = int32_t( id0 ), nd.b = int32_t( id0 + 1 ), nd.divlow = int16_t( ns.lmax ), nd.divhigh = int16_t( ns.rmin ),
-          nd.dim = ns.rule.dim;
-          a.nodes[q.node] = nd;
-          SubNode child[2];
-          child[0].begin = q.begin, child[0].end = uint16_t( q.begin + ns.idx ), child[0].node = id0;
-          child[1].begin = uint16_t( q.begin + ns.idx ), child[1].end = q.end, child[1].node = id0 + 1;
-          for ( int c = 0; c < 2; ++c ) {
-            child[c].depth = uint16_t( q.depth + 1 );
-            for ( int d = 0; d < 3; ++d ) child[c].lo[d] = lo[d], child[c].hi[d] = hi[d];
-          }
-          const int16_t cut = int16_t( ns.rule.cut );
-          if ( ns.rule.dim == 0 ) child[0].hi[0] = cut, child[1].lo[0] = cut;
-          if ( ns.rule.dim == 1 ) child[0].hi[1] = cut, child[1].lo[1] = cut;
-          if ( ns.rule.dim == 2 ) child[0].hi[2] = cut, child[1].lo[2] = cut;
-          for ( int c = 0; c < 2; ++c ) {
-            const uint32_t cc = uint32_t( child[c].end ) - child[c].begin, level = seg.level + child[c].depth;
-            if ( cc <= uint32_t( kLeafMax ) ) {
-              KdNode leaf;
-              leaf.a = int32_t( seg.begin + child[c].begin ), leaf.b = int32_t( seg.begin + child[c].end ), leaf.divlow = leaf.divhigh = 0,
-              leaf.dim = -1;
-              a.nodes[child[c].node] = leaf;
-              atomicMax( a.finishDepth, level + 1u );
-            } else if ( cc <= uint32_t( kRetire ) ) {
-              RetiredSeg r;
-              r.begin = seg.begin + child[c].begin, r.end = seg.begin + child[c].end, r.node = child[c].node, r.level = level, r.root = 0;
-              for ( int d = 0; d < 3; ++d ) r.lo[d] = child[c].lo[d], r.hi[d] = child[c].hi[d];
-              a.retired[atomicAdd( a.retiredCount, 1u )] = r;
-            } else {
-              sNode[cur ^ 1][atomicAdd( &sCount[cur ^ 1], 1u )] = child[c];
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if ( threadIdx.x == 0 ) sCount[cur] = 0;
-      cur ^= 1;
-      __syncthreads();
-    }
-    for ( uint32_t i = threadIdx.x; i < cnt; i += blockDim.x ) {
-      a.P[seg.begin + i]    = P[i];
-      a.perm[seg.begin + i] = perm[i];
-    }
-    __syncthreads();
-  }
-}
-
 
 // ---- segments of kSplitMax .. hugeMax points: one workgroup each, points where they are (global memory, L2-resident), the
 // WHOLE workgroup on one node after the other, depth by depth, until the pieces fit splitSegmentsKernel.
@@ -1274,14 +330,11 @@ __global__ __launch_bounds__( 64 * kHugeWaves ) void hugeSegmentsKernel( BuildAr
               leaf.dim = -1;
               a.nodes[child[c].node] = leaf;
               atomicMax( a.finishDepth, level + 1u );
-            } else if ( cc <= a.splitMax ) {  // to the wavefront finisher / the piece kernel, or to the workgroup that splits in LDS first
+            } else if ( cc <= a.retireMax ) {  // to the piece kernel
               RetiredSeg rs;
               rs.begin = seg.begin + child[c].begin, rs.end = seg.begin + child[c].end, rs.node = child[c].node, rs.level = level, rs.root = 0;
               for ( int d = 0; d < 3; ++d ) rs.lo[d] = child[c].lo[d], rs.hi[d] = child[c].hi[d];
-              if ( cc <= a.retireMax )
-                a.retired[atomicAdd( a.retiredCount, 1u )] = rs;
-              else
-                a.big[atomicAdd( a.bigCount, 1u )] = rs;
+              a.retired[atomicAdd( a.retiredCount, 1u )] = rs;
             } else {
               sNode[cur ^ 1][sCount[cur ^ 1]++] = child[c];
             }
@@ -2304,31 +1357,24 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   hipStream_t    s       = ctx->stream;
   const uint32_t tiles   = ( n + kScanTile - 1 ) / kScanTile;
   const size_t   maxSegs = 2 * ( size_t( n ) / ( kLeafMax + 1 ) + 1 ) + 2;
-  // 2 n + 2 nodes at most.  The finishing kernel takes ids in chunks: a wavefront leaves at most one chunk of kIdChunk unused;
-  // a lane at most kLaneIdChunk - 2 per node of 11 .. kLaneMax points it builds the subtree of (at most n / 11 of those).
-  const size_t   maxNode = 2 * size_t( n ) + 2 + size_t( kIdChunk ) * kFinishWaves * kFinishBlocks +
-                         ( size_t( n ) / ( kLeafMax + 1 ) + 1 ) * ( kLaneIdChunk - 2 );
+  const size_t   maxNode = 2 * size_t( n ) + 2;  // (every split takes exactly two ids: hugeSegmentsKernel, pieceKernel, lvDecideKernel)
   TMC2_TRY( d_ptsTree.alloc( n ) );
   TMC2_TRY( d_perm.alloc( n ) );
   TMC2_TRY( d_nodes.alloc( maxNode ) );
   DevBuf<uint32_t>   d_work, d_small;
   DevBuf<BuildSeg>   d_segs;
-  DevBuf<RetiredSeg> d_retired, d_big;
+  DevBuf<RetiredSeg> d_retired;
   const size_t       maxRetired = size_t( n ) / ( kLeafMax + 1 ) + 2;  // (retired segments are disjoint and hold > kLeafMax points)
   TMC2_TRY( d_retired.alloc( maxRetired ) );
-  TMC2_TRY( d_big.alloc( size_t( n ) / ( kRetire + 1 ) + 2 ) );  // (disjoint segments of more than kRetire points)
   DevBuf<HugeSeg> d_huge;
-  TMC2_TRY( d_huge.alloc( size_t( n ) / ( std::min( kSplitMax, kPieceMax ) + 1 ) + 2 ) );  // (disjoint segments of more than splitMax points)
-  // (test hook TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes; <= kSplitMax: that tier is off)
-  // Form of the lower tiers: pieces of at most kPieceMax points, one workgroup each, all nodes of a depth at once (pieceKernel,
-  // the default), or round 4's three tiers (TMC2_KD_FORM=tiers: kept as the cross-check of the other).
-  const char*    formEnv = ctxOption( ctx, "KD_FORM" );
-  const bool     pieces  = !( formEnv && !strcmp( formEnv, "tiers" ) );
+  TMC2_TRY( d_huge.alloc( size_t( n ) / ( kPieceMax + 1 ) + 2 ) );  // (disjoint segments of more than kPieceMax points)
+  // Below the level passes: pieces of at most kPieceMax points, one workgroup each, all nodes of a depth at once (pieceKernel);
+  // between the two, segments of up to hugeMax points are cut into pieces by one workgroup each (hugeSegmentsKernel: it saves the last
+  // few level passes, which move a few dozen segments of 4 097 .. hugeMax points with five chip-wide launches each; option
+  // KD_HUGEMAX).  Round 4's three tiers and its level passes (options KD_FORM=tiers, KD_LEVELS=r4 of round 5, kept there as a
+  // third cross-check next to the host builder and the oracle) left the library in round 6.
   const char*    hugeEnv = ctxOption( ctx, "KD_HUGEMAX" );
-  // (TMC2_KD_HUGEMAX: the largest segment the workgroup-per-segment tier takes from the level passes -- with the pieces it saves
-  //  the last few level passes, which move a few dozen segments of 4 097 .. hugeMax points with five chip-wide launches each)
-  const uint32_t hugeMax = pieces ? std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kPieceMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 16384u ) )
-                                  : std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kSplitMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 32768u ) );
+  const uint32_t hugeMax = std::min<uint32_t>( kHugeLimit, std::max<uint32_t>( kPieceMax, hugeEnv ? uint32_t( atoi( hugeEnv ) ) : 16384u ) );
   TMC2_TRY( d_work.alloc( 3 * size_t( n ) + 2 * ( size_t( tiles ) + 1 ) ) );  // seg, loc1, loc2, tile totals x 2
   TMC2_TRY( d_segs.alloc( 2 * maxSegs ) );
   TMC2_TRY( d_small.alloc( kMaxLevels + 16 ) );  // [0..64] segments per level, then node count, levels, barrier, root box
@@ -2346,46 +1392,40 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.retiredCount = d_small.p + kMaxLevels + 3;
   a.finishDepth  = d_small.p + kMaxLevels + 4;
   a.ticket       = d_small.p + kMaxLevels + 5;
-  a.big          = d_big.p;
   a.bigCount     = d_small.p + kMaxLevels + 6;
   a.huge         = d_huge.p;
   a.hugeCount    = d_small.p + kMaxLevels + 7;
   a.hugeMax      = hugeMax;
-  a.retireMax    = pieces ? uint32_t( kPieceMax ) : uint32_t( kRetire );
-  a.splitMax     = pieces ? uint32_t( kPieceMax ) : uint32_t( kSplitMax );
+  a.retireMax    = uint32_t( kPieceMax );
+  a.splitMax     = uint32_t( kPieceMax );
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
   const dim3 blk( kBlock ), grdE( std::max<uint32_t>( 1u, ( n + 2 * kBlock - 1 ) / ( 2 * kBlock ) ) ), grdT( tiles );
   const dim3 grdL( std::max<uint32_t>( 1u, ( n + kLandBlock * kLandRounds - 1 ) / ( kLandBlock * kLandRounds ) ) );
-  // round 5's level passes go with the pieces (TMC2_KD_LEVELS=r4: round 4's five launches per level, the cross-check); their
-  // swap passes keep the tile totals in LDS
-  const char*  levelsEnv = ctxOption( ctx, "KD_LEVELS" );
-  const size_t sumsLds   = ( size_t( tiles ) + 1 ) * 4;
-  const bool   newLevels = pieces && !( levelsEnv && !strcmp( levelsEnv, "r4" ) ) && sumsLds <= 48 * 1024;
+  // the swap passes keep the tile totals in LDS: ( tiles + 1 ) words
+  const size_t sumsLds = ( size_t( tiles ) + 1 ) * 4;
+  if ( sumsLds > 48 * 1024 ) {
+    setError( "kdtree: %u points -- the level passes hold one word per 2 048-point tile in LDS (at most 25 M points)", n );
+    return TMC2_E_UNSUPPORTED;
+  }
   DevBuf<LvSeg>    d_lv;
   DevBuf<uint16_t> d_list;
   DevBuf<LvPartial> d_partial;
   const size_t     maxLv = 2 * ( size_t( n ) / ( size_t( kPieceMax ) + 1 ) + 2 );  // (segments that split are disjoint and hold > kPieceMax points)
-  if ( newLevels ) {
-    TMC2_TRY( d_lv.alloc( 2 * maxLv ) );
-    TMC2_TRY( d_list.alloc( size_t( tiles ) * kScanTile ) );
-    TMC2_TRY( d_partial.alloc( size_t( n ) / ( kLandBlock * kLandRounds ) + 2 ) );
-    a.lvA = d_lv.p, a.lvB = d_lv.p + maxLv, a.list = d_list.p, a.partial = d_partial.p;
-    const char* decideOpt = ctxOption( ctx, "KD_DECIDE" );  // (test hook: "global" = the fold of a level of more than kDecideRng segments)
-    a.decideRng = decideOpt && decideOpt[0] == 'g' ? 0u : uint32_t( kDecideRng );
-    hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 128 ), 0, s, a );
-    hipLaunchKernelGGL( lvInitKernel, dim3( std::min<uint32_t>( grdE.x, 1024u ) ), blk, 0, s, a );  // (each workgroup reports the root's range once)
-    hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, 0u );
-  } else {
-    a.lvA = a.lvB = nullptr, a.list = nullptr, a.partial = nullptr, a.decideRng = 0;
-    TMC2_HIP( hipMemsetAsync( d_small.p, 0, ( kMaxLevels + 16 ) * 4, s ) );
-    hipLaunchKernelGGL( initKernel, grdE, blk, 0, s, a );
-  }
+  TMC2_TRY( d_lv.alloc( 2 * maxLv ) );
+  TMC2_TRY( d_list.alloc( size_t( tiles ) * kScanTile ) );
+  TMC2_TRY( d_partial.alloc( size_t( n ) / ( kLandBlock * kLandRounds ) + 2 ) );
+  a.lvA = d_lv.p, a.lvB = d_lv.p + maxLv, a.list = d_list.p, a.partial = d_partial.p;
+  const char* decideOpt = ctxOption( ctx, "KD_DECIDE" );  // (test hook: "global" = the fold of a level of more than kDecideRng segments)
+  a.decideRng = decideOpt && decideOpt[0] == 'g' ? 0u : uint32_t( kDecideRng );
+  hipLaunchKernelGGL( lvRootKernel, dim3( 1 ), dim3( 128 ), 0, s, a );
+  hipLaunchKernelGGL( lvInitKernel, dim3( std::min<uint32_t>( grdE.x, 1024u ) ), blk, 0, s, a );  // (each workgroup reports the root's range once)
+  hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, 0u );
   uint32_t out[kMaxLevels + 16];
   int      found = -1;
   // How many levels the passes run is only known on the device.  Frames of a sequence are alike: the count of the last tree
   // of about this size (kept in the context) is queued back to back and then checked; without it, the levels that cannot be
   // the last; afterwards two at a time per read-back (launches past the last level find nothing to do).
-  int& hint = ctx->kdLevelHint[( n >> 15 ) * 2u + ( pieces ? 1u : 0u )];
+  int& hint = ctx->kdLevelHint[( n >> 15 ) * 2u + 1u];
   for ( uint32_t level = 0; level < uint32_t( kMaxLevels ) && found < 0; ) {
     uint32_t chunkEnd = level + 1;
     if ( level == 0 && hint > 0 ) {
@@ -2395,19 +1435,11 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
       if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 2, kMaxLevels );
     }
     for ( ; level < chunkEnd; ++level ) {
-      if ( newLevels ) {
-        hipLaunchKernelGGL( lvFlagKernel<true>, grdT, blk, 0, s, a, level );
-        hipLaunchKernelGGL( lvSwapOneKernel, grdE, blk, sumsLds, s, a, level );
-        hipLaunchKernelGGL( lvFlagKernel<false>, grdT, blk, 0, s, a, level );
-        hipLaunchKernelGGL( lvSwapTwoKernel, grdL, dim3( kLandBlock ), sumsLds, s, a, level );
-        hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, level + 1u );
-      } else {
-        hipLaunchKernelGGL( rangeKernel, grdE, blk, 0, s, a, level );
-        hipLaunchKernelGGL( decideFlagKernel, grdT, blk, 0, s, a, level );
-        hipLaunchKernelGGL( swapOneKernel, grdE, blk, 0, s, a, level );
-        hipLaunchKernelGGL( flagTwoKernel, grdT, blk, 0, s, a, level );
-        hipLaunchKernelGGL( swapTwoKernel, grdE, blk, 0, s, a, level );
-      }
+      hipLaunchKernelGGL( lvFlagKernel<true>, grdT, blk, 0, s, a, level );
+      hipLaunchKernelGGL( lvSwapOneKernel, grdE, blk, sumsLds, s, a, level );
+      hipLaunchKernelGGL( lvFlagKernel<false>, grdT, blk, 0, s, a, level );
+      hipLaunchKernelGGL( lvSwapTwoKernel, grdL, dim3( kLandBlock ), sumsLds, s, a, level );
+      hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, level + 1u );
     }
     TMC2_HIP( hipGetLastError() );
     TMC2_HIP( hipMemcpyAsync( out, d_small.p, sizeof( out ), hipMemcpyDeviceToHost, s ) );
@@ -2426,67 +1458,39 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   hint  = std::max( found, 1 );
   const int32_t* box = reinterpret_cast<const int32_t*>( out + kMaxLevels + 8 );
   for ( int d = 0; d < 3; ++d ) lo[d] = box[d], hi[d] = box[3 + d];
-  if ( pieces ) {  // everything below the level passes: one workgroup per piece
-    const uint32_t hugeSegs = out[kMaxLevels + 7];
-    if ( hugeSegs )  // (segments of up to hugeMax points: one workgroup each cuts its segment into pieces, which join the list)
-      hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( hugeSegs, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );
-    const uint32_t retired = out[kMaxLevels + 3] + hugeSegs * ( 2u * hugeMax / uint32_t( kPieceMax ) );
-    if ( retired ) {
-      const char* perEnv = ctxOption( ctx, "KD_PIECE_PER" );  // positions per thread: 4 (1 024 threads) or 8 (512)
-      if ( ctxOption( ctx, "KD_PIECE_PROFILE" ) ) {  // diagnostic: where a depth's time goes (thread 0 of every workgroup, between barriers)
-        DevBuf<unsigned long long> d_prof;
-        TMC2_TRY( d_prof.alloc( 16 ) );
-        TMC2_HIP( hipMemsetAsync( d_prof.p, 0, 16 * 8, s ) );
-        a.pieceProfile = d_prof.p;
-        TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<4, true> ), kPieceLdsBytes, ctx->device, 256 ) );
-        hipLaunchKernelGGL( ( pieceKernel<4, true> ), dim3( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) ), dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
-        unsigned long long h[16];
-        TMC2_HIP( hipMemcpyAsync( h, d_prof.p, sizeof( h ), hipMemcpyDeviceToHost, s ) );
-        TMC2_HIP( hipStreamSynchronize( s ) );
-        static const char* what[8] = {"landing of the previous depth", "node records + split rules", "first flags + prefix sum", "first publish",
-                                      "first swaps", "second flags + prefix sum", "children + second publish", "second swaps"};
-        fprintf( stderr, "pieceKernel: %llu pieces, us per piece between the barriers of its depths (thread 0 of each workgroup):", h[8] );
-        for ( int k = 0; k < 8; ++k ) fprintf( stderr, " %s %.1f |", what[k], 0.01 * double( h[k] ) / double( std::max<unsigned long long>( h[8], 1 ) ) );
-        fprintf( stderr, "\n" );
-      }
-      const dim3  grid( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) );
-      if ( ctxOption( ctx, "KD_PIECE_PROFILE" ) ) {
-        // (done above)
-      } else if ( perEnv && atoi( perEnv ) == 8 ) {
-        TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<8> ), kPieceLdsBytes, ctx->device, 256 ) );
-        hipLaunchKernelGGL( pieceKernel<8>, grid, dim3( kPieceMax / 8 ), kPieceLdsBytes, s, a );
-      } else {
-        TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<4> ), kPieceLdsBytes, ctx->device, 256 ) );
-        hipLaunchKernelGGL( pieceKernel<4>, grid, dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
-      }
-      TMC2_HIP( hipGetLastError() );
-      uint32_t fin = 0;
-      TMC2_HIP( hipMemcpyAsync( &fin, a.finishDepth, 4, hipMemcpyDeviceToHost, s ) );
+  // everything below the level passes: one workgroup per piece
+  const uint32_t hugeSegs = out[kMaxLevels + 7];
+  if ( hugeSegs )  // (segments of up to hugeMax points: one workgroup each cuts its segment into pieces, which join the list)
+    hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( hugeSegs, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );
+  const uint32_t retired = out[kMaxLevels + 3] + hugeSegs * ( 2u * hugeMax / uint32_t( kPieceMax ) );
+  if ( retired ) {
+    const char* perEnv = ctxOption( ctx, "KD_PIECE_PER" );  // positions per thread: 4 (1 024 threads) or 8 (512)
+    if ( ctxOption( ctx, "KD_PIECE_PROFILE" ) ) {  // diagnostic: where a depth's time goes (thread 0 of every workgroup, between barriers)
+      DevBuf<unsigned long long> d_prof;
+      TMC2_TRY( d_prof.alloc( 16 ) );
+      TMC2_HIP( hipMemsetAsync( d_prof.p, 0, 16 * 8, s ) );
+      a.pieceProfile = d_prof.p;
+      TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<4, true> ), kPieceLdsBytes, ctx->device, 256 ) );
+      hipLaunchKernelGGL( ( pieceKernel<4, true> ), dim3( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) ), dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
+      unsigned long long h[16];
+      TMC2_HIP( hipMemcpyAsync( h, d_prof.p, sizeof( h ), hipMemcpyDeviceToHost, s ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
-      if ( fin >= uint32_t( kMaxLevels ) ) {
-        setError( "kdtree: more than %d levels", kMaxLevels - 1 );
-        return TMC2_E_UNSUPPORTED;
-      }
-      depth = std::max( depth, int( fin ) );
+      static const char* what[8] = {"landing of the previous depth", "node records + split rules", "first flags + prefix sum", "first publish",
+                                    "first swaps", "second flags + prefix sum", "children + second publish", "second swaps"};
+      fprintf( stderr, "pieceKernel: %llu pieces, us per piece between the barriers of its depths (thread 0 of each workgroup):", h[8] );
+      for ( int k = 0; k < 8; ++k ) fprintf( stderr, " %s %.1f |", what[k], 0.01 * double( h[k] ) / double( std::max<unsigned long long>( h[8], 1 ) ) );
+      fprintf( stderr, "\n" );
     }
-    return TMC2_OK;
-  }
-  const uint32_t huge = out[kMaxLevels + 7];
-  if ( huge )  // segments of up to hugeMax points: one workgroup each, their pieces join the two lists below
-    hipLaunchKernelGGL( hugeSegmentsKernel, dim3( std::min<uint32_t>( huge, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kHugeWaves ), 0, s, a );
-  // (what the level passes handed over, plus what hugeSegmentsKernel may add: both kernels below stride over the device-side counts)
-  const uint32_t big = out[kMaxLevels + 6] + huge * ( 2u * hugeMax / uint32_t( kSplitMax ) );
-  if ( big ) {  // segments between the two thresholds: one workgroup each, their pieces join the retired list
-    const size_t lds = size_t( kSplitMax ) * ( sizeof( Pt ) + 4 + 4 );
-    if ( lds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( splitSegmentsKernel ), lds, ctx->device,
-                                                     sizeof( SubNode ) * 2 * kSplitNodes + 64 ) );
-    hipLaunchKernelGGL( splitSegmentsKernel, dim3( std::min<uint32_t>( big, 4u * uint32_t( ctx->cuCount ) ) ), dim3( 64 * kSplitWaves ), lds, s, a );
-  }
-  // (its pieces: typically 2 * kSplitMax / kRetire per segment; the finishing kernel strides over whatever the list holds)
-  const uint32_t retired = out[kMaxLevels + 3] + big * uint32_t( 2 * kSplitMax / kRetire );
-  if ( retired ) {  // the subtrees below the level passes: one wavefront each
-    const uint32_t blocks = std::min<uint32_t>( ( retired + kFinishWaves - 1 ) / kFinishWaves, kFinishBlocks );
-    hipLaunchKernelGGL( finishSubtreesKernel, dim3( blocks ), dim3( 64 * kFinishWaves ), 0, s, a );
+    const dim3  grid( std::min<uint32_t>( retired, 8u * uint32_t( ctx->cuCount ) ) );
+    if ( ctxOption( ctx, "KD_PIECE_PROFILE" ) ) {
+      // (done above)
+    } else if ( perEnv && atoi( perEnv ) == 8 ) {
+      TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<8> ), kPieceLdsBytes, ctx->device, 256 ) );
+      hipLaunchKernelGGL( pieceKernel<8>, grid, dim3( kPieceMax / 8 ), kPieceLdsBytes, s, a );
+    } else {
+      TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( pieceKernel<4> ), kPieceLdsBytes, ctx->device, 256 ) );
+      hipLaunchKernelGGL( pieceKernel<4>, grid, dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
+    }
     TMC2_HIP( hipGetLastError() );
     uint32_t fin = 0;
     TMC2_HIP( hipMemcpyAsync( &fin, a.finishDepth, 4, hipMemcpyDeviceToHost, s ) );

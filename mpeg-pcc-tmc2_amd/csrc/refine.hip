@@ -691,216 +691,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __r
 }
 
 // ---- sweep kernels ----------------------------------------------------------------------------------
-// S[v] = sum of the neighbourhood's histograms (u16 lanes), arg[v] = first maximum.  16 lanes per voxel (rows hold ~64
-// entries: four independent gathers per lane, a four-step reduction).
-// UPDATE = true also closes the PREVIOUS sweep for voxel v (refresh edge class / ppi of re-scored voxels, apply the
-// INDIRECT marks, arm `active`): that only reads hist[v] and nothing here writes histograms, so it rides along.
-template <bool UPDATE>
-__global__ __launch_bounds__( 256 ) void smoothKernel( const uint4* __restrict__ hist, const uint32_t* __restrict__ adjOff,
-                                                        const uint32_t* __restrict__ rowLen,
-                                                        const uint32_t* __restrict__ adj, uint32_t V,
-                                                        uint4* __restrict__ S, uint8_t* __restrict__ arg,
-                                                        const uint8_t* __restrict__ proc, uint8_t* __restrict__ edge,
-                                                        uint8_t* __restrict__ ppi, uint32_t* __restrict__ active,
-                                                        uint8_t* __restrict__ marked, uint32_t* __restrict__ flags, int iter ) {
-  const int      lane = threadIdx.x & 15;
-  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  if ( v >= V || flags[0] ) return;
-  const uint32_t* row = adj + adjOff[v];
-  const uint32_t  len = rowLen[v];
-  uint32_t        s0 = 0, s1 = 0, s2 = 0;  // packed u16 pairs; sums <= 1024 + 255, no carry between halves
-  for ( uint32_t i = lane; i < len; i += 16 ) {
-    const uint4 h = hist[row[i]];
-    s0 += h.x;
-    s1 += h.y;
-    s2 += h.z;
-  }
-#pragma unroll
-  for ( int off = 8; off > 0; off >>= 1 ) {  // the 16 lanes of a voxel are an aligned quarter of the wave
-    s0 += __shfl_xor( s0, off, 64 );
-    s1 += __shfl_xor( s1, off, 64 );
-    s2 += __shfl_xor( s2, off, 64 );
-  }
-  if ( lane == 0 ) {
-    const uint4 out = make_uint4( s0, s1, s2, 0 );
-    S[v]            = out;
-    uint32_t b[6];
-    unpackHist( out, b );
-    int nz, a;
-    classify( b, nz, a );
-    arg[v] = uint8_t( a );
-    if ( UPDATE ) {
-      const uint8_t e0 = edge[v];
-      uint8_t       e  = e0;
-      bool          changed = false;
-      if ( proc[v] ) {
-        unpackHist( hist[v], b );
-        classify( b, nz, a );
-        if ( e != S_DIRECT_EDGE ) e = ( nz == 1 ) ? NO_EDGE : M_DIRECT_EDGE;
-        changed = ppi[v] != uint8_t( a );
-        ppi[v]  = uint8_t( a );
-      } else if ( marked[v] && e == NO_EDGE ) {
-        e = INDIRECT_EDGE;
-      }
-      if ( changed || e != e0 ) flags[2 * iter] = 1u;  // the voxel state the previous sweep leaves differs from what it found
-      edge[v]   = e;
-      active[v] = e != NO_EDGE;
-      marked[v] = 0;
-    }
-  }
-}
-
-// INDIRECT-edge closure.  Every active voxel u marks the uniform DEV neighbours v that disagree with arg[u]; a marked
-// neighbour with a LARGER index becomes active in this sweep and must mark in turn (the reference's in-order loop).
-// edge / ppi / arg are frozen during the closure, so the "u marks v" relation is a static DAG:
-//   round 0 (closureRoundZeroKernel, all voxels, 32 lanes per voxel): out[u] = compact list of the voxels u would
-//            mark; the voxels active at sweep start issue their marks and flag what they newly activate in a bitmap;
-//   tail    (closureTailKernel, ONE workgroup): walks the dependent hops level by level with the active / frontier
-//            bitmaps in LDS, so a hop costs one global load (the 16-byte head of out[u]) instead of a chain of them.
-//            The tail has next to no parallelism, so one workgroup loses nothing, needs no cross-workgroup polling,
-//            terminates exactly when the frontier is empty, and leaves the rest of the chip to the other frames.
-__global__ __launch_bounds__( 256 ) void closureRoundZeroKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                                  const uint8_t* __restrict__ arg,
-                                                                  const uint32_t* __restrict__ dev, uint32_t V,
-                                                                  uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
-                                                                  uint32_t* __restrict__ out, uint32_t* __restrict__ activeBits,
-                                                                  uint32_t* __restrict__ frontierBits, uint32_t* __restrict__ flags,
-                                                                  int iter ) {
-  const uint32_t u    = blockIdx.x * 8 + ( threadIdx.x >> 5 );
-  const uint32_t lane = threadIdx.x & 31;
-  const int      half = ( threadIdx.x >> 5 ) & 1;
-  // Fixpoint: a sweep that changed neither a label nor a voxel state leaves the next one the same input, so every
-  // later sweep is a no-op too (the reference keeps iterating to its fixed count; the result is the same).
-  if ( flags[0] ) return;
-  if ( iter > 0 && flags[2 * iter - 1] == 0 && flags[2 * iter] == 0 ) {
-    flags[0] = 1u;
-    return;
-  }
-  if ( u >= V ) return;
-  const uint32_t v    = dev[size_t( u ) * 32 + lane];
-  const uint8_t  a    = arg[u];
-  const bool     pred = v != kDevPad && edge[v] == NO_EDGE && ppi[v] != a;
-  const uint32_t m    = uint32_t( __ballot( pred ) >> ( 32 * half ) );
-  if ( pred ) out[size_t( u ) * 32 + 1 + __popc( m & ( ( 1u << lane ) - 1u ) )] = v;
-  if ( lane == 0 ) out[size_t( u ) * 32] = uint32_t( __popc( m ) );
-  // a voxel activated by a lower one during this very kernel may or may not be seen here; either way it is in the
-  // frontier bitmap, and being handled twice is harmless -- marking is idempotent
-  if ( !__hip_atomic_load( &active[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) return;
-  if ( lane == 0 ) atomicOr( &activeBits[u >> 5], 1u << ( u & 31 ) );
-  if ( pred ) {
-    marked[v] = 1;
-    if ( v > u && atomicExch( &active[v], 1u ) == 0u ) {
-      atomicOr( &activeBits[v >> 5], 1u << ( v & 31 ) );
-      atomicOr( &frontierBits[v >> 5], 1u << ( v & 31 ) );
-    }
-  }
-}
-
-__global__ __launch_bounds__( 1024 ) void closureTailKernel( const uint32_t* __restrict__ out, uint32_t W,
-                                                              uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
-                                                              uint32_t* __restrict__ activeBits,
-                                                              uint32_t* __restrict__ frontierBits, const uint32_t* __restrict__ flags ) {
-  if ( flags[0] ) return;
-  extern __shared__ uint32_t lds[];
-  uint32_t *      act = lds, *fr = lds + W, *nx = lds + 2 * size_t( W );
-  __shared__ int  any;
-  for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
-    act[w] = activeBits[w];
-    fr[w]  = frontierBits[w];
-    nx[w]  = 0;
-    if ( fr[w] ) frontierBits[w] = 0;  // both bitmaps are handed back empty for the next sweep
-    if ( act[w] ) activeBits[w] = 0;
-  }
-  if ( threadIdx.x == 0 ) any = 0;
-  __syncthreads();
-  while ( true ) {
-    bool mine = false;
-    for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
-      uint32_t bits = fr[w];
-      while ( bits ) {
-        const uint32_t u = w * 32 + uint32_t( __ffs( int( bits ) ) - 1 );
-        bits &= bits - 1;
-        const uint32_t* row  = out + size_t( u ) * 32;
-        const uint4     head = *reinterpret_cast<const uint4*>( row );  // count + the first three targets
-        const uint32_t  cnt  = head.x;
-        for ( uint32_t k = 0; k < cnt; ++k ) {
-          const uint32_t v = k == 0 ? head.y : ( k == 1 ? head.z : ( k == 2 ? head.w : row[1 + k] ) );
-          marked[v]        = 1;
-          if ( v > u ) {
-            const uint32_t bit = 1u << ( v & 31 );
-            if ( !( atomicOr( &act[v >> 5], bit ) & bit ) ) {
-              active[v] = 1u;
-              atomicOr( &nx[v >> 5], bit );
-              mine = true;
-            }
-          }
-        }
-      }
-    }
-    if ( mine ) any = 1;
-    __syncthreads();
-    const bool more = any != 0;
-    __syncthreads();
-    if ( !more ) break;
-    for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
-      fr[w] = nx[w];
-      nx[w] = 0;
-    }
-    if ( threadIdx.x == 0 ) any = 0;
-    __syncthreads();
-  }
-}
-
-// fallback of the tail for grids whose bitmaps do not fit the LDS: same walk, bitmaps in global memory
-__global__ __launch_bounds__( 1024 ) void closureTailGlobalKernel( const uint32_t* __restrict__ out, uint32_t W,
-                                                                    uint32_t* __restrict__ active, uint8_t* __restrict__ marked,
-                                                                    uint32_t* __restrict__ activeBits,
-                                                                    uint32_t* __restrict__ frontierBits,
-                                                                    uint32_t* __restrict__ nextBits, const uint32_t* __restrict__ flags ) {
-  if ( flags[0] ) return;
-  __shared__ int any;
-  uint32_t*      fr = frontierBits;
-  uint32_t*      nx = nextBits;
-  if ( threadIdx.x == 0 ) any = 0;
-  __syncthreads();
-  while ( true ) {
-    bool mine = false;
-    for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) {
-      uint32_t bits = __hip_atomic_load( &fr[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      if ( bits ) __hip_atomic_store( &fr[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      while ( bits ) {
-        const uint32_t u = w * 32 + uint32_t( __ffs( int( bits ) ) - 1 );
-        bits &= bits - 1;
-        const uint32_t* row = out + size_t( u ) * 32;
-        const uint32_t  cnt = row[0];
-        for ( uint32_t k = 0; k < cnt; ++k ) {
-          const uint32_t v = row[1 + k];
-          marked[v]        = 1;
-          if ( v > u ) {
-            const uint32_t bit = 1u << ( v & 31 );
-            if ( !( atomicOr( &activeBits[v >> 5], bit ) & bit ) ) {
-              active[v] = 1u;
-              atomicOr( &nx[v >> 5], bit );
-              mine = true;
-            }
-          }
-        }
-      }
-    }
-    if ( mine ) any = 1;
-    __syncthreads();
-    const bool more = any != 0;
-    __syncthreads();
-    if ( !more ) break;
-    uint32_t* t = fr;
-    fr          = nx;
-    nx          = t;
-    if ( threadIdx.x == 0 ) any = 0;
-    __syncthreads();
-  }
-  for ( uint32_t w = threadIdx.x; w < W; w += blockDim.x ) activeBits[w] = 0;
-}
-
+// (Rounds 1-2 recomputed everything every sweep -- smoothKernel, a two-step closure with a one-workgroup level walk,
+//  rescoreVoxelsKernel: five, then three launches per sweep.  Round 3 replaced them by the event-driven pair below and kept them
+//  behind option REFINE_SWEEPS=full as a second cross-check next to the oracle; round 6 took them out of the library:
+//  git show 5d8d688:mpeg-pcc-tmc2_amd/csrc/refine.hip.)
 // points grouped by voxel (any order inside a voxel: re-scoring is per point, the histograms are integer sums)
 __global__ __launch_bounds__( 256 ) void voxelPointListKernel( const uint32_t* __restrict__ vid, const uint32_t* __restrict__ start,
                                                                 uint32_t n, uint32_t* __restrict__ cursor,
@@ -911,82 +705,8 @@ __global__ __launch_bounds__( 256 ) void voxelPointListKernel( const uint32_t* _
   list[start[v] + atomicAdd( &cursor[v], 1u )] = j;
 }
 
-// decide + re-score in one pass over the VOXELS (16 lanes each): the voxels that are re-scored this sweep are few
-// (patch borders), so walking their point lists beats a pass over every point, and a voxel's new histogram is built in
-// registers and written once instead of through atomics.
-//   proc[v] = active and (multi-plane edge, or its smoothed histogram is not unanimous for its own plane)
-__global__ __launch_bounds__( 256 ) void rescoreVoxelsKernel( const uint8_t* __restrict__ edge, const uint8_t* __restrict__ ppi,
-                                                               const uint32_t* __restrict__ active, const uint4* __restrict__ S,
-                                                               const double* __restrict__ weight,
-                                                               const uint32_t* __restrict__ pointStart,
-                                                               const uint32_t* __restrict__ pointList,
-                                                               const double* __restrict__ normals, uint32_t V,
-                                                               uint8_t* __restrict__ proc, uint4* __restrict__ hist,
-                                                               uint8_t* __restrict__ partition, uint32_t* __restrict__ flags,
-                                                               int iter ) {
-  const uint32_t v    = blockIdx.x * 16 + ( threadIdx.x >> 4 );
-  const int      sub  = threadIdx.x & 15;
-  if ( v >= V || flags[0] ) return;
-  uint32_t b[6];
-  uint8_t  p = 0;
-  if ( active[v] ) {
-    const uint8_t edgeAt = edge[v] != NO_EDGE ? edge[v] : uint8_t( INDIRECT_EDGE );
-    unpackHist( S[v], b );
-    p = 1;
-    if ( edgeAt != M_DIRECT_EDGE ) {
-      int nz, a;
-      classify( b, nz, a );
-      if ( nz == 1 && b[ppi[v]] > 0 ) p = 0;
-    }
-  }
-  if ( sub == 0 ) proc[v] = p;
-  if ( !p ) return;  // (uniform over the 16 lanes of the voxel)
-  const double   w     = weight[v];
-  const uint32_t begin = pointStart[v], end = pointStart[v + 1];
-  uint32_t       h0 = 0, h1 = 0, h2 = 0;  // packed u16 pairs like the histogram words
-  uint32_t       moved = 0;
-  for ( uint32_t q = begin + sub; q < end; q += 16 ) {
-    const uint32_t j  = pointList[q];
-    const double   nx = normals[3 * size_t( j )], ny = normals[3 * size_t( j ) + 1], nz = normals[3 * size_t( j ) + 2];
-    const double d[6] = {nx * 1.0 + ny * 0.0 + nz * 0.0,  nx * 0.0 + ny * 1.0 + nz * 0.0,
-                         nx * 0.0 + ny * 0.0 + nz * 1.0,  nx * -1.0 + ny * 0.0 + nz * 0.0,
-                         nx * 0.0 + ny * -1.0 + nz * 0.0, nx * 0.0 + ny * 0.0 + nz * -1.0};
-    int    best = 0;
-    double bs   = d[0] + w * double( b[0] );
-#pragma unroll
-    for ( int k = 1; k < 6; ++k ) {
-      const double sc = d[k] + w * double( b[k] );
-      if ( sc > bs ) {
-        bs   = sc;
-        best = k;
-      }
-    }
-    if ( partition[j] != uint8_t( best ) ) {
-      partition[j] = uint8_t( best );
-      ++moved;
-    }
-    const uint32_t one = 1u << ( 16 * ( best & 1 ) );
-    h0 += ( best >> 1 ) == 0 ? one : 0u;
-    h1 += ( best >> 1 ) == 1 ? one : 0u;
-    h2 += ( best >> 1 ) == 2 ? one : 0u;
-  }
-#pragma unroll
-  for ( int off = 8; off > 0; off >>= 1 ) {  // the 16 lanes of a voxel are an aligned quarter of the wave
-    h0 += __shfl_xor( h0, off, 64 );
-    h1 += __shfl_xor( h1, off, 64 );
-    h2 += __shfl_xor( h2, off, 64 );
-    moved += __shfl_xor( moved, off, 64 );
-  }
-  if ( sub == 0 ) {
-    hist[v] = make_uint4( h0, h1, h2, 0 );
-    if ( moved ) atomicAdd( &flags[2 * iter + 1], moved );  // this sweep moved points (the count feeds the trace hook)
-  }
-}
-
-
 // ======================================================================================================================
-// Event-driven sweeps (the default path).  What the sweeps above recompute for every voxel every sweep is maintained
-// incrementally here, bit-exactly:
+// Event-driven sweeps.  What a sweep of the reference recomputes for every voxel is maintained incrementally here, bit-exactly:
 //   * S[v] (the smoothed histogram) only changes when the histogram of a voxel in v's neighbourhood changes.  A voxel
 //     whose points moved PUSHES the difference to the voxels that list it (reverse neighbourhood rows, built once):
 //     integer adds, so the order is irrelevant.  Late sweeps change a few dozen histograms, not 70 K rows of 88 gathers.
@@ -1436,7 +1156,7 @@ struct RefineJob {
   std::vector<int> offsets;  // the ball: its ROWS (byRows) or its cells
   uint32_t*        table = nullptr;
   uint2*           bits  = nullptr;  // occupancy bitmap of the key table (.x; kept all-zero between frames) + ranks (.y)
-  bool             tableFilled = false, eventDriven = false, byRows = true;
+  bool             tableFilled = false, byRows = true;
   int              capTier = 2;  // which instantiation of the neighbourhood kernels (launchNeighbourhood)
   size_t           Vp = 0, W2 = 0, ball = 0, perVoxel = 0;
   uint64_t         capacity = 0;
@@ -1446,9 +1166,8 @@ struct RefineJob {
       d_voxelOfRank;
   DevBuf<Pt>      d_centre;
   DevBuf<double>  d_weight;
-  DevBuf<uint8_t> d_state;  // edge | ppi | arg | marked | proc, V bytes each
+  DevBuf<uint8_t> d_state;  // edge | ppi, V bytes each (padded to whole 32-voxel words)
   DevBuf<int>     d_offsets;
-  DevBuf<uint4>   d_S;
   bool matches( int nn, double l, int it, int vd, int sr ) const {
     return nn == maxNNCount && l == lambda && it == iterationCount && vd == voxDim && sr == searchRadius;
   }
@@ -1599,15 +1318,11 @@ int RefineJob::geometry( tmc2_frame* f ) {
   TMC2_TRY( d_centre.alloc( V ) );
   TMC2_TRY( d_weight.alloc( V ) );
   Vp = ( size_t( V ) + 63 ) & ~size_t( 63 );  // sub-arrays of the state block: whole, aligned 32-voxel words
-  TMC2_TRY( d_state.alloc( Vp * 6 ) );
+  TMC2_TRY( d_state.alloc( Vp * 2 ) );
   TMC2_TRY( d_activeBuf.alloc( V ) );
   TMC2_TRY( d_offsets.alloc( offsets.size() ) );
-  TMC2_TRY( d_S.alloc( V ) );
   // every buffer of this stage that starts from zeros, in one launch (the event-driven loop's among them)
   W = ( V + 31 ) / 32;
-  // Which sweep loop: the event-driven one, unless the test hook TMC2_REFINE_SWEEPS=full asks for the sweep-everything loop
-  const char* sweepsEnv = ctxOption( ctx, "REFINE_SWEEPS" );
-  eventDriven = !( sweepsEnv && sweepsEnv[0] == 'f' );
   W2          = ( size_t( V ) + 15 ) / 16;  // closure state: two bits per voxel
   // closure scratch: state bitmaps of the two sweep parities | list counters of the two parities (one per 128 bytes) | ring
   // head, tail (64 words) | the spill ring (V voxels)
@@ -1616,23 +1331,21 @@ int RefineJob::geometry( tmc2_frame* f ) {
   TMC2_TRY( d_pointList.alloc( n ) );
   TMC2_TRY( d_cursor.alloc( V ) );
   TMC2_TRY( d_flags.alloc( 2 * size_t( iterationCount ) + 2 ) );
-  if ( eventDriven ) {
-    TMC2_TRY( d_rcount.alloc( size_t( V ) + 1 ) );
-    TMC2_TRY( d_rcursor.alloc( size_t( V ) + 1 ) );
-    TMC2_TRY( d_lastRescore.alloc( V ) );
-    TMC2_TRY( d_gbits.alloc( closureZeroWords + V ) );
-  }
+  TMC2_TRY( d_rcount.alloc( size_t( V ) + 1 ) );
+  TMC2_TRY( d_rcursor.alloc( size_t( V ) + 1 ) );
+  TMC2_TRY( d_lastRescore.alloc( V ) );
+  TMC2_TRY( d_gbits.alloc( closureZeroWords + V ) );
   TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( V ) + 1 ) * 4, 0},
                                {d_hist.p, size_t( V ) * 16, 0},
-                               {d_state.p, Vp * 6, 0},
+                               {d_state.p, Vp * 2, 0},
                                {d_cursor.p, size_t( V ) * 4, 0},
                                {d_small.p + 1, 12, 0},  // [1] row cursor, [2] overflow, [3] reverse row cursor
                                {d_flags.p, ( 2 * size_t( iterationCount ) + 2 ) * 4, 0},
-                               {d_rcount.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
-                               {d_rcursor.p, eventDriven ? ( size_t( V ) + 1 ) * 4 : 0, 0},
-                               {d_lastRescore.p, eventDriven ? size_t( V ) * 4 : 0, 0},
-                               {d_gbits.p, eventDriven ? closureZeroWords * 4 : 0, 0},
-                               {d_gbits.p + closureZeroWords, eventDriven ? size_t( V ) * 4 : 0, 0xFF}} ) );  // kNoVoxel
+                               {d_rcount.p, ( size_t( V ) + 1 ) * 4, 0},
+                               {d_rcursor.p, ( size_t( V ) + 1 ) * 4, 0},
+                               {d_lastRescore.p, size_t( V ) * 4, 0},
+                               {d_gbits.p, closureZeroWords * 4, 0},
+                               {d_gbits.p + closureZeroWords, size_t( V ) * 4, 0xFF}} ) );  // kNoVoxel
   TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, bits, d_firstPoint.p, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
@@ -1685,8 +1398,7 @@ int RefineJob::finish() {
   }
   const int  sidSetup = ctx->stageBegin( "refine_setup" );
   const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
-  uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + Vp, *d_arg = d_state.p + 2 * Vp, *d_marked = d_state.p + 4 * Vp,
-          *d_proc = d_state.p + 5 * Vp;
+  uint8_t *d_edge = d_state.p, *d_ppi = d_state.p + Vp;
   uint32_t* d_active = d_activeBuf.p;
   const dim3 grdV( ( V + 255 ) / 256 ), grdV16( ( V + 15 ) / 16 );  // 16 lanes per voxel
   for ( int attempt = 0;; ++attempt ) {
@@ -1723,186 +1435,124 @@ int RefineJob::finish() {
                       d_hist.p );
   hipLaunchKernelGGL( initVoxelStateKernel, grdV, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_count.p, V,
                       d_edge, d_ppi, d_active );
-  if ( eventDriven ) {
-    // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
-    DevBuf<uint32_t> d_roff, d_radj, d_lists;
-    DevBuf<uint4>    d_rec;
-    TMC2_TRY( d_lists.alloc( size_t( kSubLists ) * V ) );  // (a voxel is listed once per sweep: any sub-list can hold them all)
-    TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
-    const uint32_t *revOff = d_roffG.p, *revLen = d_rlenG.p, *revAdj = d_radjG.p;  // gathered behind the forward rows
-    if ( !byRows ) {  // the rounds 1-3 form: count, prefix sum, scatter
-      TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
-      TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
-      hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcount.p );
-      TMC2_TRY( exclusiveScanU32( ctx, d_rcount.p, d_roff.p, size_t( V ) + 1, nullptr ) );
-      hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
-                          d_radj.p );
-      revOff = d_roff.p, revLen = nullptr, revAdj = d_radj.p;
-    }
-    hipLaunchKernelGGL( smoothInitKernel, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                        d_rowLen.p, d_adj.p, V, d_rec.p );
-    ctx->stageEnd( sidSetup );
-    TMC2_HIP( hipGetLastError() );
-    const int sidSweep = ctx->stageBegin( "refine_sweeps" );
-    // closureKernel: a run of voxels per workgroup; LDS = the run's active voxels + the ring
-    // (test hooks: TMC2_REFINE_CLOSURE_BLOCKS = its grid, TMC2_REFINE_CLOSURE_THREADS = its workgroup; TMC2_REFINE_RING = room
-    // of the LDS ring beyond the run -- 1 sends nearly every fan-out through the spill ring)
-    const char*    gridEnv    = ctxOption( ctx, "REFINE_CLOSURE_BLOCKS" );
-    const char*    threadsEnv = ctxOption( ctx, "REFINE_CLOSURE_THREADS" );
-    const char*    ringEnv    = ctxOption( ctx, "REFINE_RING" );
-    const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 512;
-    const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
-    const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
-                                        : std::min<uint32_t>( ( refineOverlap( ctx ) ? 4u : 2u ) * uint32_t( ctx->cuCount ),
-                                                              ( V + perGroup * ( closureThreads / 32 ) - 1 ) / ( perGroup * ( closureThreads / 32 ) ) );
-    // (two workgroups per CU: 8 % slower alone than four and 3 % more frames per second with sixteen frames in flight -- a
-    // workgroup's groups idle through most of the walk, and idle waves are in the way of the other frames' kernels)
-    const uint32_t run        = std::min<uint32_t>( 8192u, std::max<uint32_t>( 1u, ( V + wantGrid - 1 ) / wantGrid ) );
-    const dim3     grdClosure( ( V + run - 1 ) / run );
-    const uint32_t ringCap    = run + ( ringEnv ? uint32_t( std::min( 8192, std::max( 1, atoi( ringEnv ) ) ) ) : 1024u );
-    const size_t   closureLds = 4 * ( size_t( run ) + ringCap );
-    if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
-    // (test hook TMC2_REFINE_SWEEP_BLOCKS: the sweep kernel's grid)
-    const char* sweepGridEnv = ctxOption( ctx, "REFINE_SWEEP_BLOCKS" );
-    const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap( ctx ) ? 8 : 4 ) * ctx->cuCount ) ) );
-    // (tmc2_set_refine_overlap( 1 ) = "few frames in flight": the chip has room, so both kernels of a sweep take the grids that
-    //  are fastest with the GPU to themselves -- four closure workgroups and eight sweep workgroups per CU)
-    // (round 4 sweep over the grids, 16 frames in flight / one sweep alone: sweep kernel 2 / 4 / 8 / 16 workgroups per CU ->
-    //  loot 109.0 / 108.1 / 107.1 / 106.6 frames/s, 338 / 327 / 305 / 289 us; longdress 174.1 / 174.9 frames/s, 54.8 / 51.9 us;
-    //  closure 1 / 2 / 4 / 8 per CU -> loot 109.3 / 109.0 / 107.8 / 107.1 frames/s, 434 / 338 / 308 / 291 us: all within
-    //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure)
-    const bool wantTrace = ctxOption( ctx, "REFINE_TRACE" ) != nullptr;
-    DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
-    const bool                 wantTiming = ctxOption( ctx, "REFINE_TIMING" ) != nullptr;
-    if ( wantTiming ) {
-      TMC2_TRY( d_timing.alloc( 8 * size_t( iterationCount ) ) );
-      TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64 * size_t( iterationCount ), s ) );
-    }
-    // d_gbits: state bitmaps of the two sweep parities | list counters of the two parities (one per 128 bytes) | ring head,
-    // tail | the spill ring
-    uint32_t*  state[2]  = {d_gbits.p, d_gbits.p + W2};
-    uint32_t*  counts[2] = {d_gbits.p + 2 * size_t( W2 ), d_gbits.p + 2 * size_t( W2 ) + kSubLists * 32};
-    uint32_t*  ctl       = d_gbits.p + 2 * size_t( W2 ) + 2 * kSubLists * 32;
-    uint32_t*  spill     = ctl + 64;
-    // (option REFINE_GRAPH=1, measured in round 5: the 2 I launches of the loop captured into ONE hipGraph per frame -- the loop has
-    //  no host decision in it.  Off by default: see DESIGN.md section 5 for what it did to the launch-bound chain.)
-    const bool      debugSweeps = ctxOption( ctx, "REFINE_DEBUG" ) != nullptr;
-    const char*     graphOpt    = ctxOption( ctx, "REFINE_GRAPH" );
-    const bool      asGraph     = graphOpt && graphOpt[0] == '1' && !debugSweeps && !wantTiming && !wantTrace;
-    if ( asGraph ) TMC2_HIP( hipStreamBeginCapture( s, hipStreamCaptureModeThreadLocal ) );
-    for ( int iter = 0; iter < iterationCount; ++iter ) {
-      const int cur    = iter & 1, nxt = cur ^ 1;
-      uint4 *   recCur = d_rec.p + size_t( cur ) * V, *recNxt = d_rec.p + size_t( nxt ) * V;
-      hipLaunchKernelGGL( closureKernel, grdClosure, dim3( closureThreads ), closureLds, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p,
-                          devStride, V, run, state[cur], state[nxt], uint32_t( W2 ), d_lists.p, V, counts[cur], counts[nxt], spill,
-                          ctl, ringCap, wantTiming ? d_timing.p + 8 * size_t( iter ) : nullptr );
-      if ( debugSweeps ) {
-        const hipError_t e = hipStreamSynchronize( s );
-        fprintf( stderr, "refine: sweep %d closure done (%d), %u workgroups of %d, run %u, ring %u\n", iter, int( e ), grdClosure.x, closureThreads, run, ringCap );
-      }
-      hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
-                          d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, revOff, revLen, revAdj, d_edge,
-                          d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
-      if ( debugSweeps ) {
-        const hipError_t e = hipStreamSynchronize( s );
-        fprintf( stderr, "refine: sweep %d sweep done (%d)\n", iter, int( e ) );
-      }
-    }
-    if ( asGraph ) {
-      hipGraph_t     graph = nullptr;
-      hipGraphExec_t exec  = nullptr;
-      TMC2_HIP( hipStreamEndCapture( s, &graph ) );
-      TMC2_HIP( hipGraphInstantiate( &exec, graph, nullptr, nullptr, 0 ) );
-      TMC2_HIP( hipGraphLaunch( exec, s ) );
-      // (the executable graph has to outlive its run: the context keeps it until its next refinement, by when the stream has passed it)
-      if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
-      if ( ctx->sweepGraph ) (void)hipGraphDestroy( static_cast<hipGraph_t>( ctx->sweepGraph ) );
-      ctx->sweepGraphExec = exec, ctx->sweepGraph = graph;
-    }
-    ctx->stageEnd( sidSweep );
-    TMC2_HIP( hipGetLastError() );
-    ctx->stageAddHostMs( "refine_sweeps_executed", double( iterationCount ) );  // (counts, not milliseconds: what the
-    ctx->stageAddHostMs( "refine_voxels", double( V ) );                        //  roofline of a sweep is quoted on,
-    ctx->stageAddHostMs( "refine_row_entries", double( totalLen ) );            //  V and L = entries / V)
-    if ( wantTiming ) {
-      std::vector<unsigned long long> t( 8 * size_t( iterationCount ) );
-      TMC2_HIP( hipMemcpyAsync( t.data(), d_timing.p, t.size() * 8, hipMemcpyDeviceToHost, s ) );
-      TMC2_HIP( hipStreamSynchronize( s ) );
-      fprintf( stderr, "refine closure (V = %u, %u workgroups, runs of %u), per sweep: us to the walk | us walking | most hops of a group | hops | spilling workgroups\n", V, grdClosure.x, run );
-      for ( int m = 0; m < iterationCount; ++m )  // wall_clock64 ticks at 100 MHz
-        fprintf( stderr, "  %2d: %5.1f %5.1f %4llu %6llu %3llu\n", m, t[8 * m] * 0.01, t[8 * m + 1] * 0.01, t[8 * m + 2], t[8 * m + 3], t[8 * m + 4] );
-    }
-    if ( wantTrace ) {  // test hook: points moved per sweep
-      std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
-      TMC2_HIP( hipMemcpyAsync( h_flags.data(), d_flags.p, h_flags.size() * 4, hipMemcpyDeviceToHost, s ) );
-      TMC2_HIP( hipStreamSynchronize( s ) );
-      fprintf( stderr, "refine: points moved per sweep:" );
-      for ( int m = 0; m < iterationCount; ++m ) fprintf( stderr, " %u", h_flags[2 * m + 1] );
-      fprintf( stderr, "\n" );
-    }
-    // (no synchronisation: the partition stays on the device and the next stage is queued behind the sweeps; the
-    // buffers go back to the context's pool, whose blocks are only ever reused by work queued on this same stream)
-    return TMC2_OK;
+  // reverse rows (CSR), S records (double-buffered), epochs, closure scratch
+  DevBuf<uint32_t> d_roff, d_radj, d_lists;
+  DevBuf<uint4>    d_rec;
+  TMC2_TRY( d_lists.alloc( size_t( kSubLists ) * V ) );  // (a voxel is listed once per sweep: any sub-list can hold them all)
+  TMC2_TRY( d_rec.alloc( 2 * size_t( V ) ) );
+  const uint32_t *revOff = d_roffG.p, *revLen = d_rlenG.p, *revAdj = d_radjG.p;  // gathered behind the forward rows
+  if ( !byRows ) {  // the rounds 1-3 form: count, prefix sum, scatter
+    TMC2_TRY( d_roff.alloc( size_t( V ) + 1 ) );
+    TMC2_TRY( d_radj.alloc( std::max<size_t>( totalLen, 1 ) ) );
+    hipLaunchKernelGGL( reverseCountKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_rcount.p );
+    TMC2_TRY( exclusiveScanU32( ctx, d_rcount.p, d_roff.p, size_t( V ) + 1, nullptr ) );
+    hipLaunchKernelGGL( reverseFillKernel, grdV16, blk, 0, s, d_adjOff.p, d_rowLen.p, d_adj.p, V, d_roff.p, d_rcursor.p,
+                        d_radj.p );
+    revOff = d_roff.p, revLen = nullptr, revAdj = d_radj.p;
   }
-  if ( devRange != 1 ) {
-    setError( "refineSegmentationGridBased: %u voxels of %d: beyond the event-driven sweep loop", V, voxDim );
-    return TMC2_E_UNSUPPORTED;
-  }
+  hipLaunchKernelGGL( smoothInitKernel, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
+                      d_rowLen.p, d_adj.p, V, d_rec.p );
   ctx->stageEnd( sidSetup );
   TMC2_HIP( hipGetLastError() );
-
   const int sidSweep = ctx->stageBegin( "refine_sweeps" );
-  DevBuf<uint32_t> d_out, d_bits;
-  TMC2_TRY( d_out.alloc( size_t( V ) * 32 ) );
-  TMC2_TRY( d_bits.alloc( 3 * size_t( W ) ) );
-  uint32_t *d_activeBits = d_bits.p, *d_frontierBits = d_bits.p + W, *d_nextBits = d_bits.p + 2 * size_t( W );
-  TMC2_HIP( hipMemsetAsync( d_bits.p, 0, 3 * size_t( W ) * 4, s ) );
-  const size_t tailLds   = 3 * size_t( W ) * 4;
-  // (test hook TMC2_REFINE_TAIL=global: take the global-memory tail regardless, the path of grids > 349 K voxels)
-  const char*  tailEnv   = ctxOption( ctx, "REFINE_TAIL" );
-  const bool   tailInLds = tailLds <= 128 * 1024 && !( tailEnv && tailEnv[0] == 'g' );
-  if ( tailInLds && tailLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureTailKernel ), tailLds, ctx->device ) );
-  // d_flags: [0] fixpoint reached; [2k + 1] sweep k moved a point; [2k + 2] sweep k changed a voxel state
-  for ( int iter = 0; iter < iterationCount; ++iter ) {
-    if ( iter == 0 )
-      hipLaunchKernelGGL( smoothKernel<false>, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
-    else
-      hipLaunchKernelGGL( smoothKernel<true>, grdV16, blk, 0, s, reinterpret_cast<const uint4*>( d_hist.p ), d_adjOff.p,
-                          d_rowLen.p, d_adj.p, V, d_S.p, d_arg, d_proc, d_edge, d_ppi, d_active, d_marked, d_flags.p, iter );
-    hipLaunchKernelGGL( closureRoundZeroKernel, dim3( ( V + 7 ) / 8 ), blk, 0, s, d_edge, d_ppi, d_arg, d_dev.p, V, d_active, d_marked,
-                        d_out.p, d_activeBits, d_frontierBits, d_flags.p, iter );
-    if ( tailInLds )
-      hipLaunchKernelGGL( closureTailKernel, dim3( 1 ), dim3( 1024 ), tailLds, s, d_out.p, W, d_active, d_marked,
-                          d_activeBits, d_frontierBits, d_flags.p );
-    else
-      hipLaunchKernelGGL( closureTailGlobalKernel, dim3( 1 ), dim3( 1024 ), 0, s, d_out.p, W, d_active, d_marked,
-                          d_activeBits, d_frontierBits, d_nextBits, d_flags.p );
-    hipLaunchKernelGGL( rescoreVoxelsKernel, grdV16, blk, 0, s, d_edge, d_ppi, d_active, d_S.p, d_weight.p, d_pointStart.p,
-                        d_pointList.p, f->d_normals.p, V, d_proc, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p,
-                        d_flags.p, iter );
-    // the voxel-state update of this sweep rides in the next sweep's smoothKernel; after the last sweep nobody reads it
+  // closureKernel: a run of voxels per workgroup; LDS = the run's active voxels + the ring
+  // (test hooks: TMC2_REFINE_CLOSURE_BLOCKS = its grid, TMC2_REFINE_CLOSURE_THREADS = its workgroup; TMC2_REFINE_RING = room
+  // of the LDS ring beyond the run -- 1 sends nearly every fan-out through the spill ring)
+  const char*    gridEnv    = ctxOption( ctx, "REFINE_CLOSURE_BLOCKS" );
+  const char*    threadsEnv = ctxOption( ctx, "REFINE_CLOSURE_THREADS" );
+  const char*    ringEnv    = ctxOption( ctx, "REFINE_RING" );
+  const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 512;
+  const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
+  const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
+                                      : std::min<uint32_t>( ( refineOverlap( ctx ) ? 4u : 2u ) * uint32_t( ctx->cuCount ),
+                                                            ( V + perGroup * ( closureThreads / 32 ) - 1 ) / ( perGroup * ( closureThreads / 32 ) ) );
+  // (two workgroups per CU: 8 % slower alone than four and 3 % more frames per second with sixteen frames in flight -- a
+  // workgroup's groups idle through most of the walk, and idle waves are in the way of the other frames' kernels)
+  const uint32_t run        = std::min<uint32_t>( 8192u, std::max<uint32_t>( 1u, ( V + wantGrid - 1 ) / wantGrid ) );
+  const dim3     grdClosure( ( V + run - 1 ) / run );
+  const uint32_t ringCap    = run + ( ringEnv ? uint32_t( std::min( 8192, std::max( 1, atoi( ringEnv ) ) ) ) : 1024u );
+  const size_t   closureLds = 4 * ( size_t( run ) + ringCap );
+  if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
+  // (test hook TMC2_REFINE_SWEEP_BLOCKS: the sweep kernel's grid)
+  const char* sweepGridEnv = ctxOption( ctx, "REFINE_SWEEP_BLOCKS" );
+  const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap( ctx ) ? 8 : 4 ) * ctx->cuCount ) ) );
+  // (tmc2_set_refine_overlap( 1 ) = "few frames in flight": the chip has room, so both kernels of a sweep take the grids that
+  //  are fastest with the GPU to themselves -- four closure workgroups and eight sweep workgroups per CU)
+  // (round 4 sweep over the grids, 16 frames in flight / one sweep alone: sweep kernel 2 / 4 / 8 / 16 workgroups per CU ->
+  //  loot 109.0 / 108.1 / 107.1 / 106.6 frames/s, 338 / 327 / 305 / 289 us; longdress 174.1 / 174.9 frames/s, 54.8 / 51.9 us;
+  //  closure 1 / 2 / 4 / 8 per CU -> loot 109.3 / 109.0 / 107.8 / 107.1 frames/s, 434 / 338 / 308 / 291 us: all within
+  //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure)
+  const bool wantTrace = ctxOption( ctx, "REFINE_TRACE" ) != nullptr;
+  DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
+  const bool                 wantTiming = ctxOption( ctx, "REFINE_TIMING" ) != nullptr;
+  if ( wantTiming ) {
+    TMC2_TRY( d_timing.alloc( 8 * size_t( iterationCount ) ) );
+    TMC2_HIP( hipMemsetAsync( d_timing.p, 0, 64 * size_t( iterationCount ), s ) );
   }
-  std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
-  TMC2_HIP( hipMemcpyAsync( h_flags.data(), d_flags.p, h_flags.size() * 4, hipMemcpyDeviceToHost, s ) );
-  ctx->stageEnd( sidSweep );
-  TMC2_HIP( hipGetLastError() );
-  TMC2_HIP( hipStreamSynchronize( s ) );
-  {
-    int executed = iterationCount;
-    if ( h_flags[0] )
-      for ( int m = 1; m < iterationCount; ++m )
-        if ( h_flags[2 * m - 1] == 0 && h_flags[2 * m] == 0 ) {
-          executed = m;
-          break;
-        }
-    ctx->stageAddHostMs( "refine_sweeps_executed", double( executed ) );  // (a count, not milliseconds)
-    if ( ctxOption( ctx, "REFINE_TRACE" ) ) {  // test hook: points moved per sweep
-      fprintf( stderr, "refine: points moved per sweep:" );
-      for ( int m = 0; m < iterationCount; ++m ) fprintf( stderr, " %u", h_flags[2 * m + 1] );
-      fprintf( stderr, "\n" );
+  // d_gbits: state bitmaps of the two sweep parities | list counters of the two parities (one per 128 bytes) | ring head,
+  // tail | the spill ring
+  uint32_t*  state[2]  = {d_gbits.p, d_gbits.p + W2};
+  uint32_t*  counts[2] = {d_gbits.p + 2 * size_t( W2 ), d_gbits.p + 2 * size_t( W2 ) + kSubLists * 32};
+  uint32_t*  ctl       = d_gbits.p + 2 * size_t( W2 ) + 2 * kSubLists * 32;
+  uint32_t*  spill     = ctl + 64;
+  // (option REFINE_GRAPH=1, measured in round 5: the 2 I launches of the loop captured into ONE hipGraph per frame -- the loop has
+  //  no host decision in it.  Off by default: see DESIGN.md section 5 for what it did to the launch-bound chain.)
+  const bool      debugSweeps = ctxOption( ctx, "REFINE_DEBUG" ) != nullptr;
+  const char*     graphOpt    = ctxOption( ctx, "REFINE_GRAPH" );
+  const bool      asGraph     = graphOpt && graphOpt[0] == '1' && !debugSweeps && !wantTiming && !wantTrace;
+  if ( asGraph ) TMC2_HIP( hipStreamBeginCapture( s, hipStreamCaptureModeThreadLocal ) );
+  for ( int iter = 0; iter < iterationCount; ++iter ) {
+    const int cur    = iter & 1, nxt = cur ^ 1;
+    uint4 *   recCur = d_rec.p + size_t( cur ) * V, *recNxt = d_rec.p + size_t( nxt ) * V;
+    hipLaunchKernelGGL( closureKernel, grdClosure, dim3( closureThreads ), closureLds, s, d_edge, d_ppi, recCur, recNxt, d_dev.p, d_devLen.p,
+                        devStride, V, run, state[cur], state[nxt], uint32_t( W2 ), d_lists.p, V, counts[cur], counts[nxt], spill,
+                        ctl, ringCap, wantTiming ? d_timing.p + 8 * size_t( iter ) : nullptr );
+    if ( debugSweeps ) {
+      const hipError_t e = hipStreamSynchronize( s );
+      fprintf( stderr, "refine: sweep %d closure done (%d), %u workgroups of %d, run %u, ring %u\n", iter, int( e ), grdClosure.x, closureThreads, run, ringCap );
+    }
+    hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
+                        d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, revOff, revLen, revAdj, d_edge,
+                        d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
+    if ( debugSweeps ) {
+      const hipError_t e = hipStreamSynchronize( s );
+      fprintf( stderr, "refine: sweep %d sweep done (%d)\n", iter, int( e ) );
     }
   }
+  if ( asGraph ) {
+    hipGraph_t     graph = nullptr;
+    hipGraphExec_t exec  = nullptr;
+    TMC2_HIP( hipStreamEndCapture( s, &graph ) );
+    TMC2_HIP( hipGraphInstantiate( &exec, graph, nullptr, nullptr, 0 ) );
+    TMC2_HIP( hipGraphLaunch( exec, s ) );
+    // (the executable graph has to outlive its run: the context keeps it until its next refinement, by when the stream has passed it)
+    if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
+    if ( ctx->sweepGraph ) (void)hipGraphDestroy( static_cast<hipGraph_t>( ctx->sweepGraph ) );
+    ctx->sweepGraphExec = exec, ctx->sweepGraph = graph;
+  }
+  ctx->stageEnd( sidSweep );
+  TMC2_HIP( hipGetLastError() );
+  ctx->stageAddHostMs( "refine_sweeps_executed", double( iterationCount ) );  // (counts, not milliseconds: what the
+  ctx->stageAddHostMs( "refine_voxels", double( V ) );                        //  roofline of a sweep is quoted on,
+  ctx->stageAddHostMs( "refine_row_entries", double( totalLen ) );            //  V and L = entries / V)
+  if ( wantTiming ) {
+    std::vector<unsigned long long> t( 8 * size_t( iterationCount ) );
+    TMC2_HIP( hipMemcpyAsync( t.data(), d_timing.p, t.size() * 8, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    fprintf( stderr, "refine closure (V = %u, %u workgroups, runs of %u), per sweep: us to the walk | us walking | most hops of a group | hops | spilling workgroups\n", V, grdClosure.x, run );
+    for ( int m = 0; m < iterationCount; ++m )  // wall_clock64 ticks at 100 MHz
+      fprintf( stderr, "  %2d: %5.1f %5.1f %4llu %6llu %3llu\n", m, t[8 * m] * 0.01, t[8 * m + 1] * 0.01, t[8 * m + 2], t[8 * m + 3], t[8 * m + 4] );
+  }
+  if ( wantTrace ) {  // test hook: points moved per sweep
+    std::vector<uint32_t> h_flags( 2 * size_t( iterationCount ) + 2 );
+    TMC2_HIP( hipMemcpyAsync( h_flags.data(), d_flags.p, h_flags.size() * 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    fprintf( stderr, "refine: points moved per sweep:" );
+    for ( int m = 0; m < iterationCount; ++m ) fprintf( stderr, " %u", h_flags[2 * m + 1] );
+    fprintf( stderr, "\n" );
+  }
+  // (no synchronisation: the partition stays on the device and the next stage is queued behind the sweeps; the
+  // buffers go back to the context's pool, whose blocks are only ever reused by work queued on this same stream)
   return TMC2_OK;
 }
 

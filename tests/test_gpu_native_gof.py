@@ -236,17 +236,17 @@ def test_gpu_native_gof_sharded_over_the_gpus_of_this_box(tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_two_contexts_two_sets_of_options():
-    """Options are per context (tmc2_ctx_set_option): two contexts of one process build the same tree through different tiers of
-    the device builder, and the environment is read once, when a context is created."""
+    """Options are per context (tmc2_ctx_set_option): two contexts of one process build the same tree through different forms of
+    the piece kernel, and the environment is read once, when a context is created."""
     import os
     xyz, _ = synth_cloud("medium")
     a = T.Context(0)
-    os.environ["TMC2_KD_FORM"] = "tiers"
+    os.environ["TMC2_KD_PIECE_PER"] = "8"
     try:
         b = T.Context(0)
     finally:
-        del os.environ["TMC2_KD_FORM"]
-    assert a.get_option("KD_FORM") is None and b.get_option("KD_FORM") == "tiers"
+        del os.environ["TMC2_KD_PIECE_PER"]
+    assert a.get_option("KD_PIECE_PER") is None and b.get_option("KD_PIECE_PER") == "8"
     a.set_option("TMC2_KD_HUGEMAX", 4096)                      # (the prefix is accepted)
     assert a.get_option("KD_HUGEMAX") == "4096"
     fa, fb = a.frame(xyz), b.frame(xyz)
