@@ -675,7 +675,6 @@ def main():
     # behind each other, and 16 frames in flight keep the chip busy (measured: 12 -> 62, 16 -> 73, 20 -> 68, 24 -> 55, 32 -> 64 frames/s)
     workers = a.workers or max(1, min(len(clouds), 16, (os.cpu_count() or 8) // world))
     slots = host_slots(a.host_steps, world, min(len(clouds), workers))
-    T.load_library().tmc2_set_host_parallelism(slots)
     # many frames in flight and idle host cores: the (exact) host k-d tree builder leaves the GPU to the other stages
     # (round 1 preferred host builds above 8 frames in flight; with the subtree-finishing device build the device wins:
     #  16 frames in flight, measured: device 85, host 75 frames/s -- and the host cores stay free)
@@ -685,6 +684,7 @@ def main():
     enc = T.GofEncoder(local, workers, a.iterations, c["bits3d"], P, c["min_w"], c["min_h"], timing=True, first_domain=rank * workers,
                        vox_dim=c["vox_dim"])
     enc.set_option("KDTREE_HOST", kd_mode)                # (options of this encoder's contexts: nothing process-wide)
+    enc.set_host_slots(slots)                             # (this encoder's own gate around the host-resident steps)
     reserve_note = None
     if a.reserve:                                          # the sequence's largest frame, before the first one arrives
         try:

@@ -96,9 +96,17 @@ void        tmc2_host_free( void* p );
  * rank of a one-process-per-GPU run lands its frames' canvases where the process that runs the video encoder reads them) */
 int         tmc2_host_register( void* p, size_t bytes );
 int         tmc2_host_unregister( void* p );
-/* process-wide limit on concurrently running host-resident steps (k-d tree builds, normal orientation); 0 = none.
- * Frames of a GOF run on separate host threads; this keeps the cache-hungry host steps at the core-complex count
- * while the GPU phases of the other frames proceed.                                                          */
+/* Limit on concurrently running host-resident steps (k-d tree builds of option KDTREE_HOST, the normal orientation's walk); 0 =
+ * none.  Frames of a GOF run on separate host threads; the gate keeps the cache-hungry host steps at the core-complex count while
+ * the GPU phases of the other frames proceed.  A gate is an object an encoder shares among ITS contexts (round 6: two encoders of
+ * one process do not draw on one count): tmc2_host_gate_create, tmc2_ctx_set_host_gate( ctx, gate ) on each (gate NULL: back to the
+ * default), tmc2_host_gate_destroy when the encoder is done (contexts that still hold it keep it alive).  A context without a gate
+ * uses the process' default one, whose limit tmc2_set_host_parallelism presets -- the last of the old process-wide setters, kept
+ * for callers that have a single encoder.                                                                              */
+typedef struct tmc2_host_gate tmc2_host_gate;
+int         tmc2_host_gate_create( int maxConcurrentHostSteps, tmc2_host_gate** out );
+void        tmc2_host_gate_destroy( tmc2_host_gate* gate );
+int         tmc2_ctx_set_host_gate( tmc2_ctx* ctx, tmc2_host_gate* gate );
 void        tmc2_set_host_parallelism( int maxConcurrentHostSteps );
 /* Per-context options: everything that tunes or cross-checks the path is a property of ONE context -- no process-global state, and
  * the library does not look at the environment while it runs.  key = the knob's name (DESIGN.md section 5 lists them):

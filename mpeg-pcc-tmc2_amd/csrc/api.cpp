@@ -47,28 +47,48 @@ void setError( const char* fmt, ... ) {
   g_lastError = buf;
 }
 
-static std::mutex              g_gateMutex;
-static std::condition_variable g_gateCv;
-static int                     g_gateLimit = 0, g_gateBusy = 0;
-void setHostParallelism( int n ) {
-  std::lock_guard<std::mutex> g( g_gateMutex );
-  g_gateLimit = n < 0 ? 0 : n;
-  g_gateCv.notify_all();
+// The gate around the host-resident, cache-hungry steps.  Round 6: a gate is an OBJECT (tmc2_host_gate_create) that an encoder
+// shares among its own contexts (tmc2_ctx_set_host_gate) -- two encoders of one process no longer draw on one process-wide count;
+// a context without one uses the process' default gate, whose limit tmc2_set_host_parallelism presets (0: none).
+}  // namespace tmc2
+struct tmc2_host_gate {
+  std::mutex              lock;
+  std::condition_variable freed;
+  int                     limit = 0, busy = 0;
+};
+namespace tmc2 {
+static std::shared_ptr<tmc2_host_gate> defaultGate() {
+  static std::shared_ptr<tmc2_host_gate> g = std::make_shared<tmc2_host_gate>();
+  return g;
 }
-HostGate::HostGate( bool wait ) {
-  std::unique_lock<std::mutex> lk( g_gateMutex );
-  if ( !wait && g_gateLimit != 0 && g_gateBusy >= g_gateLimit ) return;  // no free slot: not held
-  g_gateCv.wait( lk, [] { return g_gateLimit == 0 || g_gateBusy < g_gateLimit; } );
-  ++g_gateBusy;
+void setHostParallelism( int n ) {
+  const auto                  g = defaultGate();
+  std::lock_guard<std::mutex> lk( g->lock );
+  g->limit = n < 0 ? 0 : n;
+  g->freed.notify_all();
+}
+HostGate::HostGate( const tmc2_ctx* ctx, bool wait ) {
+  {
+    std::shared_ptr<tmc2_host_gate> own;
+    if ( ctx ) {
+      std::lock_guard<std::mutex> lk( ctx->optionsLock );
+      own = ctx->hostGate;
+    }
+    gate = own ? own : defaultGate();
+  }
+  std::unique_lock<std::mutex> lk( gate->lock );
+  if ( !wait && gate->limit != 0 && gate->busy >= gate->limit ) return;  // no free slot: not held
+  gate->freed.wait( lk, [this] { return gate->limit == 0 || gate->busy < gate->limit; } );
+  ++gate->busy;
   held = true;
 }
 HostGate::~HostGate() { release(); }
 void HostGate::release() {
   if ( !held ) return;
   held = false;
-  std::lock_guard<std::mutex> g( g_gateMutex );
-  --g_gateBusy;
-  g_gateCv.notify_one();
+  std::lock_guard<std::mutex> g( gate->lock );
+  --gate->busy;
+  gate->freed.notify_one();
 }
 
 static thread_local tmc2_ctx* g_tlsCtx = nullptr;
@@ -404,6 +424,47 @@ int tmc2_host_unregister( void* p ) {
 }
 
 void tmc2_set_host_parallelism( int maxConcurrentHostSteps ) { tmc2::setHostParallelism( maxConcurrentHostSteps ); }
+/* One encoder's budget of concurrently running host-resident steps (the k-d tree builds of option KDTREE_HOST, the orientation
+   walk): shared by the contexts it is set on, and by nobody else.  The handle is the creator's; the contexts keep the gate alive. */
+namespace {
+std::mutex                                                  g_gatesLock;
+std::map<tmc2_host_gate*, std::shared_ptr<tmc2_host_gate>> g_gates;  // handles handed out -> the shared object
+}  // namespace
+int tmc2_host_gate_create( int maxConcurrentHostSteps, tmc2_host_gate** out ) {
+  if ( !out || maxConcurrentHostSteps < 0 ) {
+    tmc2::setError( "tmc2_host_gate_create: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  auto g   = std::make_shared<tmc2_host_gate>();
+  g->limit = maxConcurrentHostSteps;
+  std::lock_guard<std::mutex> lk( g_gatesLock );
+  g_gates[g.get()] = g;
+  *out             = g.get();
+  return TMC2_OK;
+}
+void tmc2_host_gate_destroy( tmc2_host_gate* gate ) {
+  std::lock_guard<std::mutex> lk( g_gatesLock );
+  g_gates.erase( gate );  // (contexts that still use it keep it alive)
+}
+int tmc2_ctx_set_host_gate( tmc2_ctx* ctx, tmc2_host_gate* gate ) {
+  if ( !ctx ) {
+    tmc2::setError( "tmc2_ctx_set_host_gate: invalid argument" );
+    return TMC2_E_INVALID;
+  }
+  std::shared_ptr<tmc2_host_gate> g;
+  if ( gate ) {
+    std::lock_guard<std::mutex> lk( g_gatesLock );
+    const auto                  it = g_gates.find( gate );
+    if ( it == g_gates.end() ) {
+      tmc2::setError( "tmc2_ctx_set_host_gate: not a live gate" );
+      return TMC2_E_INVALID;
+    }
+    g = it->second;
+  }
+  std::lock_guard<std::mutex> lk( ctx->optionsLock );
+  ctx->hostGate = g;
+  return TMC2_OK;
+}
 
 int tmc2_ctx_synchronize( tmc2_ctx* ctx ) {
   if ( !ctx ) return TMC2_E_INVALID;
@@ -531,7 +592,7 @@ int tmc2_frame::ensureTree() {
   if ( haveTree ) return TMC2_OK;
   const int placement = tmc2::kdtreePlacement( ctx );
   // adaptive: take a host slot if one is free right now, otherwise the device builds it (same tree either way)
-  tmc2::HostGate gate( placement == 1 );
+  tmc2::HostGate gate( ctx, placement == 1 );
   if ( placement == 0 || !gate.held ) {
     const int sid = ctx->stageBegin( "kdtree_build" );
     TMC2_TRY( tmc2::buildKdTreeDevice( ctx, d_pts.p, n, d_ptsTree, d_perm, d_nodes, tree.lo, tree.hi, tree.depth ) );

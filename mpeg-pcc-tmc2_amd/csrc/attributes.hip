@@ -503,7 +503,7 @@ int reconstructPointCloud( tmc2_frame* f ) {
   f->reconCount = M;
   // ---- tree over the reconstruction (like S1) --------------------------------------------------------------
   const int placement = kdtreePlacement( ctx );
-  HostGate  treeGate( placement == 1 );
+  HostGate  treeGate( ctx, placement == 1 );
   if ( placement == 0 || !treeGate.held ) {
     const int kt = ctx->stageBegin( "kdtree_build_recon" );
     TMC2_TRY( buildKdTreeDevice( ctx, f->d_recon.p, M, f->d_reconTreePts, f->d_reconPerm, f->d_reconNodes, f->reconTree.lo,

@@ -252,6 +252,7 @@ struct tmc2_ctx {
   // environment after that, and nothing is process-wide: two encoders of one process can run with different settings.
   std::map<std::string, std::string> options;
   mutable std::mutex                 optionsLock;
+  std::shared_ptr<tmc2_host_gate>    hostGate;  // this encoder's budget of host-resident steps (guarded by optionsLock); null: the process default
   void* sweepGraph = nullptr;      // option REFINE_GRAPH: the hipGraph_t / hipGraphExec_t of the last refinement's sweeps (kept until the next one)
   void* sweepGraphExec = nullptr;
   hipStream_t                   stream = nullptr;
@@ -353,14 +354,16 @@ struct tmc2_frame {
 };
 
 namespace tmc2 {
-// Process-wide gate around the host-resident, cache-hungry steps (k-d tree build, normal orientation): each walks a
-// ~100 MB working set, so running more of them at once than there are last-level-cache domains makes all of them
-// slower.  Frames beyond the limit wait here while their siblings' GPU phases proceed.  0 = unlimited.
+// Gate around the host-resident, cache-hungry steps (k-d tree build, normal orientation): each walks a ~100 MB working set, so
+// running more of them at once than there are last-level-cache domains makes all of them slower.  Frames beyond the limit wait here
+// while their siblings' GPU phases proceed.  The gate is the context's own (tmc2_ctx_set_host_gate: one per encoder) or, without
+// one, the process' default (tmc2_set_host_parallelism).  0 = unlimited.
 struct HostGate {
-  explicit HostGate( bool wait = true );  // wait = false: take a slot only if one is free right now
+  explicit HostGate( const tmc2_ctx* ctx, bool wait = true );  // wait = false: take a slot only if one is free right now
   ~HostGate();
   void release();
   bool held = false;
+  std::shared_ptr<tmc2_host_gate> gate;
 };
 void setHostParallelism( int n );
 // RAII guard of every extern "C" entry: selects the device and makes the context's pool current

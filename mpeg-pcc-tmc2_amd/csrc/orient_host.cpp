@@ -909,7 +909,7 @@ int orientNormalsHost( tmc2_frame* f ) {
       std::vector<uint32_t> seeds, seedClusters, component( C );
       bool                  ok;
       {
-        HostGate   gate;
+        HostGate   gate( ctx );
         const auto t0 = std::chrono::steady_clock::now();
         ok            = orientCompactSigns( g, tau, clusterSign, component.data(), seeds, seedClusters );
         const auto t1 = std::chrono::steady_clock::now();
@@ -948,7 +948,7 @@ int orientNormalsHost( tmc2_frame* f ) {
   TMC2_HIP( hipStreamSynchronize( s ) );
   std::chrono::steady_clock::time_point t0, t1;
   {
-    HostGate gate;
+    HostGate gate( ctx );
     t0 = std::chrono::steady_clock::now();
     orientSpanningTreeSigns( f->h_xyz.data(), n, knn, f->k, nrm, dots, sign, ctx->orientScratch.data(), false, ctx );
     t1 = std::chrono::steady_clock::now();

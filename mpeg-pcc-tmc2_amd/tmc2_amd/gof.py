@@ -191,6 +191,16 @@ class GofEncoder:
         self.ctxs = [t.ctx for t in self.threads]
         if os.environ.get("TMC2_REFINE_OVERLAP") is None:      # (an option of THIS encoder's contexts: nothing process-wide)
             self.set_option("REFINE_OVERLAP", 1 if workers <= 4 else 0)
+        self.gate = None
+
+    def set_host_slots(self, slots):
+        """At most `slots` host-resident steps (orientation walks, host tree builds) of THIS encoder's frames at a time (0: no
+        limit): a gate of its own on its contexts (tmc2_host_gate_create / tmc2_ctx_set_host_gate), nothing process-wide."""
+        old, self.gate = self.gate, lib.HostGate(slots)
+        for c in self.ctxs:
+            c.set_host_gate(self.gate)
+        if old is not None:
+            old.close()
 
     def set_option(self, key, value):
         """tmc2_ctx_set_option on every context of this encoder (value None: unset)."""
@@ -221,6 +231,9 @@ class GofEncoder:
                 t.join()
             for c in self.ctxs:
                 c.close()
+        if self.gate is not None:
+            self.gate.close()
+            self.gate = None
 
     def upload(self, clouds):
         """Untimed: copy the GOF's point arrays to HBM (frame i lives on worker i % workers)."""

@@ -146,6 +146,10 @@ def load_library():
     L.tmc2_ctx_get_option.argtypes = [C.c_void_p, C.c_char_p]
     L.tmc2_ctx_get_option.restype = C.c_char_p
     L.tmc2_set_host_parallelism.restype = None
+    L.tmc2_host_gate_create.argtypes = [C.c_int, C.c_void_p]
+    L.tmc2_host_gate_destroy.argtypes = [C.c_void_p]
+    L.tmc2_host_gate_destroy.restype = None
+    L.tmc2_ctx_set_host_gate.argtypes = [C.c_void_p, C.c_void_p]
     L.tmc2_ctx_stage_name.restype = C.c_char_p
     L.tmc2_ctx_stage_ms.restype = C.c_double
     L.tmc2_frame_point_count.restype = C.c_uint64
@@ -158,6 +162,27 @@ def _check(rc):
         _guard_finish()
     if rc != 0:
         raise Tmc2Error("tmc2hip error %d: %s" % (rc, load_library().tmc2_last_error().decode()))
+
+
+class HostGate:
+    """One encoder's budget of concurrently running host-resident steps (tmc2_host_gate_create): shared by the contexts it is set
+    on (Context.set_host_gate) and by nobody else -- two encoders of one process do not draw on one process-wide count."""
+
+    def __init__(self, limit):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _check(self.L.tmc2_host_gate_create(int(limit), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.tmc2_host_gate_destroy(self.h)       # (contexts that still hold the gate keep it alive)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -188,6 +213,10 @@ class Context:
     def get_option(self, key):
         v = self.L.tmc2_ctx_get_option(self.h, key.encode())
         return None if v is None else v.decode()
+
+    def set_host_gate(self, gate):
+        """This context's host-resident steps wait at `gate` (a HostGate; None: the process' default gate again)."""
+        _check(self.L.tmc2_ctx_set_host_gate(self.h, None if gate is None else gate.h))
 
     def reserve(self, max_points, vox_dim, bits3d, max_w, max_h):
         """tmc2_ctx_reserve: the device memory of the sequence's largest frame, allocated now (no first-use hipMalloc later)."""

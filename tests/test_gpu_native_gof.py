@@ -256,6 +256,29 @@ def test_gpu_two_contexts_two_sets_of_options():
     assert "kdtree_build" in a.stage_ms() and "kdtree_build" in b.stage_ms()
     a.set_option("KD_HUGEMAX", None)
     assert a.get_option("KD_HUGEMAX") is None
+    # ... and so is the gate around the host-resident steps (tmc2_host_gate_create / tmc2_ctx_set_host_gate): two contexts behind ONE
+    # gate of one slot orient their frames from two threads -- one walk at a time, both finish; a third context keeps the default gate
+    import threading
+    gate = T.HostGate(1)
+    a.set_host_gate(gate)
+    b.set_host_gate(gate)
+    errs = []
+
+    def orient(fr):
+        try:
+            fr.normals_compute(16, 1)
+        except Exception as e:                                 # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=orient, args=(fr,)) for fr in (fa, fb)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs and np.array_equal(fa.get_normals().view(np.uint64), fb.get_normals().view(np.uint64))
+    gate.close()                                               # (the contexts keep it alive)
+    fa.reset()
+    fa.normals_compute(16, 1)
+    a.set_host_gate(None)
     st = a.pool_stats()
     assert st["bytes_held"] > 0 and st["hipmalloc_calls"] > 0 and st["carved_blocks"] == 0
     c = T.Context(0)

@@ -690,3 +690,18 @@ def test_gof_encoder_without_a_device_fails_instead_of_waiting():
     w.join(60)
     assert not w.is_alive(), "GofEncoder() is still waiting for a worker that died"
     assert result and "no HIP device" in result[0]
+
+
+def test_host_gate_is_an_object_of_the_caller():
+    """tmc2_host_gate_create / tmc2_host_gate_destroy / tmc2_ctx_set_host_gate (round 6: an encoder's own budget of host-resident
+    steps instead of one process-wide count): argument errors without a device."""
+    import ctypes as C
+    L = T.load_library()
+    g = C.c_void_p()
+    assert L.tmc2_host_gate_create(4, C.byref(g)) == 0 and g.value
+    assert L.tmc2_host_gate_create(-1, C.byref(g)) != 0
+    assert L.tmc2_host_gate_create(0, None) != 0
+    assert L.tmc2_ctx_set_host_gate(None, g) != 0 and b"invalid argument" in L.tmc2_last_error()
+    L.tmc2_host_gate_destroy(g)
+    L.tmc2_host_gate_destroy(g)                                # (twice: harmless)
+    L.tmc2_host_gate_destroy(None)
