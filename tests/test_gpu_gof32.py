@@ -24,6 +24,10 @@ GOF32 = {
     "redandblack_vox10_ai_r3_gof32": (2, 1, False),
     "soldier_vox10_ai_r3_gof32": (2, 1, False),
     "basketball_player_vox11_ra_r5_gof32": (2, 1, True),
+    # not a BASELINE configuration: the rough shell (1.4 M points a frame, three voxels thick) -- S3's contraction barely contracts,
+    # the pair table of the compact graph overflows on every frame and the host walks a graph of the cloud's own size: the one
+    # workload that leaves S3's happy path, pinned at size since round 6 (8 frames, all in flight)
+    "longdress_vox10_noisy_ai_r3_gof8": (1, 1, False),
 }
 
 
@@ -41,7 +45,7 @@ def test_gpu_gof32_sixteen_in_flight(name, monkeypatch):
     c, g, frames = gof_input(name)
     checked, plain, decoder = GOF32[name]
     monkeypatch.setenv("TMC2_UF_CHECK", "1")
-    enc = T.GofEncoder(0, workers=16, iterations=c["iterations"], bits3d=c["bits3d"], occ_precision=c["precision"],
+    enc = T.GofEncoder(0, workers=min(16, len(frames)), iterations=c["iterations"], bits3d=c["bits3d"], occ_precision=c["precision"],
                        min_w=c["min_w"], min_h=c["min_h"], vox_dim=c["vox_dim"])
     try:
         frs = enc.upload(frames)
