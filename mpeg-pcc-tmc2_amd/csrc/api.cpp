@@ -265,6 +265,13 @@ int tmc2_ctx_create( int device, tmc2_ctx** out ) {
     delete c;
     return TMC2_E_HIP;
   }
+  if ( hipHostMalloc( reinterpret_cast<void**>( &c->mailbox ), tmc2_ctx::kMailboxWords * 4, hipHostMallocDefault ) != hipSuccess ) {
+    setError( "hipHostMalloc failed (the context's mailbox)" );
+    (void)hipStreamDestroy( c->stream );
+    delete c;
+    return TMC2_E_HIP;
+  }
+  memset( c->mailbox, 0, tmc2_ctx::kMailboxWords * 4 );
   *out = c;
   return TMC2_OK;
 }
@@ -381,12 +388,14 @@ void tmc2::destroyContextNow( tmc2_ctx* ctx ) {
     ctx->gridBits.release();
     ctx->scanState.release();
     ctx->voxelBitmap.release();
+    ctx->constTables.clear();
   }
   if ( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
   if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
   if ( ctx->sweepGraph ) (void)hipGraphDestroy( static_cast<hipGraph_t>( ctx->sweepGraph ) );
   ctx->pool.drain();
   if ( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
+  if ( ctx->mailbox ) (void)hipHostFree( ctx->mailbox );
   delete ctx;
 }
 
@@ -587,6 +596,22 @@ bool unionCheck( const tmc2_ctx* ctx ) {
 void setRefineOverlapDefault( int on ) { g_refineOverlap.store( on ? 1 : 0, std::memory_order_relaxed ); }
 void setKdtreePlacement( int mode ) { g_kdtreeOnHost.store( mode < 0 || mode > 2 ? 0 : mode, std::memory_order_relaxed ); }
 }  // namespace tmc2
+
+const int* tmc2_ctx::constTable( uint64_t key, const std::vector<int>& host ) {
+  auto it = constTables.find( key );
+  if ( it != constTables.end() && it->second->count == host.size() ) return it->second->p;
+  auto buf = std::make_unique<tmc2::DevBuf<int>>();
+  if ( buf->alloc( std::max<size_t>( host.size(), 1 ) ) != TMC2_OK ) return nullptr;
+  buf->count = host.size();  // (the key's table: its length is part of the identity)
+  // (synchronous: the vector is the caller's local, and this happens once per context and key)
+  if ( !host.empty() && hipMemcpy( buf->p, host.data(), host.size() * sizeof( int ), hipMemcpyHostToDevice ) != hipSuccess ) {
+    tmc2::setError( "constTable: upload failed" );
+    return nullptr;
+  }
+  const int* p     = buf->p;
+  constTables[key] = std::move( buf );
+  return p;
+}
 
 int tmc2_frame::ensureTree() {
   if ( haveTree ) return TMC2_OK;

@@ -247,6 +247,17 @@ struct tmc2_ctx {
   uint32_t                      scanEpoch = 0, scanTickets = 0;
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)
   std::map<uint32_t, int>       kdLevelHint;     // levels of level passes the last device k-d tree of ~ this size took (by n >> 15)
+  // small tables that depend on the parameters only (the probe offsets of S9, the ball rows / cells of S5): uploaded once per context
+  // and key, not once per frame (round 6: each was a pageable host-to-device copy -- a staging copy and a blit -- on every frame's chain)
+  std::map<uint64_t, std::unique_ptr<tmc2::DevBuf<int>>> constTables;
+  const int* constTable( uint64_t key, const std::vector<int>& host );  // nullptr on failure (the error is set)
+  // Page-locked words the device writes and the host reads without a copy (allocated with the context; kernels take the pointer as
+  // it is: page-locked host memory is mapped into the device's address space): the answers of the stages' host round trips, one
+  // 64-byte line each (kAnswer*: which stage owns which line).  A kernel stores its answer with ONE plain store from its last
+  // workgroup; the host reads it after the hipStreamSynchronize it needed anyway -- no staging copy, no blit kernel on the chain.
+  uint32_t* mailbox = nullptr;
+  static constexpr size_t kMailboxWords = 1024;
+  volatile uint32_t* answerLine( int line ) const { return mailbox + size_t( line ) * 16; }
   // Per-context options (tmc2_ctx_set_option): key = the name of the knob without its TMC2_ prefix.  Filled ONCE, when the
   // context is created, from the process environment (every TMC2_* variable: the defaults); nothing in the library reads the
   // environment after that, and nothing is process-wide: two encoders of one process can run with different settings.

@@ -777,7 +777,6 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   DevBuf<uint32_t> d_label, d_ccCount, d_flag, d_rank, d_dist, d_small, d_tilePatch, d_d0src, d_parent, d_root, d_lab;
   DevBuf<uint8_t>  d_raw;
   DevBuf<int32_t>  d_pointPatch, d_minUv, d_bbox, d_patchStat, d_d0tmp, d_d1tmp;
-  DevBuf<int>      d_offsets;
   DevBuf<PatchDev> d_patches;
   DevBuf<unsigned long long> d_map64;
   TMC2_TRY( d_label.alloc( n ) );
@@ -791,8 +790,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_TRY( d_raw.alloc( n ) );
   TMC2_TRY( d_pointPatch.alloc( n ) );
   TMC2_TRY( d_small.alloc( 16 ) );
-  TMC2_TRY( d_offsets.alloc( offsets.size() ) );
-  TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
+  const int* d_offsets = ctx->constTable( ( uint64_t( 0x5339 ) << 32 ) | uint64_t( probeR2 ), offsets );  // (S9's probe offsets: a function of the thresholds)
+  if ( !d_offsets ) return TMC2_E_HIP;
   TMC2_TRY( fillRegions( ctx, {{ctx->voxelBitmap.p, bitmapWords * 4, 0},
                                {d_raw.p, n, 1},
                                {d_dist.p, size_t( n ) * 4, 0xFF},
@@ -945,7 +944,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
                         f->d_occupancy.p, d_patchStat.p );
     std::vector<int32_t> h_stat( 2 * size_t( P ) + 1 );  // (copied after the raw-point update below: its count rides along)
     // ---- S9 -----------------------------------------------------------------------------------------
-    hipLaunchKernelGGL( rawDistanceKernel, grdN, blk, 0, s, f->d_pts.p, n, ctx->voxelBitmap.p, bitmapBits, d_offsets.p,
+    hipLaunchKernelGGL( rawDistanceKernel, grdN, blk, 0, s, f->d_pts.p, n, ctx->voxelBitmap.p, bitmapBits, d_offsets,
                         int( offsets.size() ), thrSel, d_dist.p, d_raw.p, d_rawCount );
     TMC2_HIP( hipMemcpyAsync( h_stat.data(), d_patchStat.p, h_stat.size() * 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );

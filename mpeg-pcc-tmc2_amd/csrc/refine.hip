@@ -1167,7 +1167,7 @@ struct RefineJob {
   DevBuf<Pt>      d_centre;
   DevBuf<double>  d_weight;
   DevBuf<uint8_t> d_state;  // edge | ppi, V bytes each (padded to whole 32-voxel words)
-  DevBuf<int>     d_offsets;
+  const int*      d_offsets = nullptr;  // the ball's rows / cells: the context's table for ( radius, form )
   bool matches( int nn, double l, int it, int vd, int sr ) const {
     return nn == maxNNCount && l == lambda && it == iterationCount && vd == voxDim && sr == searchRadius;
   }
@@ -1191,13 +1191,13 @@ void RefineJob::launchNeighbourhood() {
   const int nBall = int( offsets.size() );  // rows or cells
 #define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
   hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
-                      d_count.p, table, g, V, d_offsets.p, nBall, maxNNCount, lambda, idBits, devRange, devStride,             \
+                      d_count.p, table, g, V, d_offsets, nBall, maxNNCount, lambda, idBits, devRange, devStride,             \
                       uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
                       d_small.p + 2, byRows ? bits : (const uint2*)nullptr, d_voxelOfRank.p,                                  \
                       byRows ? d_lastKey.p : (uint32_t*)nullptr );                                                              \
   if ( byRows )                                                                                                                \
   hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, d_voxelOfRank.p, \
-                      bits, g, V, d_offsets.p, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
+                      bits, g, V, d_offsets, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
                       d_small.p + 3, d_small.p + 2 )
   // LDS per wavefront = room for the ball's OCCUPIED cells (row-wise form; a surface fills 5-10 % of a ball) or for all its
   // cells; the smaller the room, the more wavefronts a CU holds (1024: 8 per SIMD, 4096: 2.5) -- a frame whose balls need more
@@ -1320,7 +1320,6 @@ int RefineJob::geometry( tmc2_frame* f ) {
   Vp = ( size_t( V ) + 63 ) & ~size_t( 63 );  // sub-arrays of the state block: whole, aligned 32-voxel words
   TMC2_TRY( d_state.alloc( Vp * 2 ) );
   TMC2_TRY( d_activeBuf.alloc( V ) );
-  TMC2_TRY( d_offsets.alloc( offsets.size() ) );
   // every buffer of this stage that starts from zeros, in one launch (the event-driven loop's among them)
   W = ( V + 31 ) / 32;
   W2          = ( size_t( V ) + 15 ) / 16;  // closure state: two bits per voxel
@@ -1346,7 +1345,8 @@ int RefineJob::geometry( tmc2_frame* f ) {
                                {d_lastRescore.p, size_t( V ) * 4, 0},
                                {d_gbits.p, closureZeroWords * 4, 0},
                                {d_gbits.p + closureZeroWords, size_t( V ) * 4, 0xFF}} ) );  // kNoVoxel
-  TMC2_HIP( hipMemcpyAsync( d_offsets.p, offsets.data(), offsets.size() * sizeof( int ), hipMemcpyHostToDevice, s ) );
+  d_offsets = ctx->constTable( ( uint64_t( 0x5335 ) << 32 ) | ( uint64_t( r2 ) << 1 ) | ( byRows ? 1u : 0u ), offsets );
+  if ( !d_offsets ) return TMC2_E_HIP;
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, bits, d_firstPoint.p, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
   if ( byRows ) {

@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 (RESET, WEIGHT, SEGMENT, PACK_FLEXIBLE, PACK_CHAIN, GPA, PACKED_SIZE, GEOMETRY, ATTRIBUTE, GET_GEOMETRY, GET_ATTRIBUTE, PLACE,
  SET_PACKING) = range(1, 14)
 MIN_W, MIN_H = 128, 128
+# TMC2_TEST_SANITIZE=thread | address,undefined: the recorders and the runner are built with that sanitizer (run the module with
+# the matching runtime preloaded: LD_PRELOAD=$(g++ -print-file-name=libtsan.so); tools/sanitize_gof_runner.sh does both)
+SANITIZE = ["-fsanitize=" + os.environ["TMC2_TEST_SANITIZE"], "-g", "-fno-omit-frame-pointer"] if os.environ.get("TMC2_TEST_SANITIZE") else []
 
 
 class Config(C.Structure):
@@ -23,11 +26,11 @@ class Config(C.Structure):
 def runner(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("mock_gof"))
     inc = os.path.join(ROOT, "include")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc,
-                    os.path.join(ROOT, "tests", "mock", "mock_tmc2hip.cpp"), "-o", os.path.join(d, "libtmc2hipmock.so"), "-pthread"], check=True)
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc,
-                    os.path.join(ROOT, "mpeg-pcc-tmc2_amd", "host", "gof_runner.cpp"), "-o", os.path.join(d, "libtmc2gofmock.so"),
-                    "-L" + d, "-ltmc2hipmock", "-Wl,-rpath," + d, "-pthread"], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc] + SANITIZE +
+                   [os.path.join(ROOT, "tests", "mock", "mock_tmc2hip.cpp"), "-o", os.path.join(d, "libtmc2hipmock.so"), "-pthread"], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc] + SANITIZE +
+                   [os.path.join(ROOT, "mpeg-pcc-tmc2_amd", "host", "gof_runner.cpp"), "-o", os.path.join(d, "libtmc2gofmock.so"),
+                    "-L" + d, "-ltmc2hipmock", "-Wl,-rpath," + d, "-pthread", "-ldl"], check=True)
     M = C.CDLL(os.path.join(d, "libtmc2hipmock.so"), mode=C.RTLD_GLOBAL)
     G = C.CDLL(os.path.join(d, "libtmc2gofmock.so"))
     M.mock_frame.restype = C.c_void_p
@@ -273,7 +276,7 @@ def _sharded_rank(args):
 def sharded_libs(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("mock_gof_sharded"))
     inc = os.path.join(ROOT, "include")
-    flags = ["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc]
+    flags = ["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I" + inc] + SANITIZE
     subprocess.run(flags + [os.path.join(ROOT, "tests", "mock", "mock_tmc2hip.cpp"), "-o", os.path.join(d, "libtmc2hipmock.so"), "-pthread"], check=True)
     subprocess.run(flags + [os.path.join(ROOT, "tests", "mock", "mock_rccl.cpp"), "-o", os.path.join(d, "libmockrccl.so")], check=True)
     subprocess.run(flags + [os.path.join(ROOT, "mpeg-pcc-tmc2_amd", "host", "gof_runner.cpp"), "-o", os.path.join(d, "libtmc2gofmock.so"),
