@@ -445,7 +445,7 @@ int gatherSeedTables( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_par
 int orientSpanningTreeSigns( const int16_t* xyz, size_t n, const uint32_t* knn, int k, const double* normals,
                              const double* edgeDot, int8_t* sign, void* scratch, bool tryContraction, const tmc2_ctx* ctx );
 double orientFirstTau( const tmc2_ctx* ctx );
-int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_cid,
+int contractOrientationDevice( tmc2_frame* f, double tau, DevBuf<uint32_t>& d_cid,
                                DevBuf<uint8_t>& d_parity, OrientCompact& g, bool& ok );
 int launchClusterSigns( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_parity, const int8_t* d_clusterSign,
                         int8_t* d_sign );

@@ -29,32 +29,73 @@ __device__ __forceinline__ uint32_t ballot16( bool pred, int lane ) {  // the 16
   return uint32_t( __ballot( pred ) >> ( lane & 48 ) ) & 0xFFFFu;
 }
 
+// n_u . n_v with the operand order and rounding of the reference's dot product (PCCMath.h operator*; -ffp-contract=off): the ONE
+// place the contraction computes it.  Rounds 2-5 kept the 16 N doubles in HBM (edgeDotKernel: 107 MB written, read again by four
+// kernels); since round 6 a pass gets the classes it needs as bits (strongAll / negAll below) and the few edges whose VALUE matters
+// -- the cross edges, ~ 4 % -- are recomputed from the two normals where they are used (same expression: same bits).
+__device__ __forceinline__ double edgeDotOf( const double* __restrict__ normals, uint32_t u, uint32_t v ) {
+  const double* a = normals + 3 * size_t( u );
+  const double* b = normals + 3 * size_t( v );
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// Which 16-point group a workgroup takes next.  The passes over the edges walk the points in TREE order (perm: tree position ->
+// point; neighbours in space are neighbours in the tree) and XCD x works through the x-th eighth of the groups (block b runs on
+// XCD b % 8 -- observed, not promised: only speed depends on it; the mapping of knnKernel): the rows, words and cluster records a
+// group's neighbours need are the ones its own XCD's L2 has just fetched, instead of every L2 seeing every region of the cloud.
+// perm == nullptr (an adjacency that came from the caller: no tree): index order, same eighths.
+struct GroupWalk {
+  uint32_t g, end, step;
+  __device__ __forceinline__ GroupWalk( uint32_t groups, bool chunked ) {  // (chunked: gridDim.x is a multiple of 8)
+    if ( !chunked ) {
+      g = blockIdx.x, end = groups, step = gridDim.x;
+      return;
+    }
+    const uint32_t x = blockIdx.x & 7u, perXcd = gridDim.x >> 3;
+    const uint32_t begin = uint32_t( ( uint64_t( groups ) * x ) >> 3 );
+    end  = uint32_t( ( uint64_t( groups ) * ( x + 1u ) ) >> 3 );
+    g    = begin + ( blockIdx.x >> 3 );
+    step = perXcd;
+  }
+};
+// ... and which point a lane of a one-point-per-lane pass takes (n: none)
+__device__ __forceinline__ uint32_t pointOfLane( const uint32_t* __restrict__ perm, bool chunked, uint32_t n ) {
+  uint32_t block = blockIdx.x;
+  if ( chunked ) block = ( blockIdx.x & 7u ) * ( gridDim.x >> 3 ) + ( blockIdx.x >> 3 );
+  const uint32_t at = block * blockDim.x + threadIdx.x;
+  return at < n ? ( perm ? perm[at] : at ) : n;
+}
+
 // Initial forest without a single atomic: every point hooks itself under the mutual strong neighbour of smallest hashed
 // priority, if that is smaller than its own (priorities strictly decrease along parent links: no cycles; the word
 // states a true relation).  Most of the union work is done before the first compare-and-swap, and the paths the
 // union pass walks end at local priority minima a few steps away.
+// Also the classes of the point's 16 edges as bits: strongAll (|n_u . n_v| >= tau), negAll (n_u . n_v < 0), mask = strongAll &
+// mutual (mutual bits: ensureMutualMask, shared with S7).
 template <int K>
-__global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                           const uint16_t* __restrict__ mutual, double tau, uint32_t n,
-                                                           uint16_t* __restrict__ mask, uint32_t* __restrict__ word,
-                                                           uint32_t* __restrict__ count ) {
+__global__ __launch_bounds__( 256 ) void initWordsKernel( const uint32_t* __restrict__ knn, const double* __restrict__ normals,
+                                                           const uint16_t* __restrict__ mutual, const uint32_t* __restrict__ perm,
+                                                           bool chunked, double tau, uint32_t n, uint16_t* __restrict__ mask,
+                                                           uint16_t* __restrict__ strongAll, uint16_t* __restrict__ negAll,
+                                                           uint32_t* __restrict__ word, uint32_t* __restrict__ count ) {
   static_assert( K == 16, "16 lanes per point" );
   const int j = threadIdx.x & 15, lane = threadIdx.x & 63;
-  for ( uint32_t i = blockIdx.x * 16 + ( threadIdx.x >> 4 ); i <= n; i += gridDim.x * 16 ) {  // (uniform over the 16 lanes of a point)
-  if ( i == n ) {
-    if ( j == 0 ) count[n] = 0;
-    continue;
-  }
-  // bit j of mask[i]: neighbour j is a mutual strong one (mutual bits: ensureMutualMask, shared with S7)
-  const double dj   = edgeDot[size_t( i ) * K + j];
-  const bool   cand = ( ( mutual[i] >> j ) & 1u ) && fabs( dj ) >= tau;
+  if ( blockIdx.x == 0 && threadIdx.x == 0 ) count[n] = 0;
+  for ( GroupWalk w( ( n + 15 ) / 16, chunked ); w.g < w.end; w.g += w.step ) {  // (uniform over the 16 lanes of a point)
+  const uint32_t at = w.g * 16 + ( threadIdx.x >> 4 );
+  if ( at >= n ) continue;
+  const uint32_t i  = perm ? perm[at] : at;
+  const uint32_t vj = knn[size_t( i ) * K + j];
+  const double   dj = edgeDotOf( normals, i, vj );
+  const bool     strong = fabs( dj ) >= tau;
+  const bool     cand   = ( ( mutual[i] >> j ) & 1u ) && strong;
   {
-    const uint32_t bits = ballot16( cand, lane );
-    if ( j == 0 ) mask[i] = uint16_t( bits );
+    const uint32_t bits = ballot16( cand, lane ), sb = ballot16( strong, lane ), nb = ballot16( dj < 0.0, lane );
+    if ( j == 0 ) mask[i] = uint16_t( bits ), strongAll[i] = uint16_t( sb ), negAll[i] = uint16_t( nb );
   }
   // candidate of this lane: neighbour j if it is a mutual strong one, else the point itself (first minimum wins below, as
   // the sequential scan over the set bits in ascending j did: strict "<" kept the earliest)
-  const uint32_t v    = cand ? knn[size_t( i ) * K + j] : i;
+  const uint32_t v    = cand ? vj : i;
   uint32_t       prio = cand ? ufPriority( v ) : 0xFFFFFFFFu;
   uint32_t       best = v, parity = cand && dj < 0.0 ? 1u : 0u;
   uint32_t       slot = uint32_t( j );
@@ -122,19 +163,23 @@ __device__ __forceinline__ bool paritySameSetStale( const uint32_t* word, uint32
 }
 
 template <int K>
-__global__ __launch_bounds__( 256 ) void parityUnionKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                             const uint16_t* __restrict__ mask, uint32_t n,
-                                                             uint32_t* __restrict__ word, int precheck, bool agent ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__( 256 ) void parityUnionKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ negAll,
+                                                             const uint16_t* __restrict__ mask, const uint32_t* __restrict__ perm,
+                                                             bool chunked, uint32_t n, uint32_t* __restrict__ word, int precheck,
+                                                             bool agent ) {
+  // (one point per lane; chunked: XCD x takes the x-th eighth of the blocks -- the words a lane's climbs touch belong to points
+  //  around its own, which the same L2 serves)
+  const uint32_t u = pointOfLane( perm, chunked, n );
   if ( u >= n ) return;
-  uint32_t m = mask[u];
+  uint32_t       m = mask[u];
+  const uint32_t neg = negAll[u];
   while ( m ) {
     const int j = __ffs( int( m ) ) - 1;
     m &= m - 1;
     const uint32_t v = knn[size_t( u ) * K + j];
     if ( v > u ) continue;  // every mutual edge is seen from both ends: the larger one acts
     if ( precheck && paritySameSetStale( word, u, v, agent ) ) continue;
-    const uint32_t s = edgeDot[size_t( u ) * K + j] < 0.0 ? 1u : 0u;  // 1: the two normals must get opposite signs
+    const uint32_t s = ( neg >> j ) & 1u;  // 1: the two normals must get opposite signs
     for ( ;; ) {
       uint32_t pa, pb;
       uint32_t a = parityFind( word, u, pa, agent ), b = parityFind( word, v, pb, agent );
@@ -181,9 +226,10 @@ __global__ __launch_bounds__( 256 ) void parityCheckKernel( const uint32_t* __re
   }
 }
 
-__global__ __launch_bounds__( 256 ) void flattenKernel( uint32_t n, uint32_t* __restrict__ word, uint32_t* __restrict__ root,
+__global__ __launch_bounds__( 256 ) void flattenKernel( uint32_t n, const uint32_t* __restrict__ perm, bool chunked,
+                                                         uint32_t* __restrict__ word, uint32_t* __restrict__ root,
                                                          uint8_t* __restrict__ parity, uint32_t* __restrict__ minIdx, bool agent ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t u = pointOfLane( perm, chunked, n );  // (as parityUnionKernel)
   if ( u >= n ) return;
   uint32_t       p;
   const uint32_t r = parityFind( word, u, p, agent );
@@ -240,38 +286,41 @@ __global__ __launch_bounds__( 256 ) void clusterFlagKernel( const uint32_t* __re
 // pass 1 over the edges (16 lanes per point, lane j = edge j): the cluster ids (rank of the cluster's first member), the
 // mutual strong edges against the settled parities, the cross edges into the pair table -- light ones raise the pair's best |d|
 template <int K>
-__global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                            const uint16_t* __restrict__ mask, const uint32_t* __restrict__ root,
+__global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __restrict__ knn, const double* __restrict__ normals,
+                                                            const uint16_t* __restrict__ strongAll, const uint16_t* __restrict__ negAll,
+                                                            const uint32_t* __restrict__ perm, bool chunked, const uint32_t* __restrict__ root,
                                                             const uint32_t* __restrict__ minIdx, const uint32_t* __restrict__ rank,
-                                                            const uint8_t* __restrict__ parity, uint32_t n, double tau, PairTable t,
+                                                            const uint8_t* __restrict__ parity, uint32_t n, PairTable t,
                                                             uint32_t* __restrict__ cid, uint16_t* __restrict__ crossMask,
                                                             uint32_t* __restrict__ flags /* [0] bad, [2] overflow */ ) {
   static_assert( K == 16, "16 lanes per point" );
   const int j = threadIdx.x & 15, lane = threadIdx.x & 63;
-  for ( uint32_t g0 = blockIdx.x * 16; g0 < n; g0 += gridDim.x * 16 ) {
-  const uint32_t u = g0 + ( threadIdx.x >> 4 );
-  const bool     in = u < n;
+  for ( GroupWalk w( ( n + 15 ) / 16, chunked ); w.g < w.end; w.g += w.step ) {
+  const uint32_t at = w.g * 16 + ( threadIdx.x >> 4 );
+  const bool     in = at < n;
+  const uint32_t u  = in ? ( perm ? perm[at] : at ) : 0u;
   bool           isCross = false, wrong = false, full = false;
   if ( in ) {
     const uint32_t cu = rank[minIdx[root[u]]], v = knn[size_t( u ) * K + j], cv = rank[minIdx[root[v]]];
-    const double   d  = edgeDot[size_t( u ) * K + j];
+    const bool     strong = ( strongAll[u] >> j ) & 1u;
+    const uint32_t neg    = ( negAll[u] >> j ) & 1u;
     if ( j == 0 ) cid[u] = cu;
     isCross = cv != cu;
     // every strong edge with both ends in one cluster -- the mutual ones the cluster was built from AND the one-way ones that
     // happen to fall inside it -- must agree with the parities: the growth may take any of them first (orient_host.cpp,
     // contractOnHost)
-    if ( !isCross && fabs( d ) >= tau ) wrong = ( uint32_t( parity[u] ) ^ parity[v] ) != ( d < 0.0 ? 1u : 0u );
+    if ( !isCross && strong ) wrong = ( uint32_t( parity[u] ) ^ parity[v] ) != neg;
     if ( isCross ) {
       const uint32_t s = pairSlot( t, cu, cv, true );
       if ( s == 0xFFFFFFFFu )
         full = true;
-      else if ( fabs( d ) < tau ) {
-        const unsigned long long w = (unsigned long long)__double_as_longlong( fabs( d ) );
-        if ( w > __hip_atomic_load( &t.bestW[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &t.bestW[s], w );
+      else if ( !strong ) {
+        const unsigned long long wgt = (unsigned long long)__double_as_longlong( fabs( edgeDotOf( normals, u, v ) ) );
+        if ( wgt > __hip_atomic_load( &t.bestW[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMax( &t.bestW[s], wgt );
       } else {
         // a strong one-way edge: one per implied relative sign is enough, and it is the FIRST in (start, slot) order -- the one
         // the host-only reduction keeps (compactOnHost), whatever the scheduling
-        uint32_t* first = &t.strongFirst[2 * size_t( s ) + ( ( d < 0.0 ? 1u : 0u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )];
+        uint32_t* first = &t.strongFirst[2 * size_t( s ) + ( neg ^ ( uint32_t( parity[u] ) ^ parity[v] ) )];
         const uint32_t id = u * 16u + uint32_t( j );
         if ( id < __hip_atomic_load( first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) atomicMin( first, id );
       }
@@ -286,16 +335,19 @@ __global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __res
 // pass 2: the edges the walk gets -- bit j of keepMask[u] -- and their number per source cluster (one report per workgroup and
 // cluster, as verifyCountKernel).  dedupe = false: every cross edge (the table overflowed).
 template <int K>
-__global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
-                                                            const uint16_t* __restrict__ crossMask, const uint32_t* __restrict__ cid,
-                                                            const uint8_t* __restrict__ parity, uint32_t n, double tau, PairTable t,
-                                                            int dedupe, uint16_t* __restrict__ keepMask, uint32_t* __restrict__ count ) {
+__global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __restrict__ knn, const double* __restrict__ normals,
+                                                            const uint16_t* __restrict__ strongAll, const uint16_t* __restrict__ negAll,
+                                                            const uint32_t* __restrict__ perm, bool chunked, const uint16_t* __restrict__ crossMask,
+                                                            const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
+                                                            uint32_t n, PairTable t, int dedupe, uint16_t* __restrict__ keepMask,
+                                                            uint32_t* __restrict__ count ) {
   static_assert( K == 16, "16 lanes per point" );
   const int           j = threadIdx.x & 15, lane = threadIdx.x & 63;
   __shared__ uint32_t sCid[16], sKept[16];
-  for ( uint32_t g0 = blockIdx.x * 16; g0 < n; g0 += gridDim.x * 16 ) {  // (uniform over the workgroup: barriers inside)
-  const uint32_t u = g0 + ( threadIdx.x >> 4 );
-  const bool     in = u < n;
+  for ( GroupWalk w( ( n + 15 ) / 16, chunked ); w.g < w.end; w.g += w.step ) {  // (uniform over the workgroup: barriers inside)
+  const uint32_t at = w.g * 16 + ( threadIdx.x >> 4 );
+  const bool     in = at < n;
+  const uint32_t u  = in ? ( perm ? perm[at] : at ) : 0u;
   bool           keep = false;
   uint32_t       cu = 0xFFFFFFFFu;
   if ( in ) {
@@ -303,14 +355,13 @@ __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __res
     keep = ( crossMask[u] >> j ) & 1u;
     if ( keep && dedupe ) {
       const uint32_t v = knn[size_t( u ) * K + j];
-      const double   d = edgeDot[size_t( u ) * K + j];
       const uint32_t s = pairSlot( t, cu, cid[v], false );
       if ( s == 0xFFFFFFFFu ) {
         keep = true;  // (unreachable after a clean insert pass; harmless: an extra edge)
-      } else if ( fabs( d ) >= tau ) {
-        keep = t.strongFirst[2 * size_t( s ) + ( ( d < 0.0 ? 1u : 0u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )] == u * 16u + uint32_t( j );
+      } else if ( ( strongAll[u] >> j ) & 1u ) {
+        keep = t.strongFirst[2 * size_t( s ) + ( ( ( negAll[u] >> j ) & 1u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )] == u * 16u + uint32_t( j );
       } else {
-        keep = (unsigned long long)__double_as_longlong( fabs( d ) ) == t.bestW[s];
+        keep = (unsigned long long)__double_as_longlong( fabs( edgeDotOf( normals, u, v ) ) ) == t.bestW[s];
       }
     }
   }
@@ -334,7 +385,8 @@ __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __res
 }
 // the kept edges, per source cluster, with the target cluster and the two ends' parities folded into the dot product
 template <int K>
-__global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* __restrict__ knn, const double* __restrict__ edgeDot,
+__global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* __restrict__ knn, const double* __restrict__ normals,
+                                                                const uint32_t* __restrict__ perm, bool chunked,
                                                                 const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
                                                                 const uint32_t* __restrict__ off, const uint16_t* __restrict__ keepMask,
                                                                 const uint32_t* __restrict__ root, const uint32_t* __restrict__ minIdx,
@@ -344,9 +396,10 @@ __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* _
   static_assert( K == 16, "16 lanes per point" );
   const int           j = threadIdx.x & 15, p = threadIdx.x >> 4;
   __shared__ uint32_t sCid[16], sKept[16], sBase[16];
-  for ( uint32_t g0 = blockIdx.x * 16; g0 < n; g0 += gridDim.x * 16 ) {  // (uniform over the workgroup: barriers inside)
-  const uint32_t u = g0 + ( threadIdx.x >> 4 );
-  const bool     in = u < n;
+  for ( GroupWalk w( ( n + 15 ) / 16, chunked ); w.g < w.end; w.g += w.step ) {  // (uniform over the workgroup: barriers inside)
+  const uint32_t at = w.g * 16 + ( threadIdx.x >> 4 );
+  const bool     in = at < n;
+  const uint32_t u  = in ? ( perm ? perm[at] : at ) : 0u;
   const uint32_t m  = in ? keepMask[u] : 0u;
   const uint32_t cu = in ? cid[u] : 0xFFFFFFFFu;
   if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( m ) );
@@ -370,21 +423,21 @@ __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* _
   }
   __syncthreads();
   if ( m ) {  // (uniform over the 16 lanes of a point)
-  uint32_t at = 0;
+  uint32_t pos0 = 0;
   if ( j == 0 ) {
     int lead = p;
     for ( int q = 0; q < p; ++q ) {
       if ( sCid[q] != cu || !sKept[q] ) continue;
       if ( lead == p ) lead = q;
-      at += sKept[q];
+      pos0 += sKept[q];
     }
-    at += sBase[lead];
+    pos0 += sBase[lead];
   }
-  at = __shfl( at, ( threadIdx.x & 63 ) & 48, 64 );
+  pos0 = __shfl( pos0, ( threadIdx.x & 63 ) & 48, 64 );
   if ( ( m >> j ) & 1u ) {
     const uint32_t v = knn[size_t( u ) * K + j];
-    const double   d = edgeDot[size_t( u ) * K + j];
-    const uint32_t pos = at + __popc( m & ( ( 1u << j ) - 1u ) );
+    const double   d = edgeDotOf( normals, u, v );
+    const uint32_t pos = pos0 + __popc( m & ( ( 1u << j ) - 1u ) );
     if ( pos < edgeCap ) edges[pos] = OrientCompactEdge{u, v, cid[v], 0u, ( ( parity[u] ^ parity[v] ) & 1 ) ? -d : d};
   }
   }
@@ -447,19 +500,20 @@ int gatherSeedTables( tmc2_frame* f, const uint32_t* d_cid, const uint8_t* d_par
 // Contracts the orientation graph of frame f on the device (k = 16) and brings its COMPACT form to the host (page-locked
 // staging of the context): clusters numbered by first member, one light cross edge per ordered pair of clusters (+ the strong
 // one-way ones).  ok = false: some cluster's strong edges disagree.  d_cid / d_parity stay valid for launchClusterSigns.
-int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double tau, DevBuf<uint32_t>& d_cid, DevBuf<uint8_t>& d_parity,
-                               OrientCompact& g, bool& ok ) {
+int contractOrientationDevice( tmc2_frame* f, double tau, DevBuf<uint32_t>& d_cid, DevBuf<uint8_t>& d_parity, OrientCompact& g, bool& ok ) {
   tmc2_ctx*      ctx = f->ctx;
   hipStream_t    s   = ctx->stream;
   const uint32_t n   = uint32_t( f->n );
   ok                 = false;
   if ( f->k != 16 ) return TMC2_OK;  // not instantiated: the caller walks the points
   DevBuf<uint32_t> d_word, d_count, d_off, d_cursor, d_small, d_root, d_minIdx, d_flag, d_rank, d_strongFirst;
-  DevBuf<uint16_t> d_mask, d_crossMask, d_keepMask;
+  DevBuf<uint16_t> d_mask, d_strongAll, d_negAll, d_crossMask, d_keepMask;
   DevBuf<unsigned long long> d_pairs;
   TMC2_TRY( d_word.alloc( n ) );
   TMC2_TRY( d_small.alloc( 8 ) );  // [0] bad flag, [1] kept cross edges, [2] pair table overflow, [3] clusters; [4], [5]: debug check
   TMC2_TRY( d_mask.alloc( n ) );
+  TMC2_TRY( d_strongAll.alloc( n ) );
+  TMC2_TRY( d_negAll.alloc( n ) );
   TMC2_TRY( d_root.alloc( n ) );
   TMC2_TRY( d_minIdx.alloc( n ) );
   TMC2_TRY( d_flag.alloc( n ) );
@@ -480,11 +534,23 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
                                {d_pairs.p, 2 * size_t( pairCap ) * 8, 0},
                                {d_strongFirst.p, 2 * size_t( pairCap ) * 4, 0xFF}} ) );
   TMC2_TRY( ensureMutualMask( f ) );
-  const dim3 grdN16( cappedBlocks( ctx, ( size_t( n ) + 15 ) / 16 ) );  // 16 lanes per point, groups of 16 points in a stride loop
+  // 16 lanes per point, groups of 16 points in a stride loop; the grids are multiples of 8 (GroupWalk: XCD x takes the x-th eighth)
+  const dim3 grdN16( ( cappedBlocks( ctx, ( size_t( n ) + 15 ) / 16 ) + 7u ) & ~7u ), grdN8( ( grdN.x + 7u ) & ~7u );
+  // option ORIENT_ORDER: "input" = index order, blocks as they come (rounds 2-5); "chunk" = index order, XCD x on the x-th eighth of
+  // the blocks; "tree" = tree order (perm), same eighths.  Unset: what was fastest pass by pass with the GPU to itself
+  // (profiles/r06_pass_order.txt) -- the union-find passes in eighths (their climbs touch the words of points around their own:
+  // parityUnionKernel 349 -> 272 us), the pair-table passes as the blocks come (in eighths the inserts of a pair of clusters
+  // meet in time: pairInsertKernel 95 -> 106 us); tree order costs every pass its coalesced own-row reads and wins nothing on
+  // clouds that arrive in scan order.
+  const char*     orderOpt = ctxOption( ctx, "ORIENT_ORDER" );
+  const bool      chunked  = !( orderOpt && orderOpt[0] == 'i' );
+  const bool      chunkedPairs = orderOpt && orderOpt[0] != 'i';
+  const uint32_t* perm     = orderOpt && orderOpt[0] == 't' && f->haveTree && f->d_perm.p && f->d_perm.count >= n ? f->d_perm.p : nullptr;
+  const double*   normals  = f->d_normals.p;
   TMC2_TRY( d_count.alloc( size_t( n ) + 1 ) );  // (initWordsKernel zeroes it; later: kept edges per cluster, C + 1 used)
-  hipLaunchKernelGGL( initWordsKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, f->d_mutual.p, tau, n, d_mask.p,
-                      d_word.p, d_count.p );
-  hipLaunchKernelGGL( parityUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, n, d_word.p, unionPrecheck( f->ctx ), unionAgentScope( f->ctx ) );
+  hipLaunchKernelGGL( initWordsKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, f->d_mutual.p, perm, chunked, tau, n, d_mask.p, d_strongAll.p,
+                      d_negAll.p, d_word.p, d_count.p );
+  hipLaunchKernelGGL( parityUnionKernel<16>, grdN8, blk, 0, s, f->d_knn.p, d_negAll.p, d_mask.p, perm, chunked, n, d_word.p, unionPrecheck( f->ctx ), unionAgentScope( f->ctx ) );
   if ( unionCheck( f->ctx ) ) {  // debug invariants (soak tests): costs a round trip
     uint32_t bad[2] = {0, 0};
     hipLaunchKernelGGL( parityCheckKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mask.p, n, d_word.p, d_small.p + 4 );
@@ -495,14 +561,14 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
       return TMC2_E_HIP;
     }
   }
-  hipLaunchKernelGGL( flattenKernel, grdN, blk, 0, s, n, d_word.p, d_root.p, d_parity.p, d_minIdx.p, unionAgentScope( f->ctx ) );
+  hipLaunchKernelGGL( flattenKernel, grdN8, blk, 0, s, n, perm, chunked, d_word.p, d_root.p, d_parity.p, d_minIdx.p, unionAgentScope( f->ctx ) );
   hipLaunchKernelGGL( clusterFlagKernel, grdN, blk, 0, s, d_root.p, d_minIdx.p, n, d_flag.p );
   TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 3 ) );
   TMC2_TRY( d_off.alloc( size_t( n ) + 1 ) );  // (per-cluster arrays sized for the worst case, n clusters: the used part is known
   TMC2_TRY( d_cursor.alloc( n ) );            //  only after the round trip below)
   PairTable t{d_pairs.p, d_pairs.p + pairCap, d_strongFirst.p, pairCap - 1};
-  hipLaunchKernelGGL( pairInsertKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_mask.p, d_root.p, d_minIdx.p, d_rank.p, d_parity.p, n,
-                      tau, t, d_cid.p, d_crossMask.p, d_small.p );
+  hipLaunchKernelGGL( pairInsertKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, chunkedPairs, d_root.p, d_minIdx.p,
+                      d_rank.p, d_parity.p, n, t, d_cid.p, d_crossMask.p, d_small.p );
   // First attempt without knowing the sizes: room for kSpecEdges kept edges and kSpecClusters clusters (three times what a
   // longdress frame needs), everything queued back to back and ONE round trip -- counters, cluster records and edges come
   // back together.  A frame that needs more room (or whose pair table overflowed) is repeated with exact sizes, two round trips.
@@ -524,10 +590,10 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
     return TMC2_E_HIP;
   }
   TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
-  hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, 1,
-                      d_keepMask.p, d_count.p );
+  hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, chunkedPairs, d_crossMask.p, d_cid.p,
+                      d_parity.p, n, t, 1, d_keepMask.p, d_count.p );
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
-  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, chunkedPairs, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
                       d_minIdx.p, n, d_small.p + 3, kSpecEdges, kSpecClusters, d_cursor.p, d_edges.p, d_rec.p );
   TMC2_HIP( hipMemcpyAsync( h_head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
   // (what a frame typically needs, plus a margin, comes along right away; the rest -- if any -- after the counters are known)
@@ -556,8 +622,8 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
       // the pair table overflowed: every cross edge goes (selection and counts again, without the table)
       ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
       TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
-      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_crossMask.p, d_cid.p, d_parity.p, n, tau, t, 0,
-                          d_keepMask.p, d_count.p );
+      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, chunkedPairs, d_crossMask.p, d_cid.p,
+                          d_parity.p, n, t, 0, d_keepMask.p, d_count.p );
       TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
       TMC2_HIP( hipMemcpyAsync( head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
@@ -570,7 +636,7 @@ int contractOrientationDevice( tmc2_frame* f, const double* d_edgeDot, double ta
     }
     TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
     TMC2_TRY( d_rec.alloc( size_t( C ) + 1 ) );
-    hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, d_edgeDot, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+    hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, chunkedPairs, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
                         d_minIdx.p, n, d_small.p + 3, std::max<uint32_t>( E, 1u ), C + 1, d_cursor.p, d_edges.p, d_rec.p );
     h_rec   = ctx->hostA.get<OrientClusterRec>( size_t( C ) + 1 );
     h_edges = ctx->hostE.get<OrientCompactEdge>( std::max<uint32_t>( E, 1u ) );

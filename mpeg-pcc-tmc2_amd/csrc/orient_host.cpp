@@ -884,10 +884,8 @@ int orientNormalsHost( tmc2_frame* f ) {
   DevBuf<int8_t>   d_sign, d_clusterSign;
   DevBuf<uint32_t> d_negCount, d_root;
   DevBuf<uint8_t>  d_parity;
-  TMC2_TRY( d_edgeDot.alloc( edges ) );
   TMC2_TRY( d_sign.alloc( n ) );
   TMC2_TRY( d_negCount.alloc( kOrientNegCountWords ) );
-  TMC2_TRY( launchEdgeDots( f, d_edgeDot.p ) );
   if ( ctx->orientScratch.size() < 2 * n ) ctx->orientScratch.resize( 2 * n );
   // ---- fast path: contract on the device, walk the clusters on the host; a frame that is inconsistent at one threshold is
   // tried with the next (orientTauLadder) --------------------------------------------------------------------------------
@@ -897,7 +895,7 @@ int orientNormalsHost( tmc2_frame* f ) {
     if ( tau != orientFirstTau( ctx ) ) ctx->stageAddHostMs( "orient_tau_retry", 0.0 );  // (counts the repeats with a tighter threshold)
     OrientCompact g{};
     const int     sid = ctx->stageBegin( "orient_contract" );
-    TMC2_TRY( contractOrientationDevice( f, d_edgeDot.p, tau, d_root, d_parity, g, contracted ) );  // (d_root: cluster ids here)
+    TMC2_TRY( contractOrientationDevice( f, tau, d_root, d_parity, g, contracted ) );  // (d_root: cluster ids here)
     ctx->stageEnd( sid );
     if ( contracted ) {
       if ( f->beforeHostWalk ) {  // device work that overlaps the walk (once, whatever the number of thresholds tried)
@@ -934,6 +932,9 @@ int orientNormalsHost( tmc2_frame* f ) {
     ctx->stageAddHostMs( "orient_normals_regrowth", 0.0 );  // counts the frames that needed the point-level walk
 
   // ---- point-level walk: rows, dot products and normals to the host ----------------------------------------------------
+  // (the 16 N dot products exist only here: the contraction works on their classes as bits and recomputes the few values it needs)
+  TMC2_TRY( d_edgeDot.alloc( edges ) );
+  TMC2_TRY( launchEdgeDots( f, d_edgeDot.p ) );
   uint32_t* knn  = ctx->hostA.get<uint32_t>( edges );
   double*   nrm  = ctx->hostB.get<double>( n * 3 );
   double*   dots = ctx->hostE.get<double>( edges );

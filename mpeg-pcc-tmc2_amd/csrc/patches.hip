@@ -80,16 +80,15 @@ __device__ __forceinline__ int waveMaxMasked( int v, bool mine ) {
 
 // bit j of mutual[u] = knn[u][j] lists u in its own row.  Depends only on the adjacency: once per call.
 // Every row is read by the point itself and by its (up to) sixteen in-neighbours: 64 N bytes if each row reached HBM once, sixteen
-// times that if none stayed cached.  Rounds 1-5 walked the points in INPUT order with the blocks dealt round-robin over the eight
-// XCDs: every L2 saw every region of the cloud (counters: 325 MB for 55 MB of contract bytes).  Round 6: the points are taken in
-// TREE order (perm: tree position -> point; neighbours in space are neighbours in the tree) and XCD x works through the x-th
-// eighth of the tree (the mapping of knnKernel) -- the rows a workgroup needs are the rows its neighbours on the same L2 have just
-// fetched.  perm == nullptr: input order (a frame whose adjacency came from the caller has no tree).
+// times that if none stayed cached.  Rounds 1-5 dealt the blocks round-robin over the eight XCDs: every L2 saw every region of the
+// cloud (counters: 325 MB for 55 MB of contract bytes).  Round 6: XCD x works through the x-th eighth of the blocks (the mapping of
+// knnKernel) -- the rows a workgroup needs are the rows its neighbours on the same L2 have just fetched (85 MB); perm != nullptr:
+// the points in TREE order instead of input order (no faster on clouds that arrive in scan order: option MUTUAL_ORDER=tree).
 template <int K>
-__global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __restrict__ knn, const uint32_t* __restrict__ perm, uint32_t n,
-                                                              uint16_t* __restrict__ mutual ) {
+__global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __restrict__ knn, const uint32_t* __restrict__ perm, bool chunked,
+                                                              uint32_t n, uint16_t* __restrict__ mutual ) {
   uint32_t block = blockIdx.x;
-  if ( perm ) {  // (grid: a multiple of 8 blocks; block b runs on XCD b % 8 -- observed, not promised: only speed depends on it)
+  if ( chunked ) {  // (grid: a multiple of 8 blocks; block b runs on XCD b % 8 -- observed, not promised: only speed depends on it)
     const uint32_t perXcd = gridDim.x >> 3;
     block                 = ( blockIdx.x & 7u ) * perXcd + ( blockIdx.x >> 3 );
   }
@@ -122,15 +121,25 @@ __global__ __launch_bounds__( 256 ) void ccMutualMaskKernel( const uint32_t* __r
 
 __device__ __forceinline__ uint32_t ufPriority( uint32_t x ) { return x * 2654435761u; }  // odd multiplier: a bijection
 
+// The point of this lane (n: none).  chunked: XCD x works through the x-th eighth of the blocks (block b runs on XCD b % 8 -- observed,
+// not promised: only speed depends on it; the grid is a multiple of 8 blocks); perm: the points in tree order instead of input order.
+__device__ __forceinline__ uint32_t pointOfLane( const uint32_t* __restrict__ perm, bool chunked, uint32_t n ) {
+  uint32_t block = blockIdx.x;
+  if ( chunked ) block = ( blockIdx.x & 7u ) * ( gridDim.x >> 3 ) + ( blockIdx.x >> 3 );
+  const uint32_t at = block * blockDim.x + threadIdx.x;
+  return at < n ? ( perm ? perm[at] : at ) : n;
+}
+
 // Initial forest without atomics: every raw point hooks itself under the eligible mutual neighbour of smallest hashed
 // priority, if smaller than its own (priorities strictly decrease along parent links: acyclic).  Most unions are done
 // before the first compare-and-swap, and the paths the union pass walks end at local priority minima.
 template <int K>
 __global__ __launch_bounds__( 256 ) void ccInitKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
                                                         const uint8_t* __restrict__ partition, const uint8_t* __restrict__ raw,
-                                                        uint32_t n, uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
+                                                        const uint32_t* __restrict__ perm, bool chunked, uint32_t n,
+                                                        uint32_t* __restrict__ parent, uint32_t* __restrict__ lab,
                                                         uint32_t* __restrict__ ccCount ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = pointOfLane( perm, chunked, n );
   if ( i >= n ) return;
   lab[i]        = kNoLabel;
   ccCount[i]    = 0;
@@ -199,9 +208,10 @@ __device__ __forceinline__ bool ufSameSetStale( const uint32_t* parent, uint32_t
 template <int K>
 __global__ __launch_bounds__( 256 ) void ccUnionKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
                                                          const uint8_t* __restrict__ partition,
-                                                         const uint8_t* __restrict__ raw, uint32_t n,
-                                                         uint32_t* __restrict__ parent, int precheck, bool agent ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+                                                         const uint8_t* __restrict__ raw, const uint32_t* __restrict__ perm,
+                                                         bool chunked, uint32_t n, uint32_t* __restrict__ parent, int precheck,
+                                                         bool agent ) {
+  const uint32_t u = pointOfLane( perm, chunked, n );
   if ( u >= n || !raw[u] ) return;
   uint32_t m = mutual[u];
   if ( !m ) return;
@@ -298,9 +308,10 @@ template <int K>
 __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restrict__ knn, const uint16_t* __restrict__ mutual,
                                                          const uint8_t* __restrict__ partition,
                                                          const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
-                                                         uint32_t n, uint32_t* __restrict__ lab, uint32_t* __restrict__ changed,
-                                                         uint32_t token, bool agent ) {
-  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+                                                         const uint32_t* __restrict__ perm, bool chunked, uint32_t n,
+                                                         uint32_t* __restrict__ lab, uint32_t* __restrict__ changed, uint32_t token,
+                                                         bool agent ) {
+  const uint32_t u = pointOfLane( perm, chunked, n );
   if ( u >= n || !raw[u] ) return;
   uint32_t m = ~uint32_t( mutual[u] ) & ( ( 1u << K ) - 1u );
   if ( !m ) return;
@@ -714,11 +725,14 @@ int ensureMutualMask( tmc2_frame* f ) {
   const uint32_t n = uint32_t( f->n );
   TMC2_TRY( f->d_mutual.alloc( n ) );
   const int kt = f->ctx->stageBegin( "k:ccMutualMask" );
-  const char*     order = ctxOption( f->ctx, "MUTUAL_ORDER" );  // (cross-check hook: "input" = rounds 1-5)
-  const uint32_t* perm  = f->haveTree && f->d_perm.p && f->d_perm.count >= n && !( order && order[0] == 'i' ) ? f->d_perm.p : nullptr;
-  const uint32_t  blocks = ( n + 255 ) / 256;
-  hipLaunchKernelGGL( ccMutualMaskKernel<16>, dim3( perm ? ( ( blocks + 7 ) & ~7u ) : blocks ), dim3( 256 ), 0, f->ctx->stream, f->d_knn.p,
-                      perm, n, f->d_mutual.p );
+  // option MUTUAL_ORDER (this pass and S7's union / relaxation passes): "input" = index order, blocks as they come (rounds 1-5);
+  // "chunk" = index order, XCD x on the x-th eighth of the blocks; "tree" = tree order, same eighths
+  const char*     order   = ctxOption( f->ctx, "MUTUAL_ORDER" );
+  const bool      chunked = !( order && order[0] == 'i' );
+  const uint32_t* perm    = order && order[0] == 't' && f->haveTree && f->d_perm.p && f->d_perm.count >= n ? f->d_perm.p : nullptr;
+  const uint32_t  blocks  = ( n + 255 ) / 256;
+  hipLaunchKernelGGL( ccMutualMaskKernel<16>, dim3( chunked ? ( ( blocks + 7 ) & ~7u ) : blocks ), dim3( 256 ), 0, f->ctx->stream, f->d_knn.p,
+                      perm, chunked, n, f->d_mutual.p );
   f->ctx->stageEnd( kt );
   TMC2_HIP( hipGetLastError() );
   f->haveMutual = true;
@@ -806,14 +820,19 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   TMC2_TRY( ensureMutualMask( f ) );  // usually there already: the orientation (S3) needs the same bits
   DevBuf<uint16_t>& d_mutual   = f->d_mutual;
   const bool        agentScope = unionAgentScope( f->ctx );
+  // the union / relaxation passes: option MUTUAL_ORDER as in ensureMutualMask (here the default is "chunk")
+  const char*     ccOrder = ctxOption( ctx, "MUTUAL_ORDER" );
+  const bool      chunked = !( ccOrder && ccOrder[0] == 'i' );
+  const uint32_t* perm    = ccOrder && ccOrder[0] == 't' && f->haveTree && f->d_perm.p && f->d_perm.count >= n ? f->d_perm.p : nullptr;
+  const dim3      grdT( chunked ? ( ( grdN.x + 7u ) & ~7u ) : grdN.x );
   while ( rawCount > 0 ) {
     // ---- S7 -----------------------------------------------------------------------------------------
     int sid = ctx->stageBegin( "patches_cc" );
-    hipLaunchKernelGGL( ccInitKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n, d_parent.p,
+    hipLaunchKernelGGL( ccInitKernel<16>, grdT, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, perm, chunked, n, d_parent.p,
                         d_lab.p, d_ccCount.p );
     {
       const int kt = ctx->stageBegin( "k:ccUnion" );
-      hipLaunchKernelGGL( ccUnionKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, n,
+      hipLaunchKernelGGL( ccUnionKernel<16>, grdT, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p, perm, chunked, n,
                           d_parent.p, unionPrecheck( f->ctx ), agentScope );
       ctx->stageEnd( kt );
       if ( unionCheck( f->ctx ) ) {  // debug invariants (soak tests): costs a round trip
@@ -837,8 +856,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     for ( int guard = 0; guard < 1 << 20; ++guard ) {
       const int kt = ctx->stageBegin( "k:ccRelax" );
       for ( int b = 0; b < 3; ++b )
-        hipLaunchKernelGGL( ccRelaxKernel<16>, grdN, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
-                            d_root.p, n, d_lab.p, d_small.p, ++relaxToken, agentScope );
+        hipLaunchKernelGGL( ccRelaxKernel<16>, grdT, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
+                            d_root.p, perm, chunked, n, d_lab.p, d_small.p, ++relaxToken, agentScope );
       ctx->stageEnd( kt );
       hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_root.p, d_lab.p, n, d_label.p, d_ccCount.p );
       hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,

@@ -307,9 +307,12 @@ def _assert_patches_equal(got, exp):
     assert np.array_equal(go, exp["occupancy"])
 
 
-@pytest.mark.parametrize("name,iters", [("tiny", 10), ("small", 10), ("medium", 20)])
-def test_gpu_segment_patches_matches_oracle(gpu_ctx, oracle, name, iters):
-    """S7-S9 alone: oracle-made adjacency / partition in, patch records + depth maps + occupancy out."""
+@pytest.mark.parametrize("name,iters,order", [("tiny", 10, None), ("small", 10, None), ("medium", 20, None), ("medium", 20, "input"), ("medium", 20, "tree"), ("medium", 20, "chunk")])
+def test_gpu_segment_patches_matches_oracle(gpu_ctx, oracle, ctx_options, name, iters, order):
+    """S7-S9 alone: oracle-made adjacency / partition in, patch records + depth maps + occupancy out.  order: how the mutual
+    mask and the union / relaxation passes of S7 walk the points (option MUTUAL_ORDER: blocks as they come, XCD eighths, tree order)."""
+    if order:
+        ctx_options.setenv("TMC2_MUTUAL_ORDER", order)
     xyz, rgb = synth_cloud(name)
     knn = oracle.knn_self(xyz, 16)
     nrm = oracle.orient_normals(xyz, knn, oracle.compute_normals(xyz, knn))
@@ -426,6 +429,19 @@ def test_gpu_orientation_contracted_and_point_level(gpu_ctx, oracle, ctx_options
         assert gpu_ctx.stage_calls().get("orient_normals_regrowth", 0) == 0
         edges.append(gpu_ctx.stage_ms()["orient_compact_edges"])
     assert edges[0] > 64 and len(set(edges)) == 1, edges
+    ctx_options.delenv("TMC2_ORIENT_SPEC")
+    # the passes over the edges with the blocks as they come (rounds 2-5) and in tree order (since round 6 the default is input
+    # order with XCD x on the x-th eighth of the blocks): the contraction is a fixed point of the graph, the order is only a
+    # matter of speed -- same compact graph, same bits
+    ctx_options.setenv("TMC2_ORIENT_SPEC", "1000000,1000000")
+    for order in ("input", "tree"):
+        ctx_options.setenv("TMC2_ORIENT_ORDER", order)
+        fr5 = gpu_ctx.frame(xyz, rgb)
+        gpu_ctx.stage_reset()
+        fr5.normals_compute(16, 1)
+        assert np.array_equal(fr5.get_normals().view(np.uint64), exp.view(np.uint64)), order
+        assert gpu_ctx.stage_ms()["orient_compact_edges"] == edges[0], order
+    ctx_options.delenv("TMC2_ORIENT_ORDER")
     ctx_options.delenv("TMC2_ORIENT_SPEC")
     ctx_options.setenv("TMC2_ORIENT_NO_CONTRACTION", "1")
     fr2 = gpu_ctx.frame(xyz, rgb)
