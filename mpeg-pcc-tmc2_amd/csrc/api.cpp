@@ -389,6 +389,7 @@ void tmc2::destroyContextNow( tmc2_ctx* ctx ) {
     ctx->scanState.release();
     ctx->voxelBitmap.release();
     ctx->constTables.clear();
+    ctx->retiredTables.clear();
   }
   if ( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
   if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
@@ -599,17 +600,21 @@ void setKdtreePlacement( int mode ) { g_kdtreeOnHost.store( mode < 0 || mode > 2
 
 const int* tmc2_ctx::constTable( uint64_t key, const std::vector<int>& host ) {
   auto it = constTables.find( key );
-  if ( it != constTables.end() && it->second->count == host.size() ) return it->second->p;
-  auto buf = std::make_unique<tmc2::DevBuf<int>>();
-  if ( buf->alloc( std::max<size_t>( host.size(), 1 ) ) != TMC2_OK ) return nullptr;
-  buf->count = host.size();  // (the key's table: its length is part of the identity)
-  // (synchronous: the vector is the caller's local, and this happens once per context and key)
-  if ( !host.empty() && hipMemcpy( buf->p, host.data(), host.size() * sizeof( int ), hipMemcpyHostToDevice ) != hipSuccess ) {
+  if ( it != constTables.end() && it->second->host == host ) return it->second->dev.p;
+  auto entry = std::make_unique<ConstTable>();
+  if ( entry->dev.alloc( std::max<size_t>( host.size(), 1 ) ) != TMC2_OK ) return nullptr;
+  entry->host = host;  // (kept: the key's identity, and the source of the copy below for as long as the runtime may read it)
+  // The block comes from the context's pool, whose blocks may still be in use by work QUEUED on the context's stream (a stage hands
+  // its buffers back without waiting): the upload has to be ordered on that stream too.  (Round 6's first version copied with
+  // hipMemcpy -- the null stream, at once -- into a block the refinement's queued sweeps were still reading: a frame in a few
+  // thousand went wrong, tests/test_gpu_fuzz.py seed 6.)
+  if ( !host.empty() && hipMemcpyAsync( entry->dev.p, entry->host.data(), host.size() * sizeof( int ), hipMemcpyHostToDevice, stream ) != hipSuccess ) {
     tmc2::setError( "constTable: upload failed" );
     return nullptr;
   }
-  const int* p     = buf->p;
-  constTables[key] = std::move( buf );
+  const int* p = entry->dev.p;
+  if ( it != constTables.end() ) retiredTables.push_back( std::move( it->second ) );  // (its block may still be read by queued work: freed with the context)
+  constTables[key] = std::move( entry );
   return p;
 }
 

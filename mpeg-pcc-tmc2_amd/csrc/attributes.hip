@@ -485,9 +485,10 @@ int reconstructPointCloud( tmc2_frame* f ) {
     hipLaunchKernelGGL( reconTileKernel<false>, dim3( tiles ), blk, 0, s, f->d_place.p, f->d_tilePatch.p, f->d_occVideo.p,
                         f->d_blockToPatch.p, f->d_geo.p, W, H, prec, d_tileCount.p, (const uint32_t*)nullptr, (Pt*)nullptr,
                         (uint32_t*)nullptr );
-    TMC2_TRY( exclusiveScanU32( ctx, d_tileCount.p, d_tileOffset.p, tiles, d_small.p ) );
-    TMC2_HIP( hipMemcpyAsync( &M, d_small.p, 4, hipMemcpyDeviceToHost, s ) );
+    volatile uint32_t* answer = ctx->answerLine( tmc2_ctx::kAnswerRecon );  // (the point count straight to a page-locked word: no copy)
+    TMC2_TRY( exclusiveScanU32( ctx, d_tileCount.p, d_tileOffset.p, tiles, d_small.p, ScanAnswer{answer, nullptr, 0} ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    M = answer[0];
   }
   if ( M == 0 ) {
     ctx->stageEnd( sid );
@@ -570,8 +571,10 @@ int generateAttributeImages( tmc2_frame* f ) {
   // ---- S18 ----------------------------------------------------------------------------------------------
   TMC2_TRY( f->d_reconRgb.alloc( size_t( M ) * 4 ) );
   const dim3 grdM( ( M + 255 ) / 256 );
+  // (the sort-depth flag is a page-locked word of the context, read after the stage's last synchronisation: no copy)
+  volatile uint32_t* h_err = ctx->answerLine( tmc2_ctx::kAnswerAttrError );
   TMC2_TRY( transferColorsDevice( ctx, frameTree( f ), f->d_pts.p, f->d_rgb.p, n, rt, f->d_recon.p, M, f->d_reconRgb.p,
-                                  d_small.p + 1 ) );
+                                  const_cast<uint32_t*>( h_err ) ) );
   // ---- S20 ----------------------------------------------------------------------------------------------
   sid = ctx->stageBegin( "attribute_images" );
   DevBuf<uint8_t> d_occ;
@@ -665,10 +668,9 @@ int generateAttributeImages( tmc2_frame* f ) {
   // ---- S22 ----------------------------------------------------------------------------------------------
   hipLaunchKernelGGL( attributeGroupDilateKernel, dim3( uint32_t( ( area + 255 ) / 256 ) ), blk, 0, s, d_occ.p, W, H, f->d_attr.p );
   ctx->stageEnd( sid );
-  uint32_t err = 0;
-  TMC2_HIP( hipMemcpyAsync( &err, d_small.p + 1, 4, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   TMC2_HIP( hipGetLastError() );
+  const uint32_t err = *h_err;
   if ( err ) {
     setError( "transferColors: a backward candidate list hit std::sort's depth limit (heapsort fallback of libstdc++ "
               "introsort is not reproduced)" );

@@ -207,20 +207,10 @@ __global__ __launch_bounds__( 256 ) void groupDilateKernel( const uint8_t* __res
 
 // placement table + list of 16x16 patch blocks, both in packing order: what the raster and the reconstruction kernels index
 int uploadPlacement( tmc2_frame* f ) {
-  const int             P = int( f->patches.size() );
-  std::vector<PlaceDev> place;
-  place.resize( size_t( P ) );
-  std::vector<uint32_t> tilePatch;
+  const int P = int( f->patches.size() );
+  size_t    tiles = 0;
   for ( int k = 0; k < P; ++k ) {
     const tmc2_patch& t = f->patches[size_t( f->packOrder[size_t( k )] )];
-    PlaceDev&         d = place[size_t( k )];
-    d.u0 = t.u0, d.v0 = t.v0, d.orient = t.patchOrientation;
-    d.sizeU = t.sizeU, d.sizeV = t.sizeV, d.sizeU0 = t.sizeU0, d.sizeV0 = t.sizeV0;
-    d.tileBase = int32_t( tilePatch.size() );
-    d.depthOff = t.depthOffset;
-    d.u1 = t.u1, d.v1 = t.v1, d.d1 = t.d1;
-    d.axN = t.normalAxis, d.axT = t.tangentAxis, d.axB = t.bitangentAxis, d.mode = t.projectionMode;
-    d.pad = 0;
     if ( t.patchOrientation != 0 && t.patchOrientation != 1 ) {
       setError( "patch orientation %d unsupported", t.patchOrientation );
       return TMC2_E_UNSUPPORTED;
@@ -229,17 +219,39 @@ int uploadPlacement( tmc2_frame* f ) {
       setError( "patch %d: negative block size or position", k );
       return TMC2_E_INVALID;
     }
-    tilePatch.insert( tilePatch.end(), size_t( t.sizeU0 ) * size_t( t.sizeV0 ), uint32_t( k ) );
+    tiles += size_t( t.sizeU0 ) * size_t( t.sizeV0 );
+  }
+  // both tables in the context's page-locked staging: the copies are DMA straight from it and nobody waits for them here (the
+  // caller synchronises the stream before the staging is refilled)
+  const size_t placeBytes = ( size_t( P ) * sizeof( PlaceDev ) + 15 ) & ~size_t( 15 );
+  uint8_t*     staging    = f->ctx->hostTables.get<uint8_t>( std::max<size_t>( placeBytes + tiles * 4, size_t( 1 ) << 20 ) );
+  if ( !staging ) {
+    setError( "uploadPlacement: hipHostMalloc failed" );
+    return TMC2_E_HIP;
+  }
+  PlaceDev* place     = reinterpret_cast<PlaceDev*>( staging );
+  uint32_t* tilePatch = reinterpret_cast<uint32_t*>( staging + placeBytes );
+  size_t    at        = 0;
+  for ( int k = 0; k < P; ++k ) {
+    const tmc2_patch& t = f->patches[size_t( f->packOrder[size_t( k )] )];
+    PlaceDev&         d = place[size_t( k )];
+    d.u0 = t.u0, d.v0 = t.v0, d.orient = t.patchOrientation;
+    d.sizeU = t.sizeU, d.sizeV = t.sizeV, d.sizeU0 = t.sizeU0, d.sizeV0 = t.sizeV0;
+    d.tileBase = int32_t( at );
+    d.depthOff = t.depthOffset;
+    d.u1 = t.u1, d.v1 = t.v1, d.d1 = t.d1;
+    d.axN = t.normalAxis, d.axT = t.tangentAxis, d.axB = t.bitangentAxis, d.mode = t.projectionMode;
+    d.pad = 0;
+    for ( size_t b = size_t( t.sizeU0 ) * size_t( t.sizeV0 ); b > 0; --b ) tilePatch[at++] = uint32_t( k );
   }
   hipStream_t s = f->ctx->stream;
   TMC2_TRY( f->d_place.alloc( size_t( std::max( P, 1 ) ) ) );
-  TMC2_TRY( f->d_tilePatch.alloc( std::max<size_t>( tilePatch.size(), 1 ) ) );
+  TMC2_TRY( f->d_tilePatch.alloc( std::max<size_t>( tiles, 1 ) ) );
   if ( P ) {
-    TMC2_HIP( hipMemcpyAsync( f->d_place.p, place.data(), size_t( P ) * sizeof( PlaceDev ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( f->d_tilePatch.p, tilePatch.data(), tilePatch.size() * 4, hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipStreamSynchronize( s ) );  // the staging vectors go out of scope
+    TMC2_HIP( hipMemcpyAsync( f->d_place.p, place, size_t( P ) * sizeof( PlaceDev ), hipMemcpyHostToDevice, s ) );
+    if ( tiles ) TMC2_HIP( hipMemcpyAsync( f->d_tilePatch.p, tilePatch, tiles * 4, hipMemcpyHostToDevice, s ) );
   }
-  f->tileCount = uint32_t( tilePatch.size() );
+  f->tileCount = uint32_t( tiles );
   return TMC2_OK;
 }
 
@@ -322,20 +334,22 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
   TMC2_TRY( uploadPlacement( f ) );
   DevBuf<PlaceDev>& d_place     = f->d_place;
   DevBuf<uint32_t>& d_tilePatch = f->d_tilePatch;
-  DevBuf<uint32_t>  d_err;
+  // (the "patch outside the canvas" flag is a page-locked word of the context: a kernel that finds one stores there, the host reads it
+  //  after the synchronisation below -- no copy)
+  volatile uint32_t* h_err = ctx->answerLine( tmc2_ctx::kAnswerGeoError );
+  *h_err                   = 0;
   DevBuf<uint8_t>  d_empty;
-  TMC2_TRY( d_err.alloc( 1 ) );
   TMC2_TRY( d_empty.alloc( size_t( Wb ) * Hb ) );
   TMC2_TRY( f->d_occMap.alloc( area ) );
   TMC2_TRY( f->d_occVideo.alloc( size_t( Wv ) * Hv ) );
   TMC2_TRY( f->d_blockToPatch.alloc( size_t( Wb ) * Hb ) );
   TMC2_TRY( f->d_geo.alloc( 2 * area ) );
   const int sid = ctx->stageBegin( "geometry_images" );
-  TMC2_TRY( fillRegions( ctx, {{d_err.p, 4, 0}, {f->d_occMap.p, area, 0}, {f->d_geo.p, 2 * area * sizeof( uint16_t ), 0}} ) );
+  TMC2_TRY( fillRegions( ctx, {{f->d_occMap.p, area, 0}, {f->d_geo.p, 2 * area * sizeof( uint16_t ), 0}} ) );
   const dim3 blk( 256 );
   if ( f->tileCount )
     hipLaunchKernelGGL( rasterTileKernel, dim3( f->tileCount ), blk, 0, s, d_place.p, d_tilePatch.p,
-                        f->d_depth0.p, f->d_depth1.p, W, H, f->d_occMap.p, f->d_geo.p, f->d_geo.p + area, d_err.p );
+                        f->d_depth0.p, f->d_depth1.p, W, H, f->d_occMap.p, f->d_geo.p, f->d_geo.p + area, const_cast<uint32_t*>( h_err ) );
   hipLaunchKernelGGL( occVideoKernel, dim3( ( Wv * Hv + 255 ) / 256 ), blk, 0, s, f->d_occMap.p, W, Wv, Hv, occPrecision,
                       f->d_occVideo.p );
   hipLaunchKernelGGL( blockToPatchKernel, dim3( ( Wb * Hb + 255 ) / 256 ), blk, 0, s, d_place.p, P, f->d_occVideo.p, Wb,
@@ -346,10 +360,9 @@ int generateGeometryImages( tmc2_frame* f, int W, int H, int occRes, int occPrec
   hipLaunchKernelGGL( groupDilateKernel, dim3( uint32_t( ( area + 255 ) / 256 ) ), blk, 0, s, f->d_occVideo.p, W, H, Wv,
                       occPrecision, f->d_geo.p );
   ctx->stageEnd( sid );
-  uint32_t err = 0;
-  TMC2_HIP( hipMemcpyAsync( &err, d_err.p, 4, hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   TMC2_HIP( hipGetLastError() );
+  const uint32_t err = *h_err;
   if ( err ) {
     setError( "generateGeometryImages: a patch falls outside the %dx%d canvas (the reference exits with code 180)", W, H );
     return TMC2_E_INVALID;

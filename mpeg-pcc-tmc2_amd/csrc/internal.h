@@ -239,6 +239,10 @@ struct tmc2_ctx {
   int                           device = 0;
   tmc2::DevicePool              pool;
   tmc2::PinnedBuf               hostA, hostB, hostC, hostD, hostE;  // staging for the host-side steps
+  // small tables of a stage's host decisions, page-locked so that their copies are plain DMA with no staging copy behind them:
+  // hostTables host -> device (patch records and tile lists of a patch round, the placement table), hostRecords device -> host (a
+  // round's boxes and counters).  Reused from round to round: every user synchronises the stream before the next one refills them.
+  tmc2::PinnedBuf               hostTables, hostRecords;
   std::vector<int32_t>          orientScratch;                      // per-vertex state of the orientation walk
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint2>           gridBits;        // its occupancy, .x: one bit per key (kept all-zero between uses: S5 probes ball rows in it), .y: occupied keys below the word
@@ -249,8 +253,13 @@ struct tmc2_ctx {
   std::map<uint32_t, int>       kdLevelHint;     // levels of level passes the last device k-d tree of ~ this size took (by n >> 15)
   // small tables that depend on the parameters only (the probe offsets of S9, the ball rows / cells of S5): uploaded once per context
   // and key, not once per frame (round 6: each was a pageable host-to-device copy -- a staging copy and a blit -- on every frame's chain)
-  std::map<uint64_t, std::unique_ptr<tmc2::DevBuf<int>>> constTables;
-  const int* constTable( uint64_t key, const std::vector<int>& host );  // nullptr on failure (the error is set)
+  struct ConstTable {
+    tmc2::DevBuf<int> dev;
+    std::vector<int>  host;
+  };
+  std::map<uint64_t, std::unique_ptr<ConstTable>> constTables;
+  std::vector<std::unique_ptr<ConstTable>>        retiredTables;
+  const int* constTable( uint64_t key, const std::vector<int>& host );  // nullptr on failure (the error is set); the upload is ordered on the context's stream
   // Page-locked words the device writes and the host reads without a copy (allocated with the context; kernels take the pointer as
   // it is: page-locked host memory is mapped into the device's address space): the answers of the stages' host round trips, one
   // 64-byte line each (kAnswer*: which stage owns which line).  A kernel stores its answer with ONE plain store from its last
@@ -258,6 +267,7 @@ struct tmc2_ctx {
   uint32_t* mailbox = nullptr;
   static constexpr size_t kMailboxWords = 1024;
   volatile uint32_t* answerLine( int line ) const { return mailbox + size_t( line ) * 16; }
+  enum { kAnswerRefineVoxels = 1, kAnswerPatchRound = 2, kAnswerRecon = 3, kAnswerOrientHead = 4, kAnswerTreeDepth = 5, kAnswerGeoError = 6, kAnswerAttrError = 7, kAnswerTreeLevels = 8 /* .. 12 */ };
   // Per-context options (tmc2_ctx_set_option): key = the name of the knob without its TMC2_ prefix.  Filled ONCE, when the
   // context is created, from the process environment (every TMC2_* variable: the defaults); nothing in the library reads the
   // environment after that, and nothing is process-wide: two encoders of one process can run with different settings.
@@ -490,7 +500,16 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n, DevBuf<Pt>& d
                        DevBuf<KdNode>& d_nodes, int32_t lo[3], int32_t hi[3], int& depth );
 // opt-in to more than 48 KB of dynamic LDS for a kernel (once per device and kernel, serialised)
 int allowLargeLds( const void* kernel, size_t bytes, int device, size_t staticBytes = 64 );
-int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total );
+// answer (optional): the total ALSO goes to host[0] of a page-locked answer line of the context (tmc2_ctx::answerLine), stored by the
+// scan's last tile, with carryWords <= 7 device words behind it (host[1 ..]: written by earlier launches of the stream -- the flags
+// and counters the host wants to read in the same round trip).  The host reads the line after the hipStreamSynchronize it needs
+// anyway: no hipMemcpyAsync, no staging copy, no blit kernel on the frame's chain.
+struct ScanAnswer {
+  volatile uint32_t* host       = nullptr;
+  const uint32_t*    carry      = nullptr;
+  int                carryWords = 0;
+};
+int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total, ScanAnswer answer = ScanAnswer() );
 // several device regions set to a byte value each in ONE launch (instead of one hipMemsetAsync per buffer)
 struct FillRegion {
   void*   p;

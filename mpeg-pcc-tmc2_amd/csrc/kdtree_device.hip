@@ -99,7 +99,10 @@ struct BuildArgs {
   unsigned long long* pieceProfile;  // option KD_PIECE_PROFILE: wall-clock ticks (10 ns) thread 0 of every workgroup spent between the barriers of a depth
   uint32_t    decideRng;            // segments of a level whose ranges the decide pass folds in LDS (kDecideRng; 0: option KD_DECIDE=global, the path of larger levels)
   uint32_t*   finishDepth;  // out: levels reached inside the retired subtrees
-  uint32_t*   ticket;       // "last block done" counter of the prefix sums
+  uint32_t*   ticket;       // workgroups of pieceKernel that are done (the last one publishes finishDepth to the host)
+  // page-locked words of the context (tmc2_ctx::answerLine) the host reads after its synchronisation instead of copying:
+  volatile uint32_t* hostSmall;  // lvDecideKernel: the whole counter block (kMaxLevels + 16 words); null: this launch does not publish
+  volatile uint32_t* hostDepth;  // pieceKernel's last workgroup: finishDepth
 };
 
 __device__ __forceinline__ int coordOf( const Pt p, int d ) { return d == 0 ? p.x : ( d == 1 ? p.y : p.z ); }
@@ -692,6 +695,11 @@ __global__ __launch_bounds__( kDecideThreads ) void lvDecideKernel( BuildArgs a,
   if ( threadIdx.x == 0 ) {
     a.counts[level + 1] = 2u * sCarry;
     *a.nodeCount        = nodeBase + 2u * sCarry;
+  }
+  if ( a.hostSmall ) {  // the last decide pass of a batch of levels: the counter block as the host will want it (one workgroup: it is all ours)
+    if ( threadIdx.x == 0 ) __threadfence();
+    __syncthreads();
+    if ( threadIdx.x < kMaxLevels + 16 ) a.hostSmall[threadIdx.x] = __hip_atomic_load( &a.counts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   }
 }
 
@@ -1342,6 +1350,13 @@ __global__ __launch_bounds__( kPieceMax / K ) void pieceKernel( BuildArgs a ) {
     }
     if ( tid == 0 && sDepth ) atomicMax( a.finishDepth, sDepth );
   }
+  if ( a.hostDepth && tid == 0 ) {  // the workgroup that is done last hands the deepest level to the host (no copy after the launch)
+    __threadfence();
+    if ( atomicAdd( a.ticket, 1u ) == gridDim.x - 1u ) {
+      __threadfence();
+      *a.hostDepth = __hip_atomic_load( a.finishDepth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    }
+  }
 }
 
 }  // namespace
@@ -1396,6 +1411,8 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
   a.huge         = d_huge.p;
   a.hugeCount    = d_small.p + kMaxLevels + 7;
   a.hugeMax      = hugeMax;
+  a.hostSmall    = nullptr;
+  a.hostDepth    = ctx->answerLine( tmc2_ctx::kAnswerTreeDepth );
   a.retireMax    = uint32_t( kPieceMax );
   a.splitMax     = uint32_t( kPieceMax );
   // grid-stride launches, two points per lane; the tile kernels take one 2048-point tile per block
@@ -1434,16 +1451,19 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
       while ( chunkEnd < uint32_t( kMaxLevels ) && ( uint64_t( hugeMax ) << std::min<uint32_t>( chunkEnd - 1, 40 ) ) < n ) ++chunkEnd;
       if ( chunkEnd == level + 1 ) chunkEnd = std::min<uint32_t>( level + 2, kMaxLevels );
     }
+    volatile uint32_t* hostSmall = ctx->answerLine( tmc2_ctx::kAnswerTreeLevels );  // (kMaxLevels + 16 = 80 words: five lines)
     for ( ; level < chunkEnd; ++level ) {
       hipLaunchKernelGGL( lvFlagKernel<true>, grdT, blk, 0, s, a, level );
       hipLaunchKernelGGL( lvSwapOneKernel, grdE, blk, sumsLds, s, a, level );
       hipLaunchKernelGGL( lvFlagKernel<false>, grdT, blk, 0, s, a, level );
       hipLaunchKernelGGL( lvSwapTwoKernel, grdL, dim3( kLandBlock ), sumsLds, s, a, level );
-      hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, a, level + 1u );
+      BuildArgs ad = a;
+      if ( level + 1 == chunkEnd ) ad.hostSmall = hostSmall;  // (the batch's last decide pass publishes the counters: no copy)
+      hipLaunchKernelGGL( lvDecideKernel, dim3( 1 ), dim3( kDecideThreads ), 0, s, ad, level + 1u );
     }
     TMC2_HIP( hipGetLastError() );
-    TMC2_HIP( hipMemcpyAsync( out, d_small.p, sizeof( out ), hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    for ( int w = 0; w < kMaxLevels + 16; ++w ) out[w] = hostSmall[w];
     for ( uint32_t l = 0; l <= level && l <= uint32_t( kMaxLevels ); ++l )
       if ( out[l] == 0 ) {
         found = int( l );
@@ -1492,9 +1512,8 @@ int buildKdTreeDevice( tmc2_ctx* ctx, const Pt* d_pts, uint64_t n64, DevBuf<Pt>&
       hipLaunchKernelGGL( pieceKernel<4>, grid, dim3( kPieceMax / 4 ), kPieceLdsBytes, s, a );
     }
     TMC2_HIP( hipGetLastError() );
-    uint32_t fin = 0;
-    TMC2_HIP( hipMemcpyAsync( &fin, a.finishDepth, 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
+    const uint32_t fin = *a.hostDepth;
     if ( fin >= uint32_t( kMaxLevels ) ) {
       setError( "kdtree: more than %d levels", kMaxLevels - 1 );
       return TMC2_E_UNSUPPORTED;

@@ -592,16 +592,18 @@ int contractOrientationDevice( tmc2_frame* f, double tau, DevBuf<uint32_t>& d_ci
   TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
   hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, chunkedPairs, d_crossMask.p, d_cid.p,
                       d_parity.p, n, t, 1, d_keepMask.p, d_count.p );
-  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
+  // (the four counters in the context's page-locked line, stored by this scan's last tile: [0] kept cross edges -- its total --,
+  //  [1] bad flag, [2] the same total again, [3] pair table overflow, [4] clusters: all settled by earlier launches -- no copy)
+  volatile uint32_t* headLine = ctx->answerLine( tmc2_ctx::kAnswerOrientHead );
+  TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1, ScanAnswer{headLine, d_small.p, 4} ) );
   hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, chunkedPairs, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
                       d_minIdx.p, n, d_small.p + 3, kSpecEdges, kSpecClusters, d_cursor.p, d_edges.p, d_rec.p );
-  TMC2_HIP( hipMemcpyAsync( h_head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
   // (what a frame typically needs, plus a margin, comes along right away; the rest -- if any -- after the counters are known)
   const uint32_t kFirstEdges = std::min( 192u * 1024, kSpecEdges ), kFirstClusters = std::min( 32u * 1024, kSpecClusters );
   TMC2_HIP( hipMemcpyAsync( h_rec, d_rec.p, size_t( kFirstClusters ) * sizeof( OrientClusterRec ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipMemcpyAsync( h_edges, d_edges.p, size_t( kFirstEdges ) * sizeof( OrientCompactEdge ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
-  uint32_t head[4] = {h_head[0], h_head[1], h_head[2], h_head[3]};
+  uint32_t head[4] = {headLine[1], headLine[0], headLine[3], headLine[4]};  // (d_small[1] is being written by the scan whose last tile carries the line: its total is [0])
   if ( head[0] ) return TMC2_OK;  // inconsistent cluster
   uint32_t E = head[1], C = head[3];
   if ( !head[2] && E <= kSpecEdges && C + 1 <= kSpecClusters ) {

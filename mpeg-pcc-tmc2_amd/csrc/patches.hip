@@ -862,12 +862,13 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
       hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_root.p, d_lab.p, n, d_label.p, d_ccCount.p );
       hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
                           uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );
-      TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 1 ) );
-      uint32_t answer[2] = {0, 0};
-      TMC2_HIP( hipMemcpyAsync( answer, d_small.p, 8, hipMemcpyDeviceToHost, s ) );
+      // (both answers in the context's page-locked line, stored by the scan's last tile: [0] the number of patches, [1] the token of
+      //  the last sweep that changed a label -- no copy)
+      volatile uint32_t* answer = ctx->answerLine( tmc2_ctx::kAnswerPatchRound );
+      TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p + 1, ScanAnswer{answer, d_small.p, 1} ) );
       TMC2_HIP( hipStreamSynchronize( s ) );
-      P = answer[1];
-      if ( answer[0] != relaxToken ) break;
+      P = answer[0];
+      if ( answer[1] != relaxToken ) break;
       // (ccCount is an accumulation: start it over before labelling again)
       TMC2_HIP( hipMemsetAsync( d_ccCount.p, 0, size_t( n ) * 4, s ) );
     }
@@ -889,14 +890,21 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
       hipLaunchKernelGGL( patchMinUvKernel, grdN, blk, 0, s, f->d_pts.p, d_pointPatch.p, d_view, n, d_minUv.p );
     hipLaunchKernelGGL( patchTrimBboxKernel, grdN, blk, 0, s, f->d_pts.p, d_view, d_minUv.p,
                         sp->enablePatchSplitting, sp->maxPatchSize, n, d_pointPatch.p, d_bbox.p );
-    std::vector<int32_t> h_bbox( 7 * size_t( P ) );
-    TMC2_HIP( hipMemcpyAsync( h_bbox.data(), d_bbox.p, h_bbox.size() * 4, hipMemcpyDeviceToHost, s ) );
-    const int32_t* h_view = h_bbox.data() + 6 * size_t( P );
+    // (boxes + views, and further down the counters, land in the context's page-locked staging: plain DMA, no staging copy behind it)
+    int32_t* h_records = ctx->hostRecords.get<int32_t>( std::max<size_t>( 9 * size_t( P ) + 1, size_t( 1 ) << 16 ) );
+    if ( !h_records ) {
+      setError( "segmentPatches: hipHostMalloc failed" );
+      return TMC2_E_HIP;
+    }
+    const int32_t* h_bbox = h_records;
+    TMC2_HIP( hipMemcpyAsync( h_records, d_bbox.p, 7 * size_t( P ) * 4, hipMemcpyDeviceToHost, s ) );
+    const int32_t* h_view = h_bbox + 6 * size_t( P );
     TMC2_HIP( hipStreamSynchronize( s ) );
     // patch geometry on the host (P is a few hundred): axes, sizes, depth origin, pool offsets, tile list
     static const int       AX[3][3] = {{0, 2, 1}, {1, 2, 0}, {2, 0, 1}};
-    std::vector<PatchDev>  h_pd( P );
-    std::vector<uint32_t>  h_tilePatch;
+    std::vector<PatchDev>  h_pdLocal( P );
+    PatchDev*              h_pd           = h_pdLocal.data();
+    size_t                 tilesSoFar     = 0;
     const size_t           patchBase      = f->patches.size();
     const int64_t          roundDepthBase = f->depthCount;
     for ( uint32_t p = 0; p < P; ++p ) {
@@ -932,22 +940,34 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
       D.u1 = T.u1, D.v1 = T.v1, D.d1 = T.d1;
       D.sizeU = T.sizeU, D.sizeV = T.sizeV, D.sizeU0 = T.sizeU0, D.sizeV0 = T.sizeV0;
       D.axN = ax[0], D.axT = ax[1], D.axB = ax[2], D.mode = T.projectionMode;
-      D.blockBase = int32_t( h_tilePatch.size() );
+      D.blockBase = int32_t( tilesSoFar );
       D.depthOff  = T.depthOffset;
       D.occOff    = T.occOffset;
-      h_tilePatch.insert( h_tilePatch.end(), size_t( T.sizeU0 ) * T.sizeV0, p );
+      tilesSoFar += size_t( T.sizeU0 ) * T.sizeV0;
       f->patches.push_back( T );
     }
     const size_t roundArea = size_t( f->depthCount - roundDepthBase );
-    const uint32_t tiles   = uint32_t( h_tilePatch.size() );
+    const uint32_t tiles   = uint32_t( tilesSoFar );
+    // the round's two tables in the context's page-locked staging (patch records | tile -> patch): the copies below are DMA from it;
+    // the round's last synchronisation (the counters) comes before the next round refills it
+    const size_t pdBytes = ( size_t( P ) * sizeof( PatchDev ) + 15 ) & ~size_t( 15 );
+    uint8_t*     h_tables = ctx->hostTables.get<uint8_t>( std::max<size_t>( pdBytes + size_t( tiles ) * 4, size_t( 1 ) << 20 ) );
+    if ( !h_tables ) {
+      setError( "segmentPatches: hipHostMalloc failed" );
+      return TMC2_E_HIP;
+    }
+    memcpy( h_tables, h_pd, size_t( P ) * sizeof( PatchDev ) );
+    uint32_t* h_tilePatch = reinterpret_cast<uint32_t*>( h_tables + pdBytes );
+    for ( uint32_t p = 0, at = 0; p < P; ++p )
+      for ( uint32_t b = uint32_t( h_pd[p].sizeU0 ) * uint32_t( h_pd[p].sizeV0 ); b > 0; --b ) h_tilePatch[at++] = p;
     TMC2_TRY( f->growPools() );
     TMC2_TRY( d_map64.alloc( roundArea ) );
     TMC2_TRY( d_d0tmp.alloc( roundArea ) );
     TMC2_TRY( d_d1tmp.alloc( roundArea ) );
     TMC2_TRY( d_d0src.alloc( roundArea ) );
     TMC2_TRY( d_tilePatch.alloc( tiles ) );
-    TMC2_HIP( hipMemcpyAsync( d_patches.p, h_pd.data(), size_t( P ) * sizeof( PatchDev ), hipMemcpyHostToDevice, s ) );
-    TMC2_HIP( hipMemcpyAsync( d_tilePatch.p, h_tilePatch.data(), size_t( tiles ) * 4, hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( d_patches.p, h_tables, size_t( P ) * sizeof( PatchDev ), hipMemcpyHostToDevice, s ) );
+    TMC2_HIP( hipMemcpyAsync( d_tilePatch.p, h_tilePatch, size_t( tiles ) * 4, hipMemcpyHostToDevice, s ) );
     hipLaunchKernelGGL( patchInitTileKernel, dim3( tiles ), blk, 0, s, d_patches.p, d_tilePatch.p, roundDepthBase, occRes,
                         d_map64.p );
     hipLaunchKernelGGL( patchDepth0Kernel, grdN, blk, 0, s, f->d_pts.p, d_pointPatch.p, d_patches.p, n, roundDepthBase,
@@ -961,11 +981,11 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     hipLaunchKernelGGL( patchResampleTileKernel, dim3( tiles ), blk, 0, s, d_patches.p, d_tilePatch.p, roundDepthBase,
                         occRes, d_d0tmp.p, d_d1tmp.p, bitmapBits, ctx->voxelBitmap.p, f->d_depth0.p, f->d_depth1.p,
                         f->d_occupancy.p, d_patchStat.p );
-    std::vector<int32_t> h_stat( 2 * size_t( P ) + 1 );  // (copied after the raw-point update below: its count rides along)
+    int32_t* h_stat = h_records + 7 * size_t( P );  // (copied after the raw-point update below: its count rides along)
     // ---- S9 -----------------------------------------------------------------------------------------
     hipLaunchKernelGGL( rawDistanceKernel, grdN, blk, 0, s, f->d_pts.p, n, ctx->voxelBitmap.p, bitmapBits, d_offsets,
                         int( offsets.size() ), thrSel, d_dist.p, d_raw.p, d_rawCount );
-    TMC2_HIP( hipMemcpyAsync( h_stat.data(), d_patchStat.p, h_stat.size() * 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipMemcpyAsync( h_stat, d_patchStat.p, ( 2 * size_t( P ) + 1 ) * 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
     rawCount = uint32_t( h_stat[2 * size_t( P )] );
     ctx->stageEnd( sid );

@@ -1307,9 +1307,10 @@ int RefineJob::geometry( tmc2_frame* f ) {
   hipLaunchKernelGGL( firstFlagKernel, grdN, blk, 0, s, d_key.p, table, bits, d_firstPoint.p, n, d_flag.p );
   DevBuf<uint32_t> d_rank;
   TMC2_TRY( d_rank.alloc( n ) );
-  TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p ) );
-  TMC2_HIP( hipMemcpyAsync( &V, d_small.p, 4, hipMemcpyDeviceToHost, s ) );
+  volatile uint32_t* answer = ctx->answerLine( tmc2_ctx::kAnswerRefineVoxels );  // (the voxel count straight to a page-locked word: no copy)
+  TMC2_TRY( exclusiveScanU32( ctx, d_flag.p, d_rank.p, n, d_small.p, ScanAnswer{answer, nullptr, 0} ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
+  V = answer[0];
   TMC2_TRY( d_count.alloc( size_t( V ) + 1 ) );  // (+1: scanned into the point-list offsets)
   TMC2_TRY( d_rowLen.alloc( V ) );
   TMC2_TRY( d_devLen.alloc( V ) );

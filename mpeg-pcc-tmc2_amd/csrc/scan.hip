@@ -33,7 +33,7 @@ constexpr unsigned long long kAggregate = 1ull << 32, kInclusive = 2ull << 32;
 __global__ __launch_bounds__( 256 ) void scanLookBackKernel( const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                               uint32_t n, unsigned long long* __restrict__ state,
                                                               uint32_t epoch, uint32_t ticketBase, uint32_t tiles,
-                                                              uint32_t* __restrict__ total ) {
+                                                              uint32_t* __restrict__ total, ScanAnswer answer ) {
   __shared__ uint32_t waveTotal[4];
   __shared__ uint32_t sTile, sPrefix;
   if ( threadIdx.x == 0 ) sTile = atomicAdd( reinterpret_cast<uint32_t*>( state ), 1u ) - ticketBase;
@@ -78,7 +78,13 @@ __global__ __launch_bounds__( 256 ) void scanLookBackKernel( const uint32_t* __r
     }
     if ( lane == 0 ) {
       sPrefix = prefix;
-      if ( tile + 1 == tiles && total ) *total = prefix + aggregate;
+      if ( tile + 1 == tiles ) {
+        if ( total ) *total = prefix + aggregate;
+        if ( answer.host ) {  // the host's copy, and the words that ride along (written by earlier launches of the stream)
+          answer.host[0] = prefix + aggregate;
+          for ( int k = 0; k < answer.carryWords; ++k ) answer.host[1 + k] = answer.carry[k];
+        }
+      }
     }
   }
   __syncthreads();
@@ -120,9 +126,13 @@ __global__ __launch_bounds__( 256 ) void fillRegionsKernel( const FillArgs a ) {
 }
 }  // namespace
 
-int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total ) {
+int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, uint32_t* d_total, ScanAnswer answer ) {
   if ( n == 0 ) {
     if ( d_total ) TMC2_HIP( hipMemsetAsync( d_total, 0, 4, ctx->stream ) );
+    if ( answer.host ) {
+      setError( "exclusiveScanU32: an answer line needs at least one element" );
+      return TMC2_E_INVALID;
+    }
     return TMC2_OK;
   }
   if ( n > 0xFFFFFFFFull - kTile ) {
@@ -138,7 +148,7 @@ int exclusiveScanU32( tmc2_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size
     ctx->scanTickets = 0;
   }
   hipLaunchKernelGGL( scanLookBackKernel, dim3( tiles ), dim3( 256 ), 0, ctx->stream, d_in, d_out, uint32_t( n ),
-                      ctx->scanState.p, ctx->scanEpoch, ctx->scanTickets, tiles, d_total );
+                      ctx->scanState.p, ctx->scanEpoch, ctx->scanTickets, tiles, d_total, answer );
   // (one scan state per context: every scan of a context is queued on ctx->stream, in order)
   const hipError_t launched = hipGetLastError();
   if ( launched != hipSuccess ) {
