@@ -155,6 +155,20 @@ __device__ __forceinline__ T loadStaleOk( const T* p, bool agent = false ) {
 }
 #endif
 
+// The element of this lane in a one-element-per-lane pass whose grid is a multiple of 8 blocks: XCD x works through the x-th eighth
+// of the blocks (block b runs on XCD b % 8 -- observed, not promised: only speed depends on it), so that neighbouring blocks --
+// neighbouring regions of the cloud in every array that is in scan order -- share an L2 instead of being dealt round-robin over
+// the eight.  Any other grid: the blocks as they come.  (chunkedGrid rounds a grid up; the surplus blocks find no element.)
+#if defined( __HIPCC__ )
+__device__ __forceinline__ uint32_t chunkedIndex() {
+  const uint32_t b = ( gridDim.x & 7u ) ? blockIdx.x : ( blockIdx.x & 7u ) * ( gridDim.x >> 3 ) + ( blockIdx.x >> 3 );
+  return b * blockDim.x + threadIdx.x;
+}
+#endif
+inline uint32_t chunkedGrid( uint32_t blocks, bool chunked = true ) {
+  return chunked ? ( blocks + 7u ) & ~7u : ( ( blocks & 7u ) ? blocks : blocks + 1u );
+}
+
 // pointToPixel of a reconstructed point in one word: canvas x, y (15 bits each: canvases up to kMaxCanvasDim pixels a side,
 // enforced where a canvas size enters -- generateGeometryImages, the decoder frame), map layer, "a D1 point follows"
 constexpr int kMaxCanvasDim = 32767;

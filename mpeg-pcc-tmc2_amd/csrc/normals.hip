@@ -91,7 +91,7 @@ __device__ void diagonalize( double a00, double a01, double a02, double a11, dou
 template <int K>
 __global__ __launch_bounds__( 256 ) void normalsKernel( const Pt* __restrict__ pts, const uint32_t* __restrict__ knn,
                                                          uint32_t n, double* __restrict__ normals ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();  // (XCD x on the x-th eighth of the blocks: the neighbours whose points a lane gathers lie around its own)
   if ( i >= n ) return;
   uint32_t nb[K];
   {
@@ -194,7 +194,8 @@ int launchNormals( tmc2_frame* f ) {
   }
   TMC2_TRY( f->d_normals.alloc( f->n * 3 ) );
   const int  sid = f->ctx->stageBegin( "normals" );
-  const dim3 block( 256 ), grid( uint32_t( ( f->n + 255 ) / 256 ) );
+  const char* pcOpt = ctxOption( f->ctx, "POINT_CHUNK" );  // (0: the blocks as they come, rounds 1-5)
+  const dim3  block( 256 ), grid( chunkedGrid( uint32_t( ( f->n + 255 ) / 256 ), !( pcOpt && pcOpt[0] == '0' ) ) );
   if ( f->k == 16 ) {
     hipLaunchKernelGGL( normalsKernel<16>, grid, block, 0, f->ctx->stream, f->d_pts.p, f->d_knn.p, uint32_t( f->n ),
                         f->d_normals.p );

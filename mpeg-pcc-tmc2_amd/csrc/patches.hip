@@ -277,7 +277,7 @@ __global__ __launch_bounds__( 256 ) void ccFlattenSeedKernel( const uint8_t* __r
                                                                uint32_t thrDetection, uint32_t n,
                                                                uint32_t* __restrict__ parent, uint32_t* __restrict__ root,
                                                                uint32_t* __restrict__ lab, bool agent ) {
-  const uint32_t u    = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t u    = chunkedIndex();
   const int      lane = threadIdx.x & 63;
   uint32_t       r    = kNoLabel;
   bool           seed = false;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__( 256 ) void patchBoundsInitKernel( uint32_t P, int3
 __global__ __launch_bounds__( 256 ) void ccLabelCountKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
                                                               const uint32_t* __restrict__ lab, uint32_t n,
                                                               uint32_t* __restrict__ label, uint32_t* __restrict__ ccCount ) {
-  const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i    = chunkedIndex();
   const int      lane = threadIdx.x & 63;
   const uint32_t l    = ( i < n && raw[i] ) ? lab[parent[i]] : kNoLabel;
   if ( i < n ) label[i] = l;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__( 256 ) void ccLabelCountKernel( const uint8_t* __re
 __global__ __launch_bounds__( 256 ) void ccSeedFlagKernel( const uint32_t* __restrict__ label,
                                                             const uint32_t* __restrict__ ccCount, uint32_t minCount,
                                                             uint32_t n, uint32_t* __restrict__ flag ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   if ( i < n ) flag[i] = ( label[i] == i && ccCount[i] >= minCount ) ? 1u : 0u;
 }
 
@@ -383,7 +383,7 @@ __global__ __launch_bounds__( 256 ) void ccAssignKernel( const uint32_t* __restr
                                                           const uint8_t* __restrict__ partition, uint32_t minCount,
                                                           uint32_t n, int32_t* __restrict__ pointPatch,
                                                           int32_t* __restrict__ patchView ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   if ( i >= n ) return;
   const uint32_t l = label[i];
   int32_t        p = -1;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__( 256 ) void patchMinUvKernel( const Pt* __restrict_
                                                             int32_t* __restrict__ minUv ) {
   __shared__ PatchAgg<2> agg;
   aggInit<2, 2>( agg );
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   const int32_t  p = i < n ? pointPatch[i] : -1;
   if ( p >= 0 ) {
     const int view = patchView[p] % 3;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__( 256 ) void patchTrimBboxKernel( const Pt* __restri
                                                                int32_t* __restrict__ pointPatch, int32_t* __restrict__ bbox ) {
   __shared__ PatchAgg<6> agg;
   aggInit<6, 3>( agg );
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   int32_t        p = i < n ? pointPatch[i] : -1;
   if ( p >= 0 ) {
     const Pt q = pts[i];
@@ -504,7 +504,7 @@ __global__ __launch_bounds__( 256 ) void patchDepth0Kernel( const Pt* __restrict
                                                              const PatchDev* __restrict__ patches, uint32_t n,
                                                              int64_t roundDepthBase,
                                                              unsigned long long* __restrict__ map64 ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   if ( i >= n ) return;
   const int32_t p = pointPatch[i];
   if ( p < 0 ) return;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__( 256 ) void patchDepth1Kernel( const Pt* __restrict
                                                              int64_t roundDepthBase, int surfaceThickness,
                                                              const int32_t* __restrict__ d0tmp,
                                                              const uint32_t* __restrict__ d0src, int32_t* __restrict__ d1tmp ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   if ( i >= n ) return;
   const int32_t p = pointPatch[i];
   if ( p < 0 ) return;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__( 256 ) void rawDistanceKernel( const Pt* __restrict
                                                              const int* __restrict__ offsets, int nOffsets,
                                                              uint32_t thrSelection, uint32_t* __restrict__ dist,
                                                              uint8_t* __restrict__ raw, uint32_t* __restrict__ rawCount ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = chunkedIndex();
   bool           isRaw = false;
   if ( i < n ) {
     const Pt  q    = pts[i];
@@ -814,8 +814,11 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
   f->patches.clear();
   f->depthCount = 0;
   f->occCount   = 0;
-  const dim3 blk( 256 ), grdN( ( n + 255 ) / 256 );
-  uint32_t   rawCount = n, relaxToken = 0;
+  // (option POINT_CHUNK=0: the one-point-per-lane passes of S7-S9 with the blocks as they come, rounds 1-5; default: XCD x takes the
+  //  x-th eighth of the blocks -- chunkedIndex)
+  const char* pcOpt = ctxOption( ctx, "POINT_CHUNK" );
+  const dim3  blk( 256 ), grdN( chunkedGrid( ( n + 255 ) / 256, !( pcOpt && pcOpt[0] == '0' ) ) );
+  uint32_t    rawCount = n, relaxToken = 0;
   int        rounds   = 0;
   TMC2_TRY( ensureMutualMask( f ) );  // usually there already: the orientation (S3) needs the same bits
   DevBuf<uint16_t>& d_mutual   = f->d_mutual;

@@ -105,15 +105,25 @@ __device__ __forceinline__ uint32_t rankOfKey( const uint2* __restrict__ bits, u
   const uint2 e = bits[k >> 5];
   return e.y + uint32_t( __popc( e.x & ( ( 1u << ( k & 31 ) ) - 1u ) ) );
 }
-// voxelOfRank[rank of the voxel's key] = voxel id (written by the voxel's first point)
+// voxelOfRank[rank of the voxel's key] = the voxel that owns the key, as ONE 8-byte record (written by the voxel's first point):
+//   .x = its cell (x | y << 10 | z << 20: what a probe compares with the cell it looked at -- keys alias) | member count & 3 << 30
+//   .y = voxel id (26 bits) | member count >> 2 << 26        (member count capped at 255, as centre[].w)
+// Round 4-5 kept the id alone and read the centre through it: rank -> id -> centre, three dependent loads per hit of a ball with the
+// bitmap word before them; the record makes it two.
+__device__ __forceinline__ uint2 rankRecord( const Pt c, uint32_t v, uint32_t members ) {
+  const uint32_t w = members & 0xFFu;
+  return make_uint2( uint32_t( c.x ) | ( uint32_t( c.y ) << 10 ) | ( uint32_t( c.z ) << 20 ) | ( ( w & 3u ) << 30 ), v | ( ( w >> 2 ) << 26 ) );
+}
 __global__ __launch_bounds__( 256 ) void rankToVoxelKernel( const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag,
                                                              const uint32_t* __restrict__ vid, uint32_t n,
-                                                             const uint2* __restrict__ bits, uint32_t* __restrict__ voxelOfRank,
+                                                             const uint2* __restrict__ bits, uint2* __restrict__ voxelOfRank,
                                                              const uint32_t* __restrict__ count, Pt* __restrict__ centre ) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ( i < n && flag[i] ) {
-    voxelOfRank[rankOfKey( bits, key[i] )] = vid[i];
-    centre[vid[i]].w = int16_t( count[vid[i]] & 0xFFu );  // (the neighbourhood pass reads a voxel's centre anyway: its member count rides along)
+    const uint32_t v = vid[i], members = count[v];
+    Pt             c = centre[v];
+    voxelOfRank[rankOfKey( bits, key[i] )] = rankRecord( c, v, members );
+    centre[v].w = int16_t( members & 0xFFu );  // (the DEV rows read a voxel's centre anyway: its member count rides along)
   }
 }
 
@@ -237,7 +247,7 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
 // phase 1: the occupied cells of the ball as packed offsets ( dx + 16 ) | ( dy + 16 ) << 5 | ( dz + 16 ) << 10 | d2 << 15
 // phase 2: id + centre of each, in place (a chunk of candidates is read whole before anything lands at or below it)
 template <int CAP>
-__device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ centre, const uint32_t* __restrict__ voxelOfRank,
+__device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ centre, const uint2* __restrict__ voxelOfRank,
                                             const uint2* __restrict__ bits, const Grid g, const int* __restrict__ rows, int nRows,
                                             int idBits, uint32_t* keys, int lane, uint32_t* __restrict__ overflow,
                                             uint32_t* bins /* LDS, zeroed, or null: members (low 20 bits) and hits (above) per squared distance */ ) {
@@ -312,18 +322,15 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
         cell[k] = uint32_t( x ) | ( uint32_t( y ) << 10 ) | ( uint32_t( z ) << 20 );  // (cell coordinates are at most 512)
       }
     }
-#pragma unroll
-    for ( int k = 0; k < kBatch; ++k )
-      if ( u[k] != 0xFFFFFFFFu ) u[k] = voxelOfRank[u[k]];
     uint32_t key[kBatch];
 #pragma unroll
     for ( int k = 0; k < kBatch; ++k ) {
       key[k] = 0xFFFFFFFFu;
       if ( u[k] != 0xFFFFFFFFu ) {
-        const Pt cu = centre[u[k]];  // aliased keys: accept only the voxel whose centre really sits here
-        if ( ( uint32_t( cu.x ) | ( uint32_t( cu.y ) << 10 ) | ( uint32_t( cu.z ) << 20 ) ) == cell[k] ) {
-          key[k] = ( d2[k] << idBits ) | u[k];
-          if ( bins ) atomicAdd( &bins[min( d2[k], 127u )], ( uint32_t( cu.w ) & 0xFFu ) | ( 1u << 20 ) );
+        const uint2 rec = voxelOfRank[u[k]];  // aliased keys: accept only the voxel whose centre really sits here
+        if ( ( rec.x & 0x3FFFFFFFu ) == cell[k] ) {
+          key[k] = ( d2[k] << idBits ) | ( rec.y & 0x3FFFFFFu );
+          if ( bins ) atomicAdd( &bins[min( d2[k], 127u )], ( ( rec.x >> 30 ) | ( ( rec.y >> 26 ) << 2 ) ) | ( 1u << 20 ) );
         }
       }
     }
@@ -355,7 +362,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
     uint32_t rowCapacity, uint32_t* __restrict__ rowLen, uint32_t* __restrict__ devLen, double* __restrict__ weight,
     uint32_t* __restrict__ adjOff, uint32_t* __restrict__ adj, uint32_t* __restrict__ dev, uint32_t* __restrict__ rowCursor,
     uint32_t* __restrict__ overflow, const uint2* __restrict__ bits /* non-null: offsets = the ball's ROWS (collectBall) */,
-    const uint32_t* __restrict__ voxelOfRank /* voxel of the rank-th occupied key */,
+    const uint2* __restrict__ voxelOfRank /* record of the voxel that owns the rank-th occupied key (rankRecord) */,
     uint32_t* __restrict__ lastKey /* the last key each row keeps: what the gathered reverse rows test against */ ) {
   __shared__ uint32_t keysAll[WAVES][CAP];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -642,7 +649,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
 // key( u seen from v ) <= lastKey[v], write them back to back (one reservation per workgroup).  The order inside a reverse
 // row is immaterial (the sweeps push integer differences over it).
 template <int CAP, int WAVES>
-__global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint32_t* __restrict__ voxelOfRank,
+__global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint2* __restrict__ voxelOfRank,
                                                                      const uint2* __restrict__ bits, Grid g, uint32_t V,
                                                                      const int* __restrict__ rows, int nRows, int idBits,
                                                                      const uint32_t* __restrict__ lastKey, uint32_t rowCapacity,
@@ -1193,10 +1200,10 @@ void RefineJob::launchNeighbourhood() {
   hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
                       d_count.p, table, g, V, d_offsets, nBall, maxNNCount, lambda, idBits, devRange, devStride,             \
                       uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
-                      d_small.p + 2, byRows ? bits : (const uint2*)nullptr, d_voxelOfRank.p,                                  \
+                      d_small.p + 2, byRows ? bits : (const uint2*)nullptr, reinterpret_cast<const uint2*>( d_voxelOfRank.p ),   \
                       byRows ? d_lastKey.p : (uint32_t*)nullptr );                                                              \
   if ( byRows )                                                                                                                \
-  hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, d_voxelOfRank.p, \
+  hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, reinterpret_cast<const uint2*>( d_voxelOfRank.p ), \
                       bits, g, V, d_offsets, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
                       d_small.p + 3, d_small.p + 2 )
   // LDS per wavefront = room for the ball's OCCUPIED cells (row-wise form; a surface fills 5-10 % of a ball) or for all its
@@ -1351,8 +1358,9 @@ int RefineJob::geometry( tmc2_frame* f ) {
   hipLaunchKernelGGL( assignVoxelKernel, grdN, blk, 0, s, f->d_pts.p, d_key.p, table, bits, d_firstPoint.p, d_rank.p, n, g, d_vid.p,
                       d_count.p, d_centre.p );
   if ( byRows ) {
-    TMC2_TRY( d_voxelOfRank.alloc( V ) );
-    hipLaunchKernelGGL( rankToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, bits, d_voxelOfRank.p, d_count.p, d_centre.p );
+    TMC2_TRY( d_voxelOfRank.alloc( 2 * size_t( V ) ) );  // (uint2 records)
+    hipLaunchKernelGGL( rankToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, bits, reinterpret_cast<uint2*>( d_voxelOfRank.p ), d_count.p,
+                        d_centre.p );
   } else {
     hipLaunchKernelGGL( tableToVoxelKernel, grdN, blk, 0, s, d_key.p, d_flag.p, d_vid.p, n, table );
   }
