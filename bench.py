@@ -736,6 +736,7 @@ def main():
     # sharing a GPU: no RCCL world to make) the ranks meet over torch.distributed as before
     native = a.host == "native" or (a.host == "auto" and (world == 1 or a.dist_backend == "nccl"))
     comm = None
+    native_fallback = [None]
     if native:
         from tmc2_amd import native_gof
         native_gof.load_library()                           # (fails here, loudly, if it was not built)
@@ -745,7 +746,24 @@ def main():
             import uuid
             box = ["/dev/shm/tmc2_gof_id_%d_%s" % (os.getuid(), uuid.uuid4().hex)]
             dist.broadcast_object_list(box, src=0)
-            comm = native_gof.Comm(enc.ctxs[0], rank, world, rendezvous=box[0])
+            why = None
+            try:
+                comm = native_gof.Comm(enc.ctxs[0], rank, world, rendezvous=box[0])
+            except Exception as e:                          # (no librccl.so to load, a communicator that does not come up, ...)
+                why = repr(e)
+            # every rank or none: a world in which one rank could not make its communicator meets over torch.distributed instead
+            # (the Python host of rounds 3-5) -- and the line says so (config.host)
+            ok = [None] * world
+            dist.all_gather_object(ok, why)
+            if any(w is not None for w in ok):
+                if a.host == "native":                      # asked for by name: no quiet substitute
+                    raise RuntimeError("bench: --host native: %s" % next(w for w in ok if w is not None))
+                if comm is not None:
+                    comm.close()
+                comm, native = None, False
+                native_fallback[0] = next(w for w in ok if w is not None)
+                if rank == 0:
+                    print("bench: the C++ / RCCL host is not available (%s): the ranks meet over torch.distributed" % native_fallback[0], file=sys.stderr)
     capacity = [c["min_w"], c["min_h"]]
     resumed_passes = [0]
 
@@ -972,7 +990,7 @@ def main():
                    "host": (("native: one tmc2_gof_encode_sharded call per GOF and rank (libtmc2gof.so: C++ threads over the C-ABI; weights, "
                              "canvas height and patch records cross the node as RCCL collectives issued from C++)" if comm is not None else
                              "native: one tmc2_gof_encode call per GOF (libtmc2gof.so, C++ threads over the C-ABI)") if native
-                            else "python: GofEncoder's worker threads over the C-ABI"),
+                            else "python: GofEncoder's worker threads over the C-ABI" + ("" if native_fallback[0] is None else " (the C++ / RCCL host was asked for and not available: %s)" % native_fallback[0])),
                    "frames_per_gpu": len(frames), "host_workers_per_gpu": workers, "host_step_slots_per_gpu": slots, "parallelism": "frames f%%%d" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": round(avg_ms, 4),

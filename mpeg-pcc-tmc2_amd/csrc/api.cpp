@@ -392,8 +392,6 @@ void tmc2::destroyContextNow( tmc2_ctx* ctx ) {
     ctx->retiredTables.clear();
   }
   if ( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
-  if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
-  if ( ctx->sweepGraph ) (void)hipGraphDestroy( static_cast<hipGraph_t>( ctx->sweepGraph ) );
   ctx->pool.drain();
   if ( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
   if ( ctx->mailbox ) (void)hipHostFree( ctx->mailbox );

@@ -288,8 +288,6 @@ struct tmc2_ctx {
   std::map<std::string, std::string> options;
   mutable std::mutex                 optionsLock;
   std::shared_ptr<tmc2_host_gate>    hostGate;  // this encoder's budget of host-resident steps (guarded by optionsLock); null: the process default
-  void* sweepGraph = nullptr;      // option REFINE_GRAPH: the hipGraph_t / hipGraphExec_t of the last refinement's sweeps (kept until the next one)
-  void* sweepGraphExec = nullptr;
   hipStream_t                   stream = nullptr;
   std::vector<tmc2::StageTimer> stages;
   std::vector<hipEvent_t>       freeEvents;

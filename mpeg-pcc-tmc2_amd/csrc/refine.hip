@@ -1504,12 +1504,10 @@ int RefineJob::finish() {
   uint32_t*  counts[2] = {d_gbits.p + 2 * size_t( W2 ), d_gbits.p + 2 * size_t( W2 ) + kSubLists * 32};
   uint32_t*  ctl       = d_gbits.p + 2 * size_t( W2 ) + 2 * kSubLists * 32;
   uint32_t*  spill     = ctl + 64;
-  // (option REFINE_GRAPH=1, measured in round 5: the 2 I launches of the loop captured into ONE hipGraph per frame -- the loop has
-  //  no host decision in it.  Off by default: see DESIGN.md section 5 for what it did to the launch-bound chain.)
+  // (Measured and dropped, twice: the 2 I launches of the loop as ONE hipGraph per frame -- round 5, option REFINE_GRAPH, removed in
+  //  round 6 -- and as ONE kernel whose phases take their work by ticket -- round 6, profiles/r06_one_launch_sweeps.txt.  The loop has no
+  //  host decision in it, but what sixteen frames in flight share is wave-slot time, not launches: DESIGN.md section 5.)
   const bool      debugSweeps = ctxOption( ctx, "REFINE_DEBUG" ) != nullptr;
-  const char*     graphOpt    = ctxOption( ctx, "REFINE_GRAPH" );
-  const bool      asGraph     = graphOpt && graphOpt[0] == '1' && !debugSweeps && !wantTiming && !wantTrace;
-  if ( asGraph ) TMC2_HIP( hipStreamBeginCapture( s, hipStreamCaptureModeThreadLocal ) );
   for ( int iter = 0; iter < iterationCount; ++iter ) {
     const int cur    = iter & 1, nxt = cur ^ 1;
     uint4 *   recCur = d_rec.p + size_t( cur ) * V, *recNxt = d_rec.p + size_t( nxt ) * V;
@@ -1527,17 +1525,6 @@ int RefineJob::finish() {
       const hipError_t e = hipStreamSynchronize( s );
       fprintf( stderr, "refine: sweep %d sweep done (%d)\n", iter, int( e ) );
     }
-  }
-  if ( asGraph ) {
-    hipGraph_t     graph = nullptr;
-    hipGraphExec_t exec  = nullptr;
-    TMC2_HIP( hipStreamEndCapture( s, &graph ) );
-    TMC2_HIP( hipGraphInstantiate( &exec, graph, nullptr, nullptr, 0 ) );
-    TMC2_HIP( hipGraphLaunch( exec, s ) );
-    // (the executable graph has to outlive its run: the context keeps it until its next refinement, by when the stream has passed it)
-    if ( ctx->sweepGraphExec ) (void)hipGraphExecDestroy( static_cast<hipGraphExec_t>( ctx->sweepGraphExec ) );
-    if ( ctx->sweepGraph ) (void)hipGraphDestroy( static_cast<hipGraph_t>( ctx->sweepGraph ) );
-    ctx->sweepGraphExec = exec, ctx->sweepGraph = graph;
   }
   ctx->stageEnd( sidSweep );
   TMC2_HIP( hipGetLastError() );
