@@ -4,7 +4,7 @@
 # BASELINE CONFIGURATION -- default steps, the reference timed on this box's host cores in the same run (north_star: every
 # throughput next to the reference's CPU/TBB path; --cpu-baseline 3 = one frame on one thread + 8 frames through its TBB path) --
 # the headline line with every side leg, the rough-shell workload, two ranks on one GPU.
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 REPO=$(pwd); O=$REPO/gpurun_out
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $O/${TAG}_smoke.log | cut -c1-200
