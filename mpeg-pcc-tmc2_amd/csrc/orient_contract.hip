@@ -332,61 +332,97 @@ __global__ __launch_bounds__( 256 ) void pairInsertKernel( const uint32_t* __res
   if ( in && j == 0 ) crossMask[u] = uint16_t( cross );
   }
 }
-// pass 2: the edges the walk gets -- bit j of keepMask[u] -- and their number per source cluster (one report per workgroup and
-// cluster, as verifyCountKernel).  dedupe = false: every cross edge (the table overflowed).
+// ---- passes 2 and 3: which cross edges the walk gets, and the edges themselves, grouped by source cluster --------------------
+// Both walk the points 256 per workgroup, 64 per wavefront: every lane fetches ONE point's mask (a coalesced load) and the
+// wavefront then takes only the groups of four consecutive points that hold a set bit, sixteen lanes per point -- most points
+// have no cross edge at all.  What the passes cost in rounds 3-5 (127 + 111 us) was neither that walk nor its barriers but the
+// global atomics on the counters of a few BIG clusters (the body of a figure is one cluster with tens of thousands of cross
+// edges): thousands of adds to one word, ~ 11 ns each, one after the other (tools/gpu/r6/call26.sh: pairSelectKernel without
+// its adds takes 67 us instead of 147).  A workgroup's 256 consecutive points belong to a handful of clusters: their counts
+// are folded in an LDS table first (key = cluster, open addressing, 512 slots for at most 256 keys) and every (workgroup,
+// cluster) pair costs ONE global atomic.
+constexpr uint32_t kFoldSlots = 512, kFoldEmpty = 0xFFFFFFFFu;
+// (one lane) adds `add` to cluster cu's entry of the workgroup's table; returns the slot, and in `old` what the entry held before
+__device__ __forceinline__ uint32_t foldAdd( uint32_t* key, uint32_t* val, uint32_t cu, uint32_t add, uint32_t& old ) {
+  uint32_t slot = ( cu * 2654435761u ) >> 23;  // (9 bits)
+  for ( ;; ) {
+    const uint32_t k = atomicCAS( &key[slot], kFoldEmpty, cu );
+    if ( k == kFoldEmpty || k == cu ) break;
+    slot = ( slot + 1u ) & ( kFoldSlots - 1u );  // (at most 256 distinct keys per round: a free slot is always found)
+  }
+  old = atomicAdd( &val[slot], add );
+  return slot;
+}
+
+// pass 2: bit j of keepMask[u] = the walk gets edge j of point u; count[c] = the edges cluster c keeps.  dedupe = false: every
+// cross edge (the table overflowed).
 template <int K>
 __global__ __launch_bounds__( 256 ) void pairSelectKernel( const uint32_t* __restrict__ knn, const double* __restrict__ normals,
                                                             const uint16_t* __restrict__ strongAll, const uint16_t* __restrict__ negAll,
-                                                            const uint32_t* __restrict__ perm, bool chunked, const uint16_t* __restrict__ crossMask,
+                                                            const uint32_t* __restrict__ perm, const uint16_t* __restrict__ crossMask,
                                                             const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
                                                             uint32_t n, PairTable t, int dedupe, uint16_t* __restrict__ keepMask,
                                                             uint32_t* __restrict__ count ) {
   static_assert( K == 16, "16 lanes per point" );
-  const int           j = threadIdx.x & 15, lane = threadIdx.x & 63;
-  __shared__ uint32_t sCid[16], sKept[16];
-  for ( GroupWalk w( ( n + 15 ) / 16, chunked ); w.g < w.end; w.g += w.step ) {  // (uniform over the workgroup: barriers inside)
-  const uint32_t at = w.g * 16 + ( threadIdx.x >> 4 );
-  const bool     in = at < n;
-  const uint32_t u  = in ? ( perm ? perm[at] : at ) : 0u;
-  bool           keep = false;
-  uint32_t       cu = 0xFFFFFFFFu;
-  if ( in ) {
-    cu   = cid[u];
-    keep = ( crossMask[u] >> j ) & 1u;
-    if ( keep && dedupe ) {
-      const uint32_t v = knn[size_t( u ) * K + j];
-      const uint32_t s = pairSlot( t, cu, cid[v], false );
-      if ( s == 0xFFFFFFFFu ) {
-        keep = true;  // (unreachable after a clean insert pass; harmless: an extra edge)
-      } else if ( ( strongAll[u] >> j ) & 1u ) {
-        keep = t.strongFirst[2 * size_t( s ) + ( ( ( negAll[u] >> j ) & 1u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )] == u * 16u + uint32_t( j );
-      } else {
-        keep = (unsigned long long)__double_as_longlong( fabs( edgeDotOf( normals, u, v ) ) ) == t.bestW[s];
+  __shared__ uint32_t fKey[kFoldSlots], fVal[kFoldSlots];
+  const int j = threadIdx.x & 15, lane = threadIdx.x & 63, p = lane >> 4;
+  for ( uint32_t s = threadIdx.x; s < kFoldSlots; s += blockDim.x ) fKey[s] = kFoldEmpty, fVal[s] = 0;
+  __syncthreads();
+  for ( uint32_t wgBase = blockIdx.x * 256u; wgBase < n; wgBase += gridDim.x * 256u ) {  // (uniform over the workgroup: barriers inside)
+  const uint32_t mineAt = wgBase + threadIdx.x;
+  const uint32_t mineU  = mineAt < n ? ( perm ? perm[mineAt] : mineAt ) : 0u;
+  const uint32_t mineCm = mineAt < n ? crossMask[mineU] : 0u;
+  if ( mineAt < n && !mineCm ) keepMask[mineU] = 0;
+  unsigned long long todo = __ballot( mineCm != 0u );
+  while ( todo ) {  // (uniform over the wavefront)
+    const int k = ( __ffsll( (long long)todo ) - 1 ) >> 2;
+    todo &= ~( 0xFull << ( 4 * k ) );
+    const uint32_t u  = __shfl( mineU, 4 * k + p, 64 );
+    const uint32_t cm = __shfl( mineCm, 4 * k + p, 64 );
+    const bool     in = cm != 0u;  // (a point without cross edges has its zero already)
+    bool           keep = false;
+    uint32_t       cu = 0xFFFFFFFFu;
+    if ( in ) {
+      cu   = cid[u];
+      keep = ( cm >> j ) & 1u;
+      if ( keep && dedupe ) {
+        const uint32_t v = knn[size_t( u ) * K + j];
+        const uint32_t sl = pairSlot( t, cu, cid[v], false );
+        if ( sl == 0xFFFFFFFFu ) {
+          keep = true;  // (unreachable after a clean insert pass; harmless: an extra edge)
+        } else if ( ( strongAll[u] >> j ) & 1u ) {
+          keep = t.strongFirst[2 * size_t( sl ) + ( ( ( negAll[u] >> j ) & 1u ) ^ ( uint32_t( parity[u] ) ^ parity[v] ) )] == u * 16u + uint32_t( j );
+        } else {
+          keep = (unsigned long long)__double_as_longlong( fabs( edgeDotOf( normals, u, v ) ) ) == t.bestW[sl];
+        }
       }
     }
-  }
-  const uint32_t kept = ballot16( keep, lane );
-  if ( in && j == 0 ) keepMask[u] = uint16_t( kept );
-  const int p = threadIdx.x >> 4;
-  if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( kept ) );
-  __syncthreads();
-  if ( in && j == 0 ) {
-    bool     first = true;
-    uint32_t total = 0;
-    for ( int q = 0; q < 16; ++q ) {
-      if ( sCid[q] != cu ) continue;
-      if ( q < p ) first = false;
-      total += sKept[q];
+    const uint32_t kept = ballot16( keep, lane );
+    if ( in && j == 0 ) {
+      keepMask[u] = uint16_t( kept );
+      uint32_t old;
+      if ( kept ) (void)foldAdd( fKey, fVal, cu, uint32_t( __popc( kept ) ), old );
     }
-    if ( first && total ) atomicAdd( &count[cu], total );
   }
-  __syncthreads();  // (the shared records are rewritten by the next group of points)
+  __syncthreads();
+  for ( uint32_t s = threadIdx.x; s < kFoldSlots; s += blockDim.x ) {  // this round's clusters: one global add each, and the table is empty again
+    const uint32_t c = fKey[s], v = fVal[s];
+    if ( c != kFoldEmpty ) {
+      if ( v ) atomicAdd( &count[c], v );
+      fKey[s] = kFoldEmpty, fVal[s] = 0;
+    }
+  }
+  __syncthreads();
   }
 }
-// the kept edges, per source cluster, with the target cluster and the two ends' parities folded into the dot product
+
+// pass 3: the kept edges, per source cluster, with the target cluster and the two ends' parities folded into the dot product; and
+// the cluster records (where a cluster's edges start, its seed point and parity: one copy to the host instead of three; the
+// sentinel record by the last point).  Queued before the host knows the number of clusters / kept edges: both come from the
+// device, writes stay inside the buffers -- a frame that needs more is repeated with exact sizes.
 template <int K>
 __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* __restrict__ knn, const double* __restrict__ normals,
-                                                                const uint32_t* __restrict__ perm, bool chunked,
+                                                                const uint32_t* __restrict__ perm,
                                                                 const uint32_t* __restrict__ cid, const uint8_t* __restrict__ parity,
                                                                 const uint32_t* __restrict__ off, const uint16_t* __restrict__ keepMask,
                                                                 const uint32_t* __restrict__ root, const uint32_t* __restrict__ minIdx,
@@ -394,54 +430,46 @@ __global__ __launch_bounds__( 256 ) void scatterCompactKernel( const uint32_t* _
                                                                 uint32_t recCap, uint32_t* __restrict__ cursor,
                                                                 OrientCompactEdge* __restrict__ edges, OrientClusterRec* __restrict__ rec ) {
   static_assert( K == 16, "16 lanes per point" );
-  const int           j = threadIdx.x & 15, p = threadIdx.x >> 4;
-  __shared__ uint32_t sCid[16], sKept[16], sBase[16];
-  for ( GroupWalk w( ( n + 15 ) / 16, chunked ); w.g < w.end; w.g += w.step ) {  // (uniform over the workgroup: barriers inside)
-  const uint32_t at = w.g * 16 + ( threadIdx.x >> 4 );
-  const bool     in = at < n;
-  const uint32_t u  = in ? ( perm ? perm[at] : at ) : 0u;
-  const uint32_t m  = in ? keepMask[u] : 0u;
-  const uint32_t cu = in ? cid[u] : 0xFFFFFFFFu;
-  if ( j == 0 ) sCid[p] = cu, sKept[p] = uint32_t( __popc( m ) );
-  // the cluster's record, written by its first member: where its edges start, the seed point and its parity (one copy to the
-  // host instead of three); the sentinel record by the last point
-  // (queued before the host knows the number of clusters / kept edges: both come from the device, writes stay inside the
-  // buffers -- a frame that needs more is repeated with exact sizes)
+  __shared__ uint32_t fKey[kFoldSlots], fVal[kFoldSlots];  // (fVal: a cluster's edges in this round; after the reservation: where they start)
+  const int      j = threadIdx.x & 15, lane = threadIdx.x & 63, p = lane >> 4;
   const uint32_t clusters = *clustersPtr;
-  if ( in && j == 0 && minIdx[root[u]] == u && cu < recCap ) rec[cu] = OrientClusterRec{off[cu], u, parity[u]};
-  if ( in && j == 0 && u == n - 1 && clusters < recCap ) rec[clusters] = OrientClusterRec{off[clusters], 0u, 0u};
+  for ( uint32_t s = threadIdx.x; s < kFoldSlots; s += blockDim.x ) fKey[s] = kFoldEmpty, fVal[s] = 0;
   __syncthreads();
-  if ( j == 0 && m ) {
-    bool     first = true;
-    uint32_t total = 0;
-    for ( int q = 0; q < 16; ++q ) {
-      if ( sCid[q] != cu || !sKept[q] ) continue;
-      if ( q < p ) first = false;
-      total += sKept[q];
-    }
-    if ( first ) sBase[p] = off[cu] + atomicAdd( &cursor[cu], total );
+  for ( uint32_t wgBase = blockIdx.x * 256u; wgBase < n; wgBase += gridDim.x * 256u ) {  // (uniform over the workgroup: barriers inside)
+  const uint32_t mineAt = wgBase + threadIdx.x;
+  const uint32_t mineU  = mineAt < n ? ( perm ? perm[mineAt] : mineAt ) : 0u;
+  const uint32_t mineM  = mineAt < n ? keepMask[mineU] : 0u;
+  uint32_t       slot = 0, within = 0;  // this lane's point: its cluster's entry, and its edges' place among the round's edges of the cluster
+  if ( mineAt < n ) {
+    const uint32_t c = ( mineM || minIdx[root[mineU]] == mineU ) ? cid[mineU] : 0u;
+    if ( minIdx[root[mineU]] == mineU && c < recCap ) rec[c] = OrientClusterRec{off[c], mineU, parity[mineU]};
+    if ( mineU == n - 1 && clusters < recCap ) rec[clusters] = OrientClusterRec{off[clusters], 0u, 0u};
+    if ( mineM ) slot = foldAdd( fKey, fVal, c, uint32_t( __popc( mineM ) ), within );
   }
   __syncthreads();
-  if ( m ) {  // (uniform over the 16 lanes of a point)
-  uint32_t pos0 = 0;
-  if ( j == 0 ) {
-    int lead = p;
-    for ( int q = 0; q < p; ++q ) {
-      if ( sCid[q] != cu || !sKept[q] ) continue;
-      if ( lead == p ) lead = q;
-      pos0 += sKept[q];
+  for ( uint32_t s = threadIdx.x; s < kFoldSlots; s += blockDim.x ) {  // one reservation per cluster of the round
+    const uint32_t c = fKey[s];
+    if ( c != kFoldEmpty ) fVal[s] = off[c] + atomicAdd( &cursor[c], fVal[s] );
+  }
+  __syncthreads();
+  const uint32_t minePos = mineM ? fVal[slot] + within : 0u;
+  unsigned long long todo = __ballot( mineM != 0u );
+  while ( todo ) {  // (uniform over the wavefront)
+    const int k = ( __ffsll( (long long)todo ) - 1 ) >> 2;
+    todo &= ~( 0xFull << ( 4 * k ) );
+    const uint32_t u    = __shfl( mineU, 4 * k + p, 64 );
+    const uint32_t m    = __shfl( mineM, 4 * k + p, 64 );
+    const uint32_t pos0 = __shfl( minePos, 4 * k + p, 64 );
+    if ( ( m >> j ) & 1u ) {
+      const uint32_t v = knn[size_t( u ) * K + j];
+      const double   d = edgeDotOf( normals, u, v );
+      const uint32_t pos = pos0 + __popc( m & ( ( 1u << j ) - 1u ) );
+      if ( pos < edgeCap ) edges[pos] = OrientCompactEdge{u, v, cid[v], 0u, ( ( parity[u] ^ parity[v] ) & 1 ) ? -d : d};
     }
-    pos0 += sBase[lead];
   }
-  pos0 = __shfl( pos0, ( threadIdx.x & 63 ) & 48, 64 );
-  if ( ( m >> j ) & 1u ) {
-    const uint32_t v = knn[size_t( u ) * K + j];
-    const double   d = edgeDotOf( normals, u, v );
-    const uint32_t pos = pos0 + __popc( m & ( ( 1u << j ) - 1u ) );
-    if ( pos < edgeCap ) edges[pos] = OrientCompactEdge{u, v, cid[v], 0u, ( ( parity[u] ^ parity[v] ) & 1 ) ? -d : d};
-  }
-  }
-  __syncthreads();  // (the shared records are rewritten by the next group of points)
+  __syncthreads();
+  for ( uint32_t s = threadIdx.x; s < kFoldSlots; s += blockDim.x ) fKey[s] = kFoldEmpty, fVal[s] = 0;
+  __syncthreads();
   }
 }
 
@@ -590,13 +618,13 @@ int contractOrientationDevice( tmc2_frame* f, double tau, DevBuf<uint32_t>& d_ci
     return TMC2_E_HIP;
   }
   TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
-  hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, chunkedPairs, d_crossMask.p, d_cid.p,
+  hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, d_crossMask.p, d_cid.p,
                       d_parity.p, n, t, 1, d_keepMask.p, d_count.p );
   // (the four counters in the context's page-locked line, stored by this scan's last tile: [0] kept cross edges -- its total --,
   //  [1] bad flag, [2] the same total again, [3] pair table overflow, [4] clusters: all settled by earlier launches -- no copy)
   volatile uint32_t* headLine = ctx->answerLine( tmc2_ctx::kAnswerOrientHead );
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1, ScanAnswer{headLine, d_small.p, 4} ) );
-  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, chunkedPairs, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+  hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
                       d_minIdx.p, n, d_small.p + 3, kSpecEdges, kSpecClusters, d_cursor.p, d_edges.p, d_rec.p );
   // (what a frame typically needs, plus a margin, comes along right away; the rest -- if any -- after the counters are known)
   const uint32_t kFirstEdges = std::min( 192u * 1024, kSpecEdges ), kFirstClusters = std::min( 32u * 1024, kSpecClusters );
@@ -624,7 +652,7 @@ int contractOrientationDevice( tmc2_frame* f, double tau, DevBuf<uint32_t>& d_ci
       // the pair table overflowed: every cross edge goes (selection and counts again, without the table)
       ctx->stageAddHostMs( "orient_pair_table_overflow", 0.0 );  // (counts the frames that took every cross edge)
       TMC2_TRY( fillRegions( ctx, {{d_count.p, ( size_t( n ) + 1 ) * 4, 0}, {d_cursor.p, size_t( n ) * 4, 0}} ) );
-      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, chunkedPairs, d_crossMask.p, d_cid.p,
+      hipLaunchKernelGGL( pairSelectKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, d_strongAll.p, d_negAll.p, perm, d_crossMask.p, d_cid.p,
                           d_parity.p, n, t, 0, d_keepMask.p, d_count.p );
       TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_off.p, size_t( n ) + 1, d_small.p + 1 ) );
       TMC2_HIP( hipMemcpyAsync( head, d_small.p, 16, hipMemcpyDeviceToHost, s ) );
@@ -638,7 +666,7 @@ int contractOrientationDevice( tmc2_frame* f, double tau, DevBuf<uint32_t>& d_ci
     }
     TMC2_TRY( d_edges.alloc( std::max<uint32_t>( E, 1u ) ) );
     TMC2_TRY( d_rec.alloc( size_t( C ) + 1 ) );
-    hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, chunkedPairs, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
+    hipLaunchKernelGGL( scatterCompactKernel<16>, grdN16, blk, 0, s, f->d_knn.p, normals, perm, d_cid.p, d_parity.p, d_off.p, d_keepMask.p, d_root.p,
                         d_minIdx.p, n, d_small.p + 3, std::max<uint32_t>( E, 1u ), C + 1, d_cursor.p, d_edges.p, d_rec.p );
     h_rec   = ctx->hostA.get<OrientClusterRec>( size_t( C ) + 1 );
     h_edges = ctx->hostE.get<OrientCompactEdge>( std::max<uint32_t>( E, 1u ) );

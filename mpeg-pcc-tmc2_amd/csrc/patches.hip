@@ -334,12 +334,13 @@ __global__ __launch_bounds__( 256 ) void ccRelaxKernel( const uint32_t* __restri
   if ( any ) *changed = token;  // (which sweep changed something last: nothing to clear between sweeps)
 }
 
+constexpr uint32_t kRawCounters = 16;  // this round's count of points still raw: sixteen words 128 bytes apart, one add per workgroup
 // start of a round's per-patch accumulators: bounding box {min 3 x INT_MAX, max 3 x 0 -- the reference starts its max at 0},
 // minimum (u, v), the two resampling counters; and this round's count of points still raw
 __global__ __launch_bounds__( 256 ) void patchBoundsInitKernel( uint32_t P, int32_t* __restrict__ bbox, int32_t* __restrict__ minUv,
                                                                  int32_t* __restrict__ patchStat, uint32_t* __restrict__ rawCount ) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if ( p == 0 ) *rawCount = 0;
+  if ( p < kRawCounters ) rawCount[p * 32] = 0;  // (the first workgroup always exists: P >= 1)
   if ( p >= P ) return;
 #pragma unroll
   for ( int d = 0; d < 3; ++d ) {
@@ -352,8 +353,11 @@ __global__ __launch_bounds__( 256 ) void patchBoundsInitKernel( uint32_t P, int3
 
 // label of every point still raw (the label of its group), and the size of every component (one atomic per run of equal
 // labels in a wavefront)
+// (round 6: the sizes are only ever compared with minCount -- ccSeedFlagKernel, ccAssignKernel -- so a component that has reached it
+//  stops counting: the body of a figure is ONE component of 10^5 points, and 13 000 wavefronts adding to its one word queued up for
+//  ~ 11 ns each; the look is a possibly stale view of a counter that only grows -- a stale read costs an add, never a wrong answer)
 __global__ __launch_bounds__( 256 ) void ccLabelCountKernel( const uint8_t* __restrict__ raw, const uint32_t* __restrict__ parent,
-                                                              const uint32_t* __restrict__ lab, uint32_t n,
+                                                              const uint32_t* __restrict__ lab, uint32_t n, uint32_t minCount,
                                                               uint32_t* __restrict__ label, uint32_t* __restrict__ ccCount ) {
   const uint32_t i    = chunkedIndex();
   const int      lane = threadIdx.x & 63;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__( 256 ) void ccLabelCountKernel( const uint8_t* __re
     const int                leader = __ffsll( (long long)todo ) - 1;
     const uint32_t           key    = __shfl( l, leader, 64 );
     const unsigned long long same   = __ballot( l == key );
-    if ( lane == leader ) atomicAdd( &ccCount[key], uint32_t( __popcll( same ) ) );
+    if ( lane == leader && loadStaleOk( &ccCount[key] ) < minCount ) atomicAdd( &ccCount[key], uint32_t( __popcll( same ) ) );
     todo &= ~same;
   }
 }
@@ -630,7 +634,7 @@ __global__ __launch_bounds__( 256 ) void patchResampleTileKernel( const PatchDev
                                                                    int16_t* __restrict__ depth0, int16_t* __restrict__ depth1,
                                                                    uint8_t* __restrict__ occupancy,
                                                                    int32_t* __restrict__ patchStat /* [p][2] sizeD, d0Count */ ) {
-  __shared__ int  anyValid[4];
+  __shared__ int  anyValid[4], tileMax[4];
   const uint32_t  tile = blockIdx.x;
   const uint32_t  p    = tilePatch[tile];
   const PatchDev  pd   = patches[p];
@@ -672,17 +676,23 @@ __global__ __launch_bounds__( 256 ) void patchResampleTileKernel( const PatchDev
   int                      mx = valid ? max( l0, l1 ) : 0;
 #pragma unroll
   for ( int off = 32; off > 0; off >>= 1 ) mx = max( mx, __shfl_xor( mx, off, 64 ) );
+  // (one report per TILE -- rounds 1-5: one per wavefront -- and the maximum only if it can raise the patch's: a big patch is
+  //  thousands of tiles adding to the same two words, ~ 11 ns each, one after the other; the look is a possibly stale view of a
+  //  word that only grows)
   if ( ( threadIdx.x & 63 ) == 0 ) {
     anyValid[threadIdx.x >> 6] = __popcll( m );
-    if ( m ) {
-      atomicMax( &patchStat[2 * p], mx );
-      atomicAdd( &patchStat[2 * p + 1], __popcll( m ) );
-    }
+    tileMax[threadIdx.x >> 6]  = mx;
   }
   __syncthreads();
-  if ( threadIdx.x == 0 )
-    occupancy[size_t( pd.occOff ) + size_t( bv ) * pd.sizeU0 + bu] =
-        ( anyValid[0] + anyValid[1] + anyValid[2] + anyValid[3] ) ? 1 : 0;
+  if ( threadIdx.x == 0 ) {
+    const int count = anyValid[0] + anyValid[1] + anyValid[2] + anyValid[3];
+    occupancy[size_t( pd.occOff ) + size_t( bv ) * pd.sizeU0 + bu] = count ? 1 : 0;
+    if ( count ) {
+      const int tmx = max( max( tileMax[0], tileMax[1] ), max( tileMax[2], tileMax[3] ) );
+      if ( tmx > loadStaleOk( &patchStat[2 * p] ) ) atomicMax( &patchStat[2 * p], tmx );
+      atomicAdd( &patchStat[2 * p + 1], count );
+    }
+  }
 }
 
 // ---- S9 -------------------------------------------------------------------------------------------------
@@ -713,8 +723,15 @@ __global__ __launch_bounds__( 256 ) void rawDistanceKernel( const Pt* __restrict
     isRaw   = best > thrSelection;
     raw[i]  = isRaw ? 1 : 0;
   }
+  // (rounds 1-5: one add per wavefront to ONE word -- 13 000 of them, ~ 11 ns each, in a queue; now folded per workgroup in LDS
+  //  and spread over kRawCounters words)
+  __shared__ uint32_t wgRaw;
+  if ( threadIdx.x == 0 ) wgRaw = 0;
+  __syncthreads();
   const unsigned long long m = __ballot( isRaw );
-  if ( ( threadIdx.x & 63 ) == 0 && m ) atomicAdd( rawCount, uint32_t( __popcll( m ) ) );
+  if ( ( threadIdx.x & 63 ) == 0 && m ) atomicAdd( &wgRaw, uint32_t( __popcll( m ) ) );
+  __syncthreads();
+  if ( threadIdx.x == 0 && wgRaw ) atomicAdd( &rawCount[( blockIdx.x % kRawCounters ) * 32], wgRaw );
 }
 
 }  // namespace
@@ -862,7 +879,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
         hipLaunchKernelGGL( ccRelaxKernel<16>, grdT, blk, 0, s, f->d_knn.p, d_mutual.p, f->d_partition.p, d_raw.p,
                             d_root.p, perm, chunked, n, d_lab.p, d_small.p, ++relaxToken, agentScope );
       ctx->stageEnd( kt );
-      hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_root.p, d_lab.p, n, d_label.p, d_ccCount.p );
+      hipLaunchKernelGGL( ccLabelCountKernel, grdN, blk, 0, s, d_raw.p, d_root.p, d_lab.p, n,
+                          uint32_t( sp->minPointCountPerCCPatchSegmentation ), d_label.p, d_ccCount.p );
       hipLaunchKernelGGL( ccSeedFlagKernel, grdN, blk, 0, s, d_label.p, d_ccCount.p,
                           uint32_t( sp->minPointCountPerCCPatchSegmentation ), n, d_flag.p );
       // (both answers in the context's page-locked line, stored by the scan's last tile: [0] the number of patches, [1] the token of
@@ -881,7 +899,8 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     sid = ctx->stageBegin( "patches_build" );
     TMC2_TRY( d_minUv.alloc( 2 * size_t( P ) ) );
     TMC2_TRY( d_bbox.alloc( 7 * size_t( P ) ) );           // boxes, then the views: one copy to the host
-    TMC2_TRY( d_patchStat.alloc( 2 * size_t( P ) + 1 ) );  // counters, then the round's count of points still raw: one copy
+    const size_t statWords = 2 * size_t( P ) + size_t( kRawCounters ) * 32;  // counters, then the round's counts of points still raw: one copy
+    TMC2_TRY( d_patchStat.alloc( statWords ) );
     int32_t*  d_view     = d_bbox.p + 6 * size_t( P );
     uint32_t* d_rawCount = reinterpret_cast<uint32_t*>( d_patchStat.p + 2 * size_t( P ) );
     TMC2_TRY( d_patches.alloc( P ) );
@@ -894,7 +913,7 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     hipLaunchKernelGGL( patchTrimBboxKernel, grdN, blk, 0, s, f->d_pts.p, d_view, d_minUv.p,
                         sp->enablePatchSplitting, sp->maxPatchSize, n, d_pointPatch.p, d_bbox.p );
     // (boxes + views, and further down the counters, land in the context's page-locked staging: plain DMA, no staging copy behind it)
-    int32_t* h_records = ctx->hostRecords.get<int32_t>( std::max<size_t>( 9 * size_t( P ) + 1, size_t( 1 ) << 16 ) );
+    int32_t* h_records = ctx->hostRecords.get<int32_t>( std::max<size_t>( 7 * size_t( P ) + statWords, size_t( 1 ) << 16 ) );
     if ( !h_records ) {
       setError( "segmentPatches: hipHostMalloc failed" );
       return TMC2_E_HIP;
@@ -988,9 +1007,10 @@ int segmentPatches( tmc2_frame* f, const tmc2_segmenter_params* sp ) {
     // ---- S9 -----------------------------------------------------------------------------------------
     hipLaunchKernelGGL( rawDistanceKernel, grdN, blk, 0, s, f->d_pts.p, n, ctx->voxelBitmap.p, bitmapBits, d_offsets,
                         int( offsets.size() ), thrSel, d_dist.p, d_raw.p, d_rawCount );
-    TMC2_HIP( hipMemcpyAsync( h_stat, d_patchStat.p, ( 2 * size_t( P ) + 1 ) * 4, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipMemcpyAsync( h_stat, d_patchStat.p, statWords * 4, hipMemcpyDeviceToHost, s ) );
     TMC2_HIP( hipStreamSynchronize( s ) );
-    rawCount = uint32_t( h_stat[2 * size_t( P )] );
+    rawCount = 0;
+    for ( uint32_t c = 0; c < kRawCounters; ++c ) rawCount += uint32_t( h_stat[2 * size_t( P ) + size_t( c ) * 32] );
     ctx->stageEnd( sid );
     for ( uint32_t p = 0; p < P; ++p ) {
       tmc2_patch& T = f->patches[patchBase + p];
