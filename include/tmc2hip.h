@@ -373,6 +373,14 @@ int tmc2_metrics_compute_frame( tmc2_frame* frame, int which, int useNormals, do
 int tmc2_metrics_compute_frame_source( tmc2_frame* frame, int which, const int16_t* srcXyz, const uint8_t* srcRgb, uint64_t n,
                                        const double* srcNormals, double resolution, double* out, int64_t* counts );
 
+/* The accumulation of QualityMetrics::compute alone (`sseC2c += ..`, `sseC2p += ..`, `sseColor[i] += ..` over the points in
+ * index order, PCCMetrics.cpp:187-198) for per-point terms the caller holds on the host: termsA[nA][5] / termsB[nB][5] = the
+ * squared distance (an integer), the point-to-plane term and the three colour terms of every point, one direction each (either
+ * may be empty).  out[10]: the five sums of A, then of B -- the doubles the reference's loop leaves, bit for bit (the ordered
+ * fp64 sums are evaluated block-wise in exact integer arithmetic: csrc/ordered_sum.h).  What tmc2_metrics_compute* run
+ * internally on the device-resident terms; exported so that the form can be checked on arbitrary terms.                */
+int tmc2_metrics_ordered_sums( tmc2_ctx* ctx, const double* termsA, uint64_t nA, const double* termsB, uint64_t nB, double* out );
+
 /* replaces: PCCMetrics::display / QualityMetrics::print (PCCMetrics.cpp:376-391, 230-279) for one frame: the text the CTC log
  * parsers read, from the numbers of tmc2_metrics_compute (out[3][8], counts[2]), the point counts before duplicate removal
  * and the peak value.  precision: that of the application's std::cout (PccAppEncoder / PccAppMetrics set 9).  text may be

@@ -24,6 +24,7 @@
 #include <numeric>
 
 #include "internal.h"
+#include "ordered_sum.h"
 
 namespace tmc2 {
 namespace {
@@ -402,70 +403,231 @@ __global__ __launch_bounds__( 256 ) void distortionTermsKernel( const Pt* __rest
 
 // ---- the sums over the points ---------------------------------------------------------------------------------------------
 // terms[a][0] (squared distances: integers) are summed as 64-bit integers by everybody; terms[a][1 .. 4] (D2 and the three
-// colour errors) in the reference's order, a = 0, 1, 2, ...  Both directions of the metric in one launch: eight ordered sums,
-// one per lane 0 .. 7 of the first wave (a dependent fp64 add costs a wave the same whether one lane or eight take part),
-// column-major in LDS so that a lane fetches two consecutive terms per load, chunk by chunk while the other waves fetch the
-// next chunk.  out[0 .. 4] = the five sums of direction A as doubles, out[5 .. 9] = of direction B.
-constexpr int kSumChunk = 1024, kSumStride = kSumChunk + 2;  // (columns 16 bytes apart in the LDS banks: the eight lanes read side by side)
-__global__ __launch_bounds__( 1024 ) void orderedSumsKernel( const double* __restrict__ termsA, uint32_t nA,
-                                                              const double* __restrict__ termsB, uint32_t nB,
-                                                              double* __restrict__ out ) {
-  extern __shared__ double buf[];  // [2 slots][8 columns][kSumStride]
-  __shared__ unsigned long long d1Total[2];
-  if ( threadIdx.x < 2 ) d1Total[threadIdx.x] = 0;
-  const uint32_t     chunks = ( max( nA, nB ) + kSumChunk - 1 ) / kSumChunk;
-  double             acc    = 0.0;  // (lanes 0 .. 7 of the first wave: one ordered sum each)
-  unsigned long long d1A = 0, d1B = 0;
-  // Round 4: the first wave only ADDS -- it never waits for global memory -- and the other fifteen only FETCH (element e of a
-  // chunk by producer thread e mod 960), one barrier per chunk instead of two: a chunk costs what its 1 024 dependent fp64 adds
-  // cost (rounds 2-3: the first wave fetched its share of the next chunk between the adds and a second barrier, and its
-  // exposed load latency was a third of the kernel).
-  const int  producer = int( threadIdx.x ) - 64;  // < 0: the adding wave
-  const auto fetch    = [&]( uint32_t c, int slot ) {
-    for ( int e = producer; e < kSumChunk; e += int( blockDim.x ) - 64 ) {
-      const uint32_t a   = c * kSumChunk + uint32_t( e );
-      double*        col = buf + size_t( slot ) * 8 * kSumStride + e;
-      if ( a < nA ) {
-        const double* t = termsA + 5 * size_t( a );
-        d1A += (unsigned long long)t[0];
+// colour errors) in the reference's order, a = 0, 1, 2, ... (`sse += dist`, PCCMetrics.cpp:73-229): eight ordered fp64 sums
+// for the two directions of the metric.  Rounds 2-5 added them term by term: one dependent add per term and chain, 4.4 ms for
+// 0.95 M points and 15.8 ms for 3 M on ONE workgroup -- the longest kernel of every trace.  Round 6 (ordered_sum.h): while a sum
+// stays in one binade an add is INTEGER arithmetic on its mantissa that needs nothing of the sum so far but its parity, so a
+// block of kOsumBlock consecutive terms is reduced in parallel to a two-entry step, and the chain over the blocks is one 64-bit
+// integer add (to the double's bit pattern) per block; the binade a block's step is computed for is guessed from an
+// approximate prefix sum and CHECKED on the exact values when the blocks are chained -- the dozen blocks per sum that straddle
+// a power of two (and the first one) are added term by term, as before.  Four launches:
+//   osumBlockKernel<false>   per block and chain an approximate sum (any order), the D1 integers
+//   osumGuessKernel          per chain a prefix sum over the blocks' approximate sums -> the binade each block is expected in
+//   osumBlockKernel<true>    per block and chain the step of the block for that binade (in-order tree of compositions)
+//   osumChainKernel          per chain (one wavefront each) the walk over the blocks; out[0 .. 4] = the five sums of direction
+//                            A as doubles, out[5 .. 9] = of direction B
+// Option METRICS_SUMS=sequential: no block is trusted (every one is added term by term) -- the cross-check of the form, and
+// the test of its fallback.
+constexpr int kOsumBlock = 1024;  // terms per block: 256 threads x 4 consecutive terms
+struct OsumBufs {                 // chain = direction * 4 + column; entry [chain * nbMax + block]
+  double*             approx;
+  unsigned long long* d1;  // [direction * nbMax + block]
+  int*                expo;
+  osum::Step*         step;
+  uint32_t            nbA, nbB, nbMax;
+};
+
+template <bool kSteps>
+__global__ __launch_bounds__( 256 ) void osumBlockKernel( const double* __restrict__ termsA, uint32_t nA,
+                                                           const double* __restrict__ termsB, uint32_t nB, OsumBufs o ) {
+  const int      dir  = blockIdx.x >= o.nbA;
+  const uint32_t k    = dir ? blockIdx.x - o.nbA : blockIdx.x;
+  const double*  term = dir ? termsB : termsA;
+  const uint32_t n    = dir ? nB : nA;
+  const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long bits[4][4];  // [term of the thread][column]
+  unsigned long long d1 = 0;
 #pragma unroll
-        for ( int k = 0; k < 4; ++k ) col[k * kSumStride] = t[1 + k];
-      }
-      if ( a < nB ) {
-        const double* t = termsB + 5 * size_t( a );
-        d1B += (unsigned long long)t[0];
+  for ( int j = 0; j < 4; ++j ) {
+    const uint32_t a = k * uint32_t( kOsumBlock ) + 4u * threadIdx.x + uint32_t( j );
+    if ( a < n ) {
+      const double* t = term + 5 * size_t( a );
+      if ( !kSteps ) d1 += (unsigned long long)t[0];
 #pragma unroll
-        for ( int k = 0; k < 4; ++k ) col[( 4 + k ) * kSumStride] = t[1 + k];
-      }
+      for ( int c = 0; c < 4; ++c ) bits[j][c] = (unsigned long long)__double_as_longlong( t[1 + c] );
+    } else {
+#pragma unroll
+      for ( int c = 0; c < 4; ++c ) bits[j][c] = 0;
     }
-  };
-  if ( chunks && producer >= 0 ) fetch( 0, 0 );
-  __syncthreads();
-  for ( uint32_t c = 0; c < chunks; ++c ) {
-    const int slot = int( c & 1 );
-    if ( producer >= 0 ) {
-      if ( c + 1 < chunks ) fetch( c + 1, slot ^ 1 );
-    } else if ( threadIdx.x < 8 ) {
-      const uint32_t n     = threadIdx.x < 4 ? nA : nB, first = c * kSumChunk;
-      const uint32_t cnt   = first < n ? min( uint32_t( kSumChunk ), n - first ) : 0u;
-      const double*  col   = buf + ( size_t( slot ) * 8 + threadIdx.x ) * kSumStride;
-      const double2* pairs = reinterpret_cast<const double2*>( col );
-      uint32_t       j     = 0;
-      for ( ; j + 16 <= cnt; j += 16 ) {  // the loads ahead of the (dependent) adds
-        const double2 a = pairs[j / 2], b = pairs[j / 2 + 1], d = pairs[j / 2 + 2], e = pairs[j / 2 + 3];
-        const double2 f = pairs[j / 2 + 4], g = pairs[j / 2 + 5], h = pairs[j / 2 + 6], i2 = pairs[j / 2 + 7];
-        acc += a.x, acc += a.y, acc += b.x, acc += b.y, acc += d.x, acc += d.y, acc += e.x, acc += e.y;
-        acc += f.x, acc += f.y, acc += g.x, acc += g.y, acc += h.x, acc += h.y, acc += i2.x, acc += i2.y;
-      }
-      for ( ; j < cnt; ++j ) acc += col[j];
-    }
-    __syncthreads();  // chunk c is summed, chunk c + 1 is in its slot
   }
-  atomicAdd( &d1Total[0], d1A );
-  atomicAdd( &d1Total[1], d1B );
-  __syncthreads();
-  if ( threadIdx.x < 2 ) out[5 * threadIdx.x] = double( d1Total[threadIdx.x] );
-  if ( threadIdx.x < 8 ) out[5 * ( threadIdx.x / 4 ) + 1 + ( threadIdx.x & 3 )] = acc;
+  if ( !kSteps ) {
+    __shared__ double             sSum[4][4];
+    __shared__ unsigned long long sD1[4];
+    double v[4];
+#pragma unroll
+    for ( int c = 0; c < 4; ++c ) {
+      bool bad = false;
+      v[c]     = 0.0;
+#pragma unroll
+      for ( int j = 0; j < 4; ++j ) {
+        const unsigned long long b = bits[j][c];
+        bad |= ( ( b >> 63 ) && ( b << 1 ) ) || ( ( b >> 52 ) & 0x7FF ) == 0x7FF;  // negative or not finite: nothing the form covers
+        v[c] += __longlong_as_double( (long long)b );
+      }
+      if ( bad ) v[c] = __longlong_as_double( 0x7FF8000000000000ll );  // (a NaN: this block and the guesses behind it fall back)
+#pragma unroll
+      for ( int off = 32; off > 0; off >>= 1 ) v[c] += __shfl_xor( v[c], off, 64 );
+    }
+#pragma unroll
+    for ( int off = 32; off > 0; off >>= 1 ) d1 += __shfl_xor( d1, off, 64 );
+    if ( lane == 0 ) {
+#pragma unroll
+      for ( int c = 0; c < 4; ++c ) sSum[wave][c] = v[c];
+      sD1[wave] = d1;
+    }
+    __syncthreads();
+    if ( threadIdx.x < 4 )
+      o.approx[( size_t( dir ) * 4 + threadIdx.x ) * o.nbMax + k] =
+          ( sSum[0][threadIdx.x] + sSum[1][threadIdx.x] ) + ( sSum[2][threadIdx.x] + sSum[3][threadIdx.x] );
+    if ( threadIdx.x == 4 ) o.d1[size_t( dir ) * o.nbMax + k] = sD1[0] + sD1[1] + sD1[2] + sD1[3];
+  } else {
+    __shared__ osum::Step sStep[4][4];
+    __shared__ int        sBad[4];
+    if ( threadIdx.x < 4 ) sBad[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for ( int c = 0; c < 4; ++c ) {
+      const int E = o.expo[( size_t( dir ) * 4 + c ) * o.nbMax + k];  // (uniform over the workgroup)
+      if ( E < 1 ) continue;
+      osum::Step s{0ull, 0ull};
+      bool       ok = true;
+#pragma unroll
+      for ( int j = 0; j < 4; ++j ) {
+        osum::Step e;
+        ok &= osum::stepOf( bits[j][c], E, e );
+        s = osum::then( s, e );
+      }
+      if ( !ok ) sBad[c] = 1;
+      // in order: lane L takes [L, L + off) then [L + off, L + 2 off)
+#pragma unroll
+      for ( int off = 1; off < 64; off <<= 1 ) {
+        osum::Step p;
+        p.d0 = __shfl_down( s.d0, off, 64 );
+        p.d1 = __shfl_down( s.d1, off, 64 );
+        if ( ( lane & ( 2 * off - 1 ) ) == 0 ) s = osum::then( s, p );
+      }
+      if ( lane == 0 ) sStep[wave][c] = s;
+    }
+    __syncthreads();
+    if ( threadIdx.x < 4 ) {
+      const int    c  = threadIdx.x;
+      const size_t at = ( size_t( dir ) * 4 + c ) * o.nbMax + k;
+      if ( o.expo[at] >= 1 ) {
+        if ( sBad[c] )
+          o.expo[at] = osum::kExpUnsafe;
+        else
+          o.step[at] = osum::then( osum::then( sStep[0][c], sStep[1][c] ), osum::then( sStep[2][c], sStep[3][c] ) );
+      }
+    }
+  }
+}
+
+// one wavefront per chain: prefix sums of the blocks' approximate sums, 64 blocks at a time
+__global__ __launch_bounds__( 64 ) void osumGuessKernel( OsumBufs o, int trustNothing ) {
+  const uint32_t chain = blockIdx.x, nb = ( chain >> 2 ) ? o.nbB : o.nbA;
+  const int      lane  = threadIdx.x;
+  double         carry = 0.0;
+  for ( uint32_t k0 = 0; k0 < nb; k0 += 64 ) {
+    const uint32_t k = k0 + uint32_t( lane );
+    const double   v = k < nb ? o.approx[size_t( chain ) * o.nbMax + k] : 0.0;
+    double         incl = v;
+#pragma unroll
+    for ( int off = 1; off < 64; off <<= 1 ) {
+      const double t = __shfl_up( incl, off, 64 );
+      if ( lane >= off ) incl += t;
+    }
+    double excl = __shfl_up( incl, 1, 64 );
+    if ( lane == 0 ) excl = 0.0;
+    const double lo = carry + excl, hi = carry + incl;  // (approximate on purpose: the chain checks the guess on the exact values)
+    if ( k < nb ) o.expo[size_t( chain ) * o.nbMax + k] = trustNothing ? osum::kExpUnsafe : ( v == 0.0 ? osum::kExpIdentity : osum::guessExponent( lo, hi ) );
+    carry += __shfl( incl, 63, 64 );
+  }
+}
+
+// one wavefront per chain, every lane on the same walk (what is sequential costs a wavefront the same on one lane or on all)
+__global__ __launch_bounds__( 64 ) void osumChainKernel( const double* __restrict__ termsA, uint32_t nA,
+                                                          const double* __restrict__ termsB, uint32_t nB, OsumBufs o,
+                                                          double* __restrict__ out, uint32_t* __restrict__ fallbacks ) {
+  __shared__ double buf[kOsumBlock];
+  const uint32_t    chain = blockIdx.x, dir = chain >> 2, col = chain & 3;
+  const uint32_t    nb = dir ? o.nbB : o.nbA, n = dir ? nB : nA;
+  const double*     term = ( dir ? termsB : termsA ) + 1 + col;
+  const int         lane = threadIdx.x;
+  unsigned long long sum = 0;  // the bit pattern of the sum so far
+  uint32_t           fb  = 0;
+  for ( uint32_t k0 = 0; k0 < nb; k0 += 64 ) {
+    const uint32_t k   = k0 + uint32_t( lane );
+    const size_t   at  = size_t( chain ) * o.nbMax + k;
+    const int      myE = k < nb ? o.expo[at] : osum::kExpIdentity;
+    osum::Step     mine{0ull, 0ull};
+    if ( k < nb && myE >= 1 ) mine = o.step[at];
+    const uint32_t cnt = min( 64u, nb - k0 );
+    for ( uint32_t j = 0; j < cnt; ++j ) {
+      const int  E = __shfl( myE, int( j ), 64 );
+      osum::Step st;
+      st.d0 = __shfl( mine.d0, int( j ), 64 );
+      st.d1 = __shfl( mine.d1, int( j ), 64 );
+      if ( osum::apply( sum, st, E ) ) continue;
+      // the block as the reference adds it
+      ++fb;
+      const uint32_t first = ( k0 + j ) * uint32_t( kOsumBlock ), terms = min( uint32_t( kOsumBlock ), n - first );
+      __syncthreads();
+      for ( uint32_t e = uint32_t( lane ); e < terms; e += 64 ) buf[e] = term[5 * size_t( first + e )];
+      __syncthreads();
+      double   acc = __longlong_as_double( (long long)sum );
+      uint32_t e   = 0;
+      for ( ; e + 8 <= terms; e += 8 ) {  // the loads ahead of the (dependent) adds
+        const double2 a = *reinterpret_cast<const double2*>( buf + e ), b = *reinterpret_cast<const double2*>( buf + e + 2 );
+        const double2 c = *reinterpret_cast<const double2*>( buf + e + 4 ), d = *reinterpret_cast<const double2*>( buf + e + 6 );
+        acc += a.x, acc += a.y, acc += b.x, acc += b.y, acc += c.x, acc += c.y, acc += d.x, acc += d.y;
+      }
+      for ( ; e < terms; ++e ) acc += buf[e];
+      sum = (unsigned long long)__double_as_longlong( acc );
+    }
+  }
+  if ( lane == 0 ) {
+    out[5 * dir + 1 + col] = __longlong_as_double( (long long)sum );
+    if ( fallbacks ) fallbacks[chain] = fb;
+  }
+  if ( col == 0 ) {  // D1: integers
+    unsigned long long d1 = 0;
+    for ( uint32_t k = uint32_t( lane ); k < nb; k += 64 ) d1 += o.d1[size_t( dir ) * o.nbMax + k];
+#pragma unroll
+    for ( int off = 32; off > 0; off >>= 1 ) d1 += __shfl_xor( d1, off, 64 );
+    if ( lane == 0 ) out[5 * dir] = double( d1 );
+  }
+}
+
+// the eight ordered sums + the two integer ones of termsA[nA][5] / termsB[nB][5] -> out[10] (device)
+int orderedSums( tmc2_ctx* ctx, const double* termsA, uint32_t nA, const double* termsB, uint32_t nB, double* out ) {
+  hipStream_t s = ctx->stream;
+  OsumBufs    o{};
+  o.nbA = ( nA + kOsumBlock - 1 ) / kOsumBlock, o.nbB = ( nB + kOsumBlock - 1 ) / kOsumBlock, o.nbMax = std::max( 1u, std::max( o.nbA, o.nbB ) );
+  DevBuf<double>             d_approx;
+  DevBuf<unsigned long long> d_d1, d_step;
+  DevBuf<uint32_t>           d_expo;
+  TMC2_TRY( d_approx.alloc( 8 * size_t( o.nbMax ) ) );
+  TMC2_TRY( d_d1.alloc( 2 * size_t( o.nbMax ) ) );
+  TMC2_TRY( d_step.alloc( 16 * size_t( o.nbMax ) ) );
+  TMC2_TRY( d_expo.alloc( 8 * size_t( o.nbMax ) ) );
+  o.approx = d_approx.p, o.d1 = d_d1.p, o.expo = reinterpret_cast<int*>( d_expo.p ), o.step = reinterpret_cast<osum::Step*>( d_step.p );
+  const char* form         = ctxOption( ctx, "METRICS_SUMS" );
+  const int   trustNothing = form && form[0] == 's';
+  if ( o.nbA + o.nbB ) hipLaunchKernelGGL( osumBlockKernel<false>, dim3( o.nbA + o.nbB ), dim3( 256 ), 0, s, termsA, nA, termsB, nB, o );
+  hipLaunchKernelGGL( osumGuessKernel, dim3( 8 ), dim3( 64 ), 0, s, o, trustNothing );
+  if ( ( o.nbA + o.nbB ) && !trustNothing ) hipLaunchKernelGGL( osumBlockKernel<true>, dim3( o.nbA + o.nbB ), dim3( 256 ), 0, s, termsA, nA, termsB, nB, o );
+  DevBuf<uint32_t> d_fb;  // (test hook: the blocks added term by term, per chain)
+  if ( ctxOption( ctx, "METRICS_SUMS_DEBUG" ) ) TMC2_TRY( d_fb.alloc( 8 ) );
+  uint32_t* d_fallbacks = d_fb.p;
+  hipLaunchKernelGGL( osumChainKernel, dim3( 8 ), dim3( 64 ), 0, s, termsA, nA, termsB, nB, o, out, d_fallbacks );
+  if ( d_fallbacks ) {
+    uint32_t fb[8];
+    TMC2_HIP( hipMemcpyAsync( fb, d_fallbacks, sizeof( fb ), hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipStreamSynchronize( s ) );
+    fprintf( stderr, "ordered sums: %u + %u blocks, added term by term per chain: %u %u %u %u | %u %u %u %u\n", o.nbA, o.nbB, fb[0], fb[1], fb[2],
+             fb[3], fb[4], fb[5], fb[6], fb[7] );
+  }
+  return TMC2_OK;
 }
 
 double psnr( double dist, double p, double factor ) { return 10 * std::log10( ( factor * p * p ) / dist ); }
@@ -591,10 +753,7 @@ int metricsDevice( tmc2_ctx* ctx, const CloudView& src, const CloudView& rec, co
     TMC2_TRY( qualityTerms( ctx, dS, dR, withNormals, K, d_termsS, d_error.p ) );
     TMC2_TRY( qualityTerms( ctx, dR, dS, withNormals, K, d_termsR, d_error.p ) );
     const int    sid = ctx->stageBegin( "metrics_sums" );
-    const size_t lds = size_t( 2 ) * 8 * kSumStride * sizeof( double );
-    TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( orderedSumsKernel ), lds, ctx->device ) );
-    hipLaunchKernelGGL( orderedSumsKernel, dim3( 1 ), dim3( 1024 ), lds, s, d_termsS.p, uint32_t( dS.n ), d_termsR.p, uint32_t( dR.n ),
-                        d_sums.p );
+    TMC2_TRY( orderedSums( ctx, d_termsS.p, uint32_t( dS.n ), d_termsR.p, uint32_t( dR.n ), d_sums.p ) );
     ctx->stageEnd( sid );
     double   sse[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t err     = 0;
@@ -697,6 +856,29 @@ extern "C" int tmc2_metrics_compute( tmc2_ctx* ctx, const int16_t* srcXyz, const
   TMC2_TRY( src.put( ctx, srcXyz, srcRgb, n, srcNormals, vs ) );
   TMC2_TRY( rec.put( ctx, recXyz, recRgb, m, nullptr, vr ) );
   return metricsBothWidths( ctx, vs, vr, srcNormals ? src.nrm.p : nullptr, resolution, out, counts );
+}
+
+extern "C" int tmc2_metrics_ordered_sums( tmc2_ctx* ctx, const double* termsA, uint64_t nA, const double* termsB, uint64_t nB, double* out ) {
+  using namespace tmc2;
+  if ( !ctx || !out || ( nA && !termsA ) || ( nB && !termsB ) || nA > 0x7FFFFFFFull || nB > 0x7FFFFFFFull ) {
+    setError( "metrics_ordered_sums: invalid argument (null pointer or more than 2^31 - 1 terms)" );
+    return TMC2_E_INVALID;
+  }
+  ApiScope       scope( ctx );
+  hipStream_t    s = ctx->stream;
+  DevBuf<double> d_a, d_b, d_out;
+  TMC2_TRY( d_a.alloc( std::max<size_t>( 5 * size_t( nA ), 1 ) ) );
+  TMC2_TRY( d_b.alloc( std::max<size_t>( 5 * size_t( nB ), 1 ) ) );
+  TMC2_TRY( d_out.alloc( 16 ) );
+  if ( nA ) TMC2_HIP( hipMemcpyAsync( d_a.p, termsA, 5 * size_t( nA ) * sizeof( double ), hipMemcpyHostToDevice, s ) );
+  if ( nB ) TMC2_HIP( hipMemcpyAsync( d_b.p, termsB, 5 * size_t( nB ) * sizeof( double ), hipMemcpyHostToDevice, s ) );
+  const int sid = ctx->stageBegin( "metrics_sums" );
+  TMC2_TRY( orderedSums( ctx, d_a.p, uint32_t( nA ), d_b.p, uint32_t( nB ), d_out.p ) );
+  ctx->stageEnd( sid );
+  TMC2_HIP( hipMemcpyAsync( out, d_out.p, 10 * sizeof( double ), hipMemcpyDeviceToHost, s ) );
+  TMC2_HIP( hipStreamSynchronize( s ) );
+  TMC2_HIP( hipGetLastError() );
+  return TMC2_OK;
 }
 
 extern "C" int tmc2_metrics_compute_frame( tmc2_frame* f, int which, int useNormals, double resolution, double* out, int64_t* counts ) {

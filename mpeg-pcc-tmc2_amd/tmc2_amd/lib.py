@@ -328,6 +328,15 @@ class Context:
                                            None if nm is None else _ptr(nm), C.c_double(resolution), _ptr(out), _ptr(counts)))
         return out, counts
 
+    def metrics_ordered_sums(self, terms_a, terms_b):
+        """The ordered sums of per-point terms [n][5] (tmc2_metrics_ordered_sums): out[10], five per direction."""
+        a = np.ascontiguousarray(terms_a, np.float64).reshape(-1, 5)
+        b = np.ascontiguousarray(terms_b, np.float64).reshape(-1, 5)
+        out = np.zeros(10, np.float64)
+        _check(self.L.tmc2_metrics_ordered_sums(self.h, _ptr(a) if len(a) else None, C.c_uint64(len(a)),
+                                                _ptr(b) if len(b) else None, C.c_uint64(len(b)), _ptr(out)))
+        return out
+
 
 class Frame:
     """Device-resident state of one point-cloud frame (tmc2_frame)."""

@@ -129,3 +129,50 @@ def test_gpu_metrics_on_the_resident_frame(gpu_ctx, oracle):
     got, gc = fr.metrics_compute(1, True)
     exp, ec = oracle.metrics(xyz, rgb, post["xyz"], post["rgb"], nrm)
     assert np.array_equal(gc, ec) and np.array_equal(bits(got), bits(exp)), (got, exp)
+
+
+def _ordered(t):
+    """The reference's loop `sse += dist` over one column: numpy's accumulate adds in index order (tests/test_ordered_sum.py
+    checks it against the plain C loop)."""
+    return np.cumsum(t)[-1] if len(t) else 0.0
+
+
+def _terms(rng, n, kind):
+    from test_ordered_sum import term_families
+    t = np.zeros((n, 5))
+    t[:, 0] = rng.integers(0, 50, n)
+    fams = [term_families(rng, n) for _ in range(4)]
+    names = sorted(k for k in fams[0] if k != "negative")
+    for c in range(4):
+        t[:, 1 + c] = fams[c][kind if kind != "mixed" else names[(c * 5 + n) % len(names)]]
+    return t
+
+
+@pytest.mark.parametrize("na,nb", [(0, 1), (1, 0), (5, 1023), (1024, 1025), (4096, 100003), (948_123, 833_077), (3_031_415, 2_900_001)])
+def test_gpu_ordered_sums_are_the_loop(gpu_ctx, ctx_options, na, nb):
+    """tmc2_metrics_ordered_sums: eight ordered fp64 sums evaluated block-wise in integer arithmetic (csrc/ordered_sum.h) = the
+    loop, bit for bit, on terms that are ties, zeros, cross binades at every scale; and the same with no block trusted
+    (METRICS_SUMS=sequential: every block through the term-by-term fallback)."""
+    rng = np.random.default_rng(na * 7 + nb)
+    kinds = ["mixed", "colour", "ties", "wide"] if max(na, nb) < 2_000_000 else ["mixed", "tenth"]
+    for kind in kinds:
+        a, b = _terms(rng, na, kind), _terms(rng, nb, kind)
+        exp = np.array([_ordered(a[:, c]) for c in range(5)] + [_ordered(b[:, c]) for c in range(5)])
+        got = gpu_ctx.metrics_ordered_sums(a, b)
+        assert np.array_equal(bits(got), bits(exp)), (kind, got, exp)
+        if max(na, nb) <= 100003:
+            ctx_options.setenv("TMC2_METRICS_SUMS", "sequential")
+            got = gpu_ctx.metrics_ordered_sums(a, b)
+            ctx_options.delenv("TMC2_METRICS_SUMS")
+            assert np.array_equal(bits(got), bits(exp)), (kind, "sequential", got, exp)
+
+
+def test_gpu_ordered_sums_negative_terms_fall_back(gpu_ctx):
+    """Not a case of the metric (its terms are squares): a block with a negative term is added as the loop adds it."""
+    rng = np.random.default_rng(5)
+    a = rng.random((20000, 5))
+    a[:, 0] = 1.0
+    a[7777, 2] = -0.5
+    a[12001, 4] = -3.0
+    exp = np.array([_ordered(a[:, c]) for c in range(5)] + [0.0] * 5)
+    assert np.array_equal(bits(gpu_ctx.metrics_ordered_sums(a, np.zeros((0, 5)))), bits(exp))
