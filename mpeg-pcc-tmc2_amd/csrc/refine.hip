@@ -997,7 +997,7 @@ __global__ __launch_bounds__( 1024 ) void closureKernel( const uint8_t* __restri
       x = __shfl( x, 0, 32 );
       if ( x == kNoVoxel ) {
         if ( pending == 0 ) break;  // nothing in the ring, nobody hopping: nothing can turn up any more
-        __builtin_amdgcn_s_sleep( 2 );
+        __builtin_amdgcn_s_sleep( 2 );  // (longer naps -- 4 x, 16 x -- measured: nothing, profiles/r06_knobs_in_flight.txt)
         continue;
       }
     }
@@ -1470,7 +1470,10 @@ int RefineJob::finish() {
   const char*    gridEnv    = ctxOption( ctx, "REFINE_CLOSURE_BLOCKS" );
   const char*    threadsEnv = ctxOption( ctx, "REFINE_CLOSURE_THREADS" );
   const char*    ringEnv    = ctxOption( ctx, "REFINE_RING" );
-  const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : 512;
+  // (round 6, sixteen in flight, this round's kernels around it -- profiles/r06_knobs_in_flight.txt: two workgroups per CU of 512 /
+  //  256 / 128 threads -> 186.2-188.4 / 191.3-192.4 / 187.5 frames/s; one per CU of 256: 190.4; four of 256: 190.0 -- half the
+  //  idle waves of rounds 3-5 for the many-in-flight regime, the walk's deepest chain is what a launch takes either way)
+  const int      closureThreads = threadsEnv ? std::min( 1024, std::max( 64, atoi( threadsEnv ) & ~63 ) ) : ( refineOverlap( ctx ) ? 512 : 256 );
   const uint32_t perGroup   = 4;  // voxels of the run per 32-lane group
   const uint32_t wantGrid   = gridEnv ? uint32_t( std::max( 1, atoi( gridEnv ) ) )
                                       : std::min<uint32_t>( ( refineOverlap( ctx ) ? 4u : 2u ) * uint32_t( ctx->cuCount ),
@@ -1484,13 +1487,15 @@ int RefineJob::finish() {
   if ( closureLds > 48 * 1024 ) TMC2_TRY( allowLargeLds( reinterpret_cast<const void*>( closureKernel ), closureLds, ctx->device ) );
   // (test hook TMC2_REFINE_SWEEP_BLOCKS: the sweep kernel's grid)
   const char* sweepGridEnv = ctxOption( ctx, "REFINE_SWEEP_BLOCKS" );
-  const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap( ctx ) ? 8 : 4 ) * ctx->cuCount ) ) );
+  const dim3  grdSweep( uint32_t( std::min<size_t>( ( size_t( V ) + 15 ) / 16, sweepGridEnv ? size_t( std::max( 1, atoi( sweepGridEnv ) ) ) : size_t( refineOverlap( ctx ) ? 8 : 2 ) * ctx->cuCount ) ) );
   // (tmc2_set_refine_overlap( 1 ) = "few frames in flight": the chip has room, so both kernels of a sweep take the grids that
   //  are fastest with the GPU to themselves -- four closure workgroups and eight sweep workgroups per CU)
   // (round 4 sweep over the grids, 16 frames in flight / one sweep alone: sweep kernel 2 / 4 / 8 / 16 workgroups per CU ->
   //  loot 109.0 / 108.1 / 107.1 / 106.6 frames/s, 338 / 327 / 305 / 289 us; longdress 174.1 / 174.9 frames/s, 54.8 / 51.9 us;
   //  closure 1 / 2 / 4 / 8 per CU -> loot 109.3 / 109.0 / 107.8 / 107.1 frames/s, 434 / 338 / 308 / 291 us: all within
-  //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure)
+  //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure;
+  //  round 6, three rounds alternating with the closure at two workgroups of 256 per CU: sweep kernel 4 / 2 / 1 per CU ->
+  //  longdress 189.2 / 191.7 / 191.8 frames/s -- two per CU)
   const bool wantTrace = ctxOption( ctx, "REFINE_TRACE" ) != nullptr;
   DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
   const bool                 wantTiming = ctxOption( ctx, "REFINE_TIMING" ) != nullptr;
