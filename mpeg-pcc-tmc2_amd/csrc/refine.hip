@@ -301,7 +301,10 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
     }
   }
   if ( cand > CAP - 160 ) {  // more occupied cells than this instantiation has room for: the host repeats with a larger one
-    if ( lane == 0 ) atomicMax( overflow, 3u );  // (atomic like every other writer of this word; the fatal code is the largest)
+    if ( lane == 0 ) {
+      atomicMax( overflow, 3u );  // (atomic like every other writer of this word; the fatal code is the largest)
+      atomicMax( overflow + 2, uint32_t( cand ) );  // (... and which one: the room the fullest ball asks for)
+    }
     cand = CAP - 160;
   }
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
@@ -535,6 +538,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   int P = 64;
   while ( P < hits ) P <<= 1;
   if ( partial ) P = 0;  // (nothing left to sort)
+  if ( P > CAP ) {  // (the instantiations between the powers of two: a row that does not fit the padded sort goes one tier up)
+    if ( lane == 0 ) {
+      atomicMax( overflow, 3u );
+      atomicMax( overflow + 2, uint32_t( CAP - 159 ) );
+    }
+    P = 0, hits = 0;
+  }
   for ( int i = hits + lane; i < P; i += 64 ) keys[i] = 0xFFFFFFFFu;
   __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
   for ( int k = 2; k <= P; k <<= 1 ) {
@@ -1167,7 +1177,7 @@ struct RefineJob {
   int              capTier = 2;  // which instantiation of the neighbourhood kernels (launchNeighbourhood)
   size_t           Vp = 0, W2 = 0, ball = 0, perVoxel = 0;
   uint64_t         capacity = 0;
-  uint32_t         res[2] = {0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag
+  uint32_t         res[4] = {0, 0, 0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag, reverse row entries, room asked for
   DevBuf<uint32_t> d_key, d_flag, d_vid, d_small, d_count, d_rowLen, d_devLen, d_adjOff, d_hist, d_activeBuf, d_pointStart,
       d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev, d_lastKey, d_roffG, d_rlenG, d_radjG,
       d_voxelOfRank;
@@ -1192,8 +1202,20 @@ RefineJob::~RefineJob() {
   }
 }
 
+// The instantiations of the neighbourhood kernels: keys of LDS room per wavefront (160 of them the kernel's own), wavefronts
+// per workgroup.  32 KB / 20 KB / 24 KB / 32 KB / 32 KB per workgroup -> 8 / 8 / 6 / 5 / 2.5 wavefronts per SIMD.  Round 6: the
+// tiers of 1280 and 1536 keys -- voxels of 2 on a surface (472 occupied cells of the ball's 3 911 on average, ~ 1 080 at most)
+// ran in the 2048 tier at 5 wavefronts per SIMD, and the pass is bound by the latency of its dependent loads.
+constexpr int kCapTiers[5] = {1024, 1280, 1536, 2048, 4096};
+constexpr int kLastCapTier = 4;
+inline int capTierFor( size_t cells ) {  // the smallest tier whose room holds `cells` keys
+  int t = 0;
+  while ( t < kLastCapTier && size_t( kCapTiers[t] - 160 ) < cells ) ++t;
+  return t;
+}
+
 // forward rows and -- on the row-wise path -- the reverse rows behind them (d_small: [1] row cursor, [2] overflow, [3] reverse
-// row cursor)
+// row cursor, [4] with overflow code 3: the room the fullest ball asks for)
 void RefineJob::launchNeighbourhood() {
   const int nBall = int( offsets.size() );  // rows or cells
 #define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
@@ -1207,14 +1229,14 @@ void RefineJob::launchNeighbourhood() {
                       bits, g, V, d_offsets, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
                       d_small.p + 3, d_small.p + 2 )
   // LDS per wavefront = room for the ball's OCCUPIED cells (row-wise form; a surface fills 5-10 % of a ball) or for all its
-  // cells; the smaller the room, the more wavefronts a CU holds (1024: 8 per SIMD, 4096: 2.5) -- a frame whose balls need more
-  // raises the overflow word to 3 and is repeated one tier up (the tier that worked is remembered per context)
-  if ( capTier == 0 ) {
-    TMC2_NEIGHBOURHOOD( 1024, 8 );
-  } else if ( capTier == 1 ) {
-    TMC2_NEIGHBOURHOOD( 2048, 4 );
-  } else {
-    TMC2_NEIGHBOURHOOD( 4096, 2 );
+  // cells; the smaller the room, the more wavefronts a CU holds (kCapTiers) -- a frame whose balls need more raises the overflow
+  // word to 3, says how much, and is repeated in the tier that holds it (remembered per context)
+  switch ( capTier ) {
+    case 0: TMC2_NEIGHBOURHOOD( 1024, 8 ); break;
+    case 1: TMC2_NEIGHBOURHOOD( 1280, 4 ); break;
+    case 2: TMC2_NEIGHBOURHOOD( 1536, 4 ); break;
+    case 3: TMC2_NEIGHBOURHOOD( 2048, 4 ); break;
+    default: TMC2_NEIGHBOURHOOD( 4096, 2 ); break;
   }
 #undef TMC2_NEIGHBOURHOOD
 }
@@ -1346,7 +1368,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
                                {d_hist.p, size_t( V ) * 16, 0},
                                {d_state.p, Vp * 2, 0},
                                {d_cursor.p, size_t( V ) * 4, 0},
-                               {d_small.p + 1, 12, 0},  // [1] row cursor, [2] overflow, [3] reverse row cursor
+                               {d_small.p + 1, 16, 0},  // [1] row cursor, [2] overflow, [3] reverse row cursor, [4] room asked for
                                {d_flags.p, ( 2 * size_t( iterationCount ) + 2 ) * 4, 0},
                                {d_rcount.p, ( size_t( V ) + 1 ) * 4, 0},
                                {d_rcursor.p, ( size_t( V ) + 1 ) * 4, 0},
@@ -1382,9 +1404,9 @@ int RefineJob::geometry( tmc2_frame* f ) {
     setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
     return TMC2_E_UNSUPPORTED;
   }
-  capTier = ball <= 2048 - 160 ? 1 : 2;
+  capTier = std::max( capTierFor( ball ), 3 );  // (the cell-by-cell form keeps every cell of the ball: the tiers of rounds 4-5)
   if ( byRows ) capTier = std::min( capTier, std::max( 0, ctx->refineCapTier ) );  // (test hook TMC2_REFINE_CAPTIER: start there)
-  if ( const char* tierEnv = ctxOption( ctx, "REFINE_CAPTIER" ) ) capTier = std::min( 2, std::max( byRows ? 0 : capTier, atoi( tierEnv ) ) );
+  if ( const char* tierEnv = ctxOption( ctx, "REFINE_CAPTIER" ) ) capTier = std::min( kLastCapTier, std::max( byRows ? 0 : capTier, atoi( tierEnv ) ) );
   TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
   if ( byRows ) {  // the reverse rows hold the same entries as the forward rows: same room
     TMC2_TRY( d_lastKey.alloc( V ) );
@@ -1393,7 +1415,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
     TMC2_TRY( d_radjG.alloc( size_t( capacity ) ) );
   }
   launchNeighbourhood();
-  TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );  // (read in finish(), after a synchronisation)
+  TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 16, hipMemcpyDeviceToHost, s ) );  // (read in finish(), after a synchronisation)
   ctx->stageEnd( sidSetup );
   TMC2_HIP( hipGetLastError() );
   return TMC2_OK;
@@ -1416,12 +1438,12 @@ int RefineJob::finish() {
     totalLen = res[0];
     if ( ctxOption( ctx, "REFINE_DEBUG" ) ) fprintf( stderr, "refine: neighbourhood attempt %d tier %d: %u row entries, overflow word %u (V = %u)\n", attempt, capTier, res[0], res[1], V );
     if ( res[1] == 0 ) break;
-    if ( ( res[1] != 1 && res[1] != 3 ) || attempt > 3 || ( res[1] == 3 && capTier >= 2 ) ) {
+    if ( ( res[1] != 1 && res[1] != 3 ) || attempt > 3 || ( res[1] == 3 && capTier >= kLastCapTier ) ) {
       setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
       return TMC2_E_HIP;
     }
     if ( res[1] == 3 ) {  // balls with more occupied cells than the instantiation holds: one tier up, for this context's next frames too
-      ++capTier;
+      capTier            = std::max( capTier + 1, capTierFor( res[3] ) );
       ctx->refineCapTier = capTier;
       ctx->stageAddHostMs( "refine_cap_tier_repeat", 0.0 );
     } else {
@@ -1434,9 +1456,9 @@ int RefineJob::finish() {
     }
     TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
     if ( byRows ) TMC2_TRY( d_radjG.alloc( size_t( capacity ) ) );
-    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 12, s ) );  // [1] row cursor, [2] overflow, [3] reverse row cursor
+    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 16, s ) );  // [1] row cursor, [2] overflow, [3] reverse row cursor, [4] room asked for
     launchNeighbourhood();
-    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 8, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 16, hipMemcpyDeviceToHost, s ) );
   }
   hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table, bits );
   tableFilled = false;

@@ -243,7 +243,7 @@ def test_gpu_refine_key_aliasing(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("vox_dim", [4, 2])
-@pytest.mark.parametrize("form", ["cells", "rows-tier1", "rows-tier2"])
+@pytest.mark.parametrize("form", ["cells", "rows-tier1", "rows-tier2", "rows-tier3", "rows-tier4"])
 def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, ctx_options, vox_dim, form):
     """S5's neighbourhood rows two ways -- row-wise through the occupancy bitmap with gathered reverse rows (round 4, default)
     and cell by cell with scattered reverse rows (rounds 1-3, TMC2_REFINE_NEIGHBOURHOOD=cells) -- and in every LDS tier of the
@@ -269,8 +269,9 @@ def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, ctx_options, vox_dim, f
 @pytest.mark.parametrize("vox_dim", [4, 2])
 def test_gpu_refine_solid_cloud_takes_the_larger_tier(oracle, vox_dim):
     """A SOLID block fills its balls (1 357 / 3 911 occupied cells a voxel): more than the smallest instantiation of the row-wise
-    neighbourhood kernels holds in LDS -- the frame is repeated one tier up (twice for voxels of 2), the context remembers, and
-    the result is the reference's."""
+    neighbourhood kernels holds in LDS -- the overflow says how much room the fullest ball asks for, the frame is repeated ONCE in
+    the tier that holds it (1 536 keys for voxels of 4, 4 096 for voxels of 2), the context remembers, and the result is the
+    reference's."""
     ctx = T.Context(0)                                                # (its own context: the tier is remembered per context)
     side = 60 if vox_dim == 4 else 40
     g = np.arange(side, dtype=np.int16)
@@ -288,7 +289,7 @@ def test_gpu_refine_solid_cloud_takes_the_larger_tier(oracle, vox_dim):
         fr.segmenter_refine_grid_based(1024, 3.0, 3, vox_dim, 192)
         assert np.array_equal(fr.get_partition(), exp), attempt
         repeats = ctx.stage_calls().get("refine_cap_tier_repeat", 0)
-        assert repeats == ((1 if vox_dim == 4 else 2) if attempt == 0 else 0), (attempt, repeats)
+        assert repeats == (1 if attempt == 0 else 0), (attempt, repeats)
         fr.close()
     ctx.close()
 
