@@ -561,16 +561,18 @@ __global__ __launch_bounds__( 64 ) void osumChainKernel( const double* __restric
     const int      myE = k < nb ? o.expo[at] : osum::kExpIdentity;
     osum::Step     mine{0ull, 0ull};
     if ( k < nb && myE >= 1 ) mine = o.step[at];
-    const uint32_t cnt = min( 64u, nb - k0 );
-    for ( uint32_t j = 0; j < cnt; ++j ) {
-      const int  E = __shfl( myE, int( j ), 64 );
+    // (fully unrolled: lane j's record through v_readlane with a constant lane -- scalar registers, no LDS crossbar; blocks past
+    //  the end read as identities)
+#pragma unroll
+    for ( int j = 0; j < 64; ++j ) {
+      const int  E = __builtin_amdgcn_readlane( myE, j );
       osum::Step st;
-      st.d0 = __shfl( mine.d0, int( j ), 64 );
-      st.d1 = __shfl( mine.d1, int( j ), 64 );
+      st.d0 = ( (unsigned long long)(uint32_t)__builtin_amdgcn_readlane( int( mine.d0 >> 32 ), j ) << 32 ) | (uint32_t)__builtin_amdgcn_readlane( int( mine.d0 ), j );
+      st.d1 = ( (unsigned long long)(uint32_t)__builtin_amdgcn_readlane( int( mine.d1 >> 32 ), j ) << 32 ) | (uint32_t)__builtin_amdgcn_readlane( int( mine.d1 ), j );
       if ( osum::apply( sum, st, E ) ) continue;
       // the block as the reference adds it
       ++fb;
-      const uint32_t first = ( k0 + j ) * uint32_t( kOsumBlock ), terms = min( uint32_t( kOsumBlock ), n - first );
+      const uint32_t first = ( k0 + uint32_t( j ) ) * uint32_t( kOsumBlock ), terms = min( uint32_t( kOsumBlock ), n - first );
       __syncthreads();
       for ( uint32_t e = uint32_t( lane ); e < terms; e += 64 ) buf[e] = term[5 * size_t( first + e )];
       __syncthreads();
