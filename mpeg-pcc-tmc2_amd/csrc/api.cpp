@@ -308,7 +308,7 @@ int tmc2_ctx_reserve( tmc2_ctx* ctx, uint64_t maxPoints, int voxelDimRefine, int
     return TMC2_E_INVALID;
   }
   tmc2::ApiScope scope( ctx );
-  const uint64_t perPoint = voxelDimRefine > 0 && voxelDimRefine <= 2 ? 4600 : 2100;
+  const uint64_t perPoint = voxelDimRefine > 0 && voxelDimRefine <= 2 ? 5500 : 2400;  // (round 6: + the balls' hits kept between S5's two passes, 640 keys per voxel)
   const int      gridShift = std::max( 1, bits3d - 1 - ( voxelDimRefine >= 4 ? 2 : ( voxelDimRefine >= 2 ? 1 : 0 ) ) );
   const uint64_t dense     = ( uint64_t( 1 ) << std::min( 33, 3 * gridShift + 1 ) ) / 32 * 8;  // uint2 per 32 keys
   const uint64_t bytes     = maxPoints * perPoint + uint64_t( maxCanvasWidth ) * uint64_t( maxCanvasHeight ) * 64 + dense + ( uint64_t( 64 ) << 20 );

@@ -261,6 +261,7 @@ struct tmc2_ctx {
   tmc2::DevBuf<uint32_t>        gridTable;       // persistent dense voxel-key table (kept all-ones between uses)
   tmc2::DevBuf<uint2>           gridBits;        // its occupancy, .x: one bit per key (kept all-zero between uses: S5 probes ball rows in it), .y: occupied keys below the word
   int                           refineCapTier = 0;  // the smallest neighbourhood-kernel instantiation that held this context's last frames
+  uint32_t                      refineHitsPerVoxel = 640;  // room per voxel for the balls' hits kept between S5's two passes over the balls (grows when a frame runs out)
   tmc2::DevBuf<unsigned long long> scanState;    // look-back state of exclusiveScanU32: [0] tile tickets, [1 + t] tile t (epoch-tagged)
   uint32_t                      scanEpoch = 0, scanTickets = 0;
   tmc2::DevBuf<uint32_t>        voxelBitmap;     // dense 3-D occupancy bitmap of the resampled cloud (S9)

@@ -237,6 +237,24 @@ __global__ __launch_bounds__( 256 ) void initVoxelStateKernel( const uint4* __re
   active[v] = e != NO_EDGE;
 }
 
+// The hits of every voxel's ball, kept between the two passes over the balls (round 6): kHitRegions regions with their own
+// cursors (128 bytes apart), a wavefront reserves room for its voxel's hits in the region of its workgroup.
+constexpr uint32_t kHitRegions = 64;
+// The rows (forward, reverse) likewise: kRowRegions regions of the row tables with their own cursors, ONE reservation per
+// wavefront.  Rounds 1-5 reserved per workgroup on ONE word: 65 K workgroups (voxels of 2, four wavefronts each) x ~ 11 ns per
+// returning atomic on one address = 0.72 ms -- the reverse rows kernel's whole 0.77 ms and half of the forward kernel's 1.3
+// (tools/gpu/r6/call34.sh: the instantiation with eight wavefronts per workgroup, half the reservations, took 0.44 ms) -- with
+// two barriers around it that made every wavefront of a workgroup wait for its slowest.  Sixteen consecutive voxels share a region.
+constexpr uint32_t kRowRegions = 128;
+__device__ __forceinline__ uint32_t rowRegionOf( uint32_t v ) { return ( v >> 4 ) & ( kRowRegions - 1u ); }
+struct BallHits {
+  uint32_t* buf;        // [kHitRegions][regionCap] keys ( d2 << idBits | voxel )
+  uint32_t  regionCap;
+  uint32_t* cursor;     // [kHitRegions * 32]
+  uint32_t* off;        // [V] where a voxel's hits start
+  uint32_t* len;        // [V] how many
+};
+
 // ---- neighbourhoods, row-wise (round 4) ----------------------------------------------------------------------------------
 // The ball as ROWS: for every (dy, dz) with dy^2 + dz^2 < r2 the cells dx = -xr .. xr (xr the largest with dx^2 + dy^2 + dz^2
 // < r2).  Keys are linear in x, so the <= 2 xr + 1 <= 25 cells of a row are consecutive BITS of the occupancy bitmap: one lane
@@ -357,26 +375,28 @@ __device__ __forceinline__ int collectBall( const Pt c, const Pt* __restrict__ c
 // within Chebyshev distance devRange (1 for voxels of 4 and more, 2 for voxels of 2: PCCPatchSegmenter.cpp:1469-1492), in
 // row order, padded to devStride entries.
 constexpr uint32_t kDevPad = 0xFFFFFFFFu;
+// wavefronts per SIMD that the LDS of a ( CAP, WAVES ) instantiation leaves room for: what the register allocation has to meet
+// (round 6: the code that keeps the ball's hits took neighbourhoodKernel from 62 to 72 registers -- 7 wavefronts instead of 8)
+constexpr int ldsWavesPerSimd( int cap, int waves ) {
+  const int perCu = ( 160 * 1024 / ( cap * waves * 4 ) ) * waves;
+  return perCu >= 32 ? 8 : ( perCu / 4 > 0 ? perCu / 4 : 1 );
+}
 
 template <int CAP, int WAVES>
-__global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
+__global__ __launch_bounds__( 64 * WAVES, ldsWavesPerSimd( CAP, WAVES ) ) void neighbourhoodKernel(
     const Pt* __restrict__ centre, const uint32_t* __restrict__ count, const uint32_t* __restrict__ table, Grid g, uint32_t V,
     const int* __restrict__ offsets, int nOffsets, int maxNN, double lambda, int idBits, int devRange, uint32_t devStride,
     uint32_t rowCapacity, uint32_t* __restrict__ rowLen, uint32_t* __restrict__ devLen, double* __restrict__ weight,
     uint32_t* __restrict__ adjOff, uint32_t* __restrict__ adj, uint32_t* __restrict__ dev, uint32_t* __restrict__ rowCursor,
     uint32_t* __restrict__ overflow, const uint2* __restrict__ bits /* non-null: offsets = the ball's ROWS (collectBall) */,
     const uint2* __restrict__ voxelOfRank /* record of the voxel that owns the rank-th occupied key (rankRecord) */,
-    uint32_t* __restrict__ lastKey /* the last key each row keeps: what the gathered reverse rows test against */ ) {
+    uint32_t* __restrict__ lastKey /* the last key each row keeps: what the gathered reverse rows test against */,
+    BallHits saved /* .buf non-null: the ball's hits are kept for the reverse rows (round 6) */ ) {
   __shared__ uint32_t keysAll[WAVES][CAP];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t      v    = blockIdx.x * WAVES + wave;
   uint32_t*           keys = keysAll[wave];
-  if ( v >= V ) {  // a wave of the last workgroup without a voxel: it reserves nothing, but stays for the two barriers of the
-    if ( lane == 0 ) keys[CAP - 2] = 0;  // row reservation below (leaving before them is undefined, whatever the hardware does)
-    __syncthreads();
-    __syncthreads();
-    return;
-  }
+  if ( v >= V ) return;  // (a wave of the last workgroup without a voxel; the kernel has no workgroup barrier)
   const uint32_t idMask  = ( 1u << idBits ) - 1u;
   const Pt       c       = centre[v];
   const int      gridMax = 1 << g.gridShift;  // cell coordinates run 0..gridMax inclusive
@@ -391,6 +411,20 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
   // (row-wise form: the bins -- members and hits per squared distance -- fill while the ball is collected: a voxel's member
   //  count rides in its centre record, which the collection reads anyway)
   if ( bits ) hits = collectBall<CAP>( c, centre, voxelOfRank, bits, g, offsets, nOffsets, idBits, keys, lane, overflow, bins );
+  if ( saved.buf ) {  // the hits as they are now (every voxel of the ball, unsorted): the reverse rows pass reads them instead of collecting the ball again
+    const uint32_t region = blockIdx.x % kHitRegions;
+    uint32_t       at     = 0;
+    if ( lane == 0 ) at = atomicAdd( &saved.cursor[region * 32], uint32_t( hits ) );  // (one reservation per wavefront, spread over kHitRegions words)
+    at = __shfl( at, 0, 64 );
+    const bool room = uint64_t( at ) + uint32_t( hits ) <= saved.regionCap;
+    if ( room )
+      for ( int i = lane; i < hits; i += 64 ) saved.buf[size_t( region ) * saved.regionCap + at + i] = keys[i];
+    if ( lane == 0 ) {
+      saved.off[v] = region * saved.regionCap + at;
+      saved.len[v] = uint32_t( hits );
+      if ( !room ) atomicMax( overflow + 3, 1u );  // (the reverse rows pass collects the balls itself, the next frames get more room)
+    }
+  }
   for ( int base = 0; !bits && base < nOffsets; base += 64 * kBatch ) {
     uint32_t u[kBatch], d2[kBatch], cell[kBatch];
 #pragma unroll
@@ -598,19 +632,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
       nn      = running;
     }
   }
-  // the row's place in the table: ONE reservation per workgroup (70 K voxels queueing on a single address otherwise); the
-  // bookkeeping words sit in the unused tail of the key arrays (a workgroup's LDS is exactly a fifth of the CU's)
-  if ( lane == 0 ) keys[CAP - 2] = uint32_t( used );
-  __syncthreads();  // (waves of the last workgroup that have no voxel have left: they wrote a zero)
-  if ( threadIdx.x == 0 ) {
-    uint32_t total = 0;
-    for ( int w = 0; w < WAVES; ++w ) total += keysAll[w][CAP - 2];
-    keysAll[0][CAP - 1] = atomicAdd( rowCursor, total );  // (the final cursor = size of the reverse rows)
-  }
-  __syncthreads();
-  uint32_t rowBase = keysAll[0][CAP - 1];
-  for ( int w = 0; w < wave; ++w ) rowBase += keysAll[w][CAP - 2];
-  const bool fit = uint64_t( rowBase ) + uint32_t( used ) <= rowCapacity;
+  // the row's place in the table: one reservation per wavefront in the region of its voxel (kRowRegions cursors 128 bytes apart)
+  const uint32_t region  = rowRegionOf( v );
+  uint32_t       rowBase = 0;
+  if ( lane == 0 ) rowBase = atomicAdd( &rowCursor[region * 32], uint32_t( used ) );
+  rowBase        = __shfl( rowBase, 0, 64 );
+  const bool fit = uint64_t( rowBase ) + uint32_t( used ) <= rowCapacity;  // (rowCapacity: of a region)
+  rowBase += region * rowCapacity;
   if ( lane == 0 ) {
     rowLen[v] = uint32_t( used );
     if ( lastKey ) lastKey[v] = partial ? lastKeyValue : ( used > 0 ? keys[used - 1] : 0u );
@@ -659,19 +687,35 @@ __global__ __launch_bounds__( 64 * WAVES ) void neighbourhoodKernel(
 // key( u seen from v ) <= lastKey[v], write them back to back (one reservation per workgroup).  The order inside a reverse
 // row is immaterial (the sweeps push integer differences over it).
 template <int CAP, int WAVES>
-__global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint2* __restrict__ voxelOfRank,
+__global__ __launch_bounds__( 64 * WAVES, ldsWavesPerSimd( CAP, WAVES ) ) void reverseRowsKernel( const Pt* __restrict__ centre, const uint2* __restrict__ voxelOfRank,
                                                                      const uint2* __restrict__ bits, Grid g, uint32_t V,
                                                                      const int* __restrict__ rows, int nRows, int idBits,
                                                                      const uint32_t* __restrict__ lastKey, uint32_t rowCapacity,
                                                                      uint32_t* __restrict__ rOff, uint32_t* __restrict__ rLen,
                                                                      uint32_t* __restrict__ radj, uint32_t* __restrict__ rowCursor,
-                                                                     uint32_t* __restrict__ overflow ) {
+                                                                     uint32_t* __restrict__ overflow, BallHits saved ) {
   __shared__ uint32_t keysAll[WAVES][CAP];
   const int           lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t      u    = blockIdx.x * WAVES + wave;
   uint32_t*           keys = keysAll[wave];
   int                 kept = 0;
-  if ( u < V ) {
+  // (round 6: the forward pass has kept every ball's hits -- unless some region ran out of room, which its flag says)
+  const bool useSaved = saved.buf && overflow[3] == 0;
+  if ( u < V && useSaved ) {
+    const uint32_t idMask = ( 1u << idBits ) - 1u;
+    const uint32_t len = saved.len[u];
+    const uint32_t* mine = saved.buf + saved.off[u];
+    for ( uint32_t base = 0; base < len; base += 64 ) {
+      const uint32_t i   = base + uint32_t( lane );
+      const uint32_t key = i < len ? mine[i] : 0u;
+      const uint32_t v   = key & idMask;
+      const bool     in  = i < len && ( ( key & ~idMask ) | u ) <= lastKey[v];
+      const unsigned long long m = __ballot( in );
+      if ( in ) keys[kept + __popcll( m & ( ( 1ull << lane ) - 1ull ) )] = v;
+      kept += __popcll( m );
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  } else if ( u < V ) {
     const uint32_t idMask = ( 1u << idBits ) - 1u;
     const int      hits   = collectBall<CAP>( centre[u], centre, voxelOfRank, bits, g, rows, nRows, idBits, keys, lane, overflow, nullptr );
     for ( int base = 0; base < hits; base += 64 ) {  // in place: a chunk is read whole before anything lands at or below it
@@ -686,22 +730,17 @@ __global__ __launch_bounds__( 64 * WAVES ) void reverseRowsKernel( const Pt* __r
     }
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
   }
-  if ( lane == 0 ) keys[CAP - 2] = uint32_t( kept );
-  __syncthreads();
-  if ( threadIdx.x == 0 ) {
-    uint32_t total = 0;
-    for ( int w = 0; w < WAVES; ++w ) total += keysAll[w][CAP - 2];
-    keysAll[0][CAP - 1] = atomicAdd( rowCursor, total );
-  }
-  __syncthreads();
   if ( u >= V ) return;
-  uint32_t rowBase = keysAll[0][CAP - 1];
-  for ( int w = 0; w < wave; ++w ) rowBase += keysAll[w][CAP - 2];
-  const bool fit = uint64_t( rowBase ) + uint32_t( kept ) <= rowCapacity;
+  const uint32_t region  = rowRegionOf( u );
+  uint32_t       rowBase = 0;
+  if ( lane == 0 ) rowBase = atomicAdd( &rowCursor[region * 32], uint32_t( kept ) );
+  rowBase        = __shfl( rowBase, 0, 64 );
+  const bool fit = uint64_t( rowBase ) + uint32_t( kept ) <= rowCapacity;  // (rowCapacity: of a region)
+  rowBase += region * rowCapacity;
   if ( lane == 0 ) {
     rLen[u] = fit ? uint32_t( kept ) : 0u;
     rOff[u] = fit ? rowBase : 0u;
-    if ( !fit ) atomicMax( overflow, 1u );  // (cannot happen when the forward rows fitted: the reverse rows hold the same entries)
+    if ( !fit ) atomicMax( overflow, 1u );  // (the reverse rows hold the same entries as the forward rows, region by region a little more or less)
   }
   if ( fit )
     for ( int i = lane; i < kept; i += 64 ) radj[size_t( rowBase ) + i] = keys[i];
@@ -1177,16 +1216,24 @@ struct RefineJob {
   int              capTier = 2;  // which instantiation of the neighbourhood kernels (launchNeighbourhood)
   size_t           Vp = 0, W2 = 0, ball = 0, perVoxel = 0;
   uint64_t         capacity = 0;
-  uint32_t         res[4] = {0, 0, 0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag, reverse row entries, room asked for
+  uint32_t         res[5] = {0, 0, 0, 0, 0};  // the neighbourhood pass' answer: row entries written, overflow flag, reverse row entries, room asked for, kept hits out of room
+  uint32_t         hitRegionCap = 0;
   DevBuf<uint32_t> d_key, d_flag, d_vid, d_small, d_count, d_rowLen, d_devLen, d_adjOff, d_hist, d_activeBuf, d_pointStart,
       d_pointList, d_cursor, d_rcount, d_rcursor, d_lastRescore, d_flags, d_gbits, d_adj, d_dev, d_lastKey, d_roffG, d_rlenG, d_radjG,
-      d_voxelOfRank;
+      d_voxelOfRank, d_hitBuf, d_hitCtl, d_hitOff, d_hitLen, d_rowCtl;
+  std::vector<uint32_t> rowCtlHost;  // the forward rows' region cursors, fetched with the pass' answer (their sum: the row entries)
   DevBuf<Pt>      d_centre;
   DevBuf<double>  d_weight;
   DevBuf<uint8_t> d_state;  // edge | ppi, V bytes each (padded to whole 32-voxel words)
   const int*      d_offsets = nullptr;  // the ball's rows / cells: the context's table for ( radius, form )
   bool matches( int nn, double l, int it, int vd, int sr ) const {
     return nn == maxNNCount && l == lambda && it == iterationCount && vd == voxDim && sr == searchRadius;
+  }
+  // entries of a row table with room for `perVoxel` entries per voxel IN EVERY REGION (rowRegionOf: sixteen consecutive voxels
+  // share a region, so a region holds at most 16 * ceil( V / 16 / kRowRegions ) voxels -- V / kRowRegions for all but tiny clouds)
+  uint64_t rowTableEntries( size_t perVoxel ) const {
+    const uint64_t groups = ( uint64_t( V ) + 15 ) / 16, perRegion = 16 * ( ( groups + kRowRegions - 1 ) / kRowRegions );
+    return uint64_t( kRowRegions ) * perRegion * perVoxel;
   }
   int  geometry( tmc2_frame* f );
   int  finish();
@@ -1218,16 +1265,21 @@ inline int capTierFor( size_t cells ) {  // the smallest tier whose room holds `
 // row cursor, [4] with overflow code 3: the room the fullest ball asks for)
 void RefineJob::launchNeighbourhood() {
   const int nBall = int( offsets.size() );  // rows or cells
+  const uint32_t rowRegionCap = uint32_t( capacity / kRowRegions );  // (the tables hold kRowRegions regions of this many entries)
+  BallHits  savedHits{};
+  if ( byRows && d_hitBuf.p ) {
+    savedHits.buf = d_hitBuf.p, savedHits.regionCap = hitRegionCap, savedHits.cursor = d_hitCtl.p, savedHits.off = d_hitOff.p, savedHits.len = d_hitLen.p;
+  }
 #define TMC2_NEIGHBOURHOOD( CAP, WAVES )                                                                                       \
   hipLaunchKernelGGL( ( neighbourhoodKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p,      \
                       d_count.p, table, g, V, d_offsets, nBall, maxNNCount, lambda, idBits, devRange, devStride,             \
-                      uint32_t( capacity ), d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_small.p + 1,   \
+                      rowRegionCap, d_rowLen.p, d_devLen.p, d_weight.p, d_adjOff.p, d_adj.p, d_dev.p, d_rowCtl.p,            \
                       d_small.p + 2, byRows ? bits : (const uint2*)nullptr, reinterpret_cast<const uint2*>( d_voxelOfRank.p ),   \
-                      byRows ? d_lastKey.p : (uint32_t*)nullptr );                                                              \
+                      byRows ? d_lastKey.p : (uint32_t*)nullptr, savedHits );                                                  \
   if ( byRows )                                                                                                                \
   hipLaunchKernelGGL( ( reverseRowsKernel<CAP, WAVES> ), dim3( ( V + WAVES - 1 ) / WAVES ), dim3( 64 * WAVES ), 0, s, d_centre.p, reinterpret_cast<const uint2*>( d_voxelOfRank.p ), \
-                      bits, g, V, d_offsets, nBall, idBits, d_lastKey.p, uint32_t( capacity ), d_roffG.p, d_rlenG.p, d_radjG.p, \
-                      d_small.p + 3, d_small.p + 2 )
+                      bits, g, V, d_offsets, nBall, idBits, d_lastKey.p, rowRegionCap, d_roffG.p, d_rlenG.p, d_radjG.p,          \
+                      d_rowCtl.p + kRowRegions * 32, d_small.p + 2, savedHits )
   // LDS per wavefront = room for the ball's OCCUPIED cells (row-wise form; a surface fills 5-10 % of a ball) or for all its
   // cells; the smaller the room, the more wavefronts a CU holds (kCapTiers) -- a frame whose balls need more raises the overflow
   // word to 3, says how much, and is repeated in the tier that holds it (remembered per context)
@@ -1368,7 +1420,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
                                {d_hist.p, size_t( V ) * 16, 0},
                                {d_state.p, Vp * 2, 0},
                                {d_cursor.p, size_t( V ) * 4, 0},
-                               {d_small.p + 1, 16, 0},  // [1] row cursor, [2] overflow, [3] reverse row cursor, [4] room asked for
+                               {d_small.p + 1, 20, 0},  // [1] row cursor, [2] overflow, [3] reverse row cursor, [4] room asked for, [5] kept hits out of room
                                {d_flags.p, ( 2 * size_t( iterationCount ) + 2 ) * 4, 0},
                                {d_rcount.p, ( size_t( V ) + 1 ) * 4, 0},
                                {d_rcursor.p, ( size_t( V ) + 1 ) * 4, 0},
@@ -1399,7 +1451,7 @@ int RefineJob::geometry( tmc2_frame* f ) {
   const char* capEnv  = ctxOption( ctx, "REFINE_ROWCAP" );
   perVoxel            = std::min<size_t>( ball, 2 * size_t( maxNNCount > 0 ? maxNNCount : 1 ) * V / std::max<uint32_t>( n, 1u ) + 32 );
   if ( capEnv && capEnv[0] == 't' ) perVoxel = 1;
-  capacity = uint64_t( V ) * perVoxel;
+  capacity = rowTableEntries( perVoxel );
   if ( capacity > 0xFFFFFFFFull ) {
     setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
     return TMC2_E_UNSUPPORTED;
@@ -1413,9 +1465,26 @@ int RefineJob::geometry( tmc2_frame* f ) {
     TMC2_TRY( d_roffG.alloc( V ) );
     TMC2_TRY( d_rlenG.alloc( V ) );
     TMC2_TRY( d_radjG.alloc( size_t( capacity ) ) );
+    // the balls' hits, kept for the reverse rows pass (option REFINE_HITS=0: it collects the balls again, as rounds 4-5 did;
+    // =tiny: a region runs out of room and says so -- the same).  Room: what this context's frames have needed, a surface's ~ 500
+    // of the 3 911 cells of a ball of voxels of 2 to begin with.
+    const char*  hitsEnv = ctxOption( ctx, "REFINE_HITS" );
+    const size_t perHit  = hitsEnv && hitsEnv[0] == 't' ? 1 : std::min<size_t>( ball, size_t( ctx->refineHitsPerVoxel ) );
+    if ( !( hitsEnv && hitsEnv[0] == '0' ) && uint64_t( V ) * perHit < 0xFFFFFFFFull ) {
+      hitRegionCap = uint32_t( ( uint64_t( V ) * perHit + kHitRegions - 1 ) / kHitRegions );
+      TMC2_TRY( d_hitBuf.alloc( size_t( hitRegionCap ) * kHitRegions ) );
+      TMC2_TRY( d_hitCtl.alloc( kHitRegions * 32 ) );
+      TMC2_TRY( d_hitOff.alloc( V ) );
+      TMC2_TRY( d_hitLen.alloc( V ) );
+      TMC2_TRY( fillRegions( ctx, {{d_hitCtl.p, kHitRegions * 32 * 4, 0}} ) );
+    }
   }
+  TMC2_TRY( d_rowCtl.alloc( 2 * kRowRegions * 32 ) );  // region cursors of the forward rows, then of the reverse rows
+  TMC2_TRY( fillRegions( ctx, {{d_rowCtl.p, 2 * kRowRegions * 32 * 4, 0}} ) );
+  rowCtlHost.assign( kRowRegions * 32, 0u );
   launchNeighbourhood();
-  TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 16, hipMemcpyDeviceToHost, s ) );  // (read in finish(), after a synchronisation)
+  TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 20, hipMemcpyDeviceToHost, s ) );  // (read in finish(), after a synchronisation)
+  TMC2_HIP( hipMemcpyAsync( rowCtlHost.data(), d_rowCtl.p, kRowRegions * 32 * 4, hipMemcpyDeviceToHost, s ) );
   ctx->stageEnd( sidSetup );
   TMC2_HIP( hipGetLastError() );
   return TMC2_OK;
@@ -1435,8 +1504,13 @@ int RefineJob::finish() {
   for ( int attempt = 0;; ++attempt ) {
     TMC2_HIP( hipStreamSynchronize( s ) );  // (usually long done: the orientation walk ran in between)
     TMC2_HIP( hipGetLastError() );
-    totalLen = res[0];
-    if ( ctxOption( ctx, "REFINE_DEBUG" ) ) fprintf( stderr, "refine: neighbourhood attempt %d tier %d: %u row entries, overflow word %u (V = %u)\n", attempt, capTier, res[0], res[1], V );
+    totalLen = 0;
+    for ( uint32_t r = 0; r < kRowRegions; ++r ) totalLen += rowCtlHost[r * 32];
+    if ( ctxOption( ctx, "REFINE_DEBUG" ) ) fprintf( stderr, "refine: neighbourhood attempt %d tier %d: %u row entries, overflow word %u (V = %u)\n", attempt, capTier, totalLen, res[1], V );
+    if ( res[4] ) {  // the kept hits ran out of room (the reverse rows pass collected the balls itself): more for this context's next frames
+      ctx->refineHitsPerVoxel = std::min<uint32_t>( 4096u - 160u, ctx->refineHitsPerVoxel * 7u / 4u );
+      ctx->stageAddHostMs( "refine_hits_out_of_room", 0.0 );
+    }
     if ( res[1] == 0 ) break;
     if ( ( res[1] != 1 && res[1] != 3 ) || attempt > 3 || ( res[1] == 3 && capTier >= kLastCapTier ) ) {
       setError( "refineSegmentationGridBased: neighbourhood pass failed (%u)", res[1] );
@@ -1449,17 +1523,21 @@ int RefineJob::finish() {
     } else {
       perVoxel = ball;  // room for whole balls
     }
-    capacity = uint64_t( V ) * perVoxel;
+    capacity = rowTableEntries( perVoxel );
     if ( capacity > 0xFFFFFFFFull ) {
       setError( "refineSegmentationGridBased: %u voxels x %zu row entries exceed the neighbourhood table", V, perVoxel );
       return TMC2_E_UNSUPPORTED;
     }
     TMC2_TRY( d_adj.alloc( size_t( capacity ) ) );
     if ( byRows ) TMC2_TRY( d_radjG.alloc( size_t( capacity ) ) );
-    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 16, s ) );  // [1] row cursor, [2] overflow, [3] reverse row cursor, [4] room asked for
+    TMC2_HIP( hipMemsetAsync( d_small.p + 1, 0, 20, s ) );  // [1] row cursor, [2] overflow, [3] reverse row cursor, [4] room asked for, [5] kept hits out of room
+    if ( d_hitCtl.p ) TMC2_HIP( hipMemsetAsync( d_hitCtl.p, 0, kHitRegions * 32 * 4, s ) );
+    TMC2_HIP( hipMemsetAsync( d_rowCtl.p, 0, 2 * kRowRegions * 32 * 4, s ) );
     launchNeighbourhood();
-    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 16, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipMemcpyAsync( res, d_small.p + 1, 20, hipMemcpyDeviceToHost, s ) );
+    TMC2_HIP( hipMemcpyAsync( rowCtlHost.data(), d_rowCtl.p, kRowRegions * 32 * 4, hipMemcpyDeviceToHost, s ) );
   }
+  d_hitBuf.release(), d_hitCtl.release(), d_hitOff.release(), d_hitLen.release();  // (both passes over the balls are done: the stream was synchronised above)
   hipLaunchKernelGGL( tableCleanKernel, grdN, blk, 0, s, d_key.p, n, table, bits );
   tableFilled = false;
   hipLaunchKernelGGL( histAccumulateKernel, grdN, blk, 0, s, d_vid.p, f->d_partition.p, (const uint8_t*)nullptr, n,

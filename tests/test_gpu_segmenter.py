@@ -267,6 +267,27 @@ def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, ctx_options, vox_dim, f
 
 
 @pytest.mark.parametrize("vox_dim", [4, 2])
+@pytest.mark.parametrize("hits", ["0", "tiny"])
+def test_gpu_refine_reverse_rows_without_the_kept_hits(oracle, ctx_options, gpu_ctx, vox_dim, hits):
+    """Round 6: the forward pass over the balls keeps every ball's hits and the reverse rows pass reads them instead of collecting
+    the balls again.  TMC2_REFINE_HITS=0 switches that off (rounds 4-5), =tiny leaves the kept hits no room: a region says so, the
+    reverse rows pass collects the balls itself, and the context gives its next frames more room -- same bits either way."""
+    ctx_options.setenv("TMC2_REFINE_HITS", hits)
+    xyz, _ = synth_cloud("small")
+    nrm = oracle.normals(xyz)
+    p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+    exp = oracle.refine_grid(xyz, nrm, p0, iterations=8, vox_dim=vox_dim)
+    for attempt in range(2):
+        fr = gpu_ctx.frame(xyz)
+        fr.set_normals(nrm)
+        fr.set_partition(p0)
+        gpu_ctx.stage_reset()
+        fr.segmenter_refine_grid_based(1024, 3.0, 8, vox_dim, 192)
+        assert np.array_equal(fr.get_partition(), exp), (hits, attempt)
+        assert gpu_ctx.stage_calls().get("refine_hits_out_of_room", 0) == (1 if hits == "tiny" else 0), (hits, attempt)
+
+
+@pytest.mark.parametrize("vox_dim", [4, 2])
 def test_gpu_refine_solid_cloud_takes_the_larger_tier(oracle, vox_dim):
     """A SOLID block fills its balls (1 357 / 3 911 occupied cells a voxel): more than the smallest instantiation of the row-wise
     neighbourhood kernels holds in LDS -- the overflow says how much room the fullest ball asks for, the frame is repeated ONCE in
