@@ -652,6 +652,49 @@ __global__ __launch_bounds__( 64 * WAVES, ldsWavesPerSimd( CAP, WAVES ) ) void n
   const uint32_t d2Max = uint32_t( 3 * devRange * devRange );
   uint32_t*      drow  = dev + size_t( v ) * devStride;
   uint32_t       nDev  = 0;
+  // (round 6: the candidates -- d2 <= 3 R^2, a few dozen of a row's hundreds, anywhere in a row whose front is not sorted -- are
+  //  gathered first, in row order, into the free room above the row; their centres are then fetched together: one round trip to
+  //  memory instead of one per 64 row entries, each waiting for the one before)
+  constexpr int kNearRoom = 192;  // (179 cells have d2 <= 12)
+  if ( used + kNearRoom <= CAP ) {
+    uint32_t* nearList = keys + used;  // (the bins above are no longer needed)
+    int       nNear    = 0;
+    for ( int base = 0; base < used; base += 64 ) {
+      const int  i    = base + lane;
+      const bool near = i < used && ( keys[i] >> idBits ) <= d2Max;
+      const unsigned long long m = __ballot( near );
+      if ( near ) {
+        const int at = nNear + __popcll( m & ( ( 1ull << lane ) - 1ull ) );
+        if ( at < kNearRoom ) nearList[at] = keys[i] & idMask;
+      }
+      nNear += __popcll( m );
+      if ( !partial && !m ) break;  // (a sorted row: nothing near can follow)
+    }
+    nNear = min( nNear, kNearRoom );  // (more than 179 cannot be near; a guard, not a case)
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    uint32_t u[3];
+    bool     in[3];
+#pragma unroll
+    for ( int k = 0; k < 3; ++k ) {
+      const int i = 64 * k + lane;
+      u[k]        = i < nNear ? nearList[i] : 0u;
+      in[k]       = false;
+      if ( i < nNear ) {
+        const Pt cu = centre[u[k]];
+        in[k]       = abs( int( cu.x ) - int( c.x ) ) <= devRange && abs( int( cu.y ) - int( c.y ) ) <= devRange &&
+                abs( int( cu.z ) - int( c.z ) ) <= devRange;
+      }
+    }
+#pragma unroll
+    for ( int k = 0; k < 3; ++k ) {
+      const unsigned long long m = __ballot( in[k] );
+      if ( in[k] ) {
+        const uint32_t pos = nDev + uint32_t( __popcll( m & ( ( 1ull << lane ) - 1ull ) ) );
+        if ( pos < devStride ) drow[pos] = u[k];
+      }
+      nDev += uint32_t( __popcll( m ) );
+    }
+  } else
   for ( int base = 0; base < used; base += 64 ) {
     const int i   = base + lane;
     bool      in  = false;
