@@ -971,15 +971,33 @@ __device__ __forceinline__ uint32_t closureHop( const Closure& c, uint32_t x, ui
   // walked as far as its length says)
   const uint32_t len  = c.stride == 32 ? 32u : c.devLen[x];
   uint32_t       keep = kNoVoxel;
-  for ( uint32_t base = 0; base < len; base += 32 ) {
-    const uint32_t v     = c.dev[size_t( x ) * c.stride + base + lane];
-    bool           first = false, fresh = false;
-    if ( v != kDevPad && c.edge[v] == NO_EDGE && c.ppi[v] != a ) {
+  // (round 6: a row of 128 is up to four chunks of 32 -- their entries, then edge / ppi of all of them, then all the returning
+  //  atomics are issued together: three dependent round trips per hop whatever the row's length, not three per chunk.  The
+  //  voxels of a row are distinct, so an atomic's answer does not depend on the other chunks'.)
+  constexpr int kChunks = 4;  // (devStride <= 128)
+  uint32_t      vAll[kChunks];
+  bool          candAll[kChunks], firstAll[kChunks], freshAll[kChunks];
+#pragma unroll
+  for ( int k = 0; k < kChunks; ++k ) vAll[k] = uint32_t( 32 * k ) < len ? c.dev[size_t( x ) * c.stride + 32 * k + lane] : kDevPad;
+#pragma unroll
+  for ( int k = 0; k < kChunks; ++k ) candAll[k] = vAll[k] != kDevPad && c.edge[vAll[k]] == NO_EDGE && c.ppi[vAll[k]] != a;
+#pragma unroll
+  for ( int k = 0; k < kChunks; ++k ) {
+    firstAll[k] = freshAll[k] = false;
+    if ( candAll[k] ) {
+      const uint32_t v   = vAll[k];
       const uint32_t sh  = ( v & 15u ) * 2u;
       const uint32_t old = atomicOr( &c.state[v >> 4], ( v > x ? 3u : 1u ) << sh ) >> sh;
-      first              = !( old & 1u );
-      fresh              = v > x && !( old & 2u );  // (v is a NO_EDGE voxel: only a mark activates it)
+      firstAll[k]        = !( old & 1u );
+      freshAll[k]        = v > x && !( old & 2u );  // (v is a NO_EDGE voxel: only a mark activates it)
     }
+  }
+#pragma unroll
+  for ( int ch = 0; ch < kChunks; ++ch ) {
+    if ( uint32_t( 32 * ch ) >= len ) continue;  // (uniform over the 32-lane group)
+    const uint32_t v     = vAll[ch];
+    const bool     first = firstAll[ch];
+    bool           fresh = freshAll[ch];
     const uint32_t mFirst = uint32_t( __ballot( first ) >> ( 32 * half ) );
     uint32_t       mFresh = uint32_t( __ballot( fresh ) >> ( 32 * half ) );
     if ( mFirst ) {
@@ -1123,7 +1141,7 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
                                                        const uint32_t* __restrict__ rlen /* null: roff is a CSR of V + 1 offsets */,
                                                        const uint32_t* __restrict__ radj, uint8_t* __restrict__ edge,
                                                        uint8_t* __restrict__ ppi, uint4* __restrict__ hist,
-                                                       uint8_t* __restrict__ partition, uint32_t* __restrict__ flags, int iter ) {
+                                                       uint8_t* __restrict__ partition, uint32_t* __restrict__ flags, int iter, int pairedPush ) {
   // the sub-lists as one index space: pre[s] = entries of the sub-lists before s
   __shared__ uint32_t pre[kSubLists + 1];
   if ( threadIdx.x < 64 ) {
@@ -1209,10 +1227,20 @@ __global__ __launch_bounds__( 256 ) void sweepKernel( const uint32_t* __restrict
         const uint32_t d0 = h0 - h.x, d1 = h1 - h.y, d2 = h2 - h.z;
         if ( d0 | d1 | d2 ) {
           const uint32_t rb = roff[v], re = rlen ? rb + rlen[v] : roff[v + 1];
+          // (round 6: the first two words in ONE 64-bit add.  A word's difference is the true integer T = dHi * 65536 + dLo modulo
+          //  2^32, and with fields below 2^15 -- pairedPush: maxNN + 255 < 32 768 -- |T| < 2^31, so T is d as an int32; adding
+          //  T0 + T1 * 2^32 as a SIGNED 64-bit number to x + y * 2^32 is exact integer arithmetic on the pair: every true word stays
+          //  within 0 .. 2^32 - 1, so the final pair decomposes into the same two words whatever the order of the adds -- a borrow
+          //  out of the low word is what the sign extension cancels.  Two atomics per target instead of three.)
+          const unsigned long long d01 = (unsigned long long)( (long long)int32_t( d0 ) + ( (long long)int32_t( d1 ) << 32 ) );
           for ( uint32_t t = rb + sub; t < re; t += 16 ) {
             uint32_t* tr = reinterpret_cast<uint32_t*>( recNxt + radj[t] );
-            if ( d0 ) atomicAdd( tr, d0 );
-            if ( d1 ) atomicAdd( tr + 1, d1 );
+            if ( pairedPush ) {
+              if ( d0 | d1 ) atomicAdd( reinterpret_cast<unsigned long long*>( tr ), d01 );
+            } else {
+              if ( d0 ) atomicAdd( tr, d0 );
+              if ( d1 ) atomicAdd( tr + 1, d1 );
+            }
             if ( d2 ) atomicAdd( tr + 2, d2 );
             tr[3] = uint32_t( iter ) + 2u;
           }
@@ -1639,6 +1667,10 @@ int RefineJob::finish() {
   //  +- 1.5 % of each other in flight -- four per CU for the sweep, two for the closure;
   //  round 6, three rounds alternating with the closure at two workgroups of 256 per CU: sweep kernel 4 / 2 / 1 per CU ->
   //  longdress 189.2 / 191.7 / 191.8 frames/s -- two per CU)
+  // (the sweep's pushes: two words of a target in one 64-bit add where the histogram fields stay below 2^15 -- a row holds at most
+  //  maxNN + 255 members; option REFINE_PUSH=words: three 32-bit adds, as rounds 2-5)
+  const char* pushEnv    = ctxOption( ctx, "REFINE_PUSH" );
+  const int   pairedPush = maxNNCount + 255 < 32768 && !( pushEnv && pushEnv[0] == 'w' ) ? 1 : 0;
   const bool wantTrace = ctxOption( ctx, "REFINE_TRACE" ) != nullptr;
   DevBuf<unsigned long long> d_timing;  // test hook TMC2_REFINE_TIMING: where the closure spends its time, per sweep
   const bool                 wantTiming = ctxOption( ctx, "REFINE_TIMING" ) != nullptr;
@@ -1668,7 +1700,7 @@ int RefineJob::finish() {
     }
     hipLaunchKernelGGL( sweepKernel, grdSweep, blk, 0, s, d_lists.p, V, counts[cur], state[cur], recCur, recNxt,
                         d_lastRescore.p, d_weight.p, d_pointStart.p, d_pointList.p, f->d_normals.p, revOff, revLen, revAdj, d_edge,
-                        d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter );
+                        d_ppi, reinterpret_cast<uint4*>( d_hist.p ), f->d_partition.p, wantTrace ? d_flags.p : nullptr, iter, pairedPush );
     if ( debugSweeps ) {
       const hipError_t e = hipStreamSynchronize( s );
       fprintf( stderr, "refine: sweep %d sweep done (%d)\n", iter, int( e ) );

@@ -267,6 +267,21 @@ def test_gpu_refine_neighbourhood_forms(gpu_ctx, oracle, ctx_options, vox_dim, f
 
 
 @pytest.mark.parametrize("vox_dim", [4, 2])
+def test_gpu_refine_push_as_three_words(oracle, ctx_options, gpu_ctx, vox_dim):
+    """The sweep's pushes add two words of a target's record in one signed 64-bit add (round 6); TMC2_REFINE_PUSH=words is the
+    three 32-bit adds of rounds 2-5: same bits."""
+    ctx_options.setenv("TMC2_REFINE_PUSH", "words")
+    xyz, _ = synth_cloud("small", 2)
+    nrm = oracle.normals(xyz)
+    p0 = oracle.initial_segmentation(nrm, oracle.weight_normal(xyz))
+    fr = gpu_ctx.frame(xyz)
+    fr.set_normals(nrm)
+    fr.set_partition(p0)
+    fr.segmenter_refine_grid_based(1024, 3.0, 8, vox_dim, 192)
+    assert np.array_equal(fr.get_partition(), oracle.refine_grid(xyz, nrm, p0, iterations=8, vox_dim=vox_dim))
+
+
+@pytest.mark.parametrize("vox_dim", [4, 2])
 @pytest.mark.parametrize("hits", ["0", "tiny"])
 def test_gpu_refine_reverse_rows_without_the_kept_hits(oracle, ctx_options, gpu_ctx, vox_dim, hits):
     """Round 6: the forward pass over the balls keeps every ball's hits and the reverse rows pass reads them instead of collecting
