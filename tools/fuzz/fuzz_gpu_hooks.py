@@ -17,7 +17,7 @@ HOOKS = {"TMC2_REFINE_RING": [None, "1", "3", "40"], "TMC2_REFINE_CLOSURE_BLOCKS
          "TMC2_REFINE_CLOSURE_THREADS": [None, "64", "256", "1024"], "TMC2_KD_HUGEMAX": [None, "8192", "10000", "16384", "131072"],
          # round 4: S5's neighbourhood forms (row-wise through the occupancy bitmap / cell by cell), the LDS tier the row-wise kernels
          # start in, the sweep kernel's grid, the pair table of the orientation's contraction
-         "TMC2_REFINE_NEIGHBOURHOOD": [None, None, "cells"], "TMC2_REFINE_CAPTIER": [None, None, "1", "2", "3", "4"], "TMC2_REFINE_HITS": [None, None, None, "0", "tiny"], "TMC2_REFINE_PUSH": [None, None, "words"],
+         "TMC2_REFINE_NEIGHBOURHOOD": [None, None, "cells"], "TMC2_REFINE_CAPTIER": [None, None, "1", "2", "3", "4"], "TMC2_REFINE_HITS": [None, None, None, "0", "tiny"], "TMC2_REFINE_PUSH": [None, None, "words"], "TMC2_KNN_SPLIT": [None, None, "0"],
          "TMC2_REFINE_SWEEP_BLOCKS": [None, "1", "64", "4096"], "TMC2_ORIENT_PAIRS": [None, None, "6", "10"],
          "TMC2_ORIENT_SPEC": [None, None, "64,16"]}
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
