@@ -104,11 +104,18 @@ __global__ __launch_bounds__( 256 ) void reconTileKernel( const PlaceDev* __rest
 // ---- S18 ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint8_t toU8( double v ) { return uint8_t( fmax( 0.0, fmin( round( v ), 255.0 ) ) ); }
 
+// easy: non-null = the first result of the queries that have an identical source point (0xFFFFFFFF for the others: only
+// their rows of idx8 / dist8 are filled -- launchKnnSplit)
 __global__ __launch_bounds__( 256 ) void forwardColorKernel( const uint32_t* __restrict__ idx8, const uint32_t* __restrict__ dist8,
+                                                              const uint32_t* __restrict__ easy,
                                                               const uint8_t* __restrict__ srcRgb4, uint32_t m,
                                                               uint8_t* __restrict__ fwdRgb4 ) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if ( t >= m ) return;
+  if ( easy && easy[t] != 0xFFFFFFFFu ) {  // "dist < 0.0001": an identical source point exists, take its colour
+    reinterpret_cast<uchar4*>( fwdRgb4 )[t] = reinterpret_cast<const uchar4*>( srcRgb4 )[easy[t]];
+    return;
+  }
   const uint4* ir = reinterpret_cast<const uint4*>( idx8 + size_t( t ) * 8 );
   const uint4* dr = reinterpret_cast<const uint4*>( dist8 + size_t( t ) * 8 );
   const uint4  i0 = ir[0], i1 = ir[1], d0 = dr[0], d1 = dr[1];
@@ -444,12 +451,23 @@ int transferColorsDevice( tmc2_ctx* ctx, const TreeDev& srcTree, const Pt* d_src
   TMC2_TRY( d_cursor.alloc( M ) );
   TMC2_TRY( d_entries.alloc( n ) );
   TMC2_TRY( d_fwd.alloc( size_t( M ) * 4 ) );
-  TMC2_TRY( launchKnnTree( ctx, srcTree, d_tgtPts, M, 8, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
-  TMC2_TRY( launchKnnTree( ctx, tgtTree, d_srcPts, n, 1, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
+  // (round 6: both searches in two launches -- the queries that have an identical point in the tree first, then the compacted
+  //  rest: knn.hip, launchKnnSplit; option KNN_SPLIT=0: one launch each, as rounds 1-5)
+  DevBuf<uint32_t> d_easy8;
+  const char*      splitEnv = ctxOption( ctx, "KNN_SPLIT" );
+  const bool       split    = !( splitEnv && splitEnv[0] == '0' );
+  if ( split ) {
+    TMC2_TRY( d_easy8.alloc( M ) );
+    TMC2_TRY( launchKnnSplit( ctx, srcTree, d_tgtPts, M, 8, d_easy8.p, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
+    TMC2_TRY( launchKnnSplit( ctx, tgtTree, d_srcPts, n, 1, d_idx1.p, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
+  } else {
+    TMC2_TRY( launchKnnTree( ctx, srcTree, d_tgtPts, M, 8, d_idx8.p, d_dist8.p, "knn8_recon_in_source" ) );
+    TMC2_TRY( launchKnnTree( ctx, tgtTree, d_srcPts, n, 1, d_idx1.p, d_dist1.p, "knn1_source_in_recon" ) );
+  }
   const int sid = ctx->stageBegin( "transfer_colors" );
   TMC2_TRY( fillRegions( ctx, {{d_count.p, size_t( M ) * 4, 0}, {d_cursor.p, size_t( M ) * 4, 0}, {d_error, 4, 0}} ) );
   const dim3 grdM( ( M + 255 ) / 256 ), grdN( ( n + 255 ) / 256 );
-  hipLaunchKernelGGL( forwardColorKernel, grdM, blk, 0, s, d_idx8.p, d_dist8.p, d_srcRgb4, M, d_fwd.p );
+  hipLaunchKernelGGL( forwardColorKernel, grdM, blk, 0, s, d_idx8.p, d_dist8.p, split ? d_easy8.p : (const uint32_t*)nullptr, d_srcRgb4, M, d_fwd.p );
   hipLaunchKernelGGL( backwardCountKernel, grdN, blk, 0, s, d_idx1.p, n, d_count.p );
   TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, M, nullptr ) );
   hipLaunchKernelGGL( backwardFillKernel, grdN, blk, 0, s, d_idx1.p, d_dist1.p, d_offset.p, n, d_cursor.p, d_entries.p );

@@ -69,12 +69,17 @@ __device__ __forceinline__ void knnInsert( uint32_t ( &bd )[K], uint32_t ( &bi )
 // SELF = true : queries are the tree-order points themselves, row j is written to out[perm[j]]
 // SELF = false: queries come from `queries` (any order), row j is written to out[j]
 // LDS = true: far-child stack in LDS, 8-byte packed entries (see the header); false: 16-byte entries in scratch
+// nqLive: non-null = the number of queries lives on the device (a compacted list: launchKnnSplit); rowMap: non-null = row j is
+// written to out[rowMap[j]]
+constexpr uint32_t kHardQuery = 0xFFFFFFFFu;
 template <int K, bool SELF, bool LDS>
 __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTree, const uint32_t* __restrict__ perm,
                                                      const KdNode* __restrict__ nodes, RootBox root,
                                                      const Pt* __restrict__ queries, uint32_t nq,
                                                      uint32_t* __restrict__ outIdx, uint32_t* __restrict__ outDist,
-                                                     int xcdAware, uint32_t nTree, int nodeBits ) {
+                                                     int xcdAware, uint32_t nTree, int nodeBits,
+                                                     const uint32_t* __restrict__ nqLive, const uint32_t* __restrict__ rowMap ) {
+  if ( nqLive ) nq = min( nq, *nqLive );
   // packed far-child entry (LDS form): node id in the low nodeBits, three offsets of ( 64 - nodeBits ) / 3 bits above it --
   // 22 + 3 x 14 for trees of up to 2^21 points and queries within [-4096, 12287]; 25 + 3 x 13 for larger trees (the vox11
   // frames: 3 M points) whose queries lie inside [0, 8191] like the tree's box (offsets < 2^13)
@@ -88,8 +93,10 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   // of the queries: its L2 holds an eighth of the tree.  (The grid is a multiple of 8 blocks; blocks past the end leave.)
   uint32_t block = blockIdx.x;
   if ( xcdAware ) {
-    const uint32_t perXcd = gridDim.x >> 3;
-    block                 = ( blockIdx.x & 7u ) * perXcd + ( blockIdx.x >> 3 );
+    // (a compacted list: the eighths are eighths of the LIVE blocks, the grid was sized for the worst case)
+    const uint32_t perXcd = nqLive ? ( ( nq + 255u ) / 256u + 7u ) >> 3 : gridDim.x >> 3;
+    if ( ( blockIdx.x >> 3 ) >= perXcd ) return;
+    block = ( blockIdx.x & 7u ) * perXcd + ( blockIdx.x >> 3 );
   }
   const uint32_t j = block * blockDim.x + threadIdx.x;
   if ( j >= nq ) return;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
     }
     if ( !found ) break;
   }
-  const size_t row = SELF ? size_t( perm[j] ) : size_t( j );
+  const size_t row = SELF ? size_t( perm[j] ) : ( rowMap ? size_t( rowMap[j] ) : size_t( j ) );
   uint32_t*    oi  = outIdx + row * K;
 #pragma unroll
   for ( int i = 0; i < K; ++i ) oi[i] = perm[bi[i]];  // (the list is full: k <= n, and everything within cap was visited)
@@ -255,8 +262,10 @@ __global__ __launch_bounds__( 256 ) void knnKernel( const Pt* __restrict__ ptsTr
   }
 }
 
+// nqLive / rowMap: see knnKernel
 template <bool SELF>
-int dispatch( const tmc2_ctx* ctx, hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, uint32_t* idx, uint32_t* dist ) {
+int dispatch( const tmc2_ctx* ctx, hipStream_t s, const TreeDev& t, const Pt* q, uint64_t nq, int k, uint32_t* idx, uint32_t* dist,
+              const uint32_t* nqLive = nullptr, const uint32_t* rowMap = nullptr ) {
   if ( t.depth > kMaxStack ) {
     setError( "k-d tree depth %d exceeds the traversal stack (%d)", t.depth, kMaxStack );
     return TMC2_E_UNSUPPORTED;
@@ -283,10 +292,10 @@ int dispatch( const tmc2_ctx* ctx, hipStream_t s, const TreeDev& t, const Pt* q,
 #define TMC2_LAUNCH_K( KK )                                                                                          \
   if ( lds ) {                                                                                                       \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, true> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,          \
-                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ), nodeBits );                                             \
+                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ), nodeBits, nqLive, rowMap );                             \
   } else {                                                                                                           \
     hipLaunchKernelGGL( ( knnKernel<KK, SELF, false> ), grid, block, 0, s, t.ptsTree, t.perm, t.nodes, rb, q,         \
-                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ), nodeBits );                                             \
+                        uint32_t( nq ), idx, dist, xcdAware, uint32_t( t.n ), nodeBits, nqLive, rowMap );                             \
   }
   switch ( k ) {
     case 1: TMC2_LAUNCH_K( 1 ); break;
@@ -345,6 +354,92 @@ int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint
                    uint32_t* d_dist, const char* stage ) {
   const int sid = ctx->stageBegin( stage );
   const int r   = dispatch<false>( ctx, ctx->stream, tree, d_queries, nq, k, d_idx, d_dist );
+  ctx->stageEnd( sid );
+  return r;
+}
+
+namespace {
+// Pass 1 of launchKnnSplit.  The reference's search descends to the leaf on the query's side of every split FIRST and scans it
+// in tree order (nanoflann searchLevel); a point of that leaf that is IDENTICAL to the query is at distance 0, enters the result
+// list at its head, and nothing can displace it from there (equal distances are inserted behind, a full list rejects them): the
+// first identical point of the descent leaf IS the reference's first result.  easyIdx[j] = its original index (and 0 as its
+// distance where the caller wants one), kHardQuery where the leaf has none -- such a query may still have an identical point
+// elsewhere (points ON a split plane go to either side): it simply takes the ordinary search.
+__global__ __launch_bounds__( 256 ) void easyQueryKernel( const Pt* __restrict__ ptsTree, const uint32_t* __restrict__ perm,
+                                                           const KdNode* __restrict__ nodes, const Pt* __restrict__ queries, uint32_t nq,
+                                                           uint32_t* __restrict__ easyIdx, uint32_t* __restrict__ easyDist ) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( j >= nq ) return;
+  const Pt  qp = queries[j];
+  const int qx = qp.x, qy = qp.y, qz = qp.z;
+  KdNode    nd = nodes[0];
+  while ( nd.dim >= 0 ) {
+    const int v = nd.dim == 0 ? qx : ( nd.dim == 1 ? qy : qz );
+    nd          = nodes[( ( v - nd.divlow ) + ( v - nd.divhigh ) ) < 0 ? uint32_t( nd.a ) : uint32_t( nd.b )];
+  }
+  uint32_t found = kHardQuery;
+  for ( int p = nd.b - 1; p >= nd.a; --p ) {  // (backwards: the FIRST identical point is what is left in `found`)
+    const Pt c = ptsTree[p];
+    if ( c.x == qp.x && c.y == qp.y && c.z == qp.z ) found = uint32_t( p );
+  }
+  easyIdx[j] = found == kHardQuery ? kHardQuery : perm[found];
+  if ( easyDist && found != kHardQuery ) easyDist[j] = 0u;
+}
+// flag[j] = 1 where the easy pass left query j to the second launch
+__global__ __launch_bounds__( 256 ) void hardFlagKernel( const uint32_t* __restrict__ easyIdx, uint32_t nq, uint32_t* __restrict__ flag ) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( j < nq ) flag[j] = easyIdx[j] == kHardQuery ? 1u : 0u;
+}
+// the hard queries back to back, in their order, with the rows they came from
+__global__ __launch_bounds__( 256 ) void gatherHardKernel( const uint32_t* __restrict__ easyIdx, const uint32_t* __restrict__ rank, const Pt* __restrict__ queries,
+                                                            uint32_t nq, Pt* __restrict__ hardQueries, uint32_t* __restrict__ rowMap ) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( j >= nq || easyIdx[j] != kHardQuery ) return;
+  const uint32_t at = rank[j];
+  hardQueries[at]   = queries[j];
+  rowMap[at]        = j;
+}
+}  // namespace
+
+// The transfer's two searches in two launches each (round 6).  Most reconstructed points ARE source points (and the other way
+// round): 84-96 % of the queries have an identical point in the tree -- but the one query in ten that has to look around for real
+// kept every wavefront as long as itself.  Pass 1 (easyQueryKernel: one descent, one leaf) answers the queries whose descent leaf
+// holds an identical point -- d_easy[j] = the reference's FIRST result, kHardQuery otherwise; pass 2 runs the ordinary k-NN kernel
+// over the compacted rest, writing rows d_idx / d_dist [j][k] in place (the live count stays on the device: no round trip).  What
+// a caller may do with an easy query depends on k: k = 1 -- d_easy IS the result (pass d_idx as d_easy: distance 0 is written
+// too); k > 1 -- only where the consumer needs nothing but the first result of a search whose first distance is 0
+// (transferColors' forward direction: `skipAvgIfIdenticalSourcePointPresent`, PCCPointSet.cpp:853-858): the rows of easy queries
+// are NOT written.
+int launchKnnSplit( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_easy, uint32_t* d_idx,
+                    uint32_t* d_dist, const char* stage ) {
+  hipStream_t s = ctx->stream;
+  if ( nq == 0 ) return TMC2_OK;
+  const int sid = ctx->stageBegin( stage );
+  DevBuf<uint32_t> d_flag, d_rank, d_rowMap, d_count;
+  DevBuf<Pt>       d_hard;
+  TMC2_TRY( d_flag.alloc( nq ) );
+  TMC2_TRY( d_rank.alloc( nq ) );
+  TMC2_TRY( d_rowMap.alloc( nq ) );
+  TMC2_TRY( d_hard.alloc( nq ) );
+  TMC2_TRY( d_count.alloc( 1 ) );
+  int r = TMC2_OK;
+  if ( tree.n == 0 ) {
+    setError( "k-NN: empty tree" );
+    r = TMC2_E_INVALID;
+  }
+  if ( r == TMC2_OK ) {
+    const dim3 blk( 256 ), grd( uint32_t( ( nq + 255 ) / 256 ) );
+    // pass 1: with k = 1 the easy results go straight to their rows (distance 0 with them)
+    hipLaunchKernelGGL( easyQueryKernel, grd, blk, 0, s, tree.ptsTree, tree.perm, tree.nodes, d_queries, uint32_t( nq ), d_easy,
+                        k == 1 ? d_dist : (uint32_t*)nullptr );
+    hipLaunchKernelGGL( hardFlagKernel, grd, blk, 0, s, d_easy, uint32_t( nq ), d_flag.p );
+    r = exclusiveScanU32( ctx, d_flag.p, d_rank.p, nq, d_count.p );
+    if ( r == TMC2_OK ) {
+      hipLaunchKernelGGL( gatherHardKernel, grd, blk, 0, s, d_easy, d_rank.p, d_queries, uint32_t( nq ), d_hard.p, d_rowMap.p );
+      // pass 2: the grid is sized for the worst case, the live count is on the device (no round trip)
+      r = dispatch<false>( ctx, s, tree, d_hard.p, nq, k, d_idx, d_dist, d_count.p, d_rowMap.p );
+    }
+  }
   ctx->stageEnd( sid );
   return r;
 }

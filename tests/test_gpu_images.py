@@ -152,6 +152,43 @@ def test_gpu_transfer_colors_long_candidate_lists(gpu_ctx, oracle):
         assert np.array_equal(gpu_ctx.transfer_colors(xyz, rgb, tgt), oracle.transfer_colors(xyz, rgb, tgt))
 
 
+@pytest.mark.parametrize("split", [None, "0"])
+def test_gpu_transfer_colors_identical_points_and_duplicates(gpu_ctx, oracle, ctx_options, split):
+    """Round 6: both searches of the colour transfer run in two launches -- the queries that have an identical point in the tree
+    first (bound 0), then the compacted rest (TMC2_KNN_SPLIT=0: one launch, as before).  The cases that decide whether the first
+    pass is exact: targets that ARE source points, targets that are not, DUPLICATE positions with different colours in the source
+    and in the target (which of several identical points the reference returns is the traversal's order), targets on split planes
+    (coordinates equal to many others along an axis), a target cloud that is all duplicates of one point."""
+    if split:
+        ctx_options.setenv("TMC2_KNN_SPLIT", split)
+    rng = np.random.default_rng(17)
+    for case in range(4):
+        xyz, rgb = synth_cloud("small", case)
+        n = len(xyz)
+        if case >= 1:      # duplicate positions in the source, different colours
+            dup = rng.integers(0, n, n // 20)
+            xyz = np.concatenate([xyz, xyz[dup]])
+            rgb = np.concatenate([rgb, rng.integers(0, 256, (len(dup), 3)).astype(np.uint8)])
+            order = rng.permutation(len(xyz))
+            xyz, rgb = xyz[order], rgb[order]
+        keep = rng.random(len(xyz)) < 0.8
+        tgt = xyz[keep]                                                                  # identical points
+        moved = (xyz[rng.integers(0, len(xyz), len(xyz) // 6)] + rng.integers(-2, 3, (len(xyz) // 6, 3))).astype(np.int16)
+        tgt = np.concatenate([tgt, np.clip(moved, 0, 1023).astype(np.int16)])            # points that look around for real
+        if case >= 2:      # duplicate positions in the target
+            tgt = np.concatenate([tgt, tgt[rng.integers(0, len(tgt), len(tgt) // 10)]])
+        if case == 3:      # a plane of equal coordinates: every descent meets divlow == divhigh == the query's coordinate
+            plane = np.stack(np.meshgrid(np.arange(300, 340), np.arange(400, 440), indexing="ij"), -1).reshape(-1, 2)
+            slab = np.concatenate([plane, np.full((len(plane), 1), 512)], 1).astype(np.int16)
+            xyz = np.concatenate([xyz, slab, slab[::3]])
+            rgb = np.concatenate([rgb, rng.integers(0, 256, (len(slab) + len(slab[::3]), 3)).astype(np.uint8)])
+            tgt = np.concatenate([tgt, slab[::2], slab[::5]])
+        tgt = tgt[rng.permutation(len(tgt))]
+        assert np.array_equal(gpu_ctx.transfer_colors(xyz, rgb, tgt), oracle.transfer_colors(xyz, rgb, tgt)), (case, split)
+    one = np.repeat(xyz[:1], 500, 0)
+    assert np.array_equal(gpu_ctx.transfer_colors(xyz, rgb, one), oracle.transfer_colors(xyz, rgb, one)), "all targets one point"
+
+
 @pytest.mark.parametrize("placement", ["device", "host", "adaptive"])
 def test_gpu_gof_encoder_worker_threads(oracle, placement):
     """The GOF orchestration used by bench.py: one pinned worker thread + context per in-flight frame, both k-d tree
