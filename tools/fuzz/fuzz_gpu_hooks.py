@@ -36,10 +36,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if len(xyz) < 64:
         continue
     env = {k: v[int(rng.integers(0, len(v)))] for k, v in HOOKS.items()}
-    for k, v in env.items():
-        os.environ.pop(k, None)
-        if v is not None:
-            os.environ[k] = v
+    for k, v in env.items():                          # (options of the context: the environment is read once, when a context is created)
+        ctx.set_option(k[len("TMC2_"):], v)
     why = []
     fr = ctx.frame(xyz)
     perm, depth = fr.kdtree_order()
@@ -50,6 +48,12 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     for k in (16, 8, 1):
         if len(xyz) >= k and not np.array_equal(fr.kdtree_search(q, k), oracle.knn(xyz, q, k)):
             why.append("knn%d" % k)
+    if len(xyz) <= 60000:                             # the colour transfer's searches (round 6: in two launches; identical and duplicate points)
+        rgb = rng.integers(0, 256, (len(xyz), 3)).astype(np.uint8)
+        tgt = np.concatenate([xyz[rng.random(len(xyz)) < 0.7], q[:1500].clip(0, 1023).astype(np.int16), xyz[rng.integers(0, len(xyz), 200)]])
+        src, col = np.concatenate([xyz, xyz[:50]]), np.concatenate([rgb, rgb[50:100]])
+        if not np.array_equal(ctx.transfer_colors(src, col, tgt), oracle.transfer_colors(src, col, tgt)):
+            why.append("transfer_colors")
     if len(xyz) <= 60000:
         nrm = oracle.normals(xyz)
         T.load_library().tmc2_set_refine_overlap(int(rng.integers(0, 2)))     # (few frames in flight: other grids, geometry ahead)
