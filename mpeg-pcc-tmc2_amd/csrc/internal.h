@@ -415,7 +415,7 @@ int launchKnnTree( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint
 // the same search in two launches: the queries with an identical point in the tree first (d_easy[j]: the first result, or
 // 0xFFFFFFFF), then the compacted rest through the ordinary kernel, rows in place (knn.hip: what a caller may do with d_easy)
 int launchKnnSplit( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_easy, uint32_t* d_idx,
-                    uint32_t* d_dist, const char* stage );
+                    uint32_t* d_dist, const char* stage, bool uniqueTreeRows = false );
 TreeDev frameTree( const tmc2_frame* f );
 int generateAttributeImages( tmc2_frame* f );
 int reconstructPointCloud( tmc2_frame* f );

@@ -367,7 +367,8 @@ namespace {
 // elsewhere (points ON a split plane go to either side): it simply takes the ordinary search.
 __global__ __launch_bounds__( 256 ) void easyQueryKernel( const Pt* __restrict__ ptsTree, const uint32_t* __restrict__ perm,
                                                            const KdNode* __restrict__ nodes, const Pt* __restrict__ queries, uint32_t nq,
-                                                           uint32_t* __restrict__ easyIdx, uint32_t* __restrict__ easyDist ) {
+                                                           uint32_t* __restrict__ easyIdx, uint32_t* __restrict__ easyDist,
+                                                           uint32_t* __restrict__ rowIdx, uint32_t* __restrict__ rowDist, int rowK ) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if ( j >= nq ) return;
   const Pt  qp = queries[j];
@@ -384,6 +385,13 @@ __global__ __launch_bounds__( 256 ) void easyQueryKernel( const Pt* __restrict__
   }
   easyIdx[j] = found == kHardQuery ? kHardQuery : perm[found];
   if ( easyDist && found != kHardQuery ) easyDist[j] = 0u;
+  // a tree of UNIQUE positions (the metric's de-duplicated clouds): the query's results at distance 0 are this one point -- row
+  // [ match, .. ] with distances [ 0, not 0, .. ] is all a consumer that asks for "every point at the minimum distance" reads
+  if ( rowIdx && found != kHardQuery ) {
+    rowIdx[size_t( j ) * rowK]      = perm[found];
+    rowDist[size_t( j ) * rowK]     = 0u;
+    rowDist[size_t( j ) * rowK + 1] = kInf;
+  }
 }
 // flag[j] = 1 where the easy pass left query j to the second launch
 __global__ __launch_bounds__( 256 ) void hardFlagKernel( const uint32_t* __restrict__ easyIdx, uint32_t nq, uint32_t* __restrict__ flag ) {
@@ -410,8 +418,11 @@ __global__ __launch_bounds__( 256 ) void gatherHardKernel( const uint32_t* __res
 // too); k > 1 -- only where the consumer needs nothing but the first result of a search whose first distance is 0
 // (transferColors' forward direction: `skipAvgIfIdenticalSourcePointPresent`, PCCPointSet.cpp:853-858): the rows of easy queries
 // are NOT written.
+// uniqueTreeRows (k > 1): the tree holds no position twice and the consumer reads a row only up to the first distance that differs
+// from the first (PCCMetrics' "all points at the minimum distance", PCCMetrics.cpp:91-96): the rows of easy queries are written
+// as [ match | 0, not 0 ].
 int launchKnnSplit( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int k, uint32_t* d_easy, uint32_t* d_idx,
-                    uint32_t* d_dist, const char* stage ) {
+                    uint32_t* d_dist, const char* stage, bool uniqueTreeRows ) {
   hipStream_t s = ctx->stream;
   if ( nq == 0 ) return TMC2_OK;
   const int sid = ctx->stageBegin( stage );
@@ -430,8 +441,9 @@ int launchKnnSplit( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uin
   if ( r == TMC2_OK ) {
     const dim3 blk( 256 ), grd( uint32_t( ( nq + 255 ) / 256 ) );
     // pass 1: with k = 1 the easy results go straight to their rows (distance 0 with them)
+    const bool rows = uniqueTreeRows && k > 1;
     hipLaunchKernelGGL( easyQueryKernel, grd, blk, 0, s, tree.ptsTree, tree.perm, tree.nodes, d_queries, uint32_t( nq ), d_easy,
-                        k == 1 ? d_dist : (uint32_t*)nullptr );
+                        k == 1 ? d_dist : (uint32_t*)nullptr, rows ? d_idx : (uint32_t*)nullptr, rows ? d_dist : (uint32_t*)nullptr, k );
     hipLaunchKernelGGL( hardFlagKernel, grd, blk, 0, s, d_easy, uint32_t( nq ), d_flag.p );
     r = exclusiveScanU32( ctx, d_flag.p, d_rank.p, nq, d_count.p );
     if ( r == TMC2_OK ) {

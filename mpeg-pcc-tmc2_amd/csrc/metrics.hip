@@ -634,6 +634,17 @@ int orderedSums( tmc2_ctx* ctx, const double* termsA, uint32_t nA, const double*
 
 double psnr( double dist, double p, double factor ) { return 10 * std::log10( ( factor * p * p ) / dist ); }
 
+// The metric's searches against a DE-DUPLICATED cloud (round 6: in two launches, knn.hip launchKnnSplit): most points of one cloud
+// are points of the other, and in a tree without duplicate positions the group "all points at the minimum distance" of such a
+// query is that one point.  Option KNN_SPLIT=0: one launch, as before.
+int metricsKnn( tmc2_ctx* ctx, const TreeDev& tree, const Pt* d_queries, uint64_t nq, int K, uint32_t* d_idx, uint32_t* d_dist ) {
+  const char* splitEnv = ctxOption( ctx, "KNN_SPLIT" );
+  if ( splitEnv && splitEnv[0] == '0' ) return launchKnnTree( ctx, tree, d_queries, nq, K, d_idx, d_dist, "metrics_knn" );
+  DevBuf<uint32_t> d_easy;
+  TMC2_TRY( d_easy.alloc( std::max<uint64_t>( nq, 1 ) ) );
+  return launchKnnSplit( ctx, tree, d_queries, nq, K, d_easy.p, d_idx, d_dist, "metrics_knn", true );
+}
+
 // per-point terms of one direction (A's points against their nearest neighbours in B)
 int qualityTerms( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool withNormals, int K, DevBuf<double>& d_terms,
                   uint32_t* d_error ) {
@@ -643,7 +654,7 @@ int qualityTerms( tmc2_ctx* ctx, const DevCloud& A, const DevCloud& B, bool with
   TMC2_TRY( d_idx.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_dist.alloc( size_t( nA ) * K ) );
   TMC2_TRY( d_terms.alloc( size_t( nA ) * 5 ) );
-  TMC2_TRY( launchKnnTree( ctx, B.devFor( A ), A.pts.p, nA, K, d_idx.p, d_dist.p, "metrics_knn" ) );
+  TMC2_TRY( metricsKnn( ctx, B.devFor( A ), A.pts.p, nA, K, d_idx.p, d_dist.p ) );
   const int sid = ctx->stageBegin( "metrics_terms" );
   hipLaunchKernelGGL( distortionTermsKernel, dim3( ( nA + 255 ) / 256 ), dim3( 256 ), 0, s, A.pts.p, A.rgb4.p, B.pts.p, B.rgb4.p,
                       withNormals ? B.nrm.p : (const double*)nullptr, d_idx.p, d_dist.p, K, nA, d_terms.p, d_error );
@@ -714,7 +725,7 @@ int metricsDevice( tmc2_ctx* ctx, const CloudView& src, const CloudView& rec, co
     TMC2_TRY( d_cursor.alloc( mR ) );
     TMC2_TRY( d_total.alloc( 1 ) );
     TMC2_TRY( dR.nrm.alloc( 3 * size_t( mR ) ) );
-    TMC2_TRY( launchKnnTree( ctx, dR.devFor( dS ), dN.pts.p, nS, K, d_idx.p, d_dist.p, "metrics_knn" ) );  // (dN = the points of dS)
+    TMC2_TRY( metricsKnn( ctx, dR.devFor( dS ), dN.pts.p, nS, K, d_idx.p, d_dist.p ) );  // (dN = the points of dS)
     TMC2_TRY( fillRegions( ctx, {{d_count.p, size_t( mR ) * 4, 0}, {d_cursor.p, size_t( mR ) * 4, 0}} ) );
     hipLaunchKernelGGL( votesCountKernel, dim3( ( nS + 255 ) / 256 ), blk, 0, s, d_idx.p, d_dist.p, K, nS, d_count.p, d_error.p );
     TMC2_TRY( exclusiveScanU32( ctx, d_count.p, d_offset.p, mR, d_total.p ) );

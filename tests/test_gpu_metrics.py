@@ -29,8 +29,13 @@ def test_gpu_metrics_match_oracle(gpu_ctx, oracle, name):
         assert np.array_equal(bits(got), bits(exp)), (got, exp)
 
 
-def test_gpu_metrics_lossy_reconstruction(gpu_ctx, oracle):
-    """Perturbed geometry (duplicates after rounding, holes -> reconstructed points nobody votes for) and colours."""
+@pytest.mark.parametrize("split", [None, "0"])
+def test_gpu_metrics_lossy_reconstruction(gpu_ctx, oracle, ctx_options, split):
+    """Perturbed geometry (duplicates after rounding, holes -> reconstructed points nobody votes for) and colours.  Round 6: the
+    metric's searches run in two launches (queries with an identical point in the de-duplicated tree first); TMC2_KNN_SPLIT=0 is
+    the one-launch form."""
+    if split:
+        ctx_options.setenv("TMC2_KNN_SPLIT", split)
     xyz, rgb = synth_cloud("small", 1)
     rec, col = _recon(oracle, xyz, rgb)
     rng = np.random.default_rng(7)
