@@ -1061,6 +1061,9 @@ def main():
                     fr.get_attribute_images(b4[i][1])
                 enc.phase_a(sub, sharder=T.Sharder(), then=rest4)
             enc.set_option("REFINE_OVERLAP", 1)                 # (what a GofEncoder of <= 4 workers -- a rank of the 8-GPU run -- sets)
+            # (... and delays the start of the second half of its frames: tmc2_amd/gof.py; BENCH_PROXY_STAGGER_US: another delay)
+            for late in enc.ctxs[2:4]:
+                late.set_option("FRAME_START_DELAY_US", os.environ.get("BENCH_PROXY_STAGGER_US", str(T.gof.FEW_FRAMES_START_DELAY_US)))
             rank_step()
             torch.cuda.synchronize()
             t0 = time.time()
@@ -1070,6 +1073,7 @@ def main():
             torch.cuda.synchronize()
             ms4 = 1000.0 * (time.time() - t0) / reps
             enc.set_option("REFINE_OVERLAP", 1 if workers <= 4 else 0)
+            enc.set_option("FRAME_START_DELAY_US", None)
             out["per_rank_proxy"] = {"frames": 4, "workers": 4, "ms": round(ms4, 2),
                                      "predicted_n8_frames_per_s": round(a.frames / (ms4 * 1e-3), 1),
                                      "predicted_n8_speedup": round(a.frames / (ms4 * 1e-3) / out["value"], 2),

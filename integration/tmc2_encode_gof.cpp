@@ -232,6 +232,11 @@ int main( int argc, char** argv ) {
     CHECK( tmc2_ctx_set_option( c, "REFINE_OVERLAP", workers <= 4 ? "1" : "0" ) );  // few frames in flight per device: shorten a frame's chain
     CHECK( tmc2_ctx_set_option( c, "KDTREE_HOST", "0" ) );  // device trees (the device build beats the host build at every number of frames in flight)
   }
+  // ... and with few frames in flight the second half of a device's frames start 2 ms after the first: frames that start together
+  // reach S3's host walk together and leave the GPU idle meanwhile (profiles/r06_rank_stagger.txt)
+  if ( workers >= 2 && workers <= 4 )
+    for ( size_t s = 0; s < ctx.size(); ++s )
+      if ( int( s % size_t( workers ) ) >= ( workers + 1 ) / 2 ) CHECK( tmc2_ctx_set_option( ctx[s], "FRAME_START_DELAY_US", "2000" ) );
 
   std::vector<Frame> gof( size_t( o.frames ) );
   // ingest + upload (all later calls on a frame are ordered on its slot's context)

@@ -1,6 +1,10 @@
 // segmenter_api.cpp -- PCCPatchSegmenter3::compute chain, parameter validation and patch accessors.
 #include <algorithm>
 
+#include <algorithm>
+#include <chrono>
+#include <thread>
+
 #include "internal.h"
 using namespace tmc2;
 
@@ -84,6 +88,14 @@ int tmc2_segmenter_compute( tmc2_frame* f, const tmc2_segmenter_params* p ) {
                                           p->iterationCountRefineSegmentation, p->voxelDimensionRefineSegmentation,
                                           p->searchRadiusRefineSegmentation );
     };
+  // Option FRAME_START_DELAY_US (few frames in flight: a rank of the 8-GPU run has four).  Frames that start together reach their
+  // host-resident step -- S3's walk, ~ 3 ms -- together, and the GPU has nothing to do meanwhile (profiles/r06_rank_concurrency.txt:
+  // a hole of ~ 3 ms in every 27 ms step).  A host that delays the start of half of its frames by about that long has one half
+  // walking while the other half's kernels run.
+  if ( const char* delay = tmc2::ctxOption( f->ctx, "FRAME_START_DELAY_US" ) ) {
+    const int us = atoi( delay );
+    if ( us > 0 ) std::this_thread::sleep_for( std::chrono::microseconds( std::min( us, 100000 ) ) );
+  }
   TMC2_TRY( tmc2_normals_compute( f, p->nnNormalEstimation, p->normalOrientation ) );
   f->beforeHostWalk = nullptr;
   TMC2_TRY( tmc2_segmenter_initial_segmentation( f, p->weightNormal ) );

@@ -122,6 +122,9 @@ def l3_domains():
         return []
 
 
+FEW_FRAMES_START_DELAY_US = 2000   # (what the late half of <= 4 frames in flight waits before it starts: GofEncoder.__init__)
+
+
 class _Worker(threading.Thread):
     """One host thread per in-flight frame slot.  It owns its tmc2_ctx (created after the thread has been pinned, so
     the context's page-locked staging and scratch land on the thread's NUMA node) and runs every call on it."""
@@ -191,6 +194,11 @@ class GofEncoder:
         self.ctxs = [t.ctx for t in self.threads]
         if os.environ.get("TMC2_REFINE_OVERLAP") is None:      # (an option of THIS encoder's contexts: nothing process-wide)
             self.set_option("REFINE_OVERLAP", 1 if workers <= 4 else 0)
+        # ... and the second half of the frames start 2 ms after the first: frames that start together reach S3's host walk (~ 3 ms)
+        # together and leave the GPU with nothing to do meanwhile (round 6: profiles/r06_rank_concurrency.txt, r06_rank_stagger.txt)
+        if os.environ.get("TMC2_FRAME_START_DELAY_US") is None and 2 <= workers <= 4:
+            for c in self.ctxs[(workers + 1) // 2:]:
+                c.set_option("FRAME_START_DELAY_US", FEW_FRAMES_START_DELAY_US)
         self.gate = None
 
     def set_host_slots(self, slots):
