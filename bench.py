@@ -846,8 +846,12 @@ def main():
     enc.stage_reset()
     sync()
     t0 = time.time()
+    step_ms, t_last = [], t0                                # (every timed step by the host's clock: the scatter inside the region)
     for _ in range(a.steps):
         W, H = step()
+        t_now = time.time()
+        step_ms.append(round(1e3 * (t_now - t_last), 2))
+        t_last = t_now
     sync()
     dt = time.time() - t0
     if world > 1:
@@ -966,7 +970,7 @@ def main():
     out = {
         "metric": "encoder patch+image-gen frames/sec, %s %d-frame GOF" % (a.workload, a.frames),
         "value": round(a.frames * a.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "priming_passes": max(0, a.prime), "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True,
+        "warmup": a.warmup, "priming_passes": max(0, a.prime), "ms_per_step": round(1000.0 * dt / a.steps, 2), "step_ms": step_ms, "higher_is_better": True,
         "first_gof_ms": pass_ms[0] if pass_ms else None, "untimed_pass_ms": pass_ms, "passes_resumed_with_larger_buffers": resumed_passes[0], "pool": dict(enc.pool_stats(), reserved=bool(a.reserve) and reserve_note is None, note=reserve_note),
         "first_gof_excess_ms_per_frame": dict(sorted(((k, round((first_stage_ms.get(k, 0.0) - v / a.steps) / max(1, len(frames)), 3))
                                                       for k, v in ms.items() if first_stage_ms.get(k, 0.0) - v / a.steps > 0.2 * len(frames)
