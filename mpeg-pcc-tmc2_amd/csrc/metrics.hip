@@ -73,12 +73,20 @@ struct KeyBase {
   int      lo[3];
   uint32_t bitsY, bitsZ, bits;  // widths of the y and z fields, total key width
 };
+// (round 6: a stride loop over at most kBoundsBlocks workgroups, folded per workgroup in LDS, six atomics per WORKGROUP.  Rounds 2-5
+//  had one wavefront per 64 points report to the six words behind a look-before-you-atomic -- but the 8 192 wavefronts that are
+//  resident when the kernel starts all look at the untouched box and all report: ~ 8 000 atomics per word, 11 ns each, 0.26 ms
+//  for a reduction over a million points)
+constexpr uint32_t kBoundsBlocks = 1024;
 __global__ __launch_bounds__( 256 ) void boundsKernel( CloudView c, int* __restrict__ box /* [6] min, max */ ) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int sMin[4][3], sMax[4][3];
   int            mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {int( 0x80000000 ), int( 0x80000000 ), int( 0x80000000 )};
-  if ( i < c.n ) {
+  for ( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x ) {
 #pragma unroll
-    for ( int d = 0; d < 3; ++d ) mn[d] = mx[d] = c.xyz[size_t( i ) * c.xyzStride + d];
+    for ( int d = 0; d < 3; ++d ) {
+      const int v = c.xyz[size_t( i ) * c.xyzStride + d];
+      mn[d] = min( mn[d], v ), mx[d] = max( mx[d], v );
+    }
   }
 #pragma unroll
   for ( int d = 0; d < 3; ++d ) {
@@ -87,10 +95,14 @@ __global__ __launch_bounds__( 256 ) void boundsKernel( CloudView c, int* __restr
   }
   if ( ( threadIdx.x & 63 ) == 0 ) {
 #pragma unroll
-    for ( int d = 0; d < 3; ++d ) {
-      if ( mn[d] < loadStaleOk( &box[d] ) ) atomicMin( &box[d], mn[d] );
-      if ( mx[d] > loadStaleOk( &box[3 + d] ) ) atomicMax( &box[3 + d], mx[d] );
-    }
+    for ( int d = 0; d < 3; ++d ) sMin[threadIdx.x >> 6][d] = mn[d], sMax[threadIdx.x >> 6][d] = mx[d];
+  }
+  __syncthreads();
+  if ( threadIdx.x < 3 ) {
+    const int d = threadIdx.x;
+    const int lo = min( min( sMin[0][d], sMin[1][d] ), min( sMin[2][d], sMin[3][d] ) ), hi = max( max( sMax[0][d], sMax[1][d] ), max( sMax[2][d], sMax[3][d] ) );
+    if ( lo < loadStaleOk( &box[d] ) ) atomicMin( &box[d], lo );
+    if ( hi > loadStaleOk( &box[3 + d] ) ) atomicMax( &box[3 + d], hi );
   }
 }
 __global__ __launch_bounds__( 256 ) void positionKeysKernel( CloudView c, KeyBase kb, uint64_t* __restrict__ key, uint32_t* __restrict__ index ) {
@@ -235,7 +247,7 @@ int removeDuplicatesDevice( tmc2_ctx* ctx, const CloudView& c, DevCloud& out, De
   const dim3 blk( 256 ), grd( ( n + 255 ) / 256 );
   int        box[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, int( 0x80000000 ), int( 0x80000000 ), int( 0x80000000 )};
   TMC2_HIP( hipMemcpyAsync( d_small.p, box, sizeof( box ), hipMemcpyHostToDevice, s ) );
-  hipLaunchKernelGGL( boundsKernel, grd, blk, 0, s, c, reinterpret_cast<int*>( d_small.p ) );
+  hipLaunchKernelGGL( boundsKernel, dim3( std::min( grd.x, kBoundsBlocks ) ), blk, 0, s, c, reinterpret_cast<int*>( d_small.p ) );
   TMC2_HIP( hipMemcpyAsync( box, d_small.p, sizeof( box ), hipMemcpyDeviceToHost, s ) );
   TMC2_HIP( hipStreamSynchronize( s ) );
   KeyBase  kb{};
