@@ -278,6 +278,8 @@ class Context:
         a = np.ascontiguousarray(src_xyz, np.int16)
         b = np.ascontiguousarray(src_rgb, np.uint8)
         c = np.ascontiguousarray(tgt_xyz, np.int16)
+        if a.shape != b.shape:                                    # (the C entry takes ONE count for both: a short colour array is read past its end)
+            raise Tmc2Error("transfer_colors: %d source points, %d source colours" % (len(a), len(b)))
         out = np.zeros((len(c), 3), np.uint8)
         _check(self.L.tmc2_transfer_colors(self.h, _ptr(a), _ptr(b), C.c_uint64(len(a)), _ptr(c), C.c_uint64(len(c)), _ptr(out)))
         return out

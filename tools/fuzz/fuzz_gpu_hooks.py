@@ -51,7 +51,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if len(xyz) <= 60000:                             # the colour transfer's searches (round 6: in two launches; identical and duplicate points)
         rgb = rng.integers(0, 256, (len(xyz), 3)).astype(np.uint8)
         tgt = np.concatenate([xyz[rng.random(len(xyz)) < 0.7], q[:1500].clip(0, 1023).astype(np.int16), xyz[rng.integers(0, len(xyz), 200)]])
-        src, col = np.concatenate([xyz, xyz[:50]]), np.concatenate([rgb, rgb[50:100]])
+        dup = min(50, len(xyz))                       # duplicate positions with other colours in the source
+        src, col = np.concatenate([xyz, xyz[:dup]]), np.concatenate([rgb, rng.integers(0, 256, (dup, 3)).astype(np.uint8)])
         if not np.array_equal(ctx.transfer_colors(src, col, tgt), oracle.transfer_colors(src, col, tgt)):
             why.append("transfer_colors")
     if len(xyz) <= 60000:
